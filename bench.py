@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- PSMC E-step throughput on MI355X.
+
+Metric (BASELINE.json): genome bins/sec through forward-backward at n=64 states.
+A "step" is one E-step pass (forward sweep, backward sweep, expected counts,
+reduction, and for N>1 the all-reduce of the sufficient statistics) over one
+synthetic whole-genome batch (~30 M bins, 90 segments shaped like human
+chromosomes + scaffolds, drawn from a 64-state PSMC model).  Observations are
+resident in HBM before the timed region; per step only the 33 KB of HMM
+parameters cross PCIe, exactly as in an EM iteration.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Weak scaling: every rank holds its own genome-sized shard (segments are
+independent given the parameters, em.c:36-55); the one exchange per step is the
+RCCL all-reduce of n*n+2n+1 doubles that replaces hmm_add_expect (khmm.c:346).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_STATES = 64
+BYTES_PER_BIN = 16 * N_STATES + 18   # obs x2, f write+read, s write+read
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def load_params():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hmm_params.npz"))
+    return g["n64_curve.a"], g["n64_curve.e"], g["n64_curve.a0"]
+
+
+def cpu_baseline(a, e, a0, segs, sample_bins):
+    """Time the CPU E-step on a bounded sample of the same workload (rank 0, N=1 only):
+    the reference itself (oracle/_ref, built from its own sources) when that .so travelled
+    with the repo, else our restatement of it."""
+    import orc
+    sample, tot = [], 0
+    for s in segs:                       # 500k-bin trunks like utils/splitfa.c:35 of the reference
+        for j in range(0, len(s), 500000):
+            if tot >= sample_bins:
+                break
+            t = s[j:j + min(500000, sample_bins - tot)]
+            sample.append(t); tot += len(t)
+    if orc.have_reference():
+        eng, kind = orc.Reference(), "reference"
+    else:
+        eng, kind = orc.Oracle(), "port"
+    t0 = time.perf_counter()
+    eng.estep(a, e, a0, sample)
+    dt = time.perf_counter() - t0
+    return {"value": tot / dt, "unit": "bins/s", "cores": 1, "kind": kind,
+            "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bins", type=int, default=30_000_000, help="bins per GPU (whole human genome ~ 3e7)")
+    ap.add_argument("--segments", type=int, default=90)
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="bins for the CPU baseline (0 = skip)")
+    ap.add_argument("--exact-extra", type=int, default=1, help="also time 1 exact-mode step (0 = skip)")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (chunk, warmup, ...)")
+    args = ap.parse_args()
+
+    import torch
+    from psmc_amd import hip, sim
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    a, e, a0 = load_params()
+    lens = sim.human_like_lengths(args.bins, n_seg=args.segments)
+    t0 = time.perf_counter()
+    segs = sim.simulate_genome(a, e, a0, lens, seed=43 + rank)
+    bins = int(sum(len(s) for s in segs))
+    log("[rank %d] synthetic genome: %d segments, %d bins, longest %d (%.1f s)"
+        % (rank, len(segs), bins, int(lens.max()), time.perf_counter() - t0))
+
+    # observations -> HBM once
+    off = np.concatenate([[0], np.cumsum((lens.astype(np.int64) + 63) // 64 * 64)])
+    host = np.full(int(off[-1]) + 256, 2, dtype=np.uint8)
+    for s, o in zip(segs, off[:-1]):
+        host[o:o + len(s)] = s
+    d_obs = torch.from_numpy(host).cuda()
+    mode = hip.MODE_FAST if args.mode == "fast" else hip.MODE_EXACT
+    es = hip.HipEStep(N_STATES, device=local, mode=mode)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        es.set_option(k, float(v))
+    es.load_segments_device(d_obs.data_ptr(), off[:-1], lens, keepalive=d_obs)
+    stats = torch.zeros(N_STATES * N_STATES + 2 * N_STATES + 1, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        if mode == hip.MODE_FAST:
+            es.estep_device(a, e, a0, stats.data_ptr(), stream.cuda_stream)
+            if dist is not None:
+                dist.all_reduce(stats)           # RCCL over xGMI: replaces hmm_add_expect across shards
+        else:
+            r = es.estep(a, e, a0)               # exact: ordered host sum (bit-identical to khmm.c)
+            if dist is not None:
+                t = torch.from_numpy(np.concatenate([r["A"].ravel(), r["E"].ravel(), [r["LL"]]])).cuda()
+                dist.all_reduce(t)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if mode == hip.MODE_FAST:
+        es.estep(a, e, a0)   # blocking form once: validates / widens the tile warm-up before timing
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kern = {"forward": 0.0, "backward": 0.0, "expect": 0.0, "reduce": 0.0, "total": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # per-kernel durations (HIP events recorded by the library on the stream the kernels ran on);
+    # measured on separate, identical steps so that the event reads do not perturb the timed region
+    nk = max(1, min(args.steps, 5)) if mode == hip.MODE_FAST else 1
+    for _ in range(nk):
+        step(); torch.cuda.synchronize()
+        t = es.timing()
+        for k in kern:
+            kern[k] += t[k] / nk
+    diag = es.fast_diag() if mode == hip.MODE_FAST else {}
+    ms_per_step = dt / args.steps * 1e3
+    value = bins * world / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        dom = max(("forward", "backward", "expect"), key=lambda k: kern[k])
+        # algorithmic HBM bytes per bin of each phase (fused backward+expect: section 8(d))
+        alg = {"forward": 8 * N_STATES + 9, "backward": 8 * N_STATES + 9, "expect": 8 * N_STATES + 9}
+        if kern[dom] > 0:
+            ach = bins * alg[dom] / (kern[dom] * 1e-3) / 1e9
+        else:
+            ach = 0.0
+        pipe = bins * BYTES_PER_BIN / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
+        out = {
+            "metric": "genome bins/sec through forward-backward (n=64)",
+            "value": value, "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: whole-genome .psmcfa-like batch, %d bins x %d states in %d segments "
+                                   "per GPU, -p 4+25*2+4+6, one E-step (EM iteration) per step" % (bins, N_STATES, len(segs)),
+                       "mode": args.mode, "bins_per_gpu": bins, "n_states": N_STATES, "segments": len(segs),
+                       "sharding": "segments/GPU + 1 RCCL all-reduce(%d f64)/step" % stats.numel() if world > 1 else "single GPU",
+                       **({"tiles": diag.get("n_chunks"), "tile_warmup_bins": diag.get("warmup"),
+                           "warm_err": max(diag.get("warm_err_fwd", 0), diag.get("warm_err_bwd", 0))} if diag else {})},
+            "roofline": {"bound": "hbm", "kernel": "k_%s_%s" % ({"forward": "fwd", "backward": "bwd", "expect": "expect"}[dom], args.mode),
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "alg_bytes_per_bin": alg[dom], "kernel_ms": kern[dom],
+                         "pipeline": {"alg_bytes_per_bin": BYTES_PER_BIN, "ms": kern["total"], "achieved": pipe,
+                                      "frac": pipe / HBM_PEAK_GBS},
+                         "kernels_ms": kern,
+                         "fp64_note": "7*n^2 flop/bin: %.1f TFLOP/s of 78.6 (VALU+MFMA f64)" %
+                                      (bins * 7 * N_STATES * N_STATES / (kern["total"] * 1e-3) / 1e12 if kern["total"] > 0 else 0.0)},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(a, e, a0, segs, args.cpu_sample)
+        if world == 1 and args.exact_extra > 0 and mode == hip.MODE_FAST:
+            try:
+                es.close(); del es
+                ex = hip.HipEStep(N_STATES, device=local, mode=hip.MODE_EXACT)
+                ex.load_segments_device(d_obs.data_ptr(), off[:-1], lens, keepalive=d_obs)
+                ex.estep(a, e, a0)
+                t1 = time.perf_counter(); ex.estep(a, e, a0); dte = time.perf_counter() - t1
+                out["exact_mode"] = {"value": bins / dte, "unit": "bins/s", "ms_per_step": dte * 1e3,
+                                     "kernels_ms": ex.timing(),
+                                     "note": "bit-identical to khmm.c; one wave per segment, critical path = longest segment"}
+                ex.close()
+            except Exception as ex_:  # the headline number must survive an extra's failure
+                out["exact_mode"] = {"error": str(ex_)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/* psmc_hip.h -- C-ABI of libpsmc_hip.so: the PSMC E-step (Baum-Welch
+ * forward-backward + expected counts) on AMD MI355X (gfx950).
+ *
+ * The reference (lh3/psmc) has no plugin/FFI seam; its E-step is the body of
+ * psmc_em(), em.c:33-55, which calls khmm.h:64-92 per segment:
+ *     hmm_pre_backward, hmm_new_data, hmm_forward, hmm_backward, hmm_lk,
+ *     hmm_expect, hmm_add_expect
+ * and psmc_decode(), aux.c:150-158, which re-runs forward/backward.  Because
+ * the f/b tables must stay in HBM, the drop-in boundary sits one level up: a
+ * batch E-step over all loaded segments.  Each entry point below names the
+ * reference code it replaces.  Plain C types only; every function returns 0 or
+ * a negative PSMC_HIP_E* code, never aborts, never prints.
+ *
+ * Conventions: n = number of hidden states (psmc's n+1, <= 64 in this build);
+ * row-major FP64; a[k*n+l]=P(k->l) (khmm.h:34); e[b*n+k], b=0 hom / 1 het
+ * (khmm.h:34; the missing-data row e[2][*]=1 of khmm.c:21 is implied);
+ * a0[k] (khmm.h:36); observations are bytes 0/1/2 exactly as psmc_read_seq
+ * decodes them (cli.c:15-32,117-125), 0-indexed as in psmc_seq_t (psmc.h:22-26).
+ */
+#ifndef PSMC_HIP_H
+#define PSMC_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSMC_HIP_MODE_EXACT 0 /* bit-identical to khmm.c (ordered sums, no FMA) */
+#define PSMC_HIP_MODE_FAST  1 /* chunked sweeps, FMA, tree reductions; stats within 1e-10 */
+
+#define PSMC_HIP_OK        0
+#define PSMC_HIP_EINVAL   -1 /* bad argument (NULL, n out of range, empty segment ...) */
+#define PSMC_HIP_ENOMEM   -2 /* host or device allocation failed */
+#define PSMC_HIP_EDEVICE  -3 /* HIP runtime error; see psmc_hip_last_error() */
+#define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (e.g. n > 64) */
+#define PSMC_HIP_ESTATE   -5 /* call order violated (no segments loaded ...) */
+#define PSMC_HIP_ECONVERGE -6 /* fast mode: warm-up did not converge within limits */
+
+typedef struct psmc_hip_ctx psmc_hip_ctx;
+
+/* Number of visible HIP devices (0 when none / no driver). */
+int psmc_hip_device_count(void);
+
+/* Replaces hmm_new_par/hmm_new_exp bookkeeping (khmm.c:10-23, 60-69). */
+int psmc_hip_create(psmc_hip_ctx **ctx, int n_states, int device, int mode);
+void psmc_hip_destroy(psmc_hip_ctx *ctx);
+const char *psmc_hip_strerror(int err);
+const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
+
+/* Tunables (all optional): "chunk" (fast-mode tile length in bins),
+ * "warmup" (fast-mode overlap in bins), "warm_tol", "rep_impl" (0 ds_bpermute,
+ * 1 v_permlane*_swap), "expect_impl" (0 VALU, 1 MFMA f64), "keep_fb" (exact
+ * mode always keeps f/b/s; fast mode keeps its scaled f). */
+int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
+
+/* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
+ * uploads all segments once; the caller keeps ownership of seq. */
+int psmc_hip_load_segments(psmc_hip_ctx *ctx, int n_seg, const uint8_t *const *seq, const int32_t *L);
+/* Same, for observations already resident in HBM: d_obs holds the segments
+ * back to back, segment i starting at byte off[i] (off[i] % 64 == 0) with at
+ * least 64 readable bytes after the last one.  The buffer is borrowed. */
+int psmc_hip_load_segments_device(psmc_hip_ctx *ctx, int n_seg, const void *d_obs, const int64_t *off,
+                                  const int32_t *L);
+/* Bootstrap multiset (psmc_resamp, aux.c:8-47): which loaded segments the next
+ * E-steps run over, in order, repeats allowed.  Default: all, in load order. */
+int psmc_hip_select(psmc_hip_ctx *ctx, int n_sel, const int32_t *seg_idx);
+
+/* Replaces em.c:33-55 + 60: one E-step over the selected segments.
+ *   A  n*n   he_sum->A            E  2*n  he_sum->E[0..1] (khmm.c:355)
+ *   A0 n     he_sum->A0 (may be NULL; unused downstream)
+ *   LL       sum of hmm_lk over segments (em.c:48)
+ *   chk      n_sel values of the khmm.c:237-238 underflow check (may be NULL) */
+int psmc_hip_estep(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, double *A, double *E,
+                   double *A0, double *LL, double *chk);
+
+/* Exact mode, for multi-process sharding: per selected segment the reference's
+ * own `he` (em.c:49) and hmm_lk, so that the caller can add them in the global
+ * input order.  segA n_sel*n*n, segE n_sel*3*n, segA0 n_sel*n, segLL n_sel. */
+int psmc_hip_estep_segments(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, double *segA,
+                            double *segE, double *segA0, double *segLL, double *chk);
+
+/* Fast mode, device-resident result for a collective: enqueues the E-step on
+ * `stream` (a hipStream_t, NULL = default) and writes n*n + 2*n + 1 doubles
+ * [A | E | LL] to the device buffer d_stats.  Asynchronous; the caller
+ * synchronises the stream (or hands d_stats to RCCL on the same stream). */
+int psmc_hip_estep_device(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, void *d_stats,
+                          void *stream);
+/* After the stream has drained: fast-mode diagnostics of the last E-step.
+ * warm_err[0/1] = largest relative mismatch between a tile's warmed-up entry
+ * vector and its neighbour's converged one (forward / backward). */
+int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err_bwd, int *n_chunks,
+                       int *warmup_used);
+
+/* Copies the forward/backward tables of one loaded segment to the host after
+ * an E-step (replaces reading hd->f, hd->b, hd->s: aux.c:159-200).  f,b: L*n,
+ * s: L.  Exact mode: the reference's values bit for bit.  Fast mode: b is not
+ * kept (NULL required) and f,s are the lag-normalised values. */
+int psmc_hip_get_tables(psmc_hip_ctx *ctx, int seg, double *f, double *b, double *s);
+
+/* Built-in check of the cross-lane primitives on the device (row replication
+ * variants, DPP broadcasts, f64 MFMA layout).  Returns 0 when all agree;
+ * a positive bitmask of failed primitives otherwise. */
+int psmc_hip_selftest(int device);
+
+/* Wall time in ms of the last E-step's kernels measured with HIP events on
+ * the stream they ran on: [0] total, [1] forward, [2] backward, [3] expect,
+ * [4] reductions. */
+int psmc_hip_last_timing(psmc_hip_ctx *ctx, double ms[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,587 @@
+// api.hip -- C-ABI of libpsmc_hip.so (see include/psmc_hip.h): context,
+// segment upload, tile planning, launch orchestration and the host-side
+// ordered reductions of the exact mode.  Built with -ffp-contract=off so that
+// no host or device expression in this file is ever fused.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "psmc_hip.h"
+#include "psmc_hip_internal.h"
+
+using namespace psmc;
+
+#define HMM_TINY_H 1e-25
+
+struct psmc_hip_ctx {
+	int n = 0, device = 0, mode = PSMC_HIP_MODE_EXACT;
+	std::string err;
+	// options
+	int chunk = 0, warmup = 4096, max_warmup = 1 << 17, rep_impl = 1, expect_impl = 1, n_sub = 4, target_waves = 2048;
+	double warm_tol = 1e-10;
+	// segments
+	int n_seg = 0;
+	std::vector<int32_t> L;
+	std::vector<int64_t> off;
+	int64_t total = 0; // padded bins
+	bool obs_borrowed = false;
+	uint8_t *d_obs = nullptr;
+	int64_t *d_seg_off = nullptr;
+	int32_t *d_seg_len = nullptr;
+	// selection
+	std::vector<int32_t> sel;      // as given
+	std::vector<int32_t> work;     // unique selected ids
+	std::vector<int32_t> sel2work; // sel[i] -> index into work
+	std::vector<int32_t> mult;     // per work item
+	int32_t *d_work = nullptr;
+	bool plan_dirty = true;
+	// parameters
+	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0
+	static constexpr size_t PAR_LEN = 4096 + 3 * 4096 + 3 * 64 + 64;
+	// tables
+	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr;
+	int64_t tab_bins = 0; bool have_b = false;
+	// exact outputs
+	double *d_segA = nullptr, *d_segE = nullptr, *d_segA0 = nullptr, *d_chk = nullptr;
+	int seg_cap = 0;
+	std::vector<double> h_segA, h_segE, h_segA0, h_chk, h_s;
+	// fast
+	std::vector<Chunk> chunks;
+	Chunk *d_chunks = nullptr;
+	int chunk_cap = 0, chunk_used = 0;
+	double *d_entry = nullptr, *d_bexit = nullptr, *d_Cpart = nullptr, *d_Epart = nullptr, *d_LLpart = nullptr;
+	double *d_stage = nullptr, *d_stats = nullptr;
+	unsigned long long *d_warm = nullptr;
+	double warm_err[2] = {0, 0};
+	// runtime
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	double last_ms[5] = {0, 0, 0, 0, 0};
+	bool timing_valid = false;
+};
+
+static int fail(psmc_hip_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+	if (c) {
+		c->err = what;
+		if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+	}
+	return code;
+}
+#define HIPCHK(c, call)                                                     \
+	do {                                                                    \
+		hipError_t e__ = (call);                                            \
+		if (e__ != hipSuccess) return fail((c), PSMC_HIP_EDEVICE, #call, e__); \
+	} while (0)
+
+template <class T> static int dev_alloc(psmc_hip_ctx *c, T **p, size_t n)
+{
+	if (*p) { (void)hipFree(*p); *p = nullptr; }
+	if (n == 0) n = 1;
+	hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+	if (e != hipSuccess) { *p = nullptr; return fail(c, PSMC_HIP_ENOMEM, "hipMalloc", e); }
+	return 0;
+}
+
+extern "C" int psmc_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" const char *psmc_hip_strerror(int err)
+{
+	switch (err) {
+	case PSMC_HIP_OK: return "ok";
+	case PSMC_HIP_EINVAL: return "invalid argument";
+	case PSMC_HIP_ENOMEM: return "out of memory";
+	case PSMC_HIP_EDEVICE: return "HIP runtime error";
+	case PSMC_HIP_ENOTSUP: return "not supported in this build";
+	case PSMC_HIP_ESTATE: return "call order violated";
+	case PSMC_HIP_ECONVERGE: return "fast-mode warm-up did not converge";
+	default: return "unknown error";
+	}
+}
+extern "C" const char *psmc_hip_last_error(const psmc_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int mode)
+{
+	if (!out) return PSMC_HIP_EINVAL;
+	*out = nullptr;
+	if (n_states < 1) return PSMC_HIP_EINVAL;
+	if (n_states > NS) return PSMC_HIP_ENOTSUP;
+	if (mode != PSMC_HIP_MODE_EXACT && mode != PSMC_HIP_MODE_FAST) return PSMC_HIP_EINVAL;
+	int nd = psmc_hip_device_count();
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	psmc_hip_ctx *c = new (std::nothrow) psmc_hip_ctx();
+	if (!c) return PSMC_HIP_ENOMEM;
+	c->n = n_states; c->device = device; c->mode = mode;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	for (int i = 0; i < 5; ++i)
+		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	if (hipHostMalloc((void **)&c->h_par, psmc_hip_ctx::PAR_LEN * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+	    hipMalloc((void **)&c->d_par, psmc_hip_ctx::PAR_LEN * sizeof(double)) != hipSuccess) {
+		psmc_hip_destroy(c);
+		return PSMC_HIP_ENOMEM;
+	}
+	*out = c;
+	return PSMC_HIP_OK;
+}
+
+extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
+	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
+	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
+	                c->d_stage, c->d_stats, c->d_warm};
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+	if (c->h_par) (void)hipHostFree(c->h_par);
+	for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
+{
+	if (!c || !key) return PSMC_HIP_EINVAL;
+	std::string k(key);
+	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
+	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; }
+	else if (k == "max_warmup") c->max_warmup = (int)v;
+	else if (k == "warm_tol") c->warm_tol = v;
+	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
+	else if (k == "expect_impl") c->expect_impl = v != 0 ? 1 : 0;
+	else if (k == "n_sub") { if (v < 1 || v > 64) return PSMC_HIP_EINVAL; c->n_sub = (int)v; c->plan_dirty = true; }
+	else if (k == "target_waves") { if (v < 1) return PSMC_HIP_EINVAL; c->target_waves = (int)v; c->plan_dirty = true; }
+	else return PSMC_HIP_EINVAL;
+	return PSMC_HIP_OK;
+}
+
+static int set_segments_common(psmc_hip_ctx *c, int n_seg, const int32_t *L)
+{
+	c->n_seg = n_seg;
+	c->L.assign(L, L + n_seg);
+	int rc;
+	if ((rc = dev_alloc(c, &c->d_seg_off, (size_t)n_seg))) return rc;
+	if ((rc = dev_alloc(c, &c->d_seg_len, (size_t)n_seg))) return rc;
+	HIPCHK(c, hipMemcpy(c->d_seg_off, c->off.data(), sizeof(int64_t) * n_seg, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_seg_len, c->L.data(), sizeof(int32_t) * n_seg, hipMemcpyHostToDevice));
+	std::vector<int32_t> all(n_seg);
+	for (int i = 0; i < n_seg; ++i) all[i] = i;
+	return psmc_hip_select(c, n_seg, all.data());
+}
+
+extern "C" int psmc_hip_load_segments(psmc_hip_ctx *c, int n_seg, const uint8_t *const *seq, const int32_t *L)
+{
+	if (!c || n_seg < 1 || !seq || !L) return fail(c, PSMC_HIP_EINVAL, "load_segments: bad argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	c->off.resize(n_seg);
+	int64_t tot = 0;
+	for (int i = 0; i < n_seg; ++i) {
+		if (L[i] < 1 || !seq[i]) return fail(c, PSMC_HIP_EINVAL, "load_segments: empty segment");
+		c->off[i] = tot;
+		tot += ((int64_t)L[i] + 63) & ~(int64_t)63;
+	}
+	c->total = tot;
+	std::vector<uint8_t> host((size_t)tot + 256, 2);
+	for (int i = 0; i < n_seg; ++i) {
+		for (int32_t j = 0; j < L[i]; ++j)
+			if (seq[i][j] > 2) return fail(c, PSMC_HIP_EINVAL, "load_segments: symbol outside {0,1,2}");
+		memcpy(host.data() + c->off[i], seq[i], (size_t)L[i]);
+	}
+	if (!c->obs_borrowed && c->d_obs) { (void)hipFree(c->d_obs); }
+	c->d_obs = nullptr; c->obs_borrowed = false;
+	int rc;
+	if ((rc = dev_alloc(c, &c->d_obs, host.size()))) return rc;
+	HIPCHK(c, hipMemcpy(c->d_obs, host.data(), host.size(), hipMemcpyHostToDevice));
+	return set_segments_common(c, n_seg, L);
+}
+
+extern "C" int psmc_hip_load_segments_device(psmc_hip_ctx *c, int n_seg, const void *d_obs, const int64_t *off,
+                                             const int32_t *L)
+{
+	if (!c || n_seg < 1 || !d_obs || !off || !L) return fail(c, PSMC_HIP_EINVAL, "load_segments_device: bad argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	int64_t end = 0;
+	for (int i = 0; i < n_seg; ++i) {
+		if (L[i] < 1 || (off[i] & 63) || off[i] < end) return fail(c, PSMC_HIP_EINVAL, "load_segments_device: bad layout");
+		end = off[i] + (((int64_t)L[i] + 63) & ~(int64_t)63);
+	}
+	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
+	c->d_obs = (uint8_t *)d_obs; c->obs_borrowed = true;
+	c->off.assign(off, off + n_seg);
+	c->total = end;
+	return set_segments_common(c, n_seg, L);
+}
+
+extern "C" int psmc_hip_select(psmc_hip_ctx *c, int n_sel, const int32_t *idx)
+{
+	if (!c || n_sel < 1 || !idx) return fail(c, PSMC_HIP_EINVAL, "select: bad argument");
+	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "select: no segments loaded");
+	std::vector<int32_t> pos(c->n_seg, -1);
+	c->sel.assign(idx, idx + n_sel);
+	c->work.clear(); c->mult.clear(); c->sel2work.resize(n_sel);
+	for (int i = 0; i < n_sel; ++i) {
+		if (idx[i] < 0 || idx[i] >= c->n_seg) return fail(c, PSMC_HIP_EINVAL, "select: index out of range");
+		if (pos[idx[i]] < 0) { pos[idx[i]] = (int32_t)c->work.size(); c->work.push_back(idx[i]); c->mult.push_back(0); }
+		c->sel2work[i] = pos[idx[i]];
+		c->mult[pos[idx[i]]]++;
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc;
+	if ((rc = dev_alloc(c, &c->d_work, c->work.size()))) return rc;
+	HIPCHK(c, hipMemcpy(c->d_work, c->work.data(), sizeof(int32_t) * c->work.size(), hipMemcpyHostToDevice));
+	c->plan_dirty = true;
+	return PSMC_HIP_OK;
+}
+
+// pad the HMM parameters to 64 states and build aeT[b][l*64+k] = e[b][l]*a[k][l]
+// (hmm_pre_backward, khmm.c:194-206: one rounding per product), then upload.
+static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, hipStream_t st)
+{
+	const int n = c->n;
+	double *pa = c->h_par, *pae = pa + 4096, *pe = pae + 3 * 4096, *pa0 = pe + 3 * 64;
+	HIPCHK(c, hipStreamSynchronize(st)); // previous async copy out of the pinned staging buffer
+	memset(pa, 0, psmc_hip_ctx::PAR_LEN * sizeof(double));
+	for (int k = 0; k < n; ++k) {
+		for (int l = 0; l < n; ++l) pa[k * 64 + l] = a[k * n + l];
+		pe[k] = e[k]; pe[64 + k] = e[n + k];
+		pa0[k] = a0[k];
+	}
+	for (int k = 0; k < 64; ++k) pe[128 + k] = 1.0; // khmm.c:21
+	for (int b = 0; b < 3; ++b)
+		for (int l = 0; l < 64; ++l)
+			for (int k = 0; k < 64; ++k) pae[b * 4096 + l * 64 + k] = pe[b * 64 + l] * pa[k * 64 + l];
+	HIPCHK(c, hipMemcpyAsync(c->d_par, pa, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
+	return 0;
+}
+
+static int ensure_tables(psmc_hip_ctx *c, bool need_b)
+{
+	const int64_t bins = c->total + 128;
+	if (c->tab_bins < bins) {
+		int rc;
+		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) return rc;
+		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
+		c->have_b = false;
+		c->tab_bins = bins;
+	}
+	if (need_b && !c->have_b) {
+		int rc;
+		if ((rc = dev_alloc(c, &c->d_b, (size_t)c->tab_bins * 64))) return rc;
+		c->have_b = true;
+	}
+	return 0;
+}
+
+static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
+{
+	memset(&p, 0, sizeof(p));
+	p.stream = st;
+	p.rep_impl = c->rep_impl; p.expect_impl = c->expect_impl; p.n_states = c->n;
+	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
+	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
+	p.d_work = c->d_work; p.n_work = (int)c->work.size();
+	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s;
+	for (int i = 0; i < 5; ++i) p.ev[i] = c->ev[i];
+}
+
+static void collect_timing(psmc_hip_ctx *c)
+{
+	float t;
+	c->timing_valid = true;
+	for (int i = 0; i < 4; ++i) {
+		if (hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]) == hipSuccess) c->last_ms[i + 1] = t;
+		else { c->last_ms[i + 1] = 0; c->timing_valid = false; }
+	}
+	if (hipEventElapsedTime(&t, c->ev[0], c->ev[4]) == hipSuccess) c->last_ms[0] = t; else c->timing_valid = false;
+}
+
+// hmm_lk, khmm.c:245-260, on the host with the platform libm (same log() the
+// reference binary would call on this machine).
+static double host_lk(const double *s, int L)
+{
+	double sum = 0.0, prod = 1.0;
+	for (int u = 0; u < L; ++u) {
+		prod *= s[u];
+		if (prod < HMM_TINY_H || prod >= 1.0 / HMM_TINY_H) { sum += log(prod); prod = 1.0; }
+	}
+	sum += log(prod);
+	return sum;
+}
+
+// ---------------------------------------------------------------- exact mode
+static int run_exact(psmc_hip_ctx *c, const double *a, const double *e, const double *a0)
+{
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep: no segments loaded");
+	int rc;
+	if ((rc = ensure_tables(c, true))) return rc;
+	const int nw = (int)c->work.size();
+	if (c->seg_cap < nw || !c->d_chk) {
+		if ((rc = dev_alloc(c, &c->d_segA, (size_t)nw * 4096))) return rc;
+		if ((rc = dev_alloc(c, &c->d_segE, (size_t)nw * 192))) return rc;
+		if ((rc = dev_alloc(c, &c->d_segA0, (size_t)nw * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_chk, (size_t)c->n_seg))) return rc;
+		c->seg_cap = nw;
+	}
+	if ((rc = stage_params(c, a, e, a0, c->stream))) return rc;
+	EstepLaunch p;
+	fill_common(c, p, c->stream);
+	p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
+	if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact", hipGetLastError());
+	c->h_segA.resize((size_t)nw * 4096); c->h_segE.resize((size_t)nw * 192); c->h_segA0.resize((size_t)nw * 64);
+	c->h_chk.resize(c->n_seg); c->h_s.resize((size_t)c->total);
+	HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * 4096, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 192, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_segA0.data(), c->d_segA0, sizeof(double) * nw * 64, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_chk.data(), c->d_chk, sizeof(double) * c->n_seg, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_s.data(), c->d_s, sizeof(double) * c->total, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	collect_timing(c);
+	return 0;
+}
+
+extern "C" int psmc_hip_estep_segments(psmc_hip_ctx *c, const double *a, const double *e, const double *a0,
+                                       double *segA, double *segE, double *segA0, double *segLL, double *chk)
+{
+	if (!c || !a || !e || !a0) return fail(c, PSMC_HIP_EINVAL, "estep_segments: bad argument");
+	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "estep_segments: exact mode only");
+	int rc = run_exact(c, a, e, a0);
+	if (rc) return rc;
+	const int n = c->n, ns = (int)c->sel.size();
+	for (int i = 0; i < ns; ++i) {
+		const int w = c->sel2work[i], seg = c->sel[i];
+		if (segA)
+			for (int k = 0; k < n; ++k)
+				memcpy(segA + ((size_t)i * n + k) * n, &c->h_segA[(size_t)w * 4096 + k * 64], sizeof(double) * n);
+		if (segE)
+			for (int b = 0; b < 3; ++b)
+				memcpy(segE + ((size_t)i * 3 + b) * n, &c->h_segE[(size_t)w * 192 + b * 64], sizeof(double) * n);
+		if (segA0) memcpy(segA0 + (size_t)i * n, &c->h_segA0[(size_t)w * 64], sizeof(double) * n);
+		if (segLL) segLL[i] = host_lk(&c->h_s[(size_t)c->off[seg]], c->L[seg]);
+		if (chk) chk[i] = c->h_chk[seg];
+	}
+	return PSMC_HIP_OK;
+}
+
+static int estep_exact(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *A, double *E,
+                       double *A0, double *LL, double *chk)
+{
+	int rc = run_exact(c, a, e, a0);
+	if (rc) return rc;
+	const int n = c->n, ns = (int)c->sel.size(), nw = (int)c->work.size();
+	std::vector<double> lk(nw);
+	for (int w = 0; w < nw; ++w) lk[w] = host_lk(&c->h_s[(size_t)c->off[c->work[w]]], c->L[c->work[w]]);
+	// hmm_add_expect in input order (khmm.c:346-359), he_sum starting from calloc'ed zeros
+	std::vector<double> sA((size_t)n * n, 0.0), sE((size_t)2 * n, 0.0), sA0(n, 0.0);
+	double ll = 0.0;
+	for (int i = 0; i < ns; ++i) {
+		const int w = c->sel2work[i];
+		const double *hA = &c->h_segA[(size_t)w * 4096], *hE = &c->h_segE[(size_t)w * 192], *hA0 = &c->h_segA0[(size_t)w * 64];
+		ll += lk[w]; // em.c:48
+		for (int k = 0; k < n; ++k) {
+			sA0[k] += hA0[k];
+			for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * 64 + l];
+		}
+		for (int b = 0; b < 2; ++b)
+			for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * 64 + l];
+		if (chk) chk[i] = c->h_chk[c->sel[i]];
+	}
+	if (A) memcpy(A, sA.data(), sizeof(double) * n * n);
+	if (E) memcpy(E, sE.data(), sizeof(double) * 2 * n);
+	if (A0) memcpy(A0, sA0.data(), sizeof(double) * n);
+	if (LL) *LL = ll;
+	return PSMC_HIP_OK;
+}
+
+// ---------------------------------------------------------------- fast mode
+static int plan_fast(psmc_hip_ctx *c)
+{
+	int64_t bins = 0;
+	for (int32_t s : c->work) bins += c->L[s];
+	int T = c->chunk;
+	if (T <= 0) { // auto: about target_waves tiles, never below 256 bins
+		T = (int)((bins + c->target_waves - 1) / c->target_waves);
+		T = std::max(256, (T + 63) & ~63);
+	}
+	c->chunks.clear();
+	for (size_t w = 0; w < c->work.size(); ++w) {
+		const int32_t s = c->work[w];
+		for (int32_t lo = 1; lo <= c->L[s]; lo += T) {
+			Chunk ch;
+			ch.off = c->off[s]; ch.L = c->L[s]; ch.lo = lo; ch.hi = std::min(c->L[s], lo + T - 1); ch.mult = c->mult[w];
+			c->chunks.push_back(ch);
+		}
+	}
+	// longest tiles first is irrelevant (all equal); keep segment order for locality
+	const int nc = (int)c->chunks.size();
+	c->chunk_used = T;
+	int rc;
+	if (nc > c->chunk_cap) {
+		if ((rc = dev_alloc(c, &c->d_chunks, (size_t)nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_entry, (size_t)nc * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)nc * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * 192))) return rc;
+		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
+		c->chunk_cap = nc;
+	}
+	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub * 4096))) return rc;
+	if (!c->d_stage) {
+		if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * STATS_LEN))) return rc;
+		if ((rc = dev_alloc(c, &c->d_stats, (size_t)STATS_LEN))) return rc;
+		if ((rc = dev_alloc(c, &c->d_warm, (size_t)2))) return rc;
+	}
+	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
+	c->plan_dirty = false;
+	return 0;
+}
+
+static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *d_out,
+                        hipStream_t st)
+{
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep: no segments loaded");
+	int rc;
+	if ((rc = ensure_tables(c, true))) return rc;
+	if (c->plan_dirty && (rc = plan_fast(c))) return rc;
+	if ((rc = stage_params(c, a, e, a0, st))) return rc;
+	EstepLaunch p;
+	fill_common(c, p, st);
+	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub;
+	p.d_entry = c->d_entry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
+	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
+	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
+	if (launch_fast(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
+	return 0;
+}
+
+static int read_warm(psmc_hip_ctx *c, hipStream_t st)
+{
+	unsigned long long w[2];
+	HIPCHK(c, hipMemcpyAsync(w, c->d_warm, sizeof(w), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipStreamSynchronize(st));
+	memcpy(&c->warm_err[0], &w[0], 8); memcpy(&c->warm_err[1], &w[1], 8);
+	return 0;
+}
+
+extern "C" int psmc_hip_estep_device(psmc_hip_ctx *c, const double *a, const double *e, const double *a0,
+                                     void *d_stats, void *stream)
+{
+	if (!c || !a || !e || !a0 || !d_stats) return fail(c, PSMC_HIP_EINVAL, "estep_device: bad argument");
+	if (c->mode != PSMC_HIP_MODE_FAST) return fail(c, PSMC_HIP_ENOTSUP, "estep_device: fast mode only");
+	c->timing_valid = false;
+	return enqueue_fast(c, a, e, a0, (double *)d_stats, (hipStream_t)stream);
+}
+
+extern "C" int psmc_hip_fast_diag(psmc_hip_ctx *c, double *wf, double *wb, int *n_chunks, int *warmup_used)
+{
+	if (!c) return PSMC_HIP_EINVAL;
+	if (c->mode != PSMC_HIP_MODE_FAST || !c->d_warm) return fail(c, PSMC_HIP_ESTATE, "fast_diag: no fast E-step yet");
+	HIPCHK(c, hipSetDevice(c->device));
+	unsigned long long w[2];
+	HIPCHK(c, hipMemcpy(w, c->d_warm, sizeof(w), hipMemcpyDeviceToHost));
+	memcpy(&c->warm_err[0], &w[0], 8); memcpy(&c->warm_err[1], &w[1], 8);
+	if (wf) *wf = c->warm_err[0];
+	if (wb) *wb = c->warm_err[1];
+	if (n_chunks) *n_chunks = (int)c->chunks.size();
+	if (warmup_used) *warmup_used = c->warmup;
+	return PSMC_HIP_OK;
+}
+
+static int estep_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *A, double *E,
+                      double *A0, double *LL, double *chk)
+{
+	const int n = c->n;
+	for (;;) {
+		int rc = enqueue_fast(c, a, e, a0, c->d_stats ? c->d_stats : nullptr, c->stream);
+		if (rc) return rc;
+		if ((rc = read_warm(c, c->stream))) return rc;
+		collect_timing(c);
+		const double worst = std::max(c->warm_err[0], c->warm_err[1]);
+		if (worst <= c->warm_tol || !(worst == worst)) break;
+		if (c->warmup >= c->max_warmup) return fail(c, PSMC_HIP_ECONVERGE, "fast-mode warm-up did not converge");
+		c->warmup = std::max(64, c->warmup * 2); // the chain forgets more slowly than assumed: widen and redo
+	}
+	std::vector<double> h((size_t)n * n + 2 * n + 1);
+	HIPCHK(c, hipMemcpy(h.data(), c->d_stats, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+	if (A) memcpy(A, h.data(), sizeof(double) * n * n);
+	if (E) memcpy(E, h.data() + (size_t)n * n, sizeof(double) * 2 * n);
+	if (LL) *LL = h[(size_t)n * n + 2 * n];
+	if (A0) memset(A0, 0, sizeof(double) * n); // unused downstream (khmm.c:321-322); not computed in fast mode
+	if (chk) for (size_t i = 0; i < c->sel.size(); ++i) chk[i] = 1.0;
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_estep(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *A, double *E,
+                              double *A0, double *LL, double *chk)
+{
+	if (!c || !a || !e || !a0) return fail(c, PSMC_HIP_EINVAL, "estep: bad argument");
+	if (c->mode == PSMC_HIP_MODE_EXACT) return estep_exact(c, a, e, a0, A, E, A0, LL, chk);
+	if (c->plan_dirty) { // d_stats must exist before the first enqueue
+		HIPCHK(c, hipSetDevice(c->device));
+		int rc = plan_fast(c);
+		if (rc) return rc;
+	}
+	return estep_fast(c, a, e, a0, A, E, A0, LL, chk);
+}
+
+extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *b, double *s)
+{
+	if (!c || seg < 0 || seg >= c->n_seg) return fail(c, PSMC_HIP_EINVAL, "get_tables: bad argument");
+	if (!c->d_f) return fail(c, PSMC_HIP_ESTATE, "get_tables: no E-step yet");
+	if (b && c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "get_tables: b is kept in exact mode only");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int n = c->n, L = c->L[seg];
+	const int64_t off = c->off[seg];
+	std::vector<double> tmp((size_t)L * 64);
+	for (int which = 0; which < 2; ++which) {
+		double *dst = which == 0 ? f : b;
+		const double *src = which == 0 ? c->d_f : c->d_b;
+		if (!dst) continue;
+		HIPCHK(c, hipMemcpy(tmp.data(), src + off * 64, sizeof(double) * (size_t)L * 64, hipMemcpyDeviceToHost));
+		for (int u = 0; u < L; ++u) memcpy(dst + (size_t)u * n, &tmp[(size_t)u * 64], sizeof(double) * n);
+	}
+	if (s) HIPCHK(c, hipMemcpy(s, c->d_s + off, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[5])
+{
+	if (!c || !ms) return PSMC_HIP_EINVAL;
+	if (!c->timing_valid) {
+		HIPCHK(c, hipSetDevice(c->device));
+		if (hipEventSynchronize(c->ev[4]) != hipSuccess) return fail(c, PSMC_HIP_ESTATE, "last_timing: nothing recorded");
+		collect_timing(c);
+		if (!c->timing_valid) return fail(c, PSMC_HIP_ESTATE, "last_timing: events incomplete");
+	}
+	for (int i = 0; i < 5; ++i) ms[i] = c->last_ms[i];
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_selftest(int device)
+{
+	int nd = psmc_hip_device_count();
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	unsigned *d = nullptr, h = 0xffffffffu;
+	if (hipMalloc((void **)&d, sizeof(unsigned)) != hipSuccess) return PSMC_HIP_ENOMEM;
+	(void)hipMemset(d, 0, sizeof(unsigned));
+	int rc = run_selftest(nullptr, d);
+	if (rc == 0 && hipDeviceSynchronize() == hipSuccess && hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess)
+		rc = (int)h;
+	else
+		rc = PSMC_HIP_EDEVICE;
+	(void)hipFree(d);
+	return rc;
+}

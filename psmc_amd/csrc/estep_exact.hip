@@ -1,0 +1,277 @@
+// estep_exact.hip -- EXACT mode of the PSMC E-step for gfx950.
+//
+// Reproduces khmm.c's hmm_forward / hmm_backward / hmm_expect (lh3/psmc
+// khmm.c:145-190, 210-241, 297-324) BIT FOR BIT: strict IEEE-754 double, no FMA
+// contraction (file built with -ffp-contract=off and uses no fma), every sum in
+// the reference's index order, true division.  That forbids tree reductions,
+// atomics and any split of a segment along the sequence, so the parallelism is
+// one wavefront per segment (lane = hidden state k) for the two sweeps, and
+// (segment x 4-row group) workgroups for the ordered accumulation of the
+// expected counts.  Data layout (bin g = seg_off + position-1):
+//   obs[g] u8 {0,1,2} | f[g*64+k], b[g*64+k], s[g] fp64 | aeT[b][l*64+k] = e[b][l]*a[k][l]
+// States are padded to 64 with zero probabilities (adds of +0.0 are exact).
+#include <hip/hip_runtime.h>
+#include "wave_prims.h"
+#include "psmc_hip_internal.h"
+
+namespace psmc {
+
+#define PSMC_TINY 1e-25 /* HMM_TINY khmm.h:28 */
+
+__device__ __forceinline__ double pick_e(int sym, double e0, double e1) {
+	return sym == 0 ? e0 : (sym == 1 ? e1 : 1.0); // e[2][*] = 1 (khmm.c:21)
+}
+
+// ---------------------------------------------------------------- forward
+// khmm.c:145-190.  One wave per selected segment.
+template <int REP>
+__global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, const double *__restrict__ e,
+                                                    const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                    const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
+                                                    const int32_t *__restrict__ work, double *__restrict__ f,
+                                                    double *__restrict__ s)
+{
+	const int lane = threadIdx.x;
+	const int seg = work[blockIdx.x];
+	const int64_t off = seg_off[seg];
+	const int L = seg_len[seg];
+	double col[64]; // at[k][l] = a[l][k] (khmm.c:162-166)
+#pragma unroll
+	for (int l = 0; l < 64; ++l) col[l] = a[l * 64 + lane];
+	const double e0 = e[lane], e1 = e[64 + lane];
+	const uint8_t *o = obs + off;
+	double *fo = f + off * 64, *so = s + off;
+
+	int symv = o[lane]; // obs is padded by >= 64 bytes at the end
+	double x;
+	{ // position 1 (khmm.c:171-174)
+		const int sym = __builtin_amdgcn_readlane(symv, 0);
+		const double g = a0[lane] * pick_e(sym, e0, e1);
+		double r[4]; rep_rows<REP>(g, r);
+		const double sum = seq_sum_rep(r);
+		x = g / sum;
+		fo[lane] = x;
+		if (lane == 0) so[0] = sum;
+	}
+	for (int base = 0; base < L; base += 64) { // positions base+1 .. base+64
+		const int nb = min(64, L - base);
+		const int symn = (base + 64 < L) ? (int)o[base + 64 + lane] : 2;
+		for (int i = (base == 0 ? 1 : 0); i < nb; ++i) { // khmm.c:176-185
+			const int sym = __builtin_amdgcn_readlane(symv, i);
+			double r[4]; rep_rows<REP>(x, r);
+			const double tmp = xdot64(r, col);
+			const double g = pick_e(sym, e0, e1) * tmp;
+			double q[4]; rep_rows<REP>(g, q);
+			const double sum = seq_sum_rep(q);
+			x = g / sum;
+			fo[(int64_t)(base + i) * 64 + lane] = x;
+			if (lane == 0) so[base + i] = sum;
+		}
+		symv = symn;
+	}
+}
+
+// ---------------------------------------------------------------- backward
+// khmm.c:210-241.  4 waves per block, one segment each.  The hom-symbol row of
+// ae lives in VGPRs; the (rare) het and missing rows are read from LDS.
+template <int REP>
+__global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ aeT, const double *__restrict__ e,
+                                                     const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                     const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
+                                                     const int32_t *__restrict__ work, int n_work,
+                                                     const double *__restrict__ s, double *__restrict__ b,
+                                                     double *__restrict__ chk)
+{
+	__shared__ double lds_ae[2 * 4096]; // [0]: het (b=1), [1]: missing (b=2); [l*64+k]
+	for (int i = threadIdx.x; i < 2 * 4096; i += 256) lds_ae[i] = aeT[4096 + i];
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (w >= n_work) return;
+	const int seg = work[w];
+	const int64_t off = seg_off[seg];
+	const int L = seg_len[seg];
+	double row0[64];
+#pragma unroll
+	for (int l = 0; l < 64; ++l) row0[l] = aeT[l * 64 + lane];
+	const uint8_t *o = obs + off;
+	const double *so = s + off;
+	double *bo = b + off * 64;
+
+	// b[L][k] = 1/s[L] (khmm.c:226)
+	double x = 1.0 / so[L - 1];
+	bo[(int64_t)(L - 1) * 64 + lane] = x;
+	// positions u = L-1 .. 1; index of u is u-1.  Walk blocks of 64 indices downwards.
+	for (int top = L - 2; top >= 0; top -= 64) { // indices top, top-1, ..., max(top-63,0)
+		const int nb = min(64, top + 1);
+		const int lo = top - 63; // lane i holds index lo+i (may be < 0 -> clamp)
+		const int idx = max(lo + lane, 0);
+		const double sv = so[idx];
+		const int symv = o[idx + 1]; // symbol of position u+1 (index u)
+		for (int i = 63; i >= 64 - nb; --i) {
+			const int sym = __builtin_amdgcn_readlane(symv, i);
+			const double su = readlane_f64(sv, i);
+			double r[4]; rep_rows<REP>(x, r);
+			double tmp;
+			if (sym == 0) {
+				tmp = xdot64(r, row0);
+			} else {
+				const double *t = lds_ae + (sym - 1) * 4096 + lane;
+				double acc = 0.0;
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { // same order as xdot64, 16 LDS operands at a time
+					double m[16];
+#pragma unroll
+					for (int l = 0; l < 16; ++l) m[l] = t[(16 * j + l) * 64];
+					PSMC_XDOT16(r[j], m, 0)
+				}
+				tmp = acc;
+			}
+			x = tmp / su;
+			bo[(int64_t)(lo + i) * 64 + lane] = x;
+		}
+	}
+	{ // underflow check value (khmm.c:237-238): sum_l a0[l]*b[1][l]*e[o_1][l]
+		const int sym = o[0];
+		const double t = a0[lane] * x * e[sym * 64 + lane];
+		double r[4]; rep_rows<REP>(t, r);
+		const double c = seq_sum_rep(r);
+		if (lane == 0) chk[seg] = c;
+	}
+}
+
+// ---------------------------------------------------------------- expect
+// khmm.c:297-324.  grid = (n_work, 17): y<16 accumulates rows 4y..4y+3 of A for
+// one segment (lane = column l) in position order; y==16 accumulates E and A0
+// (lane = state k).  Per-segment results (he of em.c:49) go to segA/segE/segA0;
+// the host adds them in input order (hmm_add_expect, khmm.c:346-359).
+__global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ aeT, const double *__restrict__ e,
+                                                       const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                       const int64_t *__restrict__ seg_off,
+                                                       const int32_t *__restrict__ seg_len, const int32_t *__restrict__ work,
+                                                       const double *__restrict__ f, const double *__restrict__ b,
+                                                       const double *__restrict__ s, double *__restrict__ segA,
+                                                       double *__restrict__ segE, double *__restrict__ segA0)
+{
+	const int lane = threadIdx.x;
+	const int seg = work[blockIdx.x];
+	const int64_t off = seg_off[seg];
+	const int L = seg_len[seg];
+	const uint8_t *o = obs + off;
+	const double *fo = f + off * 64, *bo = b + off * 64, *so = s + off;
+	constexpr int BLK = 16;
+	if (blockIdx.y < 16) {
+		const int k0 = blockIdx.y * 4;
+		double q[3][4]; // ae[sym][k0+j][l], l = lane
+#pragma unroll
+		for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) q[sy][j] = aeT[sy * 4096 + lane * 64 + k0 + j];
+		double acc[4] = {PSMC_TINY, PSMC_TINY, PSMC_TINY, PSMC_TINY}; // khmm.c:305-306
+		// u = 1..L-1 ; index i = u-1 = 0..L-2 ; uses f[i][k], b[i+1][l], obs[i+1]
+		const int n = L - 1;
+		const int fl_i = lane >> 2, fl_j = lane & 3; // f tile: lane -> (position i, row j)
+		double ft = 0.0, bn[BLK]; int sv = 2;
+		auto load_blk = [&](int i0, double &ft_, double (&bn_)[BLK], int &sv_) {
+			const int ii = min(i0 + fl_i, max(n - 1, 0));
+			ft_ = fo[(int64_t)ii * 64 + k0 + fl_j];
+			sv_ = o[min(i0 + min(lane, BLK - 1) + 1, L - 1)];
+#pragma unroll
+			for (int t = 0; t < BLK; ++t) bn_[t] = bo[(int64_t)min(i0 + t + 1, L - 1) * 64 + lane];
+		};
+		if (n > 0) load_blk(0, ft, bn, sv);
+		for (int i0 = 0; i0 < n; i0 += BLK) {
+			double ft2 = 0.0, bn2[BLK]; int sv2 = 2;
+			if (i0 + BLK < n) load_blk(i0 + BLK, ft2, bn2, sv2);
+			const int nb = min(BLK, n - i0);
+#pragma unroll
+			for (int t = 0; t < BLK; ++t) {
+				if (t < nb) {
+					const int sym = __builtin_amdgcn_readlane(sv, t);
+					const double f0 = readlane_f64(ft, 4 * t + 0), f1 = readlane_f64(ft, 4 * t + 1);
+					const double f2 = readlane_f64(ft, 4 * t + 2), f3 = readlane_f64(ft, 4 * t + 3);
+					double q0, q1, q2, q3;
+					if (sym == 0) { q0 = q[0][0]; q1 = q[0][1]; q2 = q[0][2]; q3 = q[0][3]; }
+					else if (sym == 1) { q0 = q[1][0]; q1 = q[1][1]; q2 = q[1][2]; q3 = q[1][3]; }
+					else { q0 = q[2][0]; q1 = q[2][1]; q2 = q[2][2]; q3 = q[2][3]; }
+					const double bl = bn[t];
+					acc[0] += f0 * q0 * bl; // khmm.c:316: AA[l] += fuk * q[l] * bu1[l]
+					acc[1] += f1 * q1 * bl;
+					acc[2] += f2 * q2 * bl;
+					acc[3] += f3 * q3 * bl;
+				}
+			}
+			ft = ft2; sv = sv2;
+#pragma unroll
+			for (int t = 0; t < BLK; ++t) bn[t] = bn2[t];
+		}
+		double *out = segA + (int64_t)blockIdx.x * 4096;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) out[(k0 + j) * 64 + lane] = acc[j];
+	} else {
+		double E0 = PSMC_TINY, E1 = PSMC_TINY, E2 = PSMC_TINY; // khmm.c:307-308
+		const int n = L - 1; // u = 1..L-1, index i = u-1: f[i], b[i], s[i], obs[i]
+		double fu[BLK], bu[BLK], sv = 0.0; int symv = 2;
+		auto load_blk = [&](int i0, double (&fu_)[BLK], double (&bu_)[BLK], double &sv_, int &symv_) {
+			const int ii = min(i0 + min(lane, BLK - 1), L - 1);
+			sv_ = so[ii]; symv_ = o[ii];
+#pragma unroll
+			for (int t = 0; t < BLK; ++t) {
+				const int64_t r = (int64_t)min(i0 + t, L - 1) * 64 + lane;
+				fu_[t] = fo[r]; bu_[t] = bo[r];
+			}
+		};
+		if (n > 0) load_blk(0, fu, bu, sv, symv);
+		for (int i0 = 0; i0 < n; i0 += BLK) {
+			double fu2[BLK], bu2[BLK], sv2 = 0.0; int symv2 = 2;
+			if (i0 + BLK < n) load_blk(i0 + BLK, fu2, bu2, sv2, symv2);
+			const int nb = min(BLK, n - i0);
+#pragma unroll
+			for (int t = 0; t < BLK; ++t) {
+				if (t < nb) {
+					const int sym = __builtin_amdgcn_readlane(symv, t);
+					const double ss = readlane_f64(sv, t);
+					const double v = fu[t] * bu[t] * ss; // khmm.c:317: Ec[k] += fuk * bu[k] * ss
+					if (sym == 0) E0 += v; else if (sym == 1) E1 += v; else E2 += v;
+				}
+			}
+			sv = sv2; symv = symv2;
+#pragma unroll
+			for (int t = 0; t < BLK; ++t) { fu[t] = fu2[t]; bu[t] = bu2[t]; }
+		}
+		double *oe = segE + (int64_t)blockIdx.x * 192;
+		oe[lane] = E0; oe[64 + lane] = E1; oe[128 + lane] = E2;
+		const int sym1 = o[0]; // khmm.c:321-322: A0[l] += a0[l]*e[o_1][l]*b[1][l], A0 starts at 0
+		segA0[(int64_t)blockIdx.x * 64 + lane] = 0.0 + a0[lane] * e[sym1 * 64 + lane] * bo[lane];
+	}
+}
+
+// ---------------------------------------------------------------- launchers
+int launch_exact(const EstepLaunch &p)
+{
+	const int rep = p.rep_impl;
+	if (p.n_work <= 0) return 0;
+	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
+	if (rep == 0)
+		hipLaunchKernelGGL(k_fwd_exact<0>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
+		                   p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_s);
+	else
+		hipLaunchKernelGGL(k_fwd_exact<1>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
+		                   p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_s);
+	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
+	const int nb = (p.n_work + 3) / 4;
+	if (rep == 0)
+		hipLaunchKernelGGL(k_bwd_exact<0>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
+		                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
+	else
+		hipLaunchKernelGGL(k_bwd_exact<1>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
+		                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
+	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
+	hipLaunchKernelGGL(k_expect_exact, dim3(p.n_work, 17), dim3(64), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
+	                   p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);
+	if (p.ev[4]) hipEventRecord(p.ev[4], p.stream);
+	return (int)hipGetLastError();
+}
+
+} // namespace psmc

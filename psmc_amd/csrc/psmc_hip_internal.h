@@ -1,0 +1,58 @@
+// psmc_hip_internal.h -- shared between api.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psmc {
+
+constexpr int NS = 64;          // padded number of states (one wave lane per state)
+constexpr int STATS_LEN = NS * NS + 3 * NS + 1; // padded device stats: C/A | E[3] | LL
+
+// One tile of one segment (fast mode).  Positions are 1-based like khmm.c.
+struct Chunk {
+	int64_t off;  // global bin index of the segment's first position
+	int32_t L;    // segment length
+	int32_t lo;   // first position owned by the tile
+	int32_t hi;   // last position owned by the tile
+	int32_t mult; // how many times the segment occurs in the selection (bootstrap)
+};
+
+// Everything a launch needs (device pointers unless noted).
+struct EstepLaunch {
+	hipStream_t stream;
+	int rep_impl, expect_impl, n_states;
+	// parameters (padded to NS)
+	const double *d_a;   // a[l*64+k] row-major P(l->k)... i.e. a[row*64+col]
+	const double *d_aeT; // aeT[b][l*64+k] = e[b][l]*a[k][l], b=0..2 (b=2 is a transposed)
+	const double *d_e;   // e[b*64+k], b=0..2 (row 2 = 1)
+	const double *d_a0;  // a0[k]
+	// data
+	const uint8_t *d_obs;
+	const int64_t *d_seg_off;
+	const int32_t *d_seg_len;
+	const int32_t *d_work; // exact: unique selected segment ids
+	int n_work;
+	double *d_f, *d_b, *d_s; // exact: f,b tables + s; fast: f = X (lag-normalised), d_b = bt, d_s = inv_d
+	// exact outputs
+	double *d_segA, *d_segE, *d_segA0, *d_chk;
+	// fast
+	const Chunk *d_chunks;
+	int n_chunks, warmup, n_sub;
+	double *d_entry, *d_bexit;  // [n_chunks][64] warm-up check vectors
+	double *d_Cpart;            // [n_chunks*n_sub][4096]
+	double *d_Epart;            // [n_chunks][192]
+	double *d_LLpart;           // [n_chunks]
+	double *d_stage;            // [RED_ROWS][STATS_LEN]
+	double *d_stats;            // [n*n + 2n + 1] final, unpadded [A | E | LL]
+	unsigned long long *d_warm; // [2] max warm-up mismatch (double bits)
+	double tiny_total;          // n_selected_segments * HMM_TINY
+	hipEvent_t ev[5];           // optional timing marks (may be null)
+};
+
+constexpr int RED_ROWS = 64;
+
+int launch_exact(const EstepLaunch &p);
+int launch_fast(const EstepLaunch &p);
+int run_selftest(hipStream_t stream, unsigned *d_flags);
+
+} // namespace psmc

@@ -1,0 +1,87 @@
+// selftest.hip -- on-device check of the cross-lane primitives the E-step
+// kernels are built from.  The expected values come from plain LDS indexing, so
+// a wrong assumption about a DPP / permlane / MFMA lane mapping shows up as a
+// bit in the returned mask instead of as silently wrong statistics.
+#include <hip/hip_runtime.h>
+#include "wave_prims.h"
+#include "psmc_hip_internal.h"
+
+namespace psmc {
+
+typedef double d4s_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void k_selftest(unsigned *flags)
+{
+	__shared__ double sh[64];
+	__shared__ double D[16][16];
+	const int lane = threadIdx.x;
+	const double x = 1.0 / (3.0 + lane) + 0.001 * lane * lane; // distinct, non-trivial mantissas
+	sh[lane] = x;
+	__syncthreads();
+	unsigned bad = 0;
+	double r0[4], r1[4];
+	rep_rows_bperm(x, r0);
+	rep_rows_swap(x, r1);
+	for (int j = 0; j < 4; ++j) {
+		const double want = sh[16 * j + (lane & 15)];
+		if (r0[j] != want) bad |= 1u;
+		if (r1[j] != want) bad |= 2u;
+	}
+	// from here on use LDS-built replicated registers so later checks are independent
+	double r[4];
+	for (int j = 0; j < 4; ++j) r[j] = sh[16 * j + (lane & 15)];
+	if (bcast16<0>(x) != sh[(lane & ~15) + 0]) bad |= 4u;
+	if (bcast16<5>(x) != sh[(lane & ~15) + 5]) bad |= 4u;
+	if (bcast16<15>(x) != sh[(lane & ~15) + 15]) bad |= 4u;
+	{
+		double acc = 0.5;
+		const double m = 2.0 + lane;
+		dpp_guard(r);
+		fmac_bcast<7>(acc, r[2], m); // fma(x[39], m, 0.5)
+		if (acc != __builtin_fma(sh[39], m, 0.5)) bad |= 8u;
+		double acc2 = 0.25;
+		fmac_bcast<0>(acc2, r[0], m);
+		fmac_bcast<15>(acc2, r[3], m);
+		if (acc2 != __builtin_fma(sh[63], m, __builtin_fma(sh[0], m, 0.25))) bad |= 8u;
+	}
+	{
+		double seq = 0.0;
+		for (int k = 0; k < 64; ++k) seq = seq + sh[k];
+		if (seq_sum_rep(r) != seq) bad |= 32u;
+		const double t = wave_sum_rep(r);
+		if (fabs(t - seq) > 1e-13 * fabs(seq)) bad |= 16u;
+	}
+	{ // exact dot against a serial loop
+		double m[64];
+		for (int l = 0; l < 64; ++l) m[l] = 1.0 / (1.0 + l + 0.37 * lane);
+		double want = 0.0;
+		for (int l = 0; l < 64; ++l) want = want + sh[l] * m[l];
+		if (xdot64(r, m) != want) bad |= 64u;
+		double wf = fdot64(r, m);
+		if (fabs(wf - want) > 1e-13 * fabs(want)) bad |= 128u;
+	}
+	{ // f64 MFMA 16x16x4 operand / result lane mapping
+		const int t = lane >> 4, i = lane & 15;
+		const double A = 0.5 * i + 3.0 * t + 1.0;   // A[i][t]
+		const double B = 7.0 * i - 1.0 * t + 0.25;  // B[t][j=i]
+		d4s_t acc = {0.0, 0.0, 0.0, 0.0};
+		acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, acc, 0, 0, 0);
+		for (int q = 0; q < 4; ++q) D[t + 4 * q][i] = acc[q];
+		__syncthreads();
+		for (int e = lane; e < 256; e += 64) {
+			const int ri = e >> 4, cj = e & 15;
+			double want = 0.0;
+			for (int tt = 0; tt < 4; ++tt) want += (0.5 * ri + 3.0 * tt + 1.0) * (7.0 * cj - 1.0 * tt + 0.25);
+			if (fabs(D[ri][cj] - want) > 1e-9) bad |= 256u;
+		}
+	}
+	if (bad) atomicOr(flags, bad);
+}
+
+int run_selftest(hipStream_t stream, unsigned *d_flags)
+{
+	hipLaunchKernelGGL(k_selftest, dim3(4), dim3(64), 0, stream, d_flags);
+	return (int)hipGetLastError();
+}
+
+} // namespace psmc

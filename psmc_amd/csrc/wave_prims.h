@@ -1,0 +1,151 @@
+// wave_prims.h -- gfx950 (CDNA4) wave64 cross-lane primitives used by the
+// PSMC E-step kernels.  Device-only, header-only.
+//
+// Layout vocabulary: a wave is 64 lanes = 4 DPP "rows" of 16 lanes.
+//   natural     : lane i holds x[i]                          (state k = lane)
+//   replicated  : r[j], j=0..3; lane i holds x[16*j + (i&15)] in EVERY row
+// The 64-term dot products of the forward/backward recursions are evaluated
+// with `row_newbcast` DPP (the only DPP mode CDNA4 allows on 64-bit ALU ops):
+// lane i of row R reads lane 16*R+N of the source register, so with the state
+// vector held in replicated layout every lane can read x[16*j+N] for free as an
+// operand of v_fmac_f64_dpp (fast mode) or v_mov_b64_dpp (exact mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psmc {
+
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned f64_lo(double x) { return (unsigned)__builtin_bit_cast(unsigned long long, x); }
+__device__ __forceinline__ unsigned f64_hi(double x) { return (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32); }
+__device__ __forceinline__ double f64_mk(unsigned lo, unsigned hi) {
+	return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
+// lane i <- v[(i & ~15) + N]   (compiler-visible: hazards handled by hipcc)
+template <int N> __device__ __forceinline__ double bcast16(double v) {
+	long long s = __builtin_bit_cast(long long, v);
+	long long r = __builtin_amdgcn_update_dpp(s, s, 0x150 + N, 0xf, 0xf, true); // row_newbcast:N
+	return __builtin_bit_cast(double, r);
+}
+
+// generic 64-bit DPP move (split into two v_mov_b32_dpp by the compiler)
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+	long long s = __builtin_bit_cast(long long, v);
+	long long r = __builtin_amdgcn_update_dpp(s, s, CTRL, 0xf, 0xf, true);
+	return __builtin_bit_cast(double, r);
+}
+
+// acc = fma(bcast16<N>(r), m, acc) in ONE instruction (fast mode only).
+// hipcc does not pad hazards inside asm: callers must have passed r through
+// dpp_guard() after the last VALU write of r (VALU write -> DPP read: 2 states).
+template <int N> __device__ __forceinline__ void fmac_bcast(double &acc, double r, double m) {
+	asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+	    : "+v"(acc) : "v"(r), "v"(m), "n"(N));
+}
+__device__ __forceinline__ void dpp_guard(double (&r)[4]) {
+	asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
+
+// natural -> replicated, via the LDS crossbar (no LDS memory).  Reference
+// implementation: semantics of ds_bpermute are unambiguous.
+__device__ __forceinline__ void rep_rows_bperm(double x, double (&r)[4]) {
+	const int lane = (int)(threadIdx.x & 63);
+	const unsigned lo = f64_lo(x), hi = f64_hi(x);
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int addr = (16 * j + (lane & 15)) * 4;
+		r[j] = f64_mk((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)lo),
+		              (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)hi));
+	}
+}
+
+// natural -> replicated with the gfx950 v_permlane16_swap / v_permlane32_swap
+// pair (register-only, ~14 VALU issues, no LDS latency).
+//   permlane16_swap(A,B): odd rows of A <-> even rows of B
+//   permlane32_swap(A,B): rows 2,3 of A <-> rows 0,1 of B
+// (x0,x1,x2,x3 = the four rows of x)
+//   (P,Q)   = swap16(x,x)  -> P=(x0,x0,x2,x2)  Q=(x1,x1,x3,x3)
+//   (P0,P2) = swap32(P,P)  -> (x0 x4 rows), (x2 x4 rows);  same for Q -> x1, x3
+__device__ __forceinline__ void rep_rows_swap(double x, double (&r)[4]) {
+	const unsigned lo = f64_lo(x), hi = f64_hi(x);
+	const u32x2_t pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+	const u32x2_t ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+	const u32x2_t al = __builtin_amdgcn_permlane32_swap(pl.x, pl.x, false, false);
+	const u32x2_t ah = __builtin_amdgcn_permlane32_swap(ph.x, ph.x, false, false);
+	const u32x2_t bl = __builtin_amdgcn_permlane32_swap(pl.y, pl.y, false, false);
+	const u32x2_t bh = __builtin_amdgcn_permlane32_swap(ph.y, ph.y, false, false);
+	r[0] = f64_mk(al.x, ah.x); r[2] = f64_mk(al.y, ah.y);
+	r[1] = f64_mk(bl.x, bh.x); r[3] = f64_mk(bl.y, bh.y);
+}
+
+template <int IMPL> __device__ __forceinline__ void rep_rows(double x, double (&r)[4]) {
+	if (IMPL == 0) rep_rows_bperm(x, r); else rep_rows_swap(x, r);
+}
+
+// Sum over all 64 states given the replicated form; every lane gets the total.
+// Tree order (fast mode only): 3 adds across the row groups, then a 4-level
+// butterfly inside the 16-lane row with 32-bit DPP moves.
+__device__ __forceinline__ double wave_sum_rep(const double (&r)[4]) {
+	double t = (r[0] + r[1]) + (r[2] + r[3]);
+	t = t + dpp_mov<0xB1>(t);  // quad_perm:[1,0,3,2]
+	t = t + dpp_mov<0x4E>(t);  // quad_perm:[2,3,0,1]
+	t = t + dpp_mov<0x124>(t); // row_ror:4
+	t = t + dpp_mov<0x128>(t); // row_ror:8
+	return t;
+}
+
+// Strict left-to-right sum x[0]+x[1]+...+x[63] starting from 0.0 (exact mode:
+// reproduces `for (k...) sum += v[k]` of the reference bit for bit); every
+// lane gets the total.
+#define PSMC_SEQ16(j)                                                              \
+	s = s + bcast16<0>(r[j]);  s = s + bcast16<1>(r[j]);  s = s + bcast16<2>(r[j]);  \
+	s = s + bcast16<3>(r[j]);  s = s + bcast16<4>(r[j]);  s = s + bcast16<5>(r[j]);  \
+	s = s + bcast16<6>(r[j]);  s = s + bcast16<7>(r[j]);  s = s + bcast16<8>(r[j]);  \
+	s = s + bcast16<9>(r[j]);  s = s + bcast16<10>(r[j]); s = s + bcast16<11>(r[j]); \
+	s = s + bcast16<12>(r[j]); s = s + bcast16<13>(r[j]); s = s + bcast16<14>(r[j]); \
+	s = s + bcast16<15>(r[j]);
+__device__ __forceinline__ double seq_sum_rep(const double (&r)[4]) {
+	double s = 0.0;
+	PSMC_SEQ16(0) PSMC_SEQ16(1) PSMC_SEQ16(2) PSMC_SEQ16(3)
+	return s;
+}
+
+// exact-order dot product: ((x0*m0 + x1*m1) + x2*m2) + ... , products rounded
+// separately (file is compiled with -ffp-contract=off), first term 0.0 + p0.
+#define PSMC_XDOT16(R, M, O)                                                                  \
+	acc = acc + bcast16<0>(R) * M[(O) + 0];   acc = acc + bcast16<1>(R) * M[(O) + 1];   \
+	acc = acc + bcast16<2>(R) * M[(O) + 2];   acc = acc + bcast16<3>(R) * M[(O) + 3];   \
+	acc = acc + bcast16<4>(R) * M[(O) + 4];   acc = acc + bcast16<5>(R) * M[(O) + 5];   \
+	acc = acc + bcast16<6>(R) * M[(O) + 6];   acc = acc + bcast16<7>(R) * M[(O) + 7];   \
+	acc = acc + bcast16<8>(R) * M[(O) + 8];   acc = acc + bcast16<9>(R) * M[(O) + 9];   \
+	acc = acc + bcast16<10>(R) * M[(O) + 10]; acc = acc + bcast16<11>(R) * M[(O) + 11]; \
+	acc = acc + bcast16<12>(R) * M[(O) + 12]; acc = acc + bcast16<13>(R) * M[(O) + 13]; \
+	acc = acc + bcast16<14>(R) * M[(O) + 14]; acc = acc + bcast16<15>(R) * M[(O) + 15];
+__device__ __forceinline__ double xdot64(const double (&r)[4], const double (&m)[64]) {
+	double acc = 0.0;
+	PSMC_XDOT16(r[0], m, 0) PSMC_XDOT16(r[1], m, 16) PSMC_XDOT16(r[2], m, 32) PSMC_XDOT16(r[3], m, 48)
+	return acc;
+}
+
+// fast dot product: 4 independent FMA chains (one per row group) interleaved so
+// that consecutive FMAs of one chain are 4 issues apart, then a 2-level add.
+#define PSMC_FDOT4(N)                                                          \
+	fmac_bcast<N>(c0, r[0], m[N]);      fmac_bcast<N>(c1, r[1], m[16 + N]);       \
+	fmac_bcast<N>(c2, r[2], m[32 + N]); fmac_bcast<N>(c3, r[3], m[48 + N]);
+__device__ __forceinline__ double fdot64(const double (&r)[4], const double (&m)[64]) {
+	double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+	PSMC_FDOT4(0) PSMC_FDOT4(1) PSMC_FDOT4(2) PSMC_FDOT4(3) PSMC_FDOT4(4) PSMC_FDOT4(5)
+	PSMC_FDOT4(6) PSMC_FDOT4(7) PSMC_FDOT4(8) PSMC_FDOT4(9) PSMC_FDOT4(10) PSMC_FDOT4(11)
+	PSMC_FDOT4(12) PSMC_FDOT4(13) PSMC_FDOT4(14) PSMC_FDOT4(15)
+	return (c0 + c1) + (c2 + c3);
+}
+
+// wave-uniform double out of a VGPR lane (lane index may be a runtime scalar)
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+	return f64_mk((unsigned)__builtin_amdgcn_readlane((int)f64_lo(v), lane),
+	              (unsigned)__builtin_amdgcn_readlane((int)f64_hi(v), lane));
+}
+
+} // namespace psmc

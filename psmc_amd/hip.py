@@ -1,0 +1,198 @@
+"""ctypes mirror of include/psmc_hip.h.
+
+`HipEStep` plays the role the khmm.h call sequence plays inside psmc_em()
+(lh3/psmc em.c:33-55): give it the segments once, then per EM iteration hand it
+the HMM parameters (a, e, a0) and get back the summed expected counts
+he_sum->A, he_sum->E[0..1] and the log-likelihood.  There is NO CPU fallback:
+if libpsmc_hip.so is missing or no GPU is visible, construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+MODE_EXACT = 0
+MODE_FAST = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+# every symbol include/psmc_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "psmc_hip_device_count", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
+    "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
+    "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
+    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag",
+    "psmc_hip_get_tables", "psmc_hip_selftest", "psmc_hip_last_timing",
+]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libpsmc_hip.so")
+
+
+def load_library():
+    """dlopen psmc_amd/libpsmc_hip.so (built by psmc_amd/csrc/Makefile).  Fails loudly."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise HipError("%s not built: run `make -C psmc_amd/csrc` (or __graft_entry__.build())" % p)
+    lib = C.CDLL(p)
+    lib.psmc_hip_strerror.restype = C.c_char_p
+    lib.psmc_hip_last_error.restype = C.c_char_p
+    lib.psmc_hip_last_error.argtypes = [C.c_void_p]
+    lib.psmc_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+    lib.psmc_hip_destroy.argtypes = [C.c_void_p]
+    lib.psmc_hip_destroy.restype = None
+    lib.psmc_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    lib.psmc_hip_load_segments.argtypes = [C.c_void_p, C.c_int, C.POINTER(_u8p), _i32p]
+    lib.psmc_hip_load_segments_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p]
+    lib.psmc_hip_select.argtypes = [C.c_void_p, C.c_int, _i32p]
+    lib.psmc_hip_estep.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.psmc_hip_estep_segments.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.psmc_hip_estep_device.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_void_p]
+    lib.psmc_hip_fast_diag.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.psmc_hip_get_tables.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+    lib.psmc_hip_selftest.argtypes = [C.c_int]
+    lib.psmc_hip_last_timing.argtypes = [C.c_void_p, _dp]
+    _LIB = lib
+    return lib
+
+
+def _p(x):
+    return x.ctypes.data_as(_dp) if x is not None else None
+
+
+class HipEStep:
+    """One E-step engine bound to one GPU.
+
+    a: (n, n) transition matrix, a[k, l] = P(k -> l)       (khmm.h:34)
+    e: (2, n) or (3, n) emission rows hom / het [/ missing] (khmm.h:34, khmm.c:21)
+    a0: (n,) initial distribution                           (khmm.h:36)
+    """
+
+    def __init__(self, n_states, device=0, mode=MODE_FAST, **options):
+        self.lib = load_library()
+        if self.lib.psmc_hip_device_count() <= 0:
+            raise HipError("no HIP device visible: libpsmc_hip needs an AMD GPU (no CPU fallback)")
+        self.n = int(n_states)
+        self.mode = mode
+        h = C.c_void_p()
+        rc = self.lib.psmc_hip_create(C.byref(h), self.n, int(device), int(mode))
+        if rc != 0:
+            raise HipError("psmc_hip_create: %s" % self.lib.psmc_hip_strerror(rc).decode())
+        self.h = h
+        self.n_seg = 0
+        self.n_sel = 0
+        self._keep = None
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise HipError("%s: %s (%s)" % (what, self.lib.psmc_hip_strerror(rc).decode(),
+                                            self.lib.psmc_hip_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.psmc_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self._chk(self.lib.psmc_hip_set_option(self.h, key.encode(), float(value)), "set_option(%s)" % key)
+
+    def load_segments(self, segs):
+        segs = [np.ascontiguousarray(s, dtype=np.uint8) for s in segs]
+        n = len(segs)
+        ptrs = (_u8p * n)(*[s.ctypes.data_as(_u8p) for s in segs])
+        lens = np.array([len(s) for s in segs], dtype=np.int32)
+        self._chk(self.lib.psmc_hip_load_segments(self.h, n, ptrs, lens.ctypes.data_as(_i32p)), "load_segments")
+        self.n_seg = self.n_sel = n
+        self.lens = lens
+
+    def load_segments_device(self, d_obs_ptr, offsets, lens, keepalive=None):
+        """Observations already in HBM (e.g. a torch.uint8 CUDA tensor's data_ptr())."""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        self._keep = keepalive
+        self._chk(self.lib.psmc_hip_load_segments_device(self.h, len(lens), C.c_void_p(int(d_obs_ptr)),
+                                                         off.ctypes.data_as(_i64p), lens.ctypes.data_as(_i32p)),
+                  "load_segments_device")
+        self.n_seg = self.n_sel = len(lens)
+        self.lens = lens
+
+    def select(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self._chk(self.lib.psmc_hip_select(self.h, len(idx), idx.ctypes.data_as(_i32p)), "select")
+        self.n_sel = len(idx)
+
+    def _params(self, a, e, a0):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        e = np.ascontiguousarray(np.asarray(e, dtype=np.float64)[:2])
+        a0 = np.ascontiguousarray(a0, dtype=np.float64)
+        assert a.shape == (self.n, self.n) and e.shape == (2, self.n) and a0.shape == (self.n,)
+        return a, e, a0
+
+    def estep(self, a, e, a0):
+        """dict(A (n,n), E (2,n), A0 (n,), LL, chk (n_sel,)) -- em.c:33-55."""
+        a, e, a0 = self._params(a, e, a0)
+        n = self.n
+        A = np.zeros((n, n)); E = np.zeros((2, n)); A0 = np.zeros(n); LL = C.c_double(0)
+        chk = np.zeros(self.n_sel)
+        self._chk(self.lib.psmc_hip_estep(self.h, _p(a), _p(e), _p(a0), _p(A), _p(E), _p(A0), C.byref(LL), _p(chk)),
+                  "estep")
+        return dict(A=A, E=E, A0=A0, LL=LL.value, chk=chk)
+
+    def estep_segments(self, a, e, a0):
+        """Exact mode: the per-segment `he` of em.c:49 (seg_A, seg_E incl. the missing row, seg_A0, seg_LL, chk)."""
+        a, e, a0 = self._params(a, e, a0)
+        n, ns = self.n, self.n_sel
+        sA = np.zeros((ns, n, n)); sE = np.zeros((ns, 3, n)); sA0 = np.zeros((ns, n)); sLL = np.zeros(ns)
+        chk = np.zeros(ns)
+        self._chk(self.lib.psmc_hip_estep_segments(self.h, _p(a), _p(e), _p(a0), _p(sA), _p(sE), _p(sA0), _p(sLL),
+                                                   _p(chk)), "estep_segments")
+        return dict(seg_A=sA, seg_E=sE, seg_A0=sA0, seg_LL=sLL, chk=chk)
+
+    def estep_device(self, a, e, a0, d_stats_ptr, stream_ptr=0):
+        """Fast mode, asynchronous: [A | E | LL] (n*n+2n+1 doubles) into device memory on `stream`."""
+        a, e, a0 = self._params(a, e, a0)
+        self._chk(self.lib.psmc_hip_estep_device(self.h, _p(a), _p(e), _p(a0), C.c_void_p(int(d_stats_ptr)),
+                                                 C.c_void_p(int(stream_ptr))), "estep_device")
+
+    def fast_diag(self):
+        wf = C.c_double(0); wb = C.c_double(0); nc = C.c_int(0); wu = C.c_int(0)
+        self._chk(self.lib.psmc_hip_fast_diag(self.h, C.byref(wf), C.byref(wb), C.byref(nc), C.byref(wu)), "fast_diag")
+        return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value)
+
+    def tables(self, seg, want_b=True):
+        L = int(self.lens[seg])
+        f = np.zeros((L, self.n)); s = np.zeros(L)
+        b = np.zeros((L, self.n)) if want_b else None
+        self._chk(self.lib.psmc_hip_get_tables(self.h, int(seg), _p(f), _p(b), _p(s)), "get_tables")
+        return f, b, s
+
+    def timing(self):
+        ms = np.zeros(5)
+        self._chk(self.lib.psmc_hip_last_timing(self.h, _p(ms)), "last_timing")
+        return dict(total=ms[0], forward=ms[1], backward=ms[2], expect=ms[3], reduce=ms[4])
+
+
+def selftest(device=0):
+    lib = load_library()
+    return lib.psmc_hip_selftest(int(device))

@@ -1,0 +1,70 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLD = os.path.join(HERE, "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _npz(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+class Golden:
+    """Golden vectors dumped from the real reference by tests/golden/make_golden.py."""
+
+    def __init__(self):
+        self.params_raw = _npz("hmm_params.npz")
+        self.small = _npz("estep_small.npz")
+        self.mid = _npz("estep_mid.npz")
+        self.kats = _npz("host_kats.npz")
+        s = _npz("segments_small.npz")
+        self.segs_small = [s[k] for k in sorted(s)]
+        s = _npz("segments_mid.npz")
+        self.segs_mid = [s[k] for k in sorted(s)]
+
+    def params(self, key):
+        """dict(a, e (3,n), a0, sigma, t, params, pattern, ...) of one parameter set, e.g. 'n64_curve'."""
+        pre = key + "."
+        d = {k[len(pre):]: v for k, v in self.params_raw.items() if k.startswith(pre)}
+        d["pattern"] = str(d["pattern"])
+        return d
+
+    def param_keys(self):
+        return sorted({k.split(".")[0] for k in self.params_raw})
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return Golden()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import orc
+    orc.build_oracle()
+    return orc.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    import orc
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference checkout not present (GPU box)")
+    orc.build_oracle(with_ref=True)
+    return orc.Reference()
+
+
+def bits_equal(x, y):
+    x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+    return x.shape == y.shape and np.array_equal(x.view(np.uint64), y.view(np.uint64))

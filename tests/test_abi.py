@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every symbol
+include/psmc_hip.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "psmc_amd", "csrc")], check=True)
+    from psmc_amd import hip
+    return hip.load_library()
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "psmc_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(psmc_hip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_exports_match_header(lib):
+    from psmc_amd import hip
+    names = declared_symbols()
+    assert names == sorted(hip.EXPORTS)
+    for nm in names:
+        assert hasattr(lib, nm), nm
+
+
+def test_no_silent_cpu_fallback(lib):
+    from psmc_amd import hip
+    if lib.psmc_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    assert lib.psmc_hip_create(C.byref(h), 64, 0, 0) < 0 and not h.value
+    with pytest.raises(hip.HipError):
+        hip.HipEStep(64)
+    assert lib.psmc_hip_strerror(-3).decode() == "HIP runtime error"
+
+
+def test_argument_validation(lib):
+    h = C.c_void_p()
+    assert lib.psmc_hip_create(C.byref(h), 0, 0, 0) == -1       # EINVAL
+    assert lib.psmc_hip_create(C.byref(h), 65, 0, 0) == -4      # ENOTSUP: > 64 states not in this build
+    assert lib.psmc_hip_create(C.byref(h), 64, 0, 7) == -1
+    assert lib.psmc_hip_create(None, 64, 0, 0) == -1
+
+
+def test_exact_kernels_have_no_fma():
+    """hipcc contracts a*b+c by default; the exact mode must never contain an FMA
+    outside the IEEE division expansion."""
+    out = "/tmp/psmc_exact_audit.s"
+    src = os.path.join(ROOT, "psmc_amd", "csrc", "estep_exact.hip")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, src],
+                   check=True, stderr=subprocess.DEVNULL)
+    txt = open(out).read()
+    n_div = len(re.findall(r"v_div_fmas_f64", txt))
+    n_fma = len(re.findall(r"\bv_fma_f64|\bv_fmac_f64", txt))
+    assert n_div > 0
+    # each IEEE f64 division expands to v_div_scale x2, v_rcp, 5-6 v_fma, v_div_fmas, v_div_fixup
+    assert n_fma <= 7 * n_div, (n_fma, n_div)
+    assert "v_mfma" not in txt and "v_pk_fma" not in txt

@@ -1,0 +1,40 @@
+"""The numpy specification of the fast-mode algorithm (tests/fastmodel.py)
+against the oracle: checks the algebra (lagged normalisation, shared divisors,
+per-tile posterior normalisation, a .* C factorisation) and documents how the
+error depends on the warm-up length W."""
+import numpy as np
+import pytest
+import fastmodel
+
+
+def relmax(x, y):
+    return float(np.abs(x - y).max() / np.abs(y).max())
+
+
+def test_untiled_matches_oracle(golden, oracle):
+    p = golden.params("n64_curve")
+    segs = golden.segs_small
+    ref = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    m = fastmodel.estep_fast_model(p["a"], p["e"], p["a0"], segs, T=1 << 30, W=0)
+    assert relmax(m["A"], ref["A"]) < 1e-12 and relmax(m["E"], ref["E"]) < 1e-12
+    assert abs(m["LL"] - ref["LL"]) < 1e-12 * abs(ref["LL"])
+
+
+@pytest.mark.parametrize("T,W,tol", [(1024, 4096, 1e-11), (4096, 4096, 1e-11), (512, 8192, 1e-12)])
+def test_tiled_matches_oracle(golden, oracle, T, W, tol):
+    p = golden.params("n64_curve")
+    segs = golden.segs_mid[2:]   # 20000, 12000, 5000, 800 bins
+    ref = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    m = fastmodel.estep_fast_model(p["a"], p["e"], p["a0"], segs, T=T, W=W)
+    assert relmax(m["A"], ref["A"]) < tol and relmax(m["E"], ref["E"]) < tol
+    assert abs(m["LL"] - ref["LL"]) < tol * abs(ref["LL"])
+
+
+def test_short_warmup_is_detectably_wrong(golden, oracle):
+    """W far below the forgetting length must NOT pass: this is what the runtime
+    warm-up check of the HIP path guards against."""
+    p = golden.params("n64_curve")
+    segs = golden.segs_mid[2:3]
+    ref = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    m = fastmodel.estep_fast_model(p["a"], p["e"], p["a0"], segs, T=1024, W=128)
+    assert relmax(m["A"], ref["A"]) > 1e-6

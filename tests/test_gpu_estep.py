@@ -1,0 +1,263 @@
+"""Parity tests proper: the HIP E-step (through the C-ABI of include/psmc_hip.h)
+against the golden vectors of the real reference and against the CPU oracle on
+the same seeded inputs.  Exact mode: bit for bit.  Fast mode: stated tolerances
+(statistics 1e-10 of the largest cell, LL 1e-12 relative)."""
+import os
+import subprocess
+import numpy as np
+import pytest
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FAST_TOL_STATS = 1e-10  # max |x - ref| / max |ref| over A, and over E
+FAST_TOL_LL = 1e-12     # relative
+
+
+@pytest.fixture(scope="module")
+def hip():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "psmc_amd", "csrc")], check=True)
+    from psmc_amd import hip as h
+    assert h.load_library().psmc_hip_device_count() > 0, "GPU tests need a visible HIP device"
+    return h
+
+
+def relmax(x, y):
+    return float(np.abs(np.asarray(x) - np.asarray(y)).max() / np.abs(np.asarray(y)).max())
+
+
+def random_hmm(rng, n):
+    a = rng.random((n, n)) ** 4 * 0.02 + np.eye(n) * (0.9 + 0.1 * rng.random(n))
+    a /= a.sum(1, keepdims=True)
+    e = np.ones((3, n)); e[1] = 0.001 + rng.random(n) * 0.15; e[0] = 1.0 - e[1]
+    a0 = rng.random(n) + 0.1; a0 /= a0.sum()
+    return a, e, a0
+
+
+def test_device_primitives(hip):
+    """row replication (ds_bpermute and v_permlane*_swap), row_newbcast DPP, ordered and tree
+    sums, exact / FMA dot products, f64 MFMA lane mapping -- all against plain LDS indexing."""
+    assert hip.selftest(0) == 0
+
+
+# ------------------------------------------------------------------ exact mode
+@pytest.mark.parametrize("rep", [1, 0])
+@pytest.mark.parametrize("key", ["n64_curve", "n64_flat", "n23_curve", "n23_flat"])
+def test_exact_small_golden(hip, golden, key, rep):
+    p = golden.params(key)
+    n = p["a"].shape[0]
+    es = hip.HipEStep(n, mode=hip.MODE_EXACT, rep_impl=rep)
+    es.load_segments(golden.segs_small)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    g = golden.small
+    assert bits_equal(r["A"], g[key + ".A"])
+    assert bits_equal(r["E"], g[key + ".E"])
+    assert bits_equal(r["A0"], g[key + ".A0"])
+    assert r["LL"] == float(g[key + ".LL"])
+    assert bits_equal(r["chk"], g[key + ".seg_chk"])
+    s = es.estep_segments(p["a"], p["e"], p["a0"])
+    assert bits_equal(s["seg_E"], g[key + ".seg_E"])
+    assert bits_equal(s["seg_LL"], g[key + ".seg_LL"])
+    assert bits_equal(s["seg_A"][[0, 5, 9]], g[key + ".seg_A_pick"])
+    assert bits_equal(s["seg_A"].sum(2), g[key + ".seg_A_rowsum"])
+    es.close()
+
+
+@pytest.mark.parametrize("key", ["n64_curve", "n23_flat"])
+def test_exact_tables_golden(hip, golden, key):
+    """hd->f, hd->b, hd->s of khmm.c:145-241 for a 65-bin segment."""
+    p = golden.params(key)
+    es = hip.HipEStep(p["a"].shape[0], mode=hip.MODE_EXACT)
+    es.load_segments(golden.segs_small)
+    es.estep(p["a"], p["e"], p["a0"])
+    f, b, s = es.tables(5)
+    g = golden.small
+    assert bits_equal(f, g[key + ".f65"][1:]) and bits_equal(b, g[key + ".b65"][1:]) and bits_equal(s, g[key + ".s65"][1:])
+    es.close()
+
+
+@pytest.mark.parametrize("key", ["n64_curve", "n64_flat"])
+def test_exact_mid_golden(hip, golden, key):
+    p = golden.params(key)
+    es = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    es.load_segments(golden.segs_mid)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    g = golden.mid
+    assert bits_equal(r["A"], g[key + ".A"]) and bits_equal(r["E"], g[key + ".E"])
+    assert r["LL"] == float(g[key + ".LL"])
+    assert bits_equal(r["chk"], g[key + ".seg_chk"])
+    es.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 23, 63, 64])
+def test_exact_vs_oracle_random(hip, oracle, n):
+    rng = np.random.default_rng(100 + n)
+    a, e, a0 = random_hmm(rng, n)
+    segs = [rng.choice(3, size=L, p=[0.86, 0.1, 0.04]).astype(np.uint8) for L in (1, 2, 63, 64, 65, 128, 129, 700, 5000)]
+    es = hip.HipEStep(n, mode=hip.MODE_EXACT)
+    es.load_segments(segs)
+    r = es.estep(a, e, a0)
+    o = oracle.estep(a, e, a0, segs, per_seg=True)
+    assert bits_equal(r["A"], o["A"]) and bits_equal(r["E"], o["E"]) and bits_equal(r["A0"], o["A0"])
+    assert r["LL"] == o["LL"]
+    assert bits_equal(r["chk"], o["seg_chk"])
+    es.close()
+
+
+def test_exact_bootstrap_selection(hip, golden, oracle):
+    """psmc_resamp-style multiset: repeated segments are added once per occurrence, in order."""
+    p = golden.params("n64_curve")
+    es = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    es.load_segments(golden.segs_small)
+    sel = [8, 3, 8, 10, 0, 3, 8]
+    es.select(sel)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    o = oracle.estep(p["a"], p["e"], p["a0"], [golden.segs_small[i] for i in sel])
+    assert bits_equal(r["A"], o["A"]) and bits_equal(r["E"], o["E"]) and r["LL"] == o["LL"]
+    es.close()
+
+
+def test_errors(hip):
+    es = hip.HipEStep(8, mode=hip.MODE_EXACT)
+    a, e, a0 = random_hmm(np.random.default_rng(0), 8)
+    with pytest.raises(hip.HipError):
+        es.estep(a, e, a0)                       # no segments loaded
+    with pytest.raises(hip.HipError):
+        es.load_segments([np.zeros(0, np.uint8)])  # empty segment (UB in the reference, rejected here)
+    with pytest.raises(hip.HipError):
+        es.load_segments([np.array([0, 3], np.uint8)])
+    es.load_segments([np.array([0, 1, 2], np.uint8)])
+    with pytest.raises(hip.HipError):
+        es.select([1])
+    with pytest.raises(hip.HipError):
+        hip.HipEStep(65)
+    es.close()
+
+
+# ------------------------------------------------------------------ fast mode
+def check_fast(r, o):
+    assert relmax(r["A"], o["A"]) < FAST_TOL_STATS, relmax(r["A"], o["A"])
+    assert relmax(r["E"], o["E"]) < FAST_TOL_STATS, relmax(r["E"], o["E"])
+    assert abs(r["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"]), (r["LL"], o["LL"])
+
+
+@pytest.mark.parametrize("expect_impl", [1, 0])
+@pytest.mark.parametrize("key", ["n64_curve", "n64_flat", "n23_curve"])
+def test_fast_small_golden(hip, golden, key, expect_impl):
+    p = golden.params(key)
+    es = hip.HipEStep(p["a"].shape[0], mode=hip.MODE_FAST, expect_impl=expect_impl)
+    es.load_segments(golden.segs_small)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    g = golden.small
+    check_fast(r, dict(A=g[key + ".A"], E=g[key + ".E"], LL=float(g[key + ".LL"])))
+    es.close()
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=1024), dict(chunk=256, n_sub=1), dict(chunk=4096, rep_impl=0),
+                                  dict(chunk=2048, expect_impl=0)])
+def test_fast_mid_golden(hip, golden, opts):
+    key = "n64_curve"
+    p = golden.params(key)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
+    es.load_segments(golden.segs_mid)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    g = golden.mid
+    check_fast(r, dict(A=g[key + ".A"], E=g[key + ".E"], LL=float(g[key + ".LL"])))
+    d = es.fast_diag()
+    assert d["warm_err_fwd"] <= 1e-10 and d["warm_err_bwd"] <= 1e-10
+    es.close()
+
+
+def test_fast_warmup_escalates(hip, golden):
+    """A warm-up far below the chain's memory is detected by the tile-boundary check and widened."""
+    key = "n64_curve"
+    p = golden.params(key)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=1024, warmup=64)
+    es.load_segments(golden.segs_mid)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    d = es.fast_diag()
+    assert d["warmup"] > 64
+    g = golden.mid
+    check_fast(r, dict(A=g[key + ".A"], E=g[key + ".E"], LL=float(g[key + ".LL"])))
+    es.close()
+
+
+def test_fast_deterministic_and_selection(hip, golden, oracle):
+    p = golden.params("n64_curve")
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=512)
+    es.load_segments(golden.segs_mid)
+    r1 = es.estep(p["a"], p["e"], p["a0"])
+    r2 = es.estep(p["a"], p["e"], p["a0"])
+    assert bits_equal(r1["A"], r2["A"]) and bits_equal(r1["E"], r2["E"]) and r1["LL"] == r2["LL"]
+    sel = [5, 4, 5, 3, 5]
+    es.select(sel)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    o = oracle.estep(p["a"], p["e"], p["a0"], [golden.segs_mid[i] for i in sel])
+    check_fast(r, o)
+    es.close()
+
+
+@pytest.mark.parametrize("n", [2, 23, 64])
+def test_fast_vs_oracle_random(hip, oracle, n):
+    rng = np.random.default_rng(200 + n)
+    a, e, a0 = random_hmm(rng, n)
+    segs = [rng.choice(3, size=L, p=[0.86, 0.1, 0.04]).astype(np.uint8) for L in (1, 2, 3, 64, 65, 700, 30000)]
+    es = hip.HipEStep(n, mode=hip.MODE_FAST, chunk=1024)
+    es.load_segments(segs)
+    r = es.estep(a, e, a0)
+    o = oracle.estep(a, e, a0, segs)
+    check_fast(r, o)
+    es.close()
+
+
+def test_fast_full_size_properties(hip, golden):
+    """Size-independent invariants on a genome-sized batch (no oracle at this size):
+    sum A = sum_seg (L-1); sum E = number of non-missing positions among 1..L-1;
+    additivity over disjoint segment sets; fast and exact agree on a subset."""
+    from psmc_amd import sim
+    p = golden.params("n64_curve")
+    lens = sim.human_like_lengths(3_000_000, n_seg=40)
+    segs = sim.simulate_genome(p["a"], p["e"], p["a0"], lens, seed=11)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST)
+    es.load_segments(segs)
+    r = es.estep(p["a"], p["e"], p["a0"])
+    tot = float(sum(len(s) - 1 for s in segs))
+    nonmiss = float(sum(int((s[:-1] != 2).sum()) for s in segs))
+    assert abs(r["A"].sum() - tot) < 1e-9 * tot
+    assert abs(r["E"].sum() - nonmiss) < 1e-9 * nonmiss
+    half = list(range(0, len(segs), 2)); other = list(range(1, len(segs), 2))
+    es.select(half); ra = es.estep(p["a"], p["e"], p["a0"])
+    es.select(other); rb = es.estep(p["a"], p["e"], p["a0"])
+    assert relmax(ra["A"] + rb["A"], r["A"]) < 1e-11 and abs(ra["LL"] + rb["LL"] - r["LL"]) < 1e-11 * abs(r["LL"])
+    ex = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    sub = [segs[i] for i in (len(segs) - 1, len(segs) - 2, 20)]
+    ex.load_segments(sub)
+    rx = ex.estep(p["a"], p["e"], p["a0"])
+    es.select([len(segs) - 1, len(segs) - 2, 20]); rf = es.estep(p["a"], p["e"], p["a0"])
+    check_fast(rf, rx)
+    es.close(); ex.close()
+
+
+def test_fast_device_resident_io(hip, golden):
+    """Observations and result both resident in HBM (torch only provides the memory and the stream)."""
+    import torch
+    p = golden.params("n64_curve")
+    segs = golden.segs_mid
+    lens = np.array([len(s) for s in segs], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum((lens.astype(np.int64) + 63) // 64 * 64)])
+    host = np.full(int(off[-1]) + 256, 2, dtype=np.uint8)
+    for s, o in zip(segs, off[:-1]):
+        host[o:o + len(s)] = s
+    d_obs = torch.from_numpy(host).cuda()
+    es = hip.HipEStep(64, mode=hip.MODE_FAST)
+    es.load_segments_device(d_obs.data_ptr(), off[:-1], lens, keepalive=d_obs)
+    stats = torch.zeros(64 * 64 + 2 * 64 + 1, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream()
+    es.estep_device(p["a"], p["e"], p["a0"], stats.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    h = stats.cpu().numpy()
+    g = golden.mid
+    check_fast(dict(A=h[:4096].reshape(64, 64), E=h[4096:4224].reshape(2, 64), LL=h[4224]),
+               dict(A=g["n64_curve.A"], E=g["n64_curve.E"], LL=float(g["n64_curve.LL"])))
+    es.close()

@@ -1,0 +1,80 @@
+"""The CPU oracle (oracle/psmc_oracle.c) against the golden vectors dumped from
+the real reference, bit for bit, and against the reference itself when its
+checkout is present.  Pins the oracle."""
+import numpy as np
+import pytest
+from conftest import bits_equal
+
+
+@pytest.mark.parametrize("key", ["n64_flat", "n64_curve", "n23_flat", "n23_curve"])
+def test_estep_small_bitexact(golden, oracle, key):
+    p = golden.params(key)
+    r = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_small, per_seg=True)
+    g = golden.small
+    assert bits_equal(r["A"], g[key + ".A"])
+    assert bits_equal(r["E"], g[key + ".E"])
+    assert bits_equal(r["A0"], g[key + ".A0"])
+    assert r["LL"] == float(g[key + ".LL"])
+    assert bits_equal(r["seg_E"], g[key + ".seg_E"])
+    assert bits_equal(r["seg_LL"], g[key + ".seg_LL"])
+    assert bits_equal(r["seg_chk"], g[key + ".seg_chk"])
+    assert bits_equal(r["seg_A"][[0, 5, 9]], g[key + ".seg_A_pick"])
+    assert bits_equal(r["seg_A"].sum(2), g[key + ".seg_A_rowsum"])
+
+
+@pytest.mark.parametrize("key", ["n64_curve", "n23_flat"])
+def test_tables_bitexact(golden, oracle, key):
+    p = golden.params(key)
+    f, b, s, lk, chk = oracle.fwd_bwd(p["a"], p["e"], p["a0"], golden.segs_small[5])
+    g = golden.small
+    assert bits_equal(f, g[key + ".f65"]) and bits_equal(b, g[key + ".b65"]) and bits_equal(s, g[key + ".s65"])
+    assert lk == float(g[key + ".lk65"])
+
+
+@pytest.mark.parametrize("key", ["n64_flat", "n64_curve"])
+def test_estep_mid_bitexact(golden, oracle, key):
+    p = golden.params(key)
+    r = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid, per_seg=True)
+    g = golden.mid
+    assert bits_equal(r["A"], g[key + ".A"]) and bits_equal(r["E"], g[key + ".E"])
+    assert r["LL"] == float(g[key + ".LL"])
+    assert bits_equal(r["seg_LL"], g[key + ".seg_LL"]) and bits_equal(r["seg_chk"], g[key + ".seg_chk"])
+
+
+def test_invariants(golden, oracle):
+    """sum A = sum E = L-1 per segment (+ the HMM_TINY seeds); posterior sums to 1."""
+    p = golden.params("n64_curve")
+    r = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_small, per_seg=True)
+    for i, seg in enumerate(golden.segs_small):
+        L = len(seg)
+        assert abs(r["seg_A"][i].sum() - (L - 1)) < 1e-8 * max(L, 1) + 1e-20
+        assert abs(r["seg_E"][i].sum() - (L - 1)) < 1e-8 * max(L, 1) + 1e-20
+        assert abs(r["seg_chk"][i] - 1.0) < 1e-9
+    f, b, s, lk, chk = oracle.fwd_bwd(p["a"], p["e"], p["a0"], golden.segs_small[8])
+    post = f[1:] * b[1:] * s[1:, None]
+    assert np.allclose(post.sum(1), 1.0, atol=1e-10)
+
+
+def test_Q_functions(golden, oracle):
+    """hmm_Q0/hmm_Q (khmm.c:326-382) against the reference's EM round: Q0 printed by psmc_em is
+    hmm_Q at the current parameters."""
+    p = golden.params("n64_flat")
+    g = golden.mid
+    A, E = g["n64_flat.A"], g["n64_flat.E"]
+    q0 = oracle.Q0(A, E)
+    q = oracle.Q(p["a"], p["e"], A, E, q0)
+    assert q == float(g["em_n64_flat.Q0"])
+
+
+def test_oracle_vs_reference_random(reference, oracle):
+    rng = np.random.default_rng(5)
+    for n in (3, 23, 64):
+        a = rng.random((n, n)) ** 3 + np.eye(n) * 5
+        a /= a.sum(1, keepdims=True)
+        e = np.ones((3, n)); e[1] = rng.random(n) * 0.2; e[0] = 1 - e[1]
+        a0 = rng.random(n); a0 /= a0.sum()
+        segs = [rng.choice(3, size=L, p=[0.85, 0.1, 0.05]).astype(np.uint8) for L in (1, 2, 17, 500, 3000)]
+        ro = oracle.estep(a, e, a0, segs, per_seg=True)
+        rr = reference.estep(a, e, a0, segs, per_seg=True)
+        for k in ro:
+            assert bits_equal(np.asarray(ro[k]), np.asarray(rr[k])), (n, k)

@@ -179,8 +179,10 @@ def main():
                                    "per GPU, -p 4+25*2+4+6, one E-step (EM iteration) per step" % (bins, N_STATES, len(segs)),
                        "mode": args.mode, "bins_per_gpu": bins, "n_states": N_STATES, "segments": len(segs),
                        "sharding": "segments/GPU + 1 RCCL all-reduce(%d f64)/step" % stats.numel() if world > 1 else "single GPU",
-                       **({"tiles": diag.get("n_chunks"), "tile_warmup_bins": diag.get("warmup"),
-                           "warm_err": max(diag.get("warm_err_fwd", 0), diag.get("warm_err_bwd", 0))} if diag else {})},
+                       **({"tiles": diag.get("n_chunks"), "speculative_overlap_bins": diag.get("warmup"),
+                           "repair_rounds": [diag.get("fwd_rounds"), diag.get("bwd_rounds")],
+                           "repaired_tiles": [diag.get("fwd_tiles"), diag.get("bwd_tiles")],
+                           "boundary_err": max(diag.get("warm_err_fwd", 0), diag.get("warm_err_bwd", 0))} if diag else {})},
             "roofline": {"bound": "hbm", "kernel": "k_%s_%s" % ({"forward": "fwd", "backward": "bwd", "expect": "expect"}[dom], args.mode),
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None,

@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define PSMC_HIP_MODE_EXACT 0 /* bit-identical to khmm.c (ordered sums, no FMA) */
-#define PSMC_HIP_MODE_FAST  1 /* chunked sweeps, FMA, tree reductions; stats within 1e-10 */
+#define PSMC_HIP_MODE_FAST  1 /* tiled speculative sweeps, FMA/MFMA, tree reductions; stats within 1e-10 */
 
 #define PSMC_HIP_OK        0
 #define PSMC_HIP_EINVAL   -1 /* bad argument (NULL, n out of range, empty segment ...) */
@@ -33,7 +33,7 @@ extern "C" {
 #define PSMC_HIP_EDEVICE  -3 /* HIP runtime error; see psmc_hip_last_error() */
 #define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (e.g. n > 64) */
 #define PSMC_HIP_ESTATE   -5 /* call order violated (no segments loaded ...) */
-#define PSMC_HIP_ECONVERGE -6 /* fast mode: warm-up did not converge within limits */
+#define PSMC_HIP_ECONVERGE -6 /* fast mode: tile boundaries did not converge within max_rounds */
 
 typedef struct psmc_hip_ctx psmc_hip_ctx;
 
@@ -46,10 +46,11 @@ void psmc_hip_destroy(psmc_hip_ctx *ctx);
 const char *psmc_hip_strerror(int err);
 const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 
-/* Tunables (all optional): "chunk" (fast-mode tile length in bins),
- * "warmup" (fast-mode overlap in bins), "warm_tol", "rep_impl" (0 ds_bpermute,
- * 1 v_permlane*_swap), "expect_impl" (0 VALU, 1 MFMA f64), "keep_fb" (exact
- * mode always keeps f/b/s; fast mode keeps its scaled f). */
+/* Tunables (all optional): "chunk" (fast-mode tile length in bins, 0 = auto),
+ * "warmup" (speculative overlap in bins), "warm_tol" (tile-boundary agreement
+ * demanded by verify/repair), "max_rounds", "target_waves", "n_sub" (expect
+ * waves per tile), "rep_impl" (0 ds_bpermute, 1 v_permlane*_swap),
+ * "expect_impl" (0 VALU, 1 MFMA f64). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
@@ -84,11 +85,15 @@ int psmc_hip_estep_segments(psmc_hip_ctx *ctx, const double *a, const double *e,
  * synchronises the stream (or hands d_stats to RCCL on the same stream). */
 int psmc_hip_estep_device(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, void *d_stats,
                           void *stream);
-/* After the stream has drained: fast-mode diagnostics of the last E-step.
- * warm_err[0/1] = largest relative mismatch between a tile's warmed-up entry
- * vector and its neighbour's converged one (forward / backward). */
+/* Fast-mode diagnostics of the last E-step.  warm_err_fwd/bwd = largest
+ * relative mismatch left between the vector a tile built on at its boundary and
+ * the value its neighbour computed (after the last verify round: <= warm_tol);
+ * warmup_used = speculative overlap in bins. */
 int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err_bwd, int *n_chunks,
                        int *warmup_used);
+/* How much repair the speculation needed: verify/repair rounds and the total
+ * number of tile re-runs, forward and backward; out[0..3]. */
+int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
 
 /* Copies the forward/backward tables of one loaded segment to the host after
  * an E-step (replaces reading hd->f, hd->b, hd->s: aux.c:159-200).  f,b: L*n,

@@ -21,8 +21,8 @@ struct psmc_hip_ctx {
 	int n = 0, device = 0, mode = PSMC_HIP_MODE_EXACT;
 	std::string err;
 	// options
-	int chunk = 0, warmup = 4096, max_warmup = 1 << 17, rep_impl = 1, expect_impl = 1, n_sub = 4, target_waves = 2048;
-	double warm_tol = 1e-10;
+	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 4, target_waves = 2048;
+	double warm_tol = 1e-12;
 	// segments
 	int n_seg = 0;
 	std::vector<int32_t> L;
@@ -43,7 +43,7 @@ struct psmc_hip_ctx {
 	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0
 	static constexpr size_t PAR_LEN = 4096 + 3 * 4096 + 3 * 64 + 64;
 	// tables
-	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr;
+	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr, *d_d = nullptr;
 	int64_t tab_bins = 0; bool have_b = false;
 	// exact outputs
 	double *d_segA = nullptr, *d_segE = nullptr, *d_segA0 = nullptr, *d_chk = nullptr;
@@ -53,7 +53,10 @@ struct psmc_hip_ctx {
 	std::vector<Chunk> chunks;
 	Chunk *d_chunks = nullptr;
 	int chunk_cap = 0, chunk_used = 0;
-	double *d_entry = nullptr, *d_bexit = nullptr, *d_Cpart = nullptr, *d_Epart = nullptr, *d_LLpart = nullptr;
+	double *d_entry = nullptr, *d_bentry = nullptr, *d_bexit = nullptr, *d_Cpart = nullptr, *d_Epart = nullptr,
+	       *d_LLpart = nullptr;
+	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr;
+	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
 	unsigned long long *d_warm = nullptr;
 	double warm_err[2] = {0, 0};
@@ -103,7 +106,7 @@ extern "C" const char *psmc_hip_strerror(int err)
 	case PSMC_HIP_EDEVICE: return "HIP runtime error";
 	case PSMC_HIP_ENOTSUP: return "not supported in this build";
 	case PSMC_HIP_ESTATE: return "call order violated";
-	case PSMC_HIP_ECONVERGE: return "fast-mode warm-up did not converge";
+	case PSMC_HIP_ECONVERGE: return "fast-mode tile boundaries did not converge";
 	default: return "unknown error";
 	}
 }
@@ -142,9 +145,10 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_d, c->d_bentry, c->d_dirty, c->d_cnt};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
+	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -155,8 +159,8 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	if (!c || !key) return PSMC_HIP_EINVAL;
 	std::string k(key);
 	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
-	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; }
-	else if (k == "max_warmup") c->max_warmup = (int)v;
+	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
+	else if (k == "max_rounds") c->max_rounds = (int)v;
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
 	else if (k == "expect_impl") c->expect_impl = v != 0 ? 1 : 0;
@@ -272,6 +276,7 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b)
 		int rc;
 		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) return rc;
+		if (c->mode == PSMC_HIP_MODE_FAST && (rc = dev_alloc(c, &c->d_d, (size_t)bins))) return rc;
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
 		c->have_b = false;
 		c->tab_bins = bins;
@@ -292,7 +297,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
-	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s;
+	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s; p.d_d = c->d_d;
 	for (int i = 0; i < 5; ++i) p.ev[i] = c->ev[i];
 }
 
@@ -421,6 +426,10 @@ static int plan_fast(psmc_hip_ctx *c)
 		for (int32_t lo = 1; lo <= c->L[s]; lo += T) {
 			Chunk ch;
 			ch.off = c->off[s]; ch.L = c->L[s]; ch.lo = lo; ch.hi = std::min(c->L[s], lo + T - 1); ch.mult = c->mult[w];
+			ch.flags = 0; ch.pad_ = 0;
+			if (ch.lo - c->warmup <= 1) ch.flags |= CHUNK_ANCHOR_F;
+			if ((int64_t)ch.hi + c->warmup + 1 >= ch.L) ch.flags |= CHUNK_ANCHOR_B;
+			if (ch.hi == ch.L) ch.flags |= CHUNK_LAST;
 			c->chunks.push_back(ch);
 		}
 	}
@@ -431,16 +440,21 @@ static int plan_fast(psmc_hip_ctx *c)
 	if (nc > c->chunk_cap) {
 		if ((rc = dev_alloc(c, &c->d_chunks, (size_t)nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_entry, (size_t)nc * 64))) return rc;
-		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)nc * 64))) return rc;
-		if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * 192))) return rc;
+		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)(nc + 1) * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_bentry, (size_t)nc * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
 		c->chunk_cap = nc;
 	}
 	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub * 4096))) return rc;
+	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub * 192))) return rc;
 	if (!c->d_stage) {
 		if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * STATS_LEN))) return rc;
 		if ((rc = dev_alloc(c, &c->d_stats, (size_t)STATS_LEN))) return rc;
 		if ((rc = dev_alloc(c, &c->d_warm, (size_t)2))) return rc;
+		if ((rc = dev_alloc(c, &c->d_cnt, (size_t)4))) return rc;
+		if (hipHostMalloc((void **)&c->h_cnt, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
 	}
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
 	c->plan_dirty = false;
@@ -459,10 +473,12 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	EstepLaunch p;
 	fill_common(c, p, st);
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub;
-	p.d_entry = c->d_entry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
+	p.d_entry = c->d_entry; p.d_bentry = c->d_bentry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
+	p.d_dirty = c->d_dirty; p.d_cnt = c->d_cnt; p.h_cnt = c->h_cnt; p.tol = c->warm_tol; p.max_rounds = c->max_rounds;
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
-	if (launch_fast(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
+	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
+	if (!c->report.converged) return fail(c, PSMC_HIP_ECONVERGE, "fast mode: tile boundaries did not converge within max_rounds");
 	return 0;
 }
 
@@ -499,20 +515,22 @@ extern "C" int psmc_hip_fast_diag(psmc_hip_ctx *c, double *wf, double *wb, int *
 	return PSMC_HIP_OK;
 }
 
+extern "C" int psmc_hip_fast_repairs(psmc_hip_ctx *c, int out[4])
+{
+	if (!c || !out) return PSMC_HIP_EINVAL;
+	out[0] = c->report.fwd_rounds; out[1] = c->report.bwd_rounds;
+	out[2] = c->report.fwd_tiles; out[3] = c->report.bwd_tiles;
+	return PSMC_HIP_OK;
+}
+
 static int estep_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *A, double *E,
                       double *A0, double *LL, double *chk)
 {
 	const int n = c->n;
-	for (;;) {
-		int rc = enqueue_fast(c, a, e, a0, c->d_stats ? c->d_stats : nullptr, c->stream);
-		if (rc) return rc;
-		if ((rc = read_warm(c, c->stream))) return rc;
-		collect_timing(c);
-		const double worst = std::max(c->warm_err[0], c->warm_err[1]);
-		if (worst <= c->warm_tol || !(worst == worst)) break;
-		if (c->warmup >= c->max_warmup) return fail(c, PSMC_HIP_ECONVERGE, "fast-mode warm-up did not converge");
-		c->warmup = std::max(64, c->warmup * 2); // the chain forgets more slowly than assumed: widen and redo
-	}
+	int rc = enqueue_fast(c, a, e, a0, c->d_stats, c->stream);
+	if (rc) return rc;
+	if ((rc = read_warm(c, c->stream))) return rc;
+	collect_timing(c);
 	std::vector<double> h((size_t)n * n + 2 * n + 1);
 	HIPCHK(c, hipMemcpy(h.data(), c->d_stats, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
 	if (A) memcpy(A, h.data(), sizeof(double) * n * n);

@@ -2,25 +2,30 @@
 //
 // Same mathematics as khmm.c's hmm_forward / hmm_backward / hmm_expect
 // (lh3/psmc khmm.c:145-190, 210-241, 297-324) but re-associated for the GPU:
-//   * every segment is cut into tiles of `chunk` bins; a tile's sweep starts
-//     `warmup` bins outside the tile from an arbitrary vector (the chain forgets
-//     its start), so all tiles of all segments run concurrently, one wavefront
-//     per tile, lane = hidden state;
+//   * every segment is cut into tiles of `chunk` bins, one wavefront per tile,
+//     lane = hidden state.  A tile SPECULATES: its sweep starts `warmup` bins
+//     outside the tile from an arbitrary vector.  A VERIFY kernel compares the
+//     vector each tile used at its boundary with the value its neighbour
+//     computed with a whole tile of history behind it; only tiles whose
+//     mismatch exceeds `warm_tol` are REPAIRED: re-run from the neighbour's
+//     value until the new trajectory meets the stored one again.  (The chain
+//     forgets its start in ~2-4 k bins almost everywhere but needs >60 k bins
+//     in long runs of recent-coalescence states, so a fixed overlap is either
+//     wrong or 5x redundant.)
 //   * the 64-term dot products are 64 v_fmac_f64_dpp (row_newbcast operand
-//     broadcast, transition column/row held in 128 VGPRs per lane);
-//   * lagged normalisation: X_p = e[o_p]*(a^T X_{p-1}) / d_p with
-//     d_p = sum(X_{p-1}), which takes the cross-lane reduction off the
-//     sequential critical path; sum(X_p) is then the reference's s_p and
-//     LL = sum_p log(sum X_p);
-//   * backward uses the same divisors, B_p = a(e[o_{p+1}]*B_{p+1}) / d_p, and is
-//     renormalised once per tile so that the posterior sums to one;
-//   * A = a .* sum_p X_p (x) (e[o_{p+1}]*B_{p+1}) is a K=bins GEMM: it runs on
-//     the FP64 matrix cores (v_mfma_f64_16x16x4_f64) or, as a cross-check, on
-//     the VALU; per-wave partials are reduced in a fixed order (deterministic,
-//     no atomics).
+//     broadcast; the transition column/row lives in 128 VGPRs per lane);
+//   * lagged normalisation: X_p = e[o_p]*(a^T X_{p-1}) / d_p, d_p = sum(X_{p-1}):
+//     the cross-lane reduction is off the sequential critical path; sum(X_p) is
+//     the reference's s_p and LL = sum_{p>=2} log d_p + log sum(X_L);
+//   * backward shares the divisors, B_p = a(e[o_{p+1}]*B_{p+1}) / d_p, stored as
+//     bt_p = e[o_p]*B_p, normalised once per tile so the posterior sums to one;
+//   * counts from the stored tables: C = sum_p X_p (x) bt_{p+1} is a K=bins GEMM
+//     on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), A = a .* C;
+//     S[o_p] += d_p X_p bt_p, E = S / e.  Per-wave partials are reduced in a fixed
+//     order (deterministic, no atomics on the statistics).
 // tests/fastmodel.py is the executable numpy specification of this file.
-// HBM layout: X[g*64+k] (d_f), bt[g*64+k] = e[o_p]*B_p (d_b), inv_d[g] (d_s),
-// g = seg_off + p - 1.
+// HBM layout (g = seg_off + p - 1): X[g*64+k] (d_f), bt[g*64+k] (d_b),
+// inv_d[g] (d_s), d[g] (d_d), obs[g].
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
 #include "psmc_hip_internal.h"
@@ -48,68 +53,31 @@ __device__ __forceinline__ double wave_max(double v) {
 	for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
 	return v;
 }
-
-// ------------------------------------------------------------------ forward
-template <int REP>
-__global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, const double *__restrict__ e,
-                                                   const double *__restrict__ a0, const uint8_t *__restrict__ obs,
-                                                   const Chunk *__restrict__ chunks, int W, double *__restrict__ f,
-                                                   double *__restrict__ invd, double *__restrict__ entry,
-                                                   double *__restrict__ LLpart)
-{
-	const int lane = threadIdx.x;
-	const Chunk c = chunks[blockIdx.x];
-	const uint8_t *o = obs + c.off;
-	double *fo = f + c.off * 64, *io = invd + c.off;
-	double col[64];
+__device__ __forceinline__ double wave_add(double v) {
 #pragma unroll
-	for (int l = 0; l < 64; ++l) col[l] = a[l * 64 + lane];
-	const double e0 = e[lane], e1 = e[64 + lane];
-	const int ws = max(1, c.lo - W);
-	double x, prod = 1.0, ll = 0.0;
-	int p;
-	if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
-		x = a0[lane] * pick_ef((int)o[0], e0, e1);
-		if (c.lo == 1) { fo[lane] = x; if (lane == 0) io[0] = 1.0; }
-		p = 2;
-	} else { // warm-up from the stationary prior
-		x = a0[lane];
-		p = ws;
-	}
-	int blk = (p - 1) >> 6;
-	int symv = o[(blk << 6) + lane], symn = o[((blk + 1) << 6) + lane];
-	for (; p <= c.hi; ++p) {
-		const int idx = p - 1;
-		if ((idx >> 6) != blk) { blk = idx >> 6; symv = symn; symn = o[((blk + 1) << 6) + lane]; }
-		const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
-		double r[4];
-		rep_rows<REP>(x, r);
-		dpp_guard(r);
-		if (p == c.lo) entry[(int64_t)blockIdx.x * 64 + lane] = x; // X_{lo-1} as warmed up here
-		const double sig = wave_sum_rep(r); // = s_{p-1} of the reference
-		const double inv = fast_rcp(sig);
-		if (p - 1 >= c.lo) {
-			prod *= sig;
-			if (prod < 1e-280) { ll += log(prod); prod = 1.0; }
-		}
-		const double acc = fdot64(r, col);
-		x = acc * (pick_ef(sym, e0, e1) * inv);
-		if (p >= c.lo) {
-			fo[(int64_t)idx * 64 + lane] = x;
-			if (lane == 0) io[idx] = inv;
-		}
-	}
-	{ // s_hi
-		double r[4];
-		rep_rows<REP>(x, r);
-		prod *= wave_sum_rep(r);
-		ll += log(prod);
-	}
-	if (lane == 0) LLpart[blockIdx.x] = ll * (double)c.mult;
+	for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+	return v;
+}
+// max_k |x-y| / max_k |y|  (NaN-safe: a NaN anywhere yields +inf)
+__device__ __forceinline__ double rel_mismatch(double x, double y) {
+	const double num = wave_max(fabs(x - y)), den = wave_max(fabs(y));
+	const bool bad = __any((x != x) || (y != y));
+	return bad ? __builtin_inf() : num / den;
 }
 
-// ------------------------------------------------------------------ backward
-// cached (symbol, inv_d) for descending bin indices, one coalesced load per 64
+// cached symbols for ascending / (symbol, inv_d) for descending bin indices:
+// one coalesced 64-wide load per 64 steps, prefetched one block ahead
+struct UpSyms {
+	const uint8_t *o; int lane, blk, symv, symn;
+	__device__ __forceinline__ void init(const uint8_t *o_, int lane_, int idx) {
+		o = o_; lane = lane_; blk = idx >> 6;
+		symv = o[(blk << 6) + lane]; symn = o[((blk + 1) << 6) + lane];
+	}
+	__device__ __forceinline__ int get(int idx) {
+		if ((idx >> 6) != blk) { blk = idx >> 6; symv = symn; symn = o[((blk + 1) << 6) + lane]; }
+		return __builtin_amdgcn_readlane(symv, idx & 63);
+	}
+};
 struct DownStream {
 	const uint8_t *o; const double *io; int lane, blk, symv, symn; double invv, invn;
 	__device__ __forceinline__ void fetch(int b, int &sv, double &iv) const {
@@ -127,77 +95,174 @@ struct DownStream {
 	__device__ __forceinline__ double inv(int idx) const { return readlane_f64(invv, idx & 63); }
 };
 
-template <int REP>
+// ------------------------------------------------------------------ forward
+// REPAIR=false: speculative pass over every tile.  REPAIR=true: only tiles the
+// verify kernel flagged; starts from the neighbour's stored X_{lo-1} and stops
+// as soon as the new trajectory meets the stored one (checked every 16 bins).
+template <int REP, bool REPAIR>
+__global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, const double *__restrict__ e,
+                                                   const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                   const Chunk *__restrict__ chunks, int W, double tol,
+                                                   const int *__restrict__ dirty, double *__restrict__ f,
+                                                   double *__restrict__ invd, double *__restrict__ dd,
+                                                   double *__restrict__ entry)
+{
+	if (REPAIR && !dirty[blockIdx.x]) return;
+	const int lane = threadIdx.x;
+	const Chunk c = chunks[blockIdx.x];
+	const uint8_t *o = obs + c.off;
+	double *fo = f + c.off * 64, *io = invd + c.off, *dof = dd + c.off;
+	double col[64];
+#pragma unroll
+	for (int l = 0; l < 64; ++l) col[l] = a[l * 64 + lane];
+	const double e0 = e[lane], e1 = e[64 + lane];
+	double x;
+	int p;
+	if (REPAIR) { // c.lo >= 2 for every flagged tile
+		x = fo[(int64_t)(c.lo - 2) * 64 + lane];
+		p = c.lo;
+	} else {
+		const int ws = max(1, c.lo - W);
+		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
+			x = a0[lane] * pick_ef((int)o[0], e0, e1);
+			if (c.lo == 1) { fo[lane] = x; if (lane == 0) { io[0] = 1.0; dof[0] = 1.0; } }
+			p = 2;
+		} else { // warm-up from the stationary prior
+			x = a0[lane];
+			p = ws;
+		}
+	}
+	UpSyms us;
+	us.init(o, lane, p - 1);
+	double oldv = 0.0;
+	for (; p <= c.hi; ++p) {
+		const int idx = p - 1;
+		const int sym = us.get(idx);
+		if (p == c.lo) entry[(int64_t)blockIdx.x * 64 + lane] = x; // the X_{lo-1} this tile builds on
+		if (REPAIR && ((p - c.lo) & 15) == 0) // value currently stored at the end of this 16-bin block
+			oldv = fo[(int64_t)(min(p + 15, c.hi) - 1) * 64 + lane];
+		double r[4];
+		rep_rows<REP>(x, r);
+		dpp_guard(r);
+		const double sig = wave_sum_rep(r); // = s_{p-1} of the reference
+		const double inv = fast_rcp(sig);
+		const double acc = fdot64(r, col);
+		x = acc * (pick_ef(sym, e0, e1) * inv);
+		if (p >= c.lo) {
+			fo[(int64_t)idx * 64 + lane] = x;
+			if (lane == 0) { io[idx] = inv; dof[idx] = sig; }
+			if (REPAIR && (((p - c.lo) & 15) == 15 || p == c.hi)) {
+				if (rel_mismatch(x, oldv) <= tol) break; // met the stored trajectory: the rest is already right
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------ backward
+template <int REP, bool REPAIR>
 __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, const double *__restrict__ e,
                                                    const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
-                                                   int W, const double *__restrict__ f, const double *__restrict__ invd,
-                                                   double *__restrict__ bt, double *__restrict__ bexit,
-                                                   double *__restrict__ Epart)
+                                                   int W, double tol, const int *__restrict__ dirty,
+                                                   const double *__restrict__ f, const double *__restrict__ invd,
+                                                   double *__restrict__ bt, double *__restrict__ bentry,
+                                                   double *__restrict__ bexit)
 {
+	if (REPAIR && !dirty[blockIdx.x]) return;
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x];
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
-	double E0 = 0.0, E1 = 0.0, E2 = 0.0;
-	if (top >= lo) {
-		const uint8_t *o = obs + c.off;
-		const double *fo = f + c.off * 64, *io = invd + c.off;
-		double *bto = bt + c.off * 64;
-		double row[64]; // a[k][l], k = lane
+	if (top < lo) return; // a tile holding only position L owns no transition
+	const uint8_t *o = obs + c.off;
+	const double *fo = f + c.off * 64, *io = invd + c.off;
+	double *bto = bt + c.off * 64;
+	double row[64]; // a[k][l], k = lane
 #pragma unroll
-		for (int l = 0; l < 64; ++l) row[l] = aT[l * 64 + lane];
-		const double e0 = e[lane], e1 = e[64 + lane];
-		const int q = min(c.hi + W + 1, L);                // B_q := 1
-		double btn = pick_ef((int)o[q - 1], e0, e1);       // e[o_q] * B_q, natural layout
-		DownStream ds;
-		ds.init(o, io, lane, q - 2);
-
-		// X rows of the owned positions, prefetched four steps ahead through x0..x3
-		auto ldx = [&](int pp) -> double {
-			return (pp <= top && pp >= lo) ? fo[(int64_t)(pp - 1) * 64 + lane] : 0.0;
-		};
-		int p = q - 1;
-		double x0 = ldx(p), x1 = ldx(p - 1), x2 = ldx(p - 2), x3 = ldx(p - 3);
-		// one step: consumes btn = e[o_{p+1}]*B_{p+1}, produces btn = e[o_p]*B_p
-		for (; p >= lo; --p) {
-			const double Xp = x0;
-			x0 = x1; x1 = x2; x2 = x3; x3 = ldx(p - 4);
-			const int idx = p - 1;
-			ds.seek(idx);
-			const int sym = ds.sym(idx);
-			const double inv = ds.inv(idx);
-			double r[4];
-			rep_rows<REP>(btn, r);
-			dpp_guard(r);
-			double bnew = fdot64(r, row); // (a . e*B_{p+1})[k] = B_p[k] * d_p
-			if (p <= top) {
-				if (p == top) { // normalise the tile: posterior at `top` sums to one
-					double rr[4];
-					rep_rows<REP>(Xp * bnew, rr);
-					const double kappa = 1.0 / wave_sum_rep(rr);
-					bnew *= kappa; btn *= kappa;
-					bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
-				}
-				const double v = Xp * bnew; // gamma_p(k)  (khmm.c:317 up to scaling)
-				if (sym == 0) E0 += v; else if (sym == 1) E1 += v; else E2 += v;
-			}
-			btn = bnew * (pick_ef(sym, e0, e1) * inv);
-			if (p <= top && p > lo) bto[(int64_t)idx * 64 + lane] = btn; // bt[p]
+	for (int l = 0; l < 64; ++l) row[l] = aT[l * 64 + lane];
+	const double e0 = e[lane], e1 = e[64 + lane];
+	double btn; // e[o_{p+1}] * B_{p+1}, natural layout
+	int p;
+	if (REPAIR) { // continue from the tile above (already correctly scaled)
+		btn = bexit[(int64_t)(blockIdx.x + 1) * 64 + lane];
+		bentry[(int64_t)blockIdx.x * 64 + lane] = btn;
+		bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
+		p = top;
+	} else {
+		const int q = min(c.hi + W + 1, L); // B_q := 1
+		btn = pick_ef((int)o[q - 1], e0, e1);
+		p = q - 1;
+	}
+	DownStream ds;
+	ds.init(o, io, lane, p - 1);
+	const double xtop = REPAIR ? 0.0 : fo[(int64_t)(top - 1) * 64 + lane];
+	double oldv = 0.0;
+	for (; p >= lo; --p) {
+		const int idx = p - 1;
+		ds.seek(idx);
+		const int sym = ds.sym(idx);
+		const double inv = ds.inv(idx);
+		if (REPAIR && ((top - p) & 15) == 0 && p > lo) // stored bt at the end of this 16-bin block
+			oldv = bto[(int64_t)(max(p - 15, lo + 1) - 1) * 64 + lane];
+		double r[4];
+		rep_rows<REP>(btn, r);
+		dpp_guard(r);
+		double bnew = fdot64(r, row); // (a . e*B_{p+1})[k] = B_p[k] * d_p
+		if (!REPAIR && p == top) { // normalise the tile: posterior at `top` sums to one
+			double rr[4];
+			rep_rows<REP>(xtop * bnew, rr);
+			const double kappa = 1.0 / wave_sum_rep(rr);
+			bnew *= kappa; btn *= kappa;
+			bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
+			bentry[(int64_t)blockIdx.x * 64 + lane] = btn;
+		}
+		btn = bnew * (pick_ef(sym, e0, e1) * inv);
+		if (p <= top) {
+			if (p > lo || lo == 1) bto[(int64_t)idx * 64 + lane] = btn; // bt[p]; bt[lo>1] belongs to the tile below
 			if (p == lo) bexit[(int64_t)blockIdx.x * 64 + lane] = btn;
+			if (REPAIR && p > lo && (((top - p) & 15) == 15 || p == lo + 1)) {
+				if (rel_mismatch(btn, oldv) <= tol) break;
+			}
 		}
 	}
-	const double m = (double)c.mult;
-	double *oe = Epart + (int64_t)blockIdx.x * 192;
-	oe[lane] = E0 * m; oe[64 + lane] = E1 * m; oe[128 + lane] = E2 * m;
+}
+
+// ------------------------------------------------------------------ verify
+// flags tiles whose boundary vector disagrees with the neighbour's converged
+// one; cnt[0] = number flagged, warm[which] = largest mismatch seen this round
+template <bool BWD>
+__global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks, int n_chunks, double tol,
+                                                 const double *__restrict__ f, const double *__restrict__ mine,
+                                                 const double *__restrict__ bexit, int *__restrict__ dirty,
+                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm)
+{
+	const int lane = threadIdx.x, b = blockIdx.x;
+	const Chunk c = chunks[b];
+	double m = 0.0;
+	bool check;
+	if (!BWD) {
+		check = c.lo > 1 && !(c.flags & CHUNK_ANCHOR_F);
+		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], f[(c.off + c.lo - 2) * 64 + lane]);
+	} else {
+		check = !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST)) && min(c.hi, c.L - 1) >= c.lo && b + 1 < n_chunks;
+		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], bexit[(int64_t)(b + 1) * 64 + lane]);
+	}
+	if (lane == 0) {
+		const int bad = check && !(m <= tol);
+		dirty[b] = bad;
+		if (bad) atomicAdd(&cnt[0], 1);
+		if (check) atomicMax(&warm[BWD ? 1 : 0], (unsigned long long)__double_as_longlong(m));
+	}
 }
 
 // ------------------------------------------------------------------ expect
-// C[k][l] += sum_p X_p[k] * bt_{p+1}[l] over the tile's positions lo..min(hi,L-1),
-// split over n_sub waves.  FP64 matrix cores: D(16x16) += A(16x4) B(4x16) with
+// C[k][l] += sum_p X_p[k] * bt_{p+1}[l] and S[o_p][k] += d_p X_p[k] bt_p[k] over the
+// tile's positions lo..min(hi,L-1), split over n_sub waves.  FP64 matrix cores:
+// D(16x16) += A(16x4) B(4x16) with
 //   A[i][t] = X_{p+t}[16m+i]   (lane = 16t+i),  B[t][j] = bt_{p+t+1}[16n+j] (lane = 16t+j)
 //   D[(lane>>4)+4r][lane&15] = acc[r]
 __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
-                                                      const double *__restrict__ f, const double *__restrict__ bt,
-                                                      double *__restrict__ Cpart)
+                                                         const uint8_t *__restrict__ obs, const double *__restrict__ f,
+                                                         const double *__restrict__ bt, const double *__restrict__ dd,
+                                                         double *__restrict__ Cpart, double *__restrict__ Spart)
 {
 	const int lane = threadIdx.x, t = lane >> 4, i = lane & 15;
 	const Chunk c = chunks[blockIdx.x / n_sub];
@@ -205,33 +270,48 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
 	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64 + i, *bo = bt + c.off * 64 + i;
+	const double *fo = f + c.off * 64 + i, *bo = bt + c.off * 64 + i, *dof = dd + c.off;
+	const uint8_t *o = obs + c.off;
 	d4_t acc[4][4];
+	double S[3][4];
 #pragma unroll
-	for (int m = 0; m < 4; ++m)
+	for (int m = 0; m < 4; ++m) {
 #pragma unroll
 		for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (d4_t){0.0, 0.0, 0.0, 0.0};
-	auto load = [&](int p, double (&FA)[4], double (&BM)[4]) {
+		S[0][m] = S[1][m] = S[2][m] = 0.0;
+	}
+	auto load = [&](int p, double (&FA)[4], double (&BM)[4], double (&BP)[4], double &w, int &sym) {
 		const int pp = p + t;
 		const bool ok = pp <= p1;
 		const int64_t idx = (int64_t)(ok ? pp : p1) - 1;
-		const double *fr = fo + idx * 64, *br = bo + (idx + 1) * 64;
+		const double *fr = fo + idx * 64, *br = bo + idx * 64;
 #pragma unroll
-		for (int m = 0; m < 4; ++m) { FA[m] = ok ? fr[16 * m] : 0.0; BM[m] = br[16 * m]; }
+		for (int m = 0; m < 4; ++m) { FA[m] = ok ? fr[16 * m] : 0.0; BP[m] = br[16 * m]; BM[m] = br[64 + 16 * m]; }
+		w = ok ? dof[idx] : 0.0;
+		sym = o[idx];
 	};
 	if (p0 <= p1) {
-		double FA[4], BM[4];
-		load(p0, FA, BM);
+		double FA[4], BM[4], BP[4], w; int sym;
+		load(p0, FA, BM, BP, w, sym);
 		for (int p = p0; p <= p1; p += 4) {
-			double FN[4] = {0, 0, 0, 0}, BN[4] = {0, 0, 0, 0};
-			if (p + 4 <= p1) load(p + 4, FN, BN);
+			double FN[4] = {0, 0, 0, 0}, BN[4] = {0, 0, 0, 0}, BQ[4] = {0, 0, 0, 0}, wn = 0.0; int symn = 2;
+			if (p + 4 <= p1) load(p + 4, FN, BN, BQ, wn, symn);
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
 #pragma unroll
 				for (int nn = 0; nn < 4; ++nn)
 					acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[m], BM[nn], acc[m][nn], 0, 0, 0);
+			const double w0 = sym == 0 ? w : 0.0, w1 = sym == 1 ? w : 0.0, w2 = sym == 2 ? w : 0.0;
 #pragma unroll
-			for (int m = 0; m < 4; ++m) { FA[m] = FN[m]; BM[m] = BN[m]; }
+			for (int m = 0; m < 4; ++m) {
+				const double g = FA[m] * BP[m];
+				S[0][m] = __builtin_fma(g, w0, S[0][m]);
+				S[1][m] = __builtin_fma(g, w1, S[1][m]);
+				S[2][m] = __builtin_fma(g, w2, S[2][m]);
+			}
+#pragma unroll
+			for (int m = 0; m < 4; ++m) { FA[m] = FN[m]; BM[m] = BN[m]; BP[m] = BQ[m]; }
+			w = wn; sym = symn;
 		}
 	}
 	const double mult = (double)c.mult;
@@ -242,6 +322,16 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 		for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
 			for (int r = 0; r < 4; ++r) out[(16 * m + t + 4 * r) * 64 + 16 * nn + i] = acc[m][nn][r] * mult;
+	double *os = Spart + (int64_t)blockIdx.x * 192;
+#pragma unroll
+	for (int b = 0; b < 3; ++b)
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			double v = S[b][m];
+			v += __shfl_xor(v, 16, 64);
+			v += __shfl_xor(v, 32, 64);
+			if (t == 0) os[b * 64 + 16 * m + i] = v * mult;
+		}
 }
 
 // VALU cross-check of the above: lane = k, 64 accumulators C[k][0..63] per lane.
@@ -249,8 +339,9 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 	fmac_bcast<N>(C[N], r[0], X);      fmac_bcast<N>(C[16 + N], r[1], X);    \
 	fmac_bcast<N>(C[32 + N], r[2], X); fmac_bcast<N>(C[48 + N], r[3], X);
 __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ chunks, int n_sub,
-                                                      const double *__restrict__ f, const double *__restrict__ bt,
-                                                      double *__restrict__ Cpart)
+                                                      const uint8_t *__restrict__ obs, const double *__restrict__ f,
+                                                      const double *__restrict__ bt, const double *__restrict__ dd,
+                                                      double *__restrict__ Cpart, double *__restrict__ Spart)
 {
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x / n_sub];
@@ -258,12 +349,16 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
 	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64, *bo = bt + c.off * 64;
-	double C[64];
+	const double *fo = f + c.off * 64, *bo = bt + c.off * 64, *dof = dd + c.off;
+	const uint8_t *o = obs + c.off;
+	double C[64], S0 = 0.0, S1 = 0.0, S2 = 0.0;
 #pragma unroll
 	for (int l = 0; l < 64; ++l) C[l] = 0.0;
 	for (int p = p0; p <= p1; ++p) {
 		const double X = fo[(int64_t)(p - 1) * 64 + lane];
+		const double g = X * bo[(int64_t)(p - 1) * 64 + lane] * dof[p - 1];
+		const int sym = o[p - 1];
+		if (sym == 0) S0 += g; else if (sym == 1) S1 += g; else S2 += g;
 		double r[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) r[j] = bo[(int64_t)p * 64 + 16 * j + (lane & 15)]; // replicated load of bt[p+1]
@@ -276,38 +371,35 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 	double *out = Cpart + (int64_t)blockIdx.x * 4096 + lane * 64;
 #pragma unroll
 	for (int l = 0; l < 64; ++l) out[l] = C[l] * mult;
+	double *os = Spart + (int64_t)blockIdx.x * 192;
+	os[lane] = S0 * mult; os[64 + lane] = S1 * mult; os[128 + lane] = S2 * mult;
 }
 
-// ------------------------------------------------------------------ checks
-// Largest relative mismatch between a tile's warmed-up entry vector and the
-// value its neighbour computed with a full tile of history behind it.
-__global__ __launch_bounds__(64) void k_warm_check(const Chunk *__restrict__ chunks, const double *__restrict__ f,
-                                                     const double *__restrict__ bt, const double *__restrict__ entry,
-                                                     const double *__restrict__ bexit,
-                                                     unsigned long long *__restrict__ warm)
+// ------------------------------------------------------------------ log-likelihood
+// LL of a tile = sum_{p in tile, p>=2} log d_p  (+ log sum(X_L) for the last tile):
+// running products flushed through log() like hmm_lk (khmm.c:245-260).
+__global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, const double *__restrict__ f,
+                                             const double *__restrict__ dd, double *__restrict__ LLpart)
 {
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x];
-	if (c.lo <= 1) return;
-	{
-		const double w = entry[(int64_t)blockIdx.x * 64 + lane];
-		const double tr = f[(c.off + c.lo - 2) * 64 + lane];
-		const double num = wave_max(fabs(w - tr)), den = wave_max(fabs(tr));
-		if (lane == 0) atomicMax(&warm[0], (unsigned long long)__double_as_longlong(num / den));
+	const double *dof = dd + c.off;
+	double prod = 1.0, ll = 0.0;
+	for (int p = max(c.lo, 2) + lane; p <= c.hi; p += 64) {
+		prod *= dof[p - 1];
+		if (prod < 1e-280) { ll += log(prod); prod = 1.0; }
 	}
-	if (min(c.hi, c.L - 1) >= c.lo) {
-		const double w = bexit[(int64_t)blockIdx.x * 64 + lane];
-		const double tr = bt[(c.off + c.lo - 1) * 64 + lane];
-		const double num = wave_max(fabs(w - tr)), den = wave_max(fabs(tr));
-		if (lane == 0) atomicMax(&warm[1], (unsigned long long)__double_as_longlong(num / den));
-	}
+	ll += log(prod);
+	ll = wave_add(ll);
+	if (c.hi == c.L) ll += log(wave_add(f[(c.off + c.L - 1) * 64 + lane]));
+	if (lane == 0) LLpart[blockIdx.x] = ll * (double)c.mult;
 }
 
 // ------------------------------------------------------------------ reduce
 // Fixed-order two-stage reduction of the per-wave partials (deterministic).
-__global__ __launch_bounds__(256) void k_reduce1(const double *__restrict__ Cpart, int nC,
-                                                   const double *__restrict__ Epart, const double *__restrict__ LLpart,
-                                                   int nchunks, double *__restrict__ stage)
+__global__ __launch_bounds__(256) void k_reduce1(const double *__restrict__ Cpart, const double *__restrict__ Spart,
+                                                   int nC, const double *__restrict__ LLpart, int nchunks,
+                                                   double *__restrict__ stage)
 {
 	const int y = blockIdx.y, tid = threadIdx.x;
 	double *st = stage + (int64_t)y * STATS_LEN;
@@ -318,7 +410,7 @@ __global__ __launch_bounds__(256) void k_reduce1(const double *__restrict__ Cpar
 		st[i] = s;
 	} else if (tid < 192) {
 		double s = 0.0;
-		for (int j = y; j < nchunks; j += RED_ROWS) s += Epart[(int64_t)j * 192 + tid];
+		for (int j = y; j < nC; j += RED_ROWS) s += Spart[(int64_t)j * 192 + tid];
 		st[4096 + tid] = s;
 	} else if (tid == 192) {
 		double s = 0.0;
@@ -328,7 +420,8 @@ __global__ __launch_bounds__(256) void k_reduce1(const double *__restrict__ Cpar
 }
 // Writes the final statistics UNPADDED: out = [A n*n | E 2*n | LL].
 __global__ __launch_bounds__(256) void k_reduce2(const double *__restrict__ stage, const double *__restrict__ a,
-                                                   double tiny_total, int n, double *__restrict__ out)
+                                                   const double *__restrict__ e, double tiny_total, int n,
+                                                   double *__restrict__ out)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= STATS_LEN) return;
@@ -337,48 +430,97 @@ __global__ __launch_bounds__(256) void k_reduce2(const double *__restrict__ stag
 	if (i < 4096) { // A = a .* C + n_seg*HMM_TINY (khmm.c:305-306,316)
 		const int k = i >> 6, l = i & 63;
 		if (k < n && l < n) out[k * n + l] = a[i] * s + tiny_total;
-	} else if (i < 4096 + 192) { // khmm.c:307-308; the missing-symbol row is dropped (khmm.c:355)
+	} else if (i < 4096 + 192) { // E = S / e + n_seg*HMM_TINY; the missing-symbol row is dropped (khmm.c:355)
 		const int b = (i - 4096) >> 6, k = (i - 4096) & 63;
-		if (b < 2 && k < n) out[n * n + b * n + k] = s + tiny_total;
+		if (b < 2 && k < n) out[n * n + b * n + k] = s / e[b * 64 + k] + tiny_total;
 	} else {
 		out[n * n + 2 * n] = s;
 	}
 }
 
 // ------------------------------------------------------------------ launcher
-int launch_fast(const EstepLaunch &p)
+static int read_count(const EstepLaunch &p, int *n)
+{
+	if (hipMemcpyAsync(p.h_cnt, p.d_cnt, sizeof(int), hipMemcpyDeviceToHost, p.stream) != hipSuccess) return -1;
+	if (hipStreamSynchronize(p.stream) != hipSuccess) return -1;
+	*n = p.h_cnt[0];
+	return 0;
+}
+
+int launch_fast(const EstepLaunch &p, FastReport *rep)
 {
 	if (p.n_chunks <= 0) return 0;
 	const dim3 g(p.n_chunks), b(64);
-	hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), p.stream);
-	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
-	if (p.rep_impl == 0)
-		hipLaunchKernelGGL(k_fwd_fast<0>, g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.warmup, p.d_f,
-		                   p.d_s, p.d_entry, p.d_LLpart);
-	else
-		hipLaunchKernelGGL(k_fwd_fast<1>, g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.warmup, p.d_f,
-		                   p.d_s, p.d_entry, p.d_LLpart);
-	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
 	const double *aT = p.d_aeT + 2 * 4096;
+	rep->fwd_rounds = rep->bwd_rounds = rep->fwd_tiles = rep->bwd_tiles = 0;
+	rep->converged = 1;
+	(void)hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), p.stream);
+	if (p.ev[0]) (void)hipEventRecord(p.ev[0], p.stream);
+	// ---- forward: speculate, then verify / repair until every boundary agrees
 	if (p.rep_impl == 0)
-		hipLaunchKernelGGL(k_bwd_fast<0>, g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.d_f, p.d_s,
-		                   p.d_b, p.d_bexit, p.d_Epart);
+		hipLaunchKernelGGL((k_fwd_fast<0, false>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
 	else
-		hipLaunchKernelGGL(k_bwd_fast<1>, g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.d_f, p.d_s,
-		                   p.d_b, p.d_bexit, p.d_Epart);
-	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
+		hipLaunchKernelGGL((k_fwd_fast<1, false>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
+	for (int round = 0;; ++round) {
+		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), p.stream);
+		(void)hipMemsetAsync(p.d_warm, 0, sizeof(unsigned long long), p.stream);
+		hipLaunchKernelGGL((k_verify<false>), g, b, 0, p.stream, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry,
+		                   p.d_bexit, p.d_dirty, p.d_cnt, p.d_warm);
+		int nd = 0;
+		if (read_count(p, &nd)) return -1;
+		if (nd == 0) break;
+		if (round >= p.max_rounds) { rep->converged = 0; break; }
+		rep->fwd_rounds++; rep->fwd_tiles += nd;
+		if (p.rep_impl == 0)
+			hipLaunchKernelGGL((k_fwd_fast<0, true>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
+		else
+			hipLaunchKernelGGL((k_fwd_fast<1, true>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
+	}
+	if (p.ev[1]) (void)hipEventRecord(p.ev[1], p.stream);
+	// ---- backward
+	if (p.rep_impl == 0)
+		hipLaunchKernelGGL((k_bwd_fast<0, false>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
+		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
+	else
+		hipLaunchKernelGGL((k_bwd_fast<1, false>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
+		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
+	for (int round = 0;; ++round) {
+		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), p.stream);
+		(void)hipMemsetAsync(p.d_warm + 1, 0, sizeof(unsigned long long), p.stream);
+		hipLaunchKernelGGL((k_verify<true>), g, b, 0, p.stream, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry,
+		                   p.d_bexit, p.d_dirty, p.d_cnt, p.d_warm);
+		int nd = 0;
+		if (read_count(p, &nd)) return -1;
+		if (nd == 0) break;
+		if (round >= p.max_rounds) { rep->converged = 0; break; }
+		rep->bwd_rounds++; rep->bwd_tiles += nd;
+		if (p.rep_impl == 0)
+			hipLaunchKernelGGL((k_bwd_fast<0, true>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
+			                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
+		else
+			hipLaunchKernelGGL((k_bwd_fast<1, true>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
+			                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
+	}
+	if (p.ev[2]) (void)hipEventRecord(p.ev[2], p.stream);
+	// ---- counts + log-likelihood from the stored tables
 	const int nC = p.n_chunks * p.n_sub;
 	if (p.expect_impl == 0)
-		hipLaunchKernelGGL(k_expect_valu, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_f, p.d_b, p.d_Cpart);
+		hipLaunchKernelGGL(k_expect_valu, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_d,
+		                   p.d_Cpart, p.d_Epart);
 	else
-		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_f, p.d_b, p.d_Cpart);
-	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);
-	hipLaunchKernelGGL(k_warm_check, g, b, 0, p.stream, p.d_chunks, p.d_f, p.d_b, p.d_entry, p.d_bexit, p.d_warm);
-	hipLaunchKernelGGL(k_reduce1, dim3(17, RED_ROWS), dim3(256), 0, p.stream, p.d_Cpart, nC, p.d_Epart, p.d_LLpart,
+		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_d,
+		                   p.d_Cpart, p.d_Epart);
+	hipLaunchKernelGGL(k_ll, g, b, 0, p.stream, p.d_chunks, p.d_f, p.d_d, p.d_LLpart);
+	if (p.ev[3]) (void)hipEventRecord(p.ev[3], p.stream);
+	hipLaunchKernelGGL(k_reduce1, dim3(17, RED_ROWS), dim3(256), 0, p.stream, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
 	                   p.n_chunks, p.d_stage);
-	hipLaunchKernelGGL(k_reduce2, dim3((STATS_LEN + 255) / 256), dim3(256), 0, p.stream, p.d_stage, p.d_a,
+	hipLaunchKernelGGL(k_reduce2, dim3((STATS_LEN + 255) / 256), dim3(256), 0, p.stream, p.d_stage, p.d_a, p.d_e,
 	                   p.tiny_total, p.n_states, p.d_stats);
-	if (p.ev[4]) hipEventRecord(p.ev[4], p.stream);
+	if (p.ev[4]) (void)hipEventRecord(p.ev[4], p.stream);
 	return (int)hipGetLastError();
 }
 

@@ -15,7 +15,14 @@ struct Chunk {
 	int32_t lo;   // first position owned by the tile
 	int32_t hi;   // last position owned by the tile
 	int32_t mult; // how many times the segment occurs in the selection (bootstrap)
+	int32_t flags; // CHUNK_*
+	int32_t pad_;
 };
+constexpr int CHUNK_ANCHOR_F = 1; // forward speculation started at the true segment start: exact
+constexpr int CHUNK_ANCHOR_B = 2; // backward speculation started at the true segment end: exact
+constexpr int CHUNK_LAST = 4;     // last tile of its segment
+
+struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged; };
 
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
@@ -33,14 +40,17 @@ struct EstepLaunch {
 	const int32_t *d_work; // exact: unique selected segment ids
 	int n_work;
 	double *d_f, *d_b, *d_s; // exact: f,b tables + s; fast: f = X (lag-normalised), d_b = bt, d_s = inv_d
+	double *d_d;             // fast: d_p = sum(X_{p-1})
 	// exact outputs
 	double *d_segA, *d_segE, *d_segA0, *d_chk;
 	// fast
 	const Chunk *d_chunks;
 	int n_chunks, warmup, n_sub;
-	double *d_entry, *d_bexit;  // [n_chunks][64] warm-up check vectors
+	double *d_entry, *d_bentry, *d_bexit; // [n_chunks][64] boundary vectors used / produced by each tile
+	int *d_dirty, *d_cnt, *h_cnt;         // per-tile repair flags, flagged count (device, pinned host)
+	double tol; int max_rounds;
 	double *d_Cpart;            // [n_chunks*n_sub][4096]
-	double *d_Epart;            // [n_chunks][192]
+	double *d_Epart;            // [n_chunks*n_sub][192]  S partials
 	double *d_LLpart;           // [n_chunks]
 	double *d_stage;            // [RED_ROWS][STATS_LEN]
 	double *d_stats;            // [n*n + 2n + 1] final, unpadded [A | E | LL]
@@ -52,7 +62,7 @@ struct EstepLaunch {
 constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
-int launch_fast(const EstepLaunch &p);
+int launch_fast(const EstepLaunch &p, FastReport *rep);
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 
 } // namespace psmc

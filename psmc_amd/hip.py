@@ -26,7 +26,7 @@ EXPORTS = [
     "psmc_hip_device_count", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
-    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag",
+    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs",
     "psmc_hip_get_tables", "psmc_hip_selftest", "psmc_hip_last_timing",
 ]
 
@@ -39,6 +39,27 @@ def lib_path():
     return os.path.join(_HERE, "libpsmc_hip.so")
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7, like /opt/rocm's).  Two HIP
+    runtimes in one process cannot both own the GPU, so when torch is installed make sure ITS runtime is
+    the one mapped before libpsmc_hip.so resolves libamdhip64.so.7 -- then torch tensors, torch streams and
+    our kernels live in one runtime whichever is imported first.  Without torch (e.g. the C driver) the
+    system runtime under /opt/rocm is used."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("PSMC_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library():
     """dlopen psmc_amd/libpsmc_hip.so (built by psmc_amd/csrc/Makefile).  Fails loudly."""
     global _LIB
@@ -47,6 +68,7 @@ def load_library():
     p = lib_path()
     if not os.path.exists(p):
         raise HipError("%s not built: run `make -C psmc_amd/csrc` (or __graft_entry__.build())" % p)
+    _share_torch_hip_runtime()
     lib = C.CDLL(p)
     lib.psmc_hip_strerror.restype = C.c_char_p
     lib.psmc_hip_last_error.restype = C.c_char_p
@@ -62,6 +84,7 @@ def load_library():
     lib.psmc_hip_estep_segments.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.psmc_hip_estep_device.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_void_p]
     lib.psmc_hip_fast_diag.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.psmc_hip_fast_repairs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.psmc_hip_get_tables.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     lib.psmc_hip_selftest.argtypes = [C.c_int]
     lib.psmc_hip_last_timing.argtypes = [C.c_void_p, _dp]
@@ -178,7 +201,10 @@ class HipEStep:
     def fast_diag(self):
         wf = C.c_double(0); wb = C.c_double(0); nc = C.c_int(0); wu = C.c_int(0)
         self._chk(self.lib.psmc_hip_fast_diag(self.h, C.byref(wf), C.byref(wb), C.byref(nc), C.byref(wu)), "fast_diag")
-        return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value)
+        rp = (C.c_int * 4)()
+        self._chk(self.lib.psmc_hip_fast_repairs(self.h, rp), "fast_repairs")
+        return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value,
+                    fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3])
 
     def tables(self, seg, want_b=True):
         L = int(self.lens[seg])

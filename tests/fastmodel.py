@@ -1,21 +1,26 @@
-"""numpy model of the FAST-mode E-step algorithm (chunked sweeps with warm-up
-overlap, lagged normalisation, per-chunk posterior normalisation).
+"""numpy model of the FAST-mode E-step algorithm (tiled sweeps: speculate,
+verify at the tile boundaries, repair only where the chain had not forgotten
+its start; lagged normalisation; counts as a GEMM over bins).
 
 TEST INFRASTRUCTURE: an executable specification of what the fast HIP kernels
-(psmc_amd/csrc/estep_fast.hip) compute, used on CPU to (1) check the algebra
-against the oracle and (2) quantify the tolerance as a function of the chunk
-length T and warm-up W.  Not imported by the product.
+(psmc_amd/csrc/estep_fast.hip) compute, used on CPU to check the algebra
+against the oracle and to study tolerance / work as a function of the tile
+length T, the speculative warm-up W0 and the tolerances.  Not imported by the
+product.
 
 Notation (1-indexed positions p=1..L, o_p the observation):
   forward  X_p = e[o_p] * (a^T X_{p-1}) / d_p ,  d_p = sum(X_{p-1}),  d_1 = 1
-           (so sum(X_p) = true scale s_p; LL = sum_p log(sum X_p))
-  backward Bnew_p = a (e[o_{p+1}] * B_{p+1}),  B_p = Bnew_p / d_p
-  counts   C += X_p (x) (e[o_{p+1}] * B_{p+1})   for p = 1..L-1
-           E[o_p] += X_p * Bnew_p                for p = 1..L-1
-  A = a * C   (elementwise), plus n_seg * HMM_TINY on every cell.
-Each backward chunk is normalised once at its top position so that
-sum_k X_top[k]*Bnew_top[k] = 1 (posterior sums to one); after that all products
-inside the chunk are correctly scaled because forward and backward share d_p.
+           (so sum(X_p) = the reference's s_p; LL = sum_{p>=2} log d_p + log sum(X_L))
+  backward Bnew_p = a (e[o_{p+1}] * B_{p+1}),  B_p = Bnew_p / d_p,  bt_p = e[o_p] * B_p
+  counts   C      += X_p (x) bt_{p+1}                      p = 1..L-1   (A = a .* C)
+           S[o_p] += d_p * X_p * bt_p                       p = 1..L-1   (E = S / e)
+Speculation: a tile [lo,hi] starts W0 bins outside itself from an arbitrary
+vector.  Verification compares the vector a tile used at its boundary with the
+value its neighbour computed with a whole tile of history behind it; tiles
+whose mismatch exceeds `tol` are re-run from the neighbour's value until the new
+trajectory meets the stored one to `tol` again (or the tile ends, which may make
+the next tile dirty).  A backward tile is normalised once at its top so that
+the posterior sums to one; repaired tiles inherit the scale of the tile above.
 """
 import numpy as np
 
@@ -33,68 +38,119 @@ def plan_chunks(L, T):
     return out
 
 
-def estep_fast_model(a, e, a0, segs, T=4096, W=2048, return_chunks=False):
+def _relmax(x, y):
+    return np.abs(x - y).max() / np.abs(y).max()
+
+
+def estep_fast_model(a, e, a0, segs, T=4096, W=2048, tol=None, stats=None):
+    """tol=None: pure warm-up tiling (no verification).  tol=float: speculate with W, verify, repair."""
     n = a.shape[0]
     A = np.zeros((n, n)); E = np.zeros((3, n)); LL = 0.0
-    max_warm_err = 0.0
+    work = dict(fwd_steps=0, bwd_steps=0, fwd_rounds=0, bwd_rounds=0, bins=0)
     for seg in segs:
         seg = np.asarray(seg, dtype=np.int64)
         L = len(seg)
-        o = np.concatenate([[2], seg])  # o[p], p=1..L
-        chunks = plan_chunks(L, T)
-        nc = len(chunks)
-        lo = np.array([c[0] for c in chunks]); hi = np.array([c[1] for c in chunks])
-        X_store = np.zeros((L + 2, n)); d_store = np.ones(L + 2)
-        # ---------------- forward: all chunks in lockstep
-        ws = np.maximum(1, lo - W)             # first position computed by the chunk
-        X = np.tile(a0, (nc, 1))               # "X_{ws-1}" prior (true a0 when ws==1)
-        steps = (hi - ws + 1).max()
-        ll_chunk = np.zeros(nc)
-        for t in range(steps):
-            p = ws + t
-            act = p <= hi
-            pc = np.minimum(p, L)
-            em = e[o[pc]]                      # (nc, n)
-            first = (p == 1)
-            d = np.where(first, 1.0, X.sum(1))
-            G = np.where(first[:, None], X * em, em * (X @ a))
-            Xn = G / d[:, None]
-            X = np.where(act[:, None], Xn, X)
-            st = act & (p >= lo)
-            X_store[pc[st]] = Xn[st]
-            d_store[pc[st]] = d[st]
-            ll_chunk[st] += np.log(Xn[st].sum(1))
-        LL += ll_chunk.sum()
-        # warm-up quality: compare each chunk's entry vector with the truth is
-        # not available here; instead report |X_store| continuity via oracle in tests
-        # ---------------- backward: all chunks in lockstep
-        top = np.minimum(hi, L - 1)            # first accumulating position
-        q = np.minimum(hi + W + 1, L)          # position whose B is initialised to 1
-        B = np.ones((nc, n))
-        C = np.zeros((nc, n, n)); Ec = np.zeros((nc, 3, n))
-        steps = (q - lo).max() if nc else 0
-        for t in range(steps):
-            p = q - 1 - t                      # position being produced
-            act = (p >= lo) & (p >= 1)
-            pc = np.clip(p, 1, L)
-            Bt = e[o[np.minimum(pc + 1, L)]] * B
-            Bnew = Bt @ a.T
-            Xp = X_store[pc]
-            istop = act & (p == top)
-            if istop.any():
-                c = (Xp * Bnew).sum(1)
-                kappa = np.where(istop, 1.0 / c, 1.0)
-                Bt = Bt * kappa[:, None]; Bnew = Bnew * kappa[:, None]
-            acc = act & (p <= top)
-            if acc.any():
-                C[acc] += Xp[acc][:, :, None] * Bt[acc][:, None, :]
-                sym = o[pc]
-                for b in range(3):
-                    m = acc & (sym == b)
-                    Ec[m, b] += Xp[m] * Bnew[m]
-            Bn = Bnew / d_store[pc][:, None]
-            B = np.where(act[:, None], Bn, B)
-        A += a * C.sum(0) + TINY
-        E += Ec.sum(0) + TINY
-    out = dict(A=A, E=E[:2].copy(), LL=LL)
-    return out
+        work["bins"] += L
+        o = np.concatenate([[2], seg, [2]])  # o[p], p=1..L
+        tiles = plan_chunks(L, T)
+        nc = len(tiles)
+        X = np.zeros((L + 2, n)); d = np.ones(L + 2); bt = np.zeros((L + 2, n))
+
+        def fstep(x, p):
+            dp = 1.0 if p == 1 else x.sum()
+            g = (x * e[o[p]]) if p == 1 else e[o[p]] * (x @ a)
+            return g / dp, dp
+
+        # ---------------- forward: speculative pass
+        entry = [None] * nc
+        for c, (lo, hi) in enumerate(tiles):
+            ws = max(1, lo - W)
+            x = a0.copy()
+            for p in range(ws, hi + 1):
+                if p == lo:
+                    entry[c] = x.copy()
+                x, dp = fstep(x, p)
+                work["fwd_steps"] += 1
+                if p >= lo:
+                    X[p] = x; d[p] = dp
+        # ---------------- forward: verify / repair rounds
+        if tol is not None:
+            while True:
+                dirty = [c for c in range(1, nc) if _relmax(entry[c], X[tiles[c][0] - 1]) > tol]
+                if not dirty:
+                    break
+                work["fwd_rounds"] += 1
+                for c in dirty:
+                    lo, hi = tiles[c]
+                    x = X[lo - 1].copy(); entry[c] = x.copy()
+                    for p in range(lo, hi + 1):
+                        xn, dp = fstep(x, p)
+                        work["fwd_steps"] += 1
+                        done = _relmax(xn, X[p]) <= tol
+                        X[p] = xn; d[p] = dp; x = xn
+                        if done:
+                            break
+        LL += np.log(d[2:L + 1]).sum() + np.log(X[L].sum())
+
+        # ---------------- backward
+        def bstep(btn, p):  # consumes bt_{p+1}, returns Bnew_p
+            return a @ btn
+
+        bentry = [None] * nc; bexit = [None] * nc
+        for c, (lo, hi) in enumerate(tiles):
+            top = min(hi, L - 1)
+            if top < lo:
+                continue
+            q = min(hi + W + 1, L)
+            btn = e[o[q]] * np.ones(n)
+            for p in range(q - 1, lo - 1, -1):
+                bnew = bstep(btn, p)
+                work["bwd_steps"] += 1
+                if p == top:
+                    kappa = 1.0 / (X[p] * bnew).sum()
+                    bnew *= kappa; btn = btn * kappa
+                    bt[top + 1] = btn; bentry[c] = btn.copy()
+                btn = e[o[p]] * bnew / d[p]
+                if lo < p <= top or p == 1:
+                    bt[p] = btn
+                if p == lo:
+                    bexit[c] = btn.copy()
+        if tol is not None:
+            while True:
+                dirty = [c for c in range(nc - 1)
+                         if bexit[c + 1] is not None and bentry[c] is not None
+                         and _relmax(bentry[c], bexit[c + 1]) > tol]
+                if not dirty:
+                    break
+                work["bwd_rounds"] += 1
+                for c in dirty:
+                    lo, hi = tiles[c]
+                    top = min(hi, L - 1)
+                    btn = bexit[c + 1].copy(); bentry[c] = btn.copy()
+                    bt[top + 1] = btn
+                    for p in range(top, lo - 1, -1):
+                        bnew = bstep(btn, p)
+                        work["bwd_steps"] += 1
+                        btn = e[o[p]] * bnew / d[p]
+                        if p > lo:
+                            done = _relmax(btn, bt[p]) <= tol
+                            bt[p] = btn
+                            if done:
+                                break
+                        else:
+                            bexit[c] = btn.copy()
+                            if p == 1:
+                                bt[1] = btn
+        # ---------------- counts (GEMM over bins) from the stored tables
+        if L > 1:
+            C = X[1:L].T @ bt[2:L + 1]
+            A += a * C
+            g = d[1:L, None] * X[1:L] * bt[1:L]
+            S = np.zeros((3, n))
+            for b in range(3):
+                S[b] = g[seg[:L - 1] == b].sum(0)
+            E += S / e
+        A += TINY; E += TINY
+    if stats is not None:
+        stats.update(work)
+    return dict(A=A, E=E[:2].copy(), LL=LL)

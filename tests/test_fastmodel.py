@@ -30,11 +30,25 @@ def test_tiled_matches_oracle(golden, oracle, T, W, tol):
     assert abs(m["LL"] - ref["LL"]) < tol * abs(ref["LL"])
 
 
-def test_short_warmup_is_detectably_wrong(golden, oracle):
-    """W far below the forgetting length must NOT pass: this is what the runtime
-    warm-up check of the HIP path guards against."""
+def test_short_overlap_alone_is_wrong_and_repair_fixes_it(golden, oracle):
+    """An overlap far below the forgetting length must NOT pass by itself (this is what the
+    verify kernel of the HIP path detects); with verify + repair it is right again, at a
+    fraction of the work a long fixed overlap would cost."""
     p = golden.params("n64_curve")
-    segs = golden.segs_mid[2:3]
+    segs = golden.segs_mid[2:4]
     ref = oracle.estep(p["a"], p["e"], p["a0"], segs)
     m = fastmodel.estep_fast_model(p["a"], p["e"], p["a0"], segs, T=1024, W=128)
     assert relmax(m["A"], ref["A"]) > 1e-6
+    st = {}
+    m = fastmodel.estep_fast_model(p["a"], p["e"], p["a0"], segs, T=1024, W=128, tol=1e-12, stats=st)
+    assert relmax(m["A"], ref["A"]) < 1e-11 and relmax(m["E"], ref["E"]) < 1e-11
+    assert abs(m["LL"] - ref["LL"]) < 1e-12 * abs(ref["LL"])
+    assert st["fwd_rounds"] >= 1 and st["fwd_steps"] < 4 * st["bins"]
+
+
+def test_no_overlap_with_repair(golden, oracle):
+    p = golden.params("n64_flat")
+    segs = golden.segs_small
+    ref = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    m = fastmodel.estep_fast_model(p["a"], p["e"], p["a0"], segs, T=500, W=0, tol=1e-12)
+    assert relmax(m["A"], ref["A"]) < 1e-11 and relmax(m["E"], ref["E"]) < 1e-11

@@ -169,15 +169,18 @@ def test_fast_mid_golden(hip, golden, opts):
     es.close()
 
 
-def test_fast_warmup_escalates(hip, golden):
-    """A warm-up far below the chain's memory is detected by the tile-boundary check and widened."""
+@pytest.mark.parametrize("opts", [dict(chunk=1024, warmup=64), dict(chunk=512, warmup=0), dict(chunk=2048, warmup=256, rep_impl=0)])
+def test_fast_speculation_is_repaired(hip, golden, opts):
+    """A speculative overlap far below the chain's memory leaves tile boundaries that disagree;
+    verify flags them and repair re-runs only those tiles until the statistics are right."""
     key = "n64_curve"
     p = golden.params(key)
-    es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=1024, warmup=64)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
     es.load_segments(golden.segs_mid)
     r = es.estep(p["a"], p["e"], p["a0"])
     d = es.fast_diag()
-    assert d["warmup"] > 64
+    assert d["fwd_tiles"] > 0 and d["bwd_tiles"] > 0 and d["fwd_rounds"] >= 1
+    assert d["warm_err_fwd"] <= 1e-12 and d["warm_err_bwd"] <= 1e-12
     g = golden.mid
     check_fast(r, dict(A=g[key + ".A"], E=g[key + ".E"], LL=float(g[key + ".LL"])))
     es.close()

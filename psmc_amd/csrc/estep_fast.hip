@@ -65,6 +65,13 @@ __device__ __forceinline__ double rel_mismatch(double x, double y) {
 	return bad ? __builtin_inf() : num / den;
 }
 
+// same after scaling both vectors to unit L1 norm (backward vectors of two tiles agree only
+// up to the per-tile posterior normalisation, which moves by O(warm_tol) at forward tile seams)
+__device__ __forceinline__ double rel_mismatch_dir(double x, double y) {
+	const double sx = wave_add(fabs(x)), sy = wave_add(fabs(y));
+	return rel_mismatch(x / sx, y / sy);
+}
+
 // cached symbols for ascending / (symbol, inv_d) for descending bin indices:
 // one coalesced 64-wide load per 64 steps, prefetched one block ahead
 struct UpSyms {
@@ -181,10 +188,8 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 	const double e0 = e[lane], e1 = e[64 + lane];
 	double btn; // e[o_{p+1}] * B_{p+1}, natural layout
 	int p;
-	if (REPAIR) { // continue from the tile above (already correctly scaled)
+	if (REPAIR) { // continue from the value the tile above computed at our top boundary
 		btn = bexit[(int64_t)(blockIdx.x + 1) * 64 + lane];
-		bentry[(int64_t)blockIdx.x * 64 + lane] = btn;
-		bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
 		p = top;
 	} else {
 		const int q = min(c.hi + W + 1, L); // B_q := 1
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 	}
 	DownStream ds;
 	ds.init(o, io, lane, p - 1);
-	const double xtop = REPAIR ? 0.0 : fo[(int64_t)(top - 1) * 64 + lane];
+	const double xtop = fo[(int64_t)(top - 1) * 64 + lane];
 	double oldv = 0.0;
 	for (; p >= lo; --p) {
 		const int idx = p - 1;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 		rep_rows<REP>(btn, r);
 		dpp_guard(r);
 		double bnew = fdot64(r, row); // (a . e*B_{p+1})[k] = B_p[k] * d_p
-		if (!REPAIR && p == top) { // normalise the tile: posterior at `top` sums to one
+		if (p == top) { // normalise the tile: posterior at `top` sums to one (given this tile's X)
 			double rr[4];
 			rep_rows<REP>(xtop * bnew, rr);
 			const double kappa = 1.0 / wave_sum_rep(rr);
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], f[(c.off + c.lo - 2) * 64 + lane]);
 	} else {
 		check = !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST)) && min(c.hi, c.L - 1) >= c.lo && b + 1 < n_chunks;
-		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], bexit[(int64_t)(b + 1) * 64 + lane]);
+		if (check) m = rel_mismatch_dir(mine[(int64_t)b * 64 + lane], bexit[(int64_t)(b + 1) * 64 + lane]);
 	}
 	if (lane == 0) {
 		const int bad = check && !(m <= tol);

@@ -20,7 +20,8 @@ value its neighbour computed with a whole tile of history behind it; tiles
 whose mismatch exceeds `tol` are re-run from the neighbour's value until the new
 trajectory meets the stored one to `tol` again (or the tile ends, which may make
 the next tile dirty).  A backward tile is normalised once at its top so that
-the posterior sums to one; repaired tiles inherit the scale of the tile above.
+the posterior sums to one (also when repaired), so boundary vectors of two tiles
+are compared by direction only.
 """
 import numpy as np
 
@@ -117,20 +118,24 @@ def estep_fast_model(a, e, a0, segs, T=4096, W=2048, tol=None, stats=None):
                     bexit[c] = btn.copy()
         if tol is not None:
             while True:
+                # direction only: two tiles' scales differ by the per-tile posterior normalisation
                 dirty = [c for c in range(nc - 1)
                          if bexit[c + 1] is not None and bentry[c] is not None
-                         and _relmax(bentry[c], bexit[c + 1]) > tol]
+                         and _relmax(bentry[c] / np.abs(bentry[c]).sum(), bexit[c + 1] / np.abs(bexit[c + 1]).sum()) > tol]
                 if not dirty:
                     break
                 work["bwd_rounds"] += 1
                 for c in dirty:
                     lo, hi = tiles[c]
                     top = min(hi, L - 1)
-                    btn = bexit[c + 1].copy(); bentry[c] = btn.copy()
-                    bt[top + 1] = btn
+                    btn = bexit[c + 1].copy()
                     for p in range(top, lo - 1, -1):
                         bnew = bstep(btn, p)
                         work["bwd_steps"] += 1
+                        if p == top:  # re-normalise at the tile's own top, like the speculative pass
+                            kappa = 1.0 / (X[p] * bnew).sum()
+                            bnew *= kappa; btn = btn * kappa
+                            bt[top + 1] = btn; bentry[c] = btn.copy()
                         btn = e[o[p]] * bnew / d[p]
                         if p > lo:
                             done = _relmax(btn, bt[p]) <= tol

@@ -106,6 +106,11 @@ int psmc_hip_get_tables(psmc_hip_ctx *ctx, int seg, double *f, double *b, double
  * a positive bitmask of failed primitives otherwise. */
 int psmc_hip_selftest(int device);
 
+/* Diagnostic: shader cycles per operation of the FP64 building blocks (dependent
+ * and independent v_fmac_f64_dpp chains, row replication, f64 MFMA ...), one
+ * wave; see psmc_amd/csrc/microbench.hip for the meaning of out[0..13]. */
+int psmc_hip_microbench(int device, double *out, int n);
+
 /* Wall time in ms of the last E-step's kernels measured with HIP events on
  * the stream they ran on: [0] total, [1] forward, [2] backward, [3] expect,
  * [4] reductions. */

@@ -603,3 +603,22 @@ extern "C" int psmc_hip_selftest(int device)
 	(void)hipFree(d);
 	return rc;
 }
+
+extern "C" int psmc_hip_microbench(int device, double *out, int n)
+{
+	int nd = psmc_hip_device_count();
+	if (!out || n < 1) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	double *d = nullptr, h[64];
+	if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return PSMC_HIP_ENOMEM;
+	(void)hipMemset(d, 0, sizeof(h));
+	int rc = run_microbench(nullptr, d); // first launch warms the clocks / instruction cache
+	if (rc == 0) rc = run_microbench(nullptr, d);
+	if (rc == 0 && hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+		for (int i = 0; i < n && i < 64; ++i) out[i] = h[i];
+		rc = PSMC_HIP_OK;
+	} else rc = PSMC_HIP_EDEVICE;
+	(void)hipFree(d);
+	return rc;
+}

@@ -72,36 +72,6 @@ __device__ __forceinline__ double rel_mismatch_dir(double x, double y) {
 	return rel_mismatch(x / sx, y / sy);
 }
 
-// cached symbols for ascending / (symbol, inv_d) for descending bin indices:
-// one coalesced 64-wide load per 64 steps, prefetched one block ahead
-struct UpSyms {
-	const uint8_t *o; int lane, blk, symv, symn;
-	__device__ __forceinline__ void init(const uint8_t *o_, int lane_, int idx) {
-		o = o_; lane = lane_; blk = idx >> 6;
-		symv = o[(blk << 6) + lane]; symn = o[((blk + 1) << 6) + lane];
-	}
-	__device__ __forceinline__ int get(int idx) {
-		if ((idx >> 6) != blk) { blk = idx >> 6; symv = symn; symn = o[((blk + 1) << 6) + lane]; }
-		return __builtin_amdgcn_readlane(symv, idx & 63);
-	}
-};
-struct DownStream {
-	const uint8_t *o; const double *io; int lane, blk, symv, symn; double invv, invn;
-	__device__ __forceinline__ void fetch(int b, int &sv, double &iv) const {
-		const int i = (max(b, 0) << 6) + lane;
-		sv = o[i]; iv = io[i];
-	}
-	__device__ __forceinline__ void init(const uint8_t *o_, const double *io_, int lane_, int idx) {
-		o = o_; io = io_; lane = lane_; blk = idx >> 6;
-		fetch(blk, symv, invv); fetch(blk - 1, symn, invn);
-	}
-	__device__ __forceinline__ void seek(int idx) {
-		if ((idx >> 6) != blk) { blk = idx >> 6; symv = symn; invv = invn; fetch(blk - 1, symn, invn); }
-	}
-	__device__ __forceinline__ int sym(int idx) const { return __builtin_amdgcn_readlane(symv, idx & 63); }
-	__device__ __forceinline__ double inv(int idx) const { return readlane_f64(invv, idx & 63); }
-};
-
 // ------------------------------------------------------------------ forward
 // REPAIR=false: speculative pass over every tile.  REPAIR=true: only tiles the
 // verify kernel flagged; starts from the neighbour's stored X_{lo-1} and stops
@@ -139,29 +109,36 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
 			p = ws;
 		}
 	}
-	UpSyms us;
-	us.init(o, lane, p - 1);
-	double oldv = 0.0;
-	for (; p <= c.hi; ++p) {
-		const int idx = p - 1;
-		const int sym = us.get(idx);
-		if (p == c.lo) entry[(int64_t)blockIdx.x * 64 + lane] = x; // the X_{lo-1} this tile builds on
-		if (REPAIR && ((p - c.lo) & 15) == 0) // value currently stored at the end of this 16-bin block
-			oldv = fo[(int64_t)(min(p + 15, c.hi) - 1) * 64 + lane];
-		double r[4];
-		rep_rows<REP>(x, r);
-		dpp_guard(r);
-		const double sig = wave_sum_rep(r); // = s_{p-1} of the reference
-		const double inv = fast_rcp(sig);
-		const double acc = fdot64(r, col);
-		x = acc * (pick_ef(sym, e0, e1) * inv);
-		if (p >= c.lo) {
-			fo[(int64_t)idx * 64 + lane] = x;
-			if (lane == 0) { io[idx] = inv; dof[idx] = sig; }
-			if (REPAIR && (((p - c.lo) & 15) == 15 || p == c.hi)) {
-				if (rel_mismatch(x, oldv) <= tol) break; // met the stored trajectory: the rest is already right
+	// The sweep runs in blocks of 64 bins (one coalesced symbol load each, prefetched a block
+	// ahead).  Inside a block there is NO load, so the compiler places no s_waitcnt vmcnt in
+	// the step and the per-step global stores stay fire-and-forget.
+	int symn = o[(((p - 1) >> 6) << 6) + lane];
+	bool done = false;
+	while (p <= c.hi && !done) {
+		const int blk = (p - 1) >> 6;
+		const int symv = symn;
+		symn = o[((blk + 1) << 6) + lane];
+		const int pend = min(c.hi, (blk + 1) << 6); // last position of this block
+		double oldv = 0.0;
+		if (REPAIR) oldv = fo[(int64_t)(pend - 1) * 64 + lane]; // what is stored there now
+		for (; p <= pend; ++p) {
+			const int idx = p - 1;
+			const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
+			if (p == c.lo) entry[(int64_t)blockIdx.x * 64 + lane] = x; // the X_{lo-1} this tile builds on
+			double r[4];
+			rep_rows<REP>(x, r);
+			dpp_guard(r);
+			const double sig = wave_sum_rep(r); // = s_{p-1} of the reference
+			const double inv = fast_rcp(sig);
+			const double acc = fdot64(r, col);
+			x = acc * (pick_ef(sym, e0, e1) * inv);
+			if (p >= c.lo) {
+				fo[(int64_t)idx * 64 + lane] = x;
+				if (lane == 0) { io[idx] = inv; dof[idx] = sig; }
 			}
 		}
+		// met the stored trajectory: everything after this block is already right
+		if (REPAIR && rel_mismatch(x, oldv) <= tol) done = true;
 	}
 }
 
@@ -196,37 +173,49 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 		btn = pick_ef((int)o[q - 1], e0, e1);
 		p = q - 1;
 	}
-	DownStream ds;
-	ds.init(o, io, lane, p - 1);
 	const double xtop = fo[(int64_t)(top - 1) * 64 + lane];
-	double oldv = 0.0;
-	for (; p >= lo; --p) {
-		const int idx = p - 1;
-		ds.seek(idx);
-		const int sym = ds.sym(idx);
-		const double inv = ds.inv(idx);
-		if (REPAIR && ((top - p) & 15) == 0 && p > lo) // stored bt at the end of this 16-bin block
-			oldv = bto[(int64_t)(max(p - 15, lo + 1) - 1) * 64 + lane];
-		double r[4];
-		rep_rows<REP>(btn, r);
-		dpp_guard(r);
-		double bnew = fdot64(r, row); // (a . e*B_{p+1})[k] = B_p[k] * d_p
-		if (p == top) { // normalise the tile: posterior at `top` sums to one (given this tile's X)
-			double rr[4];
-			rep_rows<REP>(xtop * bnew, rr);
-			const double kappa = 1.0 / wave_sum_rep(rr);
-			bnew *= kappa; btn *= kappa;
-			bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
-			bentry[(int64_t)blockIdx.x * 64 + lane] = btn;
-		}
-		btn = bnew * (pick_ef(sym, e0, e1) * inv);
-		if (p <= top) {
-			if (p > lo || lo == 1) bto[(int64_t)idx * 64 + lane] = btn; // bt[p]; bt[lo>1] belongs to the tile below
-			if (p == lo) bexit[(int64_t)blockIdx.x * 64 + lane] = btn;
-			if (REPAIR && p > lo && (((top - p) & 15) == 15 || p == lo + 1)) {
-				if (rel_mismatch(btn, oldv) <= tol) break;
+	// blocks of 64 bins going down; (symbol, inv_d) of a block come from one coalesced load
+	// each, prefetched a block ahead; no load inside a block (see k_fwd_fast)
+	auto fetch = [&](int b, int &sv, double &iv) {
+		const int i = (max(b, 0) << 6) + lane;
+		sv = o[i]; iv = io[i];
+	};
+	int symn; double invn;
+	fetch((p - 1) >> 6, symn, invn);
+	bool done = false;
+	while (p >= lo && !done) {
+		const int blk = (p - 1) >> 6;
+		const int symv = symn; const double invv = invn;
+		fetch(blk - 1, symn, invn);
+		const int pbeg = max(lo, (blk << 6) + 1);  // lowest position of this block
+		const int pc = max(pbeg, lo + 1);          // lowest position of the block this tile stores bt for
+		double oldv = 0.0, chkv = 0.0;
+		const bool can_check = REPAIR && pc <= min(p, top);
+		if (can_check) oldv = bto[(int64_t)(pc - 1) * 64 + lane];
+		for (; p >= pbeg; --p) {
+			const int idx = p - 1;
+			const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
+			const double inv = readlane_f64(invv, idx & 63);
+			double r[4];
+			rep_rows<REP>(btn, r);
+			dpp_guard(r);
+			double bnew = fdot64(r, row); // (a . e*B_{p+1})[k] = B_p[k] * d_p
+			if (p == top) { // normalise the tile: posterior at `top` sums to one (given this tile's X)
+				double rr[4];
+				rep_rows<REP>(xtop * bnew, rr);
+				const double kappa = 1.0 / wave_sum_rep(rr);
+				bnew *= kappa; btn *= kappa;
+				bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
+				bentry[(int64_t)blockIdx.x * 64 + lane] = btn;
+			}
+			btn = bnew * (pick_ef(sym, e0, e1) * inv);
+			if (p <= top) {
+				if (p > lo || lo == 1) bto[(int64_t)idx * 64 + lane] = btn; // bt[p]; bt[lo>1] belongs to the tile below
+				if (p == lo) bexit[(int64_t)blockIdx.x * 64 + lane] = btn;
+				if (p == pc) chkv = btn;
 			}
 		}
+		if (can_check && rel_mismatch(chkv, oldv) <= tol) done = true;
 	}
 }
 

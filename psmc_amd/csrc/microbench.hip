@@ -1,0 +1,81 @@
+// microbench.hip -- instruction latency / issue-interval probes for the FP64
+// building blocks of the E-step kernels (one wave, s_memtime shader cycles).
+// Diagnostic only: psmc_hip_microbench() fills out[] with cycles per operation.
+#include <hip/hip_runtime.h>
+#include "wave_prims.h"
+#include "psmc_hip_internal.h"
+
+namespace psmc {
+
+#define REPEAT16(X) X X X X X X X X X X X X X X X X
+#define N_ITER 64
+
+template <int WHICH>
+__device__ __forceinline__ double probe(double x, double m)
+{
+	double a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
+	double r[4] = {x, x + 0.5, x + 0.25, x + 0.125};
+	dpp_guard(r);
+	for (int it = 0; it < N_ITER; ++it) {
+		if (WHICH == 0) { REPEAT16(fmac_bcast<3>(a0, r[0], m);) }                       // dependent fmac_dpp
+		else if (WHICH == 1) { REPEAT16(a0 = __builtin_fma(a0, m, x);) }                  // dependent v_fma_f64
+		else if (WHICH == 2) { REPEAT16(a0 = a0 + m;) }                                   // dependent v_add_f64
+		else if (WHICH == 3) {                                                            // 4 chains fmac_dpp
+			REPEAT16(fmac_bcast<3>(a0, r[0], m); fmac_bcast<3>(a1, r[1], m); fmac_bcast<3>(a2, r[2], m); fmac_bcast<3>(a3, r[3], m);)
+		} else if (WHICH == 4) {                                                          // 8 chains fmac_dpp
+			REPEAT16(fmac_bcast<3>(a0, r[0], m); fmac_bcast<3>(a1, r[1], m); fmac_bcast<3>(a2, r[2], m); fmac_bcast<3>(a3, r[3], m);
+			         fmac_bcast<5>(a4, r[0], m); fmac_bcast<5>(a5, r[1], m); fmac_bcast<5>(a6, r[2], m); fmac_bcast<5>(a7, r[3], m);)
+		} else if (WHICH == 5) {                                                          // dependent rep_rows_swap
+			REPEAT16(rep_rows_swap(a0, r); a0 = r[1];)
+		} else if (WHICH == 6) {                                                          // dependent rep_rows_bperm
+			REPEAT16(rep_rows_bperm(a0, r); a0 = r[1];)
+		} else if (WHICH == 7) { REPEAT16(a0 = a0 + dpp_mov<0xB1>(a0);) }                 // dpp_mov(2x32) + add
+		else if (WHICH == 8) { REPEAT16(a0 = __builtin_amdgcn_rcp(a0);) }                 // dependent v_rcp_f64
+		else if (WHICH == 9) { REPEAT16(a0 = bcast16<3>(a0) * m;) }                       // mov_b64_dpp + mul (exact mode term)
+		else if (WHICH == 10) { REPEAT16(a0 = a0 * m; a1 = a1 * m; a2 = a2 * m; a3 = a3 * m; a4 = a4 * m; a5 = a5 * m; a6 = a6 * m; a7 = a7 * m;) } // 8 indep v_mul_f64
+		else if (WHICH == 11) { REPEAT16(a0 = a0 / m;) }                                  // dependent IEEE division
+	}
+	return a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + r[0] + r[1] + r[2] + r[3];
+}
+
+typedef double d4m_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void k_microbench(double *out, double seed)
+{
+	const int lane = threadIdx.x;
+	double sink = 0.0;
+	const double x = seed + 1e-3 * lane, m = 1.0 + 1e-9 * lane;
+#define RUN(W, OPS)                                                        \
+	{                                                                      \
+		const unsigned long long t0 = __builtin_readcyclecounter();         \
+		const double v = probe<W>(x, m);                                    \
+		const unsigned long long t1 = __builtin_readcyclecounter();         \
+		sink += v;                                                          \
+		if (lane == 0) out[W] = (double)(t1 - t0) / (double)(N_ITER * 16 * (OPS)); \
+	}
+	RUN(0, 1) RUN(1, 1) RUN(2, 1) RUN(3, 4) RUN(4, 8) RUN(5, 1) RUN(6, 1) RUN(7, 1) RUN(8, 1) RUN(9, 1) RUN(10, 8) RUN(11, 1)
+	{ // f64 MFMA: dependent accumulate chain, and 4 independent accumulators
+		d4m_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+		unsigned long long t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER; ++it) { REPEAT16(c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c0, 0, 0, 0);) }
+		unsigned long long t1 = __builtin_readcyclecounter();
+		if (lane == 0) out[12] = (double)(t1 - t0) / (N_ITER * 16);
+		t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER; ++it) {
+			REPEAT16(c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c1, 0, 0, 0);
+			         c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c3, 0, 0, 0);)
+		}
+		t1 = __builtin_readcyclecounter();
+		if (lane == 0) out[13] = (double)(t1 - t0) / (N_ITER * 16 * 4);
+		sink += c0[0] + c1[1] + c2[2] + c3[3];
+	}
+	if (sink == 123.456) out[63] = sink;
+}
+
+int run_microbench(hipStream_t stream, double *d_out)
+{
+	hipLaunchKernelGGL(k_microbench, dim3(1), dim3(64), 0, stream, d_out, 0.37);
+	return (int)hipGetLastError();
+}
+
+} // namespace psmc

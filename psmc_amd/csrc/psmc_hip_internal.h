@@ -64,5 +64,6 @@ constexpr int RED_ROWS = 64;
 int launch_exact(const EstepLaunch &p);
 int launch_fast(const EstepLaunch &p, FastReport *rep);
 int run_selftest(hipStream_t stream, unsigned *d_flags);
+int run_microbench(hipStream_t stream, double *d_out);
 
 } // namespace psmc

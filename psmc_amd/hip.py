@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs",
-    "psmc_hip_get_tables", "psmc_hip_selftest", "psmc_hip_last_timing",
+    "psmc_hip_get_tables", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench",
 ]
 
 
@@ -222,3 +222,20 @@ class HipEStep:
 def selftest(device=0):
     lib = load_library()
     return lib.psmc_hip_selftest(int(device))
+
+
+MICROBENCH_NAMES = ["fmac_dpp dependent", "v_fma_f64 dependent", "v_add_f64 dependent", "fmac_dpp 4 chains (per op)",
+                    "fmac_dpp 8 chains (per op)", "rep_rows_swap dependent", "rep_rows_bperm dependent",
+                    "dpp_mov+add dependent", "v_rcp_f64 dependent", "mov_b64_dpp+mul dependent",
+                    "v_mul_f64 8 indep (per op)", "f64 division dependent", "mfma_f64_16x16x4 dependent",
+                    "mfma_f64_16x16x4 4 accumulators (per op)"]
+
+
+def microbench(device=0):
+    lib = load_library()
+    out = np.zeros(14)
+    lib.psmc_hip_microbench.argtypes = [C.c_int, _dp, C.c_int]
+    rc = lib.psmc_hip_microbench(int(device), _p(out), 14)
+    if rc != 0:
+        raise HipError("microbench: %s" % lib.psmc_hip_strerror(rc).decode())
+    return dict(zip(MICROBENCH_NAMES, out.tolist()))

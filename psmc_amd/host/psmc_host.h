@@ -1,0 +1,131 @@
+/* psmc_host.h -- host side of the MI355X PSMC driver: everything lh3/psmc does
+ * around the E-step (command line, .psmcfa input, model -> HMM parameters,
+ * Hooke-Jeeves M-step, .psmc output, bootstrap resampling, decoding output).
+ * The E-step itself is NOT here: it is reached through `psmc_estep_backend`,
+ * which the psmc binary binds to libpsmc_hip.so (include/psmc_hip.h).
+ *
+ * Written from scratch; evaluation order of every floating-point expression
+ * follows the reference so that, given bit-identical sufficient statistics,
+ * the .psmc output is byte-identical.  Citations are
+ * file:line in the lh3/psmc checkout.
+ */
+#ifndef PSMC_HOST_H
+#define PSMC_HOST_H
+#include <stdint.h>
+#include <stdio.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSMC_HOST_VERSION "0.6.5-r74-dirty" /* the MM Version line of the reference (cli.c:13), kept for byte parity */
+#define PSMC_N_FIXED 3        /* theta0, rho0, max_t precede the lambdas (psmc.h:12) */
+#define PSMC_T_INFINITY 1000.0 /* psmc.h:14 */
+
+/* ---- -p pattern (cli.c:66-99) */
+typedef struct {
+	int n_states; /* number of atomic intervals = psmc's n + 1 */
+	int n_free;   /* number of free lambda parameters */
+	int *group;   /* group[k] in [0,n_free): which lambda interval k uses (par_map) */
+} psmc_pattern;
+int  psmc_pattern_parse(const char *text, psmc_pattern *out); /* 0 ok, -1 malformed */
+void psmc_pattern_free(psmc_pattern *p);
+
+/* ---- .psmcfa input (cli.c:15-32, 103-138; kseq.h:172-223) */
+typedef struct {
+	char *name;
+	uint8_t *sym;    /* 0 hom, 1 het, 2 missing */
+	int32_t L;       /* bins */
+	int32_t L_called; /* bins that are not missing (L_e) */
+	int32_t n_het;   /* het bins (n_e) */
+} psmc_segment;
+typedef struct {
+	int n_seg;
+	psmc_segment *seg;
+	int64_t sum_called; /* sum of L_called: "sum_L" of the MM line */
+	int64_t sum_het;    /* "sum_n" */
+} psmc_input;
+int  psmc_input_read(const char *path, psmc_input *in); /* path "-" = stdin; gz or plain */
+void psmc_input_resample(psmc_input *in);                /* -b, aux.c:8-47 (drand48) */
+void psmc_input_free(psmc_input *in);
+uint8_t psmc_symbol_of(unsigned char c);                 /* the 256-entry table of cli.c:15-32 */
+
+/* ---- model: population parameters -> HMM parameters (core.c) */
+typedef struct {
+	psmc_pattern pat;
+	char *pattern_text;
+	double alpha;      /* -l, time-interval skew (cli.c:150) */
+	int has_dt;        /* divergence model (-T) */
+	double *fixed_t;   /* user time intervals from -i (inp_ti) or NULL */
+	int n_params;
+	double *params;    /* theta0, rho0, max_t, lambda[n_free], [dt] */
+	/* derived by psmc_model_update */
+	double *t;         /* n_states + 1 boundaries, t[n_states] = infinity */
+	double *sigma, *post_sigma;
+	double C_pi, C_sigma;
+	double *a, *e, *a0; /* n*n, 3*n (row 2 = 1), n */
+	/* EM bookkeeping printed every round */
+	double lk, Q0, Q1;
+} psmc_model;
+psmc_model *psmc_model_new(const psmc_pattern *pat, const char *pattern_text, double alpha, int has_dt);
+void psmc_model_free(psmc_model *m);
+void psmc_model_update(psmc_model *m);                       /* psmc_update_hmm, core.c:61-133 */
+void psmc_model_avg_t(const psmc_model *m, double *avg_t);   /* psmc_avg_t, core.c:135-162 */
+void psmc_model_cap(psmc_model *m, int k0);                  /* psmc_cap_matrix, aux.c:115-127 */
+
+/* ---- M-step pieces (khmm.c:326-382, kmin.c:48-107, em.c:15-25) */
+double psmc_Q0(int n, const double *A, const double *E);
+double psmc_Q(int n, const double *a, const double *e, const double *A, const double *E, double Q0);
+typedef double (*psmc_objective)(int n, double *x, void *data);
+double psmc_hooke_jeeves(psmc_objective f, int n, double *x, void *data, double r, double eps, int max_calls);
+
+/* ---- the E-step seam */
+typedef struct psmc_estep_backend {
+	void *self;
+	int  (*load)(void *self, int n_seg, const uint8_t *const *sym, const int32_t *L);
+	/* em.c:33-55: A n*n, E 2*n (hom, het), LL; returns 0 or an error code */
+	int  (*estep)(void *self, const double *a, const double *e, const double *a0, double *A, double *E, double *LL,
+	              double *chk);
+	/* hd->f, hd->b, hd->s of one segment, L*n / L*n / L (aux.c:157-158) */
+	int  (*tables)(void *self, int seg, double *f, double *b, double *s);
+	const char *(*error)(void *self);
+	void (*destroy)(void *self);
+} psmc_estep_backend;
+
+/* ---- run state + driver (main.c, em.c, aux.c) */
+typedef struct {
+	/* options, defaults of cli.c:142-154 */
+	int n_iters;      /* -N */
+	double max_t;     /* -t */
+	double tr_ratio;  /* -r */
+	double alpha;     /* -l */
+	double ran_init;  /* -I */
+	double dt0;       /* -T (<0: off) */
+	int cap_k;        /* -C */
+	int decode, full_decode, print_prob, simulate, bootstrap; /* -d -D -s -S -b */
+	char *pattern_text; /* -p */
+	char *param_file; /* -i */
+	char *cnt_file;   /* -c */
+	char *out_file;   /* -o */
+	char *in_file;
+	FILE *out;
+} psmc_options;
+void psmc_options_default(psmc_options *o);
+int  psmc_options_parse(psmc_options *o, int argc, char **argv); /* 0 ok, 1 usage printed */
+void psmc_options_free(psmc_options *o);
+
+/* Whole program given an E-step backend: header, RD 0, n_iters EM rounds,
+ * optional decoding / simulation.  Returns the process exit status. */
+int psmc_run(psmc_options *o, psmc_estep_backend *be);
+
+/* one EM round (psmc_em, em.c:27-78); prints the IT line to out */
+int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, FILE *out);
+void psmc_print_round(const psmc_model *m, int64_t sum_called, FILE *out); /* psmc_print_data, aux.c:49-82 */
+
+/* synthetic data for benchmarks: hmm_simulate-like draw (khmm.c:386-423) with our own RNG */
+void psmc_simulate_segment(int n, const double *a, const double *e, const double *a0, int32_t L, uint64_t seed,
+                           double miss_rate, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

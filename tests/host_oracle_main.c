@@ -1,0 +1,70 @@
+/* host_oracle_main.c -- TEST INFRASTRUCTURE.  The host driver (psmc_amd/host)
+ * with the CPU oracle injected as E-step backend, so that the host logic
+ * (command line, reader, model, M-step, writer, decoding output) can be checked
+ * byte for byte against the reference's golden .psmc files on a machine without
+ * a GPU.  Built by tests/test_host_cli.py; never shipped: the product binary
+ * (psmc_amd/host/psmc) has no such backend. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "psmc_host.h"
+#include "psmc_oracle.h"
+
+typedef struct { int n, n_seg; const uint8_t **sym; int32_t *L; double *a, *e, *a0; } orc_be;
+
+static int ob_load(void *self, int n_seg, const uint8_t *const *sym, const int32_t *L)
+{
+	orc_be *o = (orc_be *)self;
+	o->n_seg = n_seg;
+	o->sym = (const uint8_t **)malloc(sizeof(void *) * n_seg);
+	o->L = (int32_t *)malloc(sizeof(int32_t) * n_seg);
+	for (int i = 0; i < n_seg; ++i) { o->sym[i] = sym[i]; o->L[i] = L[i]; }
+	return 0;
+}
+static int ob_estep(void *self, const double *a, const double *e, const double *a0, double *A, double *E, double *LL, double *chk)
+{
+	orc_be *o = (orc_be *)self;
+	const int n = o->n;
+	memcpy(o->a, a, sizeof(double) * n * n); memcpy(o->e, e, sizeof(double) * 3 * n); memcpy(o->a0, a0, sizeof(double) * n);
+	double *c = (double *)malloc(sizeof(double) * o->n_seg);
+	orc_estep(n, a, e, a0, o->n_seg, o->sym, o->L, A, E, 0, LL, 0, 0, 0, c);
+	for (int i = 0; i < o->n_seg; ++i)
+		if (c[i] > 1.0 + 1e-6 || c[i] < 1.0 - 1e-6) fprintf(stderr, "++ Underflow may have happened (%lg).\n", c[i]);
+	if (chk) memcpy(chk, c, sizeof(double) * o->n_seg);
+	free(c);
+	return 0;
+}
+static int ob_tables(void *self, int seg, double *f, double *b, double *s)
+{
+	orc_be *o = (orc_be *)self;
+	const int n = o->n, L = o->L[seg];
+	double *ae = (double *)malloc(sizeof(double) * 3 * n * n);
+	double *ff = (double *)malloc(sizeof(double) * (size_t)(L + 1) * n), *bb = (double *)malloc(sizeof(double) * (size_t)(L + 1) * n);
+	double *ss = (double *)malloc(sizeof(double) * (size_t)(L + 1));
+	orc_pre_backward(n, o->a, o->e, ae);
+	orc_forward(n, o->a, o->e, o->a0, L, o->sym[seg], ff, ss);
+	orc_backward(n, ae, o->e, o->a0, L, o->sym[seg], ss, bb);
+	memcpy(f, ff + n, sizeof(double) * (size_t)L * n); memcpy(b, bb + n, sizeof(double) * (size_t)L * n);
+	memcpy(s, ss + 1, sizeof(double) * (size_t)L);
+	free(ae); free(ff); free(bb); free(ss);
+	return 0;
+}
+static const char *ob_error(void *self) { return "oracle backend"; }
+static void ob_destroy(void *self) {}
+
+int main(int argc, char **argv)
+{
+	psmc_options o;
+	psmc_options_default(&o);
+	if (psmc_options_parse(&o, argc, argv)) return 1;
+	psmc_pattern pat;
+	char str[256] = "4+5*3+4";
+	if (o.param_file) { FILE *fp = fopen(o.param_file, "r"); if (!fp || fscanf(fp, "%255s", str) != 1) return 1; fclose(fp); }
+	else if (o.pattern_text) snprintf(str, sizeof str, "%s", o.pattern_text);
+	if (psmc_pattern_parse(str, &pat)) return 1;
+	orc_be ob; memset(&ob, 0, sizeof ob);
+	ob.n = pat.n_states;
+	ob.a = (double *)malloc(sizeof(double) * ob.n * ob.n); ob.e = (double *)malloc(sizeof(double) * 3 * ob.n); ob.a0 = (double *)malloc(sizeof(double) * ob.n);
+	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, ob_error, ob_destroy};
+	return psmc_run(&o, &be);
+}

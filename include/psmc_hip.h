@@ -111,6 +111,11 @@ int psmc_hip_selftest(int device);
  * wave; see psmc_amd/csrc/microbench.hip for the meaning of out[0..13]. */
 int psmc_hip_microbench(int device, double *out, int n);
 
+/* Diagnostic: an 8-byte-per-lane streaming copy (reads and writes 8*n_doubles bytes, 5
+ * launches) to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the access
+ * width the kernels use; *ms_out = average duration of one launch. */
+int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out);
+
 /* Wall time in ms of the last E-step's kernels measured with HIP events on
  * the stream they ran on: [0] total, [1] forward, [2] backward, [3] expect,
  * [4] reductions. */

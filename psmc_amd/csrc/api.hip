@@ -622,3 +622,26 @@ extern "C" int psmc_hip_microbench(int device, double *out, int n)
 	(void)hipFree(d);
 	return rc;
 }
+
+extern "C" int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out)
+{
+	int nd = psmc_hip_device_count();
+	if (n_doubles < 1) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	double *a = nullptr, *b = nullptr;
+	if (hipMalloc((void **)&a, sizeof(double) * n_doubles) != hipSuccess) return PSMC_HIP_ENOMEM;
+	if (hipMalloc((void **)&b, sizeof(double) * n_doubles) != hipSuccess) { (void)hipFree(a); return PSMC_HIP_ENOMEM; }
+	(void)hipMemset(a, 0, sizeof(double) * n_doubles);
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	int rc = run_stream_probe(nullptr, a, b, (size_t)n_doubles); // warm
+	(void)hipEventRecord(e0, nullptr);
+	for (int i = 0; i < 4 && rc == 0; ++i) rc = run_stream_probe(nullptr, a, b, (size_t)n_doubles);
+	(void)hipEventRecord(e1, nullptr);
+	float ms = 0;
+	if (rc == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { if (ms_out) *ms_out = ms / 4; rc = PSMC_HIP_OK; }
+	else rc = PSMC_HIP_EDEVICE;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+	return rc;
+}

@@ -72,6 +72,18 @@ __global__ __launch_bounds__(64) void k_microbench(double *out, double seed)
 	if (sink == 123.456) out[63] = sink;
 }
 
+// 8-byte-per-lane streaming copy of a known size: calibrates the FETCH_SIZE / WRITE_SIZE
+// PMC counters for the access width the E-step kernels use (MI355X_MICROARCH.md, HBM section).
+__global__ __launch_bounds__(256) void k_stream_copy8(const double *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i] + 1.0;
+}
+int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n)
+{
+	hipLaunchKernelGGL(k_stream_copy8, dim3(8192), dim3(256), 0, stream, src, dst, n);
+	return (int)hipGetLastError();
+}
+
 int run_microbench(hipStream_t stream, double *d_out)
 {
 	hipLaunchKernelGGL(k_microbench, dim3(1), dim3(64), 0, stream, d_out, 0.37);

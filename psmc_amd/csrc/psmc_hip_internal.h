@@ -65,5 +65,6 @@ int launch_exact(const EstepLaunch &p);
 int launch_fast(const EstepLaunch &p, FastReport *rep);
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 int run_microbench(hipStream_t stream, double *d_out);
+int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n);
 
 } // namespace psmc

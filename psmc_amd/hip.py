@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs",
-    "psmc_hip_get_tables", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench",
+    "psmc_hip_get_tables", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe",
 ]
 
 
@@ -239,3 +239,14 @@ def microbench(device=0):
     if rc != 0:
         raise HipError("microbench: %s" % lib.psmc_hip_strerror(rc).decode())
     return dict(zip(MICROBENCH_NAMES, out.tolist()))
+
+
+def stream_probe(n_doubles=1 << 27, device=0):
+    """Known-size 8 B/lane copy (for PMC calibration); returns (ms per launch, GB/s read+write)."""
+    lib = load_library()
+    lib.psmc_hip_stream_probe.argtypes = [C.c_int, C.c_longlong, _dp]
+    ms = C.c_double(0)
+    rc = lib.psmc_hip_stream_probe(int(device), int(n_doubles), C.byref(ms))
+    if rc != 0:
+        raise HipError("stream_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+    return ms.value, 16.0 * n_doubles / (ms.value * 1e-3) / 1e9

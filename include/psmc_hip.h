@@ -117,9 +117,10 @@ int psmc_hip_microbench(int device, double *out, int n);
 int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out);
 
 /* Wall time in ms of the last E-step's kernels measured with HIP events on
- * the stream they ran on: [0] total, [1] forward, [2] backward, [3] expect,
- * [4] reductions. */
-int psmc_hip_last_timing(psmc_hip_ctx *ctx, double ms[5]);
+ * the stream they ran on: [0] total, [1] forward stage, [2] backward stage,
+ * [3] expect (+LL), [4] reductions; fast mode also [5] the speculative forward
+ * sweep kernel alone and [6] the speculative backward sweep kernel alone. */
+int psmc_hip_last_timing(psmc_hip_ctx *ctx, double ms[7]);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ struct psmc_hip_ctx {
 	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0
 	static constexpr size_t PAR_LEN = 4096 + 3 * 4096 + 3 * 64 + 64;
 	// tables
-	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr, *d_d = nullptr;
+	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr;
 	int64_t tab_bins = 0; bool have_b = false;
 	// exact outputs
 	double *d_segA = nullptr, *d_segE = nullptr, *d_segA0 = nullptr, *d_chk = nullptr;
@@ -62,8 +62,8 @@ struct psmc_hip_ctx {
 	double warm_err[2] = {0, 0};
 	// runtime
 	hipStream_t stream = nullptr;
-	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-	double last_ms[5] = {0, 0, 0, 0, 0};
+	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	double last_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 	bool timing_valid = false;
 };
 
@@ -126,7 +126,7 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (!c) return PSMC_HIP_ENOMEM;
 	c->n = n_states; c->device = device; c->mode = mode;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	for (int i = 0; i < 5; ++i)
+	for (int i = 0; i < 7; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipHostMalloc((void **)&c->h_par, psmc_hip_ctx::PAR_LEN * sizeof(double), hipHostMallocDefault) != hipSuccess ||
 	    hipMalloc((void **)&c->d_par, psmc_hip_ctx::PAR_LEN * sizeof(double)) != hipSuccess) {
@@ -145,11 +145,11 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_d, c->d_bentry, c->d_dirty, c->d_cnt};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-	for (int i = 0; i < 5; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 7; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -276,7 +276,6 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b)
 		int rc;
 		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) return rc;
-		if (c->mode == PSMC_HIP_MODE_FAST && (rc = dev_alloc(c, &c->d_d, (size_t)bins))) return rc;
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
 		c->have_b = false;
 		c->tab_bins = bins;
@@ -297,8 +296,8 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
-	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s; p.d_d = c->d_d;
-	for (int i = 0; i < 5; ++i) p.ev[i] = c->ev[i];
+	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s;
+	for (int i = 0; i < 7; ++i) p.ev[i] = c->mode == PSMC_HIP_MODE_FAST || i < 5 ? c->ev[i] : nullptr;
 }
 
 static void collect_timing(psmc_hip_ctx *c)
@@ -310,6 +309,11 @@ static void collect_timing(psmc_hip_ctx *c)
 		else { c->last_ms[i + 1] = 0; c->timing_valid = false; }
 	}
 	if (hipEventElapsedTime(&t, c->ev[0], c->ev[4]) == hipSuccess) c->last_ms[0] = t; else c->timing_valid = false;
+	c->last_ms[5] = c->last_ms[6] = 0;
+	if (c->mode == PSMC_HIP_MODE_FAST) { // the two speculative sweep kernels alone
+		if (hipEventElapsedTime(&t, c->ev[0], c->ev[5]) == hipSuccess) c->last_ms[5] = t;
+		if (hipEventElapsedTime(&t, c->ev[1], c->ev[6]) == hipSuccess) c->last_ms[6] = t;
+	}
 }
 
 // hmm_lk, khmm.c:245-260, on the host with the platform libm (same log() the
@@ -574,7 +578,7 @@ extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *
 	return PSMC_HIP_OK;
 }
 
-extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[5])
+extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[7])
 {
 	if (!c || !ms) return PSMC_HIP_EINVAL;
 	if (!c->timing_valid) {
@@ -583,7 +587,7 @@ extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[5])
 		collect_timing(c);
 		if (!c->timing_valid) return fail(c, PSMC_HIP_ESTATE, "last_timing: events incomplete");
 	}
-	for (int i = 0; i < 5; ++i) ms[i] = c->last_ms[i];
+	for (int i = 0; i < 7; ++i) ms[i] = c->last_ms[i];
 	return PSMC_HIP_OK;
 }
 

@@ -13,10 +13,13 @@
 //     in long runs of recent-coalescence states, so a fixed overlap is either
 //     wrong or 5x redundant.)
 //   * the 64-term dot products are 64 v_fmac_f64_dpp (row_newbcast operand
-//     broadcast; the transition column/row lives in 128 VGPRs per lane);
-//   * lagged normalisation: X_p = e[o_p]*(a^T X_{p-1}) / d_p, d_p = sum(X_{p-1}):
-//     the cross-lane reduction is off the sequential critical path; sum(X_p) is
-//     the reference's s_p and LL = sum_{p>=2} log d_p + log sum(X_L);
+//     broadcast straight from the natural-layout state register; 64 matrix entries
+//     in 128 VGPRs per lane; a 2-level permlane-swap transpose-reduce brings the
+//     result back to natural layout -- wave_prims.h matvec64_nat);
+//   * lagged, sparse normalisation: X_p = e[o_p]*(a^T X_{p-1}) / d_p with
+//     d_p = sum(X_{p-1}) when p % 4 == 0 and 1 otherwise: the cross-lane reduction
+//     is off the sequential critical path and paid every 4th bin only;
+//     LL = sum_p log d_p + log sum(X_L) telescopes for ANY positive d_p;
 //   * backward shares the divisors, B_p = a(e[o_{p+1}]*B_{p+1}) / d_p, stored as
 //     bt_p = e[o_p]*B_p, normalised once per tile so the posterior sums to one;
 //   * counts from the stored tables: C = sum_p X_p (x) bt_{p+1} is a K=bins GEMM
@@ -25,7 +28,7 @@
 //     order (deterministic, no atomics on the statistics).
 // tests/fastmodel.py is the executable numpy specification of this file.
 // HBM layout (g = seg_off + p - 1): X[g*64+k] (d_f), bt[g*64+k] (d_b),
-// inv_d[g] (d_s), d[g] (d_d), obs[g].
+// inv_d[g] = 1/d_p (d_s; written at p % 4 == 0 only), obs[g].
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
 #include "psmc_hip_internal.h"
@@ -81,17 +84,16 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
                                                    const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                    const Chunk *__restrict__ chunks, int W, double tol,
                                                    const int *__restrict__ dirty, double *__restrict__ f,
-                                                   double *__restrict__ invd, double *__restrict__ dd,
-                                                   double *__restrict__ entry)
+                                                   double *__restrict__ invd, double *__restrict__ entry)
 {
 	if (REPAIR && !dirty[blockIdx.x]) return;
+	if (REPAIR) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x];
 	const uint8_t *o = obs + c.off;
-	double *fo = f + c.off * 64, *io = invd + c.off, *dof = dd + c.off;
-	double col[64];
-#pragma unroll
-	for (int l = 0; l < 64; ++l) col[l] = a[l * 64 + lane];
+	double *fo = f + c.off * 64, *io = invd + c.off;
+	double A[64]; // A[16j+N] = a[16r+N][16j+m]
+	load_nat_matrix(a, lane, A);
 	const double e0 = e[lane], e1 = e[64 + lane];
 	double x;
 	int p;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
 		const int ws = max(1, c.lo - W);
 		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
 			x = a0[lane] * pick_ef((int)o[0], e0, e1);
-			if (c.lo == 1) { fo[lane] = x; if (lane == 0) { io[0] = 1.0; dof[0] = 1.0; } }
+			if (c.lo == 1) fo[lane] = x;
 			p = 2;
 		} else { // warm-up from the stationary prior
 			x = a0[lane];
@@ -125,17 +127,14 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
 			const int idx = p - 1;
 			const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
 			if (p == c.lo) entry[(int64_t)blockIdx.x * 64 + lane] = x; // the X_{lo-1} this tile builds on
-			double r[4];
-			rep_rows<REP>(x, r);
-			dpp_guard(r);
-			const double sig = wave_sum_rep(r); // = s_{p-1} of the reference
-			const double inv = fast_rcp(sig);
-			const double acc = fdot64(r, col);
-			x = acc * (pick_ef(sym, e0, e1) * inv);
-			if (p >= c.lo) {
-				fo[(int64_t)idx * 64 + lane] = x;
-				if (lane == 0) { io[idx] = inv; dof[idx] = sig; }
+			double ev = pick_ef(sym, e0, e1);
+			if ((p & (NORM_EVERY - 1)) == 0) { // d_p = sum(X_{p-1}), off the critical path
+				const double inv = fast_rcp(wave_sum_nat(x));
+				ev *= inv;
+				if (p >= c.lo && lane == 0) io[idx] = inv;
 			}
+			x = matvec64_nat(x, A) * ev;
+			if (p >= c.lo) fo[(int64_t)idx * 64 + lane] = x;
 		}
 		// met the stored trajectory: everything after this block is already right
 		if (REPAIR && rel_mismatch(x, oldv) <= tol) done = true;
@@ -152,6 +151,7 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
                                                    double *__restrict__ bexit)
 {
 	if (REPAIR && !dirty[blockIdx.x]) return;
+	if (REPAIR) __builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x];
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
@@ -159,9 +159,8 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 	const uint8_t *o = obs + c.off;
 	const double *fo = f + c.off * 64, *io = invd + c.off;
 	double *bto = bt + c.off * 64;
-	double row[64]; // a[k][l], k = lane
-#pragma unroll
-	for (int l = 0; l < 64; ++l) row[l] = aT[l * 64 + lane];
+	double A[64]; // A[16j+N] = a[16j+m][16r+N] = aT[16r+N][16j+m]
+	load_nat_matrix(aT, lane, A);
 	const double e0 = e[lane], e1 = e[64 + lane];
 	double btn; // e[o_{p+1}] * B_{p+1}, natural layout
 	int p;
@@ -195,20 +194,16 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 		for (; p >= pbeg; --p) {
 			const int idx = p - 1;
 			const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
-			const double inv = readlane_f64(invv, idx & 63);
-			double r[4];
-			rep_rows<REP>(btn, r);
-			dpp_guard(r);
-			double bnew = fdot64(r, row); // (a . e*B_{p+1})[k] = B_p[k] * d_p
+			double ev = pick_ef(sym, e0, e1);
+			if ((p & (NORM_EVERY - 1)) == 0) ev *= readlane_f64(invv, idx & 63); // the divisor forward used at p
+			double bnew = matvec64_nat(btn, A); // (a . e*B_{p+1})[k] = B_p[k] * d_p
 			if (p == top) { // normalise the tile: posterior at `top` sums to one (given this tile's X)
-				double rr[4];
-				rep_rows<REP>(xtop * bnew, rr);
-				const double kappa = 1.0 / wave_sum_rep(rr);
+				const double kappa = 1.0 / wave_sum_nat(xtop * bnew);
 				bnew *= kappa; btn *= kappa;
 				bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
 				bentry[(int64_t)blockIdx.x * 64 + lane] = btn;
 			}
-			btn = bnew * (pick_ef(sym, e0, e1) * inv);
+			btn = bnew * ev;
 			if (p <= top) {
 				if (p > lo || lo == 1) bto[(int64_t)idx * 64 + lane] = btn; // bt[p]; bt[lo>1] belongs to the tile below
 				if (p == lo) bexit[(int64_t)blockIdx.x * 64 + lane] = btn;
@@ -255,7 +250,7 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 //   D[(lane>>4)+4r][lane&15] = acc[r]
 __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
                                                          const uint8_t *__restrict__ obs, const double *__restrict__ f,
-                                                         const double *__restrict__ bt, const double *__restrict__ dd,
+                                                         const double *__restrict__ bt, const double *__restrict__ invd,
                                                          double *__restrict__ Cpart, double *__restrict__ Spart)
 {
 	const int lane = threadIdx.x, t = lane >> 4, i = lane & 15;
@@ -264,7 +259,7 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
 	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64 + i, *bo = bt + c.off * 64 + i, *dof = dd + c.off;
+	const double *fo = f + c.off * 64 + i, *bo = bt + c.off * 64 + i, *io = invd + c.off;
 	const uint8_t *o = obs + c.off;
 	d4_t acc[4][4];
 	double S[3][4];
@@ -281,7 +276,9 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 		const double *fr = fo + idx * 64, *br = bo + idx * 64;
 #pragma unroll
 		for (int m = 0; m < 4; ++m) { FA[m] = ok ? fr[16 * m] : 0.0; BP[m] = br[16 * m]; BM[m] = br[64 + 16 * m]; }
-		w = ok ? dof[idx] : 0.0;
+		double iv = 1.0; // d_p = 1/inv_d at the normalising positions, 1 elsewhere
+		if (ok && ((int)(idx + 1) & (NORM_EVERY - 1)) == 0) iv = io[idx];
+		w = ok ? 1.0 / iv : 0.0;
 		sym = o[idx];
 	};
 	if (p0 <= p1) {
@@ -334,7 +331,7 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 	fmac_bcast<N>(C[32 + N], r[2], X); fmac_bcast<N>(C[48 + N], r[3], X);
 __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ chunks, int n_sub,
                                                       const uint8_t *__restrict__ obs, const double *__restrict__ f,
-                                                      const double *__restrict__ bt, const double *__restrict__ dd,
+                                                      const double *__restrict__ bt, const double *__restrict__ invd,
                                                       double *__restrict__ Cpart, double *__restrict__ Spart)
 {
 	const int lane = threadIdx.x;
@@ -343,14 +340,15 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
 	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64, *bo = bt + c.off * 64, *dof = dd + c.off;
+	const double *fo = f + c.off * 64, *bo = bt + c.off * 64, *io = invd + c.off;
 	const uint8_t *o = obs + c.off;
 	double C[64], S0 = 0.0, S1 = 0.0, S2 = 0.0;
 #pragma unroll
 	for (int l = 0; l < 64; ++l) C[l] = 0.0;
 	for (int p = p0; p <= p1; ++p) {
 		const double X = fo[(int64_t)(p - 1) * 64 + lane];
-		const double g = X * bo[(int64_t)(p - 1) * 64 + lane] * dof[p - 1];
+		const double dp = (p & (NORM_EVERY - 1)) == 0 ? 1.0 / io[p - 1] : 1.0;
+		const double g = X * bo[(int64_t)(p - 1) * 64 + lane] * dp;
 		const int sym = o[p - 1];
 		if (sym == 0) S0 += g; else if (sym == 1) S1 += g; else S2 += g;
 		double r[4];
@@ -370,20 +368,21 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 }
 
 // ------------------------------------------------------------------ log-likelihood
-// LL of a tile = sum_{p in tile, p>=2} log d_p  (+ log sum(X_L) for the last tile):
-// running products flushed through log() like hmm_lk (khmm.c:245-260).
+// LL of a tile = sum over its normalising positions of log d_p = -log inv_d  (+ log sum(X_L)
+// for the last tile): running products flushed through log() like hmm_lk (khmm.c:245-260).
 __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, const double *__restrict__ f,
-                                             const double *__restrict__ dd, double *__restrict__ LLpart)
+                                             const double *__restrict__ invd, double *__restrict__ LLpart)
 {
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x];
-	const double *dof = dd + c.off;
+	const double *io = invd + c.off;
 	double prod = 1.0, ll = 0.0;
-	for (int p = max(c.lo, 2) + lane; p <= c.hi; p += 64) {
-		prod *= dof[p - 1];
-		if (prod < 1e-280) { ll += log(prod); prod = 1.0; }
+	const int first = (max(c.lo, 2) + NORM_EVERY - 1) & ~(NORM_EVERY - 1);
+	for (int p = first + NORM_EVERY * lane; p <= c.hi; p += NORM_EVERY * 64) {
+		prod *= io[p - 1];
+		if (prod > 1e280 || prod < 1e-280) { ll -= log(prod); prod = 1.0; }
 	}
-	ll += log(prod);
+	ll -= log(prod);
 	ll = wave_add(ll);
 	if (c.hi == c.L) ll += log(wave_add(f[(c.off + c.L - 1) * 64 + lane]));
 	if (lane == 0) LLpart[blockIdx.x] = ll * (double)c.mult;
@@ -453,10 +452,11 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	// ---- forward: speculate, then verify / repair until every boundary agrees
 	if (p.rep_impl == 0)
 		hipLaunchKernelGGL((k_fwd_fast<0, false>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
+		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
 	else
 		hipLaunchKernelGGL((k_fwd_fast<1, false>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
+		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
+	if (p.ev[5]) (void)hipEventRecord(p.ev[5], p.stream);
 	for (int round = 0;; ++round) {
 		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), p.stream);
 		(void)hipMemsetAsync(p.d_warm, 0, sizeof(unsigned long long), p.stream);
@@ -469,10 +469,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		rep->fwd_rounds++; rep->fwd_tiles += nd;
 		if (p.rep_impl == 0)
 			hipLaunchKernelGGL((k_fwd_fast<0, true>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
+			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
 		else
 			hipLaunchKernelGGL((k_fwd_fast<1, true>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_d, p.d_entry);
+			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
 	}
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], p.stream);
 	// ---- backward
@@ -482,6 +482,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	else
 		hipLaunchKernelGGL((k_bwd_fast<1, false>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
 		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
+	if (p.ev[6]) (void)hipEventRecord(p.ev[6], p.stream);
 	for (int round = 0;; ++round) {
 		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), p.stream);
 		(void)hipMemsetAsync(p.d_warm + 1, 0, sizeof(unsigned long long), p.stream);
@@ -503,12 +504,12 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	// ---- counts + log-likelihood from the stored tables
 	const int nC = p.n_chunks * p.n_sub;
 	if (p.expect_impl == 0)
-		hipLaunchKernelGGL(k_expect_valu, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_d,
+		hipLaunchKernelGGL(k_expect_valu, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
 		                   p.d_Cpart, p.d_Epart);
 	else
-		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_d,
+		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
 		                   p.d_Cpart, p.d_Epart);
-	hipLaunchKernelGGL(k_ll, g, b, 0, p.stream, p.d_chunks, p.d_f, p.d_d, p.d_LLpart);
+	hipLaunchKernelGGL(k_ll, g, b, 0, p.stream, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], p.stream);
 	hipLaunchKernelGGL(k_reduce1, dim3(17, RED_ROWS), dim3(256), 0, p.stream, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
 	                   p.n_chunks, p.d_stage);

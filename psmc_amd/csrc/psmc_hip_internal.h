@@ -5,7 +5,8 @@
 
 namespace psmc {
 
-constexpr int NS = 64;          // padded number of states (one wave lane per state)
+constexpr int NS = 64;
+constexpr int NORM_EVERY = 4;   // fast mode rescales the forward vector at positions p % NORM_EVERY == 0          // padded number of states (one wave lane per state)
 constexpr int STATS_LEN = NS * NS + 3 * NS + 1; // padded device stats: C/A | E[3] | LL
 
 // One tile of one segment (fast mode).  Positions are 1-based like khmm.c.
@@ -40,7 +41,6 @@ struct EstepLaunch {
 	const int32_t *d_work; // exact: unique selected segment ids
 	int n_work;
 	double *d_f, *d_b, *d_s; // exact: f,b tables + s; fast: f = X (lag-normalised), d_b = bt, d_s = inv_d
-	double *d_d;             // fast: d_p = sum(X_{p-1})
 	// exact outputs
 	double *d_segA, *d_segE, *d_segA0, *d_chk;
 	// fast
@@ -56,7 +56,7 @@ struct EstepLaunch {
 	double *d_stats;            // [n*n + 2n + 1] final, unpadded [A | E | LL]
 	unsigned long long *d_warm; // [2] max warm-up mismatch (double bits)
 	double tiny_total;          // n_selected_segments * HMM_TINY
-	hipEvent_t ev[5];           // optional timing marks (may be null)
+	hipEvent_t ev[7];           // optional timing marks (may be null): 0..4 stage ends, 5/6 after the speculative sweeps
 };
 
 constexpr int RED_ROWS = 64;

@@ -60,6 +60,20 @@ __global__ __launch_bounds__(64) void k_selftest(unsigned *flags)
 		double wf = fdot64(r, m);
 		if (fabs(wf - want) > 1e-13 * fabs(want)) bad |= 128u;
 	}
+	{ // natural-layout matvec and wave sum
+		double Mreg[64];
+		// M[l][k] = 1/(1 + l + 0.37 k): load the lane's 64 entries exactly like load_nat_matrix would
+		const int rr = lane >> 4, mm = lane & 15;
+		for (int j = 0; j < 4; ++j)
+			for (int N = 0; N < 16; ++N) Mreg[16 * j + N] = 1.0 / (1.0 + (16 * rr + N) + 0.37 * (16 * j + mm));
+		double want = 0.0;
+		for (int l = 0; l < 64; ++l) want = __builtin_fma(sh[l], 1.0 / (1.0 + l + 0.37 * lane), want);
+		const double got = matvec64_nat(x, Mreg);
+		if (fabs(got - want) > 1e-13 * fabs(want)) bad |= 512u;
+		double seq = 0.0;
+		for (int k = 0; k < 64; ++k) seq = seq + sh[k];
+		if (fabs(wave_sum_nat(x) - seq) > 1e-13 * fabs(seq)) bad |= 1024u;
+	}
 	{ // f64 MFMA 16x16x4 operand / result lane mapping
 		const int t = lane >> 4, i = lane & 15;
 		const double A = 0.5 * i + 3.0 * t + 1.0;   // A[i][t]

@@ -142,6 +142,64 @@ __device__ __forceinline__ double fdot64(const double (&r)[4], const double (&m)
 	return (c0 + c1) + (c2 + c3);
 }
 
+// ---- natural-layout matvec (fast mode) -----------------------------------------------
+// y[k] = sum_l x[l] * M[l][k] with x AND y in natural layout and no replication step:
+// lane (r,m) (row r = lane>>4, m = lane&15) accumulates, for each of the four output groups
+// j, the partial sum over ITS OWN input block r:  P_j = sum_N x[16r+N] * A[16j+N],
+// A[16j+N] = M[16r+N][16j+m]  (row_newbcast:N reads x[16r+N] straight from the natural
+// register).  The four partials are then transposed-and-reduced across rows with the
+// gfx950 permlane swaps:
+//   swap16(P0,P1): P0=(P0.r0,P1.r0,P0.r2,P1.r2) P1=(P0.r1,P1.r1,P0.r3,P1.r3); S01=P0+P1
+//   swap16(P2,P3) likewise -> S23;  swap32(S01,S23): rows 2,3 of S01 <-> rows 0,1 of S23;
+//   y = S01+S23 has row j = sum_r P_j.r = y[16j+m]: natural layout again.
+__device__ __forceinline__ void swap16_f64(double &a, double &b) {
+	const u32x2_t l = __builtin_amdgcn_permlane16_swap(f64_lo(a), f64_lo(b), false, false);
+	const u32x2_t h = __builtin_amdgcn_permlane16_swap(f64_hi(a), f64_hi(b), false, false);
+	a = f64_mk(l.x, h.x); b = f64_mk(l.y, h.y);
+}
+__device__ __forceinline__ void swap32_f64(double &a, double &b) {
+	const u32x2_t l = __builtin_amdgcn_permlane32_swap(f64_lo(a), f64_lo(b), false, false);
+	const u32x2_t h = __builtin_amdgcn_permlane32_swap(f64_hi(a), f64_hi(b), false, false);
+	a = f64_mk(l.x, h.x); b = f64_mk(l.y, h.y);
+}
+#define PSMC_NDOT4(N)                                                  \
+	fmac_bcast<N>(p0, x, A[N]);      fmac_bcast<N>(p1, x, A[16 + N]);      \
+	fmac_bcast<N>(p2, x, A[32 + N]); fmac_bcast<N>(p3, x, A[48 + N]);
+__device__ __forceinline__ double matvec64_nat(double x, const double (&A)[64]) {
+	double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+	asm volatile("s_nop 1" : "+v"(x)); // VALU write of x -> DPP read: 2 wait states
+	PSMC_NDOT4(0) PSMC_NDOT4(1) PSMC_NDOT4(2) PSMC_NDOT4(3) PSMC_NDOT4(4) PSMC_NDOT4(5)
+	PSMC_NDOT4(6) PSMC_NDOT4(7) PSMC_NDOT4(8) PSMC_NDOT4(9) PSMC_NDOT4(10) PSMC_NDOT4(11)
+	PSMC_NDOT4(12) PSMC_NDOT4(13) PSMC_NDOT4(14) PSMC_NDOT4(15)
+	swap16_f64(p0, p1);
+	swap16_f64(p2, p3);
+	double s01 = p0 + p1, s23 = p2 + p3;
+	swap32_f64(s01, s23);
+	return s01 + s23;
+}
+// register image of a 64x64 matrix M (row-major, M[l*64+k]) for matvec64_nat
+__device__ __forceinline__ void load_nat_matrix(const double *__restrict__ M, int lane, double (&A)[64]) {
+	const int r = lane >> 4, m = lane & 15;
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+#pragma unroll
+		for (int N = 0; N < 16; ++N) A[16 * j + N] = M[(16 * r + N) * 64 + 16 * j + m];
+}
+// sum over all 64 lanes of a natural-layout value; every lane gets the total (tree order)
+__device__ __forceinline__ double wave_sum_nat(double x) {
+	double t = x;
+	t = t + dpp_mov<0xB1>(t);  // quad_perm:[1,0,3,2]
+	t = t + dpp_mov<0x4E>(t);  // quad_perm:[2,3,0,1]
+	t = t + dpp_mov<0x124>(t); // row_ror:4
+	t = t + dpp_mov<0x128>(t); // row_ror:8   -> row sums
+	double c = t;
+	swap16_f64(t, c);
+	t = t + c;                 // (t0+t1, t0+t1, t2+t3, t2+t3)
+	c = t;
+	swap32_f64(t, c);
+	return t + c;
+}
+
 // wave-uniform double out of a VGPR lane (lane index may be a runtime scalar)
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
 	return f64_mk((unsigned)__builtin_amdgcn_readlane((int)f64_lo(v), lane),

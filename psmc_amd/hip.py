@@ -214,9 +214,10 @@ class HipEStep:
         return f, b, s
 
     def timing(self):
-        ms = np.zeros(5)
+        ms = np.zeros(7)
         self._chk(self.lib.psmc_hip_last_timing(self.h, _p(ms)), "last_timing")
-        return dict(total=ms[0], forward=ms[1], backward=ms[2], expect=ms[3], reduce=ms[4])
+        return dict(total=ms[0], forward=ms[1], backward=ms[2], expect=ms[3], reduce=ms[4],
+                    fwd_sweep=ms[5], bwd_sweep=ms[6])
 
 
 def selftest(device=0):

@@ -48,7 +48,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 
 /* Tunables (all optional): "chunk" (fast-mode tile length in bins, 0 = auto),
  * "warmup" (speculative overlap in bins), "warm_tol" (tile-boundary agreement
- * demanded by verify/repair), "max_rounds", "target_waves", "n_sub" (expect
+ * demanded by verify/repair), "max_rounds", "overlap" (1: run repair rounds
+ * beside the next bulk phase on a second stream), "target_waves", "n_sub" (expect
  * waves per tile), "rep_impl" (0 ds_bpermute, 1 v_permlane*_swap),
  * "expect_impl" (0 VALU, 1 MFMA f64). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);

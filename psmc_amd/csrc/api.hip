@@ -21,7 +21,7 @@ struct psmc_hip_ctx {
 	int n = 0, device = 0, mode = PSMC_HIP_MODE_EXACT;
 	std::string err;
 	// options
-	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 4, target_waves = 2048;
+	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 4, target_waves = 2048, overlap = 1;
 	double warm_tol = 1e-12;
 	// segments
 	int n_seg = 0;
@@ -55,7 +55,9 @@ struct psmc_hip_ctx {
 	int chunk_cap = 0, chunk_used = 0;
 	double *d_entry = nullptr, *d_bentry = nullptr, *d_bexit = nullptr, *d_Cpart = nullptr, *d_Epart = nullptr,
 	       *d_LLpart = nullptr;
-	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr;
+	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
+	hipStream_t stream2 = nullptr;
+	hipEvent_t evx[4] = {nullptr, nullptr, nullptr, nullptr};
 	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
 	unsigned long long *d_warm = nullptr;
@@ -126,6 +128,9 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (!c) return PSMC_HIP_ENOMEM;
 	c->n = n_states; c->device = device; c->mode = mode;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	for (int i = 0; i < 4; ++i)
+		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 7; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipHostMalloc((void **)&c->h_par, psmc_hip_ctx::PAR_LEN * sizeof(double), hipHostMallocDefault) != hipSuccess ||
@@ -142,14 +147,17 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	for (int i = 0; i < 7; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 4; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -161,6 +169,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
 	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
 	else if (k == "max_rounds") c->max_rounds = (int)v;
+	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
 	else if (k == "expect_impl") c->expect_impl = v != 0 ? 1 : 0;
@@ -312,7 +321,8 @@ static void collect_timing(psmc_hip_ctx *c)
 	c->last_ms[5] = c->last_ms[6] = 0;
 	if (c->mode == PSMC_HIP_MODE_FAST) { // the two speculative sweep kernels alone
 		if (hipEventElapsedTime(&t, c->ev[0], c->ev[5]) == hipSuccess) c->last_ms[5] = t;
-		if (hipEventElapsedTime(&t, c->ev[1], c->ev[6]) == hipSuccess) c->last_ms[6] = t;
+		if (c->overlap) { if (hipEventElapsedTime(&t, c->evx[0], c->evx[1]) == hipSuccess) c->last_ms[6] = t; } // ran on the second stream
+		else if (hipEventElapsedTime(&t, c->ev[1], c->ev[6]) == hipSuccess) c->last_ms[6] = t;
 	}
 }
 
@@ -447,6 +457,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)(nc + 1) * 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bentry, (size_t)nc * 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_touch, (size_t)3 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
 		c->chunk_cap = nc;
 	}
@@ -479,6 +490,9 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub;
 	p.d_entry = c->d_entry; p.d_bentry = c->d_bentry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
 	p.d_dirty = c->d_dirty; p.d_cnt = c->d_cnt; p.h_cnt = c->h_cnt; p.tol = c->warm_tol; p.max_rounds = c->max_rounds;
+	p.d_touch_f = c->d_touch; p.d_touch_b = c->d_touch + p.n_chunks; p.d_force_b = c->d_touch + 2 * p.n_chunks;
+	p.stream2 = c->stream2; p.overlap = c->overlap;
+	for (int i = 0; i < 4; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
 	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());

@@ -84,11 +84,13 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
                                                    const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                    const Chunk *__restrict__ chunks, int W, double tol,
                                                    const int *__restrict__ dirty, double *__restrict__ f,
-                                                   double *__restrict__ invd, double *__restrict__ entry)
+                                                   double *__restrict__ invd, double *__restrict__ entry,
+                                                   int *__restrict__ touch_f, int *__restrict__ force_b)
 {
 	if (REPAIR && !dirty[blockIdx.x]) return;
 	if (REPAIR) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	const int lane = threadIdx.x;
+	if (REPAIR && lane == 0) { touch_f[blockIdx.x] = 1; force_b[blockIdx.x] = 1; } // X / inv_d of this tile change
 	const Chunk c = chunks[blockIdx.x];
 	const uint8_t *o = obs + c.off;
 	double *fo = f + c.off * 64, *io = invd + c.off;
@@ -148,11 +150,13 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
                                                    int W, double tol, const int *__restrict__ dirty,
                                                    const double *__restrict__ f, const double *__restrict__ invd,
                                                    double *__restrict__ bt, double *__restrict__ bentry,
-                                                   double *__restrict__ bexit)
+                                                   double *__restrict__ bexit, int *__restrict__ touch_b,
+                                                   int *__restrict__ force_b)
 {
 	if (REPAIR && !dirty[blockIdx.x]) return;
 	if (REPAIR) __builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
+	if (REPAIR && lane == 0) { touch_b[blockIdx.x] = 1; force_b[blockIdx.x] = 0; }
 	const Chunk c = chunks[blockIdx.x];
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
 	if (top < lo) return; // a tile holding only position L owns no transition
@@ -164,10 +168,10 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 	const double e0 = e[lane], e1 = e[64 + lane];
 	double btn; // e[o_{p+1}] * B_{p+1}, natural layout
 	int p;
-	if (REPAIR) { // continue from the value the tile above computed at our top boundary
+	if (REPAIR && !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST))) { // continue from the value the tile above computed at our top boundary
 		btn = bexit[(int64_t)(blockIdx.x + 1) * 64 + lane];
 		p = top;
-	} else {
+	} else { // speculative start; also the redo of a tile anchored at the true segment end
 		const int q = min(c.hi + W + 1, L); // B_q := 1
 		btn = pick_ef((int)o[q - 1], e0, e1);
 		p = q - 1;
@@ -221,7 +225,8 @@ template <bool BWD>
 __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks, int n_chunks, double tol,
                                                  const double *__restrict__ f, const double *__restrict__ mine,
                                                  const double *__restrict__ bexit, int *__restrict__ dirty,
-                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm)
+                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm,
+                                                 const int *__restrict__ force_b)
 {
 	const int lane = threadIdx.x, b = blockIdx.x;
 	const Chunk c = chunks[b];
@@ -235,7 +240,10 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 		if (check) m = rel_mismatch_dir(mine[(int64_t)b * 64 + lane], bexit[(int64_t)(b + 1) * 64 + lane]);
 	}
 	if (lane == 0) {
-		const int bad = check && !(m <= tol);
+		// a tile whose X / inv_d were rewritten by a forward repair after (or while) its backward
+		// sweep ran must redo that sweep, whatever its boundary looks like
+		const bool forced = BWD && force_b[b] && min(c.hi, c.L - 1) >= c.lo;
+		const int bad = (check && !(m <= tol)) || forced;
 		dirty[b] = bad;
 		if (bad) atomicAdd(&cnt[0], 1);
 		if (check) atomicMax(&warm[BWD ? 1 : 0], (unsigned long long)__double_as_longlong(m));
@@ -243,6 +251,16 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 }
 
 // ------------------------------------------------------------------ expect
+// Inputs of a tile's counts that a repair may have rewritten after an early expect pass:
+// X / inv_d (forward repair of the tile), bt[lo+1..top+1] (its backward repair) and bt[lo]
+// (stored by the tile below as its top boundary value).
+__device__ __forceinline__ bool tile_touched(const Chunk *__restrict__ chunks, int b, const int *__restrict__ touch_f,
+                                             const int *__restrict__ touch_b)
+{
+	bool t = touch_f[b] || touch_b[b];
+	if (b > 0 && chunks[b - 1].off == chunks[b].off) t = t || touch_b[b - 1];
+	return t;
+}
 // C[k][l] += sum_p X_p[k] * bt_{p+1}[l] and S[o_p][k] += d_p X_p[k] bt_p[k] over the
 // tile's positions lo..min(hi,L-1), split over n_sub waves.  FP64 matrix cores:
 // D(16x16) += A(16x4) B(4x16) with
@@ -251,10 +269,13 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
                                                          const uint8_t *__restrict__ obs, const double *__restrict__ f,
                                                          const double *__restrict__ bt, const double *__restrict__ invd,
-                                                         double *__restrict__ Cpart, double *__restrict__ Spart)
+                                                         double *__restrict__ Cpart, double *__restrict__ Spart,
+                                                         const int *__restrict__ touch_f, const int *__restrict__ touch_b,
+                                                         int redo)
 {
 	const int lane = threadIdx.x, t = lane >> 4, i = lane & 15;
 	const Chunk c = chunks[blockIdx.x / n_sub];
+	if (redo && !tile_touched(chunks, blockIdx.x / n_sub, touch_f, touch_b)) return;
 	const int sub = blockIdx.x % n_sub;
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
@@ -332,10 +353,13 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ chunks, int n_sub,
                                                       const uint8_t *__restrict__ obs, const double *__restrict__ f,
                                                       const double *__restrict__ bt, const double *__restrict__ invd,
-                                                      double *__restrict__ Cpart, double *__restrict__ Spart)
+                                                      double *__restrict__ Cpart, double *__restrict__ Spart,
+                                                      const int *__restrict__ touch_f, const int *__restrict__ touch_b,
+                                                      int redo)
 {
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x / n_sub];
+	if (redo && !tile_touched(chunks, blockIdx.x / n_sub, touch_f, touch_b)) return;
 	const int sub = blockIdx.x % n_sub;
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
@@ -440,82 +464,116 @@ static int read_count(const EstepLaunch &p, int *n)
 	return 0;
 }
 
+template <bool REPAIR>
+static void launch_fwd(const EstepLaunch &p, hipStream_t st)
+{
+	const dim3 g(p.n_chunks), b(64);
+	if (p.rep_impl == 0)
+		hipLaunchKernelGGL((k_fwd_fast<0, REPAIR>), g, b, 0, st, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.warmup,
+		                   p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry, p.d_touch_f, p.d_force_b);
+	else
+		hipLaunchKernelGGL((k_fwd_fast<1, REPAIR>), g, b, 0, st, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.warmup,
+		                   p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry, p.d_touch_f, p.d_force_b);
+}
+template <bool REPAIR>
+static void launch_bwd(const EstepLaunch &p, hipStream_t st)
+{
+	const dim3 g(p.n_chunks), b(64);
+	const double *aT = p.d_aeT + 2 * 4096;
+	if (p.rep_impl == 0)
+		hipLaunchKernelGGL((k_bwd_fast<0, REPAIR>), g, b, 0, st, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
+		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit, p.d_touch_b, p.d_force_b);
+	else
+		hipLaunchKernelGGL((k_bwd_fast<1, REPAIR>), g, b, 0, st, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
+		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit, p.d_touch_b, p.d_force_b);
+}
+static void launch_expect(const EstepLaunch &p, hipStream_t st, int redo)
+{
+	const int nC = p.n_chunks * p.n_sub;
+	if (p.expect_impl == 0)
+		hipLaunchKernelGGL(k_expect_valu, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
+		                   p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
+	else
+		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
+		                   p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
+}
+
+// One fast-mode E-step.  With p.overlap the low-occupancy repair rounds (a few dozen
+// latency-bound waves) are overlapped with the next bulk phase on a second stream:
+//   main: fwd speculate | fwd verify/repair ............ | bwd verify/repair ........ | expect(redo) reduce
+//   aux :               | bwd speculate (maybe stale in) | k_ll, expect (all tiles)   |
+// Anything that consumed data a repair later rewrote is recomputed: forward-repaired tiles
+// are force-flagged for the backward repair, and tiles whose X / bt / inv_d changed after the
+// early expect pass are re-run (their per-wave partials are simply overwritten).
 int launch_fast(const EstepLaunch &p, FastReport *rep)
 {
 	if (p.n_chunks <= 0) return 0;
 	const dim3 g(p.n_chunks), b(64);
-	const double *aT = p.d_aeT + 2 * 4096;
+	hipStream_t sm = p.stream, sa = p.overlap ? p.stream2 : p.stream;
 	rep->fwd_rounds = rep->bwd_rounds = rep->fwd_tiles = rep->bwd_tiles = 0;
 	rep->converged = 1;
-	(void)hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), p.stream);
-	if (p.ev[0]) (void)hipEventRecord(p.ev[0], p.stream);
-	// ---- forward: speculate, then verify / repair until every boundary agrees
-	if (p.rep_impl == 0)
-		hipLaunchKernelGGL((k_fwd_fast<0, false>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
-	else
-		hipLaunchKernelGGL((k_fwd_fast<1, false>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-		                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
-	if (p.ev[5]) (void)hipEventRecord(p.ev[5], p.stream);
+	(void)hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), sm);
+	(void)hipMemsetAsync(p.d_touch_f, 0, 3 * sizeof(int) * (size_t)p.n_chunks, sm); // touch_f | touch_b | force_b
+	if (p.ev[0]) (void)hipEventRecord(p.ev[0], sm);
+	// ---- forward: speculate
+	launch_fwd<false>(p, sm);
+	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
+	// ---- backward speculation may start as soon as the forward tables exist
+	if (p.overlap) { (void)hipEventRecord(p.evx[0], sm); (void)hipStreamWaitEvent(sa, p.evx[0], 0); launch_bwd<false>(p, sa); (void)hipEventRecord(p.evx[1], sa); }
+	// ---- forward: verify / repair until every boundary agrees
 	for (int round = 0;; ++round) {
-		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), p.stream);
-		(void)hipMemsetAsync(p.d_warm, 0, sizeof(unsigned long long), p.stream);
-		hipLaunchKernelGGL((k_verify<false>), g, b, 0, p.stream, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry,
-		                   p.d_bexit, p.d_dirty, p.d_cnt, p.d_warm);
+		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), sm);
+		(void)hipMemsetAsync(p.d_warm, 0, sizeof(unsigned long long), sm);
+		hipLaunchKernelGGL((k_verify<false>), g, b, 0, sm, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry, p.d_bexit,
+		                   p.d_dirty, p.d_cnt, p.d_warm, p.d_force_b);
 		int nd = 0;
 		if (read_count(p, &nd)) return -1;
 		if (nd == 0) break;
 		if (round >= p.max_rounds) { rep->converged = 0; break; }
 		rep->fwd_rounds++; rep->fwd_tiles += nd;
-		if (p.rep_impl == 0)
-			hipLaunchKernelGGL((k_fwd_fast<0, true>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
-		else
-			hipLaunchKernelGGL((k_fwd_fast<1, true>), g, b, 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-			                   p.warmup, p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry);
+		launch_fwd<true>(p, sm);
 	}
-	if (p.ev[1]) (void)hipEventRecord(p.ev[1], p.stream);
-	// ---- backward
-	if (p.rep_impl == 0)
-		hipLaunchKernelGGL((k_bwd_fast<0, false>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
-		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
-	else
-		hipLaunchKernelGGL((k_bwd_fast<1, false>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
-		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
-	if (p.ev[6]) (void)hipEventRecord(p.ev[6], p.stream);
+	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
+	if (p.overlap) {
+		(void)hipStreamWaitEvent(sm, p.evx[1], 0);          // backward speculation finished
+		(void)hipEventRecord(p.evx[2], sm);                 // forward tables final
+		(void)hipStreamWaitEvent(sa, p.evx[2], 0);
+		hipLaunchKernelGGL(k_ll, g, b, 0, sa, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
+		launch_expect(p, sa, 0);                            // early pass over every tile
+		(void)hipEventRecord(p.evx[3], sa);
+	} else {
+		launch_bwd<false>(p, sm);
+	}
+	if (p.ev[6]) (void)hipEventRecord(p.ev[6], sm);
+	// ---- backward: verify / repair
 	for (int round = 0;; ++round) {
-		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), p.stream);
-		(void)hipMemsetAsync(p.d_warm + 1, 0, sizeof(unsigned long long), p.stream);
-		hipLaunchKernelGGL((k_verify<true>), g, b, 0, p.stream, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry,
-		                   p.d_bexit, p.d_dirty, p.d_cnt, p.d_warm);
+		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), sm);
+		(void)hipMemsetAsync(p.d_warm + 1, 0, sizeof(unsigned long long), sm);
+		hipLaunchKernelGGL((k_verify<true>), g, b, 0, sm, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
+		                   p.d_dirty, p.d_cnt, p.d_warm, p.d_force_b);
 		int nd = 0;
 		if (read_count(p, &nd)) return -1;
 		if (nd == 0) break;
 		if (round >= p.max_rounds) { rep->converged = 0; break; }
 		rep->bwd_rounds++; rep->bwd_tiles += nd;
-		if (p.rep_impl == 0)
-			hipLaunchKernelGGL((k_bwd_fast<0, true>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
-			                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
-		else
-			hipLaunchKernelGGL((k_bwd_fast<1, true>), g, b, 0, p.stream, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
-			                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit);
+		launch_bwd<true>(p, sm);
 	}
-	if (p.ev[2]) (void)hipEventRecord(p.ev[2], p.stream);
+	if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 	// ---- counts + log-likelihood from the stored tables
+	if (p.overlap) {
+		(void)hipStreamWaitEvent(sm, p.evx[3], 0);
+		launch_expect(p, sm, 1);                            // only tiles a repair rewrote
+	} else {
+		launch_expect(p, sm, 0);
+		hipLaunchKernelGGL(k_ll, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
+	}
+	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
 	const int nC = p.n_chunks * p.n_sub;
-	if (p.expect_impl == 0)
-		hipLaunchKernelGGL(k_expect_valu, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
-		                   p.d_Cpart, p.d_Epart);
-	else
-		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), b, 0, p.stream, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
-		                   p.d_Cpart, p.d_Epart);
-	hipLaunchKernelGGL(k_ll, g, b, 0, p.stream, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
-	if (p.ev[3]) (void)hipEventRecord(p.ev[3], p.stream);
-	hipLaunchKernelGGL(k_reduce1, dim3(17, RED_ROWS), dim3(256), 0, p.stream, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
+	hipLaunchKernelGGL(k_reduce1, dim3(17, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
 	                   p.n_chunks, p.d_stage);
-	hipLaunchKernelGGL(k_reduce2, dim3((STATS_LEN + 255) / 256), dim3(256), 0, p.stream, p.d_stage, p.d_a, p.d_e,
+	hipLaunchKernelGGL(k_reduce2, dim3((STATS_LEN + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
 	                   p.tiny_total, p.n_states, p.d_stats);
-	if (p.ev[4]) (void)hipEventRecord(p.ev[4], p.stream);
+	if (p.ev[4]) (void)hipEventRecord(p.ev[4], sm);
 	return (int)hipGetLastError();
 }
 

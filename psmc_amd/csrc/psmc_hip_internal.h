@@ -27,7 +27,9 @@ struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged;
 
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
-	hipStream_t stream;
+	hipStream_t stream, stream2; // main, and the second stream phases are overlapped on
+	hipEvent_t evx[4];           // cross-stream dependencies
+	int overlap;
 	int rep_impl, expect_impl, n_states;
 	// parameters (padded to NS)
 	const double *d_a;   // a[l*64+k] row-major P(l->k)... i.e. a[row*64+col]
@@ -48,6 +50,7 @@ struct EstepLaunch {
 	int n_chunks, warmup, n_sub;
 	double *d_entry, *d_bentry, *d_bexit; // [n_chunks][64] boundary vectors used / produced by each tile
 	int *d_dirty, *d_cnt, *h_cnt;         // per-tile repair flags, flagged count (device, pinned host)
+	int *d_touch_f, *d_touch_b, *d_force_b; // [n_chunks] each, contiguous: repaired-this-E-step flags
 	double tol; int max_rounds;
 	double *d_Cpart;            // [n_chunks*n_sub][4096]
 	double *d_Epart;            // [n_chunks*n_sub][192]  S partials

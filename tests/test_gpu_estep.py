@@ -155,7 +155,8 @@ def test_fast_small_golden(hip, golden, key, expect_impl):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=1024), dict(chunk=256, n_sub=1), dict(chunk=4096, rep_impl=0),
-                                  dict(chunk=2048, expect_impl=0)])
+                                  dict(chunk=2048, expect_impl=0), dict(chunk=1024, overlap=0), dict(chunk=512, warmup=128, overlap=1),
+                                  dict(chunk=512, warmup=128, overlap=0)])
 def test_fast_mid_golden(hip, golden, opts):
     key = "n64_curve"
     p = golden.params(key)
@@ -184,6 +185,21 @@ def test_fast_speculation_is_repaired(hip, golden, opts):
     g = golden.mid
     check_fast(r, dict(A=g[key + ".A"], E=g[key + ".E"], LL=float(g[key + ".LL"])))
     es.close()
+
+
+def test_fast_overlap_equals_sequential(hip, golden):
+    """The two-stream schedule (repairs beside the next bulk phase, early expect + redo of touched
+    tiles) must give bit-identical statistics to the plain sequential schedule."""
+    p = golden.params("n64_curve")
+    out = []
+    for ov in (0, 1):
+        es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=768, warmup=256, overlap=ov)
+        es.load_segments(golden.segs_mid)
+        out.append(es.estep(p["a"], p["e"], p["a0"]))
+        d = es.fast_diag()
+        assert d["fwd_tiles"] > 0
+        es.close()
+    assert bits_equal(out[0]["A"], out[1]["A"]) and bits_equal(out[0]["E"], out[1]["E"]) and out[0]["LL"] == out[1]["LL"]
 
 
 def test_fast_deterministic_and_selection(hip, golden, oracle):

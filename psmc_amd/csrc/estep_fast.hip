@@ -156,6 +156,9 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 	if (REPAIR && !dirty[blockIdx.x]) return;
 	if (REPAIR) __builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
+	// A tile re-run because a forward repair rewrote its X / inv_d (not because of its boundary)
+	// must not stop when it meets its old trajectory: the old one is stale BELOW that point.
+	const bool forced = REPAIR && force_b[blockIdx.x] != 0;
 	if (REPAIR && lane == 0) { touch_b[blockIdx.x] = 1; force_b[blockIdx.x] = 0; }
 	const Chunk c = chunks[blockIdx.x];
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 		const int pbeg = max(lo, (blk << 6) + 1);  // lowest position of this block
 		const int pc = max(pbeg, lo + 1);          // lowest position of the block this tile stores bt for
 		double oldv = 0.0, chkv = 0.0;
-		const bool can_check = REPAIR && pc <= min(p, top);
+		const bool can_check = REPAIR && !forced && pc <= min(p, top);
 		if (can_check) oldv = bto[(int64_t)(pc - 1) * 64 + lane];
 		for (; p >= pbeg; --p) {
 			const int idx = p - 1;

@@ -16,11 +16,10 @@
 //     broadcast straight from the natural-layout state register; 64 matrix entries
 //     in 128 VGPRs per lane; a 2-level permlane-swap transpose-reduce brings the
 //     result back to natural layout -- wave_prims.h matvec64_nat);
-//   * lagged, sparse, exact normalisation: X_p = e[o_p]*(a^T X_{p-1}) / d_p with
-//     d_p = 2^floor(log2 sum(X_{p-1})) when p % 4 == 0 and 1 otherwise: the
-//     cross-lane reduction is off the sequential critical path, paid every 4th bin,
-//     and the division is exact; LL = sum_p log d_p + log sum(X_L) telescopes for
-//     ANY positive d_p;
+//   * lagged, sparse normalisation: X_p = e[o_p]*(a^T X_{p-1}) / d_p with
+//     d_p = sum(X_{p-1}) when p % 4 == 0 and 1 otherwise: the cross-lane reduction
+//     is off the sequential critical path and paid every 4th bin only;
+//     LL = sum_p log d_p + log sum(X_L) telescopes for ANY positive d_p;
 //   * backward shares the divisors, B_p = a(e[o_{p+1}]*B_{p+1}) / d_p, stored as
 //     bt_p = e[o_p]*B_p, normalised once per tile so the posterior sums to one;
 //   * counts from the stored tables: C = sum_p X_p (x) bt_{p+1} is a K=bins GEMM
@@ -40,6 +39,16 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double pick_ef(int sym, double e0, double e1) {
 	return sym == 0 ? e0 : (sym == 1 ? e1 : 1.0);
+}
+
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (x is a sum of probabilities)
+__device__ __forceinline__ double fast_rcp(double x) {
+	double r = __builtin_amdgcn_rcp(x);
+	double t = __builtin_fma(-x, r, 1.0);
+	r = __builtin_fma(r, t, r);
+	t = __builtin_fma(-x, r, 1.0);
+	r = __builtin_fma(r, t, r);
+	return r;
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -121,12 +130,8 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
 			const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
 			if (p == c.lo) entry[(int64_t)blockIdx.x * 64 + lane] = x; // the X_{lo-1} this tile builds on
 			double ev = pick_ef(sym, e0, e1);
-			if ((p & (NORM_EVERY - 1)) == 0) { // off the critical path
-				// d_p = sum(X_{p-1}) rounded down to a power of two: rescaling is then EXACT (no
-				// rounding enters the recursion, LL = ln2 * sum of exponents + log sum(X_L)), and the
-				// backward sweep is bit-for-bit invariant to which d_p it sees in its warm-up region,
-				// which is what keeps the overlapped schedule deterministic.
-				const double inv = __builtin_ldexp(1.0, 1 - __builtin_amdgcn_frexp_exp(wave_sum_nat(x)));
+			if ((p & (NORM_EVERY - 1)) == 0) { // d_p = sum(X_{p-1}), off the critical path
+				const double inv = fast_rcp(wave_sum_nat(x));
 				ev *= inv;
 				if (p >= c.lo && lane == 0) io[idx] = inv;
 			}
@@ -197,7 +202,17 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 			const int idx = p - 1;
 			const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
 			double ev = pick_ef(sym, e0, e1);
-			if ((p & (NORM_EVERY - 1)) == 0) ev *= readlane_f64(invv, idx & 63); // the divisor forward used at p
+			if ((p & (NORM_EVERY - 1)) == 0) {
+				if (p <= top) {
+					ev *= readlane_f64(invv, idx & 63); // the divisor forward used at p
+				} else {
+					// Warm-up region: any scaling will do (the tile is normalised at `top`), so use an
+					// exact power of two taken from our own magnitude instead of the forward divisor
+					// stored there: with the overlapped schedule that one may be being rewritten by a
+					// forward repair, and reading it would make the result depend on timing.
+					ev = __builtin_ldexp(ev, -__builtin_amdgcn_frexp_exp(wave_sum_nat(btn)));
+				}
+			}
 			double bnew = matvec64_nat(btn, A); // (a . e*B_{p+1})[k] = B_p[k] * d_p
 			if (p == top) { // normalise the tile: posterior at `top` sums to one (given this tile's X)
 				const double kappa = 1.0 / wave_sum_nat(xtop * bnew);

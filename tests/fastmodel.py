@@ -9,7 +9,7 @@ length T, the speculative warm-up W0 and the tolerances.  Not imported by the
 product.
 
 Notation (1-indexed positions p=1..L, o_p the observation):
-  forward  X_p = e[o_p] * (a^T X_{p-1}) / d_p ,  d_p = 2^floor(log2 sum(X_{p-1})) if p % NORM_EVERY == 0 else 1
+  forward  X_p = e[o_p] * (a^T X_{p-1}) / d_p ,  d_p = sum(X_{p-1}) if p % NORM_EVERY == 0 else 1
            (LL = sum_p log d_p + log sum(X_L) telescopes for any positive d_p)
   backward Bnew_p = a (e[o_{p+1}] * B_{p+1}),  B_p = Bnew_p / d_p,  bt_p = e[o_p] * B_p
   counts   C      += X_p (x) bt_{p+1}                      p = 1..L-1   (A = a .* C)
@@ -59,8 +59,7 @@ def estep_fast_model(a, e, a0, segs, T=4096, W=2048, tol=None, stats=None):
         X = np.zeros((L + 2, n)); d = np.ones(L + 2); bt = np.zeros((L + 2, n))
 
         def fstep(x, p):
-            # d_p: power of two just below sum(X_{p-1}) at the normalising positions (exact rescaling)
-            dp = 2.0 ** (np.frexp(x.sum())[1] - 1) if p % NORM_EVERY == 0 else 1.0
+            dp = x.sum() if p % NORM_EVERY == 0 else 1.0
             g = (x * e[o[p]]) if p == 1 else e[o[p]] * (x @ a)
             return g / dp, dp
 

@@ -98,8 +98,8 @@ int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
 
 /* Copies the forward/backward tables of one loaded segment to the host after
  * an E-step (replaces reading hd->f, hd->b, hd->s: aux.c:159-200).  f,b: L*n,
- * s: L.  Exact mode: the reference's values bit for bit.  Fast mode: b is not
- * kept (NULL required) and f,s are the lag-normalised values. */
+ * s: L.  Exact mode: the reference's values bit for bit.  Fast mode (diagnostic):
+ * f = X, b = bt = e[o_p]*B_p, s = 1/d_p at p % 4 == 0. */
 int psmc_hip_get_tables(psmc_hip_ctx *ctx, int seg, double *f, double *b, double *s);
 
 /* Built-in check of the cross-lane primitives on the device (row replication

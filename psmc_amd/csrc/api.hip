@@ -576,7 +576,6 @@ extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *
 {
 	if (!c || seg < 0 || seg >= c->n_seg) return fail(c, PSMC_HIP_EINVAL, "get_tables: bad argument");
 	if (!c->d_f) return fail(c, PSMC_HIP_ESTATE, "get_tables: no E-step yet");
-	if (b && c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "get_tables: b is kept in exact mode only");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int n = c->n, L = c->L[seg];
 	const int64_t off = c->off[seg];

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
 			if (p == c.lo) entry[(int64_t)blockIdx.x * 64 + lane] = x; // the X_{lo-1} this tile builds on
 			double ev = pick_ef(sym, e0, e1);
 			if ((p & (NORM_EVERY - 1)) == 0) { // d_p = sum(X_{p-1}), off the critical path
-				const double inv = fast_rcp(wave_sum_nat(x));
+				const double inv = fast_rcp(first_lane_f64(wave_sum_nat(x))); // one value for all lanes and for the table
 				ev *= inv;
 				if (p >= c.lo && lane == 0) io[idx] = inv;
 			}
@@ -210,7 +210,9 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 					// exact power of two taken from our own magnitude instead of the forward divisor
 					// stored there: with the overlapped schedule that one may be being rewritten by a
 					// forward repair, and reading it would make the result depend on timing.
-					ev = __builtin_ldexp(ev, -__builtin_amdgcn_frexp_exp(wave_sum_nat(btn)));
+					// (lane 0's exponent for everyone: the butterfly sum differs by an ulp between lanes,
+					// which flips the exponent when the sum sits on a power of two, e.g. all-missing data)
+					ev = __builtin_ldexp(ev, -__builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(wave_sum_nat(btn))));
 				}
 			}
 			double bnew = matvec64_nat(btn, A); // (a . e*B_{p+1})[k] = B_p[k] * d_p

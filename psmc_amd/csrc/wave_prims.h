@@ -200,6 +200,11 @@ __device__ __forceinline__ double wave_sum_nat(double x) {
 	return t + c;
 }
 
+// lane 0's value in every lane (tree reductions agree between lanes only to an ulp)
+__device__ __forceinline__ double first_lane_f64(double v) {
+	return f64_mk((unsigned)__builtin_amdgcn_readfirstlane((int)f64_lo(v)), (unsigned)__builtin_amdgcn_readfirstlane((int)f64_hi(v)));
+}
+
 // wave-uniform double out of a VGPR lane (lane index may be a runtime scalar)
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
 	return f64_mk((unsigned)__builtin_amdgcn_readlane((int)f64_lo(v), lane),

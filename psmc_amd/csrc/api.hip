@@ -21,7 +21,7 @@ struct psmc_hip_ctx {
 	int n = 0, device = 0, mode = PSMC_HIP_MODE_EXACT;
 	std::string err;
 	// options
-	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 4, target_waves = 2048, overlap = 1;
+	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
 	double warm_tol = 1e-12;
 	// segments
 	int n_seg = 0;

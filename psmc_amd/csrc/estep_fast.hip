@@ -171,7 +171,11 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 	const double e0 = e[lane], e1 = e[64 + lane];
 	double btn; // e[o_{p+1}] * B_{p+1}, natural layout
 	int p;
-	if (REPAIR && !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST))) { // continue from the value the tile above computed at our top boundary
+	// A forced tile re-speculates from its own warm-up (exactly what the sequential schedule's
+	// speculative pass computes from the final forward tables) rather than from the tile above,
+	// whose own speculative output may have been computed from half-rewritten data: this keeps
+	// the overlapped schedule bit-identical to the sequential one and reproducible run to run.
+	if (REPAIR && !forced && !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST))) { // continue from the value the tile above computed at our top boundary
 		btn = bexit[(int64_t)(blockIdx.x + 1) * 64 + lane];
 		p = top;
 	} else { // speculative start; also the redo of a tile anchored at the true segment end

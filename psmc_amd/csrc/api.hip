@@ -21,7 +21,7 @@ struct psmc_hip_ctx {
 	int n = 0, device = 0, mode = PSMC_HIP_MODE_EXACT;
 	std::string err;
 	// options
-	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
+	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 3;
 	double warm_tol = 1e-12;
 	// segments
 	int n_seg = 0;
@@ -169,7 +169,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
 	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
 	else if (k == "max_rounds") c->max_rounds = (int)v;
-	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
+	else if (k == "overlap") c->overlap = (int)v & 3; /* bit 0: backward speculation beside forward repairs; bit 1: early expect */
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
 	else if (k == "expect_impl") c->expect_impl = v != 0 ? 1 : 0;
@@ -321,7 +321,7 @@ static void collect_timing(psmc_hip_ctx *c)
 	c->last_ms[5] = c->last_ms[6] = 0;
 	if (c->mode == PSMC_HIP_MODE_FAST) { // the two speculative sweep kernels alone
 		if (hipEventElapsedTime(&t, c->ev[0], c->ev[5]) == hipSuccess) c->last_ms[5] = t;
-		if (c->overlap) { if (hipEventElapsedTime(&t, c->evx[0], c->evx[1]) == hipSuccess) c->last_ms[6] = t; } // ran on the second stream
+		if (c->overlap & 1) { if (hipEventElapsedTime(&t, c->evx[0], c->evx[1]) == hipSuccess) c->last_ms[6] = t; } // ran on the second stream
 		else if (hipEventElapsedTime(&t, c->ev[1], c->ev[6]) == hipSuccess) c->last_ms[6] = t;
 	}
 }

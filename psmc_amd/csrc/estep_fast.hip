@@ -262,8 +262,12 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 		// a tile whose X / inv_d were rewritten by a forward repair after (or while) its backward
 		// sweep ran must redo that sweep, whatever its boundary looks like
 		const bool forced = BWD && force_b[b] && min(c.hi, c.L - 1) >= c.lo;
+		// ... and a tile whose upper neighbour is about to be redone waits one round: that
+		// neighbour's current boundary vector came from a sweep over half-rewritten tables, and
+		// consuming it would make the result depend on timing.
+		const bool wait = BWD && check && b + 1 < n_chunks && force_b[b + 1] != 0;
 		const int bad = (check && !(m <= tol)) || forced;
-		dirty[b] = bad;
+		dirty[b] = bad && !(wait && !forced);
 		if (bad) atomicAdd(&cnt[0], 1);
 		if (check) atomicMax(&warm[BWD ? 1 : 0], (unsigned long long)__double_as_longlong(m));
 	}
@@ -529,6 +533,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (p.n_chunks <= 0) return 0;
 	const dim3 g(p.n_chunks), b(64);
 	hipStream_t sm = p.stream, sa = p.overlap ? p.stream2 : p.stream;
+	const bool ov_bwd = (p.overlap & 1) != 0, ov_exp = (p.overlap & 2) != 0; // what runs beside the repairs
 	rep->fwd_rounds = rep->bwd_rounds = rep->fwd_tiles = rep->bwd_tiles = 0;
 	rep->converged = 1;
 	(void)hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), sm);
@@ -538,7 +543,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	launch_fwd<false>(p, sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	// ---- backward speculation may start as soon as the forward tables exist
-	if (p.overlap) { (void)hipEventRecord(p.evx[0], sm); (void)hipStreamWaitEvent(sa, p.evx[0], 0); launch_bwd<false>(p, sa); (void)hipEventRecord(p.evx[1], sa); }
+	if (ov_bwd) { (void)hipEventRecord(p.evx[0], sm); (void)hipStreamWaitEvent(sa, p.evx[0], 0); launch_bwd<false>(p, sa); (void)hipEventRecord(p.evx[1], sa); }
 	// ---- forward: verify / repair until every boundary agrees
 	for (int round = 0;; ++round) {
 		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), sm);
@@ -553,15 +558,19 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		launch_fwd<true>(p, sm);
 	}
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
-	if (p.overlap) {
+	if (ov_bwd) {
 		(void)hipStreamWaitEvent(sm, p.evx[1], 0);          // backward speculation finished
-		(void)hipEventRecord(p.evx[2], sm);                 // forward tables final
+	} else {
+		// sequential: the backward speculation sees the final forward tables, nothing to force
+		(void)hipMemsetAsync(p.d_force_b, 0, sizeof(int) * (size_t)p.n_chunks, sm);
+		launch_bwd<false>(p, sm);
+	}
+	if (ov_exp) {
+		(void)hipEventRecord(p.evx[2], sm);                 // forward tables final, backward speculation done
 		(void)hipStreamWaitEvent(sa, p.evx[2], 0);
 		hipLaunchKernelGGL(k_ll, g, b, 0, sa, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
 		launch_expect(p, sa, 0);                            // early pass over every tile
 		(void)hipEventRecord(p.evx[3], sa);
-	} else {
-		launch_bwd<false>(p, sm);
 	}
 	if (p.ev[6]) (void)hipEventRecord(p.ev[6], sm);
 	// ---- backward: verify / repair
@@ -579,7 +588,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	}
 	if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 	// ---- counts + log-likelihood from the stored tables
-	if (p.overlap) {
+	if (ov_exp) {
 		(void)hipStreamWaitEvent(sm, p.evx[3], 0);
 		launch_expect(p, sm, 1);                            // only tiles a repair rewrote
 	} else {

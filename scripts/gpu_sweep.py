@@ -20,7 +20,7 @@ for s, o in zip(segs, off[:-1]):
 d_obs = torch.from_numpy(host).cuda()
 ref = None
 grid = [dict(), dict(overlap=0), dict(warmup=2048), dict(warmup=1024), dict(warmup=0), dict(chunk=8192), dict(chunk=8192, warmup=2048),
-        dict(chunk=20480), dict(chunk=32768), dict(chunk=32768, overlap=0), dict(chunk=49152), dict(target_waves=3072), dict(target_waves=1024),
+        dict(chunk=20480), dict(chunk=32768), dict(chunk=32768, overlap=0), dict(overlap=1), dict(overlap=2), dict(chunk=49152), dict(target_waves=3072), dict(target_waves=1024),
         dict(n_sub=8), dict(warm_tol=1e-10), dict(warm_tol=1e-9)]
 for opts in grid:
     es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)

@@ -138,7 +138,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    kern = {"forward": 0.0, "backward": 0.0, "expect": 0.0, "reduce": 0.0, "total": 0.0, "fwd_sweep": 0.0, "bwd_sweep": 0.0}
+    kern = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -154,8 +154,8 @@ def main():
     for _ in range(nk):
         step(); torch.cuda.synchronize()
         t = es.timing()
-        for k in kern:
-            kern[k] += t[k] / nk
+        for k in t:
+            kern[k] = kern.get(k, 0.0) + t[k] / nk
     diag = es.fast_diag() if mode == hip.MODE_FAST else {}
     ms_per_step = dt / args.steps * 1e3
     value = bins * world / (dt / args.steps)

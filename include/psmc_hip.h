@@ -48,8 +48,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 
 /* Tunables (all optional): "chunk" (fast-mode tile length in bins, 0 = auto),
  * "warmup" (speculative overlap in bins), "warm_tol" (tile-boundary agreement
- * demanded by verify/repair), "max_rounds", "overlap" (1: run repair rounds
- * beside the next bulk phase on a second stream), "target_waves", "n_sub" (expect
+ * demanded by verify/repair), "max_rounds", "overlap" (1: forward chain, backward
+ * chain and the early counts pass on three streams; 0: one stream), "target_waves", "n_sub" (expect
  * waves per tile), "rep_impl" (0 ds_bpermute, 1 v_permlane*_swap),
  * "expect_impl" (0 VALU, 1 MFMA f64). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
@@ -117,10 +117,12 @@ int psmc_hip_microbench(int device, double *out, int n);
  * width the kernels use; *ms_out = average duration of one launch. */
 int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out);
 
-/* Wall time in ms of the last E-step's kernels measured with HIP events on
- * the stream they ran on: [0] total, [1] forward stage, [2] backward stage,
- * [3] expect (+LL), [4] reductions; fast mode also [5] the speculative forward
- * sweep kernel alone and [6] the speculative backward sweep kernel alone. */
+/* Wall time in ms of the last E-step measured with HIP events on the streams the
+ * kernels ran on.  Exact mode: [0] total, [1] forward, [2] backward, [3] expect,
+ * [4] host-copy tail.  Fast mode: [0] total, [1] both sweep chains (speculate +
+ * repair rounds; forward and backward run concurrently), [2] LL + redo of the
+ * counts after the chains, [3] the full expect kernel alone, [4] reductions, [5] the
+ * speculative forward sweep kernel alone, [6] the speculative backward sweep alone. */
 int psmc_hip_last_timing(psmc_hip_ctx *ctx, double ms[7]);
 
 #ifdef __cplusplus

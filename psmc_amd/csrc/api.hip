@@ -21,7 +21,7 @@ struct psmc_hip_ctx {
 	int n = 0, device = 0, mode = PSMC_HIP_MODE_EXACT;
 	std::string err;
 	// options
-	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 3;
+	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
 	double warm_tol = 1e-12;
 	// segments
 	int n_seg = 0;
@@ -40,10 +40,10 @@ struct psmc_hip_ctx {
 	int32_t *d_work = nullptr;
 	bool plan_dirty = true;
 	// parameters
-	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0
-	static constexpr size_t PAR_LEN = 4096 + 3 * 4096 + 3 * 64 + 64;
+	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0 | re(3)
+	static constexpr size_t PAR_LEN = 4096 + 3 * 4096 + 3 * 64 + 64 + 3 * 64; // ... | re(3)
 	// tables
-	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr;
+	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr, *d_sb = nullptr;
 	int64_t tab_bins = 0; bool have_b = false;
 	// exact outputs
 	double *d_segA = nullptr, *d_segE = nullptr, *d_segA0 = nullptr, *d_chk = nullptr;
@@ -56,7 +56,7 @@ struct psmc_hip_ctx {
 	double *d_entry = nullptr, *d_bentry = nullptr, *d_bexit = nullptr, *d_Cpart = nullptr, *d_Epart = nullptr,
 	       *d_LLpart = nullptr;
 	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
-	hipStream_t stream2 = nullptr;
+	hipStream_t stream2 = nullptr, stream3 = nullptr;
 	hipEvent_t evx[4] = {nullptr, nullptr, nullptr, nullptr};
 	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
@@ -64,7 +64,7 @@ struct psmc_hip_ctx {
 	double warm_err[2] = {0, 0};
 	// runtime
 	hipStream_t stream = nullptr;
-	hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	double last_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 	bool timing_valid = false;
 };
@@ -129,9 +129,10 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	c->n = n_states; c->device = device; c->mode = mode;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 4; ++i)
 		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	for (int i = 0; i < 7; ++i)
+	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipHostMalloc((void **)&c->h_par, psmc_hip_ctx::PAR_LEN * sizeof(double), hipHostMallocDefault) != hipSuccess ||
 	    hipMalloc((void **)&c->d_par, psmc_hip_ctx::PAR_LEN * sizeof(double)) != hipSuccess) {
@@ -148,16 +149,18 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+	if (c->stream3) (void)hipStreamSynchronize(c->stream3);
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-	for (int i = 0; i < 7; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 4; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	if (c->stream3) (void)hipStreamDestroy(c->stream3);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -169,7 +172,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
 	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
 	else if (k == "max_rounds") c->max_rounds = (int)v;
-	else if (k == "overlap") c->overlap = (int)v & 3; /* bit 0: backward speculation beside forward repairs; bit 1: early expect */
+	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
 	else if (k == "expect_impl") c->expect_impl = v != 0 ? 1 : 0;
@@ -262,7 +265,7 @@ extern "C" int psmc_hip_select(psmc_hip_ctx *c, int n_sel, const int32_t *idx)
 static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, hipStream_t st)
 {
 	const int n = c->n;
-	double *pa = c->h_par, *pae = pa + 4096, *pe = pae + 3 * 4096, *pa0 = pe + 3 * 64;
+	double *pa = c->h_par, *pae = pa + 4096, *pe = pae + 3 * 4096, *pa0 = pe + 3 * 64, *pre = pa0 + 64;
 	HIPCHK(c, hipStreamSynchronize(st)); // previous async copy out of the pinned staging buffer
 	memset(pa, 0, psmc_hip_ctx::PAR_LEN * sizeof(double));
 	for (int k = 0; k < n; ++k) {
@@ -271,6 +274,7 @@ static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const
 		pa0[k] = a0[k];
 	}
 	for (int k = 0; k < 64; ++k) pe[128 + k] = 1.0; // khmm.c:21
+	for (int i = 0; i < 192; ++i) pre[i] = pe[i] > 0.0 ? 1.0 / pe[i] : 0.0; // fast-mode expect divides the emission back out
 	for (int b = 0; b < 3; ++b)
 		for (int l = 0; l < 64; ++l)
 			for (int k = 0; k < 64; ++k) pae[b * 4096 + l * 64 + k] = pe[b * 64 + l] * pa[k * 64 + l];
@@ -285,6 +289,7 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b)
 		int rc;
 		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) return rc;
+		if (c->mode == PSMC_HIP_MODE_FAST && (rc = dev_alloc(c, &c->d_sb, (size_t)bins))) return rc;
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
 		c->have_b = false;
 		c->tab_bins = bins;
@@ -303,26 +308,31 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.stream = st;
 	p.rep_impl = c->rep_impl; p.expect_impl = c->expect_impl; p.n_states = c->n;
 	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
+	p.d_re = c->d_par + 4 * 4096 + 192 + 64;
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
-	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s;
-	for (int i = 0; i < 7; ++i) p.ev[i] = c->mode == PSMC_HIP_MODE_FAST || i < 5 ? c->ev[i] : nullptr;
+	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s; p.d_sb = c->d_sb;
+	for (int i = 0; i < 10; ++i) p.ev[i] = c->mode == PSMC_HIP_MODE_FAST || i < 5 ? c->ev[i] : nullptr;
 }
 
 static void collect_timing(psmc_hip_ctx *c)
 {
 	float t;
 	c->timing_valid = true;
-	for (int i = 0; i < 4; ++i) {
-		if (hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]) == hipSuccess) c->last_ms[i + 1] = t;
-		else { c->last_ms[i + 1] = 0; c->timing_valid = false; }
-	}
-	if (hipEventElapsedTime(&t, c->ev[0], c->ev[4]) == hipSuccess) c->last_ms[0] = t; else c->timing_valid = false;
+	auto el = [&](hipEvent_t a, hipEvent_t b, double &out) {
+		if (hipEventElapsedTime(&t, a, b) == hipSuccess) out = t; else { out = 0; c->timing_valid = false; }
+	};
+	el(c->ev[0], c->ev[4], c->last_ms[0]);
 	c->last_ms[5] = c->last_ms[6] = 0;
-	if (c->mode == PSMC_HIP_MODE_FAST) { // the two speculative sweep kernels alone
-		if (hipEventElapsedTime(&t, c->ev[0], c->ev[5]) == hipSuccess) c->last_ms[5] = t;
-		if (c->overlap & 1) { if (hipEventElapsedTime(&t, c->evx[0], c->evx[1]) == hipSuccess) c->last_ms[6] = t; } // ran on the second stream
-		else if (hipEventElapsedTime(&t, c->ev[1], c->ev[6]) == hipSuccess) c->last_ms[6] = t;
+	if (c->mode == PSMC_HIP_MODE_FAST) {
+		el(c->ev[0], c->ev[1], c->last_ms[1]);  // both sweep chains (speculate + repairs), run concurrently
+		el(c->ev[1], c->ev[3], c->last_ms[2]);  // LL + what is left of the counts after the chains
+		el(c->ev[8], c->ev[9], c->last_ms[3]);  // the full expect pass (kernel alone)
+		el(c->ev[3], c->ev[4], c->last_ms[4]);
+		el(c->ev[0], c->ev[5], c->last_ms[5]);  // speculative forward sweep kernel
+		el(c->ev[7], c->ev[6], c->last_ms[6]);  // speculative backward sweep kernel
+	} else {
+		for (int i = 0; i < 4; ++i) el(c->ev[i], c->ev[i + 1], c->last_ms[i + 1]);
 	}
 }
 
@@ -456,8 +466,8 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_entry, (size_t)nc * 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)(nc + 1) * 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bentry, (size_t)nc * 64))) return rc;
-		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_touch, (size_t)3 * nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
 		c->chunk_cap = nc;
 	}
@@ -490,8 +500,8 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub;
 	p.d_entry = c->d_entry; p.d_bentry = c->d_bentry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
 	p.d_dirty = c->d_dirty; p.d_cnt = c->d_cnt; p.h_cnt = c->h_cnt; p.tol = c->warm_tol; p.max_rounds = c->max_rounds;
-	p.d_touch_f = c->d_touch; p.d_touch_b = c->d_touch + p.n_chunks; p.d_force_b = c->d_touch + 2 * p.n_chunks;
-	p.stream2 = c->stream2; p.overlap = c->overlap;
+	p.d_touch_f = c->d_touch; p.d_touch_b = c->d_touch + p.n_chunks; p.d_dirty_b = c->d_dirty + p.n_chunks;
+	p.stream2 = c->stream2; p.stream3 = c->stream3; p.overlap = c->overlap;
 	for (int i = 0; i < 4; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;

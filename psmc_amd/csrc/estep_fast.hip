@@ -20,15 +20,18 @@
 //     d_p = sum(X_{p-1}) when p % 4 == 0 and 1 otherwise: the cross-lane reduction
 //     is off the sequential critical path and paid every 4th bin only;
 //     LL = sum_p log d_p + log sum(X_L) telescopes for ANY positive d_p;
-//   * backward shares the divisors, B_p = a(e[o_{p+1}]*B_{p+1}) / d_p, stored as
-//     bt_p = e[o_p]*B_p, normalised once per tile so the posterior sums to one;
-//   * counts from the stored tables: C = sum_p X_p (x) bt_{p+1} is a K=bins GEMM
-//     on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), A = a .* C;
-//     S[o_p] += d_p X_p bt_p, E = S / e.  Per-wave partials are reduced in a fixed
-//     order (deterministic, no atomics on the statistics).
+//   * the backward sweep is the mirror image and needs NOTHING from the forward one:
+//     bt_p = e[o_p]*(a bt_{p+1})*sb_p with its own lagged scale sb_p = 1/sum(bt_{p+1})
+//     at p % 4 == 0, so the two sweeps (and their repair rounds) run concurrently
+//     on two streams;
+//   * counts from the stored tables, normalised per position in the expect kernel:
+//     G_p = sum_k X_p bt_p / e[o_p] (= sb_p sum_kl X_p[k] a[k][l] bt_{p+1}[l]),
+//     E[o_p] += X_p bt_p / e[o_p] / G_p, and C = sum_p (sb_p/G_p) X_p (x) bt_{p+1} is a
+//     K=bins GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), A = a .* C.
+//     Per-wave partials are reduced in a fixed order (deterministic, no atomics).
 // tests/fastmodel.py is the executable numpy specification of this file.
 // HBM layout (g = seg_off + p - 1): X[g*64+k] (d_f), bt[g*64+k] (d_b),
-// inv_d[g] = 1/d_p (d_s; written at p % 4 == 0 only), obs[g].
+// inv_d[g] = 1/d_p (d_s) and sb[g] (d_sb), both written at p % 4 == 0 only, obs[g].
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
 #include "psmc_hip_internal.h"
@@ -68,13 +71,6 @@ __device__ __forceinline__ double rel_mismatch(double x, double y) {
 	return bad ? __builtin_inf() : num / den;
 }
 
-// same after scaling both vectors to unit L1 norm (backward vectors of two tiles agree only
-// up to the per-tile posterior normalisation, which moves by O(warm_tol) at forward tile seams)
-__device__ __forceinline__ double rel_mismatch_dir(double x, double y) {
-	const double sx = wave_add(fabs(x)), sy = wave_add(fabs(y));
-	return rel_mismatch(x / sx, y / sy);
-}
-
 // ------------------------------------------------------------------ forward
 // REPAIR=false: speculative pass over every tile.  REPAIR=true: only tiles the
 // verify kernel flagged; starts from the neighbour's stored X_{lo-1} and stops
@@ -85,12 +81,12 @@ __global__ __launch_bounds__(64) void k_fwd_fast(const double *__restrict__ a, c
                                                    const Chunk *__restrict__ chunks, int W, double tol,
                                                    const int *__restrict__ dirty, double *__restrict__ f,
                                                    double *__restrict__ invd, double *__restrict__ entry,
-                                                   int *__restrict__ touch_f, int *__restrict__ force_b)
+                                                   int *__restrict__ touch_f)
 {
 	if (REPAIR && !dirty[blockIdx.x]) return;
 	if (REPAIR) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	const int lane = threadIdx.x;
-	if (REPAIR && lane == 0) { touch_f[blockIdx.x] = 1; force_b[blockIdx.x] = 1; } // X / inv_d of this tile change
+	if (REPAIR && lane == 0) touch_f[blockIdx.x] = 1; // X / inv_d of this tile change
 	const Chunk c = chunks[blockIdx.x];
 	const uint8_t *o = obs + c.off;
 	double *fo = f + c.off * 64, *io = invd + c.off;
@@ -148,85 +144,59 @@ template <int REP, bool REPAIR>
 __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, const double *__restrict__ e,
                                                    const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                    int W, double tol, const int *__restrict__ dirty,
-                                                   const double *__restrict__ f, const double *__restrict__ invd,
-                                                   double *__restrict__ bt, double *__restrict__ bentry,
-                                                   double *__restrict__ bexit, int *__restrict__ touch_b,
-                                                   int *__restrict__ force_b)
+                                                   double *__restrict__ bt, double *__restrict__ sb,
+                                                   double *__restrict__ bentry, double *__restrict__ bexit,
+                                                   int *__restrict__ touch_b)
 {
 	if (REPAIR && !dirty[blockIdx.x]) return;
 	if (REPAIR) __builtin_amdgcn_s_setprio(3);
 	const int lane = threadIdx.x;
-	// A tile re-run because a forward repair rewrote its X / inv_d (not because of its boundary)
-	// must not stop when it meets its old trajectory: the old one is stale BELOW that point.
-	const bool forced = REPAIR && force_b[blockIdx.x] != 0;
-	if (REPAIR && lane == 0) { touch_b[blockIdx.x] = 1; force_b[blockIdx.x] = 0; }
+	if (REPAIR && lane == 0) touch_b[blockIdx.x] = 1;
 	const Chunk c = chunks[blockIdx.x];
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
 	if (top < lo) return; // a tile holding only position L owns no transition
 	const uint8_t *o = obs + c.off;
-	const double *fo = f + c.off * 64, *io = invd + c.off;
-	double *bto = bt + c.off * 64;
+	double *bto = bt + c.off * 64, *sbo = sb + c.off;
 	double A[64]; // A[16j+N] = a[16j+m][16r+N] = aT[16r+N][16j+m]
 	load_nat_matrix(aT, lane, A);
 	const double e0 = e[lane], e1 = e[64 + lane];
-	double btn; // e[o_{p+1}] * B_{p+1}, natural layout
+	double btn; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling), natural layout
 	int p;
-	// A forced tile re-speculates from its own warm-up (exactly what the sequential schedule's
-	// speculative pass computes from the final forward tables) rather than from the tile above,
-	// whose own speculative output may have been computed from half-rewritten data: this keeps
-	// the overlapped schedule bit-identical to the sequential one and reproducible run to run.
-	if (REPAIR && !forced && !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST))) { // continue from the value the tile above computed at our top boundary
+	if (REPAIR) { // continue from the value the tile above computed at our top boundary
 		btn = bexit[(int64_t)(blockIdx.x + 1) * 64 + lane];
 		p = top;
-	} else { // speculative start; also the redo of a tile anchored at the true segment end
+	} else {
 		const int q = min(c.hi + W + 1, L); // B_q := 1
 		btn = pick_ef((int)o[q - 1], e0, e1);
 		p = q - 1;
 	}
-	const double xtop = fo[(int64_t)(top - 1) * 64 + lane];
-	// blocks of 64 bins going down; (symbol, inv_d) of a block come from one coalesced load
-	// each, prefetched a block ahead; no load inside a block (see k_fwd_fast)
-	auto fetch = [&](int b, int &sv, double &iv) {
-		const int i = (max(b, 0) << 6) + lane;
-		sv = o[i]; iv = io[i];
-	};
-	int symn; double invn;
-	fetch((p - 1) >> 6, symn, invn);
+	// blocks of 64 bins going down, one coalesced symbol load per block prefetched a block ahead,
+	// no load inside a block (see k_fwd_fast)
+	int symn = o[(max((p - 1) >> 6, 0) << 6) + lane];
 	bool done = false;
 	while (p >= lo && !done) {
 		const int blk = (p - 1) >> 6;
-		const int symv = symn; const double invv = invn;
-		fetch(blk - 1, symn, invn);
+		const int symv = symn;
+		symn = o[(max(blk - 1, 0) << 6) + lane];
 		const int pbeg = max(lo, (blk << 6) + 1);  // lowest position of this block
 		const int pc = max(pbeg, lo + 1);          // lowest position of the block this tile stores bt for
 		double oldv = 0.0, chkv = 0.0;
-		const bool can_check = REPAIR && !forced && pc <= min(p, top);
+		const bool can_check = REPAIR && pc <= min(p, top);
 		if (can_check) oldv = bto[(int64_t)(pc - 1) * 64 + lane];
 		for (; p >= pbeg; --p) {
 			const int idx = p - 1;
 			const int sym = __builtin_amdgcn_readlane(symv, idx & 63);
 			double ev = pick_ef(sym, e0, e1);
-			if ((p & (NORM_EVERY - 1)) == 0) {
-				if (p <= top) {
-					ev *= readlane_f64(invv, idx & 63); // the divisor forward used at p
-				} else {
-					// Warm-up region: any scaling will do (the tile is normalised at `top`), so use an
-					// exact power of two taken from our own magnitude instead of the forward divisor
-					// stored there: with the overlapped schedule that one may be being rewritten by a
-					// forward repair, and reading it would make the result depend on timing.
-					// (lane 0's exponent for everyone: the butterfly sum differs by an ulp between lanes,
-					// which flips the exponent when the sum sits on a power of two, e.g. all-missing data)
-					ev = __builtin_ldexp(ev, -__builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_exp(wave_sum_nat(btn))));
-				}
+			if ((p & (NORM_EVERY - 1)) == 0) { // sb_p = 1/sum(bt_{p+1}), off the critical path
+				const double sc = fast_rcp(first_lane_f64(wave_sum_nat(btn)));
+				ev *= sc;
+				if (p <= top && lane == 0) sbo[idx] = sc;
 			}
-			double bnew = matvec64_nat(btn, A); // (a . e*B_{p+1})[k] = B_p[k] * d_p
-			if (p == top) { // normalise the tile: posterior at `top` sums to one (given this tile's X)
-				const double kappa = 1.0 / wave_sum_nat(xtop * bnew);
-				bnew *= kappa; btn *= kappa;
+			if (p == top) { // the boundary vector this tile builds on
 				bto[(int64_t)top * 64 + lane] = btn; // bt[top+1]
 				bentry[(int64_t)blockIdx.x * 64 + lane] = btn;
 			}
-			btn = bnew * ev;
+			btn = matvec64_nat(btn, A) * ev;
 			if (p <= top) {
 				if (p > lo || lo == 1) bto[(int64_t)idx * 64 + lane] = btn; // bt[p]; bt[lo>1] belongs to the tile below
 				if (p == lo) bexit[(int64_t)blockIdx.x * 64 + lane] = btn;
@@ -244,8 +214,7 @@ template <bool BWD>
 __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks, int n_chunks, double tol,
                                                  const double *__restrict__ f, const double *__restrict__ mine,
                                                  const double *__restrict__ bexit, int *__restrict__ dirty,
-                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm,
-                                                 const int *__restrict__ force_b)
+                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm)
 {
 	const int lane = threadIdx.x, b = blockIdx.x;
 	const Chunk c = chunks[b];
@@ -256,26 +225,19 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], f[(c.off + c.lo - 2) * 64 + lane]);
 	} else {
 		check = !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST)) && min(c.hi, c.L - 1) >= c.lo && b + 1 < n_chunks;
-		if (check) m = rel_mismatch_dir(mine[(int64_t)b * 64 + lane], bexit[(int64_t)(b + 1) * 64 + lane]);
+		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], bexit[(int64_t)(b + 1) * 64 + lane]);
 	}
 	if (lane == 0) {
-		// a tile whose X / inv_d were rewritten by a forward repair after (or while) its backward
-		// sweep ran must redo that sweep, whatever its boundary looks like
-		const bool forced = BWD && force_b[b] && min(c.hi, c.L - 1) >= c.lo;
-		// ... and a tile whose upper neighbour is about to be redone waits one round: that
-		// neighbour's current boundary vector came from a sweep over half-rewritten tables, and
-		// consuming it would make the result depend on timing.
-		const bool wait = BWD && check && b + 1 < n_chunks && force_b[b + 1] != 0;
-		const int bad = (check && !(m <= tol)) || forced;
-		dirty[b] = bad && !(wait && !forced);
-		if (bad) atomicAdd(&cnt[0], 1);
+		const int bad = check && !(m <= tol);
+		dirty[b] = bad;
+		if (bad) atomicAdd(cnt, 1);
 		if (check) atomicMax(&warm[BWD ? 1 : 0], (unsigned long long)__double_as_longlong(m));
 	}
 }
 
 // ------------------------------------------------------------------ expect
-// Inputs of a tile's counts that a repair may have rewritten after an early expect pass:
-// X / inv_d (forward repair of the tile), bt[lo+1..top+1] (its backward repair) and bt[lo]
+// Inputs of a tile's counts that a repair may have rewritten after the early expect pass:
+// X (forward repair of the tile), bt[lo+1..top+1] and sb (its backward repair) and bt[lo]
 // (stored by the tile below as its top boundary value).
 __device__ __forceinline__ bool tile_touched(const Chunk *__restrict__ chunks, int b, const int *__restrict__ touch_f,
                                              const int *__restrict__ touch_b)
@@ -284,17 +246,20 @@ __device__ __forceinline__ bool tile_touched(const Chunk *__restrict__ chunks, i
 	if (b > 0 && chunks[b - 1].off == chunks[b].off) t = t || touch_b[b - 1];
 	return t;
 }
-// C[k][l] += sum_p X_p[k] * bt_{p+1}[l] and S[o_p][k] += d_p X_p[k] bt_p[k] over the
-// tile's positions lo..min(hi,L-1), split over n_sub waves.  FP64 matrix cores:
-// D(16x16) += A(16x4) B(4x16) with
-//   A[i][t] = X_{p+t}[16m+i]   (lane = 16t+i),  B[t][j] = bt_{p+t+1}[16n+j] (lane = 16t+j)
+// Over the tile's positions lo..min(hi,L-1), split over n_sub waves:
+//   g_p[k] = X_p[k] bt_p[k] / e[o_p][k],  G_p = sum_k g_p[k]      (posterior normaliser)
+//   S[o_p][k] += g_p[k] / G_p                                      (emission counts)
+//   C[k][l]  += (sb_p / G_p) X_p[k] * bt_{p+1}[l]                   (transition counts / a[k][l])
+// C runs on the FP64 matrix cores: D(16x16) += A(16x4) B(4x16) with
+//   A[i][t] = (sb/G)_{p+t} X_{p+t}[16m+i]  (lane = 16t+i),  B[t][j] = bt_{p+t+1}[16n+j] (lane = 16t+j)
 //   D[(lane>>4)+4r][lane&15] = acc[r]
+// so row group t of the wave holds position p+t and G is a 16-lane (one DPP row) reduction.
 __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
                                                          const uint8_t *__restrict__ obs, const double *__restrict__ f,
-                                                         const double *__restrict__ bt, const double *__restrict__ invd,
-                                                         double *__restrict__ Cpart, double *__restrict__ Spart,
-                                                         const int *__restrict__ touch_f, const int *__restrict__ touch_b,
-                                                         int redo)
+                                                         const double *__restrict__ bt, const double *__restrict__ sb,
+                                                         const double *__restrict__ re, double *__restrict__ Cpart,
+                                                         double *__restrict__ Spart, const int *__restrict__ touch_f,
+                                                         const int *__restrict__ touch_b, int redo)
 {
 	const int lane = threadIdx.x, t = lane >> 4, i = lane & 15;
 	const Chunk c = chunks[blockIdx.x / n_sub];
@@ -303,8 +268,11 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
 	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64 + i, *bo = bt + c.off * 64 + i, *io = invd + c.off;
+	const double *fo = f + c.off * 64 + i, *bo = bt + c.off * 64 + i, *sbo = sb + c.off;
 	const uint8_t *o = obs + c.off;
+	double re0[4], re1[4]; // 1/e[b][16m+i]
+#pragma unroll
+	for (int m = 0; m < 4; ++m) { re0[m] = re[16 * m + i]; re1[m] = re[64 + 16 * m + i]; }
 	d4_t acc[4][4];
 	double S[3][4];
 #pragma unroll
@@ -313,40 +281,52 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 		for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (d4_t){0.0, 0.0, 0.0, 0.0};
 		S[0][m] = S[1][m] = S[2][m] = 0.0;
 	}
-	auto load = [&](int p, double (&FA)[4], double (&BM)[4], double (&BP)[4], double &w, int &sym) {
+	auto load = [&](int p, double (&FA)[4], double (&BM)[4], double (&BP)[4], double &sc, int &sym, bool &ok) {
 		const int pp = p + t;
-		const bool ok = pp <= p1;
+		ok = pp <= p1;
 		const int64_t idx = (int64_t)(ok ? pp : p1) - 1;
 		const double *fr = fo + idx * 64, *br = bo + idx * 64;
 #pragma unroll
-		for (int m = 0; m < 4; ++m) { FA[m] = ok ? fr[16 * m] : 0.0; BP[m] = br[16 * m]; BM[m] = br[64 + 16 * m]; }
-		double iv = 1.0; // d_p = 1/inv_d at the normalising positions, 1 elsewhere
-		if (ok && ((int)(idx + 1) & (NORM_EVERY - 1)) == 0) iv = io[idx];
-		w = ok ? 1.0 / iv : 0.0;
+		for (int m = 0; m < 4; ++m) { FA[m] = fr[16 * m]; BP[m] = br[16 * m]; BM[m] = br[64 + 16 * m]; }
+		sc = 1.0; // sb_p at the normalising positions, 1 elsewhere
+		if (((int)(idx + 1) & (NORM_EVERY - 1)) == 0) sc = sbo[idx];
 		sym = o[idx];
 	};
 	if (p0 <= p1) {
-		double FA[4], BM[4], BP[4], w; int sym;
-		load(p0, FA, BM, BP, w, sym);
+		double FA[4], BM[4], BP[4], sc; int sym; bool ok;
+		load(p0, FA, BM, BP, sc, sym, ok);
 		for (int p = p0; p <= p1; p += 4) {
-			double FN[4] = {0, 0, 0, 0}, BN[4] = {0, 0, 0, 0}, BQ[4] = {0, 0, 0, 0}, wn = 0.0; int symn = 2;
-			if (p + 4 <= p1) load(p + 4, FN, BN, BQ, wn, symn);
+			double FN[4] = {0, 0, 0, 0}, BN[4] = {0, 0, 0, 0}, BQ[4] = {0, 0, 0, 0}, scn = 1.0; int symn = 2; bool okn = false;
+			if (p + 4 <= p1) load(p + 4, FN, BN, BQ, scn, symn, okn);
+			// per-position normaliser: row group t reduces its own position over the 64 states
+			double g[4], G = 0.0;
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				const double r = sym == 0 ? re0[m] : (sym == 1 ? re1[m] : 1.0);
+				g[m] = FA[m] * BP[m] * r;
+				G += g[m];
+			}
+			G = G + dpp_mov<0xB1>(G);  // quad_perm:[1,0,3,2]
+			G = G + dpp_mov<0x4E>(G);  // quad_perm:[2,3,0,1]
+			G = G + dpp_mov<0x124>(G); // row_ror:4
+			G = G + dpp_mov<0x128>(G); // row_ror:8
+			const double iG = ok ? 1.0 / G : 0.0; // padded rows of the last group contribute nothing
+			const double w0 = sym == 0 ? iG : 0.0, w1 = sym == 1 ? iG : 0.0, w2 = sym == 2 ? iG : 0.0, wa = sc * iG;
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				S[0][m] = __builtin_fma(g[m], w0, S[0][m]);
+				S[1][m] = __builtin_fma(g[m], w1, S[1][m]);
+				S[2][m] = __builtin_fma(g[m], w2, S[2][m]);
+				FA[m] *= wa;
+			}
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
 #pragma unroll
 				for (int nn = 0; nn < 4; ++nn)
 					acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[m], BM[nn], acc[m][nn], 0, 0, 0);
-			const double w0 = sym == 0 ? w : 0.0, w1 = sym == 1 ? w : 0.0, w2 = sym == 2 ? w : 0.0;
-#pragma unroll
-			for (int m = 0; m < 4; ++m) {
-				const double g = FA[m] * BP[m];
-				S[0][m] = __builtin_fma(g, w0, S[0][m]);
-				S[1][m] = __builtin_fma(g, w1, S[1][m]);
-				S[2][m] = __builtin_fma(g, w2, S[2][m]);
-			}
 #pragma unroll
 			for (int m = 0; m < 4; ++m) { FA[m] = FN[m]; BM[m] = BN[m]; BP[m] = BQ[m]; }
-			w = wn; sym = symn;
+			sc = scn; sym = symn; ok = okn;
 		}
 	}
 	const double mult = (double)c.mult;
@@ -375,10 +355,10 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 	fmac_bcast<N>(C[32 + N], r[2], X); fmac_bcast<N>(C[48 + N], r[3], X);
 __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ chunks, int n_sub,
                                                       const uint8_t *__restrict__ obs, const double *__restrict__ f,
-                                                      const double *__restrict__ bt, const double *__restrict__ invd,
-                                                      double *__restrict__ Cpart, double *__restrict__ Spart,
-                                                      const int *__restrict__ touch_f, const int *__restrict__ touch_b,
-                                                      int redo)
+                                                      const double *__restrict__ bt, const double *__restrict__ sb,
+                                                      const double *__restrict__ re, double *__restrict__ Cpart,
+                                                      double *__restrict__ Spart, const int *__restrict__ touch_f,
+                                                      const int *__restrict__ touch_b, int redo)
 {
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x / n_sub];
@@ -387,17 +367,19 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
 	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64, *bo = bt + c.off * 64, *io = invd + c.off;
+	const double *fo = f + c.off * 64, *bo = bt + c.off * 64, *sbo = sb + c.off;
 	const uint8_t *o = obs + c.off;
+	const double re0 = re[lane], re1 = re[64 + lane];
 	double C[64], S0 = 0.0, S1 = 0.0, S2 = 0.0;
 #pragma unroll
 	for (int l = 0; l < 64; ++l) C[l] = 0.0;
 	for (int p = p0; p <= p1; ++p) {
-		const double X = fo[(int64_t)(p - 1) * 64 + lane];
-		const double dp = (p & (NORM_EVERY - 1)) == 0 ? 1.0 / io[p - 1] : 1.0;
-		const double g = X * bo[(int64_t)(p - 1) * 64 + lane] * dp;
 		const int sym = o[p - 1];
-		if (sym == 0) S0 += g; else if (sym == 1) S1 += g; else S2 += g;
+		const double sc = (p & (NORM_EVERY - 1)) == 0 ? sbo[p - 1] : 1.0;
+		const double g = fo[(int64_t)(p - 1) * 64 + lane] * bo[(int64_t)(p - 1) * 64 + lane] * (sym == 0 ? re0 : (sym == 1 ? re1 : 1.0));
+		const double iG = 1.0 / first_lane_f64(wave_sum_nat(g));
+		if (sym == 0) S0 += g * iG; else if (sym == 1) S1 += g * iG; else S2 += g * iG;
+		double X = fo[(int64_t)(p - 1) * 64 + lane] * (sc * iG);
 		double r[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) r[j] = bo[(int64_t)p * 64 + 16 * j + (lane & 15)]; // replicated load of bt[p+1]
@@ -470,33 +452,25 @@ __global__ __launch_bounds__(256) void k_reduce2(const double *__restrict__ stag
 	if (i < 4096) { // A = a .* C + n_seg*HMM_TINY (khmm.c:305-306,316)
 		const int k = i >> 6, l = i & 63;
 		if (k < n && l < n) out[k * n + l] = a[i] * s + tiny_total;
-	} else if (i < 4096 + 192) { // E = S / e + n_seg*HMM_TINY; the missing-symbol row is dropped (khmm.c:355)
+	} else if (i < 4096 + 192) { // E + n_seg*HMM_TINY; the missing-symbol row is dropped (khmm.c:355)
 		const int b = (i - 4096) >> 6, k = (i - 4096) & 63;
-		if (b < 2 && k < n) out[n * n + b * n + k] = s / e[b * 64 + k] + tiny_total;
+		if (b < 2 && k < n) out[n * n + b * n + k] = s + tiny_total;
 	} else {
 		out[n * n + 2 * n] = s;
 	}
 }
 
 // ------------------------------------------------------------------ launcher
-static int read_count(const EstepLaunch &p, int *n)
-{
-	if (hipMemcpyAsync(p.h_cnt, p.d_cnt, sizeof(int), hipMemcpyDeviceToHost, p.stream) != hipSuccess) return -1;
-	if (hipStreamSynchronize(p.stream) != hipSuccess) return -1;
-	*n = p.h_cnt[0];
-	return 0;
-}
-
 template <bool REPAIR>
 static void launch_fwd(const EstepLaunch &p, hipStream_t st)
 {
 	const dim3 g(p.n_chunks), b(64);
 	if (p.rep_impl == 0)
 		hipLaunchKernelGGL((k_fwd_fast<0, REPAIR>), g, b, 0, st, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.warmup,
-		                   p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry, p.d_touch_f, p.d_force_b);
+		                   p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
 	else
 		hipLaunchKernelGGL((k_fwd_fast<1, REPAIR>), g, b, 0, st, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.warmup,
-		                   p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry, p.d_touch_f, p.d_force_b);
+		                   p.tol, p.d_dirty, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
 }
 template <bool REPAIR>
 static void launch_bwd(const EstepLaunch &p, hipStream_t st)
@@ -505,95 +479,104 @@ static void launch_bwd(const EstepLaunch &p, hipStream_t st)
 	const double *aT = p.d_aeT + 2 * 4096;
 	if (p.rep_impl == 0)
 		hipLaunchKernelGGL((k_bwd_fast<0, REPAIR>), g, b, 0, st, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
-		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit, p.d_touch_b, p.d_force_b);
+		                   p.d_dirty_b, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 	else
 		hipLaunchKernelGGL((k_bwd_fast<1, REPAIR>), g, b, 0, st, aT, p.d_e, p.d_obs, p.d_chunks, p.warmup, p.tol,
-		                   p.d_dirty, p.d_f, p.d_s, p.d_b, p.d_bentry, p.d_bexit, p.d_touch_b, p.d_force_b);
+		                   p.d_dirty_b, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 }
 static void launch_expect(const EstepLaunch &p, hipStream_t st, int redo)
 {
 	const int nC = p.n_chunks * p.n_sub;
 	if (p.expect_impl == 0)
-		hipLaunchKernelGGL(k_expect_valu, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
-		                   p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
+		hipLaunchKernelGGL(k_expect_valu, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,
+		                   p.d_re, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
 	else
-		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_s,
-		                   p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
+		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,
+		                   p.d_re, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
 }
 
-// One fast-mode E-step.  With p.overlap the low-occupancy repair rounds (a few dozen
-// latency-bound waves) are overlapped with the next bulk phase on a second stream:
-//   main: fwd speculate | fwd verify/repair ............ | bwd verify/repair ........ | expect(redo) reduce
-//   aux :               | bwd speculate (maybe stale in) | k_ll, expect (all tiles)   |
-// Anything that consumed data a repair later rewrote is recomputed: forward-repaired tiles
-// are force-flagged for the backward repair, and tiles whose X / bt / inv_d changed after the
-// early expect pass are re-run (their per-wave partials are simply overwritten).
+// One fast-mode E-step.  The forward and the backward sweep do not depend on each other, so
+// with p.overlap they run on two streams from the start, each followed by its own
+// verify / repair rounds (a few dozen latency-bound waves); as soon as both speculative
+// sweeps are done an early pass of the counts runs over every tile on a third stream, and
+// tiles a repair rewrote afterwards are simply recomputed (their per-wave partials are
+// overwritten):
+//   main: fwd speculate | fwd verify/repair ...          | k_ll | expect(redo) reduce
+//   aux : bwd speculate | bwd verify/repair ...          |
+//   exp :               | expect (all tiles)             |
+// p.overlap == 0 runs the same kernels back to back on one stream (bit-identical result).
 int launch_fast(const EstepLaunch &p, FastReport *rep)
 {
 	if (p.n_chunks <= 0) return 0;
 	const dim3 g(p.n_chunks), b(64);
-	hipStream_t sm = p.stream, sa = p.overlap ? p.stream2 : p.stream;
-	const bool ov_bwd = (p.overlap & 1) != 0, ov_exp = (p.overlap & 2) != 0; // what runs beside the repairs
+	const bool ov = p.overlap != 0;
+	hipStream_t sm = p.stream, sa = ov ? p.stream2 : p.stream, sx = ov ? p.stream3 : p.stream;
 	rep->fwd_rounds = rep->bwd_rounds = rep->fwd_tiles = rep->bwd_tiles = 0;
 	rep->converged = 1;
 	(void)hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), sm);
-	(void)hipMemsetAsync(p.d_touch_f, 0, 3 * sizeof(int) * (size_t)p.n_chunks, sm); // touch_f | touch_b | force_b
+	(void)hipMemsetAsync(p.d_touch_f, 0, 2 * sizeof(int) * (size_t)p.n_chunks, sm); // touch_f | touch_b
 	if (p.ev[0]) (void)hipEventRecord(p.ev[0], sm);
-	// ---- forward: speculate
+	(void)hipEventRecord(p.evx[0], sm);
+	if (ov) (void)hipStreamWaitEvent(sa, p.evx[0], 0); // parameters uploaded, flags cleared
+	// ---- both speculative sweeps
 	launch_fwd<false>(p, sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
-	// ---- backward speculation may start as soon as the forward tables exist
-	if (ov_bwd) { (void)hipEventRecord(p.evx[0], sm); (void)hipStreamWaitEvent(sa, p.evx[0], 0); launch_bwd<false>(p, sa); (void)hipEventRecord(p.evx[1], sa); }
-	// ---- forward: verify / repair until every boundary agrees
-	for (int round = 0;; ++round) {
-		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), sm);
-		(void)hipMemsetAsync(p.d_warm, 0, sizeof(unsigned long long), sm);
-		hipLaunchKernelGGL((k_verify<false>), g, b, 0, sm, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry, p.d_bexit,
-		                   p.d_dirty, p.d_cnt, p.d_warm, p.d_force_b);
-		int nd = 0;
-		if (read_count(p, &nd)) return -1;
-		if (nd == 0) break;
-		if (round >= p.max_rounds) { rep->converged = 0; break; }
-		rep->fwd_rounds++; rep->fwd_tiles += nd;
-		launch_fwd<true>(p, sm);
+	if (p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
+	launch_bwd<false>(p, sa);
+	if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
+	if (ov) { // early expect over every tile once both sweeps exist
+		(void)hipEventRecord(p.evx[1], sm); (void)hipEventRecord(p.evx[2], sa);
+		(void)hipStreamWaitEvent(sx, p.evx[1], 0); (void)hipStreamWaitEvent(sx, p.evx[2], 0);
+		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sx);
+		launch_expect(p, sx, 0);
+		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sx);
+		(void)hipEventRecord(p.evx[3], sx);
+	}
+	// ---- verify / repair rounds of both directions in lockstep
+	bool fdone = false, bdone = false;
+	for (int round = 0; !(fdone && bdone); ++round) {
+		if (!fdone) {
+			(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), sm);
+			(void)hipMemsetAsync(p.d_warm, 0, sizeof(unsigned long long), sm);
+			hipLaunchKernelGGL((k_verify<false>), g, b, 0, sm, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry, p.d_bexit,
+			                   p.d_dirty, p.d_cnt, p.d_warm);
+			if (hipMemcpyAsync(p.h_cnt, p.d_cnt, sizeof(int), hipMemcpyDeviceToHost, sm) != hipSuccess) return -1;
+		}
+		if (!bdone) {
+			(void)hipMemsetAsync(p.d_cnt + 1, 0, sizeof(int), sa);
+			(void)hipMemsetAsync(p.d_warm + 1, 0, sizeof(unsigned long long), sa);
+			hipLaunchKernelGGL((k_verify<true>), g, b, 0, sa, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
+			                   p.d_dirty_b, p.d_cnt + 1, p.d_warm);
+			if (hipMemcpyAsync(p.h_cnt + 1, p.d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, sa) != hipSuccess) return -1;
+		}
+		if (!fdone && hipStreamSynchronize(sm) != hipSuccess) return -1;
+		if (!bdone && hipStreamSynchronize(sa) != hipSuccess) return -1;
+		if (!fdone) {
+			const int nd = p.h_cnt[0];
+			if (nd == 0) fdone = true;
+			else if (round >= p.max_rounds) { rep->converged = 0; fdone = true; }
+			else { rep->fwd_rounds++; rep->fwd_tiles += nd; launch_fwd<true>(p, sm); }
+		}
+		if (!bdone) {
+			const int nd = p.h_cnt[1];
+			if (nd == 0) bdone = true;
+			else if (round >= p.max_rounds) { rep->converged = 0; bdone = true; }
+			else { rep->bwd_rounds++; rep->bwd_tiles += nd; launch_bwd<true>(p, sa); }
+		}
 	}
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
-	if (ov_bwd) {
-		(void)hipStreamWaitEvent(sm, p.evx[1], 0);          // backward speculation finished
+	// ---- counts + log-likelihood from the final tables
+	hipLaunchKernelGGL(k_ll, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
+	if (ov) {
+		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // backward chain done
+		(void)hipStreamWaitEvent(sm, p.evx[3], 0);                                     // early expect done
+		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
+		launch_expect(p, sm, 1); // only tiles a repair rewrote
 	} else {
-		// sequential: the backward speculation sees the final forward tables, nothing to force
-		(void)hipMemsetAsync(p.d_force_b, 0, sizeof(int) * (size_t)p.n_chunks, sm);
-		launch_bwd<false>(p, sm);
-	}
-	if (ov_exp) {
-		(void)hipEventRecord(p.evx[2], sm);                 // forward tables final, backward speculation done
-		(void)hipStreamWaitEvent(sa, p.evx[2], 0);
-		hipLaunchKernelGGL(k_ll, g, b, 0, sa, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
-		launch_expect(p, sa, 0);                            // early pass over every tile
-		(void)hipEventRecord(p.evx[3], sa);
-	}
-	if (p.ev[6]) (void)hipEventRecord(p.ev[6], sm);
-	// ---- backward: verify / repair
-	for (int round = 0;; ++round) {
-		(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), sm);
-		(void)hipMemsetAsync(p.d_warm + 1, 0, sizeof(unsigned long long), sm);
-		hipLaunchKernelGGL((k_verify<true>), g, b, 0, sm, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
-		                   p.d_dirty, p.d_cnt, p.d_warm, p.d_force_b);
-		int nd = 0;
-		if (read_count(p, &nd)) return -1;
-		if (nd == 0) break;
-		if (round >= p.max_rounds) { rep->converged = 0; break; }
-		rep->bwd_rounds++; rep->bwd_tiles += nd;
-		launch_bwd<true>(p, sm);
-	}
-	if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
-	// ---- counts + log-likelihood from the stored tables
-	if (ov_exp) {
-		(void)hipStreamWaitEvent(sm, p.evx[3], 0);
-		launch_expect(p, sm, 1);                            // only tiles a repair rewrote
-	} else {
+		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
+		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sm);
 		launch_expect(p, sm, 0);
-		hipLaunchKernelGGL(k_ll, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
+		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sm);
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
 	const int nC = p.n_chunks * p.n_sub;

@@ -27,7 +27,7 @@ struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged;
 
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
-	hipStream_t stream, stream2; // main, and the second stream phases are overlapped on
+	hipStream_t stream, stream2, stream3; // forward chain (main), backward chain, early expect
 	hipEvent_t evx[4];           // cross-stream dependencies
 	int overlap;
 	int rep_impl, expect_impl, n_states;
@@ -36,6 +36,7 @@ struct EstepLaunch {
 	const double *d_aeT; // aeT[b][l*64+k] = e[b][l]*a[k][l], b=0..2 (b=2 is a transposed)
 	const double *d_e;   // e[b*64+k], b=0..2 (row 2 = 1)
 	const double *d_a0;  // a0[k]
+	const double *d_re;  // re[b*64+k] = 1/e[b][k] (0 where e is 0), b=0..2
 	// data
 	const uint8_t *d_obs;
 	const int64_t *d_seg_off;
@@ -49,8 +50,9 @@ struct EstepLaunch {
 	const Chunk *d_chunks;
 	int n_chunks, warmup, n_sub;
 	double *d_entry, *d_bentry, *d_bexit; // [n_chunks][64] boundary vectors used / produced by each tile
-	int *d_dirty, *d_cnt, *h_cnt;         // per-tile repair flags, flagged count (device, pinned host)
-	int *d_touch_f, *d_touch_b, *d_force_b; // [n_chunks] each, contiguous: repaired-this-E-step flags
+	int *d_dirty, *d_dirty_b, *d_cnt, *h_cnt; // per-tile repair flags (fwd, bwd), flagged counts [2] (device, pinned host)
+	int *d_touch_f, *d_touch_b;           // [n_chunks] each, contiguous: repaired-this-E-step flags
+	double *d_sb;                         // backward scale factors (fast mode), like d_s
 	double tol; int max_rounds;
 	double *d_Cpart;            // [n_chunks*n_sub][4096]
 	double *d_Epart;            // [n_chunks*n_sub][192]  S partials
@@ -59,7 +61,8 @@ struct EstepLaunch {
 	double *d_stats;            // [n*n + 2n + 1] final, unpadded [A | E | LL]
 	unsigned long long *d_warm; // [2] max warm-up mismatch (double bits)
 	double tiny_total;          // n_selected_segments * HMM_TINY
-	hipEvent_t ev[7];           // optional timing marks (may be null): 0..4 stage ends, 5/6 after the speculative sweeps
+	hipEvent_t ev[10];          // timing marks: 0 start, 1 chains done, 2 before expect(redo), 3 after, 4 end,
+	                            // 5 fwd sweep end, 7/6 bwd sweep start/end, 8/9 full expect pass start/end
 };
 
 constexpr int RED_ROWS = 64;

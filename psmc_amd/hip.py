@@ -216,8 +216,10 @@ class HipEStep:
     def timing(self):
         ms = np.zeros(7)
         self._chk(self.lib.psmc_hip_last_timing(self.h, _p(ms)), "last_timing")
-        return dict(total=ms[0], forward=ms[1], backward=ms[2], expect=ms[3], reduce=ms[4],
-                    fwd_sweep=ms[5], bwd_sweep=ms[6])
+        if self.mode == MODE_FAST:  # forward and backward chains run concurrently: see include/psmc_hip.h
+            return dict(total=ms[0], chains=ms[1], tail=ms[2], expect=ms[3], reduce=ms[4], fwd_sweep=ms[5],
+                        bwd_sweep=ms[6], forward=ms[1], backward=ms[2])
+        return dict(total=ms[0], forward=ms[1], backward=ms[2], expect=ms[3], reduce=ms[4], fwd_sweep=0.0, bwd_sweep=0.0)
 
 
 def selftest(device=0):

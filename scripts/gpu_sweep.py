@@ -20,7 +20,7 @@ for s, o in zip(segs, off[:-1]):
 d_obs = torch.from_numpy(host).cuda()
 ref = None
 grid = [dict(), dict(overlap=0), dict(warmup=2048), dict(warmup=1024), dict(warmup=0), dict(chunk=8192), dict(chunk=8192, warmup=2048),
-        dict(chunk=20480), dict(chunk=32768), dict(chunk=32768, overlap=0), dict(overlap=1), dict(overlap=2), dict(chunk=49152), dict(target_waves=3072), dict(target_waves=1024),
+        dict(chunk=20480), dict(chunk=32768), dict(chunk=32768, overlap=0), dict(chunk=12288), dict(chunk=16384), dict(chunk=24576), dict(chunk=49152), dict(target_waves=3072), dict(target_waves=1024),
         dict(n_sub=8), dict(warm_tol=1e-10), dict(warm_tol=1e-9)]
 for opts in grid:
     es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
@@ -36,7 +36,7 @@ for opts in grid:
         ref = r
     err = float(np.abs(r["A"] - ref["A"]).max() / np.abs(ref["A"]).max())
     print(json.dumps(dict(opts=opts, ms=round(dt * 1e3, 2), bins_per_s=round(int(lens.sum()) / dt / 1e6, 1),
-                          fwd=round(t["forward"], 2), bwd=round(t["backward"], 2), exp=round(t["expect"], 2),
+                          chains=round(t["forward"], 2), tail=round(t["backward"], 2), exp=round(t["expect"], 2), fsw=round(t["fwd_sweep"], 2), bsw=round(t["bwd_sweep"], 2),
                           red=round(t["reduce"], 2), tiles=d["n_chunks"], rounds=[d["fwd_rounds"], d["bwd_rounds"]],
                           rep_tiles=[d["fwd_tiles"], d["bwd_tiles"]], dA_vs_first=err, LL=r["LL"])), flush=True)
     es.close()

@@ -11,17 +11,18 @@ product.
 Notation (1-indexed positions p=1..L, o_p the observation):
   forward  X_p = e[o_p] * (a^T X_{p-1}) / d_p ,  d_p = sum(X_{p-1}) if p % NORM_EVERY == 0 else 1
            (LL = sum_p log d_p + log sum(X_L) telescopes for any positive d_p)
-  backward Bnew_p = a (e[o_{p+1}] * B_{p+1}),  B_p = Bnew_p / d_p,  bt_p = e[o_p] * B_p
-  counts   C      += X_p (x) bt_{p+1}                      p = 1..L-1   (A = a .* C)
-           S[o_p] += d_p * X_p * bt_p                       p = 1..L-1   (E = S / e)
+  backward bt_p = e[o_p] * (a bt_{p+1}) * sb_p,  sb_p = 1/sum(bt_{p+1}) if p % NORM_EVERY == 0 else 1
+           (independent of the forward tables: the two sweeps run concurrently)
+  counts   G_p = sum_k X_p bt_p / e[o_p]                    (posterior normaliser, per position)
+           C  += (sb_p / G_p) X_p (x) bt_{p+1}             p = 1..L-1   (A = a .* C)
+           E[o_p] += X_p * bt_p / e[o_p] / G_p               p = 1..L-1
 Speculation: a tile [lo,hi] starts W0 bins outside itself from an arbitrary
 vector.  Verification compares the vector a tile used at its boundary with the
 value its neighbour computed with a whole tile of history behind it; tiles
 whose mismatch exceeds `tol` are re-run from the neighbour's value until the new
 trajectory meets the stored one to `tol` again (or the tile ends, which may make
-the next tile dirty).  A backward tile is normalised once at its top so that
-the posterior sums to one (also when repaired), so boundary vectors of two tiles
-are compared by direction only.
+the next tile dirty).  Both sweeps are self-normalising, so stored vectors of
+neighbouring tiles agree in scale as well as in direction.
 """
 import numpy as np
 
@@ -94,9 +95,12 @@ def estep_fast_model(a, e, a0, segs, T=4096, W=2048, tol=None, stats=None):
                             break
         LL += np.log(d[2:L + 1]).sum() + np.log(X[L].sum())
 
-        # ---------------- backward
-        def bstep(btn, p):  # consumes bt_{p+1}, returns Bnew_p
-            return a @ btn
+        # ---------------- backward: independent of the forward tables (own lagged scaling)
+        sb = np.ones(L + 2)
+
+        def bstep(btn, p):  # consumes bt_{p+1}; returns bt_p and the scale it applied
+            sp = 1.0 / btn.sum() if p % NORM_EVERY == 0 else 1.0
+            return e[o[p]] * (a @ btn) * sp, sp
 
         bentry = [None] * nc; bexit = [None] * nc
         for c, (lo, hi) in enumerate(tiles):
@@ -106,38 +110,33 @@ def estep_fast_model(a, e, a0, segs, T=4096, W=2048, tol=None, stats=None):
             q = min(hi + W + 1, L)
             btn = e[o[q]] * np.ones(n)
             for p in range(q - 1, lo - 1, -1):
-                bnew = bstep(btn, p)
-                work["bwd_steps"] += 1
                 if p == top:
-                    kappa = 1.0 / (X[p] * bnew).sum()
-                    bnew *= kappa; btn = btn * kappa
                     bt[top + 1] = btn; bentry[c] = btn.copy()
-                btn = e[o[p]] * bnew / d[p]
-                if lo < p <= top or p == 1:
-                    bt[p] = btn
-                if p == lo:
-                    bexit[c] = btn.copy()
+                btn, sp = bstep(btn, p)
+                work["bwd_steps"] += 1
+                if p <= top:
+                    sb[p] = sp
+                    if p > lo or p == 1:
+                        bt[p] = btn
+                    if p == lo:
+                        bexit[c] = btn.copy()
         if tol is not None:
             while True:
-                # direction only: two tiles' scales differ by the per-tile posterior normalisation
                 dirty = [c for c in range(nc - 1)
                          if bexit[c + 1] is not None and bentry[c] is not None
-                         and _relmax(bentry[c] / np.abs(bentry[c]).sum(), bexit[c + 1] / np.abs(bexit[c + 1]).sum()) > tol]
+                         and tiles[c][1] + W + 1 < L and _relmax(bentry[c], bexit[c + 1]) > tol]
                 if not dirty:
                     break
                 work["bwd_rounds"] += 1
                 for c in dirty:
                     lo, hi = tiles[c]
                     top = min(hi, L - 1)
-                    btn = bexit[c + 1].copy()
+                    btn = bexit[c + 1].copy(); bentry[c] = btn.copy()
+                    bt[top + 1] = btn
                     for p in range(top, lo - 1, -1):
-                        bnew = bstep(btn, p)
+                        btn, sp = bstep(btn, p)
                         work["bwd_steps"] += 1
-                        if p == top:  # re-normalise at the tile's own top, like the speculative pass
-                            kappa = 1.0 / (X[p] * bnew).sum()
-                            bnew *= kappa; btn = btn * kappa
-                            bt[top + 1] = btn; bentry[c] = btn.copy()
-                        btn = e[o[p]] * bnew / d[p]
+                        sb[p] = sp
                         if p > lo:
                             done = _relmax(btn, bt[p]) <= tol
                             bt[p] = btn
@@ -147,15 +146,20 @@ def estep_fast_model(a, e, a0, segs, T=4096, W=2048, tol=None, stats=None):
                             bexit[c] = btn.copy()
                             if p == 1:
                                 bt[1] = btn
-        # ---------------- counts (GEMM over bins) from the stored tables
+        # ---------------- counts (GEMM over bins) from the stored tables, normalised per position:
+        #   G_p = sum_k X_p bt_p / e[o_p]   (= sb_p * sum_kl X_p[k] a[k][l] bt_{p+1}[l])
+        #   gamma_p = X_p bt_p / e[o_p] / G_p ;  xi_p = (sb_p / G_p) X_p (x) bt_{p+1} .* a
         if L > 1:
-            C = X[1:L].T @ bt[2:L + 1]
+            re = np.where(e > 0, 1.0 / np.where(e > 0, e, 1.0), 0.0)
+            g = X[1:L] * bt[1:L] * re[seg[:L - 1]]
+            G = g.sum(1)
+            C = (X[1:L] * (sb[1:L] / G)[:, None]).T @ bt[2:L + 1]
             A += a * C
-            g = d[1:L, None] * X[1:L] * bt[1:L]
             S = np.zeros((3, n))
+            gam = g / G[:, None]
             for b in range(3):
-                S[b] = g[seg[:L - 1] == b].sum(0)
-            E += S / e
+                S[b] = gam[seg[:L - 1] == b].sum(0)
+            E += S
         A += TINY; E += TINY
     if stats is not None:
         stats.update(work)

@@ -57,7 +57,7 @@ struct psmc_hip_ctx {
 	       *d_LLpart = nullptr;
 	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
 	hipStream_t stream2 = nullptr, stream3 = nullptr;
-	hipEvent_t evx[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t evx[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
 	unsigned long long *d_warm = nullptr;
@@ -130,7 +130,7 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < 6; ++i)
 		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
@@ -158,7 +158,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	for (int i = 0; i < 4; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+	for (int i = 0; i < 6; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream3) (void)hipStreamDestroy(c->stream3);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -502,7 +502,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_dirty = c->d_dirty; p.d_cnt = c->d_cnt; p.h_cnt = c->h_cnt; p.tol = c->warm_tol; p.max_rounds = c->max_rounds;
 	p.d_touch_f = c->d_touch; p.d_touch_b = c->d_touch + p.n_chunks; p.d_dirty_b = c->d_dirty + p.n_chunks;
 	p.stream2 = c->stream2; p.stream3 = c->stream3; p.overlap = c->overlap;
-	for (int i = 0; i < 4; ++i) p.evx[i] = c->evx[i];
+	for (int i = 0; i < 6; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
 	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());

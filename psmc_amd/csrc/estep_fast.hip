@@ -532,38 +532,45 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sx);
 		(void)hipEventRecord(p.evx[3], sx);
 	}
-	// ---- verify / repair rounds of both directions in lockstep
-	bool fdone = false, bdone = false;
-	for (int round = 0; !(fdone && bdone); ++round) {
-		if (!fdone) {
-			(void)hipMemsetAsync(p.d_cnt, 0, sizeof(int), sm);
-			(void)hipMemsetAsync(p.d_warm, 0, sizeof(unsigned long long), sm);
-			hipLaunchKernelGGL((k_verify<false>), g, b, 0, sm, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry, p.d_bexit,
+	// ---- verify / repair rounds: each direction advances on its own stream as soon as ITS
+	// flagged-tile count is back (polled, so the faster chain never waits for the slower one)
+	struct Chain { hipStream_t st; hipEvent_t rb; int slot; bool bwd, done, pending; int round; };
+	Chain ch[2] = {{sm, p.evx[4], 0, false, false, false, 0}, {sa, p.evx[5], 1, true, false, false, 0}};
+	auto post_verify = [&](Chain &c) -> int {
+		(void)hipMemsetAsync(p.d_cnt + c.slot, 0, sizeof(int), c.st);
+		(void)hipMemsetAsync(p.d_warm + c.slot, 0, sizeof(unsigned long long), c.st);
+		if (!c.bwd)
+			hipLaunchKernelGGL((k_verify<false>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry, p.d_bexit,
 			                   p.d_dirty, p.d_cnt, p.d_warm);
-			if (hipMemcpyAsync(p.h_cnt, p.d_cnt, sizeof(int), hipMemcpyDeviceToHost, sm) != hipSuccess) return -1;
-		}
-		if (!bdone) {
-			(void)hipMemsetAsync(p.d_cnt + 1, 0, sizeof(int), sa);
-			(void)hipMemsetAsync(p.d_warm + 1, 0, sizeof(unsigned long long), sa);
-			hipLaunchKernelGGL((k_verify<true>), g, b, 0, sa, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
+		else
+			hipLaunchKernelGGL((k_verify<true>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
 			                   p.d_dirty_b, p.d_cnt + 1, p.d_warm);
-			if (hipMemcpyAsync(p.h_cnt + 1, p.d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, sa) != hipSuccess) return -1;
+		if (hipMemcpyAsync(p.h_cnt + c.slot, p.d_cnt + c.slot, sizeof(int), hipMemcpyDeviceToHost, c.st) != hipSuccess) return -1;
+		if (hipEventRecord(c.rb, c.st) != hipSuccess) return -1;
+		c.pending = true;
+		return 0;
+	};
+	if (post_verify(ch[0]) || post_verify(ch[1])) return -1;
+	while (!(ch[0].done && ch[1].done)) {
+		bool progressed = false;
+		for (int d = 0; d < 2; ++d) {
+			Chain &c = ch[d];
+			if (c.done || !c.pending) continue;
+			const hipError_t q = ov ? hipEventQuery(c.rb) : hipEventSynchronize(c.rb);
+			if (q == hipErrorNotReady) continue;
+			if (q != hipSuccess) return -1;
+			c.pending = false; progressed = true;
+			const int nd = p.h_cnt[c.slot];
+			if (nd == 0) { c.done = true; continue; }
+			if (c.round >= p.max_rounds) { rep->converged = 0; c.done = true; continue; }
+			++c.round;
+			if (!c.bwd) { rep->fwd_rounds++; rep->fwd_tiles += nd; launch_fwd<true>(p, c.st); }
+			else { rep->bwd_rounds++; rep->bwd_tiles += nd; launch_bwd<true>(p, c.st); }
+			if (post_verify(c)) return -1;
 		}
-		if (!fdone && hipStreamSynchronize(sm) != hipSuccess) return -1;
-		if (!bdone && hipStreamSynchronize(sa) != hipSuccess) return -1;
-		if (!fdone) {
-			const int nd = p.h_cnt[0];
-			if (nd == 0) fdone = true;
-			else if (round >= p.max_rounds) { rep->converged = 0; fdone = true; }
-			else { rep->fwd_rounds++; rep->fwd_tiles += nd; launch_fwd<true>(p, sm); }
-		}
-		if (!bdone) {
-			const int nd = p.h_cnt[1];
-			if (nd == 0) bdone = true;
-			else if (round >= p.max_rounds) { rep->converged = 0; bdone = true; }
-			else { rep->bwd_rounds++; rep->bwd_tiles += nd; launch_bwd<true>(p, sa); }
-		}
+		if (!progressed) __builtin_ia32_pause();
 	}
+	if (hipStreamSynchronize(sm) != hipSuccess) return -1;
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
 	// ---- counts + log-likelihood from the final tables
 	hipLaunchKernelGGL(k_ll, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);

@@ -28,7 +28,7 @@ struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged;
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
 	hipStream_t stream, stream2, stream3; // forward chain (main), backward chain, early expect
-	hipEvent_t evx[4];           // cross-stream dependencies
+	hipEvent_t evx[6];           // cross-stream dependencies; 4/5: count read-backs of the two chains
 	int overlap;
 	int rep_impl, expect_impl, n_states;
 	// parameters (padded to NS)

@@ -8,13 +8,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 bins = int(sys.argv[2]) if len(sys.argv) > 2 else 30000003
 
 def short(nm):
-    m = re.search(r'psmc::(k_[a-z0-9_]+)(<[^>]*>)?', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)(I[^E]*E)?E?v', nm)
-    if not m: return nm.split('(')[0][:40]
-    k, t = m.group(1), m.group(2) or ''
-    rep = ('true' in t) or ('Lb1' in t)
-    if k in ('k_fwd_fast', 'k_bwd_fast'): return k + ('<repair>' if rep else '<speculate>')
-    if k == 'k_verify': return k + ('<bwd>' if rep else '<fwd>')
-    return k
+    rep = ('true>' in nm) or ('Lb1' in nm)
+    for k in ('k_fwd_fast', 'k_bwd_fast'):
+        if k in nm: return k + ('<repair>' if rep else '<speculate>')
+    if 'k_verify' in nm: return 'k_verify' + ('<bwd>' if rep else '<fwd>')
+    m = re.search(r'psmc::(k_[a-z0-9_]+)', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)E', nm)
+    return m.group(1) if m else nm.split('(')[0][:40]
 
 db = os.path.join(ROOT, "gpurun_out", "prof", "bench_results.db")
 if os.path.exists(db):

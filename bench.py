@@ -86,12 +86,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # BENCH_SINGLE_GPU_TEST=1: exercise the N>1 code path on a 1-GPU box (all ranks on device 0, gloo)
+    single_gpu_test = os.environ.get("BENCH_SINGLE_GPU_TEST") == "1"
+    if single_gpu_test:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if single_gpu_test:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     a, e, a0 = load_params()
     lens = sim.human_like_lengths(args.bins, n_seg=args.segments)
@@ -119,12 +126,15 @@ def main():
     def step():
         if mode == hip.MODE_FAST:
             es.estep_device(a, e, a0, stats.data_ptr(), stream.cuda_stream)
-            if dist is not None:
+            if dist is not None and not single_gpu_test:
                 dist.all_reduce(stats)           # RCCL over xGMI: replaces hmm_add_expect across shards
+            elif dist is not None:
+                t = stats.cpu(); dist.all_reduce(t); stats.copy_(t)
         else:
             r = es.estep(a, e, a0)               # exact: ordered host sum (bit-identical to khmm.c)
             if dist is not None:
-                t = torch.from_numpy(np.concatenate([r["A"].ravel(), r["E"].ravel(), [r["LL"]]])).cuda()
+                t = torch.from_numpy(np.concatenate([r["A"].ravel(), r["E"].ravel(), [r["LL"]]]))
+                t = t if single_gpu_test else t.cuda()
                 dist.all_reduce(t)
 
     def sync():
@@ -145,7 +155,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_gpu_test else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # per-kernel durations (HIP events recorded by the library on the stream the kernels ran on);

@@ -102,6 +102,12 @@ int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
  * f = X, b = bt = e[o_p]*B_p, s = 1/d_p at p % 4 == 0. */
 int psmc_hip_get_tables(psmc_hip_ctx *ctx, int seg, double *f, double *b, double *s);
 
+/* Posterior decoding of one segment on the device after an exact E-step: replaces
+ * hmm_post_decode (khmm.c:264-281) + the max-posterior bookkeeping of aux.c:165-182.
+ * path[u-1] = argmax_k f[u][k]*b[u][k]*s[u] (first maximum wins), maxp[u-1] = its value;
+ * 12 bytes per bin leave the GPU instead of the 2*8*n of the tables. */
+int psmc_hip_decode(psmc_hip_ctx *ctx, int seg, int32_t *path, double *maxp);
+
 /* Built-in check of the cross-lane primitives on the device (row replication
  * variants, DPP broadcasts, f64 MFMA layout).  Returns 0 when all agree;
  * a positive bitmask of failed primitives otherwise. */

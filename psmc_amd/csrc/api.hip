@@ -601,6 +601,25 @@ extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *
 	return PSMC_HIP_OK;
 }
 
+extern "C" int psmc_hip_decode(psmc_hip_ctx *c, int seg, int32_t *path, double *maxp)
+{
+	if (!c || seg < 0 || seg >= c->n_seg || !path) return fail(c, PSMC_HIP_EINVAL, "decode: bad argument");
+	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "decode: exact mode only");
+	if (!c->d_f || !c->have_b) return fail(c, PSMC_HIP_ESTATE, "decode: no E-step yet");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int L = c->L[seg];
+	int32_t *dp = nullptr; double *dm = nullptr;
+	if (hipMalloc((void **)&dp, sizeof(int32_t) * (size_t)L) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipMalloc");
+	if (hipMalloc((void **)&dm, sizeof(double) * (size_t)L) != hipSuccess) { (void)hipFree(dp); return fail(c, PSMC_HIP_ENOMEM, "hipMalloc"); }
+	int rc = launch_post_decode(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], L, c->n, dp, dm);
+	hipError_t e1 = hipMemcpyAsync(path, dp, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, c->stream);
+	hipError_t e2 = maxp ? hipMemcpyAsync(maxp, dm, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+	hipError_t e3 = hipStreamSynchronize(c->stream);
+	(void)hipFree(dp); (void)hipFree(dm);
+	if (rc || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, PSMC_HIP_EDEVICE, "decode");
+	return PSMC_HIP_OK;
+}
+
 extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[7])
 {
 	if (!c || !ms) return PSMC_HIP_EINVAL;

@@ -246,6 +246,37 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 	}
 }
 
+// ---------------------------------------------------------------- posterior decoding
+// hmm_post_decode (khmm.c:264-281) on the tables of one segment: path[u] = argmax_k
+// f[u][k]*b[u][k]*s[u] with the FIRST maximum winning (the reference compares with `<`),
+// maxp[u] = that posterior.  One wave per 64 positions, lane = state.
+__global__ __launch_bounds__(64) void k_post_decode(const double *__restrict__ f, const double *__restrict__ b,
+                                                      const double *__restrict__ s, int64_t off, int L, int n,
+                                                      int32_t *__restrict__ path, double *__restrict__ maxp)
+{
+	const int lane = threadIdx.x;
+	const int u0 = blockIdx.x * 64, u1 = min(L, u0 + 64);
+	for (int u = u0; u < u1; ++u) {
+		const int64_t g = off + u;
+		double v = lane < n ? f[g * 64 + lane] * b[g * 64 + lane] * s[g] : -1.0;
+		int k = lane;
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) {
+			const double ov = __shfl_xor(v, m, 64);
+			const int ok = __shfl_xor(k, m, 64);
+			if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+		}
+		if (lane == 0) { path[u] = k; maxp[u] = v; }
+	}
+}
+
+int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
+                       int32_t *path, double *maxp)
+{
+	hipLaunchKernelGGL(k_post_decode, dim3((L + 63) / 64), dim3(64), 0, st, f, b, s, off, L, n, path, maxp);
+	return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers
 int launch_exact(const EstepLaunch &p)
 {

@@ -69,6 +69,8 @@ constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
 int launch_fast(const EstepLaunch &p, FastReport *rep);
+int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
+                       int32_t *path, double *maxp);
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 int run_microbench(hipStream_t stream, double *d_out);
 int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n);

@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs",
-    "psmc_hip_get_tables", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe",
+    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe",
 ]
 
 
@@ -86,6 +86,7 @@ def load_library():
     lib.psmc_hip_fast_diag.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.psmc_hip_fast_repairs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.psmc_hip_get_tables.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+    lib.psmc_hip_decode.argtypes = [C.c_void_p, C.c_int, _i32p, _dp]
     lib.psmc_hip_selftest.argtypes = [C.c_int]
     lib.psmc_hip_last_timing.argtypes = [C.c_void_p, _dp]
     _LIB = lib
@@ -212,6 +213,13 @@ class HipEStep:
         b = np.zeros((L, self.n)) if want_b else None
         self._chk(self.lib.psmc_hip_get_tables(self.h, int(seg), _p(f), _p(b), _p(s)), "get_tables")
         return f, b, s
+
+    def decode(self, seg):
+        """(path, maxp): posterior-argmax state and its probability per bin (khmm.c:264-281), exact mode."""
+        L = int(self.lens[seg])
+        path = np.zeros(L, dtype=np.int32); mp = np.zeros(L)
+        self._chk(self.lib.psmc_hip_decode(self.h, int(seg), path.ctypes.data_as(_i32p), _p(mp)), "decode")
+        return path, mp
 
     def timing(self):
         ms = np.zeros(7)

@@ -32,6 +32,7 @@ static int hb_estep(void *self, const double *a, const double *e, const double *
 	return 0;
 }
 static int hb_tables(void *self, int seg, double *f, double *b, double *s) { return psmc_hip_get_tables(((hip_be *)self)->ctx, seg, f, b, s); }
+static int hb_decode(void *self, int seg, int32_t *path, double *maxp) { return psmc_hip_decode(((hip_be *)self)->ctx, seg, path, maxp); }
 static const char *hb_error(void *self) { return psmc_hip_last_error(((hip_be *)self)->ctx); }
 static void hb_destroy(void *self) { hip_be *h = (hip_be *)self; psmc_hip_destroy(h->ctx); free(h->chk); }
 
@@ -63,7 +64,7 @@ int main(int argc, char *argv[])
 		psmc_options_free(&o);
 		return 2;
 	}
-	psmc_estep_backend be = {&h, hb_load, hb_estep, hb_tables, hb_error, hb_destroy};
+	psmc_estep_backend be = {&h, hb_load, hb_estep, hb_tables, hb_decode, hb_error, hb_destroy};
 	int status = psmc_run(&o, &be);
 	be.destroy(be.self);
 	psmc_options_free(&o);

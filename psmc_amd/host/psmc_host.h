@@ -87,6 +87,8 @@ typedef struct psmc_estep_backend {
 	              double *chk);
 	/* hd->f, hd->b, hd->s of one segment, L*n / L*n / L (aux.c:157-158) */
 	int  (*tables)(void *self, int seg, double *f, double *b, double *s);
+	/* optional (may be NULL): posterior argmax path[L] and its probability maxp[L] (khmm.c:264-281) */
+	int  (*decode)(void *self, int seg, int32_t *path, double *maxp);
 	const char *(*error)(void *self);
 	void (*destroy)(void *self);
 } psmc_estep_backend;

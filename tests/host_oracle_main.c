@@ -65,6 +65,6 @@ int main(int argc, char **argv)
 	orc_be ob; memset(&ob, 0, sizeof ob);
 	ob.n = pat.n_states;
 	ob.a = (double *)malloc(sizeof(double) * ob.n * ob.n); ob.e = (double *)malloc(sizeof(double) * 3 * ob.n); ob.a0 = (double *)malloc(sizeof(double) * ob.n);
-	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, ob_error, ob_destroy};
+	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, 0, ob_error, ob_destroy};
 	return psmc_run(&o, &be);
 }

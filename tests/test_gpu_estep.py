@@ -118,6 +118,22 @@ def test_exact_bootstrap_selection(hip, golden, oracle):
     es.close()
 
 
+def test_exact_device_decode(hip, golden, oracle):
+    """psmc_hip_decode: posterior argmax path and its probability (hmm_post_decode, khmm.c:264-281),
+    index work bit-exact, first maximum wins."""
+    for key in ("n64_curve", "n23_flat"):
+        p = golden.params(key)
+        es = hip.HipEStep(p["a"].shape[0], mode=hip.MODE_EXACT)
+        es.load_segments(golden.segs_small)
+        es.estep(p["a"], p["e"], p["a0"])
+        for seg in (3, 8, 11, 12):
+            f, b, s, lk, chk = oracle.fwd_bwd(p["a"], p["e"], p["a0"], golden.segs_small[seg])
+            path, mp = oracle.post_decode(f, b, s)
+            gp, gm = es.decode(seg)
+            assert np.array_equal(gp, path[1:]) and bits_equal(gm, mp[1:])
+        es.close()
+
+
 def test_errors(hip):
     es = hip.HipEStep(8, mode=hip.MODE_EXACT)
     a, e, a0 = random_hmm(np.random.default_rng(0), 8)

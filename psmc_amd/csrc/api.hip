@@ -18,7 +18,7 @@ using namespace psmc;
 #define HMM_TINY_H 1e-25
 
 struct psmc_hip_ctx {
-	int n = 0, device = 0, mode = PSMC_HIP_MODE_EXACT;
+	int n = 0, ns = 64, device = 0, mode = PSMC_HIP_MODE_EXACT; // ns: states padded to 64 or 128
 	std::string err;
 	// options
 	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
@@ -41,7 +41,7 @@ struct psmc_hip_ctx {
 	bool plan_dirty = true;
 	// parameters
 	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0 | re(3)
-	static constexpr size_t PAR_LEN = 4096 + 3 * 4096 + 3 * 64 + 64 + 3 * 64; // ... | re(3)
+	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128; // ns=64: ... | re(3) (16832); ns=128: a | aT | e(3) | a0
 	// tables
 	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr, *d_sb = nullptr;
 	int64_t tab_bins = 0; bool have_b = false;
@@ -119,14 +119,14 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (!out) return PSMC_HIP_EINVAL;
 	*out = nullptr;
 	if (n_states < 1) return PSMC_HIP_EINVAL;
-	if (n_states > NS) return PSMC_HIP_ENOTSUP;
 	if (mode != PSMC_HIP_MODE_EXACT && mode != PSMC_HIP_MODE_FAST) return PSMC_HIP_EINVAL;
+	if (n_states > 128 || (n_states > NS && mode == PSMC_HIP_MODE_FAST)) return PSMC_HIP_ENOTSUP; // fast mode: one lane per state
 	int nd = psmc_hip_device_count();
 	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
 	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
 	psmc_hip_ctx *c = new (std::nothrow) psmc_hip_ctx();
 	if (!c) return PSMC_HIP_ENOMEM;
-	c->n = n_states; c->device = device; c->mode = mode;
+	c->n = n_states; c->ns = n_states > 64 ? 128 : 64; c->device = device; c->mode = mode;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
@@ -265,6 +265,19 @@ extern "C" int psmc_hip_select(psmc_hip_ctx *c, int n_sel, const int32_t *idx)
 static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, hipStream_t st)
 {
 	const int n = c->n;
+	if (c->ns == 128) { // a | aT | e(3) | a0, stride 128; the e*a products are formed on the device
+		double *pa = c->h_par, *pt = pa + 16384, *pe = pt + 16384, *pa0 = pe + 384;
+		HIPCHK(c, hipStreamSynchronize(st));
+		memset(pa, 0, psmc_hip_ctx::PAR_LEN * sizeof(double));
+		for (int k = 0; k < n; ++k) {
+			for (int l = 0; l < n; ++l) { pa[k * 128 + l] = a[k * n + l]; pt[l * 128 + k] = a[k * n + l]; }
+			pe[k] = e[k]; pe[128 + k] = e[n + k];
+			pa0[k] = a0[k];
+		}
+		for (int k = 0; k < 128; ++k) pe[256 + k] = 1.0; // khmm.c:21
+		HIPCHK(c, hipMemcpyAsync(c->d_par, pa, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
+		return 0;
+	}
 	double *pa = c->h_par, *pae = pa + 4096, *pe = pae + 3 * 4096, *pa0 = pe + 3 * 64, *pre = pa0 + 64;
 	HIPCHK(c, hipStreamSynchronize(st)); // previous async copy out of the pinned staging buffer
 	memset(pa, 0, psmc_hip_ctx::PAR_LEN * sizeof(double));
@@ -287,7 +300,7 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b)
 	const int64_t bins = c->total + 128;
 	if (c->tab_bins < bins) {
 		int rc;
-		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * c->ns))) return rc;
 		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) return rc;
 		if (c->mode == PSMC_HIP_MODE_FAST && (rc = dev_alloc(c, &c->d_sb, (size_t)bins))) return rc;
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
@@ -296,7 +309,7 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b)
 	}
 	if (need_b && !c->have_b) {
 		int rc;
-		if ((rc = dev_alloc(c, &c->d_b, (size_t)c->tab_bins * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_b, (size_t)c->tab_bins * c->ns))) return rc;
 		c->have_b = true;
 	}
 	return 0;
@@ -309,6 +322,8 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.rep_impl = c->rep_impl; p.expect_impl = c->expect_impl; p.n_states = c->n;
 	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
 	p.d_re = c->d_par + 4 * 4096 + 192 + 64;
+	p.ns = c->ns;
+	if (c->ns == 128) { p.d_aeT = c->d_par + 16384; p.d_e = c->d_par + 32768; p.d_a0 = c->d_par + 32768 + 384; p.d_re = nullptr; }
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
 	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s; p.d_sb = c->d_sb;
@@ -357,10 +372,11 @@ static int run_exact(psmc_hip_ctx *c, const double *a, const double *e, const do
 	int rc;
 	if ((rc = ensure_tables(c, true))) return rc;
 	const int nw = (int)c->work.size();
+	const size_t S = (size_t)c->ns;
 	if (c->seg_cap < nw || !c->d_chk) {
-		if ((rc = dev_alloc(c, &c->d_segA, (size_t)nw * 4096))) return rc;
-		if ((rc = dev_alloc(c, &c->d_segE, (size_t)nw * 192))) return rc;
-		if ((rc = dev_alloc(c, &c->d_segA0, (size_t)nw * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_segA, (size_t)nw * S * S))) return rc;
+		if ((rc = dev_alloc(c, &c->d_segE, (size_t)nw * 3 * S))) return rc;
+		if ((rc = dev_alloc(c, &c->d_segA0, (size_t)nw * S))) return rc;
 		if ((rc = dev_alloc(c, &c->d_chk, (size_t)c->n_seg))) return rc;
 		c->seg_cap = nw;
 	}
@@ -369,11 +385,11 @@ static int run_exact(psmc_hip_ctx *c, const double *a, const double *e, const do
 	fill_common(c, p, c->stream);
 	p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
 	if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact", hipGetLastError());
-	c->h_segA.resize((size_t)nw * 4096); c->h_segE.resize((size_t)nw * 192); c->h_segA0.resize((size_t)nw * 64);
+	c->h_segA.resize((size_t)nw * S * S); c->h_segE.resize((size_t)nw * 3 * S); c->h_segA0.resize((size_t)nw * S);
 	c->h_chk.resize(c->n_seg); c->h_s.resize((size_t)c->total);
-	HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * 4096, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 192, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipMemcpyAsync(c->h_segA0.data(), c->d_segA0, sizeof(double) * nw * 64, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_segA0.data(), c->d_segA0, sizeof(double) * nw * S, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->h_chk.data(), c->d_chk, sizeof(double) * c->n_seg, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->h_s.data(), c->d_s, sizeof(double) * c->total, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -389,15 +405,16 @@ extern "C" int psmc_hip_estep_segments(psmc_hip_ctx *c, const double *a, const d
 	int rc = run_exact(c, a, e, a0);
 	if (rc) return rc;
 	const int n = c->n, ns = (int)c->sel.size();
+	const size_t S = (size_t)c->ns;
 	for (int i = 0; i < ns; ++i) {
 		const int w = c->sel2work[i], seg = c->sel[i];
 		if (segA)
 			for (int k = 0; k < n; ++k)
-				memcpy(segA + ((size_t)i * n + k) * n, &c->h_segA[(size_t)w * 4096 + k * 64], sizeof(double) * n);
+				memcpy(segA + ((size_t)i * n + k) * n, &c->h_segA[(size_t)w * S * S + k * S], sizeof(double) * n);
 		if (segE)
 			for (int b = 0; b < 3; ++b)
-				memcpy(segE + ((size_t)i * 3 + b) * n, &c->h_segE[(size_t)w * 192 + b * 64], sizeof(double) * n);
-		if (segA0) memcpy(segA0 + (size_t)i * n, &c->h_segA0[(size_t)w * 64], sizeof(double) * n);
+				memcpy(segE + ((size_t)i * 3 + b) * n, &c->h_segE[(size_t)w * 3 * S + b * S], sizeof(double) * n);
+		if (segA0) memcpy(segA0 + (size_t)i * n, &c->h_segA0[(size_t)w * S], sizeof(double) * n);
 		if (segLL) segLL[i] = host_lk(&c->h_s[(size_t)c->off[seg]], c->L[seg]);
 		if (chk) chk[i] = c->h_chk[seg];
 	}
@@ -410,6 +427,7 @@ static int estep_exact(psmc_hip_ctx *c, const double *a, const double *e, const 
 	int rc = run_exact(c, a, e, a0);
 	if (rc) return rc;
 	const int n = c->n, ns = (int)c->sel.size(), nw = (int)c->work.size();
+	const size_t S = (size_t)c->ns;
 	std::vector<double> lk(nw);
 	for (int w = 0; w < nw; ++w) lk[w] = host_lk(&c->h_s[(size_t)c->off[c->work[w]]], c->L[c->work[w]]);
 	// hmm_add_expect in input order (khmm.c:346-359), he_sum starting from calloc'ed zeros
@@ -417,14 +435,14 @@ static int estep_exact(psmc_hip_ctx *c, const double *a, const double *e, const 
 	double ll = 0.0;
 	for (int i = 0; i < ns; ++i) {
 		const int w = c->sel2work[i];
-		const double *hA = &c->h_segA[(size_t)w * 4096], *hE = &c->h_segE[(size_t)w * 192], *hA0 = &c->h_segA0[(size_t)w * 64];
+		const double *hA = &c->h_segA[(size_t)w * S * S], *hE = &c->h_segE[(size_t)w * 3 * S], *hA0 = &c->h_segA0[(size_t)w * S];
 		ll += lk[w]; // em.c:48
 		for (int k = 0; k < n; ++k) {
 			sA0[k] += hA0[k];
-			for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * 64 + l];
+			for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * S + l];
 		}
 		for (int b = 0; b < 2; ++b)
-			for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * 64 + l];
+			for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * S + l];
 		if (chk) chk[i] = c->h_chk[c->sel[i]];
 	}
 	if (A) memcpy(A, sA.data(), sizeof(double) * n * n);
@@ -589,13 +607,14 @@ extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *
 	HIPCHK(c, hipSetDevice(c->device));
 	const int n = c->n, L = c->L[seg];
 	const int64_t off = c->off[seg];
-	std::vector<double> tmp((size_t)L * 64);
+	const size_t S = (size_t)c->ns;
+	std::vector<double> tmp((size_t)L * S);
 	for (int which = 0; which < 2; ++which) {
 		double *dst = which == 0 ? f : b;
 		const double *src = which == 0 ? c->d_f : c->d_b;
 		if (!dst) continue;
-		HIPCHK(c, hipMemcpy(tmp.data(), src + off * 64, sizeof(double) * (size_t)L * 64, hipMemcpyDeviceToHost));
-		for (int u = 0; u < L; ++u) memcpy(dst + (size_t)u * n, &tmp[(size_t)u * 64], sizeof(double) * n);
+		HIPCHK(c, hipMemcpy(tmp.data(), src + off * S, sizeof(double) * (size_t)L * S, hipMemcpyDeviceToHost));
+		for (int u = 0; u < L; ++u) memcpy(dst + (size_t)u * n, &tmp[(size_t)u * S], sizeof(double) * n);
 	}
 	if (s) HIPCHK(c, hipMemcpy(s, c->d_s + off, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
 	return PSMC_HIP_OK;
@@ -611,7 +630,7 @@ extern "C" int psmc_hip_decode(psmc_hip_ctx *c, int seg, int32_t *path, double *
 	int32_t *dp = nullptr; double *dm = nullptr;
 	if (hipMalloc((void **)&dp, sizeof(int32_t) * (size_t)L) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipMalloc");
 	if (hipMalloc((void **)&dm, sizeof(double) * (size_t)L) != hipSuccess) { (void)hipFree(dp); return fail(c, PSMC_HIP_ENOMEM, "hipMalloc"); }
-	int rc = launch_post_decode(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], L, c->n, dp, dm);
+	int rc = launch_post_decode(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], L, c->n, c->ns, dp, dm);
 	hipError_t e1 = hipMemcpyAsync(path, dp, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, c->stream);
 	hipError_t e2 = maxp ? hipMemcpyAsync(maxp, dm, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
 	hipError_t e3 = hipStreamSynchronize(c->stream);

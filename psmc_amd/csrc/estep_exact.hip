@@ -141,11 +141,17 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 }
 
 // ---------------------------------------------------------------- expect
-// khmm.c:297-324.  grid = (n_work, 17): y<16 accumulates rows 4y..4y+3 of A for
-// one segment (lane = column l) in position order; y==16 accumulates E and A0
-// (lane = state k).  Per-segment results (he of em.c:49) go to segA/segE/segA0;
-// the host adds them in input order (hmm_add_expect, khmm.c:346-359).
-__global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ aeT, const double *__restrict__ e,
+// khmm.c:297-324.  S = padded number of states (64 or 128), H = S/64 column halves.
+// grid = (n_work, (S/4)*H + H): the first (S/4)*H blocks accumulate rows 4g..4g+3 of
+// A for one segment (lane = column lane+64*half) in position order; the last H
+// accumulate E and A0 (lane = state lane+64*half).  Per-segment results (he of
+// em.c:49) go to segA/segE/segA0; the host adds them in input order
+// (hmm_add_expect, khmm.c:346-359).  For S == 64 `aeT` is the precomputed
+// e[b][l]*a[k][l]; for S == 128 the same single-rounding product is formed here
+// from `a` (row-major) and `e`.
+template <int S>
+__global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ a, const double *__restrict__ aeT,
+                                                       const double *__restrict__ e,
                                                        const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                        const int64_t *__restrict__ seg_off,
                                                        const int32_t *__restrict__ seg_len, const int32_t *__restrict__ work,
@@ -153,20 +159,25 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
                                                        const double *__restrict__ s, double *__restrict__ segA,
                                                        double *__restrict__ segE, double *__restrict__ segA0)
 {
+	constexpr int H = S / 64, NA = (S / 4) * H;
 	const int lane = threadIdx.x;
 	const int seg = work[blockIdx.x];
 	const int64_t off = seg_off[seg];
 	const int L = seg_len[seg];
 	const uint8_t *o = obs + off;
-	const double *fo = f + off * 64, *bo = b + off * 64, *so = s + off;
+	const double *fo = f + off * S, *bo = b + off * S, *so = s + off;
 	constexpr int BLK = 16;
-	if (blockIdx.y < 16) {
-		const int k0 = blockIdx.y * 4;
-		double q[3][4]; // ae[sym][k0+j][l], l = lane
+	if (blockIdx.y < NA) {
+		const int k0 = (blockIdx.y / H) * 4;
+		const int col = lane + 64 * (blockIdx.y % H);
+		double q[3][4]; // ae[sym][k0+j][l], l = col
 #pragma unroll
 		for (int sy = 0; sy < 3; ++sy)
 #pragma unroll
-			for (int j = 0; j < 4; ++j) q[sy][j] = aeT[sy * 4096 + lane * 64 + k0 + j];
+			for (int j = 0; j < 4; ++j) {
+				if constexpr (S == 64) q[sy][j] = aeT[sy * 4096 + lane * 64 + k0 + j];
+				else q[sy][j] = e[sy * S + col] * a[(k0 + j) * S + col]; // khmm.c:194-206
+			}
 		double acc[4] = {PSMC_TINY, PSMC_TINY, PSMC_TINY, PSMC_TINY}; // khmm.c:305-306
 		// u = 1..L-1 ; index i = u-1 = 0..L-2 ; uses f[i][k], b[i+1][l], obs[i+1]
 		const int n = L - 1;
@@ -174,10 +185,10 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 		double ft = 0.0, bn[BLK]; int sv = 2;
 		auto load_blk = [&](int i0, double &ft_, double (&bn_)[BLK], int &sv_) {
 			const int ii = min(i0 + fl_i, max(n - 1, 0));
-			ft_ = fo[(int64_t)ii * 64 + k0 + fl_j];
+			ft_ = fo[(int64_t)ii * S + k0 + fl_j];
 			sv_ = o[min(i0 + min(lane, BLK - 1) + 1, L - 1)];
 #pragma unroll
-			for (int t = 0; t < BLK; ++t) bn_[t] = bo[(int64_t)min(i0 + t + 1, L - 1) * 64 + lane];
+			for (int t = 0; t < BLK; ++t) bn_[t] = bo[(int64_t)min(i0 + t + 1, L - 1) * S + col];
 		};
 		if (n > 0) load_blk(0, ft, bn, sv);
 		for (int i0 = 0; i0 < n; i0 += BLK) {
@@ -205,10 +216,11 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 #pragma unroll
 			for (int t = 0; t < BLK; ++t) bn[t] = bn2[t];
 		}
-		double *out = segA + (int64_t)blockIdx.x * 4096;
+		double *out = segA + (int64_t)blockIdx.x * (S * S);
 #pragma unroll
-		for (int j = 0; j < 4; ++j) out[(k0 + j) * 64 + lane] = acc[j];
+		for (int j = 0; j < 4; ++j) out[(k0 + j) * S + col] = acc[j];
 	} else {
+		const int col = lane + 64 * (blockIdx.y - NA);
 		double E0 = PSMC_TINY, E1 = PSMC_TINY, E2 = PSMC_TINY; // khmm.c:307-308
 		const int n = L - 1; // u = 1..L-1, index i = u-1: f[i], b[i], s[i], obs[i]
 		double fu[BLK], bu[BLK], sv = 0.0; int symv = 2;
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 			sv_ = so[ii]; symv_ = o[ii];
 #pragma unroll
 			for (int t = 0; t < BLK; ++t) {
-				const int64_t r = (int64_t)min(i0 + t, L - 1) * 64 + lane;
+				const int64_t r = (int64_t)min(i0 + t, L - 1) * S + col;
 				fu_[t] = fo[r]; bu_[t] = bo[r];
 			}
 		};
@@ -239,17 +251,18 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 #pragma unroll
 			for (int t = 0; t < BLK; ++t) { fu[t] = fu2[t]; bu[t] = bu2[t]; }
 		}
-		double *oe = segE + (int64_t)blockIdx.x * 192;
-		oe[lane] = E0; oe[64 + lane] = E1; oe[128 + lane] = E2;
+		double *oe = segE + (int64_t)blockIdx.x * (3 * S);
+		oe[col] = E0; oe[S + col] = E1; oe[2 * S + col] = E2;
 		const int sym1 = o[0]; // khmm.c:321-322: A0[l] += a0[l]*e[o_1][l]*b[1][l], A0 starts at 0
-		segA0[(int64_t)blockIdx.x * 64 + lane] = 0.0 + a0[lane] * e[sym1 * 64 + lane] * bo[lane];
+		segA0[(int64_t)blockIdx.x * S + col] = 0.0 + a0[col] * e[sym1 * S + col] * bo[col];
 	}
 }
 
 // ---------------------------------------------------------------- posterior decoding
 // hmm_post_decode (khmm.c:264-281) on the tables of one segment: path[u] = argmax_k
 // f[u][k]*b[u][k]*s[u] with the FIRST maximum winning (the reference compares with `<`),
-// maxp[u] = that posterior.  One wave per 64 positions, lane = state.
+// maxp[u] = that posterior.  One wave per 64 positions, lane = state (and state+64).
+template <int S>
 __global__ __launch_bounds__(64) void k_post_decode(const double *__restrict__ f, const double *__restrict__ b,
                                                       const double *__restrict__ s, int64_t off, int L, int n,
                                                       int32_t *__restrict__ path, double *__restrict__ maxp)
@@ -258,8 +271,13 @@ __global__ __launch_bounds__(64) void k_post_decode(const double *__restrict__ f
 	const int u0 = blockIdx.x * 64, u1 = min(L, u0 + 64);
 	for (int u = u0; u < u1; ++u) {
 		const int64_t g = off + u;
-		double v = lane < n ? f[g * 64 + lane] * b[g * 64 + lane] * s[g] : -1.0;
+		double v = lane < n ? f[g * S + lane] * b[g * S + lane] * s[g] : -1.0;
 		int k = lane;
+		if constexpr (S == 128) {
+			const int k2 = lane + 64;
+			const double v2 = k2 < n ? f[g * S + k2] * b[g * S + k2] * s[g] : -1.0;
+			if (v2 > v) { v = v2; k = k2; }
+		}
 #pragma unroll
 		for (int m = 32; m >= 1; m >>= 1) {
 			const double ov = __shfl_xor(v, m, 64);
@@ -271,9 +289,233 @@ __global__ __launch_bounds__(64) void k_post_decode(const double *__restrict__ f
 }
 
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
-                       int32_t *path, double *maxp)
+                       int ns, int32_t *path, double *maxp)
 {
-	hipLaunchKernelGGL(k_post_decode, dim3((L + 63) / 64), dim3(64), 0, st, f, b, s, off, L, n, path, maxp);
+	if (ns == 128)
+		hipLaunchKernelGGL(k_post_decode<128>, dim3((L + 63) / 64), dim3(64), 0, st, f, b, s, off, L, n, path, maxp);
+	else
+		hipLaunchKernelGGL(k_post_decode<64>, dim3((L + 63) / 64), dim3(64), 0, st, f, b, s, off, L, n, path, maxp);
+	return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- 65..128 states
+// Same recursions with two ADJACENT states per lane (k = 2*lane and 2*lane + 1;
+// `-p "64*2"` of the reference's README gives 128).  The 128x128 transition matrix
+// (128 KB) no longer fits a lane's registers, so each block keeps it in LDS
+// (M[l*128+k]) and streams it through the ordered dot product: one ds_read_b128
+// per source state l feeds both of the lane's outputs, whose two add chains
+// interleave.  e[b][l]*a[k][l] of the backward sweep is formed on the fly with one
+// rounding, exactly as hmm_pre_backward does (khmm.c:194-206).
+constexpr int S2 = 128;
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// strict left-to-right sum over states 0..127; ev/od: replicated forms of the even / odd states
+#define PSMC_SEQ2(N, B) s = s + bcast16<N>(ev[B]); s = s + bcast16<N>(od[B]);
+#define PSMC_SEQ2x16(B)                                                                         \
+	PSMC_SEQ2(0, B) PSMC_SEQ2(1, B) PSMC_SEQ2(2, B) PSMC_SEQ2(3, B) PSMC_SEQ2(4, B) PSMC_SEQ2(5, B)     \
+	PSMC_SEQ2(6, B) PSMC_SEQ2(7, B) PSMC_SEQ2(8, B) PSMC_SEQ2(9, B) PSMC_SEQ2(10, B) PSMC_SEQ2(11, B)   \
+	PSMC_SEQ2(12, B) PSMC_SEQ2(13, B) PSMC_SEQ2(14, B) PSMC_SEQ2(15, B)
+__device__ __forceinline__ double seq_sum_rep2(const double (&ev)[4], const double (&od)[4]) {
+	double s = 0.0;
+	PSMC_SEQ2x16(0) PSMC_SEQ2x16(1) PSMC_SEQ2x16(2) PSMC_SEQ2x16(3)
+	return s;
+}
+
+// two consecutive source states l = 2*(16 blk + N) and l + 1 (rows R, R+1 of the 16 staged rows)
+#define PSMC_XT2(N, R)                                                                          \
+	{ const double xb = bcast16<N>(r0); acc0 = acc0 + xb * mc[R].x; acc1 = acc1 + xb * mc[R].y; }     \
+	{ const double xb = bcast16<N>(r1); acc0 = acc0 + xb * mc[(R) + 1].x; acc1 = acc1 + xb * mc[(R) + 1].y; }
+// same with the emission factor: (e_l * M[l][k]) * x_l, the product e*a rounded first (khmm.c:203)
+#define PSMC_XT2E(N, R)                                                                         \
+	{ const double xb = bcast16<N>(r0), eb = bcast16<N>(e0);                                        \
+	  acc0 = acc0 + (eb * mc[R].x) * xb; acc1 = acc1 + (eb * mc[R].y) * xb; }                       \
+	{ const double xb = bcast16<N>(r1), eb = bcast16<N>(e1);                                        \
+	  acc0 = acc0 + (eb * mc[(R) + 1].x) * xb; acc1 = acc1 + (eb * mc[(R) + 1].y) * xb; }
+#define PSMC_XT2x8(T, N0)                                                                       \
+	T(N0 + 0, 0) T(N0 + 1, 2) T(N0 + 2, 4) T(N0 + 3, 6) T(N0 + 4, 8) T(N0 + 5, 10) T(N0 + 6, 12) T(N0 + 7, 14)
+
+// One group of 16 source states (rows 16*IT .. 16*IT+15 of M) of the ordered dot product below.
+template <bool WITH_E, int IT>
+__device__ __forceinline__ void xdot128_group(const d2_t *t, d2_t (&mc)[16], double &acc0, double &acc1,
+                                              const double (&rx0)[4], const double (&rx1)[4], const double (&ee0)[4],
+                                              const double (&ee1)[4])
+{
+	d2_t mn[16];
+	if constexpr (IT < 7) {
+#pragma unroll
+		for (int l = 0; l < 16; ++l) mn[l] = t[(16 * (IT + 1) + l) * 64];
+	}
+	__builtin_amdgcn_sched_barrier(0);
+	double r0 = rx0[IT >> 1], r1 = rx1[IT >> 1], e0 = WITH_E ? ee0[IT >> 1] : 0.0, e1 = WITH_E ? ee1[IT >> 1] : 0.0;
+	asm volatile("" : "+v"(r0), "+v"(r1), "+v"(e0), "+v"(e1));
+	if constexpr (WITH_E) {
+		if constexpr ((IT & 1) == 0) { PSMC_XT2x8(PSMC_XT2E, 0) } else { PSMC_XT2x8(PSMC_XT2E, 8) }
+	} else {
+		if constexpr ((IT & 1) == 0) { PSMC_XT2x8(PSMC_XT2, 0) } else { PSMC_XT2x8(PSMC_XT2, 8) }
+	}
+	__builtin_amdgcn_sched_barrier(0);
+	if constexpr (IT < 7) {
+#pragma unroll
+		for (int l = 0; l < 16; ++l) mc[l] = mn[l];
+	}
+}
+
+// y[j] = sum_{l=0..127} (WITH_E ? e_l * M[l][k] : M[l][k]) * x_l,  k = 2*lane + j, strict l order.
+// x[j] = value of state 2*lane + j; ee0/ee1[blk] = e of the even / odd states in replicated form.
+// The 8 groups of 16 rows are software-pipelined by hand: the reads of the next group are
+// issued before the 32 ordered terms of the current one; the scheduling barriers keep the
+// compiler from hoisting all 128 reads, and the opaque copies from keeping (spilling) values
+// across groups.
+template <int REP, bool WITH_E>
+__device__ __forceinline__ void xdot128_lds(const double *m_lds, int lane, const double (&x)[2], const double (&ee0)[4],
+                                            const double (&ee1)[4], double (&y)[2])
+{
+	double rx0[4], rx1[4];
+	rep_rows<REP>(x[0], rx0); rep_rows<REP>(x[1], rx1);
+	asm volatile("" : "+v"(lane)); // opaque per call: the LDS reads are loop invariant and must not be hoisted out of the sweep
+	const d2_t *t = reinterpret_cast<const d2_t *>(m_lds) + lane; // row stride 64 d2
+	d2_t mc[16];
+#pragma unroll
+	for (int l = 0; l < 16; ++l) mc[l] = t[l * 64];
+	double acc0 = 0.0, acc1 = 0.0;
+	xdot128_group<WITH_E, 0>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	xdot128_group<WITH_E, 1>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	xdot128_group<WITH_E, 2>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	xdot128_group<WITH_E, 3>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	xdot128_group<WITH_E, 4>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	xdot128_group<WITH_E, 5>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	xdot128_group<WITH_E, 6>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	xdot128_group<WITH_E, 7>(t, mc, acc0, acc1, rx0, rx1, ee0, ee1);
+	y[0] = acc0; y[1] = acc1;
+}
+
+// blockDim.x / 64 segments per block (1, 2 or 4 waves sharing the LDS copy of the matrix)
+template <int REP>
+__global__ __launch_bounds__(256) void k_fwd_exact128(const double *__restrict__ a, const double *__restrict__ e,
+                                                        const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                        const int64_t *__restrict__ seg_off,
+                                                        const int32_t *__restrict__ seg_len, const int32_t *__restrict__ work,
+                                                        int n_work, double *__restrict__ f, double *__restrict__ s)
+{
+	extern __shared__ double lds_m[]; // a[l*128+k]: at[k][l] of khmm.c:162-166 read column-wise
+	for (int i = threadIdx.x; i < S2 * S2; i += blockDim.x) lds_m[i] = a[i];
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (w >= n_work) return;
+	const int seg = work[w];
+	const int64_t off = seg_off[seg];
+	const int L = seg_len[seg];
+	const double e0[2] = {e[2 * lane], e[2 * lane + 1]}, e1[2] = {e[S2 + 2 * lane], e[S2 + 2 * lane + 1]};
+	const uint8_t *o = obs + off;
+	double *fo = f + off * S2, *so = s + off;
+	int symv = o[lane]; // obs is padded by >= 64 bytes at the end
+	double x[2];
+	const double no_e[4] = {0, 0, 0, 0};
+	auto finish = [&](const double (&g)[2], int idx) { // normalise by the ordered sum, store (khmm.c:180-184)
+		double q0[4], q1[4];
+		rep_rows<REP>(g[0], q0); rep_rows<REP>(g[1], q1);
+		const double sum = seq_sum_rep2(q0, q1);
+		x[0] = g[0] / sum; x[1] = g[1] / sum;
+		d2_t v; v.x = x[0]; v.y = x[1];
+		reinterpret_cast<d2_t *>(fo + (int64_t)idx * S2)[lane] = v;
+		if (lane == 0) so[idx] = sum;
+	};
+	{ // position 1 (khmm.c:171-174)
+		const int sym = __builtin_amdgcn_readlane(symv, 0);
+		const double g[2] = {a0[2 * lane] * pick_e(sym, e0[0], e1[0]), a0[2 * lane + 1] * pick_e(sym, e0[1], e1[1])};
+		finish(g, 0);
+	}
+	for (int base = 0; base < L; base += 64) {
+		const int nb = min(64, L - base);
+		const int symn = (base + 64 < L) ? (int)o[base + 64 + lane] : 2;
+		for (int i = (base == 0 ? 1 : 0); i < nb; ++i) { // khmm.c:176-185
+			const int sym = __builtin_amdgcn_readlane(symv, i);
+			double tmp[2];
+			xdot128_lds<REP, false>(lds_m, lane, x, no_e, no_e, tmp);
+			const double g[2] = {pick_e(sym, e0[0], e1[0]) * tmp[0], pick_e(sym, e0[1], e1[1]) * tmp[1]};
+			finish(g, base + i);
+		}
+		symv = symn;
+	}
+}
+
+template <int REP>
+__global__ __launch_bounds__(256) void k_bwd_exact128(const double *__restrict__ aT, const double *__restrict__ e,
+                                                        const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                        const int64_t *__restrict__ seg_off,
+                                                        const int32_t *__restrict__ seg_len, const int32_t *__restrict__ work,
+                                                        int n_work, const double *__restrict__ s, double *__restrict__ b,
+                                                        double *__restrict__ chk)
+{
+	extern __shared__ double lds_m[]; // aT[l*128+k] = a[k][l], then e[0][*], e[1][*], e[2][*]
+	for (int i = threadIdx.x; i < S2 * S2; i += blockDim.x) lds_m[i] = aT[i];
+	for (int i = threadIdx.x; i < 3 * S2; i += blockDim.x) lds_m[S2 * S2 + i] = e[i];
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (w >= n_work) return;
+	const int seg = work[w];
+	const int64_t off = seg_off[seg];
+	const int L = seg_len[seg];
+	const uint8_t *o = obs + off;
+	const double *so = s + off;
+	double *bo = b + off * S2;
+	double x[2];
+	x[0] = x[1] = 1.0 / so[L - 1]; // b[L][k] = 1/s[L] (khmm.c:226)
+	{ d2_t v; v.x = x[0]; v.y = x[1]; reinterpret_cast<d2_t *>(bo + (int64_t)(L - 1) * S2)[lane] = v; }
+	for (int top = L - 2; top >= 0; top -= 64) {
+		const int nb = min(64, top + 1);
+		const int lo = top - 63;
+		const int idx = max(lo + lane, 0);
+		const double sv = so[idx];
+		const int symv = o[idx + 1]; // symbol of position u+1 (index u)
+		for (int i = 63; i >= 64 - nb; --i) {
+			const int sym = __builtin_amdgcn_readlane(symv, i);
+			const double su = readlane_f64(sv, i);
+			// emission row of this symbol in replicated form (even / odd states); row 2 is all 1.0
+			// (khmm.c:21) and 1.0*a[k][l] is a[k][l] exactly, so one code path serves all symbols
+			double y[2], ee0[4], ee1[4];
+			const d2_t *ep = reinterpret_cast<const d2_t *>(lds_m + S2 * S2 + sym * S2) + (lane & 15);
+#pragma unroll
+			for (int blk = 0; blk < 4; ++blk) { const d2_t v = ep[16 * blk]; ee0[blk] = v.x; ee1[blk] = v.y; }
+			xdot128_lds<REP, true>(lds_m, lane, x, ee0, ee1, y);
+			x[0] = y[0] / su; x[1] = y[1] / su;
+			d2_t v; v.x = x[0]; v.y = x[1];
+			reinterpret_cast<d2_t *>(bo + (int64_t)(lo + i) * S2)[lane] = v;
+		}
+	}
+	{ // underflow check value (khmm.c:237-238)
+		const int sym = o[0];
+		const double t0 = a0[2 * lane] * x[0] * e[sym * S2 + 2 * lane], t1 = a0[2 * lane + 1] * x[1] * e[sym * S2 + 2 * lane + 1];
+		double q0[4], q1[4];
+		rep_rows<REP>(t0, q0); rep_rows<REP>(t1, q1);
+		const double c = seq_sum_rep2(q0, q1);
+		if (lane == 0) chk[seg] = c;
+	}
+}
+
+template <int REP> static int launch_exact128_t(const EstepLaunch &p)
+{
+	const size_t lds = sizeof(double) * (S2 * S2 + 3 * S2); // 131 KB of the CU's 160 KB
+	// per device and cheap: allow more than the default 64 KB of dynamic LDS
+	if (hipFuncSetAttribute((const void *)k_fwd_exact128<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+	    hipFuncSetAttribute((const void *)k_bwd_exact128<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+		return (int)hipGetLastError();
+	// the sweeps are LDS-bandwidth bound: spread the segments over all 256 CUs before stacking waves on one
+	const int wpb = p.n_work <= 256 ? 1 : (p.n_work <= 512 ? 2 : 4);
+	const int nb = (p.n_work + wpb - 1) / wpb;
+	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
+	hipLaunchKernelGGL(k_fwd_exact128<REP>, dim3(nb), dim3(64 * wpb), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
+	                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_f, p.d_s);
+	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
+	hipLaunchKernelGGL(k_bwd_exact128<REP>, dim3(nb), dim3(64 * wpb), lds, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
+	                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
+	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
+	hipLaunchKernelGGL(k_expect_exact<128>, dim3(p.n_work, 66), dim3(64), 0, p.stream, p.d_a, p.d_aeT, p.d_e, p.d_a0,
+	                   p.d_obs, p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);
+	if (p.ev[4]) hipEventRecord(p.ev[4], p.stream);
 	return (int)hipGetLastError();
 }
 
@@ -282,6 +524,7 @@ int launch_exact(const EstepLaunch &p)
 {
 	const int rep = p.rep_impl;
 	if (p.n_work <= 0) return 0;
+	if (p.ns == 128) return rep == 0 ? launch_exact128_t<0>(p) : launch_exact128_t<1>(p);
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
 	if (rep == 0)
 		hipLaunchKernelGGL(k_fwd_exact<0>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
@@ -298,8 +541,8 @@ int launch_exact(const EstepLaunch &p)
 		hipLaunchKernelGGL(k_bwd_exact<1>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
 		                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
-	hipLaunchKernelGGL(k_expect_exact, dim3(p.n_work, 17), dim3(64), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
-	                   p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+	hipLaunchKernelGGL(k_expect_exact<64>, dim3(p.n_work, 17), dim3(64), 0, p.stream, p.d_a, p.d_aeT, p.d_e, p.d_a0,
+	                   p.d_obs, p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
 	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);
 	if (p.ev[4]) hipEventRecord(p.ev[4], p.stream);
 	return (int)hipGetLastError();

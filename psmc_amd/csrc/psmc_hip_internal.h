@@ -31,6 +31,7 @@ struct EstepLaunch {
 	hipEvent_t evx[6];           // cross-stream dependencies; 4/5: count read-backs of the two chains
 	int overlap;
 	int rep_impl, expect_impl, n_states;
+	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)
 	// parameters (padded to NS)
 	const double *d_a;   // a[l*64+k] row-major P(l->k)... i.e. a[row*64+col]
 	const double *d_aeT; // aeT[b][l*64+k] = e[b][l]*a[k][l], b=0..2 (b=2 is a transposed)
@@ -70,7 +71,7 @@ constexpr int RED_ROWS = 64;
 int launch_exact(const EstepLaunch &p);
 int launch_fast(const EstepLaunch &p, FastReport *rep);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
-                       int32_t *path, double *maxp);
+                       int ns, int32_t *path, double *maxp);
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 int run_microbench(hipStream_t stream, double *d_out);
 int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n);

@@ -28,6 +28,7 @@ class Golden:
         self.small = _npz("estep_small.npz")
         self.mid = _npz("estep_mid.npz")
         self.kats = _npz("host_kats.npz")
+        self.n128 = _npz("estep_n128.npz")  # make_golden_n128.py: -p "64*2", 128 states
         s = _npz("segments_small.npz")
         self.segs_small = [s[k] for k in sorted(s)]
         s = _npz("segments_mid.npz")

@@ -105,6 +105,45 @@ def test_exact_vs_oracle_random(hip, oracle, n):
     es.close()
 
 
+@pytest.mark.parametrize("rep", [1, 0])
+def test_exact_n128_golden(hip, golden, rep):
+    """-p "64*2": 128 states, two per lane, transition matrix in LDS (k_fwd/bwd_exact128)."""
+    g, k = golden.n128, "n128_curve"
+    a, e, a0 = g[k + ".a"], g[k + ".e"], g[k + ".a0"]
+    es = hip.HipEStep(128, mode=hip.MODE_EXACT, rep_impl=rep)
+    es.load_segments(golden.segs_small)
+    r = es.estep(a, e, a0)
+    assert bits_equal(r["A"], g[k + ".A"]) and bits_equal(r["E"], g[k + ".E"]) and bits_equal(r["A0"], g[k + ".A0"])
+    assert r["LL"] == float(g[k + ".LL"])
+    assert bits_equal(r["chk"], g[k + ".seg_chk"])
+    s = es.estep_segments(a, e, a0)
+    assert bits_equal(s["seg_E"], g[k + ".seg_E"]) and bits_equal(s["seg_LL"], g[k + ".seg_LL"])
+    assert bits_equal(s["seg_A"].sum(2), g[k + ".seg_A_rowsum"]) and bits_equal(s["seg_A"].sum(1), g[k + ".seg_A_colsum"])
+    f, b, sc = es.tables(5)
+    assert bits_equal(f, g[k + ".f65"][1:]) and bits_equal(b, g[k + ".b65"][1:]) and bits_equal(sc, g[k + ".s65"][1:])
+    es.close()
+
+
+@pytest.mark.parametrize("n", [65, 100, 127, 128])
+def test_exact_wide_vs_oracle_random(hip, oracle, n):
+    rng = np.random.default_rng(300 + n)
+    a, e, a0 = random_hmm(rng, n)
+    segs = [rng.choice(3, size=L, p=[0.86, 0.1, 0.04]).astype(np.uint8) for L in (1, 2, 63, 64, 65, 129, 700, 3000)]
+    es = hip.HipEStep(n, mode=hip.MODE_EXACT)
+    es.load_segments(segs)
+    es.select([7, 0, 3, 7, 5])
+    r = es.estep(a, e, a0)
+    o = oracle.estep(a, e, a0, [segs[i] for i in (7, 0, 3, 7, 5)], per_seg=True)
+    assert bits_equal(r["A"], o["A"]) and bits_equal(r["E"], o["E"]) and bits_equal(r["A0"], o["A0"])
+    assert r["LL"] == o["LL"]
+    assert bits_equal(r["chk"], o["seg_chk"])
+    f, b, s, lk, chk = oracle.fwd_bwd(a, e, a0, segs[5])
+    path, mp = oracle.post_decode(f, b, s)
+    gp, gm = es.decode(5)
+    assert np.array_equal(gp, path[1:]) and bits_equal(gm, mp[1:])
+    es.close()
+
+
 def test_exact_bootstrap_selection(hip, golden, oracle):
     """psmc_resamp-style multiset: repeated segments are added once per occurrence, in order."""
     p = golden.params("n64_curve")
@@ -147,7 +186,9 @@ def test_errors(hip):
     with pytest.raises(hip.HipError):
         es.select([1])
     with pytest.raises(hip.HipError):
-        hip.HipEStep(65)
+        hip.HipEStep(129)                        # exact mode: at most 128 states (two per lane)
+    with pytest.raises(hip.HipError):
+        hip.HipEStep(65, mode=hip.MODE_FAST)     # fast mode: one lane per state
     es.close()
 
 

@@ -31,6 +31,22 @@ def test_tables_bitexact(golden, oracle, key):
     assert lk == float(g[key + ".lk65"])
 
 
+def test_estep_n128_bitexact(golden, oracle):
+    """-p "64*2" (128 states): E-step statistics and tables of the reference."""
+    g, k = golden.n128, "n128_curve"
+    a, e, a0 = g[k + ".a"], g[k + ".e"], g[k + ".a0"]
+    assert a.shape == (128, 128)
+    r = oracle.estep(a, e, a0, golden.segs_small, per_seg=True)
+    assert bits_equal(r["A"], g[k + ".A"]) and bits_equal(r["E"], g[k + ".E"]) and bits_equal(r["A0"], g[k + ".A0"])
+    assert r["LL"] == float(g[k + ".LL"])
+    assert bits_equal(r["seg_E"], g[k + ".seg_E"]) and bits_equal(r["seg_LL"], g[k + ".seg_LL"])
+    assert bits_equal(r["seg_chk"], g[k + ".seg_chk"])
+    assert bits_equal(r["seg_A"].sum(2), g[k + ".seg_A_rowsum"]) and bits_equal(r["seg_A"].sum(1), g[k + ".seg_A_colsum"])
+    f, b, s, lk, chk = oracle.fwd_bwd(a, e, a0, golden.segs_small[5])
+    assert bits_equal(f, g[k + ".f65"]) and bits_equal(b, g[k + ".b65"]) and bits_equal(s, g[k + ".s65"])
+    assert lk == float(g[k + ".lk65"])
+
+
 @pytest.mark.parametrize("key", ["n64_flat", "n64_curve"])
 def test_estep_mid_bitexact(golden, oracle, key):
     p = golden.params(key)

@@ -23,6 +23,11 @@ struct psmc_hip_ctx {
 	// options
 	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
 	double warm_tol = 1e-12;
+	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
+	int struct_tiles = 8192;   // "struct_tiles": tiles aimed at when the structured sweeps are used (4 per wave)
+	bool use_struct = false, planned_struct = false;
+	int *d_list = nullptr;     // list_f | list_b | rlist_f | rlist_b, n_chunks each
+	int n_sub_used = 6;
 	// segments
 	int n_seg = 0;
 	std::vector<int32_t> L;
@@ -41,7 +46,8 @@ struct psmc_hip_ctx {
 	bool plan_dirty = true;
 	// parameters
 	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0 | re(3)
-	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128; // ns=64: ... | re(3) (16832); ns=128: a | aT | e(3) | a0
+	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128; // ns=64: ... | re(3) | sp(5) (17152); ns=128: a | aT | e(3) | a0
+	static constexpr size_t SP_OFF = 4 * 4096 + 192 + 64 + 192; // structured vectors P | R | qa | c | dd
 	// tables
 	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr, *d_sb = nullptr;
 	int64_t tab_bins = 0; bool have_b = false;
@@ -153,7 +159,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_list};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -172,6 +178,8 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
 	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
 	else if (k == "max_rounds") c->max_rounds = (int)v;
+	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
+	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->plan_dirty = true; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
@@ -260,6 +268,33 @@ extern "C" int psmc_hip_select(psmc_hip_ctx *c, int n_sel, const int32_t *idx)
 	return PSMC_HIP_OK;
 }
 
+// Does a[][] have the PSMC form  a[k][l] = P_k qa_l (l<k),  R_k c_l (l>k)  (core.c:112-122)?
+// Numerical factorisation with qa_0 = c_{n-1} = 1, then a check of EVERY off-diagonal entry to
+// 64 ulp and of dd = diag - P.qa - R.c >= 0.  sp = P | R | qa | c | dd (64 each, zero padded).
+static bool factor_structure(int n, const double *a /* stride 64 */, double *sp)
+{
+	double *P = sp, *R = sp + 64, *qa = sp + 128, *cc = sp + 192, *dd = sp + 256;
+	memset(sp, 0, 5 * 64 * sizeof(double));
+	if (n < 3) return false;
+	const double pl = a[(n - 1) * 64 + 0], pu = a[0 * 64 + (n - 1)];
+	if (!(pl > 1e-280) || !(pu > 1e-280)) return false;
+	for (int l = 0; l < n - 1; ++l) qa[l] = a[(n - 1) * 64 + l] / pl;
+	for (int k = 1; k < n; ++k) P[k] = a[k * 64 + 0];
+	for (int l = 1; l < n; ++l) cc[l] = a[0 * 64 + l] / pu;
+	for (int k = 0; k < n - 1; ++k) R[k] = a[k * 64 + (n - 1)];
+	const double tol = 64 * 2.220446049250313e-16;
+	for (int k = 0; k < n; ++k) {
+		for (int l = 0; l < n; ++l) {
+			if (l == k) continue;
+			const double v = a[k * 64 + l], w = l < k ? P[k] * qa[l] : R[k] * cc[l];
+			if (!(fabs(v - w) <= tol * fabs(v) + 1e-290)) return false;
+		}
+		dd[k] = a[k * 64 + k] - P[k] * qa[k] - R[k] * cc[k];
+		if (!(dd[k] >= 0.0)) return false;
+	}
+	return true;
+}
+
 // pad the HMM parameters to 64 states and build aeT[b][l*64+k] = e[b][l]*a[k][l]
 // (hmm_pre_backward, khmm.c:194-206: one rounding per product), then upload.
 static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, hipStream_t st)
@@ -291,6 +326,7 @@ static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const
 	for (int b = 0; b < 3; ++b)
 		for (int l = 0; l < 64; ++l)
 			for (int k = 0; k < 64; ++k) pae[b * 4096 + l * 64 + k] = pe[b * 64 + l] * pa[k * 64 + l];
+	c->use_struct = c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, pa, pa + psmc_hip_ctx::SP_OFF);
 	HIPCHK(c, hipMemcpyAsync(c->d_par, pa, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
 	return 0;
 }
@@ -322,6 +358,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.rep_impl = c->rep_impl; p.expect_impl = c->expect_impl; p.n_states = c->n;
 	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
 	p.d_re = c->d_par + 4 * 4096 + 192 + 64;
+	p.d_sp = c->d_par + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
 	p.ns = c->ns;
 	if (c->ns == 128) { p.d_aeT = c->d_par + 16384; p.d_e = c->d_par + 32768; p.d_a0 = c->d_par + 32768 + 384; p.d_re = nullptr; }
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
@@ -458,8 +495,10 @@ static int plan_fast(psmc_hip_ctx *c)
 	int64_t bins = 0;
 	for (int32_t s : c->work) bins += c->L[s];
 	int T = c->chunk;
-	if (T <= 0) { // auto: about target_waves tiles, never below 256 bins
-		T = (int)((bins + c->target_waves - 1) / c->target_waves);
+	const bool st = c->use_struct;
+	if (T <= 0) { // auto: about target_waves (dense: 1 tile per wave) or struct_tiles (4 per wave) tiles, never below 256 bins
+		const int want = st ? c->struct_tiles : c->target_waves;
+		T = (int)((bins + want - 1) / want);
 		T = std::max(256, (T + 63) & ~63);
 	}
 	c->chunks.clear();
@@ -475,9 +514,23 @@ static int plan_fast(psmc_hip_ctx *c)
 			c->chunks.push_back(ch);
 		}
 	}
-	// longest tiles first is irrelevant (all equal); keep segment order for locality
 	const int nc = (int)c->chunks.size();
 	c->chunk_used = T;
+	c->planned_struct = st;
+	// the counts kernel splits a tile over n_sub waves: keep about the same number of partial blocks
+	c->n_sub_used = st ? std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1))) : c->n_sub;
+	// structured sweeps: four tiles share a wave, so order the tiles by their step count (longest first)
+	std::vector<int> lists((size_t)4 * nc, 0);
+	{
+		std::vector<std::pair<int, int>> kf(nc), kb(nc);
+		for (int i = 0; i < nc; ++i) {
+			const Chunk &ch = c->chunks[i];
+			kf[i] = {-(ch.hi - std::max(1, ch.lo - c->warmup) + 1), i};
+			kb[i] = {-(std::min(ch.hi + c->warmup + 1, ch.L) - ch.lo), i};
+		}
+		std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
+		for (int i = 0; i < nc; ++i) { lists[i] = kf[i].second; lists[(size_t)nc + i] = kb[i].second; }
+	}
 	int rc;
 	if (nc > c->chunk_cap) {
 		if ((rc = dev_alloc(c, &c->d_chunks, (size_t)nc))) return rc;
@@ -487,10 +540,11 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_list, (size_t)4 * nc))) return rc;
 		c->chunk_cap = nc;
 	}
-	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub * 4096))) return rc;
-	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub * 192))) return rc;
+	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub_used * 4096))) return rc;
+	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub_used * 192))) return rc;
 	if (!c->d_stage) {
 		if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * STATS_LEN))) return rc;
 		if ((rc = dev_alloc(c, &c->d_stats, (size_t)STATS_LEN))) return rc;
@@ -500,6 +554,7 @@ static int plan_fast(psmc_hip_ctx *c)
 			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
 	}
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_list, lists.data(), sizeof(int) * lists.size(), hipMemcpyHostToDevice));
 	c->plan_dirty = false;
 	return 0;
 }
@@ -511,11 +566,13 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep: no segments loaded");
 	int rc;
 	if ((rc = ensure_tables(c, true))) return rc;
-	if (c->plan_dirty && (rc = plan_fast(c))) return rc;
-	if ((rc = stage_params(c, a, e, a0, st))) return rc;
+	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
+	if ((c->plan_dirty || c->planned_struct != c->use_struct) && (rc = plan_fast(c))) return rc;
 	EstepLaunch p;
 	fill_common(c, p, st);
-	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub;
+	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub_used;
+	p.d_list_f = c->d_list; p.d_list_b = c->d_list + p.n_chunks;
+	p.d_rlist_f = c->d_list + 2 * p.n_chunks; p.d_rlist_b = c->d_list + 3 * p.n_chunks;
 	p.d_entry = c->d_entry; p.d_bentry = c->d_bentry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
 	p.d_dirty = c->d_dirty; p.d_cnt = c->d_cnt; p.h_cnt = c->h_cnt; p.tol = c->warm_tol; p.max_rounds = c->max_rounds;
 	p.d_touch_f = c->d_touch; p.d_touch_b = c->d_touch + p.n_chunks; p.d_dirty_b = c->d_dirty + p.n_chunks;
@@ -566,6 +623,13 @@ extern "C" int psmc_hip_fast_repairs(psmc_hip_ctx *c, int out[4])
 	if (!c || !out) return PSMC_HIP_EINVAL;
 	out[0] = c->report.fwd_rounds; out[1] = c->report.bwd_rounds;
 	out[2] = c->report.fwd_tiles; out[3] = c->report.bwd_tiles;
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[4])
+{
+	if (!c || !out) return PSMC_HIP_EINVAL;
+	out[0] = c->use_struct ? 1 : 0; out[1] = c->chunk_used; out[2] = (int)c->chunks.size(); out[3] = c->n_sub_used;
 	return PSMC_HIP_OK;
 }
 

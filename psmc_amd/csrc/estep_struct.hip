@@ -1,0 +1,316 @@
+// estep_struct.hip -- FAST-mode sweeps for transition matrices with the PSMC structure.
+//
+// psmc_update_hmm (lh3/psmc core.c:112-122) builds a[k][l] from two rank-1 triangles:
+//   l < k:  a[k][l] = P_k * qa_l        (tmp * ak1/cpik  times  q_aux[l])
+//   l > k:  a[k][l] = R_k * c_l         (tmp * q_aux[k]/cpik  times  alpha_l - alpha_{l+1})
+// so a matrix-vector product is two scans instead of N^2 multiply-adds:
+//   forward   (a^T x)_j = qa_j * SUF_j(x.P) + c_j * PRE_j(x.R) + dd_j * x_j
+//   backward  (a z)_k   = R_k * SUF_k(z.c) + P_k * PRE_k(z.qa) + dd_k * z_k
+// with SUF / PRE the INCLUSIVE suffix / prefix sums over the states and
+// dd = diag(a) - P.qa - R.c >= 0 (checked on the host), i.e. only additions of
+// non-negative terms: no cancellation.  The host factors `a` numerically
+// (api.hip factor_structure) and falls back to the dense kernels of estep_fast.hip
+// when the matrix does not have this form (e.g. after psmc_cap_matrix, aux.c:115-127).
+//
+// Mapping: a step costs O(N), so a wavefront carries FOUR tiles, one per 16-lane DPP
+// row, four adjacent states per lane (k = 4*(lane&15) + i).  The scans are three local
+// adds plus a 4-level row_shr / row_shl DPP scan that never leaves the row, so rows are
+// independent "mini waves": each has its own tile, position, symbols and predicates.
+// Everything else (speculate / verify / repair protocol, lagged sparse normalisation,
+// table layout X[g*64+k], bt[g*64+k], inv_d[g], sb[g]) is the one of estep_fast.hip, so
+// the verify, LL, expect and reduce kernels are shared.
+#include <hip/hip_runtime.h>
+#include "wave_prims.h"
+#include "struct_prims.h"
+#include "psmc_hip_internal.h"
+
+namespace psmc {
+
+// symbol i (0..15) of a 16-byte block, clamped to 0..3 (row 3 of the LDS emission table is 1.0 like row 2)
+template <int I> __device__ __forceinline__ int sym_of(const uint4 sv) {
+	const unsigned w = I < 4 ? sv.x : (I < 8 ? sv.y : (I < 12 ? sv.z : sv.w));
+	return (int)((w >> (8 * (I & 3))) & 3u);
+}
+// wave-uniform copy of a 64-bit lane value
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int lane) {
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
+	return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+// The 16 symbols of block `bb` of each row's segment, selected per lane.  The four loads have
+// wave-uniform addresses, so they are SCALAR loads (SMEM, lgkmcnt): a vector load inside the sweep
+// would make every block wait for the stores of the previous one (on gfx9 vmcnt is ONE in-order
+// counter for loads and stores), which is what bounds a latency-critical repair wave.
+__device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, const int64_t (&roff)[4], const int (&bb)[4],
+                                             int row)
+{
+	const uint4 s0 = *reinterpret_cast<const uint4 *>(obs + roff[0] + ((int64_t)bb[0] << 4));
+	const uint4 s1 = *reinterpret_cast<const uint4 *>(obs + roff[1] + ((int64_t)bb[1] << 4));
+	const uint4 s2 = *reinterpret_cast<const uint4 *>(obs + roff[2] + ((int64_t)bb[2] << 4));
+	const uint4 s3 = *reinterpret_cast<const uint4 *>(obs + roff[3] + ((int64_t)bb[3] << 4));
+	uint4 v;
+	v.x = row == 0 ? s0.x : (row == 1 ? s1.x : (row == 2 ? s2.x : s3.x));
+	v.y = row == 0 ? s0.y : (row == 1 ? s1.y : (row == 2 ? s2.y : s3.y));
+	v.z = row == 0 ? s0.z : (row == 1 ? s1.z : (row == 2 ? s2.z : s3.z));
+	v.w = row == 0 ? s0.w : (row == 1 ? s1.w : (row == 2 ? s2.w : s3.w));
+	return v;
+}
+
+__device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructPar &c) {
+	// sp = P | R | qa | c | dd, 64 each
+	load4(sp + (fwd ? 0 : 192) + k0, c.mS);   // forward: P,  backward: c
+	load4(sp + (fwd ? 128 : 64) + k0, c.wS);  // forward: qa, backward: R
+	load4(sp + (fwd ? 64 : 128) + k0, c.mP);  // forward: R,  backward: qa
+	load4(sp + (fwd ? 192 : 0) + k0, c.wP);   // forward: c,  backward: P
+	load4(sp + 256 + k0, c.dd);
+}
+
+// ------------------------------------------------------------------ forward
+// MODE 0: per-step range / store predicates (first, last and lo-containing blocks);
+// MODE 1: all 16 positions are inside [lo, hi]: compute and store;  MODE 2: warm-up, nothing stored.
+template <int MODE, int I>
+__device__ __forceinline__ void fwd_step(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+                                         int p_first, int p_last, int lo, double (&x)[4], double *fo, double *io,
+                                         double *entry_row)
+{
+	const int p = base + I + 1, idx = base + I;
+	if (MODE == 0 && !(p >= p_first && p <= p_last)) return;
+	if (MODE == 0 && p == lo) store4(entry_row, x); // the X_{lo-1} this tile builds on
+	double ev[4];
+	load4(lds_e + sym_of<I>(sv) * 64 + k0, ev);
+	if (((I + 1) & 3) == 0) { // p % NORM_EVERY == 0 (blocks are 16-aligned): d_p = sum(X_{p-1}), off the critical path
+		const double inv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
+		ev[0] *= inv; ev[1] *= inv; ev[2] *= inv; ev[3] *= inv;
+		if ((MODE == 1 || (MODE == 0 && p >= lo)) && m == 0) io[idx] = inv;
+	}
+	struct_step(c, x);
+	x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
+	if (MODE == 1 || (MODE == 0 && p >= lo)) store4(fo + (int64_t)idx * 64, x);
+}
+template <int MODE>
+__device__ __forceinline__ void fwd_block(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+                                          int p_first, int p_last, int lo, double (&x)[4], double *fo, double *io,
+                                          double *entry_row)
+{
+#define PSMC_FS(I) fwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, p_last, lo, x, fo, io, entry_row);
+	PSMC_FS(0) PSMC_FS(1) PSMC_FS(2) PSMC_FS(3) PSMC_FS(4) PSMC_FS(5) PSMC_FS(6) PSMC_FS(7)
+	PSMC_FS(8) PSMC_FS(9) PSMC_FS(10) PSMC_FS(11) PSMC_FS(12) PSMC_FS(13) PSMC_FS(14) PSMC_FS(15)
+#undef PSMC_FS
+}
+
+// list[4*blockIdx.x + row] = tile of this row.  REPAIR: the list holds the flagged tiles only; a row
+// starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel then
+// decides whether the next tile has to follow).  No vector-memory load inside the sweep.
+template <bool REPAIR>
+__global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                     const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                     const Chunk *__restrict__ chunks, const int *__restrict__ list,
+                                                     int n_list, int W, double *__restrict__ f,
+                                                     double *__restrict__ invd, double *__restrict__ entry,
+                                                     int *__restrict__ touch_f)
+{
+	__shared__ double lds_e[4 * 64]; // e[0], e[1], 1, 1
+	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
+	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
+	__syncthreads();
+	if (REPAIR) __builtin_amdgcn_s_setprio(3);
+	const int slot = blockIdx.x * 4 + (lane >> 4);
+	const bool valid = slot < n_list;
+	const int tile = list[valid ? slot : 0];
+	const Chunk c = chunks[tile];
+	const uint8_t *o = obs + c.off;
+	double *fo = f + c.off * 64 + k0, *io = invd + c.off, *entry_row = entry + (int64_t)tile * 64 + k0;
+	StructPar sc;
+	load_struct_par(sp, k0, true, sc);
+	double x[4];
+	int p_first;
+	if (REPAIR) { // c.lo >= 2 for every flagged tile
+		if (valid && m == 0) touch_f[tile] = 1; // X / inv_d of this tile change
+		load4(fo + (int64_t)(c.lo - 2) * 64, x);
+		p_first = c.lo;
+	} else {
+		const int ws = max(1, c.lo - W);
+		load4(a0 + k0, x);
+		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
+			double ev[4];
+			load4(lds_e + ((int)o[0] & 3) * 64 + k0, ev);
+			x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
+			if (valid && c.lo == 1) store4(fo, x);
+			p_first = 2;
+		} else { // warm-up from the stationary prior
+			p_first = ws;
+		}
+	}
+	const int p_last = c.hi;
+	const int b_first = (p_first - 1) >> 4;
+	const int nblk = (valid && p_last >= p_first) ? ((p_last - 1) >> 4) - b_first + 1 : 0;
+	// row-uniform scalars (lane 16r speaks for row r)
+	int64_t roff[4]; int rbf[4], rnb[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		roff[r] = readlane_i64(c.off, 16 * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
+	}
+	const int nb_max = max(max(rnb[0], rnb[1]), max(rnb[2], rnb[3]));
+	for (int bi = 0; bi < nb_max; ++bi) {
+		int bb[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) bb[r] = rbf[r] + min(bi, max(rnb[r] - 1, 0));
+		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
+		if (bi < nblk) {
+			const int base = (b_first + bi) << 4;
+			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(c.lo >= base + 1 && c.lo <= base + 16);
+			const int mode = !full ? 0 : (base + 1 >= c.lo ? 1 : 2);
+			if (__all(mode == 1)) fwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, x, fo, io, entry_row);
+			else if (__all(mode == 2)) fwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, x, fo, io, entry_row);
+			else fwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, x, fo, io, entry_row);
+		}
+	}
+}
+
+// ------------------------------------------------------------------ backward
+// bt_p = e[o_p] * (a bt_{p+1}) * sb_p, positions descending.  A tile owns bt[lo+1 .. top+1] and sb[lo..top]
+// (top = min(hi, L-1)); bt[lo] is stored by the tile below as its boundary value unless lo == 1.
+// MODE 1: every position of the block is in [lo+1, top-1];  MODE 2: warm-up above top;  MODE 0: general.
+template <int MODE, int I>
+__device__ __forceinline__ void bwd_step(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+                                         int p_first, int lo, int top, double (&x)[4], double *bto, double *sbo,
+                                         double *bentry_row, double *bexit_row)
+{
+	const int p = base + I + 1, idx = base + I;
+	if (MODE == 0 && !(p <= p_first && p >= lo)) return;
+	double ev[4];
+	load4(lds_e + sym_of<I>(sv) * 64 + k0, ev);
+	if (((I + 1) & 3) == 0) { // sb_p = 1/sum(bt_{p+1}), off the critical path
+		const double s = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
+		ev[0] *= s; ev[1] *= s; ev[2] *= s; ev[3] *= s;
+		if ((MODE == 1 || (MODE == 0 && p <= top)) && m == 0) sbo[idx] = s;
+	}
+	if (MODE == 0 && p == top) { // the boundary vector this tile builds on
+		store4(bto + (int64_t)top * 64, x); // bt[top+1]
+		store4(bentry_row, x);
+	}
+	struct_step(c, x);
+	x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
+	if (MODE == 1) store4(bto + (int64_t)idx * 64, x);
+	if (MODE == 0 && p <= top) {
+		if (p > lo || lo == 1) store4(bto + (int64_t)idx * 64, x);
+		if (p == lo) store4(bexit_row, x);
+	}
+}
+template <int MODE>
+__device__ __forceinline__ void bwd_block(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+                                          int p_first, int lo, int top, double (&x)[4], double *bto, double *sbo,
+                                          double *bentry_row, double *bexit_row)
+{
+#define PSMC_BS(I) bwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
+	PSMC_BS(15) PSMC_BS(14) PSMC_BS(13) PSMC_BS(12) PSMC_BS(11) PSMC_BS(10) PSMC_BS(9) PSMC_BS(8)
+	PSMC_BS(7) PSMC_BS(6) PSMC_BS(5) PSMC_BS(4) PSMC_BS(3) PSMC_BS(2) PSMC_BS(1) PSMC_BS(0)
+#undef PSMC_BS
+}
+
+template <bool REPAIR>
+__global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                     const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
+                                                     const int *__restrict__ list, int n_list, int W,
+                                                     double *__restrict__ bt, double *__restrict__ sb,
+                                                     double *__restrict__ bentry, double *__restrict__ bexit,
+                                                     int *__restrict__ touch_b)
+{
+	__shared__ double lds_e[4 * 64];
+	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
+	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
+	__syncthreads();
+	if (REPAIR) __builtin_amdgcn_s_setprio(3);
+	const int slot = blockIdx.x * 4 + (lane >> 4);
+	const int tile = list[slot < n_list ? slot : 0];
+	const Chunk c = chunks[tile];
+	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
+	const bool valid = slot < n_list && top >= lo; // a tile holding only position L owns no transition
+	const uint8_t *o = obs + c.off;
+	double *bto = bt + c.off * 64 + k0, *sbo = sb + c.off;
+	double *bentry_row = bentry + (int64_t)tile * 64 + k0, *bexit_row = bexit + (int64_t)tile * 64 + k0;
+	StructPar sc;
+	load_struct_par(sp, k0, false, sc);
+	double x[4]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
+	int p_first;
+	if (REPAIR) { // continue from the value the tile above computed at our top boundary
+		if (valid && m == 0) touch_b[tile] = 1;
+		load4(bexit + (int64_t)(tile + 1) * 64 + k0, x);
+		p_first = top;
+	} else {
+		const int q = min(c.hi + W + 1, L); // B_q := 1
+		load4(lds_e + ((int)o[q - 1] & 3) * 64 + k0, x);
+		p_first = q - 1;
+	}
+	const int b_first = (p_first - 1) >> 4; // highest block
+	const int nblk = valid ? b_first - ((lo - 1) >> 4) + 1 : 0;
+	int64_t roff[4]; int rbf[4], rnb[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r) {
+		roff[r] = readlane_i64(c.off, 16 * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
+	}
+	const int nb_max = max(max(rnb[0], rnb[1]), max(rnb[2], rnb[3]));
+	for (int bi = 0; bi < nb_max; ++bi) {
+		int bb[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) bb[r] = rbf[r] - min(bi, max(rnb[r] - 1, 0));
+		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
+		if (bi < nblk) {
+			const int base = (b_first - bi) << 4;
+			const int mode = (base + 1 > lo && base + 16 < top) ? 1 : ((base + 1 > top && base + 16 <= p_first) ? 2 : 0);
+			if (__all(mode == 1)) bwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
+			else if (__all(mode == 2)) bwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
+			else bwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
+		}
+	}
+}
+
+// ------------------------------------------------------------------ dirty-tile lists
+// deterministic compaction of the verify kernel's flags: out[0..cnt) = flagged tiles in ascending order
+__global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, int n, int *__restrict__ out)
+{
+	const int lane = threadIdx.x;
+	int base = 0;
+	for (int i0 = 0; i0 < n; i0 += 64) {
+		const int i = i0 + lane;
+		const bool d = i < n && dirty[i] != 0;
+		const unsigned long long mask = __ballot(d);
+		if (d) out[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+		base += __popcll(mask);
+	}
+}
+
+// ------------------------------------------------------------------ launchers
+void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list)
+{
+	if (n_list <= 0) return;
+	const dim3 g((n_list + 3) / 4), b(64);
+	if (!repair)
+		hipLaunchKernelGGL((k_fwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.d_list_f, n_list,
+		                   p.warmup, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
+	else
+		hipLaunchKernelGGL((k_fwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.d_rlist_f, n_list,
+		                   p.warmup, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
+}
+void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list)
+{
+	if (n_list <= 0) return;
+	const dim3 g((n_list + 3) / 4), b(64);
+	if (!repair)
+		hipLaunchKernelGGL((k_bwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_list_b, n_list, p.warmup,
+		                   p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+	else
+		hipLaunchKernelGGL((k_bwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_rlist_b, n_list, p.warmup,
+		                   p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+}
+void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
+{
+	hipLaunchKernelGGL(k_compact, dim3(1), dim3(64), 0, st, bwd ? p.d_dirty_b : p.d_dirty, p.n_chunks,
+	                   bwd ? p.d_rlist_b : p.d_rlist_f);
+}
+
+} // namespace psmc

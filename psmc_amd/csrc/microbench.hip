@@ -3,6 +3,7 @@
 // Diagnostic only: psmc_hip_microbench() fills out[] with cycles per operation.
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
+#include "struct_prims.h"
 #include "psmc_hip_internal.h"
 
 namespace psmc {
@@ -68,6 +69,41 @@ __global__ __launch_bounds__(64) void k_microbench(double *out, double seed)
 		t1 = __builtin_readcyclecounter();
 		if (lane == 0) out[13] = (double)(t1 - t0) / (N_ITER * 16 * 4);
 		sink += c0[0] + c1[1] + c2[2] + c3[3];
+	}
+	{ // structured O(N) sweep step (estep_struct.hip): dependent chain, 4 tiles per wave
+		StructPar c;
+		double xv[4];
+		for (int i = 0; i < 4; ++i) {
+			c.mS[i] = 0.01 + 1e-4 * (lane + i); c.wS[i] = 0.3; c.mP[i] = 0.02; c.wP[i] = 0.2 + 1e-3 * i; c.dd[i] = 0.97;
+			xv[i] = x + i;
+		}
+		unsigned long long t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER; ++it) { REPEAT16(struct_step(c, xv);) }
+		unsigned long long t1 = __builtin_readcyclecounter();
+		if (lane == 0) out[14] = (double)(t1 - t0) / (N_ITER * 16);
+		sink += xv[0] + xv[1] + xv[2] + xv[3];
+		// the same with the emission multiply and the every-4th-step normalisation
+		t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER * 4; ++it) {
+			double ev[4] = {m, m, m, m};
+			struct_step(c, xv); xv[0] *= ev[0]; xv[1] *= ev[1]; xv[2] *= ev[2]; xv[3] *= ev[3];
+			struct_step(c, xv); xv[0] *= ev[0]; xv[1] *= ev[1]; xv[2] *= ev[2]; xv[3] *= ev[3];
+			struct_step(c, xv); xv[0] *= ev[0]; xv[1] *= ev[1]; xv[2] *= ev[2]; xv[3] *= ev[3];
+			const double inv = rcp_newton(row_sum16((xv[0] + xv[1]) + (xv[2] + xv[3])));
+			ev[0] *= inv; ev[1] *= inv; ev[2] *= inv; ev[3] *= inv;
+			struct_step(c, xv); xv[0] *= ev[0]; xv[1] *= ev[1]; xv[2] *= ev[2]; xv[3] *= ev[3];
+		}
+		t1 = __builtin_readcyclecounter();
+		if (lane == 0) out[15] = (double)(t1 - t0) / (N_ITER * 16);
+		sink += xv[0] + xv[1] + xv[2] + xv[3];
+		// shader clock in MHz: cycle counter against the 100 MHz constant clock
+		const unsigned long long w0 = wall_clock64();
+		t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER * 4; ++it) { REPEAT16(struct_step(c, xv);) }
+		t1 = __builtin_readcyclecounter();
+		const unsigned long long w1 = wall_clock64();
+		if (lane == 0) out[16] = (double)(t1 - t0) / (double)(w1 - w0) * 100.0;
+		sink += xv[0];
 	}
 	if (sink == 123.456) out[63] = sink;
 }

@@ -38,6 +38,10 @@ struct EstepLaunch {
 	const double *d_e;   // e[b*64+k], b=0..2 (row 2 = 1)
 	const double *d_a0;  // a0[k]
 	const double *d_re;  // re[b*64+k] = 1/e[b][k] (0 where e is 0), b=0..2
+	const double *d_sp;  // structured transition: P | R | qa | c | dd, 64 each (estep_struct.hip); valid when structured
+	int structured;      // a[k][l] = P_k qa_l (l<k), R_k c_l (l>k): O(N) sweeps, 4 tiles per wave
+	const int *d_list_f, *d_list_b; // [n_chunks] tiles in launch order (similar step counts share a wave)
+	int *d_rlist_f, *d_rlist_b;     // [n_chunks] compacted flagged tiles of the current repair round
 	// data
 	const uint8_t *d_obs;
 	const int64_t *d_seg_off;
@@ -70,6 +74,9 @@ constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
 int launch_fast(const EstepLaunch &p, FastReport *rep);
+void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list);
+void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list);
+void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
                        int ns, int32_t *path, double *maxp);
 int run_selftest(hipStream_t stream, unsigned *d_flags);

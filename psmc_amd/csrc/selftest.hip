@@ -4,6 +4,7 @@
 // bit in the returned mask instead of as silently wrong statistics.
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
+#include "struct_prims.h"
 #include "psmc_hip_internal.h"
 
 namespace psmc {
@@ -87,6 +88,40 @@ __global__ __launch_bounds__(64) void k_selftest(unsigned *flags)
 			double want = 0.0;
 			for (int tt = 0; tt < 4; ++tt) want += (0.5 * ri + 3.0 * tt + 1.0) * (7.0 * cj - 1.0 * tt + 0.25);
 			if (fabs(D[ri][cj] - want) > 1e-9) bad |= 256u;
+		}
+	}
+	{ // row-local exclusive scans (structured sweeps): lane m of a row sums the row's lanes above / below it
+		const double es = row_excl_suffix(x), ep = row_excl_prefix(x);
+		double ws = 0.0, wp = 0.0;
+		for (int j = (lane & 15) + 1; j < 16; ++j) ws += sh[(lane & ~15) + j];
+		for (int j = 0; j < (lane & 15); ++j) wp += sh[(lane & ~15) + j];
+		if (fabs(es - ws) > 1e-13 * (fabs(ws) + 1e-300) || fabs(ep - wp) > 1e-13 * (fabs(wp) + 1e-300)) bad |= 2048u;
+		double rs = 0.0;
+		for (int j = 0; j < 16; ++j) rs += sh[(lane & ~15) + j];
+		if (fabs(row_sum16(x) - rs) > 1e-13 * rs) bad |= 2048u;
+	}
+	{ // structured step == dense product with a[k][l] = P_k qa_l (l<k), R_k c_l (l>k), dd on the diagonal (+P.qa+R.c)
+		__shared__ double sP[64], sR[64], sq[64], sc[64], sd[64], sx[4][64];
+		sP[lane] = 0.01 + 0.003 * lane; sR[lane] = 0.02 / (1.0 + lane); sq[lane] = 0.5 + 0.01 * lane;
+		sc[lane] = 1.0 / (3.0 + 0.2 * lane); sd[lane] = 0.9 - 0.002 * lane;
+		for (int r = 0; r < 4; ++r) sx[r][lane] = 1.0 / (1.0 + ((lane * 7 + r * 13) % 64)) + 1e-3 * r; // 4 different vectors, one per row
+		__syncthreads();
+		const int row = lane >> 4, k0 = 4 * (lane & 15);
+		StructPar c;
+		double xv[4];
+		for (int i = 0; i < 4; ++i) {
+			c.mS[i] = sP[k0 + i]; c.wS[i] = sq[k0 + i]; c.mP[i] = sR[k0 + i]; c.wP[i] = sc[k0 + i]; c.dd[i] = sd[k0 + i];
+			xv[i] = sx[row][k0 + i];
+		}
+		struct_step(c, xv); // forward form: y_j = sum_k x_k a[k][j]
+		for (int i = 0; i < 4; ++i) {
+			const int j = k0 + i;
+			double want = 0.0;
+			for (int k = 0; k < 64; ++k) {
+				const double akj = k > j ? sP[k] * sq[j] : (k < j ? sR[k] * sc[j] : sd[j] + sP[j] * sq[j] + sR[j] * sc[j]);
+				want += sx[row][k] * akj;
+			}
+			if (fabs(xv[i] - want) > 1e-13 * fabs(want)) bad |= 4096u;
 		}
 	}
 	if (bad) atomicOr(flags, bad);

@@ -1,0 +1,88 @@
+// struct_prims.h -- row-local (16-lane) scans and the O(N) structured matrix-vector step
+// shared by estep_struct.hip and the device self-test.  See estep_struct.hip for the algebra.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wave_prims.h"
+
+namespace psmc {
+
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+
+// v_mov_b32_dpp pair; lanes without a source lane in their row read 0
+template <int CTRL> __device__ __forceinline__ double dpp_z(double v) {
+	long long s = __builtin_bit_cast(long long, v);
+	long long r = __builtin_amdgcn_update_dpp(0LL, s, CTRL, 0xf, 0xf, true);
+	return __builtin_bit_cast(double, r);
+}
+// sum over the lanes m' > m of the same 16-lane row
+__device__ __forceinline__ double row_excl_suffix(double t) {
+	t = t + dpp_z<0x101>(t); // row_shl:1
+	t = t + dpp_z<0x102>(t);
+	t = t + dpp_z<0x104>(t);
+	t = t + dpp_z<0x108>(t);
+	return dpp_z<0x101>(t);
+}
+// sum over the lanes m' < m of the same 16-lane row
+__device__ __forceinline__ double row_excl_prefix(double t) {
+	t = t + dpp_z<0x111>(t); // row_shr:1
+	t = t + dpp_z<0x112>(t);
+	t = t + dpp_z<0x114>(t);
+	t = t + dpp_z<0x118>(t);
+	return dpp_z<0x111>(t);
+}
+// sum / max over the 16 lanes of a row, identical in every lane of the row
+__device__ __forceinline__ double row_sum16(double t) {
+	t = t + dpp_mov<0xB1>(t);  // quad_perm:[1,0,3,2]
+	t = t + dpp_mov<0x4E>(t);  // quad_perm:[2,3,0,1]
+	t = t + dpp_mov<0x124>(t); // row_ror:4
+	t = t + dpp_mov<0x128>(t); // row_ror:8
+	return bcast16<0>(t);       // butterfly orders differ by an ulp between lanes: take lane 0's
+}
+__device__ __forceinline__ double row_max16(double t) {
+	t = fmax(t, dpp_mov<0xB1>(t));
+	t = fmax(t, dpp_mov<0x4E>(t));
+	t = fmax(t, dpp_mov<0x124>(t));
+	t = fmax(t, dpp_mov<0x128>(t));
+	return t;
+}
+__device__ __forceinline__ double rcp_newton(double x) {
+	double r = __builtin_amdgcn_rcp(x);
+	double t = __builtin_fma(-x, r, 1.0);
+	r = __builtin_fma(r, t, r);
+	t = __builtin_fma(-x, r, 1.0);
+	r = __builtin_fma(r, t, r);
+	return r;
+}
+
+// per-lane constants of one sweep direction (4 states per lane)
+struct StructPar { double mS[4], wS[4], mP[4], wP[4], dd[4]; };
+
+// x <- M x for the structured M: wS.SUF(x.mS) + wP.PRE(x.mP) + dd.x
+__device__ __forceinline__ void struct_step(const StructPar &c, double (&x)[4])
+{
+	const double u0 = x[0] * c.mS[0], u1 = x[1] * c.mS[1], u2 = x[2] * c.mS[2], u3 = x[3] * c.mS[3];
+	const double v0 = x[0] * c.mP[0], v1 = x[1] * c.mP[1], v2 = x[2] * c.mP[2], v3 = x[3] * c.mP[3];
+	const double su2 = u2 + u3, su1 = u1 + su2, su0 = u0 + su1; // local inclusive suffix sums
+	const double pv1 = v0 + v1, pv2 = pv1 + v2, pv3 = pv2 + v3; // local inclusive prefix sums
+	const double ES = row_excl_suffix(su0), EP = row_excl_prefix(pv3);
+	// the lane-local part does not wait for the row scans
+	const double t0 = __builtin_fma(c.wS[0], su0, __builtin_fma(c.wP[0], v0, c.dd[0] * x[0]));
+	const double t1 = __builtin_fma(c.wS[1], su1, __builtin_fma(c.wP[1], pv1, c.dd[1] * x[1]));
+	const double t2 = __builtin_fma(c.wS[2], su2, __builtin_fma(c.wP[2], pv2, c.dd[2] * x[2]));
+	const double t3 = __builtin_fma(c.wS[3], u3, __builtin_fma(c.wP[3], pv3, c.dd[3] * x[3]));
+	x[0] = __builtin_fma(c.wS[0], ES, __builtin_fma(c.wP[0], EP, t0));
+	x[1] = __builtin_fma(c.wS[1], ES, __builtin_fma(c.wP[1], EP, t1));
+	x[2] = __builtin_fma(c.wS[2], ES, __builtin_fma(c.wP[2], EP, t2));
+	x[3] = __builtin_fma(c.wS[3], ES, __builtin_fma(c.wP[3], EP, t3));
+}
+
+__device__ __forceinline__ void load4(const double *p, double (&v)[4]) {
+	const d2v_t a = reinterpret_cast<const d2v_t *>(p)[0], b = reinterpret_cast<const d2v_t *>(p)[1];
+	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+__device__ __forceinline__ void store4(double *p, const double (&v)[4]) {
+	d2v_t a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+	reinterpret_cast<d2v_t *>(p)[0] = a; reinterpret_cast<d2v_t *>(p)[1] = b;
+}
+
+} // namespace psmc

@@ -26,7 +26,7 @@ EXPORTS = [
     "psmc_hip_device_count", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
-    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs",
+    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe",
 ]
 
@@ -85,6 +85,7 @@ def load_library():
     lib.psmc_hip_estep_device.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_void_p]
     lib.psmc_hip_fast_diag.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.psmc_hip_fast_repairs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.psmc_hip_fast_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.psmc_hip_get_tables.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     lib.psmc_hip_decode.argtypes = [C.c_void_p, C.c_int, _i32p, _dp]
     lib.psmc_hip_selftest.argtypes = [C.c_int]
@@ -204,8 +205,11 @@ class HipEStep:
         self._chk(self.lib.psmc_hip_fast_diag(self.h, C.byref(wf), C.byref(wb), C.byref(nc), C.byref(wu)), "fast_diag")
         rp = (C.c_int * 4)()
         self._chk(self.lib.psmc_hip_fast_repairs(self.h, rp), "fast_repairs")
+        fi = (C.c_int * 4)()
+        self._chk(self.lib.psmc_hip_fast_info(self.h, fi), "fast_info")
         return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value,
-                    fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3])
+                    fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3],
+                    structured=bool(fi[0]), tile_len=fi[1], n_sub=fi[3])
 
     def tables(self, seg, want_b=True):
         L = int(self.lens[seg])
@@ -239,14 +243,15 @@ MICROBENCH_NAMES = ["fmac_dpp dependent", "v_fma_f64 dependent", "v_add_f64 depe
                     "fmac_dpp 8 chains (per op)", "rep_rows_swap dependent", "rep_rows_bperm dependent",
                     "dpp_mov+add dependent", "v_rcp_f64 dependent", "mov_b64_dpp+mul dependent",
                     "v_mul_f64 8 indep (per op)", "f64 division dependent", "mfma_f64_16x16x4 dependent",
-                    "mfma_f64_16x16x4 4 accumulators (per op)"]
+                    "mfma_f64_16x16x4 4 accumulators (per op)", "structured step dependent (per step)",
+                    "structured step + emission + norm/4 (per step)", "cycle counter MHz (vs 100 MHz wall clock)"]
 
 
 def microbench(device=0):
     lib = load_library()
-    out = np.zeros(14)
+    out = np.zeros(len(MICROBENCH_NAMES))
     lib.psmc_hip_microbench.argtypes = [C.c_int, _dp, C.c_int]
-    rc = lib.psmc_hip_microbench(int(device), _p(out), 14)
+    rc = lib.psmc_hip_microbench(int(device), _p(out), len(MICROBENCH_NAMES))
     if rc != 0:
         raise HipError("microbench: %s" % lib.psmc_hip_strerror(rc).decode())
     return dict(zip(MICROBENCH_NAMES, out.tolist()))

@@ -19,9 +19,12 @@ for s, o in zip(segs, off[:-1]):
     host[o:o + len(s)] = s
 d_obs = torch.from_numpy(host).cuda()
 ref = None
-grid = [dict(), dict(overlap=0), dict(warmup=2048), dict(warmup=1024), dict(warmup=0), dict(chunk=8192), dict(chunk=8192, warmup=2048),
-        dict(chunk=20480), dict(chunk=32768), dict(chunk=32768, overlap=0), dict(chunk=12288), dict(chunk=16384), dict(chunk=24576), dict(chunk=49152), dict(target_waves=3072), dict(target_waves=1024),
-        dict(n_sub=8), dict(warm_tol=1e-10), dict(warm_tol=1e-9)]
+grid = [dict(structured=0), dict(), dict(overlap=0), dict(struct_tiles=2048), dict(struct_tiles=4096), dict(struct_tiles=16384),
+        dict(struct_tiles=32768), dict(struct_tiles=4096, warmup=2048), dict(struct_tiles=8192, warmup=2048),
+        dict(struct_tiles=16384, warmup=2048), dict(struct_tiles=16384, warmup=1024), dict(struct_tiles=8192, warmup=8192),
+        dict(struct_tiles=8192, n_sub=2), dict(struct_tiles=4096, n_sub=3)]
+if len(sys.argv) > 2:
+    grid = [json.loads(x) for x in sys.argv[2:]]
 for opts in grid:
     es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
     es.load_segments_device(d_obs.data_ptr(), off[:-1], lens, keepalive=d_obs)
@@ -38,5 +41,5 @@ for opts in grid:
     print(json.dumps(dict(opts=opts, ms=round(dt * 1e3, 2), bins_per_s=round(int(lens.sum()) / dt / 1e6, 1),
                           chains=round(t["forward"], 2), tail=round(t["backward"], 2), exp=round(t["expect"], 2), fsw=round(t["fwd_sweep"], 2), bsw=round(t["bwd_sweep"], 2),
                           red=round(t["reduce"], 2), tiles=d["n_chunks"], rounds=[d["fwd_rounds"], d["bwd_rounds"]],
-                          rep_tiles=[d["fwd_tiles"], d["bwd_tiles"]], dA_vs_first=err, LL=r["LL"])), flush=True)
+                          rep_tiles=[d["fwd_tiles"], d["bwd_tiles"]], struct=d["structured"], tile=d["tile_len"], n_sub=d["n_sub"], dA_vs_first=err, LL=r["LL"])), flush=True)
     es.close()

@@ -52,7 +52,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * chain and the early counts pass on three streams; 0: one stream), "target_waves", "n_sub" (expect
  * waves per tile), "rep_impl" (0 ds_bpermute, 1 v_permlane*_swap),
  * "expect_impl" (0 VALU, 1 MFMA f64), "structured" (1 auto / 0 always dense sweeps),
- * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront). */
+ * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront), "learn" (1: tiles
+ * that needed a repair are glued to their neighbour for the following E-steps of this context;
+ * results then depend on the call history within the stated tolerance), "group_cap" (bins). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
@@ -96,8 +98,8 @@ int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err
 /* How much repair the speculation needed: verify/repair rounds and the total
  * number of tile re-runs, forward and backward; out[0..3]. */
 int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
-/* Diagnostic: out = {structured sweeps used (0/1), tile length in bins, number of tiles,
- * count-kernel waves per tile} of the last fast-mode E-step.  The O(N) structured sweeps
+/* Diagnostic: out = {structured sweeps used (0/1), tile length in bins, forward sweep items,
+ * backward sweep items} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured sweeps
  *  are chosen automatically when a[][] has the two rank-1
  * triangles psmc_update_hmm builds (core.c:112-122); otherwise the dense sweeps run. */
 int psmc_hip_fast_info(psmc_hip_ctx *ctx, int out[4]);

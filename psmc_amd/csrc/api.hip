@@ -26,7 +26,14 @@ struct psmc_hip_ctx {
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
 	int struct_tiles = 8192;   // "struct_tiles": tiles aimed at when the structured sweeps are used (4 per wave)
 	bool use_struct = false, planned_struct = false;
-	int *d_list = nullptr;     // list_f | list_b | rlist_f | rlist_b, n_chunks each
+	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
+	int group_cap = 49152;     // "group_cap": longest run of glued tiles, in bins
+	int *d_items = nullptr;    // items_f | items_b | ritems_f | ritems_b, 2*n_chunks ints each
+	int *h_ritems = nullptr;   // pinned, 2 * 2*n_chunks ints
+	std::vector<uint8_t> glue_f, glue_b; // glue_f[b]: tile b continues the forward item of b-1; glue_b[b]: b continues b+1's backward item
+	std::vector<int> flagged_f, flagged_b;
+	bool items_dirty = true;
+	int n_items_f = 0, n_items_b = 0;
 	int n_sub_used = 6;
 	// segments
 	int n_seg = 0;
@@ -159,10 +166,11 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_list};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+	if (c->h_ritems) (void)hipHostFree(c->h_ritems);
 	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 6; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -179,6 +187,8 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
 	else if (k == "max_rounds") c->max_rounds = (int)v;
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
+	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
+	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->plan_dirty = true; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
@@ -519,18 +529,8 @@ static int plan_fast(psmc_hip_ctx *c)
 	c->planned_struct = st;
 	// the counts kernel splits a tile over n_sub waves: keep about the same number of partial blocks
 	c->n_sub_used = st ? std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1))) : c->n_sub;
-	// structured sweeps: four tiles share a wave, so order the tiles by their step count (longest first)
-	std::vector<int> lists((size_t)4 * nc, 0);
-	{
-		std::vector<std::pair<int, int>> kf(nc), kb(nc);
-		for (int i = 0; i < nc; ++i) {
-			const Chunk &ch = c->chunks[i];
-			kf[i] = {-(ch.hi - std::max(1, ch.lo - c->warmup) + 1), i};
-			kb[i] = {-(std::min(ch.hi + c->warmup + 1, ch.L) - ch.lo), i};
-		}
-		std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
-		for (int i = 0; i < nc; ++i) { lists[i] = kf[i].second; lists[(size_t)nc + i] = kb[i].second; }
-	}
+	c->glue_f.assign(nc, 0); c->glue_b.assign(nc, 0); // a new tiling forgets what was learned
+	c->items_dirty = true;
 	int rc;
 	if (nc > c->chunk_cap) {
 		if ((rc = dev_alloc(c, &c->d_chunks, (size_t)nc))) return rc;
@@ -540,7 +540,10 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_list, (size_t)4 * nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_items, (size_t)8 * nc))) return rc;
+		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
+		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocDefault) != hipSuccess)
+			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
 		c->chunk_cap = nc;
 	}
 	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub_used * 4096))) return rc;
@@ -554,9 +557,51 @@ static int plan_fast(psmc_hip_ctx *c)
 			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
 	}
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_list, lists.data(), sizeof(int) * lists.size(), hipMemcpyHostToDevice));
 	c->plan_dirty = false;
 	return 0;
+}
+
+// Sweep items of the structured kernels: maximal runs of glued tiles (one segment, at most group_cap
+// bins), ordered by step count so that the four rows of a wave finish together (longest first).
+static int build_items(psmc_hip_ctx *c)
+{
+	const int nc = (int)c->chunks.size(), W = c->warmup;
+	std::vector<std::pair<int, std::pair<int, int>>> kf, kb; // (-steps, (first, count))
+	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
+		int e = b + 1;
+		while (e < nc && c->glue_f[e] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
+		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
+		kf.push_back({-(l.hi - std::max(1, h.lo - W) + 1), {b, e - b}});
+		b = e;
+	}
+	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
+		int e = b + 1;
+		while (e < nc && c->glue_b[e - 1] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap &&
+		       c->chunks[e].lo < c->chunks[e].L) // a last tile holding only position L owns no transition: never a group's top
+			++e;
+		const Chunk &lo = c->chunks[b], &top = c->chunks[e - 1];
+		kb.push_back({-(std::min(top.hi + W + 1, top.L) - lo.lo), {b, e - b}});
+		b = e;
+	}
+	std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
+	std::vector<int> h((size_t)4 * nc, 0);
+	for (size_t i = 0; i < kf.size(); ++i) { h[2 * i] = kf[i].second.first; h[2 * i + 1] = kf[i].second.second; }
+	for (size_t i = 0; i < kb.size(); ++i) { h[(size_t)2 * nc + 2 * i] = kb[i].second.first; h[(size_t)2 * nc + 2 * i + 1] = kb[i].second.second; }
+	c->n_items_f = (int)kf.size(); c->n_items_b = (int)kb.size();
+	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+	c->items_dirty = false;
+	return 0;
+}
+
+// Tiles a repair round had to touch start where the chain forgets slowly: glue each to the neighbour it
+// depends on, so that from the next E-step on one row walks the region while the sweep is still running.
+static void learn_groups(psmc_hip_ctx *c)
+{
+	const int nc = (int)c->chunks.size();
+	for (int b : c->flagged_f)
+		if (b > 0 && b < nc && !c->glue_f[b] && c->chunks[b - 1].off == c->chunks[b].off) { c->glue_f[b] = 1; c->items_dirty = true; }
+	for (int b : c->flagged_b)
+		if (b >= 0 && b + 1 < nc && !c->glue_b[b] && c->chunks[b + 1].off == c->chunks[b].off) { c->glue_b[b] = 1; c->items_dirty = true; }
 }
 
 static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *d_out,
@@ -571,8 +616,12 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	EstepLaunch p;
 	fill_common(c, p, st);
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub_used;
-	p.d_list_f = c->d_list; p.d_list_b = c->d_list + p.n_chunks;
-	p.d_rlist_f = c->d_list + 2 * p.n_chunks; p.d_rlist_b = c->d_list + 3 * p.n_chunks;
+	if (c->use_struct && c->items_dirty && (rc = build_items(c))) return rc;
+	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
+	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;
+	p.n_items_f = c->n_items_f; p.n_items_b = c->n_items_b; p.tile_len = c->chunk_used; p.h_ritems = c->h_ritems;
+	c->flagged_f.clear(); c->flagged_b.clear();
+	p.flagged_f = &c->flagged_f; p.flagged_b = &c->flagged_b;
 	p.d_entry = c->d_entry; p.d_bentry = c->d_bentry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
 	p.d_dirty = c->d_dirty; p.d_cnt = c->d_cnt; p.h_cnt = c->h_cnt; p.tol = c->warm_tol; p.max_rounds = c->max_rounds;
 	p.d_touch_f = c->d_touch; p.d_touch_b = c->d_touch + p.n_chunks; p.d_dirty_b = c->d_dirty + p.n_chunks;
@@ -582,6 +631,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
 	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
 	if (!c->report.converged) return fail(c, PSMC_HIP_ECONVERGE, "fast mode: tile boundaries did not converge within max_rounds");
+	if (c->use_struct && c->learn) learn_groups(c);
 	return 0;
 }
 
@@ -629,7 +679,8 @@ extern "C" int psmc_hip_fast_repairs(psmc_hip_ctx *c, int out[4])
 extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[4])
 {
 	if (!c || !out) return PSMC_HIP_EINVAL;
-	out[0] = c->use_struct ? 1 : 0; out[1] = c->chunk_used; out[2] = (int)c->chunks.size(); out[3] = c->n_sub_used;
+	out[0] = c->use_struct ? 1 : 0; out[1] = c->chunk_used; out[2] = c->use_struct ? c->n_items_f : (int)c->chunks.size();
+	out[3] = c->use_struct ? c->n_items_b : (int)c->chunks.size();
 	return PSMC_HIP_OK;
 }
 

@@ -519,10 +519,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	(void)hipEventRecord(p.evx[0], sm);
 	if (ov) (void)hipStreamWaitEvent(sa, p.evx[0], 0); // parameters uploaded, flags cleared
 	// ---- both speculative sweeps
-	if (p.structured) launch_fwd_struct(p, sm, false, p.n_chunks); else launch_fwd<false>(p, sm);
+	if (p.structured) launch_fwd_struct(p, sm, false, p.n_items_f); else launch_fwd<false>(p, sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	if (p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
-	if (p.structured) launch_bwd_struct(p, sa, false, p.n_chunks); else launch_bwd<false>(p, sa);
+	if (p.structured) launch_bwd_struct(p, sa, false, p.n_items_b); else launch_bwd<false>(p, sa);
 	if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
 	if (ov) { // early expect over every tile once both sweeps exist
 		(void)hipEventRecord(p.evx[1], sm); (void)hipEventRecord(p.evx[2], sa);
@@ -545,7 +545,11 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		else
 			hipLaunchKernelGGL((k_verify<true>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
 			                   p.d_dirty_b, p.d_cnt + 1, p.d_warm);
-		if (p.structured) launch_compact(p, c.st, c.bwd); // flagged tiles, ascending: the next repair launch packs them 4 per wave
+		if (p.structured) { // flagged tiles, ascending: the next repair launch packs them 4 per wave; the host keeps a copy
+			launch_compact(p, c.st, c.bwd);
+			if (hipMemcpyAsync(p.h_ritems + (size_t)c.slot * 2 * p.n_chunks, c.bwd ? p.d_ritems_b : p.d_ritems_f,
+			                   sizeof(int) * 2 * (size_t)p.n_chunks, hipMemcpyDeviceToHost, c.st) != hipSuccess) return -1;
+		}
 		if (hipMemcpyAsync(p.h_cnt + c.slot, p.d_cnt + c.slot, sizeof(int), hipMemcpyDeviceToHost, c.st) != hipSuccess) return -1;
 		if (hipEventRecord(c.rb, c.st) != hipSuccess) return -1;
 		c.pending = true;
@@ -565,6 +569,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 			if (nd == 0) { c.done = true; continue; }
 			if (c.round >= p.max_rounds) { rep->converged = 0; c.done = true; continue; }
 			++c.round;
+			if (p.structured) {
+				std::vector<int> *fl = c.bwd ? p.flagged_b : p.flagged_f;
+				if (fl) for (int i = 0; i < nd; ++i) fl->push_back(p.h_ritems[(size_t)c.slot * 2 * p.n_chunks + 2 * i]);
+			}
 			if (!c.bwd) {
 				rep->fwd_rounds++; rep->fwd_tiles += nd;
 				if (p.structured) launch_fwd_struct(p, c.st, true, nd); else launch_fwd<true>(p, c.st);

@@ -65,47 +65,60 @@ __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, i
 	load4(sp + 256 + k0, c.dd);
 }
 
+// A sweep ITEM is a run of `count` consecutive tiles of one segment that one row walks through in
+// sequence (count == 1 unless the host glued tiles: see api.hip learn_groups -- where the chain forgets
+// slowly a speculative start is wrong and the repair rounds would walk the region tile by tile anyway;
+// gluing lets one row do that walk while the rest of the sweep is still running).  All tiles of an item
+// but the last are T positions long.
+struct SweepItem { int first, count; };
+
 // ------------------------------------------------------------------ forward
-// MODE 0: per-step range / store predicates (first, last and lo-containing blocks);
-// MODE 1: all 16 positions are inside [lo, hi]: compute and store;  MODE 2: warm-up, nothing stored.
+// per-row bookkeeping of the tile boundary the sweep crosses next
+struct FwdCursor { int next_lo, tile; };
+
+// MODE 0: per-step range / store / boundary predicates;  MODE 1: all 16 positions are computed and
+// stored and no tile starts inside the block;  MODE 2: warm-up, nothing stored.
 template <int MODE, int I>
 __device__ __forceinline__ void fwd_step(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
-                                         int p_first, int p_last, int lo, double (&x)[4], double *fo, double *io,
-                                         double *entry_row)
+                                         int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[4],
+                                         double *fo, double *io, double *entry)
 {
 	const int p = base + I + 1, idx = base + I;
 	if (MODE == 0 && !(p >= p_first && p <= p_last)) return;
-	if (MODE == 0 && p == lo) store4(entry_row, x); // the X_{lo-1} this tile builds on
+	if (MODE == 0 && p == cur.next_lo) { // the X_{lo-1} this tile builds on
+		store4(entry + (int64_t)cur.tile * 64 + k0, x);
+		cur.tile += 1; cur.next_lo += T;
+	}
 	double ev[4];
 	load4(lds_e + sym_of<I>(sv) * 64 + k0, ev);
 	if (((I + 1) & 3) == 0) { // p % NORM_EVERY == 0 (blocks are 16-aligned): d_p = sum(X_{p-1}), off the critical path
 		const double inv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
 		ev[0] *= inv; ev[1] *= inv; ev[2] *= inv; ev[3] *= inv;
-		if ((MODE == 1 || (MODE == 0 && p >= lo)) && m == 0) io[idx] = inv;
+		if ((MODE == 1 || (MODE == 0 && p >= lo0)) && m == 0) io[idx] = inv;
 	}
 	struct_step(c, x);
 	x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
-	if (MODE == 1 || (MODE == 0 && p >= lo)) store4(fo + (int64_t)idx * 64, x);
+	if (MODE == 1 || (MODE == 0 && p >= lo0)) store4(fo + (int64_t)idx * 64, x);
 }
 template <int MODE>
 __device__ __forceinline__ void fwd_block(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
-                                          int p_first, int p_last, int lo, double (&x)[4], double *fo, double *io,
-                                          double *entry_row)
+                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[4],
+                                          double *fo, double *io, double *entry)
 {
-#define PSMC_FS(I) fwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, p_last, lo, x, fo, io, entry_row);
+#define PSMC_FS(I) fwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, p_last, lo0, T, cur, x, fo, io, entry);
 	PSMC_FS(0) PSMC_FS(1) PSMC_FS(2) PSMC_FS(3) PSMC_FS(4) PSMC_FS(5) PSMC_FS(6) PSMC_FS(7)
 	PSMC_FS(8) PSMC_FS(9) PSMC_FS(10) PSMC_FS(11) PSMC_FS(12) PSMC_FS(13) PSMC_FS(14) PSMC_FS(15)
 #undef PSMC_FS
 }
 
-// list[4*blockIdx.x + row] = tile of this row.  REPAIR: the list holds the flagged tiles only; a row
-// starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel then
-// decides whether the next tile has to follow).  No vector-memory load inside the sweep.
+// items[4*blockIdx.x + row] = work of this row.  REPAIR: the list holds the flagged tiles (count 1); a
+// row starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel
+// then decides whether the next tile has to follow).  No vector-memory load inside the sweep.
 template <bool REPAIR>
 __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
-                                                     const Chunk *__restrict__ chunks, const int *__restrict__ list,
-                                                     int n_list, int W, double *__restrict__ f,
+                                                     const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
+                                                     int n_items, int W, int T, double *__restrict__ f,
                                                      double *__restrict__ invd, double *__restrict__ entry,
                                                      int *__restrict__ touch_f)
 {
@@ -113,19 +126,20 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
 	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
 	__syncthreads();
-	if (REPAIR) __builtin_amdgcn_s_setprio(3);
 	const int slot = blockIdx.x * 4 + (lane >> 4);
-	const bool valid = slot < n_list;
-	const int tile = list[valid ? slot : 0];
-	const Chunk c = chunks[tile];
+	const bool valid = slot < n_items;
+	const SweepItem it = items[valid ? slot : 0];
+	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
+	const Chunk c = chunks[it.first];
+	const int p_last = chunks[it.first + it.count - 1].hi;
 	const uint8_t *o = obs + c.off;
-	double *fo = f + c.off * 64 + k0, *io = invd + c.off, *entry_row = entry + (int64_t)tile * 64 + k0;
+	double *fo = f + c.off * 64 + k0, *io = invd + c.off;
 	StructPar sc;
 	load_struct_par(sp, k0, true, sc);
 	double x[4];
 	int p_first;
 	if (REPAIR) { // c.lo >= 2 for every flagged tile
-		if (valid && m == 0) touch_f[tile] = 1; // X / inv_d of this tile change
+		if (valid && m == 0) touch_f[it.first] = 1; // X / inv_d of this tile change
 		load4(fo + (int64_t)(c.lo - 2) * 64, x);
 		p_first = c.lo;
 	} else {
@@ -141,7 +155,10 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 			p_first = ws;
 		}
 	}
-	const int p_last = c.hi;
+	// tile boundaries ahead: the head's own lo (unless it is position 1, which no step computes), then every T
+	FwdCursor cur;
+	cur.tile = c.lo >= p_first ? it.first : it.first + 1;
+	cur.next_lo = c.lo >= p_first ? c.lo : c.lo + T;
 	const int b_first = (p_first - 1) >> 4;
 	const int nblk = (valid && p_last >= p_first) ? ((p_last - 1) >> 4) - b_first + 1 : 0;
 	// row-uniform scalars (lane 16r speaks for row r)
@@ -160,11 +177,15 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
 		if (bi < nblk) {
 			const int base = (b_first + bi) << 4;
-			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(c.lo >= base + 1 && c.lo <= base + 16);
+			if (cur.next_lo == base + 1 && base + 1 >= p_first && base + 1 <= p_last) { // a tile starts exactly at this block
+				store4(entry + (int64_t)cur.tile * 64 + k0, x);
+				cur.tile += 1; cur.next_lo += T;
+			}
+			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
 			const int mode = !full ? 0 : (base + 1 >= c.lo ? 1 : 2);
-			if (__all(mode == 1)) fwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, x, fo, io, entry_row);
-			else if (__all(mode == 2)) fwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, x, fo, io, entry_row);
-			else fwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, x, fo, io, entry_row);
+			if (__all(mode == 1)) fwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, T, cur, x, fo, io, entry);
+			else if (__all(mode == 2)) fwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, T, cur, x, fo, io, entry);
+			else fwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, T, cur, x, fo, io, entry);
 		}
 	}
 }
@@ -172,48 +193,56 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 // ------------------------------------------------------------------ backward
 // bt_p = e[o_p] * (a bt_{p+1}) * sb_p, positions descending.  A tile owns bt[lo+1 .. top+1] and sb[lo..top]
 // (top = min(hi, L-1)); bt[lo] is stored by the tile below as its boundary value unless lo == 1.
-// MODE 1: every position of the block is in [lo+1, top-1];  MODE 2: warm-up above top;  MODE 0: general.
+// The cursor holds the tile the row is in; when p passes its lo the row moves into the tile below.
+struct BwdCursor { int lo, top, tile; };
+
+// MODE 1: every position of the block is strictly inside (lo, top) of the current tile;
+// MODE 2: warm-up above the top tile's top;  MODE 0: general.
 template <int MODE, int I>
 __device__ __forceinline__ void bwd_step(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
-                                         int p_first, int lo, int top, double (&x)[4], double *bto, double *sbo,
-                                         double *bentry_row, double *bexit_row)
+                                         int p_first, int p_low, int T, BwdCursor &cur, double (&x)[4], double *bto,
+                                         double *sbo, double *bentry, double *bexit)
 {
 	const int p = base + I + 1, idx = base + I;
-	if (MODE == 0 && !(p <= p_first && p >= lo)) return;
+	if (MODE == 0 && !(p <= p_first && p >= p_low)) return;
 	double ev[4];
 	load4(lds_e + sym_of<I>(sv) * 64 + k0, ev);
 	if (((I + 1) & 3) == 0) { // sb_p = 1/sum(bt_{p+1}), off the critical path
 		const double s = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
 		ev[0] *= s; ev[1] *= s; ev[2] *= s; ev[3] *= s;
-		if ((MODE == 1 || (MODE == 0 && p <= top)) && m == 0) sbo[idx] = s;
+		if ((MODE == 1 || (MODE == 0 && p <= cur.top)) && m == 0) sbo[idx] = s;
 	}
-	if (MODE == 0 && p == top) { // the boundary vector this tile builds on
-		store4(bto + (int64_t)top * 64, x); // bt[top+1]
-		store4(bentry_row, x);
+	if (MODE == 0 && p == cur.top) { // the boundary vector this tile builds on
+		store4(bto + (int64_t)cur.top * 64, x); // bt[top+1]
+		store4(bentry + (int64_t)cur.tile * 64 + k0, x);
 	}
 	struct_step(c, x);
 	x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
 	if (MODE == 1) store4(bto + (int64_t)idx * 64, x);
-	if (MODE == 0 && p <= top) {
-		if (p > lo || lo == 1) store4(bto + (int64_t)idx * 64, x);
-		if (p == lo) store4(bexit_row, x);
+	if (MODE == 0 && p <= cur.top) {
+		if (p > cur.lo || cur.lo == 1) store4(bto + (int64_t)idx * 64, x);
+		if (p == cur.lo) { // leaving the tile: hand over to the one below
+			store4(bexit + (int64_t)cur.tile * 64 + k0, x);
+			cur.tile -= 1; cur.top = cur.lo - 1; cur.lo -= T;
+		}
 	}
 }
 template <int MODE>
 __device__ __forceinline__ void bwd_block(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
-                                          int p_first, int lo, int top, double (&x)[4], double *bto, double *sbo,
-                                          double *bentry_row, double *bexit_row)
+                                          int p_first, int p_low, int T, BwdCursor &cur, double (&x)[4], double *bto,
+                                          double *sbo, double *bentry, double *bexit)
 {
-#define PSMC_BS(I) bwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
+#define PSMC_BS(I) bwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 	PSMC_BS(15) PSMC_BS(14) PSMC_BS(13) PSMC_BS(12) PSMC_BS(11) PSMC_BS(10) PSMC_BS(9) PSMC_BS(8)
 	PSMC_BS(7) PSMC_BS(6) PSMC_BS(5) PSMC_BS(4) PSMC_BS(3) PSMC_BS(2) PSMC_BS(1) PSMC_BS(0)
 #undef PSMC_BS
 }
 
+// items: tiles first .. first+count-1, walked from the highest down.
 template <bool REPAIR>
 __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
-                                                     const int *__restrict__ list, int n_list, int W,
+                                                     const SweepItem *__restrict__ items, int n_items, int W, int T,
                                                      double *__restrict__ bt, double *__restrict__ sb,
                                                      double *__restrict__ bentry, double *__restrict__ bexit,
                                                      int *__restrict__ touch_b)
@@ -222,30 +251,32 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
 	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
 	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
 	__syncthreads();
-	if (REPAIR) __builtin_amdgcn_s_setprio(3);
 	const int slot = blockIdx.x * 4 + (lane >> 4);
-	const int tile = list[slot < n_list ? slot : 0];
-	const Chunk c = chunks[tile];
-	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
-	const bool valid = slot < n_list && top >= lo; // a tile holding only position L owns no transition
+	const SweepItem it = items[slot < n_items ? slot : 0];
+	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
+	const int t_top = it.first + it.count - 1;
+	const Chunk c = chunks[t_top];
+	const int L = c.L, p_low = chunks[it.first].lo;
+	BwdCursor cur;
+	cur.lo = c.lo; cur.top = min(c.hi, L - 1); cur.tile = t_top;
+	const bool valid = slot < n_items && cur.top >= cur.lo; // a tile holding only position L owns no transition
 	const uint8_t *o = obs + c.off;
 	double *bto = bt + c.off * 64 + k0, *sbo = sb + c.off;
-	double *bentry_row = bentry + (int64_t)tile * 64 + k0, *bexit_row = bexit + (int64_t)tile * 64 + k0;
 	StructPar sc;
 	load_struct_par(sp, k0, false, sc);
 	double x[4]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
 	int p_first;
 	if (REPAIR) { // continue from the value the tile above computed at our top boundary
-		if (valid && m == 0) touch_b[tile] = 1;
-		load4(bexit + (int64_t)(tile + 1) * 64 + k0, x);
-		p_first = top;
+		if (valid && m == 0) touch_b[t_top] = 1;
+		load4(bexit + (int64_t)(t_top + 1) * 64 + k0, x);
+		p_first = cur.top;
 	} else {
 		const int q = min(c.hi + W + 1, L); // B_q := 1
 		load4(lds_e + ((int)o[q - 1] & 3) * 64 + k0, x);
 		p_first = q - 1;
 	}
 	const int b_first = (p_first - 1) >> 4; // highest block
-	const int nblk = valid ? b_first - ((lo - 1) >> 4) + 1 : 0;
+	const int nblk = valid ? b_first - ((p_low - 1) >> 4) + 1 : 0;
 	int64_t roff[4]; int rbf[4], rnb[4];
 #pragma unroll
 	for (int r = 0; r < 4; ++r) {
@@ -261,17 +292,18 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
 		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
 		if (bi < nblk) {
 			const int base = (b_first - bi) << 4;
-			const int mode = (base + 1 > lo && base + 16 < top) ? 1 : ((base + 1 > top && base + 16 <= p_first) ? 2 : 0);
-			if (__all(mode == 1)) bwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
-			else if (__all(mode == 2)) bwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
-			else bwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, lo, top, x, bto, sbo, bentry_row, bexit_row);
+			const int mode = (base + 1 > cur.lo && base + 16 < cur.top) ? 1 : ((base + 1 > cur.top && base + 16 <= p_first) ? 2 : 0);
+			if (__all(mode == 1)) bwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else if (__all(mode == 2)) bwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else bwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 		}
 	}
 }
 
 // ------------------------------------------------------------------ dirty-tile lists
-// deterministic compaction of the verify kernel's flags: out[0..cnt) = flagged tiles in ascending order
-__global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, int n, int *__restrict__ out)
+// deterministic compaction of the verify kernel's flags: out[0..cnt) = flagged tiles in ascending
+// order, each as a one-tile sweep item
+__global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, int n, SweepItem *__restrict__ out)
 {
 	const int lane = threadIdx.x;
 	int base = 0;
@@ -279,38 +311,38 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 		const int i = i0 + lane;
 		const bool d = i < n && dirty[i] != 0;
 		const unsigned long long mask = __ballot(d);
-		if (d) out[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+		if (d) { SweepItem s; s.first = i; s.count = 1; out[base + __popcll(mask & ((1ull << lane) - 1ull))] = s; }
 		base += __popcll(mask);
 	}
 }
 
 // ------------------------------------------------------------------ launchers
-void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list)
+void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_items)
 {
-	if (n_list <= 0) return;
-	const dim3 g((n_list + 3) / 4), b(64);
+	if (n_items <= 0) return;
+	const dim3 g((n_items + 3) / 4), b(64);
 	if (!repair)
-		hipLaunchKernelGGL((k_fwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.d_list_f, n_list,
-		                   p.warmup, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
+		hipLaunchKernelGGL((k_fwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+		                   (const SweepItem *)p.d_items_f, n_items, p.warmup, p.tile_len, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
 	else
-		hipLaunchKernelGGL((k_fwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, p.d_rlist_f, n_list,
-		                   p.warmup, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
+		hipLaunchKernelGGL((k_fwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+		                   (const SweepItem *)p.d_ritems_f, n_items, p.warmup, p.tile_len, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
 }
-void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list)
+void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_items)
 {
-	if (n_list <= 0) return;
-	const dim3 g((n_list + 3) / 4), b(64);
+	if (n_items <= 0) return;
+	const dim3 g((n_items + 3) / 4), b(64);
 	if (!repair)
-		hipLaunchKernelGGL((k_bwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_list_b, n_list, p.warmup,
-		                   p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+		hipLaunchKernelGGL((k_bwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, (const SweepItem *)p.d_items_b,
+		                   n_items, p.warmup, p.tile_len, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 	else
-		hipLaunchKernelGGL((k_bwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_rlist_b, n_list, p.warmup,
-		                   p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+		hipLaunchKernelGGL((k_bwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, (const SweepItem *)p.d_ritems_b,
+		                   n_items, p.warmup, p.tile_len, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 }
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
 {
 	hipLaunchKernelGGL(k_compact, dim3(1), dim3(64), 0, st, bwd ? p.d_dirty_b : p.d_dirty, p.n_chunks,
-	                   bwd ? p.d_rlist_b : p.d_rlist_f);
+	                   (SweepItem *)(bwd ? p.d_ritems_b : p.d_ritems_f));
 }
 
 } // namespace psmc

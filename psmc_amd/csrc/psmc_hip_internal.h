@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace psmc {
 
@@ -40,8 +41,11 @@ struct EstepLaunch {
 	const double *d_re;  // re[b*64+k] = 1/e[b][k] (0 where e is 0), b=0..2
 	const double *d_sp;  // structured transition: P | R | qa | c | dd, 64 each (estep_struct.hip); valid when structured
 	int structured;      // a[k][l] = P_k qa_l (l<k), R_k c_l (l>k): O(N) sweeps, 4 tiles per wave
-	const int *d_list_f, *d_list_b; // [n_chunks] tiles in launch order (similar step counts share a wave)
-	int *d_rlist_f, *d_rlist_b;     // [n_chunks] compacted flagged tiles of the current repair round
+	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)
+	int n_items_f, n_items_b, tile_len;
+	int *d_ritems_f, *d_ritems_b;     // [n_chunks][2] flagged tiles of the current repair round as one-tile items
+	int *h_ritems;                    // pinned [2][n_chunks][2]: the same lists read back, so that the host can learn the groups
+	std::vector<int> *flagged_f, *flagged_b; // out: tiles flagged in any round of this E-step (may be null)
 	// data
 	const uint8_t *d_obs;
 	const int64_t *d_seg_off;

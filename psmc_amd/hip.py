@@ -209,7 +209,7 @@ class HipEStep:
         self._chk(self.lib.psmc_hip_fast_info(self.h, fi), "fast_info")
         return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value,
                     fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3],
-                    structured=bool(fi[0]), tile_len=fi[1], n_sub=fi[3])
+                    structured=bool(fi[0]), tile_len=fi[1], items_fwd=fi[2], items_bwd=fi[3])
 
     def tables(self, seg, want_b=True):
         L = int(self.lens[seg])

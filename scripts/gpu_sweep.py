@@ -28,7 +28,9 @@ if len(sys.argv) > 2:
 for opts in grid:
     es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
     es.load_segments_device(d_obs.data_ptr(), off[:-1], lens, keepalive=d_obs)
-    r = es.estep(a, e, a0)
+    hist = []
+    for _ in range(4):
+        t0 = time.perf_counter(); r = es.estep(a, e, a0); hist.append(round((time.perf_counter() - t0) * 1e3, 1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
@@ -41,5 +43,5 @@ for opts in grid:
     print(json.dumps(dict(opts=opts, ms=round(dt * 1e3, 2), bins_per_s=round(int(lens.sum()) / dt / 1e6, 1),
                           chains=round(t["forward"], 2), tail=round(t["backward"], 2), exp=round(t["expect"], 2), fsw=round(t["fwd_sweep"], 2), bsw=round(t["bwd_sweep"], 2),
                           red=round(t["reduce"], 2), tiles=d["n_chunks"], rounds=[d["fwd_rounds"], d["bwd_rounds"]],
-                          rep_tiles=[d["fwd_tiles"], d["bwd_tiles"]], struct=d["structured"], tile=d["tile_len"], n_sub=d["n_sub"], dA_vs_first=err, LL=r["LL"])), flush=True)
+                          rep_tiles=[d["fwd_tiles"], d["bwd_tiles"]], struct=d["structured"], tile=d["tile_len"], items=[d["items_fwd"], d["items_bwd"]], hist=hist, dA_vs_first=err, LL=r["LL"])), flush=True)
     es.close()

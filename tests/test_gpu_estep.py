@@ -252,7 +252,7 @@ def test_fast_overlap_equals_sequential(hip, golden):
     p = golden.params("n64_curve")
     out = []
     for ov in (0, 3):
-        es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=768, warmup=256, overlap=ov)
+        es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=768, warmup=256, overlap=ov, learn=0)
         es.load_segments(golden.segs_mid)
         r1 = es.estep(p["a"], p["e"], p["a0"])
         r2 = es.estep(p["a"], p["e"], p["a0"])
@@ -265,9 +265,55 @@ def test_fast_overlap_equals_sequential(hip, golden):
     assert abs(out[0]["LL"] - out[1]["LL"]) <= 1e-14 * abs(out[1]["LL"])
 
 
+def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
+    """The O(N) sweeps are chosen exactly when a[][] has psmc_update_hmm's two rank-1 triangles
+    (core.c:112-122); a capped matrix (psmc_cap_matrix, aux.c:115-127) or a random one falls back
+    to the dense sweeps.  Both agree with the oracle."""
+    p = golden.params("n64_curve")
+    o = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid)
+    for st in (1, 0):
+        es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=1024, structured=st)
+        es.load_segments(golden.segs_mid)
+        check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+        assert es.fast_diag()["structured"] == bool(st)
+        es.close()
+    a = p["a"].copy()  # cap at state 40: columns >= 40 are summed into column 40
+    a[:, 40] = a[:, 40:].sum(1); a[:, 41:] = 0.0
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=1024)
+    es.load_segments(golden.segs_mid)
+    check_fast(es.estep(a, p["e"], p["a0"]), oracle.estep(a, p["e"], p["a0"], golden.segs_mid))
+    assert not es.fast_diag()["structured"]
+    check_fast(es.estep(p["a"], p["e"], p["a0"]), o)  # and back: the plan follows the matrix
+    assert es.fast_diag()["structured"]
+    es.close()
+
+
+def test_fast_learns_slow_regions(hip, golden, oracle):
+    """Tiles that needed a repair are glued to their neighbour for the following E-steps of the
+    context: the repair rounds disappear, the result stays inside the tolerance, and two contexts
+    with the same call history agree bit for bit."""
+    p = golden.params("n64_curve")
+    o = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid)
+    runs = []
+    for rep in range(2):
+        es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=768, warmup=256, group_cap=200000)
+        es.load_segments(golden.segs_mid)
+        hist = []
+        for it in range(4):
+            r = es.estep(p["a"], p["e"], p["a0"])
+            check_fast(r, o)
+            d = es.fast_diag()
+            hist.append((r, d["fwd_rounds"] + d["bwd_rounds"], d["items_fwd"]))
+        es.close()
+        assert hist[0][1] > 0 and hist[3][1] == 0 and hist[3][2] < hist[0][2], [h[1:] for h in hist]
+        runs.append(hist)
+    for (r1, _, _), (r2, _, _) in zip(*runs):
+        assert bits_equal(r1["A"], r2["A"]) and bits_equal(r1["E"], r2["E"]) and r1["LL"] == r2["LL"]
+
+
 def test_fast_deterministic_and_selection(hip, golden, oracle):
     p = golden.params("n64_curve")
-    es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=512)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=512, learn=0)
     es.load_segments(golden.segs_mid)
     r1 = es.estep(p["a"], p["e"], p["a0"])
     r2 = es.estep(p["a"], p["e"], p["a0"])

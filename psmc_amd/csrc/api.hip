@@ -27,9 +27,10 @@ struct psmc_hip_ctx {
 	int struct_tiles = 8192;   // "struct_tiles": tiles aimed at when the structured sweeps are used (4 per wave)
 	bool use_struct = false, planned_struct = false;
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
-	int group_cap = 49152;     // "group_cap": longest run of glued tiles, in bins
+	int group_cap = 131072;    // "group_cap": longest run of glued tiles, in bins
 	int *d_items = nullptr;    // items_f | items_b | ritems_f | ritems_b, 2*n_chunks ints each
-	int *h_ritems = nullptr;   // pinned, 2 * 2*n_chunks ints
+	int *h_ritems = nullptr;   // pinned + device-mapped, 2 * 2*n_chunks ints
+	int *m_ritems = nullptr, *m_cnt = nullptr; // device views of h_ritems / h_cnt
 	std::vector<uint8_t> glue_f, glue_b; // glue_f[b]: tile b continues the forward item of b-1; glue_b[b]: b continues b+1's backward item
 	std::vector<int> flagged_f, flagged_b;
 	bool items_dirty = true;
@@ -69,8 +70,9 @@ struct psmc_hip_ctx {
 	double *d_entry = nullptr, *d_bentry = nullptr, *d_bexit = nullptr, *d_Cpart = nullptr, *d_Epart = nullptr,
 	       *d_LLpart = nullptr;
 	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
-	hipStream_t stream2 = nullptr, stream3 = nullptr;
-	hipEvent_t evx[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;
+	hipEvent_t evx[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	int n_long_f = 0, n_long_b = 0, n_mem_f = 0, n_mem_b = 0;
 	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
 	unsigned long long *d_warm = nullptr;
@@ -104,6 +106,12 @@ template <class T> static int dev_alloc(psmc_hip_ctx *c, T **p, size_t n)
 	if (e != hipSuccess) { *p = nullptr; return fail(c, PSMC_HIP_ENOMEM, "hipMalloc", e); }
 	return 0;
 }
+
+// The fast E-step keeps four streams busy (forward chain, backward chain, counts, walks) beside the
+// caller's.  HIP hands a process 4 hardware queues by default and streams beyond that share one -- a
+// kernel then waits for an unrelated one.  Ask for 8 before the runtime starts (no effect, and no harm,
+// if the host program initialised HIP earlier or set the variable itself).
+__attribute__((constructor)) static void psmc_hip_more_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" int psmc_hip_device_count(void)
 {
@@ -143,7 +151,8 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	for (int i = 0; i < 6; ++i)
+	if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	for (int i = 0; i < 8; ++i)
 		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
@@ -163,6 +172,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+	if (c->stream4) (void)hipStreamSynchronize(c->stream4);
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
@@ -172,7 +182,8 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_ritems) (void)hipHostFree(c->h_ritems);
 	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	for (int i = 0; i < 6; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+	for (int i = 0; i < 8; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+	if (c->stream4) (void)hipStreamDestroy(c->stream4);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream3) (void)hipStreamDestroy(c->stream3);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -540,10 +551,11 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_items, (size_t)8 * nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_items, (size_t)12 * nc))) return rc;
 		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
-		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocDefault) != hipSuccess)
-			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
+		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+		    hipHostGetDevicePointer((void **)&c->m_ritems, c->h_ritems, 0) != hipSuccess)
+			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
 		c->chunk_cap = nc;
 	}
 	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub_used * 4096))) return rc;
@@ -553,8 +565,9 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_stats, (size_t)STATS_LEN))) return rc;
 		if ((rc = dev_alloc(c, &c->d_warm, (size_t)2))) return rc;
 		if ((rc = dev_alloc(c, &c->d_cnt, (size_t)4))) return rc;
-		if (hipHostMalloc((void **)&c->h_cnt, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
-			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
+		if (hipHostMalloc((void **)&c->h_cnt, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+		    hipHostGetDevicePointer((void **)&c->m_cnt, c->h_cnt, 0) != hipSuccess)
+			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
 	}
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
 	c->plan_dirty = false;
@@ -566,12 +579,14 @@ static int plan_fast(psmc_hip_ctx *c)
 static int build_items(psmc_hip_ctx *c)
 {
 	const int nc = (int)c->chunks.size(), W = c->warmup;
-	std::vector<std::pair<int, std::pair<int, int>>> kf, kb; // (-steps, (first, count))
+	// key: glued runs first (launched apart from the bulk), then longest first
+	std::vector<std::pair<long long, std::pair<int, int>>> kf, kb; // (key, (first, count))
+	auto key = [](int steps, int count) { return (count > 1 ? -(1ll << 40) : 0ll) - steps; };
 	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
 		int e = b + 1;
 		while (e < nc && c->glue_f[e] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
 		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
-		kf.push_back({-(l.hi - std::max(1, h.lo - W) + 1), {b, e - b}});
+		kf.push_back({key(l.hi - std::max(1, h.lo - W) + 1, e - b), {b, e - b}});
 		b = e;
 	}
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
@@ -580,15 +595,31 @@ static int build_items(psmc_hip_ctx *c)
 		       c->chunks[e].lo < c->chunks[e].L) // a last tile holding only position L owns no transition: never a group's top
 			++e;
 		const Chunk &lo = c->chunks[b], &top = c->chunks[e - 1];
-		kb.push_back({-(std::min(top.hi + W + 1, top.L) - lo.lo), {b, e - b}});
+		kb.push_back({key(std::min(top.hi + W + 1, top.L) - lo.lo, e - b), {b, e - b}});
 		b = e;
 	}
 	std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
-	std::vector<int> h((size_t)4 * nc, 0);
-	for (size_t i = 0; i < kf.size(); ++i) { h[2 * i] = kf[i].second.first; h[2 * i + 1] = kf[i].second.second; }
-	for (size_t i = 0; i < kb.size(); ++i) { h[(size_t)2 * nc + 2 * i] = kb[i].second.first; h[(size_t)2 * nc + 2 * i + 1] = kb[i].second.second; }
+	// layout of d_items (ints): items_f | items_b | ritems_f | ritems_b | members_f | members_b, 2*nc each
+	std::vector<int> h((size_t)4 * nc, 0), mem((size_t)4 * nc, 0);
+	c->n_mem_f = c->n_mem_b = 0;
+	for (size_t i = 0; i < kf.size(); ++i) {
+		h[2 * i] = kf[i].second.first; h[2 * i + 1] = kf[i].second.second;
+		if (kf[i].second.second > 1)
+			for (int t = 0; t < kf[i].second.second; ++t) { mem[2 * (size_t)c->n_mem_f] = kf[i].second.first + t; mem[2 * (size_t)c->n_mem_f + 1] = 1; ++c->n_mem_f; }
+	}
+	for (size_t i = 0; i < kb.size(); ++i) {
+		h[(size_t)2 * nc + 2 * i] = kb[i].second.first; h[(size_t)2 * nc + 2 * i + 1] = kb[i].second.second;
+		if (kb[i].second.second > 1)
+			for (int t = 0; t < kb[i].second.second; ++t) {
+				mem[(size_t)2 * nc + 2 * (size_t)c->n_mem_b] = kb[i].second.first + t; mem[(size_t)2 * nc + 2 * (size_t)c->n_mem_b + 1] = 1; ++c->n_mem_b;
+			}
+	}
 	c->n_items_f = (int)kf.size(); c->n_items_b = (int)kb.size();
+	c->n_long_f = c->n_long_b = 0; // glued runs sort first (more steps than any single tile)
+	while (c->n_long_f < c->n_items_f && kf[c->n_long_f].second.second > 1) ++c->n_long_f;
+	while (c->n_long_b < c->n_items_b && kb[c->n_long_b].second.second > 1) ++c->n_long_b;
 	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
 	c->items_dirty = false;
 	return 0;
 }
@@ -619,14 +650,16 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	if (c->use_struct && c->items_dirty && (rc = build_items(c))) return rc;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
 	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;
-	p.n_items_f = c->n_items_f; p.n_items_b = c->n_items_b; p.tile_len = c->chunk_used; p.h_ritems = c->h_ritems;
+	p.n_items_f = c->n_items_f; p.n_items_b = c->n_items_b; p.tile_len = c->chunk_used; p.h_ritems = c->h_ritems; p.m_ritems = c->m_ritems; p.m_cnt = c->m_cnt;
 	c->flagged_f.clear(); c->flagged_b.clear();
 	p.flagged_f = &c->flagged_f; p.flagged_b = &c->flagged_b;
 	p.d_entry = c->d_entry; p.d_bentry = c->d_bentry; p.d_bexit = c->d_bexit; p.d_Cpart = c->d_Cpart; p.d_Epart = c->d_Epart;
 	p.d_dirty = c->d_dirty; p.d_cnt = c->d_cnt; p.h_cnt = c->h_cnt; p.tol = c->warm_tol; p.max_rounds = c->max_rounds;
 	p.d_touch_f = c->d_touch; p.d_touch_b = c->d_touch + p.n_chunks; p.d_dirty_b = c->d_dirty + p.n_chunks;
-	p.stream2 = c->stream2; p.stream3 = c->stream3; p.overlap = c->overlap;
-	for (int i = 0; i < 6; ++i) p.evx[i] = c->evx[i];
+	p.stream2 = c->stream2; p.stream3 = c->stream3; p.stream4 = c->stream4; p.overlap = c->overlap;
+	p.n_long_f = c->n_long_f; p.n_long_b = c->n_long_b; p.n_mem_f = c->n_mem_f; p.n_mem_b = c->n_mem_b;
+	p.d_members_f = c->d_items + 8 * p.n_chunks; p.d_members_b = c->d_items + 10 * p.n_chunks;
+	for (int i = 0; i < 8; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
 	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());

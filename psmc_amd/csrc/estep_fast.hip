@@ -519,10 +519,24 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	(void)hipEventRecord(p.evx[0], sm);
 	if (ov) (void)hipStreamWaitEvent(sa, p.evx[0], 0); // parameters uploaded, flags cleared
 	// ---- both speculative sweeps
-	if (p.structured) launch_fwd_struct(p, sm, false, p.n_items_f); else launch_fwd<false>(p, sm);
+	// Glued runs (structured sweeps only) are long sequential chains.  A WALK leaves only the boundary
+	// vector of every tile it passes (no table stores: pure latency, untouched by the bulk's HBM traffic);
+	// it starts now, beside the bulk, on a stream of its own (the backward one borrows the counts'
+	// stream, which is idle until the bulk is done).  Afterwards all tiles of the runs are recomputed
+	// in parallel from those boundary vectors; they are flagged for the redo pass of the counts.
+	const bool lw = p.structured && ov && (p.n_long_f > 0 || p.n_long_b > 0);
+	const bool lf = lw && p.n_long_f > 0, lb = lw && p.n_long_b > 0;
+	if (lw) { // both directions in one launch on one extra stream (hardware queues are scarce)
+		(void)hipStreamWaitEvent(p.stream4, p.evx[0], 0);
+		launch_walks(p, p.stream4);
+		(void)hipEventRecord(p.evx[6], p.stream4);
+	}
+	if (p.structured) launch_fwd_struct(p, sm, 0, lf ? p.n_long_f : 0, p.n_items_f - (lf ? p.n_long_f : 0));
+	else launch_fwd<false>(p, sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	if (p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
-	if (p.structured) launch_bwd_struct(p, sa, false, p.n_items_b); else launch_bwd<false>(p, sa);
+	if (p.structured) launch_bwd_struct(p, sa, 0, lb ? p.n_long_b : 0, p.n_items_b - (lb ? p.n_long_b : 0));
+	else launch_bwd<false>(p, sa);
 	if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
 	if (ov) { // early expect over every tile once both sweeps exist
 		(void)hipEventRecord(p.evx[1], sm); (void)hipEventRecord(p.evx[2], sa);
@@ -545,16 +559,13 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		else
 			hipLaunchKernelGGL((k_verify<true>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
 			                   p.d_dirty_b, p.d_cnt + 1, p.d_warm);
-		if (p.structured) { // flagged tiles, ascending: the next repair launch packs them 4 per wave; the host keeps a copy
-			launch_compact(p, c.st, c.bwd);
-			if (hipMemcpyAsync(p.h_ritems + (size_t)c.slot * 2 * p.n_chunks, c.bwd ? p.d_ritems_b : p.d_ritems_f,
-			                   sizeof(int) * 2 * (size_t)p.n_chunks, hipMemcpyDeviceToHost, c.st) != hipSuccess) return -1;
-		}
-		if (hipMemcpyAsync(p.h_cnt + c.slot, p.d_cnt + c.slot, sizeof(int), hipMemcpyDeviceToHost, c.st) != hipSuccess) return -1;
+		launch_compact(p, c.st, c.bwd); // flagged tiles in ascending order + their number, straight into host-mapped memory
 		if (hipEventRecord(c.rb, c.st) != hipSuccess) return -1;
 		c.pending = true;
 		return 0;
 	};
+	if (lf) { (void)hipStreamWaitEvent(sm, p.evx[6], 0); launch_fwd_struct(p, sm, 3, 0, p.n_mem_f); }
+	if (lb) { (void)hipStreamWaitEvent(sa, p.evx[6], 0); launch_bwd_struct(p, sa, 3, 0, p.n_mem_b); }
 	if (post_verify(ch[0]) || post_verify(ch[1])) return -1;
 	while (!(ch[0].done && ch[1].done)) {
 		bool progressed = false;
@@ -575,10 +586,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 			}
 			if (!c.bwd) {
 				rep->fwd_rounds++; rep->fwd_tiles += nd;
-				if (p.structured) launch_fwd_struct(p, c.st, true, nd); else launch_fwd<true>(p, c.st);
+				if (p.structured) launch_fwd_struct(p, c.st, 1, 0, nd); else launch_fwd<true>(p, c.st);
 			} else {
 				rep->bwd_rounds++; rep->bwd_tiles += nd;
-				if (p.structured) launch_bwd_struct(p, c.st, true, nd); else launch_bwd<true>(p, c.st);
+				if (p.structured) launch_bwd_struct(p, c.st, 1, 0, nd); else launch_bwd<true>(p, c.st);
 			}
 			if (post_verify(c)) return -1;
 		}

@@ -27,10 +27,9 @@
 namespace psmc {
 
 // symbol i (0..15) of a 16-byte block, clamped to 0..3 (row 3 of the LDS emission table is 1.0 like row 2)
-template <int I> __device__ __forceinline__ int sym_of(const uint4 sv) {
-	const unsigned w = I < 4 ? sv.x : (I < 8 ? sv.y : (I < 12 ? sv.z : sv.w));
-	return (int)((w >> (8 * (I & 3))) & 3u);
-}
+template <int J> __device__ __forceinline__ int sym_of(unsigned w) { return (int)((w >> (8 * J)) & 3u); }
+// word g (0..3) of the block's 16 symbols
+__device__ __forceinline__ unsigned sym_word(const uint4 sv, int g) { return g == 0 ? sv.x : (g == 1 ? sv.y : (g == 2 ? sv.z : sv.w)); }
 // wave-uniform copy of a 64-bit lane value
 __device__ __forceinline__ int64_t readlane_i64(int64_t v, int lane) {
 	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
@@ -71,6 +70,8 @@ __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, i
 // gluing lets one row do that walk while the rest of the sweep is still running).  All tiles of an item
 // but the last are T positions long.
 struct SweepItem { int first, count; };
+constexpr int SWEEP_WALK = 1;       // leave only the boundary vectors (entry / bentry / bexit) of the tiles walked through
+constexpr int SWEEP_FROM_ENTRY = 2; // REPAIR kernels: start from the boundary vector a walk left instead of the neighbour's table row
 
 // ------------------------------------------------------------------ forward
 // per-row bookkeeping of the tile boundary the sweep crosses next
@@ -78,20 +79,22 @@ struct FwdCursor { int next_lo, tile; };
 
 // MODE 0: per-step range / store / boundary predicates;  MODE 1: all 16 positions are computed and
 // stored and no tile starts inside the block;  MODE 2: warm-up, nothing stored.
-template <int MODE, int I>
-__device__ __forceinline__ void fwd_step(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int J>
+__device__ __forceinline__ void fwd_step(const StructPar &c, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[4],
                                          double *fo, double *io, double *entry)
 {
-	const int p = base + I + 1, idx = base + I;
+	// base = index of the group's first position (multiple of 4), J = step inside the group;
+	// lo0 = first position whose X is stored (INT_MAX for a walk, which only leaves the boundary vectors)
+	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p >= p_first && p <= p_last)) return;
 	if (MODE == 0 && p == cur.next_lo) { // the X_{lo-1} this tile builds on
 		store4(entry + (int64_t)cur.tile * 64 + k0, x);
 		cur.tile += 1; cur.next_lo += T;
 	}
 	double ev[4];
-	load4(lds_e + sym_of<I>(sv) * 64 + k0, ev);
-	if (((I + 1) & 3) == 0) { // p % NORM_EVERY == 0 (blocks are 16-aligned): d_p = sum(X_{p-1}), off the critical path
+	load4(lds_e + sym_of<J>(w) * 64 + k0, ev);
+	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}), off the critical path
 		const double inv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
 		ev[0] *= inv; ev[1] *= inv; ev[2] *= inv; ev[3] *= inv;
 		if ((MODE == 1 || (MODE == 0 && p >= lo0)) && m == 0) io[idx] = inv;
@@ -105,28 +108,36 @@ __device__ __forceinline__ void fwd_block(const StructPar &c, const double *lds_
                                           int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[4],
                                           double *fo, double *io, double *entry)
 {
-#define PSMC_FS(I) fwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, p_last, lo0, T, cur, x, fo, io, entry);
-	PSMC_FS(0) PSMC_FS(1) PSMC_FS(2) PSMC_FS(3) PSMC_FS(4) PSMC_FS(5) PSMC_FS(6) PSMC_FS(7)
-	PSMC_FS(8) PSMC_FS(9) PSMC_FS(10) PSMC_FS(11) PSMC_FS(12) PSMC_FS(13) PSMC_FS(14) PSMC_FS(15)
-#undef PSMC_FS
+	// four groups of four unrolled steps: 16 fully unrolled steps x 3 modes x 2 directions overflow the
+	// instruction cache once the forward, backward and count kernels run side by side
+#pragma unroll 1
+	for (int g = 0; g < 4; ++g) {
+		const unsigned w = sym_word(sv, g);
+		const int pb = base + 4 * g;
+		fwd_step<MODE, 0>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		fwd_step<MODE, 1>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		fwd_step<MODE, 2>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		fwd_step<MODE, 3>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+	}
 }
 
 // items[4*blockIdx.x + row] = work of this row.  REPAIR: the list holds the flagged tiles (count 1); a
 // row starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel
 // then decides whether the next tile has to follow).  No vector-memory load inside the sweep.
 template <bool REPAIR>
-__global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
-                                                     const double *__restrict__ a0, const uint8_t *__restrict__ obs,
-                                                     const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
-                                                     int n_items, int W, int T, double *__restrict__ f,
-                                                     double *__restrict__ invd, double *__restrict__ entry,
-                                                     int *__restrict__ touch_f)
+__device__ __forceinline__ void fwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
+                                                const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
+                                                int n_items, int W, int T, int flags, double *__restrict__ f,
+                                                double *__restrict__ invd, double *__restrict__ entry,
+                                                int *__restrict__ touch_f)
 {
+	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
 	__shared__ double lds_e[4 * 64]; // e[0], e[1], 1, 1
 	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
 	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
 	__syncthreads();
-	const int slot = blockIdx.x * 4 + (lane >> 4);
+	const int slot = block * 4 + (lane >> 4);
 	const bool valid = slot < n_items;
 	const SweepItem it = items[valid ? slot : 0];
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
@@ -138,9 +149,10 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 	load_struct_par(sp, k0, true, sc);
 	double x[4];
 	int p_first;
-	if (REPAIR) { // c.lo >= 2 for every flagged tile
-		if (valid && m == 0) touch_f[it.first] = 1; // X / inv_d of this tile change
-		load4(fo + (int64_t)(c.lo - 2) * 64, x);
+	if (REPAIR && valid && m == 0) touch_f[it.first] = 1; // X / inv_d of this tile change
+	if (REPAIR && c.lo > 1) { // from the neighbour's stored X_{lo-1}, or from the boundary vector a walk left
+		if (from_entry) load4(entry + (int64_t)it.first * 64 + k0, x);
+		else load4(fo + (int64_t)(c.lo - 2) * 64, x);
 		p_first = c.lo;
 	} else {
 		const int ws = max(1, c.lo - W);
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 			double ev[4];
 			load4(lds_e + ((int)o[0] & 3) * 64 + k0, ev);
 			x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
-			if (valid && c.lo == 1) store4(fo, x);
+			if (valid && c.lo == 1 && !walk) store4(fo, x);
 			p_first = 2;
 		} else { // warm-up from the stationary prior
 			p_first = ws;
@@ -157,6 +169,7 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 	}
 	// tile boundaries ahead: the head's own lo (unless it is position 1, which no step computes), then every T
 	FwdCursor cur;
+	const int lo_store = walk ? 0x7fffffff : c.lo;
 	cur.tile = c.lo >= p_first ? it.first : it.first + 1;
 	cur.next_lo = c.lo >= p_first ? c.lo : c.lo + T;
 	const int b_first = (p_first - 1) >> 4;
@@ -179,48 +192,59 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
 			const int base = (b_first + bi) << 4;
 			if (cur.next_lo == base + 1 && base + 1 >= p_first && base + 1 <= p_last) { // a tile starts exactly at this block
 				store4(entry + (int64_t)cur.tile * 64 + k0, x);
-				cur.tile += 1; cur.next_lo += T;
+						cur.tile += 1; cur.next_lo += T;
 			}
 			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
-			const int mode = !full ? 0 : (base + 1 >= c.lo ? 1 : 2);
-			if (__all(mode == 1)) fwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, T, cur, x, fo, io, entry);
-			else if (__all(mode == 2)) fwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, T, cur, x, fo, io, entry);
-			else fwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_last, c.lo, T, cur, x, fo, io, entry);
+			const int mode = !full ? 0 : (base + 1 >= lo_store ? 1 : 2);
+			if (__all(mode == 1)) fwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else if (__all(mode == 2)) fwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else fwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 		}
 	}
+}
+
+template <bool REPAIR>
+__global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                     const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                     const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
+                                                     int n_items, int W, int T, int flags, double *__restrict__ f,
+                                                     double *__restrict__ invd, double *__restrict__ entry,
+                                                     int *__restrict__ touch_f)
+{
+	fwd_struct_body<REPAIR>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
 }
 
 // ------------------------------------------------------------------ backward
 // bt_p = e[o_p] * (a bt_{p+1}) * sb_p, positions descending.  A tile owns bt[lo+1 .. top+1] and sb[lo..top]
 // (top = min(hi, L-1)); bt[lo] is stored by the tile below as its boundary value unless lo == 1.
 // The cursor holds the tile the row is in; when p passes its lo the row moves into the tile below.
-struct BwdCursor { int lo, top, tile; };
+struct BwdCursor { int lo, top, tile; bool store; }; // store: false for a walk, which only leaves the boundary vectors
 
 // MODE 1: every position of the block is strictly inside (lo, top) of the current tile;
 // MODE 2: warm-up above the top tile's top;  MODE 0: general.
-template <int MODE, int I>
-__device__ __forceinline__ void bwd_step(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int J>
+__device__ __forceinline__ void bwd_step(const StructPar &c, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_low, int T, BwdCursor &cur, double (&x)[4], double *bto,
                                          double *sbo, double *bentry, double *bexit)
 {
-	const int p = base + I + 1, idx = base + I;
+	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p <= p_first && p >= p_low)) return;
 	double ev[4];
-	load4(lds_e + sym_of<I>(sv) * 64 + k0, ev);
-	if (((I + 1) & 3) == 0) { // sb_p = 1/sum(bt_{p+1}), off the critical path
+	load4(lds_e + sym_of<J>(w) * 64 + k0, ev);
+	if (J == 3) { // sb_p = 1/sum(bt_{p+1}), off the critical path
 		const double s = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
 		ev[0] *= s; ev[1] *= s; ev[2] *= s; ev[3] *= s;
-		if ((MODE == 1 || (MODE == 0 && p <= cur.top)) && m == 0) sbo[idx] = s;
+		if ((MODE == 1 || (MODE == 0 && p <= cur.top && cur.store)) && m == 0) sbo[idx] = s;
 	}
 	if (MODE == 0 && p == cur.top) { // the boundary vector this tile builds on
-		store4(bto + (int64_t)cur.top * 64, x); // bt[top+1]
+		if (cur.store) store4(bto + (int64_t)cur.top * 64, x); // bt[top+1]
 		store4(bentry + (int64_t)cur.tile * 64 + k0, x);
 	}
 	struct_step(c, x);
 	x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
 	if (MODE == 1) store4(bto + (int64_t)idx * 64, x);
 	if (MODE == 0 && p <= cur.top) {
-		if (p > cur.lo || cur.lo == 1) store4(bto + (int64_t)idx * 64, x);
+		if (cur.store && (p > cur.lo || cur.lo == 1)) store4(bto + (int64_t)idx * 64, x);
 		if (p == cur.lo) { // leaving the tile: hand over to the one below
 			store4(bexit + (int64_t)cur.tile * 64 + k0, x);
 			cur.tile -= 1; cur.top = cur.lo - 1; cur.lo -= T;
@@ -232,26 +256,31 @@ __device__ __forceinline__ void bwd_block(const StructPar &c, const double *lds_
                                           int p_first, int p_low, int T, BwdCursor &cur, double (&x)[4], double *bto,
                                           double *sbo, double *bentry, double *bexit)
 {
-#define PSMC_BS(I) bwd_step<MODE, I>(c, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-	PSMC_BS(15) PSMC_BS(14) PSMC_BS(13) PSMC_BS(12) PSMC_BS(11) PSMC_BS(10) PSMC_BS(9) PSMC_BS(8)
-	PSMC_BS(7) PSMC_BS(6) PSMC_BS(5) PSMC_BS(4) PSMC_BS(3) PSMC_BS(2) PSMC_BS(1) PSMC_BS(0)
-#undef PSMC_BS
+#pragma unroll 1
+	for (int g = 3; g >= 0; --g) {
+		const unsigned w = sym_word(sv, g);
+		const int pb = base + 4 * g;
+		bwd_step<MODE, 3>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 2>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 1>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 0>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+	}
 }
 
 // items: tiles first .. first+count-1, walked from the highest down.
 template <bool REPAIR>
-__global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
-                                                     const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
-                                                     const SweepItem *__restrict__ items, int n_items, int W, int T,
-                                                     double *__restrict__ bt, double *__restrict__ sb,
-                                                     double *__restrict__ bentry, double *__restrict__ bexit,
-                                                     int *__restrict__ touch_b)
+__device__ __forceinline__ void bwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
+                                                const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
+                                                const SweepItem *__restrict__ items, int n_items, int W, int T,
+                                                int flags, double *__restrict__ bt, double *__restrict__ sb,
+                                                double *__restrict__ bentry, double *__restrict__ bexit,
+                                                int *__restrict__ touch_b)
 {
 	__shared__ double lds_e[4 * 64];
 	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
 	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
 	__syncthreads();
-	const int slot = blockIdx.x * 4 + (lane >> 4);
+	const int slot = block * 4 + (lane >> 4);
 	const SweepItem it = items[slot < n_items ? slot : 0];
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	const int t_top = it.first + it.count - 1;
@@ -260,6 +289,8 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
 	BwdCursor cur;
 	cur.lo = c.lo; cur.top = min(c.hi, L - 1); cur.tile = t_top;
 	const bool valid = slot < n_items && cur.top >= cur.lo; // a tile holding only position L owns no transition
+	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
+	cur.store = !walk;
 	const uint8_t *o = obs + c.off;
 	double *bto = bt + c.off * 64 + k0, *sbo = sb + c.off;
 	StructPar sc;
@@ -268,7 +299,8 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
 	int p_first;
 	if (REPAIR) { // continue from the value the tile above computed at our top boundary
 		if (valid && m == 0) touch_b[t_top] = 1;
-		load4(bexit + (int64_t)(t_top + 1) * 64 + k0, x);
+		if (from_entry) load4(bentry + (int64_t)t_top * 64 + k0, x); // the boundary vector a walk left for this tile
+		else load4(bexit + (int64_t)(t_top + 1) * 64 + k0, x);
 		p_first = cur.top;
 	} else {
 		const int q = min(c.hi + W + 1, L); // B_q := 1
@@ -292,7 +324,8 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
 		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
 		if (bi < nblk) {
 			const int base = (b_first - bi) << 4;
-			const int mode = (base + 1 > cur.lo && base + 16 < cur.top) ? 1 : ((base + 1 > cur.top && base + 16 <= p_first) ? 2 : 0);
+			int mode = (base + 1 > cur.lo && base + 16 < cur.top) ? 1 : ((base + 1 > cur.top && base + 16 <= p_first) ? 2 : 0);
+			if (walk && mode == 1) mode = 2;
 			if (__all(mode == 1)) bwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 			else if (__all(mode == 2)) bwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 			else bwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
@@ -300,10 +333,42 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
 	}
 }
 
+template <bool REPAIR>
+__global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                     const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
+                                                     const SweepItem *__restrict__ items, int n_items, int W, int T,
+                                                     int flags, double *__restrict__ bt, double *__restrict__ sb,
+                                                     double *__restrict__ bentry, double *__restrict__ bexit,
+                                                     int *__restrict__ touch_b)
+{
+	bwd_struct_body<REPAIR>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
+}
+
+// Both directions' walks over the glued runs in ONE launch (blocks [0, nbf) forward, the rest backward):
+// a process only gets a handful of hardware queues, and a walk that shares one with another stream's
+// kernel would wait for it.
+__global__ __launch_bounds__(64) void k_walk_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
+                                                      int n_f, const SweepItem *__restrict__ items_b, int n_b, int W, int T,
+                                                      double *__restrict__ entry, double *__restrict__ bentry,
+                                                      double *__restrict__ bexit)
+{
+	const int nbf = (n_f + 3) / 4;
+	if ((int)blockIdx.x < nbf)
+		fwd_struct_body<false>(blockIdx.x, sp, e, a0, obs, chunks, items_f, n_f, W, T, SWEEP_WALK, nullptr, nullptr, entry, nullptr);
+	else
+		bwd_struct_body<false>(blockIdx.x - nbf, sp, e, obs, chunks, items_b, n_b, W, T, SWEEP_WALK, nullptr, nullptr, bentry, bexit,
+		                       nullptr);
+}
+
 // ------------------------------------------------------------------ dirty-tile lists
 // deterministic compaction of the verify kernel's flags: out[0..cnt) = flagged tiles in ascending
 // order, each as a one-tile sweep item
-__global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, int n, SweepItem *__restrict__ out)
+// host_out / host_cnt are host-mapped pinned memory: the host learns the count (and the list) without a
+// copy command, which would be a blit kernel queued behind whatever is running
+__global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, int n, SweepItem *__restrict__ out,
+                                                  SweepItem *__restrict__ host_out, int *__restrict__ host_cnt)
 {
 	const int lane = threadIdx.x;
 	int base = 0;
@@ -311,38 +376,61 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 		const int i = i0 + lane;
 		const bool d = i < n && dirty[i] != 0;
 		const unsigned long long mask = __ballot(d);
-		if (d) { SweepItem s; s.first = i; s.count = 1; out[base + __popcll(mask & ((1ull << lane) - 1ull))] = s; }
+		if (d) {
+			SweepItem s; s.first = i; s.count = 1;
+			const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+			out[at] = s;
+			if (host_out) host_out[at] = s;
+		}
 		base += __popcll(mask);
 	}
+	if (lane == 0) *host_cnt = base;
+	__threadfence_system();
 }
 
 // ------------------------------------------------------------------ launchers
-void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_items)
+// which: 0 = the sweep items [first, first+n), 1 = flagged tiles of the current repair round,
+//        2 = walks over the glued runs [0, n) (boundary vectors only), 3 = every tile of the glued
+//        runs, recomputed from the boundary vector its walk left
+void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
-	if (!repair)
-		hipLaunchKernelGGL((k_fwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-		                   (const SweepItem *)p.d_items_f, n_items, p.warmup, p.tile_len, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
+	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
+	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? SWEEP_FROM_ENTRY : 0);
+	if (which == 0 || which == 2)
+		hipLaunchKernelGGL((k_fwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, items, n_items,
+		                   p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
 	else
-		hipLaunchKernelGGL((k_fwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-		                   (const SweepItem *)p.d_ritems_f, n_items, p.warmup, p.tile_len, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
+		hipLaunchKernelGGL((k_fwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, items, n_items,
+		                   p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
 }
-void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_items)
+void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
-	if (!repair)
-		hipLaunchKernelGGL((k_bwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, (const SweepItem *)p.d_items_b,
-		                   n_items, p.warmup, p.tile_len, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
+	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? SWEEP_FROM_ENTRY : 0);
+	if (which == 0 || which == 2)
+		hipLaunchKernelGGL((k_bwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup,
+		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 	else
-		hipLaunchKernelGGL((k_bwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, (const SweepItem *)p.d_ritems_b,
-		                   n_items, p.warmup, p.tile_len, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+		hipLaunchKernelGGL((k_bwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup,
+		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 }
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
 {
 	hipLaunchKernelGGL(k_compact, dim3(1), dim3(64), 0, st, bwd ? p.d_dirty_b : p.d_dirty, p.n_chunks,
-	                   (SweepItem *)(bwd ? p.d_ritems_b : p.d_ritems_f));
+	                   (SweepItem *)(bwd ? p.d_ritems_b : p.d_ritems_f),
+	                   (SweepItem *)(p.m_ritems ? p.m_ritems + (size_t)(bwd ? 1 : 0) * 2 * p.n_chunks : nullptr), p.m_cnt + (bwd ? 1 : 0));
+}
+void launch_walks(const EstepLaunch &p, hipStream_t st)
+{
+	const int nb = (p.n_long_f + 3) / 4 + (p.n_long_b + 3) / 4;
+	if (nb <= 0) return;
+	hipLaunchKernelGGL(k_walk_struct, dim3(nb), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+	                   (const SweepItem *)p.d_items_f, p.n_long_f, (const SweepItem *)p.d_items_b, p.n_long_b, p.warmup, p.tile_len,
+	                   p.d_entry, p.d_bentry, p.d_bexit);
 }
 
 } // namespace psmc

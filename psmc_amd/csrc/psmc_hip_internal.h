@@ -29,7 +29,7 @@ struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged;
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
 	hipStream_t stream, stream2, stream3; // forward chain (main), backward chain, early expect
-	hipEvent_t evx[6];           // cross-stream dependencies; 4/5: count read-backs of the two chains
+	hipEvent_t evx[8];           // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
 	int overlap;
 	int rep_impl, expect_impl, n_states;
 	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)
@@ -43,8 +43,13 @@ struct EstepLaunch {
 	int structured;      // a[k][l] = P_k qa_l (l<k), R_k c_l (l>k): O(N) sweeps, 4 tiles per wave
 	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)
 	int n_items_f, n_items_b, tile_len;
+	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
+	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
+	int n_mem_f, n_mem_b;
+	hipStream_t stream4;
 	int *d_ritems_f, *d_ritems_b;     // [n_chunks][2] flagged tiles of the current repair round as one-tile items
-	int *h_ritems;                    // pinned [2][n_chunks][2]: the same lists read back, so that the host can learn the groups
+	int *h_ritems;                    // host view of pinned, device-mapped [2][n_chunks][2]: the same lists, so that the host can learn the groups
+	int *m_ritems, *m_cnt;            // device views of the mapped h_ritems / h_cnt (written by k_compact, no copy commands)
 	std::vector<int> *flagged_f, *flagged_b; // out: tiles flagged in any round of this E-step (may be null)
 	// data
 	const uint8_t *d_obs;
@@ -78,9 +83,10 @@ constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
 int launch_fast(const EstepLaunch &p, FastReport *rep);
-void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list);
-void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, bool repair, int n_list);
+void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
+void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
+void launch_walks(const EstepLaunch &p, hipStream_t st);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
                        int ns, int32_t *path, double *maxp);
 int run_selftest(hipStream_t stream, unsigned *d_flags);

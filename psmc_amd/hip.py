@@ -60,6 +60,9 @@ def _share_torch_hip_runtime():
         pass
 
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # see api.hip: streams of one E-step must not share a hardware queue
+
+
 def load_library():
     """dlopen psmc_amd/libpsmc_hip.so (built by psmc_amd/csrc/Makefile).  Fails loudly."""
     global _LIB

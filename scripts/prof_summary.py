@@ -9,7 +9,7 @@ bins = int(sys.argv[2]) if len(sys.argv) > 2 else 30000003
 
 def short(nm):
     rep = ('true>' in nm) or ('Lb1' in nm)
-    for k in ('k_fwd_fast', 'k_bwd_fast'):
+    for k in ('k_fwd_fast', 'k_bwd_fast', 'k_fwd_struct', 'k_bwd_struct'):
         if k in nm: return k + ('<repair>' if rep else '<speculate>')
     if 'k_verify' in nm: return 'k_verify' + ('<bwd>' if rep else '<fwd>')
     m = re.search(r'psmc::(k_[a-z0-9_]+)', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)E', nm)

@@ -56,6 +56,10 @@ int main(int argc, char *argv[])
 		fprintf(stderr, "psmc: decoding needs the exact forward/backward tables; using PSMC_HIP_MODE=exact\n");
 		mode = PSMC_HIP_MODE_EXACT;
 	}
+	{ /* the O(N) objective goes with the fast E-step unless asked otherwise */
+		const char *fm = getenv("PSMC_FAST_MSTEP");
+		o.fast_mstep = fm ? atoi(fm) != 0 : (mode == PSMC_HIP_MODE_FAST);
+	}
 	hip_be h;
 	memset(&h, 0, sizeof h);
 	int rc = psmc_hip_create(&h.ctx, n_states, dev_s ? atoi(dev_s) : 0, mode);

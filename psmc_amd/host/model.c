@@ -118,6 +118,61 @@ void psmc_model_update(psmc_model *m)
 	free(lambda); free(alpha); free(beta); free(q_aux); free(q); free(tau);
 }
 
+/* The factors of psmc_model_update's matrix instead of the matrix (fast M-step):
+ *   a[k][l] = FL_k * qa_l (l < k),  FU_k * c_l (l > k),  D_k (l == k);  e[0][k] = exp(le0_k), e[1][k] = 1 - e[0][k]
+ * with the same scalar recurrences as above.  out = log FL | log FU | log D | log qa | log c | le0 | log e1,
+ * N each (entries that do not exist -- FL_0, FU_n, qa_n, c_0 -- are 0).  Returns 0 when a factor is not
+ * positive (the reference's Q is then -HMM_INF, khmm.c:369-377), else 1.  Does not touch a/e/a0/sigma. */
+int psmc_model_logfactors(psmc_model *m, double *out)
+{
+	const int N = m->pat.n_states, n = N - 1;
+	double *w = (double *)malloc(sizeof(double) * (size_t)(5 * N + 1));
+	double *lambda = w, *alpha = w + N, *beta = w + 2 * N + 1, *q_aux = w + 3 * N + 1, *tau = w + 4 * N + 1;
+	double *lFL = out, *lFU = out + N, *lD = out + 2 * N, *lqa = out + 3 * N, *lc = out + 4 * N, *le0 = out + 5 * N, *le1 = out + 6 * N;
+	const double theta = m->params[0], rho = m->params[1], max_t = m->params[2];
+	double dt = 0.0;
+	int ok = 1;
+	memset(out, 0, sizeof(double) * (size_t)(7 * N));
+	for (int k = 0; k <= n; ++k) lambda[k] = m->params[m->pat.group[k] + PSMC_N_FIXED];
+	time_boundaries(m, max_t, m->t);
+	if (m->has_dt) { dt = m->params[m->n_params - 1]; if (dt < 0) dt = 0; }
+	const double *t = m->t;
+	for (int k = 0; k <= n; ++k) tau[k] = t[k + 1] - t[k];
+	alpha[0] = 1.0;
+	for (int k = 1; k <= n; ++k) alpha[k] = alpha[k - 1] * exp(-tau[k - 1] / lambda[k - 1]);
+	alpha[n + 1] = 0.0;
+	beta[0] = 0.0;
+	for (int k = 1; k <= n; ++k) beta[k] = beta[k - 1] + lambda[k - 1] * (1.0 / alpha[k] - 1.0 / alpha[k - 1]);
+	for (int l = 0; l < n; ++l) q_aux[l] = (alpha[l] - alpha[l + 1]) * (beta[l] - lambda[l] / alpha[l]) + tau[l];
+	double C_pi = 0.0;
+	for (int l = 0; l <= n; ++l) C_pi += lambda[l] * (alpha[l] - alpha[l + 1]);
+	const double C_sigma = 1.0 / (C_pi * rho) + 0.5;
+	double sum_t = 0.0;
+	for (int k = 0; k <= n && ok; ++k) {
+		const double ak1 = alpha[k] - alpha[k + 1], lak = lambda[k];
+		const double cpik = ak1 * (sum_t + lak) - alpha[k + 1] * tau[k];
+		const double pik = cpik / C_pi;
+		const double sigma_k = (ak1 / (C_pi * rho) + pik / 2.0) / C_sigma;
+		const double avg_t = interval_mean_time(pik, C_sigma, sigma_k, rho, sum_t, tau[k], lak, alpha[k], alpha[k + 1]);
+		const double tmp = pik / (C_sigma * sigma_k);
+		const double qkk = (ak1 * ak1 * (beta[k] - lak / alpha[k]) + 2 * lak * ak1 - 2 * alpha[k + 1] * tau[k]) / cpik;
+		const double D = tmp * qkk + (1.0 - tmp);
+		if (!(D > 0.0)) ok = 0; else lD[k] = log(D);
+		if (k > 0) { const double FL = tmp * (ak1 / cpik); if (!(FL > 0.0)) ok = 0; else lFL[k] = log(FL); }
+		if (k < n) {
+			const double FU = tmp * (q_aux[k] / cpik);
+			if (!(FU > 0.0) || !(q_aux[k] > 0.0)) ok = 0; else { lFU[k] = log(FU); lqa[k] = log(q_aux[k]); }
+		}
+		if (k > 0) { if (!(ak1 > 0.0)) ok = 0; else lc[k] = log(ak1); }
+		const double x = -theta * (avg_t + dt), e1 = 1.0 - exp(x);
+		le0[k] = x;
+		if (!(e1 > 0.0) || !(exp(x) > 0.0)) ok = 0; else le1[k] = log(e1);
+		sum_t += tau[k];
+	}
+	free(w);
+	return ok;
+}
+
 void psmc_model_avg_t(const psmc_model *m, double *avg_t)
 {
 	const int N = m->pat.n_states, n = N - 1;

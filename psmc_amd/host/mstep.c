@@ -12,7 +12,11 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 #include "psmc_host.h"
+
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
 #define HJ_RADIUS 0.5
 #define HJ_EPS 1e-7
@@ -107,7 +111,29 @@ double psmc_hooke_jeeves(psmc_objective f, int n, double *x, void *data, double 
 	return fx1;
 }
 
-typedef struct { psmc_model *m; const double *A, *E; double Q0; int calls; } q_ctx;
+typedef struct {
+	psmc_model *m; const double *A, *E; double Q0; int calls;
+	double *sums, *lf; /* fast objective: SL | SU | DG | CL | CU (5N, from A, once per round); 7N log factors per call */
+} q_ctx;
+
+/* Fast objective: log a[k][l] = log FL_k + log qa_l (l<k), log FU_k + log c_l (l>k), so
+ * sum_kl A[k][l] log a[k][l] needs 5N logarithms and the triangular row / column sums of A instead of
+ * N*N logarithms and the matrix itself.  Equal to psmc_Q up to rounding (~1e-13 relative): the direct
+ * search may take a different path, which PSMC_HIP_MODE=fast accepts by definition. */
+static double neg_Q_fast(int n, double *x, void *data)
+{
+	q_ctx *c = (q_ctx *)data;
+	const int N = c->m->pat.n_states;
+	++c->calls;
+	for (int i = 0; i < n; ++i) c->m->params[i] = fabs(x[i]);
+	if (!psmc_model_logfactors(c->m, c->lf)) return -Q_MINUS_INF;
+	const double *lFL = c->lf, *lFU = lFL + N, *lD = lFU + N, *lqa = lD + N, *lc = lqa + N, *le0 = lc + N, *le1 = le0 + N;
+	const double *SL = c->sums, *SU = SL + N, *DG = SU + N, *CL = DG + N, *CU = CL + N;
+	double sum = 0.0;
+	for (int k = 0; k < N; ++k) sum += c->E[k] * le0[k] + c->E[N + k] * le1[k];
+	for (int k = 0; k < N; ++k) sum += SL[k] * lFL[k] + SU[k] * lFU[k] + DG[k] * lD[k] + CL[k] * lqa[k] + CU[k] * lc[k];
+	return -(sum - c->Q0);
+}
 
 static double neg_Q(int n, double *x, void *data)
 {	/* em.c:15-25 */
@@ -125,17 +151,34 @@ int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, F
 	double LL = 0.0;
 	(void)in;
 	/* E-step on the device: em.c:33-55 */
+	const double t_e0 = now_ms();
 	int rc = be->estep(be->self, m->a, m->e, m->a0, A, E, &LL, 0);
+	const double t_e1 = now_ms();
 	if (rc) { free(A); free(E); return rc; }
 	/* M-step: em.c:56-68 */
 	q_ctx c;
 	c.m = m; c.A = A; c.E = E; c.calls = 0;
 	c.Q0 = psmc_Q0(N, A, E);
+	c.sums = c.lf = 0;
+	if (m->fast_mstep) {
+		c.sums = (double *)calloc((size_t)5 * N, sizeof(double)); c.lf = (double *)calloc((size_t)7 * N, sizeof(double));
+		for (int k = 0; k < N; ++k)
+			for (int l = 0; l < N; ++l) {
+				const double v = A[(size_t)k * N + l];
+				if (l < k) { c.sums[k] += v; c.sums[3 * N + l] += v; }          /* SL_k, CL_l */
+				else if (l > k) { c.sums[N + k] += v; c.sums[4 * N + l] += v; } /* SU_k, CU_l */
+				else c.sums[2 * N + k] = v;
+			}
+	}
 	m->lk = LL;
 	double *x = (double *)calloc((size_t)m->n_params, sizeof(double));
 	memcpy(x, m->params, sizeof(double) * (size_t)m->n_params);
 	m->Q0 = psmc_Q(N, m->a, m->e, A, E, c.Q0);
-	m->Q1 = -psmc_hooke_jeeves(neg_Q, m->n_params, x, &c, HJ_RADIUS, HJ_EPS, HJ_MAXCALL);
+	m->Q1 = -psmc_hooke_jeeves(m->fast_mstep ? neg_Q_fast : neg_Q, m->n_params, x, &c, HJ_RADIUS, HJ_EPS, HJ_MAXCALL);
+	if (m->fast_mstep) { psmc_model_update(m); free(c.sums); free(c.lf); } /* a/e/a0/sigma of the LAST trial point, like em.c:21-22 */
+	if (getenv("PSMC_TIMING")) /* stderr only: the .psmc stream stays byte-identical */
+		fprintf(stderr, "[psmc] E-step %.1f ms, M-step %.1f ms (%d objective calls%s)\n", t_e1 - t_e0, now_ms() - t_e1, c.calls,
+		        m->fast_mstep ? ", O(N) objective" : "");
 	fprintf(out, "IT\t%d\n", c.calls);
 	free(x);
 	{ /* posterior state occupancy, em.c:69-74 */

@@ -65,11 +65,13 @@ typedef struct {
 	double *a, *e, *a0; /* n*n, 3*n (row 2 = 1), n */
 	/* EM bookkeeping printed every round */
 	double lk, Q0, Q1;
+	int fast_mstep;    /* 1: O(N) objective from the matrix factors (not bit-identical: fast mode only) */
 } psmc_model;
 psmc_model *psmc_model_new(const psmc_pattern *pat, const char *pattern_text, double alpha, int has_dt);
 void psmc_model_free(psmc_model *m);
 void psmc_model_update(psmc_model *m);                       /* psmc_update_hmm, core.c:61-133 */
 void psmc_model_avg_t(const psmc_model *m, double *avg_t);   /* psmc_avg_t, core.c:135-162 */
+int  psmc_model_logfactors(psmc_model *m, double *out7N);    /* logs of the factors of a[][] and e[][] (fast M-step) */
 void psmc_model_cap(psmc_model *m, int k0);                  /* psmc_cap_matrix, aux.c:115-127 */
 
 /* ---- M-step pieces (khmm.c:326-382, kmin.c:48-107, em.c:15-25) */
@@ -104,6 +106,7 @@ typedef struct {
 	double dt0;       /* -T (<0: off) */
 	int cap_k;        /* -C */
 	int decode, full_decode, print_prob, simulate, bootstrap; /* -d -D -s -S -b */
+	int fast_mstep;   /* not a reference option: set by the driver for PSMC_HIP_MODE=fast (PSMC_FAST_MSTEP=0 to keep the exact objective) */
 	char *pattern_text; /* -p */
 	char *param_file; /* -i */
 	char *cnt_file;   /* -c */

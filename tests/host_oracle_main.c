@@ -57,6 +57,7 @@ int main(int argc, char **argv)
 	psmc_options o;
 	psmc_options_default(&o);
 	if (psmc_options_parse(&o, argc, argv)) return 1;
+	o.fast_mstep = getenv("PSMC_FAST_MSTEP") && atoi(getenv("PSMC_FAST_MSTEP")) != 0; /* O(N) objective (what PSMC_HIP_MODE=fast uses) */
 	psmc_pattern pat;
 	char str[256] = "4+5*3+4";
 	if (o.param_file) { FILE *fp = fopen(o.param_file, "r"); if (!fp || fscanf(fp, "%255s", str) != 1) return 1; fclose(fp); }

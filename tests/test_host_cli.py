@@ -59,6 +59,24 @@ def test_host_logic_byte_identical(oracle_psmc, name):
         assert len(a) == len(b)
 
 
+def test_fast_mstep_objective_close(oracle_psmc):
+    """PSMC_FAST_MSTEP=1 (the O(N) objective PSMC_HIP_MODE=fast uses: 5N logarithms and the triangular
+    sums of A instead of N*N logarithms) equals hmm_Q up to rounding: same first-round search, LK of the
+    later rounds within 1e-6 relative (the direct search is chaotic in the last digits), same layout."""
+    args = open(os.path.join(CLI, "mid_n64_N4.args")).read().split()
+    env = dict(os.environ, PSMC_FAST_MSTEP="1")
+    r = subprocess.run([oracle_psmc] + args, cwd=CLI, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    got, want = r.stdout.splitlines(), golden_text("mid_n64_N4").splitlines()
+    assert len(got) == len(want) and [l[:2] for l in got] == [l[:2] for l in want]
+    for tag, tol in (("LK", 1e-6), ("QD", 1e-3), ("TR", 1e-3), ("RS", 2e-2)):
+        for g, w in zip([l for l in got if l.startswith(tag)], [l for l in want if l.startswith(tag)]):
+            for x, y in zip(g.split()[1:], w.split()[1:]):
+                if "->" in (x, y):
+                    continue
+                assert abs(float(x) - float(y)) <= tol * max(abs(float(y)), 1e-3), (g, w)
+
+
 @pytest.fixture(scope="module")
 def host():
     subprocess.run(["make", "-s", "-C", HOST, "libpsmc_host.so"], check=True)
@@ -195,6 +213,6 @@ def test_psmc_binary_fast_mode_close():
     want = [l for l in golden_text("mid_n64_N4").splitlines() if l.startswith("LK")]
     assert len(got) == len(want)
     g1, w1 = float(got[1].split()[1]), float(want[1].split()[1])
-    assert abs(g1 - w1) <= 1e-9 * abs(w1) + 1e-6
+    assert abs(g1 - w1) <= 1e-7 * abs(w1) + 1e-6  # round 1 depends on round 0's M-step: O(N) objective, see test_fast_mstep_objective_close
     for g, w in zip(got[2:], want[2:]):
         assert abs(float(g.split()[1]) - float(w.split()[1])) <= 1e-4 * abs(float(w.split()[1]))

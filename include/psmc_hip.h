@@ -54,7 +54,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * "expect_impl" (0 VALU, 1 MFMA f64), "structured" (1 auto / 0 always dense sweeps),
  * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront), "learn" (1: tiles
  * that needed a repair are glued to their neighbour for the following E-steps of this context;
- * results then depend on the call history within the stated tolerance), "group_cap" (bins). */
+ * results then depend on the call history within the stated tolerance), "group_cap" (bins), "fuse" (1: with the structured sweeps, backward sweep and counts
+ * in one kernel -- bt never stored, half the HBM traffic, FP64-issue bound; default 0). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:

@@ -524,27 +524,42 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	// it starts now, beside the bulk, on a stream of its own (the backward one borrows the counts'
 	// stream, which is idle until the bulk is done).  Afterwards all tiles of the runs are recomputed
 	// in parallel from those boundary vectors; they are flagged for the redo pass of the counts.
-	const bool lw = p.structured && ov && (p.n_long_f > 0 || p.n_long_b > 0);
+	const bool lw = p.structured && (p.n_long_f > 0 || p.n_long_b > 0) && (ov || p.fused);
 	const bool lf = lw && p.n_long_f > 0, lb = lw && p.n_long_b > 0;
+	hipStream_t sw = ov ? p.stream4 : sm;
 	if (lw) { // both directions in one launch on one extra stream (hardware queues are scarce)
-		(void)hipStreamWaitEvent(p.stream4, p.evx[0], 0);
-		launch_walks(p, p.stream4);
-		(void)hipEventRecord(p.evx[6], p.stream4);
+		if (ov) (void)hipStreamWaitEvent(sw, p.evx[0], 0);
+		launch_walks(p, sw);
+		(void)hipEventRecord(p.evx[6], sw);
 	}
 	if (p.structured) launch_fwd_struct(p, sm, 0, lf ? p.n_long_f : 0, p.n_items_f - (lf ? p.n_long_f : 0));
 	else launch_fwd<false>(p, sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
+	(void)hipEventRecord(p.evx[1], sm);
 	if (p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
-	if (p.structured) launch_bwd_struct(p, sa, 0, lb ? p.n_long_b : 0, p.n_items_b - (lb ? p.n_long_b : 0));
-	else launch_bwd<false>(p, sa);
-	if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
-	if (ov) { // early expect over every tile once both sweeps exist
-		(void)hipEventRecord(p.evx[1], sm); (void)hipEventRecord(p.evx[2], sa);
-		(void)hipStreamWaitEvent(sx, p.evx[1], 0); (void)hipStreamWaitEvent(sx, p.evx[2], 0);
-		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sx);
-		launch_expect(p, sx, 0);
-		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sx);
-		(void)hipEventRecord(p.evx[3], sx);
+	if (p.fused) {
+		// Fused backward + counts (estep_fused.hip): a warm-up-only pass of the 4-tiles-per-wave sweep leaves
+		// every bulk tile's start vector (beside the forward sweep, which is HBM-bound and leaves the VALUs
+		// idle); then one wave per tile walks it backwards and feeds the matrix cores.  bt never reaches HBM.
+		const int nb0 = lb ? p.n_long_b : 0;
+		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0);
+		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles
+		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
+		launch_bwd_count(p, sa, 0, nb0, p.n_items_b - nb0);
+		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sa);
+		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
+	} else {
+		if (p.structured) launch_bwd_struct(p, sa, 0, lb ? p.n_long_b : 0, p.n_items_b - (lb ? p.n_long_b : 0));
+		else launch_bwd<false>(p, sa);
+		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
+		if (ov) { // early expect over every tile once both sweeps exist
+			(void)hipEventRecord(p.evx[2], sa);
+			(void)hipStreamWaitEvent(sx, p.evx[1], 0); (void)hipStreamWaitEvent(sx, p.evx[2], 0);
+			if (p.ev[8]) (void)hipEventRecord(p.ev[8], sx);
+			launch_expect(p, sx, 0);
+			if (p.ev[9]) (void)hipEventRecord(p.ev[9], sx);
+			(void)hipEventRecord(p.evx[3], sx);
+		}
 	}
 	// ---- verify / repair rounds: each direction advances on its own stream as soon as ITS
 	// flagged-tile count is back (polled, so the faster chain never waits for the slower one)
@@ -565,7 +580,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		return 0;
 	};
 	if (lf) { (void)hipStreamWaitEvent(sm, p.evx[6], 0); launch_fwd_struct(p, sm, 3, 0, p.n_mem_f); }
-	if (lb) { (void)hipStreamWaitEvent(sa, p.evx[6], 0); launch_bwd_struct(p, sa, 3, 0, p.n_mem_b); }
+	if (p.fused) {
+		(void)hipEventRecord(p.evx[7], sm); (void)hipStreamWaitEvent(sa, p.evx[7], 0); // X of the run tiles
+		if (lb) { (void)hipStreamWaitEvent(sa, p.evx[6], 0); launch_bwd_count(p, sa, 3, 0, p.n_mem_b); }
+	} else if (lb) { (void)hipStreamWaitEvent(sa, p.evx[6], 0); launch_bwd_struct(p, sa, 3, 0, p.n_mem_b); }
 	if (post_verify(ch[0]) || post_verify(ch[1])) return -1;
 	while (!(ch[0].done && ch[1].done)) {
 		bool progressed = false;
@@ -589,7 +607,9 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 				if (p.structured) launch_fwd_struct(p, c.st, 1, 0, nd); else launch_fwd<true>(p, c.st);
 			} else {
 				rep->bwd_rounds++; rep->bwd_tiles += nd;
-				if (p.structured) launch_bwd_struct(p, c.st, 1, 0, nd); else launch_bwd<true>(p, c.st);
+				if (p.fused) launch_bwd_count(p, c.st, 1, 0, nd);
+				else if (p.structured) launch_bwd_struct(p, c.st, 1, 0, nd);
+				else launch_bwd<true>(p, c.st);
 			}
 			if (post_verify(c)) return -1;
 		}
@@ -599,7 +619,11 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
 	// ---- counts + log-likelihood from the final tables
 	hipLaunchKernelGGL(k_ll, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
-	if (ov) {
+	if (p.fused) {
+		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
+		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
+		launch_bwd_count(p, sm, 2, 0, p.n_chunks); // tiles whose X a forward repair rewrote after their counts were taken
+	} else if (ov) {
 		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // backward chain done
 		(void)hipStreamWaitEvent(sm, p.evx[3], 0);                                     // early expect done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);

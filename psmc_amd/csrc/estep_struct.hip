@@ -71,6 +71,8 @@ __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, i
 // but the last are T positions long.
 struct SweepItem { int first, count; };
 constexpr int SWEEP_WALK = 1;       // leave only the boundary vectors (entry / bentry / bexit) of the tiles walked through
+constexpr int SWEEP_TOP_ONLY = 4;   // backward: stop once the top tile's start vector (bentry) is stored: the warm-up alone
+constexpr int SWEEP_NO_TOUCH = 8;   // REPAIR kernels: do not flag the tile for the redo pass of the counts
 constexpr int SWEEP_FROM_ENTRY = 2; // REPAIR kernels: start from the boundary vector a walk left instead of the neighbour's table row
 
 // ------------------------------------------------------------------ forward
@@ -149,7 +151,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	load_struct_par(sp, k0, true, sc);
 	double x[4];
 	int p_first;
-	if (REPAIR && valid && m == 0) touch_f[it.first] = 1; // X / inv_d of this tile change
+	if (REPAIR && valid && m == 0 && !(flags & SWEEP_NO_TOUCH)) touch_f[it.first] = 1; // X / inv_d of this tile change
 	if (REPAIR && c.lo > 1) { // from the neighbour's stored X_{lo-1}, or from the boundary vector a walk left
 		if (from_entry) load4(entry + (int64_t)it.first * 64 + k0, x);
 		else load4(fo + (int64_t)(c.lo - 2) * 64, x);
@@ -285,11 +287,12 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	const int t_top = it.first + it.count - 1;
 	const Chunk c = chunks[t_top];
-	const int L = c.L, p_low = chunks[it.first].lo;
+	const int L = c.L;
 	BwdCursor cur;
 	cur.lo = c.lo; cur.top = min(c.hi, L - 1); cur.tile = t_top;
+	const int p_low = (flags & SWEEP_TOP_ONLY) ? cur.top : chunks[it.first].lo;
 	const bool valid = slot < n_items && cur.top >= cur.lo; // a tile holding only position L owns no transition
-	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
+	const bool walk = (flags & (SWEEP_WALK | SWEEP_TOP_ONLY)) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
 	cur.store = !walk;
 	const uint8_t *o = obs + c.off;
 	double *bto = bt + c.off * 64 + k0, *sbo = sb + c.off;
@@ -391,13 +394,14 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 // ------------------------------------------------------------------ launchers
 // which: 0 = the sweep items [first, first+n), 1 = flagged tiles of the current repair round,
 //        2 = walks over the glued runs [0, n) (boundary vectors only), 3 = every tile of the glued
-//        runs, recomputed from the boundary vector its walk left
+//        runs, recomputed from the boundary vector its walk left, 4 (backward) = warm-up only: leave
+//        the start vector of every item's top tile in bentry (fused backward + counts)
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
-	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? SWEEP_FROM_ENTRY : 0);
+	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | (p.fused ? SWEEP_NO_TOUCH : 0)) : 0);
 	if (which == 0 || which == 2)
 		hipLaunchKernelGGL((k_fwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, items, n_items,
 		                   p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
@@ -410,8 +414,8 @@ void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
-	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? SWEEP_FROM_ENTRY : 0);
-	if (which == 0 || which == 2)
+	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? SWEEP_FROM_ENTRY : (which == 4 ? SWEEP_TOP_ONLY : 0));
+	if (which == 0 || which == 2 || which == 4)
 		hipLaunchKernelGGL((k_bwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup,
 		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 	else

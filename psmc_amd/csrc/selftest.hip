@@ -124,6 +124,21 @@ __global__ __launch_bounds__(64) void k_selftest(unsigned *flags)
 			if (fabs(xv[i] - want) > 1e-13 * fabs(want)) bad |= 4096u;
 		}
 	}
+	{ // one-state-per-lane structured step (fused backward + counts kernel) against the same dense product
+		__shared__ double tP[64], tR[64], tq[64], tc[64], td[64];
+		tP[lane] = 0.01 + 0.003 * lane; tR[lane] = 0.02 / (1.0 + lane); tq[lane] = 0.5 + 0.01 * lane;
+		tc[lane] = 1.0 / (3.0 + 0.2 * lane); td[lane] = 0.9 - 0.002 * lane;
+		__syncthreads();
+		const WaveScanMasks wm = wave_scan_masks(lane);
+		StructPar1 c1; c1.mS = tP[lane]; c1.wS = tq[lane]; c1.mP = tR[lane]; c1.wP = tc[lane]; c1.dd = td[lane];
+		const double got = struct_step1(c1, x, wm);
+		double want = 0.0;
+		for (int k = 0; k < 64; ++k) {
+			const double akj = k > lane ? tP[k] * tq[lane] : (k < lane ? tR[k] * tc[lane] : td[lane] + tP[lane] * tq[lane] + tR[lane] * tc[lane]);
+			want += sh[k] * akj;
+		}
+		if (fabs(got - want) > 1e-13 * fabs(want)) bad |= 8192u;
+	}
 	if (bad) atomicOr(flags, bad);
 }
 

@@ -45,6 +45,34 @@ __device__ __forceinline__ double row_max16(double t) {
 	t = fmax(t, dpp_mov<0x128>(t));
 	return t;
 }
+// inclusive prefix / suffix sums over all 64 lanes (one state per lane): the row scans above plus the
+// totals of the other rows, read with v_readlane and added under per-lane 0/1 masks
+// (mlo[r] = 1 for lanes of rows > r, mhi[r] = 1 for lanes of rows < r+1 ... see wave_scan_masks)
+struct WaveScanMasks { double pre[3], suf[3]; };
+__device__ __forceinline__ WaveScanMasks wave_scan_masks(int lane) {
+	const int row = lane >> 4;
+	WaveScanMasks m;
+	m.pre[0] = row > 0 ? 1.0 : 0.0; m.pre[1] = row > 1 ? 1.0 : 0.0; m.pre[2] = row > 2 ? 1.0 : 0.0; // add total of row 0 / 1 / 2
+	m.suf[0] = row < 1 ? 1.0 : 0.0; m.suf[1] = row < 2 ? 1.0 : 0.0; m.suf[2] = row < 3 ? 1.0 : 0.0; // add total of row 1 / 2 / 3
+	return m;
+}
+__device__ __forceinline__ double wave_prefix_incl(double t, const WaveScanMasks &m) {
+	t = t + dpp_z<0x111>(t); t = t + dpp_z<0x112>(t); t = t + dpp_z<0x114>(t); t = t + dpp_z<0x118>(t);
+	const double r0 = readlane_f64(t, 15), r1 = readlane_f64(t, 31), r2 = readlane_f64(t, 47); // row totals
+	return __builtin_fma(m.pre[2], r2, __builtin_fma(m.pre[1], r1, __builtin_fma(m.pre[0], r0, t)));
+}
+__device__ __forceinline__ double wave_suffix_incl(double t, const WaveScanMasks &m) {
+	t = t + dpp_z<0x101>(t); t = t + dpp_z<0x102>(t); t = t + dpp_z<0x104>(t); t = t + dpp_z<0x108>(t);
+	const double r1 = readlane_f64(t, 16), r2 = readlane_f64(t, 32), r3 = readlane_f64(t, 48);
+	return __builtin_fma(m.suf[0], r1, __builtin_fma(m.suf[1], r2, __builtin_fma(m.suf[2], r3, t)));
+}
+// one-state-per-lane form of struct_step: x <- wS.SUF(x.mS) + wP.PRE(x.mP) + dd.x
+struct StructPar1 { double mS, wS, mP, wP, dd; };
+__device__ __forceinline__ double struct_step1(const StructPar1 &c, double x, const WaveScanMasks &m) {
+	const double SI = wave_suffix_incl(x * c.mS, m), PI = wave_prefix_incl(x * c.mP, m);
+	return __builtin_fma(c.wS, SI, __builtin_fma(c.wP, PI, c.dd * x));
+}
+
 __device__ __forceinline__ double rcp_newton(double x) {
 	double r = __builtin_amdgcn_rcp(x);
 	double t = __builtin_fma(-x, r, 1.0);

@@ -16,12 +16,13 @@ for key in ("n64_curve", "n64_flat", "n23_curve"):
     n = p["a"].shape[0]
     for segs, nm in ((g.segs_small, "small"), (g.segs_mid, "mid")):
         o = O.estep(p["a"], p["e"], p["a0"], segs)
-        for st in (1, 0):
-            for opts in (dict(), dict(chunk=256, warmup=512), dict(chunk=1024, warmup=64)):
-                es = hip.HipEStep(n, mode=hip.MODE_FAST, structured=st, **opts)
+        for st in (2, 1):
+            for opts in (dict(), dict(chunk=256, warmup=512), dict(chunk=1024, warmup=64), dict(chunk=1000, warmup=100, overlap=0)):
+                es = hip.HipEStep(n, mode=hip.MODE_FAST, structured=1, fuse=st - 1, **opts)
                 es.load_segments(segs)
                 r = es.estep(p["a"], p["e"], p["a0"])
+                r = es.estep(p["a"], p["e"], p["a0"])
                 d = es.fast_diag()
-                print(key, nm, "struct" if st else "dense ", opts, "A %.2e E %.2e LL %.2e" % (rel(r["A"], o["A"]), rel(r["E"], o["E"]), abs(r["LL"] - o["LL"]) / abs(o["LL"])),
+                print(key, nm, "fused " if st == 2 else "struct", opts, "A %.2e E %.2e LL %.2e" % (rel(r["A"], o["A"]), rel(r["E"], o["E"]), abs(r["LL"] - o["LL"]) / abs(o["LL"])),
                       "used_struct", d["structured"], "tiles", d["n_chunks"], "rounds", d["fwd_rounds"], d["bwd_rounds"], "nrep", d["fwd_tiles"], d["bwd_tiles"])
                 es.close()

@@ -288,6 +288,21 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
     es.close()
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0)])
+def test_fast_fused_backward_counts(hip, golden, oracle, opts):
+    """fuse=1: the wave that walks a tile backwards feeds bt straight into the f64 matrix cores (bt is never
+    stored).  Same tolerance, with speculation failures repaired (first call) and with learned runs (second)."""
+    p = golden.params("n64_curve")
+    o = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, fuse=1, **opts)
+    es.load_segments(golden.segs_mid)
+    for it in range(3):
+        check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+    es.select([5, 4, 5, 3, 5])
+    check_fast(es.estep(p["a"], p["e"], p["a0"]), oracle.estep(p["a"], p["e"], p["a0"], [golden.segs_mid[i] for i in (5, 4, 5, 3, 5)]))
+    es.close()
+
+
 def test_fast_learns_slow_regions(hip, golden, oracle):
     """Tiles that needed a repair are glued to their neighbour for the following E-steps of the
     context: the repair rounds disappear, the result stays inside the tolerance, and two contexts

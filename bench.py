@@ -178,15 +178,18 @@ def main():
     if rank == 0:
         # dominant KERNEL (one launch): the speculative forward / backward sweep or the expect kernel
         if mode == hip.MODE_FAST:
-            fam = "struct" if diag.get("structured") else "fast"
-            cand = {"k_fwd_%s<speculate>" % fam: kern["fwd_sweep"], "k_bwd_%s<speculate>" % fam: kern["bwd_sweep"], "k_expect_mfma": kern["expect"]}
+            if diag.get("structured"):  # both bulk sweeps are ONE launch (k_sweep_struct): 2 x (8n+9) bytes per bin
+                cand = {"k_sweep_struct": kern["fwd_sweep"], "k_expect_mfma": kern["expect"]}
+            else:
+                cand = {"k_fwd_fast<speculate>": kern["fwd_sweep"], "k_bwd_fast<speculate>": kern["bwd_sweep"], "k_expect_mfma": kern["expect"]}
         else:
             cand = {"k_fwd_exact": kern["forward"], "k_bwd_exact": kern["backward"], "k_expect_exact": kern["expect"]}
         dom = max(cand, key=lambda k: cand[k])
         dom_ms = cand[dom]
         # algorithmic HBM bytes per bin of each phase (forward writes the table and
         # the scale, the fused backward+expect reads them back; obs once per sweep)
-        alg_b = (16 * N_STATES + 17) if dom == "k_expect_mfma" else (8 * N_STATES + 9)  # counts: read X and bt (+ scales, obs)
+        # counts: read X and bt (+ scales, obs); k_sweep_struct: write X and bt (+ scales), read obs twice; one sweep: half
+        alg_b = (16 * N_STATES + 17) if dom == "k_expect_mfma" else ((16 * N_STATES + 18) if dom == "k_sweep_struct" else (8 * N_STATES + 9))
         ach = bins * alg_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         pipe = bins * BYTES_PER_BIN / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
         traffic = None

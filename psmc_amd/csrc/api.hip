@@ -26,6 +26,7 @@ struct psmc_hip_ctx {
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
 	int struct_tiles = 8192;   // "struct_tiles": tiles aimed at when the structured sweeps are used (4 per wave)
 	bool use_struct = false, planned_struct = false;
+	int walk_impl = 1;         // "walk_impl"
 	int fuse = 0;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip); off: same speed, see DESIGN.md
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
 	int group_cap = 131072;    // "group_cap": longest run of glued tiles, in bins
@@ -200,6 +201,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "max_rounds") c->max_rounds = (int)v;
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
+	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->plan_dirty = true; }
@@ -383,6 +385,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.d_re = c->d_par + 4 * 4096 + 192 + 64;
 	p.d_sp = c->d_par + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1) ? 1 : 0;
+	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
 	if (c->ns == 128) { p.d_aeT = c->d_par + 16384; p.d_e = c->d_par + 32768; p.d_a0 = c->d_par + 32768 + 384; p.d_re = nullptr; }
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;

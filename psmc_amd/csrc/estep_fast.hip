@@ -532,11 +532,18 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		launch_walks(p, sw);
 		(void)hipEventRecord(p.evx[6], sw);
 	}
-	if (p.structured) launch_fwd_struct(p, sm, 0, lf ? p.n_long_f : 0, p.n_items_f - (lf ? p.n_long_f : 0));
+	const int ff0 = lf ? p.n_long_f : 0, fb0 = lb ? p.n_long_b : 0;
+	const bool one = p.structured && !p.fused; // both bulk sweeps in one launch (k_sweep_struct)
+	if (one) {
+		if (p.ev[7]) (void)hipEventRecord(p.ev[7], sm);
+		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0);
+		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sm);
+	} else if (p.structured) launch_fwd_struct(p, sm, 0, ff0, p.n_items_f - ff0);
 	else launch_fwd<false>(p, sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	(void)hipEventRecord(p.evx[1], sm);
-	if (p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
+	if (one && ov) (void)hipStreamWaitEvent(sa, p.evx[1], 0); // the backward chain follows the same launch
+	if (!one && p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
 	if (p.fused) {
 		// Fused backward + counts (estep_fused.hip): a warm-up-only pass of the 4-tiles-per-wave sweep leaves
 		// every bulk tile's start vector (beside the forward sweep, which is HBM-bound and leaves the VALUs
@@ -549,9 +556,11 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sa);
 		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
 	} else {
-		if (p.structured) launch_bwd_struct(p, sa, 0, lb ? p.n_long_b : 0, p.n_items_b - (lb ? p.n_long_b : 0));
-		else launch_bwd<false>(p, sa);
-		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
+		if (!one) {
+			if (p.structured) launch_bwd_struct(p, sa, 0, fb0, p.n_items_b - fb0);
+			else launch_bwd<false>(p, sa);
+			if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
+		}
 		if (ov) { // early expect over every tile once both sweeps exist
 			(void)hipEventRecord(p.evx[2], sa);
 			(void)hipStreamWaitEvent(sx, p.evx[1], 0); (void)hipStreamWaitEvent(sx, p.evx[2], 0);

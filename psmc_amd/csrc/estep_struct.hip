@@ -365,6 +365,101 @@ __global__ __launch_bounds__(64) void k_walk_struct(const double *__restrict__ s
 		                       nullptr);
 }
 
+// ------------------------------------------------------------------ walks, one state per lane
+// A walk is pure latency (one run, ~50 k sequential steps), so it gets a wave of its own with one state per
+// lane: 54 instructions per step instead of 85 (struct_step1: two 64-lane scans), no LDS, symbols from
+// scalar loads fetched a group ahead.  Blocks [0, n_f) walk the forward runs, the rest the backward runs.
+__device__ __forceinline__ double walk_ev(int sym, double e0, double e1) { return sym == 0 ? e0 : (sym == 1 ? e1 : 1.0); }
+
+__global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                       const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                       const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
+                                                       int n_f, const SweepItem *__restrict__ items_b, int n_b, int W, int T,
+                                                       double *__restrict__ entry, double *__restrict__ bentry,
+                                                       double *__restrict__ bexit)
+{
+	const int lane = threadIdx.x;
+	__builtin_amdgcn_s_setprio(3);
+	const WaveScanMasks wm = wave_scan_masks(lane);
+	const double e0 = e[lane], e1 = e[64 + lane];
+	if ((int)blockIdx.x < n_f) { // ---------------- forward
+		const SweepItem it = items_f[blockIdx.x];
+		const Chunk c = chunks[it.first];
+		const int p_last = chunks[it.first + it.count - 1].hi;
+		const uint8_t *o = obs + c.off;
+		StructPar1 s1; s1.mS = sp[lane]; s1.wS = sp[128 + lane]; s1.mP = sp[64 + lane]; s1.wP = sp[192 + lane]; s1.dd = sp[256 + lane];
+		double x = a0[lane];
+		int p_first;
+		const int ws = max(1, c.lo - W);
+		if (ws == 1) { x *= walk_ev((int)o[0] & 3, e0, e1); p_first = 2; } else p_first = ws;
+		int tile = c.lo >= p_first ? it.first : it.first + 1, next_lo = c.lo >= p_first ? c.lo : c.lo + T;
+		// groups of four positions aligned to p % 4 == 1 .. 0 (indices 4g .. 4g+3): the last one normalises
+		const int g_first = (p_first - 1) >> 2, g_last = (p_last - 1) >> 2;
+		unsigned w = *reinterpret_cast<const unsigned *>(o + 4 * g_first);
+		for (int g = g_first; g <= g_last; ++g) {
+			const unsigned wn = *reinterpret_cast<const unsigned *>(o + 4 * min(g + 1, g_last)); // next group's symbols
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const int p = 4 * g + j + 1;
+				if (p < p_first || p > p_last) continue;
+				if (p == next_lo) { entry[(int64_t)tile * 64 + lane] = x; ++tile; next_lo += T; }
+				double ev = walk_ev((int)((w >> (8 * j)) & 3u), e0, e1);
+				if (j == 3) ev *= rcp_newton(first_lane_f64(wave_sum_nat(x)));
+				x = struct_step1(s1, x, wm) * ev;
+			}
+			w = wn;
+		}
+	} else { // ---------------- backward
+		const SweepItem it = items_b[blockIdx.x - n_f];
+		int tile = it.first + it.count - 1;
+		const Chunk c = chunks[tile];
+		const int L = c.L, p_low = chunks[it.first].lo;
+		int lo = c.lo, top = min(c.hi, L - 1);
+		if (top < lo) return;
+		const uint8_t *o = obs + c.off;
+		StructPar1 s1; s1.mS = sp[192 + lane]; s1.wS = sp[64 + lane]; s1.mP = sp[128 + lane]; s1.wP = sp[lane]; s1.dd = sp[256 + lane];
+		const int q = min(c.hi + W + 1, L); // B_q := 1
+		double x = walk_ev((int)o[q - 1] & 3, e0, e1);
+		const int p_first = q - 1;
+		const int g_first = (p_first - 1) >> 2, g_last = (p_low - 1) >> 2;
+		unsigned w = *reinterpret_cast<const unsigned *>(o + 4 * g_first);
+		for (int g = g_first; g >= g_last; --g) {
+			const unsigned wn = *reinterpret_cast<const unsigned *>(o + 4 * max(g - 1, g_last));
+#pragma unroll
+			for (int j = 3; j >= 0; --j) {
+				const int p = 4 * g + j + 1;
+				if (p > p_first || p < p_low) continue;
+				double ev = walk_ev((int)((w >> (8 * j)) & 3u), e0, e1);
+				if (j == 3) ev *= rcp_newton(first_lane_f64(wave_sum_nat(x)));
+				if (p == top) bentry[(int64_t)tile * 64 + lane] = x; // the boundary vector this tile builds on
+				x = struct_step1(s1, x, wm) * ev;
+				if (p == lo) { bexit[(int64_t)tile * 64 + lane] = x; --tile; top = lo - 1; lo -= T; }
+			}
+			w = wn;
+		}
+	}
+}
+
+// The bulk of both sweeps in ONE launch: even blocks walk forward items, odd blocks backward items (as long
+// as both lists last), so the two table writers share the chip from the first to the last wave and the
+// E-step needs one stream less.  Per launch: 2 x (8n+9) algorithmic bytes per bin.
+__global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                       const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                       const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
+                                                       int n_f, const SweepItem *__restrict__ items_b, int n_b, int W, int T,
+                                                       double *__restrict__ f, double *__restrict__ invd,
+                                                       double *__restrict__ entry, double *__restrict__ bt,
+                                                       double *__restrict__ sb, double *__restrict__ bentry,
+                                                       double *__restrict__ bexit)
+{
+	const int nbf = (n_f + 3) / 4, nbb = (n_b + 3) / 4, both = 2 * min(nbf, nbb), b = blockIdx.x;
+	bool fwd; int blk;
+	if (b < both) { fwd = (b & 1) == 0; blk = b >> 1; }
+	else { fwd = nbf > nbb; blk = b - both + min(nbf, nbb); }
+	if (fwd) fwd_struct_body<false>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, 0, f, invd, entry, nullptr);
+	else bwd_struct_body<false>(blk, sp, e, obs, chunks, items_b, n_b, W, T, 0, bt, sb, bentry, bexit, nullptr);
+}
+
 // ------------------------------------------------------------------ dirty-tile lists
 // deterministic compaction of the verify kernel's flags: out[0..cnt) = flagged tiles in ascending
 // order, each as a one-tile sweep item
@@ -428,8 +523,24 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
 	                   (SweepItem *)(bwd ? p.d_ritems_b : p.d_ritems_f),
 	                   (SweepItem *)(p.m_ritems ? p.m_ritems + (size_t)(bwd ? 1 : 0) * 2 * p.n_chunks : nullptr), p.m_cnt + (bwd ? 1 : 0));
 }
+// bulk of both sweeps: forward items [ff, ff+nf) and backward items [fb, fb+nb)
+void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb)
+{
+	const int nblk = (nf + 3) / 4 + (nb + 3) / 4;
+	if (nblk <= 0) return;
+	hipLaunchKernelGGL(k_sweep_struct, dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+	                   (const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len,
+	                   p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit);
+}
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {
+	if (p.walk_impl == 1) { // one wave per run, one state per lane
+		if (p.n_long_f + p.n_long_b <= 0) return;
+		hipLaunchKernelGGL(k_walk1_struct, dim3(p.n_long_f + p.n_long_b), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+		                   (const SweepItem *)p.d_items_f, p.n_long_f, (const SweepItem *)p.d_items_b, p.n_long_b, p.warmup,
+		                   p.tile_len, p.d_entry, p.d_bentry, p.d_bexit);
+		return;
+	}
 	const int nb = (p.n_long_f + 3) / 4 + (p.n_long_b + 3) / 4;
 	if (nb <= 0) return;
 	hipLaunchKernelGGL(k_walk_struct, dim3(nb), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,

@@ -104,6 +104,19 @@ __global__ __launch_bounds__(64) void k_microbench(double *out, double seed)
 		const unsigned long long w1 = wall_clock64();
 		if (lane == 0) out[16] = (double)(t1 - t0) / (double)(w1 - w0) * 100.0;
 		sink += xv[0];
+		// one-state-per-lane step (walks, fused kernel): two 64-lane scans, emission, norm every 4th step
+		const WaveScanMasks wm = wave_scan_masks(lane);
+		StructPar1 c1; c1.mS = c.mS[0]; c1.wS = c.wS[0]; c1.mP = c.mP[0]; c1.wP = c.wP[1]; c1.dd = c.dd[0];
+		double y = x;
+		t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER * 4; ++it) {
+			y = struct_step1(c1, y, wm) * m; y = struct_step1(c1, y, wm) * m; y = struct_step1(c1, y, wm) * m;
+			const double inv = rcp_newton(first_lane_f64(wave_sum_nat(y)));
+			y = struct_step1(c1, y, wm) * (m * inv);
+		}
+		t1 = __builtin_readcyclecounter();
+		if (lane == 0) out[17] = (double)(t1 - t0) / (N_ITER * 16);
+		sink += y;
 	}
 	if (sink == 123.456) out[63] = sink;
 }

@@ -138,6 +138,9 @@ __global__ __launch_bounds__(64) void k_selftest(unsigned *flags)
 			want += sh[k] * akj;
 		}
 		if (fabs(got - want) > 1e-13 * fabs(want)) bad |= 8192u;
+		double pre = 0.0;
+		for (int k = 0; k <= lane; ++k) pre += sh[k];
+		if (fabs(wave_prefix_incl(x, wm) - pre) > 1e-13 * pre || fabs(wave_prefix_incl_bc(x) - pre) > 1e-13 * pre) bad |= 16384u;
 	}
 	if (bad) atomicOr(flags, bad);
 }

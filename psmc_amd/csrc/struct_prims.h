@@ -61,6 +61,19 @@ __device__ __forceinline__ double wave_prefix_incl(double t, const WaveScanMasks
 	const double r0 = readlane_f64(t, 15), r1 = readlane_f64(t, 31), r2 = readlane_f64(t, 47); // row totals
 	return __builtin_fma(m.pre[2], r2, __builtin_fma(m.pre[1], r1, __builtin_fma(m.pre[0], r0, t)));
 }
+// the same with the gfx9 row_bcast DPP modes: lane 15 of a row into the next row (rows 1,3), then lane 31
+// into rows 2,3 -- no scalar round trip
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_zm(double v) {
+	long long s = __builtin_bit_cast(long long, v);
+	long long r = __builtin_amdgcn_update_dpp(0LL, s, CTRL, ROWMASK, 0xf, false);
+	return __builtin_bit_cast(double, r);
+}
+__device__ __forceinline__ double wave_prefix_incl_bc(double t) {
+	t = t + dpp_z<0x111>(t); t = t + dpp_z<0x112>(t); t = t + dpp_z<0x114>(t); t = t + dpp_z<0x118>(t);
+	t = t + dpp_zm<0x142, 0xA>(t); // row_bcast:15
+	t = t + dpp_zm<0x143, 0xC>(t); // row_bcast:31
+	return t;
+}
 __device__ __forceinline__ double wave_suffix_incl(double t, const WaveScanMasks &m) {
 	t = t + dpp_z<0x101>(t); t = t + dpp_z<0x102>(t); t = t + dpp_z<0x104>(t); t = t + dpp_z<0x108>(t);
 	const double r1 = readlane_f64(t, 16), r2 = readlane_f64(t, 32), r3 = readlane_f64(t, 48);
@@ -69,7 +82,7 @@ __device__ __forceinline__ double wave_suffix_incl(double t, const WaveScanMasks
 // one-state-per-lane form of struct_step: x <- wS.SUF(x.mS) + wP.PRE(x.mP) + dd.x
 struct StructPar1 { double mS, wS, mP, wP, dd; };
 __device__ __forceinline__ double struct_step1(const StructPar1 &c, double x, const WaveScanMasks &m) {
-	const double SI = wave_suffix_incl(x * c.mS, m), PI = wave_prefix_incl(x * c.mP, m);
+	const double SI = wave_suffix_incl(x * c.mS, m), PI = wave_prefix_incl_bc(x * c.mP);
 	return __builtin_fma(c.wS, SI, __builtin_fma(c.wP, PI, c.dd * x));
 }
 

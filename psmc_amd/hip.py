@@ -247,7 +247,8 @@ MICROBENCH_NAMES = ["fmac_dpp dependent", "v_fma_f64 dependent", "v_add_f64 depe
                     "dpp_mov+add dependent", "v_rcp_f64 dependent", "mov_b64_dpp+mul dependent",
                     "v_mul_f64 8 indep (per op)", "f64 division dependent", "mfma_f64_16x16x4 dependent",
                     "mfma_f64_16x16x4 4 accumulators (per op)", "structured step dependent (per step)",
-                    "structured step + emission + norm/4 (per step)", "cycle counter MHz (vs 100 MHz wall clock)"]
+                    "structured step + emission + norm/4 (per step)", "cycle counter MHz (vs 100 MHz wall clock)",
+                    "one-state-per-lane structured step + emission + norm/4 (per step)"]
 
 
 def microbench(device=0):

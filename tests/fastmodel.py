@@ -164,3 +164,38 @@ def estep_fast_model(a, e, a0, segs, T=4096, W=2048, tol=None, stats=None):
     if stats is not None:
         stats.update(work)
     return dict(A=A, E=E[:2].copy(), LL=LL)
+
+
+# ---------------------------------------------------------------------------------------------
+# Structured O(N) sweeps (psmc_amd/csrc/estep_struct.hip, api.hip factor_structure): numpy mirror.
+def factor_structure(a, ulps=64):
+    """a[k][l] = P_k qa_l (l<k), R_k c_l (l>k) with qa_0 = c_{n-1} = 1, dd = diag - P.qa - R.c >= 0,
+    every off-diagonal entry checked to `ulps`; returns None when the matrix does not have the form
+    (lh3/psmc core.c:112-122 builds it this way; psmc_cap_matrix, aux.c:115-127, destroys it)."""
+    a = np.asarray(a, dtype=np.float64)
+    n = a.shape[0]
+    if n < 3 or not (a[n - 1, 0] > 1e-280 and a[0, n - 1] > 1e-280):
+        return None
+    P = np.zeros(n); R = np.zeros(n); qa = np.zeros(n); c = np.zeros(n)
+    qa[:n - 1] = a[n - 1, :n - 1] / a[n - 1, 0]
+    P[1:] = a[1:, 0]
+    c[1:] = a[0, 1:] / a[0, n - 1]
+    R[:n - 1] = a[:n - 1, n - 1]
+    w = np.where(np.tri(n, k=-1, dtype=bool), np.outer(P, qa), np.outer(R, c))
+    off = ~np.eye(n, dtype=bool)
+    if not np.all(np.abs(a - w)[off] <= ulps * 2.220446049250313e-16 * np.abs(a)[off] + 1e-290):
+        return None
+    dd = np.diag(a) - P * qa - R * c
+    if not np.all(dd >= 0):
+        return None
+    return dict(P=P, R=R, qa=qa, c=c, dd=dd)
+
+
+def struct_step_forward(f, x):
+    """(a^T x)_j = qa_j SUF_j(x.P) + c_j PRE_j(x.R) + dd_j x_j, inclusive suffix / prefix sums."""
+    return f["qa"] * np.cumsum((x * f["P"])[::-1])[::-1] + f["c"] * np.cumsum(x * f["R"]) + f["dd"] * x
+
+
+def struct_step_backward(f, z):
+    """(a z)_k = R_k SUF_k(z.c) + P_k PRE_k(z.qa) + dd_k z_k."""
+    return f["R"] * np.cumsum((z * f["c"])[::-1])[::-1] + f["P"] * np.cumsum(z * f["qa"]) + f["dd"] * z

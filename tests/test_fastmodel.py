@@ -52,3 +52,22 @@ def test_no_overlap_with_repair(golden, oracle):
     ref = oracle.estep(p["a"], p["e"], p["a0"], segs)
     m = fastmodel.estep_fast_model(p["a"], p["e"], p["a0"], segs, T=500, W=0, tol=1e-12)
     assert relmax(m["A"], ref["A"]) < 1e-11 and relmax(m["E"], ref["E"]) < 1e-11
+
+
+def test_structured_factorisation(golden):
+    """The O(N) sweeps rest on a[k][l] = P_k qa_l below and R_k c_l above the diagonal (core.c:112-122):
+    every golden transition matrix factors to 64 ulp with dd >= 0, the two-scan step equals the dense
+    product, and a capped matrix (aux.c:115-127) or a generic one is rejected (dense fallback)."""
+    rng = np.random.default_rng(3)
+    for key in golden.param_keys() + ["n128"]:
+        a = golden.n128["n128_curve.a"] if key == "n128" else golden.params(key)["a"]
+        f = fastmodel.factor_structure(a)
+        assert f is not None, key
+        x = rng.random(a.shape[0]) ** 3
+        assert relmax(fastmodel.struct_step_forward(f, x), a.T @ x) < 1e-13
+        assert relmax(fastmodel.struct_step_backward(f, x), a @ x) < 1e-13
+    a = golden.params("n64_curve")["a"].copy()
+    a[:, 40] = a[:, 40:].sum(1); a[:, 41:] = 0.0
+    assert fastmodel.factor_structure(a) is None
+    b = rng.random((64, 64)); b /= b.sum(1, keepdims=True)
+    assert fastmodel.factor_structure(b) is None

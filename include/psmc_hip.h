@@ -11,7 +11,8 @@
  * reference code it replaces.  Plain C types only; every function returns 0 or
  * a negative PSMC_HIP_E* code, never aborts, never prints.
  *
- * Conventions: n = number of hidden states (psmc's n+1; <= 128 in exact mode, <= 64 in fast mode);
+ * Conventions: n = number of hidden states (psmc's n+1; <= 128; fast mode beyond 64 needs a
+ * matrix of the PSMC form, i.e. the structured sweeps);
  * row-major FP64; a[k*n+l]=P(k->l) (khmm.h:34); e[b*n+k], b=0 hom / 1 het
  * (khmm.h:34; the missing-data row e[2][*]=1 of khmm.c:21 is implied);
  * a0[k] (khmm.h:36); observations are bytes 0/1/2 exactly as psmc_read_seq
@@ -31,7 +32,7 @@ extern "C" {
 #define PSMC_HIP_EINVAL   -1 /* bad argument (NULL, n out of range, empty segment ...) */
 #define PSMC_HIP_ENOMEM   -2 /* host or device allocation failed */
 #define PSMC_HIP_EDEVICE  -3 /* HIP runtime error; see psmc_hip_last_error() */
-#define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (n > 128, or n > 64 in fast mode) */
+#define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (n > 128; fast mode, n > 64, generic matrix) */
 #define PSMC_HIP_ESTATE   -5 /* call order violated (no segments loaded ...) */
 #define PSMC_HIP_ECONVERGE -6 /* fast mode: tile boundaries did not converge within max_rounds */
 

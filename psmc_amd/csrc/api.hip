@@ -56,7 +56,8 @@ struct psmc_hip_ctx {
 	bool plan_dirty = true;
 	// parameters
 	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0 | re(3)
-	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128; // ns=64: ... | re(3) | sp(5) (17152); ns=128: a | aT | e(3) | a0
+	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128 + 3 * 128 + 5 * 128; // ns=64: ... | re(3) | sp(5) (17152); ns=128: a | aT | e(3) | a0 | re(3) | sp(5)
+	static constexpr size_t RE128_OFF = 2 * 16384 + 3 * 128 + 128, SP128_OFF = RE128_OFF + 3 * 128;
 	static constexpr size_t SP_OFF = 4 * 4096 + 192 + 64 + 192; // structured vectors P | R | qa | c | dd
 	// tables
 	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr, *d_sb = nullptr;
@@ -143,7 +144,7 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	*out = nullptr;
 	if (n_states < 1) return PSMC_HIP_EINVAL;
 	if (mode != PSMC_HIP_MODE_EXACT && mode != PSMC_HIP_MODE_FAST) return PSMC_HIP_EINVAL;
-	if (n_states > 128 || (n_states > NS && mode == PSMC_HIP_MODE_FAST)) return PSMC_HIP_ENOTSUP; // fast mode: one lane per state
+	if (n_states > 128) return PSMC_HIP_ENOTSUP; // fast mode beyond 64 states: structured matrices only (checked per E-step)
 	int nd = psmc_hip_device_count();
 	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
 	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
@@ -296,25 +297,25 @@ extern "C" int psmc_hip_select(psmc_hip_ctx *c, int n_sel, const int32_t *idx)
 // Does a[][] have the PSMC form  a[k][l] = P_k qa_l (l<k),  R_k c_l (l>k)  (core.c:112-122)?
 // Numerical factorisation with qa_0 = c_{n-1} = 1, then a check of EVERY off-diagonal entry to
 // 64 ulp and of dd = diag - P.qa - R.c >= 0.  sp = P | R | qa | c | dd (64 each, zero padded).
-static bool factor_structure(int n, const double *a /* stride 64 */, double *sp)
+static bool factor_structure(int n, int S, const double *a /* stride S */, double *sp /* 5 * S */)
 {
-	double *P = sp, *R = sp + 64, *qa = sp + 128, *cc = sp + 192, *dd = sp + 256;
-	memset(sp, 0, 5 * 64 * sizeof(double));
+	double *P = sp, *R = sp + S, *qa = sp + 2 * S, *cc = sp + 3 * S, *dd = sp + 4 * S;
+	memset(sp, 0, 5 * (size_t)S * sizeof(double));
 	if (n < 3) return false;
-	const double pl = a[(n - 1) * 64 + 0], pu = a[0 * 64 + (n - 1)];
+	const double pl = a[(n - 1) * S + 0], pu = a[0 * S + (n - 1)];
 	if (!(pl > 1e-280) || !(pu > 1e-280)) return false;
-	for (int l = 0; l < n - 1; ++l) qa[l] = a[(n - 1) * 64 + l] / pl;
-	for (int k = 1; k < n; ++k) P[k] = a[k * 64 + 0];
-	for (int l = 1; l < n; ++l) cc[l] = a[0 * 64 + l] / pu;
-	for (int k = 0; k < n - 1; ++k) R[k] = a[k * 64 + (n - 1)];
+	for (int l = 0; l < n - 1; ++l) qa[l] = a[(n - 1) * S + l] / pl;
+	for (int k = 1; k < n; ++k) P[k] = a[k * S + 0];
+	for (int l = 1; l < n; ++l) cc[l] = a[0 * S + l] / pu;
+	for (int k = 0; k < n - 1; ++k) R[k] = a[k * S + (n - 1)];
 	const double tol = 64 * 2.220446049250313e-16;
 	for (int k = 0; k < n; ++k) {
 		for (int l = 0; l < n; ++l) {
 			if (l == k) continue;
-			const double v = a[k * 64 + l], w = l < k ? P[k] * qa[l] : R[k] * cc[l];
+			const double v = a[k * S + l], w = l < k ? P[k] * qa[l] : R[k] * cc[l];
 			if (!(fabs(v - w) <= tol * fabs(v) + 1e-290)) return false;
 		}
-		dd[k] = a[k * 64 + k] - P[k] * qa[k] - R[k] * cc[k];
+		dd[k] = a[k * S + k] - P[k] * qa[k] - R[k] * cc[k];
 		if (!(dd[k] >= 0.0)) return false;
 	}
 	return true;
@@ -335,6 +336,11 @@ static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const
 			pa0[k] = a0[k];
 		}
 		for (int k = 0; k < 128; ++k) pe[256 + k] = 1.0; // khmm.c:21
+		if (c->mode == PSMC_HIP_MODE_FAST) {
+			double *pre = pa + psmc_hip_ctx::RE128_OFF;
+			for (int i = 0; i < 384; ++i) pre[i] = pe[i] > 0.0 ? 1.0 / pe[i] : 0.0;
+			c->use_struct = c->struct_opt && factor_structure(n, 128, pa, pa + psmc_hip_ctx::SP128_OFF);
+		}
 		HIPCHK(c, hipMemcpyAsync(c->d_par, pa, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
 		return 0;
 	}
@@ -351,7 +357,7 @@ static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const
 	for (int b = 0; b < 3; ++b)
 		for (int l = 0; l < 64; ++l)
 			for (int k = 0; k < 64; ++k) pae[b * 4096 + l * 64 + k] = pe[b * 64 + l] * pa[k * 64 + l];
-	c->use_struct = c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, pa, pa + psmc_hip_ctx::SP_OFF);
+	c->use_struct = c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, 64, pa, pa + psmc_hip_ctx::SP_OFF);
 	HIPCHK(c, hipMemcpyAsync(c->d_par, pa, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
 	return 0;
 }
@@ -384,10 +390,13 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
 	p.d_re = c->d_par + 4 * 4096 + 192 + 64;
 	p.d_sp = c->d_par + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
-	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1) ? 1 : 0;
+	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
 	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
-	if (c->ns == 128) { p.d_aeT = c->d_par + 16384; p.d_e = c->d_par + 32768; p.d_a0 = c->d_par + 32768 + 384; p.d_re = nullptr; }
+	if (c->ns == 128) {
+		p.d_aeT = c->d_par + 16384; p.d_e = c->d_par + 32768; p.d_a0 = c->d_par + 32768 + 384;
+		p.d_re = c->d_par + psmc_hip_ctx::RE128_OFF; p.d_sp = c->d_par + psmc_hip_ctx::SP128_OFF;
+	}
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
 	p.d_f = c->d_f; p.d_b = c->d_b; p.d_s = c->d_s; p.d_sb = c->d_sb;
@@ -545,15 +554,15 @@ static int plan_fast(psmc_hip_ctx *c)
 	c->chunk_used = T;
 	c->planned_struct = st;
 	// the counts kernel splits a tile over n_sub waves: keep about the same number of partial blocks
-	c->n_sub_used = st ? (c->fuse && c->expect_impl == 1 ? 1 : std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1)))) : c->n_sub;
+	c->n_sub_used = st ? (c->fuse && c->expect_impl == 1 && c->ns == 64 ? 1 : std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1)))) : c->n_sub;
 	c->glue_f.assign(nc, 0); c->glue_b.assign(nc, 0); // a new tiling forgets what was learned
 	c->items_dirty = true;
 	int rc;
 	if (nc > c->chunk_cap) {
 		if ((rc = dev_alloc(c, &c->d_chunks, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_entry, (size_t)nc * 64))) return rc;
-		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)(nc + 1) * 64))) return rc;
-		if ((rc = dev_alloc(c, &c->d_bentry, (size_t)nc * 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_entry, (size_t)nc * c->ns))) return rc;
+		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)(nc + 1) * c->ns))) return rc;
+		if ((rc = dev_alloc(c, &c->d_bentry, (size_t)nc * c->ns))) return rc;
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
@@ -564,11 +573,12 @@ static int plan_fast(psmc_hip_ctx *c)
 			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
 		c->chunk_cap = nc;
 	}
-	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub_used * 4096))) return rc;
-	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub_used * 192))) return rc;
+	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub_used * c->ns * c->ns))) return rc;
+	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub_used * 3 * c->ns))) return rc;
 	if (!c->d_stage) {
-		if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * STATS_LEN))) return rc;
-		if ((rc = dev_alloc(c, &c->d_stats, (size_t)STATS_LEN))) return rc;
+		const size_t sl = (size_t)c->ns * c->ns + 3 * (size_t)c->ns + 1;
+		if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * sl))) return rc;
+		if ((rc = dev_alloc(c, &c->d_stats, sl))) return rc;
 		if ((rc = dev_alloc(c, &c->d_warm, (size_t)2))) return rc;
 		if ((rc = dev_alloc(c, &c->d_cnt, (size_t)4))) return rc;
 		if (hipHostMalloc((void **)&c->h_cnt, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
@@ -649,6 +659,8 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	int rc;
 	if ((rc = ensure_tables(c, true))) return rc;
 	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
+	if (c->ns == 128 && !c->use_struct)
+		return fail(c, PSMC_HIP_ENOTSUP, "fast mode beyond 64 states needs a transition matrix of the PSMC form (structured sweeps)");
 	if ((c->plan_dirty || c->planned_struct != c->use_struct) && (rc = plan_fast(c))) return rc;
 	EstepLaunch p;
 	fill_common(c, p, st);

@@ -210,7 +210,20 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 // ------------------------------------------------------------------ verify
 // flags tiles whose boundary vector disagrees with the neighbour's converged
 // one; cnt[0] = number flagged, warm[which] = largest mismatch seen this round
-template <bool BWD>
+// max_k |x-y| / max_k |y| over S = 64 or 128 states (lane and lane + 64)
+template <int S> __device__ __forceinline__ double rel_mismatch_vec(const double *x, const double *y, int lane) {
+	double xv = x[lane], yv = y[lane];
+	double num = fabs(xv - yv), den = fabs(yv);
+	bool bad = (xv != xv) || (yv != yv);
+	if (S == 128) {
+		xv = x[64 + lane]; yv = y[64 + lane];
+		num = fmax(num, fabs(xv - yv)); den = fmax(den, fabs(yv));
+		bad = bad || (xv != xv) || (yv != yv);
+	}
+	num = wave_max(num); den = wave_max(den);
+	return __any(bad) ? __builtin_inf() : num / den;
+}
+template <bool BWD, int S>
 __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks, int n_chunks, double tol,
                                                  const double *__restrict__ f, const double *__restrict__ mine,
                                                  const double *__restrict__ bexit, int *__restrict__ dirty,
@@ -222,10 +235,10 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 	bool check;
 	if (!BWD) {
 		check = c.lo > 1 && !(c.flags & CHUNK_ANCHOR_F);
-		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], f[(c.off + c.lo - 2) * 64 + lane]);
+		if (check) m = rel_mismatch_vec<S>(mine + (int64_t)b * S, f + (c.off + c.lo - 2) * S, lane);
 	} else {
 		check = !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST)) && min(c.hi, c.L - 1) >= c.lo && b + 1 < n_chunks;
-		if (check) m = rel_mismatch(mine[(int64_t)b * 64 + lane], bexit[(int64_t)(b + 1) * 64 + lane]);
+		if (check) m = rel_mismatch_vec<S>(mine + (int64_t)b * S, bexit + (int64_t)(b + 1) * S, lane);
 	}
 	if (lane == 0) {
 		const int bad = check && !(m <= tol);
@@ -254,54 +267,63 @@ __device__ __forceinline__ bool tile_touched(const Chunk *__restrict__ chunks, i
 //   A[i][t] = (sb/G)_{p+t} X_{p+t}[16m+i]  (lane = 16t+i),  B[t][j] = bt_{p+t+1}[16n+j] (lane = 16t+j)
 //   D[(lane>>4)+4r][lane&15] = acc[r]
 // so row group t of the wave holds position p+t and G is a 16-lane (one DPP row) reduction.
-__global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
+// S = 128 (the fast path of -p "64*2"): C is cut into (S/64)^2 quadrants of 64x64, one wave each; every
+// wave still reduces G over all S states.  blockIdx.x = partial * (S/64)^2 + quadrant.
+template <int S>
+__global__ __launch_bounds__(64, S == 64 ? 2 : 1) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
                                                          const uint8_t *__restrict__ obs, const double *__restrict__ f,
                                                          const double *__restrict__ bt, const double *__restrict__ sb,
                                                          const double *__restrict__ re, double *__restrict__ Cpart,
                                                          double *__restrict__ Spart, const int *__restrict__ touch_f,
                                                          const int *__restrict__ touch_b, int redo)
 {
+	constexpr int Q = S / 64, NB = S / 16;
 	const int lane = threadIdx.x, t = lane >> 4, i = lane & 15;
-	const Chunk c = chunks[blockIdx.x / n_sub];
-	if (redo && !tile_touched(chunks, blockIdx.x / n_sub, touch_f, touch_b)) return;
-	const int sub = blockIdx.x % n_sub;
+	const int part = blockIdx.x / (Q * Q), quad = blockIdx.x % (Q * Q), qm = quad / Q, qn = quad % Q;
+	const Chunk c = chunks[part / n_sub];
+	if (redo && !tile_touched(chunks, part / n_sub, touch_f, touch_b)) return;
+	const int sub = part % n_sub;
 	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
 	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
 	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64 + i, *bo = bt + c.off * 64 + i, *sbo = sb + c.off;
+	const double *fo = f + c.off * S + i, *bo = bt + c.off * S + i, *sbo = sb + c.off;
 	const uint8_t *o = obs + c.off;
-	double re0[4], re1[4]; // 1/e[b][16m+i]
+	double re0[NB], re1[NB]; // 1/e[b][16m+i]
 #pragma unroll
-	for (int m = 0; m < 4; ++m) { re0[m] = re[16 * m + i]; re1[m] = re[64 + 16 * m + i]; }
+	for (int m = 0; m < NB; ++m) { re0[m] = re[16 * m + i]; re1[m] = re[S + 16 * m + i]; }
 	d4_t acc[4][4];
-	double S[3][4];
+	double Sacc[3][4];
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
 #pragma unroll
 		for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (d4_t){0.0, 0.0, 0.0, 0.0};
-		S[0][m] = S[1][m] = S[2][m] = 0.0;
+		Sacc[0][m] = Sacc[1][m] = Sacc[2][m] = 0.0;
 	}
-	auto load = [&](int p, double (&FA)[4], double (&BM)[4], double (&BP)[4], double &sc, int &sym, bool &ok) {
+	auto load = [&](int p, double (&FA)[NB], double (&BM)[4], double (&BP)[NB], double &sc, int &sym, bool &ok) {
 		const int pp = p + t;
 		ok = pp <= p1;
 		const int64_t idx = (int64_t)(ok ? pp : p1) - 1;
-		const double *fr = fo + idx * 64, *br = bo + idx * 64;
+		const double *fr = fo + idx * S, *br = bo + idx * S;
 #pragma unroll
-		for (int m = 0; m < 4; ++m) { FA[m] = fr[16 * m]; BP[m] = br[16 * m]; BM[m] = br[64 + 16 * m]; }
+		for (int m = 0; m < NB; ++m) { FA[m] = fr[16 * m]; BP[m] = br[16 * m]; }
+#pragma unroll
+		for (int m = 0; m < 4; ++m) BM[m] = br[S + 64 * qn + 16 * m];
 		sc = 1.0; // sb_p at the normalising positions, 1 elsewhere
 		if (((int)(idx + 1) & (NORM_EVERY - 1)) == 0) sc = sbo[idx];
 		sym = o[idx];
 	};
 	if (p0 <= p1) {
-		double FA[4], BM[4], BP[4], sc; int sym; bool ok;
+		double FA[NB], BM[4], BP[NB], sc; int sym; bool ok;
 		load(p0, FA, BM, BP, sc, sym, ok);
 		for (int p = p0; p <= p1; p += 4) {
-			double FN[4] = {0, 0, 0, 0}, BN[4] = {0, 0, 0, 0}, BQ[4] = {0, 0, 0, 0}, scn = 1.0; int symn = 2; bool okn = false;
-			if (p + 4 <= p1) load(p + 4, FN, BN, BQ, scn, symn, okn);
-			// per-position normaliser: row group t reduces its own position over the 64 states
-			double g[4], G = 0.0;
+			double FN[NB], BN[4] = {0, 0, 0, 0}, BQ[NB], scn = 1.0; int symn = 2; bool okn = false;
 #pragma unroll
-			for (int m = 0; m < 4; ++m) {
+			for (int m = 0; m < NB; ++m) { FN[m] = 0.0; BQ[m] = 0.0; }
+			if (p + 4 <= p1) load(p + 4, FN, BN, BQ, scn, symn, okn);
+			// per-position normaliser: row group t reduces its own position over the S states
+			double g[NB], G = 0.0;
+#pragma unroll
+			for (int m = 0; m < NB; ++m) {
 				const double r = sym == 0 ? re0[m] : (sym == 1 ? re1[m] : 1.0);
 				g[m] = FA[m] * BP[m] * r;
 				G += g[m];
@@ -312,41 +334,47 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 			G = G + dpp_mov<0x128>(G); // row_ror:8
 			const double iG = ok ? 1.0 / G : 0.0; // padded rows of the last group contribute nothing
 			const double w0 = sym == 0 ? iG : 0.0, w1 = sym == 1 ? iG : 0.0, w2 = sym == 2 ? iG : 0.0, wa = sc * iG;
+			double FM[4];
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
-				S[0][m] = __builtin_fma(g[m], w0, S[0][m]);
-				S[1][m] = __builtin_fma(g[m], w1, S[1][m]);
-				S[2][m] = __builtin_fma(g[m], w2, S[2][m]);
-				FA[m] *= wa;
+				const double gm = g[4 * qm + m];
+				Sacc[0][m] = __builtin_fma(gm, w0, Sacc[0][m]);
+				Sacc[1][m] = __builtin_fma(gm, w1, Sacc[1][m]);
+				Sacc[2][m] = __builtin_fma(gm, w2, Sacc[2][m]);
+				FM[m] = FA[4 * qm + m] * wa;
 			}
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
 #pragma unroll
 				for (int nn = 0; nn < 4; ++nn)
-					acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[m], BM[nn], acc[m][nn], 0, 0, 0);
+					acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(FM[m], BM[nn], acc[m][nn], 0, 0, 0);
 #pragma unroll
-			for (int m = 0; m < 4; ++m) { FA[m] = FN[m]; BM[m] = BN[m]; BP[m] = BQ[m]; }
+			for (int m = 0; m < NB; ++m) { FA[m] = FN[m]; BP[m] = BQ[m]; }
+#pragma unroll
+			for (int m = 0; m < 4; ++m) BM[m] = BN[m];
 			sc = scn; sym = symn; ok = okn;
 		}
 	}
 	const double mult = (double)c.mult;
-	double *out = Cpart + (int64_t)blockIdx.x * 4096;
+	double *out = Cpart + (int64_t)part * (S * S) + (int64_t)(64 * qm) * S + 64 * qn;
 #pragma unroll
 	for (int m = 0; m < 4; ++m)
 #pragma unroll
 		for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-			for (int r = 0; r < 4; ++r) out[(16 * m + t + 4 * r) * 64 + 16 * nn + i] = acc[m][nn][r] * mult;
-	double *os = Spart + (int64_t)blockIdx.x * 192;
+			for (int r = 0; r < 4; ++r) out[(16 * m + t + 4 * r) * S + 16 * nn + i] = acc[m][nn][r] * mult;
+	if (qn == 0) {
+		double *os = Spart + (int64_t)part * (3 * S) + 64 * qm;
 #pragma unroll
-	for (int b = 0; b < 3; ++b)
+		for (int b = 0; b < 3; ++b)
 #pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			double v = S[b][m];
-			v += __shfl_xor(v, 16, 64);
-			v += __shfl_xor(v, 32, 64);
-			if (t == 0) os[b * 64 + 16 * m + i] = v * mult;
-		}
+			for (int m = 0; m < 4; ++m) {
+				double v = Sacc[b][m];
+				v += __shfl_xor(v, 16, 64);
+				v += __shfl_xor(v, 32, 64);
+				if (t == 0) os[b * S + 16 * m + i] = v * mult;
+			}
+	}
 }
 
 // VALU cross-check of the above: lane = k, 64 accumulators C[k][0..63] per lane.
@@ -399,6 +427,7 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 // ------------------------------------------------------------------ log-likelihood
 // LL of a tile = sum over its normalising positions of log d_p = -log inv_d  (+ log sum(X_L)
 // for the last tile): running products flushed through log() like hmm_lk (khmm.c:245-260).
+template <int S>
 __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, const double *__restrict__ f,
                                              const double *__restrict__ invd, double *__restrict__ LLpart)
 {
@@ -413,47 +442,58 @@ __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, con
 	}
 	ll -= log(prod);
 	ll = wave_add(ll);
-	if (c.hi == c.L) ll += log(wave_add(f[(c.off + c.L - 1) * 64 + lane]));
+	if (c.hi == c.L) {
+		double v = f[(c.off + c.L - 1) * S + lane];
+		if (S == 128) v += f[(c.off + c.L - 1) * S + 64 + lane];
+		ll += log(wave_add(v));
+	}
 	if (lane == 0) LLpart[blockIdx.x] = ll * (double)c.mult;
 }
 
 // ------------------------------------------------------------------ reduce
 // Fixed-order two-stage reduction of the per-wave partials (deterministic).
+template <int S>
 __global__ __launch_bounds__(256) void k_reduce1(const double *__restrict__ Cpart, const double *__restrict__ Spart,
                                                    int nC, const double *__restrict__ LLpart, int nchunks,
                                                    double *__restrict__ stage)
 {
+	constexpr int SL = S * S + 3 * S + 1; // C | S-counts | LL of one stage row
 	const int y = blockIdx.y, tid = threadIdx.x;
-	double *st = stage + (int64_t)y * STATS_LEN;
-	if (blockIdx.x < 16) {
+	double *st = stage + (int64_t)y * SL;
+	if ((int)blockIdx.x < S * S / 256) {
 		const int i = blockIdx.x * 256 + tid;
 		double s = 0.0;
-		for (int j = y; j < nC; j += RED_ROWS) s += Cpart[(int64_t)j * 4096 + i];
+		for (int j = y; j < nC; j += RED_ROWS) s += Cpart[(int64_t)j * (S * S) + i];
 		st[i] = s;
-	} else if (tid < 192) {
-		double s = 0.0;
-		for (int j = y; j < nC; j += RED_ROWS) s += Spart[(int64_t)j * 192 + tid];
-		st[4096 + tid] = s;
-	} else if (tid == 192) {
-		double s = 0.0;
-		for (int j = y; j < nchunks; j += RED_ROWS) s += LLpart[j];
-		st[4096 + 192] = s;
+	} else {
+		for (int i = tid; i < 3 * S; i += 256) {
+			double s = 0.0;
+			for (int j = y; j < nC; j += RED_ROWS) s += Spart[(int64_t)j * (3 * S) + i];
+			st[S * S + i] = s;
+		}
+		if (tid == 255) {
+			double s = 0.0;
+			for (int j = y; j < nchunks; j += RED_ROWS) s += LLpart[j];
+			st[S * S + 3 * S] = s;
+		}
 	}
 }
 // Writes the final statistics UNPADDED: out = [A n*n | E 2*n | LL].
+template <int S>
 __global__ __launch_bounds__(256) void k_reduce2(const double *__restrict__ stage, const double *__restrict__ a,
                                                    const double *__restrict__ e, double tiny_total, int n,
                                                    double *__restrict__ out)
 {
+	constexpr int SL = S * S + 3 * S + 1;
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= STATS_LEN) return;
+	if (i >= SL) return;
 	double s = 0.0;
-	for (int y = 0; y < RED_ROWS; ++y) s += stage[(int64_t)y * STATS_LEN + i];
-	if (i < 4096) { // A = a .* C + n_seg*HMM_TINY (khmm.c:305-306,316)
-		const int k = i >> 6, l = i & 63;
+	for (int y = 0; y < RED_ROWS; ++y) s += stage[(int64_t)y * SL + i];
+	if (i < S * S) { // A = a .* C + n_seg*HMM_TINY (khmm.c:305-306,316)
+		const int k = i / S, l = i % S;
 		if (k < n && l < n) out[k * n + l] = a[i] * s + tiny_total;
-	} else if (i < 4096 + 192) { // E + n_seg*HMM_TINY; the missing-symbol row is dropped (khmm.c:355)
-		const int b = (i - 4096) >> 6, k = (i - 4096) & 63;
+	} else if (i < S * S + 3 * S) { // E + n_seg*HMM_TINY; the missing-symbol row is dropped (khmm.c:355)
+		const int b = (i - S * S) / S, k = (i - S * S) % S;
 		if (b < 2 && k < n) out[n * n + b * n + k] = s + tiny_total;
 	} else {
 		out[n * n + 2 * n] = s;
@@ -491,8 +531,14 @@ static void launch_expect(const EstepLaunch &p, hipStream_t st, int redo)
 		hipLaunchKernelGGL(k_expect_valu, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,
 		                   p.d_re, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
 	else
-		hipLaunchKernelGGL(k_expect_mfma, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,
-		                   p.d_re, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
+	{
+		if (p.ns == 128)
+			hipLaunchKernelGGL(k_expect_mfma<128>, dim3(nC * 4), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,
+			                   p.d_re, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
+		else
+			hipLaunchKernelGGL(k_expect_mfma<64>, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,
+			                   p.d_re, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
+	}
 }
 
 // One fast-mode E-step.  The forward and the backward sweep do not depend on each other, so
@@ -577,12 +623,11 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	auto post_verify = [&](Chain &c) -> int {
 		(void)hipMemsetAsync(p.d_cnt + c.slot, 0, sizeof(int), c.st);
 		(void)hipMemsetAsync(p.d_warm + c.slot, 0, sizeof(unsigned long long), c.st);
-		if (!c.bwd)
-			hipLaunchKernelGGL((k_verify<false>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_entry, p.d_bexit,
-			                   p.d_dirty, p.d_cnt, p.d_warm);
-		else
-			hipLaunchKernelGGL((k_verify<true>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, p.d_bentry, p.d_bexit,
-			                   p.d_dirty_b, p.d_cnt + 1, p.d_warm);
+#define PSMC_LV(BW, S, MINE, DIRTY, CNT) hipLaunchKernelGGL((k_verify<BW, S>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, \
+			MINE, p.d_bexit, DIRTY, CNT, p.d_warm)
+		if (!c.bwd) { if (p.ns == 128) PSMC_LV(false, 128, p.d_entry, p.d_dirty, p.d_cnt); else PSMC_LV(false, 64, p.d_entry, p.d_dirty, p.d_cnt); }
+		else { if (p.ns == 128) PSMC_LV(true, 128, p.d_bentry, p.d_dirty_b, p.d_cnt + 1); else PSMC_LV(true, 64, p.d_bentry, p.d_dirty_b, p.d_cnt + 1); }
+#undef PSMC_LV
 		launch_compact(p, c.st, c.bwd); // flagged tiles in ascending order + their number, straight into host-mapped memory
 		if (hipEventRecord(c.rb, c.st) != hipSuccess) return -1;
 		c.pending = true;
@@ -627,7 +672,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (hipStreamSynchronize(sm) != hipSuccess) return -1;
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
 	// ---- counts + log-likelihood from the final tables
-	hipLaunchKernelGGL(k_ll, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
+	if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
+	else hipLaunchKernelGGL(k_ll<64>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
 	if (p.fused) {
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
@@ -645,10 +691,17 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
 	const int nC = p.n_chunks * p.n_sub;
-	hipLaunchKernelGGL(k_reduce1, dim3(17, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
-	                   p.n_chunks, p.d_stage);
-	hipLaunchKernelGGL(k_reduce2, dim3((STATS_LEN + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
-	                   p.tiny_total, p.n_states, p.d_stats);
+	if (p.ns == 128) {
+		hipLaunchKernelGGL(k_reduce1<128>, dim3(128 * 128 / 256 + 1, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
+		                   p.n_chunks, p.d_stage);
+		hipLaunchKernelGGL(k_reduce2<128>, dim3((128 * 128 + 3 * 128 + 1 + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
+		                   p.tiny_total, p.n_states, p.d_stats);
+	} else {
+		hipLaunchKernelGGL(k_reduce1<64>, dim3(17, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
+		                   p.n_chunks, p.d_stage);
+		hipLaunchKernelGGL(k_reduce2<64>, dim3((STATS_LEN + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
+		                   p.tiny_total, p.n_states, p.d_stats);
+	}
 	if (p.ev[4]) (void)hipEventRecord(p.ev[4], sm);
 	return (int)hipGetLastError();
 }

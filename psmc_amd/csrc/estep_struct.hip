@@ -55,13 +55,23 @@ __device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, co
 	return v;
 }
 
-__device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructPar &c) {
-	// sp = P | R | qa | c | dd, 64 each
-	load4(sp + (fwd ? 0 : 192) + k0, c.mS);   // forward: P,  backward: c
-	load4(sp + (fwd ? 128 : 64) + k0, c.wS);  // forward: qa, backward: R
-	load4(sp + (fwd ? 64 : 128) + k0, c.mP);  // forward: R,  backward: qa
-	load4(sp + (fwd ? 192 : 0) + k0, c.wP);   // forward: c,  backward: P
-	load4(sp + 256 + k0, c.dd);
+template <int NPL> __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructParN<NPL> &c) {
+	constexpr int S = 16 * NPL; // sp = P | R | qa | c | dd, S each
+	loadN<NPL>(sp + (fwd ? 0 : 3 * S) + k0, c.mS);  // forward: P,  backward: c
+	loadN<NPL>(sp + (fwd ? 2 * S : S) + k0, c.wS);  // forward: qa, backward: R
+	loadN<NPL>(sp + (fwd ? S : 2 * S) + k0, c.mP);  // forward: R,  backward: qa
+	loadN<NPL>(sp + (fwd ? 3 * S : 0) + k0, c.wP);  // forward: c,  backward: P
+	loadN<NPL>(sp + 4 * S + k0, c.dd);
+}
+template <int NPL> __device__ __forceinline__ double lane_sum(const double (&x)[NPL]) {
+	double t = (x[0] + x[1]) + (x[2] + x[3]);
+	if constexpr (NPL == 8) t = t + ((x[4] + x[5]) + (x[6] + x[7]));
+	return t;
+}
+// e[0] | e[1] | 1 | 1 (rows of S) for the per-symbol emission fetch
+template <int S> __device__ __forceinline__ void fill_lds_e(double *lds_e, const double *__restrict__ e, int lane) {
+#pragma unroll
+	for (int i = lane; i < S; i += 64) { lds_e[i] = e[i]; lds_e[S + i] = e[S + i]; lds_e[2 * S + i] = 1.0; lds_e[3 * S + i] = 1.0; }
 }
 
 // A sweep ITEM is a run of `count` consecutive tiles of one segment that one row walks through in
@@ -81,33 +91,36 @@ struct FwdCursor { int next_lo, tile; };
 
 // MODE 0: per-step range / store / boundary predicates;  MODE 1: all 16 positions are computed and
 // stored and no tile starts inside the block;  MODE 2: warm-up, nothing stored.
-template <int MODE, int J>
-__device__ __forceinline__ void fwd_step(const StructPar &c, const double *lds_e, int k0, int m, unsigned w, int base,
-                                         int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[4],
+template <int MODE, int J, int NPL>
+__device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
+                                         int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                          double *fo, double *io, double *entry)
 {
 	// base = index of the group's first position (multiple of 4), J = step inside the group;
 	// lo0 = first position whose X is stored (INT_MAX for a walk, which only leaves the boundary vectors)
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p >= p_first && p <= p_last)) return;
+	constexpr int S = 16 * NPL;
 	if (MODE == 0 && p == cur.next_lo) { // the X_{lo-1} this tile builds on
-		store4(entry + (int64_t)cur.tile * 64 + k0, x);
+		storeN<NPL>(entry + (int64_t)cur.tile * S + k0, x);
 		cur.tile += 1; cur.next_lo += T;
 	}
-	double ev[4];
-	load4(lds_e + sym_of<J>(w) * 64 + k0, ev);
+	double ev[NPL];
+	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
 	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}), off the critical path
-		const double inv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
-		ev[0] *= inv; ev[1] *= inv; ev[2] *= inv; ev[3] *= inv;
+		const double inv = rcp_newton(row_sum16(lane_sum<NPL>(x)));
+#pragma unroll
+		for (int i = 0; i < NPL; ++i) ev[i] *= inv;
 		if ((MODE == 1 || (MODE == 0 && p >= lo0)) && m == 0) io[idx] = inv;
 	}
-	struct_step(c, x);
-	x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
-	if (MODE == 1 || (MODE == 0 && p >= lo0)) store4(fo + (int64_t)idx * 64, x);
+	struct_step<NPL>(c, x);
+#pragma unroll
+	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
+	if (MODE == 1 || (MODE == 0 && p >= lo0)) storeN<NPL>(fo + (int64_t)idx * S, x);
 }
-template <int MODE>
-__device__ __forceinline__ void fwd_block(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
-                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[4],
+template <int MODE, int NPL>
+__device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                           double *fo, double *io, double *entry)
 {
 	// four groups of four unrolled steps: 16 fully unrolled steps x 3 modes x 2 directions overflow the
@@ -116,17 +129,17 @@ __device__ __forceinline__ void fwd_block(const StructPar &c, const double *lds_
 	for (int g = 0; g < 4; ++g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g;
-		fwd_step<MODE, 0>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
-		fwd_step<MODE, 1>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
-		fwd_step<MODE, 2>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
-		fwd_step<MODE, 3>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		fwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		fwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		fwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		fwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
 	}
 }
 
 // items[4*blockIdx.x + row] = work of this row.  REPAIR: the list holds the flagged tiles (count 1); a
 // row starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel
 // then decides whether the next tile has to follow).  No vector-memory load inside the sweep.
-template <bool REPAIR>
+template <bool REPAIR, int NPL>
 __device__ __forceinline__ void fwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                 const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -135,9 +148,10 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
                                                 int *__restrict__ touch_f)
 {
 	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
-	__shared__ double lds_e[4 * 64]; // e[0], e[1], 1, 1
-	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
-	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
+	constexpr int S = 16 * NPL;
+	__shared__ double lds_e[4 * S]; // e[0], e[1], 1, 1
+	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
+	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
 	const int slot = block * 4 + (lane >> 4);
 	const bool valid = slot < n_items;
@@ -146,24 +160,25 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	const Chunk c = chunks[it.first];
 	const int p_last = chunks[it.first + it.count - 1].hi;
 	const uint8_t *o = obs + c.off;
-	double *fo = f + c.off * 64 + k0, *io = invd + c.off;
-	StructPar sc;
-	load_struct_par(sp, k0, true, sc);
-	double x[4];
+	double *fo = f + c.off * S + k0, *io = invd + c.off;
+	StructParN<NPL> sc;
+	load_struct_par<NPL>(sp, k0, true, sc);
+	double x[NPL];
 	int p_first;
 	if (REPAIR && valid && m == 0 && !(flags & SWEEP_NO_TOUCH)) touch_f[it.first] = 1; // X / inv_d of this tile change
 	if (REPAIR && c.lo > 1) { // from the neighbour's stored X_{lo-1}, or from the boundary vector a walk left
-		if (from_entry) load4(entry + (int64_t)it.first * 64 + k0, x);
-		else load4(fo + (int64_t)(c.lo - 2) * 64, x);
+		if (from_entry) loadN<NPL>(entry + (int64_t)it.first * S + k0, x);
+		else loadN<NPL>(fo + (int64_t)(c.lo - 2) * S, x);
 		p_first = c.lo;
 	} else {
 		const int ws = max(1, c.lo - W);
-		load4(a0 + k0, x);
+		loadN<NPL>(a0 + k0, x);
 		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
-			double ev[4];
-			load4(lds_e + ((int)o[0] & 3) * 64 + k0, ev);
-			x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
-			if (valid && c.lo == 1 && !walk) store4(fo, x);
+			double ev[NPL];
+			loadN<NPL>(lds_e + ((int)o[0] & 3) * S + k0, ev);
+#pragma unroll
+			for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
+			if (valid && c.lo == 1 && !walk) storeN<NPL>(fo, x);
 			p_first = 2;
 		} else { // warm-up from the stationary prior
 			p_first = ws;
@@ -193,19 +208,19 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 		if (bi < nblk) {
 			const int base = (b_first + bi) << 4;
 			if (cur.next_lo == base + 1 && base + 1 >= p_first && base + 1 <= p_last) { // a tile starts exactly at this block
-				store4(entry + (int64_t)cur.tile * 64 + k0, x);
+				storeN<NPL>(entry + (int64_t)cur.tile * S + k0, x);
 						cur.tile += 1; cur.next_lo += T;
 			}
 			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
 			const int mode = !full ? 0 : (base + 1 >= lo_store ? 1 : 2);
-			if (__all(mode == 1)) fwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else if (__all(mode == 2)) fwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else fwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			if (__all(mode == 1)) fwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else if (__all(mode == 2)) fwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else fwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 		}
 	}
 }
 
-template <bool REPAIR>
+template <bool REPAIR, int NPL>
 __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ invd, double *__restrict__ entry,
                                                      int *__restrict__ touch_f)
 {
-	fwd_struct_body<REPAIR>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
+	fwd_struct_body<REPAIR, NPL>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
 }
 
 // ------------------------------------------------------------------ backward
@@ -224,53 +239,56 @@ struct BwdCursor { int lo, top, tile; bool store; }; // store: false for a walk,
 
 // MODE 1: every position of the block is strictly inside (lo, top) of the current tile;
 // MODE 2: warm-up above the top tile's top;  MODE 0: general.
-template <int MODE, int J>
-__device__ __forceinline__ void bwd_step(const StructPar &c, const double *lds_e, int k0, int m, unsigned w, int base,
-                                         int p_first, int p_low, int T, BwdCursor &cur, double (&x)[4], double *bto,
+template <int MODE, int J, int NPL>
+__device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
+                                         int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                          double *sbo, double *bentry, double *bexit)
 {
+	constexpr int S = 16 * NPL;
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p <= p_first && p >= p_low)) return;
-	double ev[4];
-	load4(lds_e + sym_of<J>(w) * 64 + k0, ev);
+	double ev[NPL];
+	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
 	if (J == 3) { // sb_p = 1/sum(bt_{p+1}), off the critical path
-		const double s = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
-		ev[0] *= s; ev[1] *= s; ev[2] *= s; ev[3] *= s;
+		const double s = rcp_newton(row_sum16(lane_sum<NPL>(x)));
+#pragma unroll
+		for (int i = 0; i < NPL; ++i) ev[i] *= s;
 		if ((MODE == 1 || (MODE == 0 && p <= cur.top && cur.store)) && m == 0) sbo[idx] = s;
 	}
 	if (MODE == 0 && p == cur.top) { // the boundary vector this tile builds on
-		if (cur.store) store4(bto + (int64_t)cur.top * 64, x); // bt[top+1]
-		store4(bentry + (int64_t)cur.tile * 64 + k0, x);
+		if (cur.store) storeN<NPL>(bto + (int64_t)cur.top * S, x); // bt[top+1]
+		storeN<NPL>(bentry + (int64_t)cur.tile * S + k0, x);
 	}
-	struct_step(c, x);
-	x[0] *= ev[0]; x[1] *= ev[1]; x[2] *= ev[2]; x[3] *= ev[3];
-	if (MODE == 1) store4(bto + (int64_t)idx * 64, x);
+	struct_step<NPL>(c, x);
+#pragma unroll
+	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
+	if (MODE == 1) storeN<NPL>(bto + (int64_t)idx * S, x);
 	if (MODE == 0 && p <= cur.top) {
-		if (cur.store && (p > cur.lo || cur.lo == 1)) store4(bto + (int64_t)idx * 64, x);
+		if (cur.store && (p > cur.lo || cur.lo == 1)) storeN<NPL>(bto + (int64_t)idx * S, x);
 		if (p == cur.lo) { // leaving the tile: hand over to the one below
-			store4(bexit + (int64_t)cur.tile * 64 + k0, x);
+			storeN<NPL>(bexit + (int64_t)cur.tile * S + k0, x);
 			cur.tile -= 1; cur.top = cur.lo - 1; cur.lo -= T;
 		}
 	}
 }
-template <int MODE>
-__device__ __forceinline__ void bwd_block(const StructPar &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
-                                          int p_first, int p_low, int T, BwdCursor &cur, double (&x)[4], double *bto,
+template <int MODE, int NPL>
+__device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+                                          int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                           double *sbo, double *bentry, double *bexit)
 {
 #pragma unroll 1
 	for (int g = 3; g >= 0; --g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g;
-		bwd_step<MODE, 3>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 2>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 1>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 0>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 	}
 }
 
 // items: tiles first .. first+count-1, walked from the highest down.
-template <bool REPAIR>
+template <bool REPAIR, int NPL>
 __device__ __forceinline__ void bwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                 const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -278,9 +296,10 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
                                                 double *__restrict__ bentry, double *__restrict__ bexit,
                                                 int *__restrict__ touch_b)
 {
-	__shared__ double lds_e[4 * 64];
-	const int lane = threadIdx.x, m = lane & 15, k0 = 4 * m;
-	lds_e[lane] = e[lane]; lds_e[64 + lane] = e[64 + lane]; lds_e[128 + lane] = 1.0; lds_e[192 + lane] = 1.0;
+	constexpr int S = 16 * NPL;
+	__shared__ double lds_e[4 * S];
+	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
+	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
 	const int slot = block * 4 + (lane >> 4);
 	const SweepItem it = items[slot < n_items ? slot : 0];
@@ -295,19 +314,19 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	const bool walk = (flags & (SWEEP_WALK | SWEEP_TOP_ONLY)) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
 	cur.store = !walk;
 	const uint8_t *o = obs + c.off;
-	double *bto = bt + c.off * 64 + k0, *sbo = sb + c.off;
-	StructPar sc;
-	load_struct_par(sp, k0, false, sc);
-	double x[4]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
+	double *bto = bt + c.off * S + k0, *sbo = sb + c.off;
+	StructParN<NPL> sc;
+	load_struct_par<NPL>(sp, k0, false, sc);
+	double x[NPL]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
 	int p_first;
 	if (REPAIR) { // continue from the value the tile above computed at our top boundary
 		if (valid && m == 0) touch_b[t_top] = 1;
-		if (from_entry) load4(bentry + (int64_t)t_top * 64 + k0, x); // the boundary vector a walk left for this tile
-		else load4(bexit + (int64_t)(t_top + 1) * 64 + k0, x);
+		if (from_entry) loadN<NPL>(bentry + (int64_t)t_top * S + k0, x); // the boundary vector a walk left for this tile
+		else loadN<NPL>(bexit + (int64_t)(t_top + 1) * S + k0, x);
 		p_first = cur.top;
 	} else {
 		const int q = min(c.hi + W + 1, L); // B_q := 1
-		load4(lds_e + ((int)o[q - 1] & 3) * 64 + k0, x);
+		loadN<NPL>(lds_e + ((int)o[q - 1] & 3) * S + k0, x);
 		p_first = q - 1;
 	}
 	const int b_first = (p_first - 1) >> 4; // highest block
@@ -329,14 +348,14 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 			const int base = (b_first - bi) << 4;
 			int mode = (base + 1 > cur.lo && base + 16 < cur.top) ? 1 : ((base + 1 > cur.top && base + 16 <= p_first) ? 2 : 0);
 			if (walk && mode == 1) mode = 2;
-			if (__all(mode == 1)) bwd_block<1>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else if (__all(mode == 2)) bwd_block<2>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else bwd_block<0>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			if (__all(mode == 1)) bwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else if (__all(mode == 2)) bwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else bwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 		}
 	}
 }
 
-template <bool REPAIR>
+template <bool REPAIR, int NPL>
 __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                      const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -344,12 +363,13 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ bentry, double *__restrict__ bexit,
                                                      int *__restrict__ touch_b)
 {
-	bwd_struct_body<REPAIR>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
+	bwd_struct_body<REPAIR, NPL>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
 }
 
 // Both directions' walks over the glued runs in ONE launch (blocks [0, nbf) forward, the rest backward):
 // a process only gets a handful of hardware queues, and a walk that shares one with another stream's
 // kernel would wait for it.
+template <int NPL>
 __global__ __launch_bounds__(64) void k_walk_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                       const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                       const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
@@ -359,9 +379,9 @@ __global__ __launch_bounds__(64) void k_walk_struct(const double *__restrict__ s
 {
 	const int nbf = (n_f + 3) / 4;
 	if ((int)blockIdx.x < nbf)
-		fwd_struct_body<false>(blockIdx.x, sp, e, a0, obs, chunks, items_f, n_f, W, T, SWEEP_WALK, nullptr, nullptr, entry, nullptr);
+		fwd_struct_body<false, NPL>(blockIdx.x, sp, e, a0, obs, chunks, items_f, n_f, W, T, SWEEP_WALK, nullptr, nullptr, entry, nullptr);
 	else
-		bwd_struct_body<false>(blockIdx.x - nbf, sp, e, obs, chunks, items_b, n_b, W, T, SWEEP_WALK, nullptr, nullptr, bentry, bexit,
+		bwd_struct_body<false, NPL>(blockIdx.x - nbf, sp, e, obs, chunks, items_b, n_b, W, T, SWEEP_WALK, nullptr, nullptr, bentry, bexit,
 		                       nullptr);
 }
 
@@ -443,6 +463,7 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 // The bulk of both sweeps in ONE launch: even blocks walk forward items, odd blocks backward items (as long
 // as both lists last), so the two table writers share the chip from the first to the last wave and the
 // E-step needs one stream less.  Per launch: 2 x (8n+9) algorithmic bytes per bin.
+template <int NPL>
 __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                        const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                        const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
@@ -456,8 +477,8 @@ __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ 
 	bool fwd; int blk;
 	if (b < both) { fwd = (b & 1) == 0; blk = b >> 1; }
 	else { fwd = nbf > nbb; blk = b - both + min(nbf, nbb); }
-	if (fwd) fwd_struct_body<false>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, 0, f, invd, entry, nullptr);
-	else bwd_struct_body<false>(blk, sp, e, obs, chunks, items_b, n_b, W, T, 0, bt, sb, bentry, bexit, nullptr);
+	if (fwd) fwd_struct_body<false, NPL>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, 0, f, invd, entry, nullptr);
+	else bwd_struct_body<false, NPL>(blk, sp, e, obs, chunks, items_b, n_b, W, T, 0, bt, sb, bentry, bexit, nullptr);
 }
 
 // ------------------------------------------------------------------ dirty-tile lists
@@ -497,12 +518,12 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
 	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | (p.fused ? SWEEP_NO_TOUCH : 0)) : 0);
-	if (which == 0 || which == 2)
-		hipLaunchKernelGGL((k_fwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, items, n_items,
-		                   p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
-	else
-		hipLaunchKernelGGL((k_fwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, items, n_items,
-		                   p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f);
+#define PSMC_LF(REP, NPL) hipLaunchKernelGGL((k_fwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
+	const bool rep = !(which == 0 || which == 2);
+	if (p.ns == 128) { if (rep) PSMC_LF(true, 8); else PSMC_LF(false, 8); }
+	else { if (rep) PSMC_LF(true, 4); else PSMC_LF(false, 4); }
+#undef PSMC_LF
 }
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
@@ -510,12 +531,12 @@ void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
 	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? SWEEP_FROM_ENTRY : (which == 4 ? SWEEP_TOP_ONLY : 0));
-	if (which == 0 || which == 2 || which == 4)
-		hipLaunchKernelGGL((k_bwd_struct<false>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup,
-		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
-	else
-		hipLaunchKernelGGL((k_bwd_struct<true>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup,
-		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+#define PSMC_LB(REP, NPL) hipLaunchKernelGGL((k_bwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, \
+		n_items, p.warmup, p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b)
+	const bool rep = !(which == 0 || which == 2 || which == 4);
+	if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
+	else { if (rep) PSMC_LB(true, 4); else PSMC_LB(false, 4); }
+#undef PSMC_LB
 }
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
 {
@@ -528,13 +549,15 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 {
 	const int nblk = (nf + 3) / 4 + (nb + 3) / 4;
 	if (nblk <= 0) return;
-	hipLaunchKernelGGL(k_sweep_struct, dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-	                   (const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len,
-	                   p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit);
+#define PSMC_LS(NPL) hipLaunchKernelGGL(k_sweep_struct<NPL>, dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, \
+		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit)
+	if (p.ns == 128) PSMC_LS(8); else PSMC_LS(4);
+#undef PSMC_LS
 }
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {
-	if (p.walk_impl == 1) { // one wave per run, one state per lane
+	if (p.walk_impl == 1 && p.ns == 64) { // one wave per run, one state per lane
 		if (p.n_long_f + p.n_long_b <= 0) return;
 		hipLaunchKernelGGL(k_walk1_struct, dim3(p.n_long_f + p.n_long_b), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
 		                   (const SweepItem *)p.d_items_f, p.n_long_f, (const SweepItem *)p.d_items_b, p.n_long_b, p.warmup,
@@ -543,9 +566,11 @@ void launch_walks(const EstepLaunch &p, hipStream_t st)
 	}
 	const int nb = (p.n_long_f + 3) / 4 + (p.n_long_b + 3) / 4;
 	if (nb <= 0) return;
-	hipLaunchKernelGGL(k_walk_struct, dim3(nb), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-	                   (const SweepItem *)p.d_items_f, p.n_long_f, (const SweepItem *)p.d_items_b, p.n_long_b, p.warmup, p.tile_len,
-	                   p.d_entry, p.d_bentry, p.d_bexit);
+#define PSMC_LW(NPL) hipLaunchKernelGGL(k_walk_struct<NPL>, dim3(nb), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+		(const SweepItem *)p.d_items_f, p.n_long_f, (const SweepItem *)p.d_items_b, p.n_long_b, p.warmup, p.tile_len, \
+		p.d_entry, p.d_bentry, p.d_bexit)
+	if (p.ns == 128) PSMC_LW(8); else PSMC_LW(4);
+#undef PSMC_LW
 }
 
 } // namespace psmc

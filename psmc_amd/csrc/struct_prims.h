@@ -95,35 +95,39 @@ __device__ __forceinline__ double rcp_newton(double x) {
 	return r;
 }
 
-// per-lane constants of one sweep direction (4 states per lane)
-struct StructPar { double mS[4], wS[4], mP[4], wP[4], dd[4]; };
+// per-lane constants of one sweep direction (NPL adjacent states per lane; 16 lanes = one tile:
+// NPL = 4 for up to 64 states, 8 for up to 128)
+template <int NPL> struct StructParN { double mS[NPL], wS[NPL], mP[NPL], wP[NPL], dd[NPL]; };
+typedef StructParN<4> StructPar;
 
 // x <- M x for the structured M: wS.SUF(x.mS) + wP.PRE(x.mP) + dd.x
-__device__ __forceinline__ void struct_step(const StructPar &c, double (&x)[4])
+template <int NPL>
+__device__ __forceinline__ void struct_step(const StructParN<NPL> &c, double (&x)[NPL])
 {
-	const double u0 = x[0] * c.mS[0], u1 = x[1] * c.mS[1], u2 = x[2] * c.mS[2], u3 = x[3] * c.mS[3];
-	const double v0 = x[0] * c.mP[0], v1 = x[1] * c.mP[1], v2 = x[2] * c.mP[2], v3 = x[3] * c.mP[3];
-	const double su2 = u2 + u3, su1 = u1 + su2, su0 = u0 + su1; // local inclusive suffix sums
-	const double pv1 = v0 + v1, pv2 = pv1 + v2, pv3 = pv2 + v3; // local inclusive prefix sums
-	const double ES = row_excl_suffix(su0), EP = row_excl_prefix(pv3);
-	// the lane-local part does not wait for the row scans
-	const double t0 = __builtin_fma(c.wS[0], su0, __builtin_fma(c.wP[0], v0, c.dd[0] * x[0]));
-	const double t1 = __builtin_fma(c.wS[1], su1, __builtin_fma(c.wP[1], pv1, c.dd[1] * x[1]));
-	const double t2 = __builtin_fma(c.wS[2], su2, __builtin_fma(c.wP[2], pv2, c.dd[2] * x[2]));
-	const double t3 = __builtin_fma(c.wS[3], u3, __builtin_fma(c.wP[3], pv3, c.dd[3] * x[3]));
-	x[0] = __builtin_fma(c.wS[0], ES, __builtin_fma(c.wP[0], EP, t0));
-	x[1] = __builtin_fma(c.wS[1], ES, __builtin_fma(c.wP[1], EP, t1));
-	x[2] = __builtin_fma(c.wS[2], ES, __builtin_fma(c.wP[2], EP, t2));
-	x[3] = __builtin_fma(c.wS[3], ES, __builtin_fma(c.wP[3], EP, t3));
+	double su[NPL], pv[NPL]; // lane-local inclusive suffix sums of x.mS / prefix sums of x.mP
+	su[NPL - 1] = x[NPL - 1] * c.mS[NPL - 1];
+#pragma unroll
+	for (int i = NPL - 2; i >= 0; --i) su[i] = x[i] * c.mS[i] + su[i + 1];
+	pv[0] = x[0] * c.mP[0];
+#pragma unroll
+	for (int i = 1; i < NPL; ++i) pv[i] = pv[i - 1] + x[i] * c.mP[i];
+	const double ES = row_excl_suffix(su[0]), EP = row_excl_prefix(pv[NPL - 1]);
+#pragma unroll
+	for (int i = 0; i < NPL; ++i) { // the lane-local part does not wait for the row scans
+		const double t = __builtin_fma(c.wS[i], su[i], __builtin_fma(c.wP[i], pv[i], c.dd[i] * x[i]));
+		x[i] = __builtin_fma(c.wS[i], ES, __builtin_fma(c.wP[i], EP, t));
+	}
 }
 
-__device__ __forceinline__ void load4(const double *p, double (&v)[4]) {
-	const d2v_t a = reinterpret_cast<const d2v_t *>(p)[0], b = reinterpret_cast<const d2v_t *>(p)[1];
-	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+template <int NPL> __device__ __forceinline__ void loadN(const double *p, double (&v)[NPL]) {
+#pragma unroll
+	for (int i = 0; i < NPL / 2; ++i) { const d2v_t a = reinterpret_cast<const d2v_t *>(p)[i]; v[2 * i] = a.x; v[2 * i + 1] = a.y; }
 }
-__device__ __forceinline__ void store4(double *p, const double (&v)[4]) {
-	d2v_t a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
-	reinterpret_cast<d2v_t *>(p)[0] = a; reinterpret_cast<d2v_t *>(p)[1] = b;
+template <int NPL> __device__ __forceinline__ void storeN(double *p, const double (&v)[NPL]) {
+#pragma unroll
+	for (int i = 0; i < NPL / 2; ++i) { d2v_t a; a.x = v[2 * i]; a.y = v[2 * i + 1]; reinterpret_cast<d2v_t *>(p)[i] = a; }
 }
+__device__ __forceinline__ void load4(const double *p, double (&v)[4]) { loadN<4>(p, v); }
+__device__ __forceinline__ void store4(double *p, const double (&v)[4]) { storeN<4>(p, v); }
 
 } // namespace psmc

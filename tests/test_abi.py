@@ -45,7 +45,6 @@ def test_argument_validation(lib):
     h = C.c_void_p()
     assert lib.psmc_hip_create(C.byref(h), 0, 0, 0) == -1       # EINVAL
     assert lib.psmc_hip_create(C.byref(h), 129, 0, 0) == -4     # ENOTSUP: > 128 states not in this build
-    assert lib.psmc_hip_create(C.byref(h), 65, 0, 1) == -4      # ENOTSUP: fast mode is one lane per state (<= 64)
     assert lib.psmc_hip_create(C.byref(h), 64, 0, 7) == -1
     assert lib.psmc_hip_create(None, 64, 0, 0) == -1
 

@@ -187,8 +187,12 @@ def test_errors(hip):
         es.select([1])
     with pytest.raises(hip.HipError):
         hip.HipEStep(129)                        # exact mode: at most 128 states (two per lane)
+    es.close()
+    es = hip.HipEStep(65, mode=hip.MODE_FAST)    # beyond 64 states the fast mode has the structured sweeps only
+    a, e, a0 = random_hmm(np.random.default_rng(1), 65)
+    es.load_segments([np.array([0, 1, 2, 0, 0], np.uint8)])
     with pytest.raises(hip.HipError):
-        hip.HipEStep(65, mode=hip.MODE_FAST)     # fast mode: one lane per state
+        es.estep(a, e, a0)                       # a random matrix does not have the PSMC form
     es.close()
 
 
@@ -300,6 +304,26 @@ def test_fast_fused_backward_counts(hip, golden, oracle, opts):
         check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
     es.select([5, 4, 5, 3, 5])
     check_fast(es.estep(p["a"], p["e"], p["a0"]), oracle.estep(p["a"], p["e"], p["a0"], [golden.segs_mid[i] for i in (5, 4, 5, 3, 5)]))
+    es.close()
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=512, warmup=256), dict(chunk=1000, warmup=100, overlap=0, learn=0)])
+def test_fast_n128(hip, golden, oracle, opts):
+    """-p "64*2" in fast mode: 8 states per lane in the structured sweeps, the counts in four 64x64 quadrants."""
+    g, k = golden.n128, "n128_curve"
+    a, e, a0 = g[k + ".a"], g[k + ".e"], g[k + ".a0"]
+    segs = golden.segs_small + golden.segs_mid[2:]
+    o = oracle.estep(a, e, a0, segs)
+    es = hip.HipEStep(128, mode=hip.MODE_FAST, **opts)
+    es.load_segments(segs)
+    for it in range(2):
+        check_fast(es.estep(a, e, a0), o)
+    assert es.fast_diag()["structured"]
+    es.close()
+    es = hip.HipEStep(100, mode=hip.MODE_FAST, **opts)  # a sub-block of the same matrix keeps the two rank-1 triangles
+    a2 = a[:100, :100] / a[:100, :100].sum(1, keepdims=True)
+    es.load_segments(segs)
+    check_fast(es.estep(a2, e[:, :100], a0[:100] / a0[:100].sum()), oracle.estep(a2, e[:, :100], a0[:100] / a0[:100].sum(), segs))
     es.close()
 
 

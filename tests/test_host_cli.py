@@ -202,6 +202,20 @@ def test_psmc_binary_byte_identical_on_gpu(name):
 
 
 @pytest.mark.gpu
+def test_psmc_binary_fast_mode_n128_close():
+    """-p "64*2" with PSMC_HIP_MODE=fast: 8-states-per-lane sweeps, quadrant counts, O(N) objective."""
+    args = open(os.path.join(CLI, "small_n128_N2.args")).read().split()
+    env = dict(os.environ, PSMC_HIP_MODE="fast")
+    r = subprocess.run([os.path.join(HOST, "psmc")] + args, cwd=CLI, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    got = [l for l in r.stdout.splitlines() if l.startswith("LK")]
+    want = [l for l in golden_text("small_n128_N2").splitlines() if l.startswith("LK")]
+    assert len(got) == len(want)
+    for g, w in zip(got[1:], want[1:]):
+        assert abs(float(g.split()[1]) - float(w.split()[1])) <= 1e-5 * abs(float(w.split()[1]))
+
+
+@pytest.mark.gpu
 def test_psmc_binary_fast_mode_close():
     """PSMC_HIP_MODE=fast: same file structure; LK within 1e-9 relative in the first round (later
     rounds diverge at the 1e-5 level through the chaotic direct search, like a recompiled reference)."""

@@ -327,6 +327,21 @@ def test_fast_n128(hip, golden, oracle, opts):
     es.close()
 
 
+@pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, walk_impl=0),
+                                  dict(chunk=64, warmup=0, fuse=1), dict(chunk=5000, warmup=16, overlap=0)])
+def test_fast_odd_tilings(hip, golden, oracle, opts):
+    """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
+    everything is repaired / learned into runs and stays inside the tolerance."""
+    p = golden.params("n64_curve")
+    segs = golden.segs_small + golden.segs_mid[3:]
+    o = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
+    es.load_segments(segs)
+    for it in range(3):
+        check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+    es.close()
+
+
 def test_fast_learns_slow_regions(hip, golden, oracle):
     """Tiles that needed a repair are glued to their neighbour for the following E-steps of the
     context: the repair rounds disappear, the result stays inside the tolerance, and two contexts

@@ -100,6 +100,14 @@ int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err
 /* How much repair the speculation needed: verify/repair rounds and the total
  * number of tile re-runs, forward and backward; out[0..3]. */
 int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
+/* Fast mode, matrices of the PSMC form (two rank-1 triangles, core.c:112-122), n <= 64: the E-step without the
+ * N x N counts.  The EM objective needs of A only  SL_k = sum_{l<k} A[k][l],  SU_k = sum_{l>k} A[k][l],
+ * DG_k = A[k][k],  CL_l = sum_{k>l} A[k][l],  CU_l = sum_{k<l} A[k][l]  (psmc_amd/host/mstep.c); they come out
+ * of the backward sweep in O(N) per bin.  sums = SL | SU | DG | CL | CU (5n), E as in psmc_hip_estep (2n).
+ * PSMC_HIP_ENOTSUP when the matrix does not have the form.  Replaces em.c:33-55 + the reads of hmm_Q. */
+int psmc_hip_estep_factored(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, double *sums,
+                            double *E, double *LL);
+
 /* Diagnostic: out = {structured sweeps used (0/1), tile length in bins, forward sweep items,
  * backward sweep items} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured sweeps
  *  are chosen automatically when a[][] has the two rank-1

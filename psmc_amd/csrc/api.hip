@@ -26,6 +26,7 @@ struct psmc_hip_ctx {
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
 	int struct_tiles = 8192;   // "struct_tiles": tiles aimed at when the structured sweeps are used (4 per wave)
 	bool use_struct = false, planned_struct = false;
+	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
 	int fuse = 0;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip); off: same speed, see DESIGN.md
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
@@ -391,6 +392,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.d_re = c->d_par + 4 * 4096 + 192 + 64;
 	p.d_sp = c->d_par + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
+	if (c->want_factored) p.fused = 2;
 	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
 	if (c->ns == 128) {
@@ -661,6 +663,8 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
 	if (c->ns == 128 && !c->use_struct)
 		return fail(c, PSMC_HIP_ENOTSUP, "fast mode beyond 64 states needs a transition matrix of the PSMC form (structured sweeps)");
+	if (c->want_factored && !(c->use_struct && c->ns == 64))
+		return fail(c, PSMC_HIP_ENOTSUP, "factored statistics need a transition matrix of the PSMC form and at most 64 states");
 	if ((c->plan_dirty || c->planned_struct != c->use_struct) && (rc = plan_fast(c))) return rc;
 	EstepLaunch p;
 	fill_common(c, p, st);
@@ -724,6 +728,29 @@ extern "C" int psmc_hip_fast_repairs(psmc_hip_ctx *c, int out[4])
 	if (!c || !out) return PSMC_HIP_EINVAL;
 	out[0] = c->report.fwd_rounds; out[1] = c->report.bwd_rounds;
 	out[2] = c->report.fwd_tiles; out[3] = c->report.bwd_tiles;
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_estep_factored(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *sums,
+                                       double *E, double *LL)
+{
+	if (!c || !a || !e || !a0) return fail(c, PSMC_HIP_EINVAL, "estep_factored: bad argument");
+	if (c->mode != PSMC_HIP_MODE_FAST) return fail(c, PSMC_HIP_ENOTSUP, "estep_factored: fast mode only");
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc;
+	if (c->plan_dirty && (rc = plan_fast(c))) return rc; // d_stats must exist before the first enqueue
+	c->want_factored = true;
+	rc = enqueue_fast(c, a, e, a0, c->d_stats, c->stream);
+	c->want_factored = false;
+	if (rc) return rc;
+	if ((rc = read_warm(c, c->stream))) return rc;
+	collect_timing(c);
+	const int n = c->n;
+	std::vector<double> h((size_t)7 * n + 1);
+	HIPCHK(c, hipMemcpy(h.data(), c->d_stats, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+	if (sums) memcpy(sums, h.data(), sizeof(double) * 5 * n);
+	if (E) memcpy(E, h.data() + (size_t)5 * n, sizeof(double) * 2 * n);
+	if (LL) *LL = h[(size_t)7 * n];
 	return PSMC_HIP_OK;
 }
 

@@ -1,0 +1,217 @@
+// estep_factored.hip -- FAST mode, structured matrices: the sufficient statistics in O(N) per bin.
+//
+// With a[k][l] = P_k qa_l (l<k), R_k c_l (l>k) the EM objective needs of the N x N expected transition
+// counts A only five vectors (psmc_amd/host/mstep.c neg_Q_fast):
+//   SL_k = sum_{l<k} A[k][l]   SU_k = sum_{l>k} A[k][l]   DG_k = A[k][k]
+//   CL_l = sum_{k>l} A[k][l]   CU_l = sum_{k<l} A[k][l]
+// and with A[k][l] = a[k][l] sum_p w_p X_p[k] bt_{p+1}[l] every one of them is a scan away from what the
+// backward step computes anyway (z = bt_{p+1}, w_p = sb_p / G_p):
+//   SL_k = P_k   sum_p w_p X_p[k] PREexcl_k(z.qa)      SU_k = R_k sum_p w_p X_p[k] SUFexcl_k(z.c)
+//   CL_l = qa_l  sum_p w_p z_l    SUFexcl_l(X_p.P)     CU_l = c_l sum_p w_p z_l    PREexcl_l(X_p.R)
+//   DG_k = a_kk  sum_p w_p X_p[k] z_k
+// So the counts GEMM (2 N^2 flop per bin, 1 KB of table reads per bin, the bt table) disappears: the wave
+// that walks four tiles backwards reads X, keeps bt in registers and accumulates 7 x 4 numbers per lane.
+// HBM per bin: 8N (write X) + 8N (read X).  Entry point psmc_hip_estep_factored (include/psmc_hip.h).
+#include <hip/hip_runtime.h>
+#include "wave_prims.h"
+#include "struct_prims.h"
+#include "psmc_hip_internal.h"
+
+namespace psmc {
+
+struct SweepItemA { int first, count; };
+constexpr int NPLA = 4, SA = 64, NACC = 7; // SL SU DG CL CU E0 E1
+
+__device__ __forceinline__ int64_t readlane_i64a(int64_t v, int lane) {
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
+	return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// mode 0: tiles items[0..n) from bentry;  mode 1: flagged tiles items[0..n) from the exit vector of the tile
+// above (which becomes their bentry);  mode 2: every tile b < n whose X a forward repair rewrote, from bentry.
+__global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                            const double *__restrict__ re, const uint8_t *__restrict__ obs,
+                                                            const Chunk *__restrict__ chunks, const SweepItemA *__restrict__ items,
+                                                            int n, int mode, const double *__restrict__ f,
+                                                            double *__restrict__ bentry, double *__restrict__ bexit,
+                                                            double *__restrict__ part, const int *__restrict__ touch_f,
+                                                            int *__restrict__ touch_b)
+{
+	__shared__ double lds_e[4 * SA], lds_re[4 * SA]; // e / 1/e rows: hom, het, 1, 1
+	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLA * m;
+	lds_e[lane] = e[lane]; lds_e[SA + lane] = e[SA + lane]; lds_e[2 * SA + lane] = 1.0; lds_e[3 * SA + lane] = 1.0;
+	lds_re[lane] = re[lane]; lds_re[SA + lane] = re[SA + lane]; lds_re[2 * SA + lane] = 1.0; lds_re[3 * SA + lane] = 1.0;
+	__syncthreads();
+	const int slot = blockIdx.x * 4 + row;
+	int tile; bool valid = slot < n;
+	if (mode == 2) { tile = valid ? slot : 0; valid = valid && touch_f[tile] != 0; }
+	else tile = items[valid ? slot : 0].first;
+	if (!__any(valid)) return;
+	if (mode == 1) __builtin_amdgcn_s_setprio(3);
+	const Chunk c = chunks[tile];
+	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
+	const bool work = valid && top >= lo; // a tile holding only position L owns no transition: zero partials
+	const double *fo = f + c.off * SA + k0;
+	StructParN<NPLA> sc; // backward: mS = c, wS = R, mP = qa, wP = P
+	loadN<NPLA>(sp + 3 * SA + k0, sc.mS); loadN<NPLA>(sp + SA + k0, sc.wS);
+	loadN<NPLA>(sp + 2 * SA + k0, sc.mP); loadN<NPLA>(sp + k0, sc.wP); loadN<NPLA>(sp + 4 * SA + k0, sc.dd);
+	double x[NPLA];
+	if (mode == 1) {
+		loadN<NPLA>(bexit + (int64_t)(tile + 1) * SA + k0, x);
+		if (work) { storeN<NPLA>(bentry + (int64_t)tile * SA + k0, x); if (m == 0) touch_b[tile] = 1; }
+	} else {
+		loadN<NPLA>(bentry + (int64_t)tile * SA + k0, x);
+	}
+	double acc[NACC][NPLA];
+#pragma unroll
+	for (int q = 0; q < NACC; ++q)
+#pragma unroll
+		for (int i = 0; i < NPLA; ++i) acc[q][i] = 0.0;
+	// groups of four positions 4g+1 .. 4g+4 (indices 4g .. 4g+3), highest first; the group's last
+	// position (p % 4 == 0) carries the scale factor
+	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
+	const int ng = g_hi - g_lo + 1;
+	const int64_t off0 = readlane_i64a(c.off, 0), off1 = readlane_i64a(c.off, 16), off2 = readlane_i64a(c.off, 32), off3 = readlane_i64a(c.off, 48);
+	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
+	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
+	const int ng_max = max(max(n0, n1), max(n2, n3));
+	auto load_group = [&](int g, double (&X)[4][NPLA]) { // X rows of the group's positions, clamped into the tile
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int p = min(max(4 * g + j + 1, lo), max(top, lo));
+			loadN<NPLA>(fo + (int64_t)(p - 1) * SA, X[j]);
+		}
+	};
+	double Xg[4][NPLA], Xn[4][NPLA];
+	load_group(max(g_hi, 0), Xg);
+	for (int gi = 0; gi < ng_max; ++gi) {
+		// the group's four symbols of every row: scalar loads (see estep_struct.hip row_symbols)
+		const unsigned w0 = *reinterpret_cast<const unsigned *>(obs + off0 + 4 * (int64_t)max(gh0 - min(gi, max(n0 - 1, 0)), 0));
+		const unsigned w1 = *reinterpret_cast<const unsigned *>(obs + off1 + 4 * (int64_t)max(gh1 - min(gi, max(n1 - 1, 0)), 0));
+		const unsigned w2 = *reinterpret_cast<const unsigned *>(obs + off2 + 4 * (int64_t)max(gh2 - min(gi, max(n2 - 1, 0)), 0));
+		const unsigned w3 = *reinterpret_cast<const unsigned *>(obs + off3 + 4 * (int64_t)max(gh3 - min(gi, max(n3 - 1, 0)), 0));
+		const unsigned w = row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
+		if (gi < ng) {
+			const int g = g_hi - gi;
+			if (gi + 1 < ng) load_group(g - 1, Xn);
+#pragma unroll
+			for (int j = 3; j >= 0; --j) {
+				const int p = 4 * g + j + 1;
+				if (p > top || p < lo) continue;
+				const int sym = (int)((w >> (8 * j)) & 3u);
+				double ev[NPLA], rv[NPLA];
+				loadN<NPLA>(lds_e + sym * SA + k0, ev);
+				loadN<NPLA>(lds_re + sym * SA + k0, rv);
+				double sbv = 1.0;
+				if (j == 3) { // sb_p = 1/sum(bt_{p+1})
+					sbv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
+#pragma unroll
+					for (int i = 0; i < NPLA; ++i) ev[i] *= sbv;
+				}
+				const double(&X)[NPLA] = Xg[j];
+				// lane-local inclusive scans: z.c / z.qa (the backward step) and X.P / X.R (the column sums)
+				double su[NPLA + 1], pv[NPLA + 1], sx[NPLA + 1], px[NPLA + 1];
+				su[NPLA] = 0.0; sx[NPLA] = 0.0; pv[0] = 0.0; px[0] = 0.0; // pv / px are shifted by one: pv[i+1] = inclusive at i
+#pragma unroll
+				for (int i = NPLA - 1; i >= 0; --i) { su[i] = x[i] * sc.mS[i] + su[i + 1]; sx[i] = X[i] * sc.wP[i] + sx[i + 1]; }
+#pragma unroll
+				for (int i = 0; i < NPLA; ++i) { pv[i + 1] = pv[i] + x[i] * sc.mP[i]; px[i + 1] = px[i] + X[i] * sc.wS[i]; }
+				const double ES = row_excl_suffix(su[0]), EP = row_excl_prefix(pv[NPLA]);
+				const double EX = row_excl_suffix(sx[0]), PX = row_excl_prefix(px[NPLA]);
+				double bt[NPLA], gk[NPLA], G = 0.0;
+#pragma unroll
+				for (int i = 0; i < NPLA; ++i) {
+					const double t = __builtin_fma(sc.wS[i], su[i], __builtin_fma(sc.wP[i], pv[i + 1], sc.dd[i] * x[i]));
+					bt[i] = __builtin_fma(sc.wS[i], ES, __builtin_fma(sc.wP[i], EP, t)) * ev[i];
+					gk[i] = X[i] * bt[i] * rv[i];
+					G += gk[i];
+				}
+				const double iG = rcp_newton(row_sum16(G)), wgt = sbv * iG;
+				const double h0 = sym == 0 ? iG : 0.0, h1 = sym == 1 ? iG : 0.0;
+#pragma unroll
+				for (int i = 0; i < NPLA; ++i) {
+					const double wx = wgt * X[i], wz = wgt * x[i];
+					acc[0][i] = __builtin_fma(wx, EP + pv[i], acc[0][i]);     // SL: strictly below k
+					acc[1][i] = __builtin_fma(wx, ES + su[i + 1], acc[1][i]); // SU: strictly above k
+					acc[2][i] = __builtin_fma(wx, x[i], acc[2][i]);           // DG
+					acc[3][i] = __builtin_fma(wz, EX + sx[i + 1], acc[3][i]); // CL: rows k > l
+					acc[4][i] = __builtin_fma(wz, PX + px[i], acc[4][i]);     // CU: rows k < l
+					acc[5][i] = __builtin_fma(gk[i], h0, acc[5][i]);
+					acc[6][i] = __builtin_fma(gk[i], h1, acc[6][i]);
+					x[i] = bt[i];
+				}
+				if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+#pragma unroll
+				for (int i = 0; i < NPLA; ++i) Xg[j][i] = Xn[j][i];
+		}
+	}
+	if (valid) {
+		const double mult = (double)c.mult;
+		double *out = part + (int64_t)tile * (NACC * SA) + k0;
+#pragma unroll
+		for (int i = 0; i < NPLA; ++i) {
+			const double akk = sc.dd[i] + sc.wP[i] * sc.mP[i] + sc.wS[i] * sc.mS[i]; // a[k][k]
+			acc[0][i] *= sc.wP[i] * mult; acc[1][i] *= sc.wS[i] * mult; acc[2][i] *= akk * mult;
+			acc[3][i] *= sc.mP[i] * mult; acc[4][i] *= sc.mS[i] * mult; acc[5][i] *= mult; acc[6][i] *= mult;
+		}
+#pragma unroll
+		for (int q = 0; q < NACC; ++q) storeN<NPLA>(out + q * SA, acc[q]);
+	}
+}
+
+// Fixed-order two-stage sum over the tiles: stage[y][q*64+k] = sum of the tiles j = y (mod RED_ROWS), then
+// out (unpadded) = SL | SU | DG | CL | CU | E0 | E1 | LL; the HMM_TINY seeds of khmm.c:305-308 are added per
+// cell (k cells below the diagonal of row k, ...).
+constexpr int FSL = NACC * SA + 1;
+__global__ __launch_bounds__(64) void k_reduce_factored1(const double *__restrict__ part, int n_tiles,
+                                                           const double *__restrict__ LLpart, double *__restrict__ stage)
+{
+	const int k = threadIdx.x, q = blockIdx.x, y = blockIdx.y;
+	if (q < NACC) {
+		double s = 0.0;
+		for (int j = y; j < n_tiles; j += RED_ROWS) s += part[(int64_t)j * (NACC * SA) + q * SA + k];
+		stage[(int64_t)y * FSL + q * SA + k] = s;
+	} else if (k == 0) {
+		double s = 0.0;
+		for (int j = y; j < n_tiles; j += RED_ROWS) s += LLpart[j];
+		stage[(int64_t)y * FSL + NACC * SA] = s;
+	}
+}
+__global__ __launch_bounds__(64) void k_reduce_factored2(const double *__restrict__ stage, double tiny_total, int n,
+                                                           double *__restrict__ out)
+{
+	const int k = threadIdx.x, q = blockIdx.x;
+	if (q == NACC) {
+		if (k == 0) {
+			double s = 0.0;
+			for (int y = 0; y < RED_ROWS; ++y) s += stage[(int64_t)y * FSL + NACC * SA];
+			out[NACC * n] = s;
+		}
+		return;
+	}
+	double s = 0.0;
+	for (int y = 0; y < RED_ROWS; ++y) s += stage[(int64_t)y * FSL + q * SA + k];
+	if (k < n) {
+		const double cells = q == 0 ? k : (q == 1 ? n - 1 - k : (q == 2 ? 1 : (q == 3 ? n - 1 - k : (q == 4 ? k : 1))));
+		out[q * n + k] = s + cells * tiny_total;
+	}
+}
+
+void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n)
+{
+	if (n <= 0) return;
+	const SweepItemA *items = (const SweepItemA *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
+	hipLaunchKernelGGL(k_bwd_acc_struct, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+	                   which == 1 ? 1 : (which == 2 ? 2 : 0), p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
+}
+void launch_reduce_factored(const EstepLaunch &p, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_reduce_factored1, dim3(NACC + 1, RED_ROWS), dim3(64), 0, st, p.d_Cpart, p.n_chunks, p.d_LLpart, p.d_stage);
+	hipLaunchKernelGGL(k_reduce_factored2, dim3(NACC + 1), dim3(64), 0, st, p.d_stage, p.tiny_total, p.n_states, p.d_stats);
+}
+
+} // namespace psmc

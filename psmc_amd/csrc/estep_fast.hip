@@ -598,7 +598,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0);
 		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
-		launch_bwd_count(p, sa, 0, nb0, p.n_items_b - nb0);
+		if (p.fused == 2) launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0); else launch_bwd_count(p, sa, 0, nb0, p.n_items_b - nb0);
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sa);
 		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
 	} else {
@@ -636,7 +636,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (lf) { (void)hipStreamWaitEvent(sm, p.evx[6], 0); launch_fwd_struct(p, sm, 3, 0, p.n_mem_f); }
 	if (p.fused) {
 		(void)hipEventRecord(p.evx[7], sm); (void)hipStreamWaitEvent(sa, p.evx[7], 0); // X of the run tiles
-		if (lb) { (void)hipStreamWaitEvent(sa, p.evx[6], 0); launch_bwd_count(p, sa, 3, 0, p.n_mem_b); }
+		if (lb) {
+			(void)hipStreamWaitEvent(sa, p.evx[6], 0);
+			if (p.fused == 2) launch_bwd_acc(p, sa, 3, 0, p.n_mem_b); else launch_bwd_count(p, sa, 3, 0, p.n_mem_b);
+		}
 	} else if (lb) { (void)hipStreamWaitEvent(sa, p.evx[6], 0); launch_bwd_struct(p, sa, 3, 0, p.n_mem_b); }
 	if (post_verify(ch[0]) || post_verify(ch[1])) return -1;
 	while (!(ch[0].done && ch[1].done)) {
@@ -661,7 +664,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 				if (p.structured) launch_fwd_struct(p, c.st, 1, 0, nd); else launch_fwd<true>(p, c.st);
 			} else {
 				rep->bwd_rounds++; rep->bwd_tiles += nd;
-				if (p.fused) launch_bwd_count(p, c.st, 1, 0, nd);
+				if (p.fused == 2) launch_bwd_acc(p, c.st, 1, 0, nd);
+				else if (p.fused) launch_bwd_count(p, c.st, 1, 0, nd);
 				else if (p.structured) launch_bwd_struct(p, c.st, 1, 0, nd);
 				else launch_bwd<true>(p, c.st);
 			}
@@ -677,7 +681,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (p.fused) {
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
-		launch_bwd_count(p, sm, 2, 0, p.n_chunks); // tiles whose X a forward repair rewrote after their counts were taken
+		// tiles whose X a forward repair rewrote after their counts were taken
+		if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else launch_bwd_count(p, sm, 2, 0, p.n_chunks);
 	} else if (ov) {
 		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // backward chain done
 		(void)hipStreamWaitEvent(sm, p.evx[3], 0);                                     // early expect done
@@ -691,7 +696,9 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
 	const int nC = p.n_chunks * p.n_sub;
-	if (p.ns == 128) {
+	if (p.fused == 2) {
+		launch_reduce_factored(p, sm);
+	} else if (p.ns == 128) {
 		hipLaunchKernelGGL(k_reduce1<128>, dim3(128 * 128 / 256 + 1, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
 		                   p.n_chunks, p.d_stage);
 		hipLaunchKernelGGL(k_reduce2<128>, dim3((128 * 128 + 3 * 128 + 1 + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,

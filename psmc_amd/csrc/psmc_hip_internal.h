@@ -42,7 +42,8 @@ struct EstepLaunch {
 	const double *d_sp;  // structured transition: P | R | qa | c | dd, 64 each (estep_struct.hip); valid when structured
 	int structured;      // a[k][l] = P_k qa_l (l<k), R_k c_l (l>k): O(N) sweeps, 4 tiles per wave
 	int walk_impl;       // 1: one wave per glued run, one state per lane (k_walk1_struct); 0: four runs per wave
-	int fused;           // structured only: backward sweep and counts in one kernel, bt never stored (estep_fused.hip)
+	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
+	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
 	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)
 	int n_items_f, n_items_b, tile_len;
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
@@ -91,6 +92,8 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 void launch_walks(const EstepLaunch &p, hipStream_t st);
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb);
 void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
+void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
+void launch_reduce_factored(const EstepLaunch &p, hipStream_t st);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
                        int ns, int32_t *path, double *maxp);
 int run_selftest(hipStream_t stream, unsigned *d_flags);

@@ -26,7 +26,7 @@ EXPORTS = [
     "psmc_hip_device_count", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
-    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info",
+    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe",
 ]
 
@@ -202,6 +202,17 @@ class HipEStep:
         a, e, a0 = self._params(a, e, a0)
         self._chk(self.lib.psmc_hip_estep_device(self.h, _p(a), _p(e), _p(a0), C.c_void_p(int(d_stats_ptr)),
                                                  C.c_void_p(int(stream_ptr))), "estep_device")
+
+    def estep_factored(self, a, e, a0):
+        """Fast mode, PSMC-form matrix: dict(sums (5, n) = SL, SU, DG, CL, CU; E (2, n); LL) without the N x N counts."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        e = np.ascontiguousarray(np.asarray(e, dtype=np.float64)[:2])
+        a0 = np.ascontiguousarray(a0, dtype=np.float64)
+        n = self.n
+        sums = np.zeros((5, n)); E = np.zeros((2, n)); LL = C.c_double(0)
+        self.lib.psmc_hip_estep_factored.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_double)]
+        self._chk(self.lib.psmc_hip_estep_factored(self.h, _p(a), _p(e), _p(a0), _p(sums), _p(E), C.byref(LL)), "estep_factored")
+        return dict(sums=sums, E=E, LL=LL.value)
 
     def fast_diag(self):
         wf = C.c_double(0); wb = C.c_double(0); nc = C.c_int(0); wu = C.c_int(0)

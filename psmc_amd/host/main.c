@@ -10,7 +10,7 @@
 #include "psmc_host.h"
 #include "psmc_hip.h"
 
-typedef struct { psmc_hip_ctx *ctx; int n_seg; double *chk; char msg[256]; } hip_be;
+typedef struct { psmc_hip_ctx *ctx; int n_seg, n_states; double *chk; char msg[256]; } hip_be;
 
 static int hb_load(void *self, int n_seg, const uint8_t *const *sym, const int32_t *L)
 {
@@ -30,6 +30,26 @@ static int hb_estep(void *self, const double *a, const double *e, const double *
 		if (chk) chk[i] = h->chk[i];
 	}
 	return 0;
+}
+static int hb_estep_factored(void *self, const double *a, const double *e, const double *a0, double *sums, double *E, double *LL)
+{
+	hip_be *h = (hip_be *)self;
+	int rc = psmc_hip_estep_factored(h->ctx, a, e, a0, sums, E, LL);
+	if (rc != PSMC_HIP_ENOTSUP) return rc;
+	/* a matrix without the two rank-1 triangles (e.g. -C): full counts, triangular sums on the host */
+	const int n = h->n_states;
+	double *A = (double *)calloc((size_t)n * n, sizeof(double));
+	rc = psmc_hip_estep(h->ctx, a, e, a0, A, E, 0, LL, h->chk);
+	if (rc == 0) {
+		memset(sums, 0, sizeof(double) * 5 * (size_t)n);
+		for (int k = 0; k < n; ++k)
+			for (int l = 0; l < n; ++l) {
+				const double v = A[(size_t)k * n + l];
+				if (l < k) { sums[k] += v; sums[3 * n + l] += v; } else if (l > k) { sums[n + k] += v; sums[4 * n + l] += v; } else sums[2 * n + k] = v;
+			}
+	}
+	free(A);
+	return rc;
 }
 static int hb_tables(void *self, int seg, double *f, double *b, double *s) { return psmc_hip_get_tables(((hip_be *)self)->ctx, seg, f, b, s); }
 static int hb_decode(void *self, int seg, int32_t *path, double *maxp) { return psmc_hip_decode(((hip_be *)self)->ctx, seg, path, maxp); }
@@ -62,13 +82,17 @@ int main(int argc, char *argv[])
 	}
 	hip_be h;
 	memset(&h, 0, sizeof h);
+	h.n_states = n_states;
 	int rc = psmc_hip_create(&h.ctx, n_states, dev_s ? atoi(dev_s) : 0, mode);
 	if (rc) {
 		fprintf(stderr, "psmc: cannot start the MI355X E-step (%s); this build has no CPU path\n", psmc_hip_strerror(rc));
 		psmc_options_free(&o);
 		return 2;
 	}
-	psmc_estep_backend be = {&h, hb_load, hb_estep, hb_tables, hb_decode, hb_error, hb_destroy};
+	/* the factored E-step goes with the O(N) objective: fast mode, n <= 64 (PSMC_FACTORED=0 keeps the full counts) */
+	const char *fs = getenv("PSMC_FACTORED");
+	const int use_factored = o.fast_mstep && mode == PSMC_HIP_MODE_FAST && n_states <= 64 && !(fs && atoi(fs) == 0);
+	psmc_estep_backend be = {&h, hb_load, hb_estep, hb_tables, hb_decode, use_factored ? hb_estep_factored : 0, hb_error, hb_destroy};
 	int status = psmc_run(&o, &be);
 	be.destroy(be.self);
 	psmc_options_free(&o);

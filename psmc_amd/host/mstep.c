@@ -150,17 +150,23 @@ int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, F
 	double *A = (double *)calloc((size_t)N * N, sizeof(double)), *E = (double *)calloc((size_t)2 * N, sizeof(double));
 	double LL = 0.0;
 	(void)in;
-	/* E-step on the device: em.c:33-55 */
+	/* E-step on the device: em.c:33-55.  With the O(N) objective only the triangular sums of A are needed, and
+	 * a backend that can produce them directly skips the n*n counts altogether. */
+	const int factored = m->fast_mstep && be->estep_factored != 0;
+	double *sums = factored ? (double *)calloc((size_t)5 * N, sizeof(double)) : 0;
 	const double t_e0 = now_ms();
-	int rc = be->estep(be->self, m->a, m->e, m->a0, A, E, &LL, 0);
+	int rc = factored ? be->estep_factored(be->self, m->a, m->e, m->a0, sums, E, &LL)
+	                  : be->estep(be->self, m->a, m->e, m->a0, A, E, &LL, 0);
 	const double t_e1 = now_ms();
-	if (rc) { free(A); free(E); return rc; }
+	if (rc) { free(A); free(E); free(sums); return rc; }
 	/* M-step: em.c:56-68 */
 	q_ctx c;
 	c.m = m; c.A = A; c.E = E; c.calls = 0;
-	c.Q0 = psmc_Q0(N, A, E);
+	c.Q0 = factored ? 0.0 : psmc_Q0(N, A, E); /* a constant of the search; needs the full matrix (only printed: QD line) */
 	c.sums = c.lf = 0;
-	if (m->fast_mstep) {
+	if (factored) {
+		c.sums = sums; c.lf = (double *)calloc((size_t)7 * N, sizeof(double));
+	} else if (m->fast_mstep) {
 		c.sums = (double *)calloc((size_t)5 * N, sizeof(double)); c.lf = (double *)calloc((size_t)7 * N, sizeof(double));
 		for (int k = 0; k < N; ++k)
 			for (int l = 0; l < N; ++l) {
@@ -173,7 +179,10 @@ int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, F
 	m->lk = LL;
 	double *x = (double *)calloc((size_t)m->n_params, sizeof(double));
 	memcpy(x, m->params, sizeof(double) * (size_t)m->n_params);
-	m->Q0 = psmc_Q(N, m->a, m->e, A, E, c.Q0);
+	if (factored) { double *xx = (double *)malloc(sizeof(double) * (size_t)m->n_params); /* Q at the current parameters, same objective */
+		memcpy(xx, m->params, sizeof(double) * (size_t)m->n_params);
+		const int keep = c.calls; m->Q0 = -neg_Q_fast(m->n_params, xx, &c); c.calls = keep; free(xx);
+	} else m->Q0 = psmc_Q(N, m->a, m->e, A, E, c.Q0);
 	m->Q1 = -psmc_hooke_jeeves(m->fast_mstep ? neg_Q_fast : neg_Q, m->n_params, x, &c, HJ_RADIUS, HJ_EPS, HJ_MAXCALL);
 	if (m->fast_mstep) { psmc_model_update(m); free(c.sums); free(c.lf); } /* a/e/a0/sigma of the LAST trial point, like em.c:21-22 */
 	if (getenv("PSMC_TIMING")) /* stderr only: the .psmc stream stays byte-identical */

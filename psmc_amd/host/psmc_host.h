@@ -91,6 +91,9 @@ typedef struct psmc_estep_backend {
 	int  (*tables)(void *self, int seg, double *f, double *b, double *s);
 	/* optional (may be NULL): posterior argmax path[L] and its probability maxp[L] (khmm.c:264-281) */
 	int  (*decode)(void *self, int seg, int32_t *path, double *maxp);
+	/* optional (may be NULL): the E-step without the n*n counts -- sums = SL | SU | DG | CL | CU (5n: the triangular
+	 * row / column sums of A and its diagonal), E 2n, LL; what the O(N) objective reads (fast M-step only) */
+	int  (*estep_factored)(void *self, const double *a, const double *e, const double *a0, double *sums, double *E, double *LL);
 	const char *(*error)(void *self);
 	void (*destroy)(void *self);
 } psmc_estep_backend;

@@ -34,6 +34,22 @@ static int ob_estep(void *self, const double *a, const double *e, const double *
 	free(c);
 	return 0;
 }
+/* the factored E-step of the HIP backend, restated with the oracle: triangular sums of its A */
+static int ob_estep_factored(void *self, const double *a, const double *e, const double *a0, double *sums, double *E, double *LL)
+{
+	orc_be *o = (orc_be *)self;
+	const int n = o->n;
+	double *A = (double *)calloc((size_t)n * n, sizeof(double));
+	int rc = ob_estep(self, a, e, a0, A, E, LL, 0);
+	memset(sums, 0, sizeof(double) * 5 * (size_t)n);
+	for (int k = 0; k < n; ++k)
+		for (int l = 0; l < n; ++l) {
+			const double v = A[(size_t)k * n + l];
+			if (l < k) { sums[k] += v; sums[3 * n + l] += v; } else if (l > k) { sums[n + k] += v; sums[4 * n + l] += v; } else sums[2 * n + k] = v;
+		}
+	free(A);
+	return rc;
+}
 static int ob_tables(void *self, int seg, double *f, double *b, double *s)
 {
 	orc_be *o = (orc_be *)self;
@@ -66,6 +82,7 @@ int main(int argc, char **argv)
 	orc_be ob; memset(&ob, 0, sizeof ob);
 	ob.n = pat.n_states;
 	ob.a = (double *)malloc(sizeof(double) * ob.n * ob.n); ob.e = (double *)malloc(sizeof(double) * 3 * ob.n); ob.a0 = (double *)malloc(sizeof(double) * ob.n);
-	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, 0, ob_error, ob_destroy};
+	const int fac = o.fast_mstep && getenv("PSMC_FACTORED") && atoi(getenv("PSMC_FACTORED")) != 0;
+	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, 0, fac ? ob_estep_factored : 0, ob_error, ob_destroy};
 	return psmc_run(&o, &be);
 }

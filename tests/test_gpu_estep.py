@@ -342,6 +342,42 @@ def test_fast_odd_tilings(hip, golden, oracle, opts):
     es.close()
 
 
+def tri_sums(A):
+    """SL, SU, DG, CL, CU of a count matrix (what the O(N) objective of psmc_amd/host/mstep.c reads)."""
+    lo, up = np.tril(A, -1), np.triu(A, 1)
+    return np.stack([lo.sum(1), up.sum(1), np.diag(A).copy(), lo.sum(0), up.sum(0)])
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0)])
+def test_fast_factored_statistics(hip, golden, oracle, opts):
+    """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
+    (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset."""
+    for key in ("n64_curve", "n23_flat"):
+        p = golden.params(key)
+        n = p["a"].shape[0]
+        o = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid)
+        want = tri_sums(o["A"])
+        es = hip.HipEStep(n, mode=hip.MODE_FAST, **opts)
+        es.load_segments(golden.segs_mid)
+        for it in range(3):
+            r = es.estep_factored(p["a"], p["e"], p["a0"])
+            assert relmax(r["sums"], want) < FAST_TOL_STATS and relmax(r["E"], o["E"]) < FAST_TOL_STATS
+            assert abs(r["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
+        check_fast(es.estep(p["a"], p["e"], p["a0"]), o)  # the full-matrix entry point on the same context
+        sel = [5, 4, 5, 3, 5]
+        es.select(sel)
+        o2 = oracle.estep(p["a"], p["e"], p["a0"], [golden.segs_mid[i] for i in sel])
+        r = es.estep_factored(p["a"], p["e"], p["a0"])
+        assert relmax(r["sums"], tri_sums(o2["A"])) < FAST_TOL_STATS and relmax(r["E"], o2["E"]) < FAST_TOL_STATS
+        es.close()
+    es = hip.HipEStep(8, mode=hip.MODE_FAST)
+    a, e, a0 = random_hmm(np.random.default_rng(0), 8)
+    es.load_segments([np.array([0, 1, 2, 0], np.uint8)])
+    with pytest.raises(hip.HipError):
+        es.estep_factored(a, e, a0)  # not of the PSMC form
+    es.close()
+
+
 def test_fast_learns_slow_regions(hip, golden, oracle):
     """Tiles that needed a repair are glued to their neighbour for the following E-steps of the
     context: the repair rounds disappear, the result stays inside the tolerance, and two contexts

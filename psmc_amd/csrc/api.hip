@@ -28,6 +28,10 @@ struct psmc_hip_ctx {
 	bool use_struct = false, planned_struct = false;
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
+	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
+	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
+	double *d_Kcol = nullptr; size_t kcol_cap = 0;
+	hipStream_t stream5 = nullptr;
 	int fuse = 0;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip); off: same speed, see DESIGN.md
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
 	int group_cap = 131072;    // "group_cap": longest run of glued tiles, in bins
@@ -75,7 +79,7 @@ struct psmc_hip_ctx {
 	       *d_LLpart = nullptr;
 	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
 	hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;
-	hipEvent_t evx[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t evx[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	int n_long_f = 0, n_long_b = 0, n_mem_f = 0, n_mem_b = 0;
 	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
@@ -156,7 +160,8 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	for (int i = 0; i < 8; ++i)
+	if (hipStreamCreateWithFlags(&c->stream5, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
@@ -177,17 +182,19 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (c->stream3) (void)hipStreamSynchronize(c->stream3);
 	if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+	if (c->stream5) (void)hipStreamSynchronize(c->stream5);
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items, c->d_Kcol};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_ritems) (void)hipHostFree(c->h_ritems);
 	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	for (int i = 0; i < 8; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+	for (int i = 0; i < 10; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
 	if (c->stream4) (void)hipStreamDestroy(c->stream4);
+	if (c->stream5) (void)hipStreamDestroy(c->stream5);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->stream3) (void)hipStreamDestroy(c->stream3);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -204,6 +211,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
+	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->plan_dirty = true; }
@@ -568,7 +576,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_items, (size_t)12 * nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_items, (size_t)24 * nc + 64))) return rc;
 		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
 		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
 		    hipHostGetDevicePointer((void **)&c->m_ritems, c->h_ritems, 0) != hipSuccess)
@@ -638,6 +646,47 @@ static int build_items(psmc_hip_ctx *c)
 	while (c->n_long_b < c->n_items_b && kb[c->n_long_b].second.second > 1) ++c->n_long_b;
 	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
+	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": only its head tile is walked
+	// (from the usual speculative warm-up); the boundary vectors of its other tiles come from the transfer matrices.
+	//   d_items + 12nc: wl_f (2nc) | wl_b (2nc) | kc tiles (4nc: KcTile) | runs (4nc + : KcRun)
+	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b;
+	c->n_wl_f = c->n_wl_b = 0;
+	const bool chains = c->kc_min >= 2 && c->ns == 64;
+	auto add_runs = [&](const std::vector<std::pair<long long, std::pair<int, int>>> &k, int n_long, bool bwd) {
+		int &nw = bwd ? c->n_wl_b : c->n_wl_f;
+		std::vector<int> &rv = bwd ? runs_b : runs_f;
+		int *w = wl.data() + (bwd ? (size_t)2 * nc : 0);
+		for (int i = 0; i < n_long; ++i) {
+			int first = k[i].second.first, count = k[i].second.second;
+			if (chains && count >= c->kc_min && !bwd && c->chunks[first].lo == 1) {
+				// position 1 is an initial condition, not a step: there is no X_0 for a transfer matrix to start from.
+				// Walk through the first tile as well and chain from the second one.
+				w[2 * nw] = first; w[2 * nw + 1] = 2; ++nw;
+				first += 1; count -= 1;
+				if (count >= 2) {
+					rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
+					for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
+				}
+			} else if (chains && count >= c->kc_min) {
+				w[2 * nw] = bwd ? first + count - 1 : first; w[2 * nw + 1] = 1; ++nw; // head tile only
+				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
+				if (!bwd) for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
+				else for (int t = first + count - 1; t > first; --t) { kc.push_back(t); kc.push_back(1); }
+			} else { w[2 * nw] = first; w[2 * nw + 1] = count; ++nw; }
+		}
+	};
+	add_runs(kf, c->n_long_f, false);
+	add_runs(kb, c->n_long_b, true);
+	c->n_chain_f = (int)runs_f.size() / 4; c->n_chain_b = (int)runs_b.size() / 4; c->n_kc = (int)kc.size() / 2;
+	if ((size_t)c->n_kc > (size_t)2 * nc || (size_t)(c->n_chain_f + c->n_chain_b) > (size_t)nc) return fail(c, PSMC_HIP_ESTATE, "build_items: list overflow");
+	HIPCHK(c, hipMemcpy(c->d_items + (size_t)12 * nc, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice));
+	if (c->n_kc > 0) {
+		std::vector<int> runs(runs_f); runs.insert(runs.end(), runs_b.begin(), runs_b.end());
+		HIPCHK(c, hipMemcpy(c->d_items + (size_t)16 * nc, kc.data(), sizeof(int) * kc.size(), hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_items + (size_t)20 * nc, runs.data(), sizeof(int) * runs.size(), hipMemcpyHostToDevice));
+		const size_t need = (size_t)c->n_kc * (4096 + 64);
+		if (need > c->kcol_cap) { int rc; if ((rc = dev_alloc(c, &c->d_Kcol, need))) return rc; c->kcol_cap = need; }
+	}
 	c->items_dirty = false;
 	return 0;
 }
@@ -681,7 +730,11 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.stream2 = c->stream2; p.stream3 = c->stream3; p.stream4 = c->stream4; p.overlap = c->overlap;
 	p.n_long_f = c->n_long_f; p.n_long_b = c->n_long_b; p.n_mem_f = c->n_mem_f; p.n_mem_b = c->n_mem_b;
 	p.d_members_f = c->d_items + 8 * p.n_chunks; p.d_members_b = c->d_items + 10 * p.n_chunks;
-	for (int i = 0; i < 8; ++i) p.evx[i] = c->evx[i];
+	p.d_wl_f = c->d_items + 12 * (size_t)p.n_chunks; p.d_wl_b = c->d_items + 14 * (size_t)p.n_chunks; p.n_wl_f = c->n_wl_f; p.n_wl_b = c->n_wl_b;
+	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
+	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
+	p.d_Kcol = c->d_Kcol; p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * 4096 : nullptr; p.stream5 = c->stream5;
+	for (int i = 0; i < 10; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
 	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());

@@ -210,15 +210,18 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 // ------------------------------------------------------------------ verify
 // flags tiles whose boundary vector disagrees with the neighbour's converged
 // one; cnt[0] = number flagged, warm[which] = largest mismatch seen this round
-// max_k |x-y| / max_k |y| over S = 64 or 128 states (lane and lane + 64)
+// max_k |x/|x| - y/|y|| / max_k (y/|y|) over S = 64 or 128 states (lane and lane + 64), |.| = sum: boundary
+// vectors are compared as DIRECTIONS (a vector from the transfer-matrix chain has an arbitrary scale; every
+// consumer -- per-position normaliser of the counts, k_ll -- is scale-free)
 template <int S> __device__ __forceinline__ double rel_mismatch_vec(const double *x, const double *y, int lane) {
-	double xv = x[lane], yv = y[lane];
-	double num = fabs(xv - yv), den = fabs(yv);
-	bool bad = (xv != xv) || (yv != yv);
+	double xv = x[lane], yv = y[lane], xw = 0.0, yw = 0.0;
+	if (S == 128) { xw = x[64 + lane]; yw = y[64 + lane]; }
+	const double ix = 1.0 / wave_add(xv + xw), iy = 1.0 / wave_add(yv + yw);
+	double num = fabs(xv * ix - yv * iy), den = fabs(yv * iy);
+	bool bad = (xv != xv) || (yv != yv) || (ix != ix) || (iy != iy);
 	if (S == 128) {
-		xv = x[64 + lane]; yv = y[64 + lane];
-		num = fmax(num, fabs(xv - yv)); den = fmax(den, fabs(yv));
-		bad = bad || (xv != xv) || (yv != yv);
+		num = fmax(num, fabs(xw * ix - yw * iy)); den = fmax(den, fabs(yw * iy));
+		bad = bad || (xw != xw) || (yw != yw);
 	}
 	num = wave_max(num); den = wave_max(den);
 	return __any(bad) ? __builtin_inf() : num / den;
@@ -429,7 +432,8 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 // for the last tile): running products flushed through log() like hmm_lk (khmm.c:245-260).
 template <int S>
 __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, const double *__restrict__ f,
-                                             const double *__restrict__ invd, double *__restrict__ LLpart)
+                                             const double *__restrict__ invd, const double *__restrict__ entry,
+                                             double *__restrict__ LLpart)
 {
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x];
@@ -442,6 +446,11 @@ __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, con
 	}
 	ll -= log(prod);
 	ll = wave_add(ll);
+	if (c.lo > 1) { // the tile was computed from entry = X_{lo-1} up to a factor: put the telescoping sum back in step
+		double u = f[(c.off + c.lo - 2) * S + lane], v = entry[(int64_t)blockIdx.x * S + lane];
+		if (S == 128) { u += f[(c.off + c.lo - 2) * S + 64 + lane]; v += entry[(int64_t)blockIdx.x * S + 64 + lane]; }
+		ll += log(wave_add(u)) - log(wave_add(v));
+	}
 	if (c.hi == c.L) {
 		double v = f[(c.off + c.L - 1) * S + lane];
 		if (S == 128) v += f[(c.off + c.L - 1) * S + 64 + lane];
@@ -575,8 +584,25 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	hipStream_t sw = ov ? p.stream4 : sm;
 	if (lw) { // both directions in one launch on one extra stream (hardware queues are scarce)
 		if (ov) (void)hipStreamWaitEvent(sw, p.evx[0], 0);
-		launch_walks(p, sw);
+		launch_walks(p, sw); // short runs, and the head tile of every long run
+		if (p.n_kc > 0) { // long runs: transfer matrices of their tiles (a stream of their own), then the chain
+			hipStream_t sk = ov ? p.stream5 : sm;
+			if (ov) (void)hipStreamWaitEvent(sk, p.evx[0], 0);
+			launch_kchain(p, sk, sw, p.evx[8]);
+		}
 		(void)hipEventRecord(p.evx[6], sw);
+		// All boundary vectors of the runs exist: recompute their tiles right away, beside the bulk (forward on
+		// the walk stream, backward on the transfer-matrix stream), so that the counts find them finished.
+		hipStream_t sk = ov ? p.stream5 : sm;
+		if (lf) launch_fwd_struct(p, sw, 3, 0, p.n_mem_f);
+		(void)hipEventRecord(p.evx[7], sw);
+		if (ov) (void)hipStreamWaitEvent(sk, p.fused ? p.evx[7] : p.evx[6], 0); // fused: the backward pass reads the run tiles' X
+		if (lb) {
+			if (p.fused == 2) launch_bwd_acc(p, sk, 3, 0, p.n_mem_b);
+			else if (p.fused) launch_bwd_count(p, sk, 3, 0, p.n_mem_b);
+			else launch_bwd_struct(p, sk, 3, 0, p.n_mem_b);
+		}
+		(void)hipEventRecord(p.evx[9], sk);
 	}
 	const int ff0 = lf ? p.n_long_f : 0, fb0 = lb ? p.n_long_b : 0;
 	const bool one = p.structured && !p.fused; // both bulk sweeps in one launch (k_sweep_struct)
@@ -610,6 +636,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (ov) { // early expect over every tile once both sweeps exist
 			(void)hipEventRecord(p.evx[2], sa);
 			(void)hipStreamWaitEvent(sx, p.evx[1], 0); (void)hipStreamWaitEvent(sx, p.evx[2], 0);
+			if (lw) { (void)hipStreamWaitEvent(sx, p.evx[7], 0); (void)hipStreamWaitEvent(sx, p.evx[9], 0); } // run tiles
 			if (p.ev[8]) (void)hipEventRecord(p.ev[8], sx);
 			launch_expect(p, sx, 0);
 			if (p.ev[9]) (void)hipEventRecord(p.ev[9], sx);
@@ -633,14 +660,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		c.pending = true;
 		return 0;
 	};
-	if (lf) { (void)hipStreamWaitEvent(sm, p.evx[6], 0); launch_fwd_struct(p, sm, 3, 0, p.n_mem_f); }
-	if (p.fused) {
-		(void)hipEventRecord(p.evx[7], sm); (void)hipStreamWaitEvent(sa, p.evx[7], 0); // X of the run tiles
-		if (lb) {
-			(void)hipStreamWaitEvent(sa, p.evx[6], 0);
-			if (p.fused == 2) launch_bwd_acc(p, sa, 3, 0, p.n_mem_b); else launch_bwd_count(p, sa, 3, 0, p.n_mem_b);
-		}
-	} else if (lb) { (void)hipStreamWaitEvent(sa, p.evx[6], 0); launch_bwd_struct(p, sa, 3, 0, p.n_mem_b); }
+	if (lw && ov) { (void)hipStreamWaitEvent(sm, p.evx[7], 0); (void)hipStreamWaitEvent(sa, p.evx[9], 0); } // run tiles done
 	if (post_verify(ch[0]) || post_verify(ch[1])) return -1;
 	while (!(ch[0].done && ch[1].done)) {
 		bool progressed = false;
@@ -676,8 +696,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (hipStreamSynchronize(sm) != hipSuccess) return -1;
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
 	// ---- counts + log-likelihood from the final tables
-	if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
-	else hipLaunchKernelGGL(k_ll<64>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_LLpart);
+	if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
+	else hipLaunchKernelGGL(k_ll<64>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
 	if (p.fused) {
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);

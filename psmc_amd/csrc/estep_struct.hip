@@ -320,7 +320,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	double x[NPL]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
 	int p_first;
 	if (REPAIR) { // continue from the value the tile above computed at our top boundary
-		if (valid && m == 0) touch_b[t_top] = 1;
+		if (valid && m == 0 && !(flags & SWEEP_NO_TOUCH)) touch_b[t_top] = 1;
 		if (from_entry) loadN<NPL>(bentry + (int64_t)t_top * S + k0, x); // the boundary vector a walk left for this tile
 		else loadN<NPL>(bexit + (int64_t)(t_top + 1) * S + k0, x);
 		p_first = cur.top;
@@ -460,6 +460,109 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 	}
 }
 
+// ------------------------------------------------------------------ transfer matrices of the long runs
+// A walk over a run of r tiles is r*T sequential steps.  For the LONG runs the sequential part is taken out:
+// the linear map of every tile (K_t: start vector -> exit vector) is computed column by column -- 64 unit
+// vectors swept through the tile, 4 per wave, all tiles of all runs at once -- and a tiny chain kernel then
+// applies the K_t one after the other (a 64 x 64 product each).  Columns are kept comparable by scaling
+// with powers of two only (exact) and carrying the exponent.
+struct KcTile { int tile, dir; }; // dir 0: forward (lo..hi), 1: backward (top..lo)
+
+__global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                      const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
+                                                      const KcTile *__restrict__ kc, double *__restrict__ Kcol,
+                                                      double *__restrict__ Kexp)
+{
+	constexpr int NPL = 4, S = 64;
+	__shared__ double lds_e[4 * S];
+	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
+	fill_lds_e<S>(lds_e, e, lane);
+	__syncthreads();
+	const int j = blockIdx.x >> 4, col = 4 * (blockIdx.x & 15) + (lane >> 4);
+	const KcTile kt = kc[j];
+	const Chunk c = chunks[kt.tile];
+	const bool fwd = kt.dir == 0;
+	// backward: the map stops above the tile's lowest scaled position p* (the first p >= lo with p % 4 == 0); the
+	// chain kernel takes the last steps p* .. lo itself, with the real scale factor, so that the exit vector has
+	// the scale a sweep would give it (the counts at a tile boundary mix bt of the two neighbours)
+	const int top = fwd ? c.hi : min(c.hi, c.L - 1);
+	const int lo = fwd ? c.lo : min(((c.lo + 3) & ~3) + 1, top + 1);
+	const uint8_t *o = obs + c.off;
+	StructParN<NPL> sc;
+	load_struct_par<NPL>(sp, k0, fwd, sc);
+	double x[NPL];
+#pragma unroll
+	for (int i = 0; i < NPL; ++i) x[i] = (k0 + i == col) ? 1.0 : 0.0;
+	int E = 0;
+	const int n = top - lo + 1;
+	for (int q = 0; q < n; ++q) {
+		const int p = fwd ? lo + q : top - q;
+		const int sym = (int)o[p - 1] & 3; // wave-uniform: a scalar byte load
+		double ev[NPL];
+		loadN<NPL>(lds_e + sym * S + k0, ev);
+		if ((p & 3) == 0) { // rescale the column by a power of two and remember the exponent
+			const double s = row_sum16(lane_sum<NPL>(x));
+			const int ex = s > 0.0 ? __builtin_amdgcn_frexp_exp(s) : 0;
+#pragma unroll
+			for (int i = 0; i < NPL; ++i) x[i] = __builtin_amdgcn_ldexp(x[i], -ex);
+			E += ex;
+		}
+		struct_step<NPL>(sc, x);
+#pragma unroll
+		for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
+	}
+	storeN<NPL>(Kcol + ((int64_t)j * 64 + col) * 64 + k0, x);
+	if (m == 0) Kexp[(int64_t)j * 64 + col] = (double)E;
+}
+
+// run r: forward (r < n_f): entry[first+1 .. first+count-1] from entry[first];  backward: bentry[first+count-2 .. first]
+// from bentry[first+count-1].  The vectors are left with sum 1 (the verify kernel and k_ll are scale-free).
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+	return v;
+}
+struct KcRun { int first, count, kc0, pad; }; // kc0: index of the run's first transfer matrix in Kcol
+
+__global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ runs, int n_f, const double *__restrict__ Kcol,
+                                                        const double *__restrict__ Kexp, const double *__restrict__ sp,
+                                                        const double *__restrict__ e, const uint8_t *__restrict__ obs,
+                                                        const Chunk *__restrict__ chunks, double *__restrict__ entry,
+                                                        double *__restrict__ bentry)
+{
+	const int lane = threadIdx.x;
+	const bool fwd = (int)blockIdx.x < n_f;
+	const KcRun r = runs[blockIdx.x];
+	double *vec = fwd ? entry : bentry;
+	int t = fwd ? r.first : r.first + r.count - 1;
+	double x = vec[(int64_t)t * 64 + lane];
+	const WaveScanMasks wm = wave_scan_masks(lane);
+	StructPar1 s1; s1.mS = sp[192 + lane]; s1.wS = sp[64 + lane]; s1.mP = sp[128 + lane]; s1.wP = sp[lane]; s1.dd = sp[256 + lane]; // backward
+	const double e0 = e[lane], e1 = e[64 + lane];
+	for (int q = 0; q + 1 < r.count; ++q) {
+		const int64_t kb = (int64_t)(r.kc0 + q) * 64;
+		const double ex = Kexp[kb + lane];
+		const double emax = wave_max_f64(x > 0.0 ? ex : -1e300);
+		const double xs = x > 0.0 ? __builtin_amdgcn_ldexp(x, (int)(ex - emax)) : 0.0;
+		double y = 0.0;
+		for (int k = 0; k < 64; ++k) y = __builtin_fma(readlane_f64(xs, k), Kcol[(kb + k) * 64 + lane], y);
+		y *= rcp_newton(first_lane_f64(wave_sum_nat(y)));
+		if (!fwd) { // the tile's last steps p* .. lo with the sweep's own scaling: bt_lo as the sweep leaves it
+			const Chunk c = chunks[t];
+			const int top = min(c.hi, c.L - 1), ps = min((c.lo + 3) & ~3, top);
+			const uint8_t *o = obs + c.off;
+			for (int pp = ps; pp >= c.lo; --pp) {
+				double ev = walk_ev((int)o[pp - 1] & 3, e0, e1);
+				if ((pp & 3) == 0) ev *= rcp_newton(first_lane_f64(wave_sum_nat(y)));
+				y = struct_step1(s1, y, wm) * ev;
+			}
+		}
+		t += fwd ? 1 : -1;
+		vec[(int64_t)t * 64 + lane] = y;
+		x = y;
+	}
+}
+
 // The bulk of both sweeps in ONE launch: even blocks walk forward items, odd blocks backward items (as long
 // as both lists last), so the two table writers share the chip from the first to the last wave and the
 // E-step needs one stream less.  Per launch: 2 x (8n+9) algorithmic bytes per bin.
@@ -517,7 +620,7 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
-	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | (p.fused ? SWEEP_NO_TOUCH : 0)) : 0);
+	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0); // run tiles are done before the counts start
 #define PSMC_LF(REP, NPL) hipLaunchKernelGGL((k_fwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
 	const bool rep = !(which == 0 || which == 2);
@@ -530,7 +633,7 @@ void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
-	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? SWEEP_FROM_ENTRY : (which == 4 ? SWEEP_TOP_ONLY : 0));
+	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? SWEEP_TOP_ONLY : 0));
 #define PSMC_LB(REP, NPL) hipLaunchKernelGGL((k_bwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, \
 		n_items, p.warmup, p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b)
 	const bool rep = !(which == 0 || which == 2 || which == 4);
@@ -555,19 +658,28 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 	if (p.ns == 128) PSMC_LS(8); else PSMC_LS(4);
 #undef PSMC_LS
 }
+void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols)
+{
+	if (p.n_kc <= 0) return;
+	hipLaunchKernelGGL(k_kcol_struct, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
+	                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
+	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
+	hipLaunchKernelGGL(k_kchain_struct, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
+	                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry);
+}
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {
 	if (p.walk_impl == 1 && p.ns == 64) { // one wave per run, one state per lane
-		if (p.n_long_f + p.n_long_b <= 0) return;
-		hipLaunchKernelGGL(k_walk1_struct, dim3(p.n_long_f + p.n_long_b), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
-		                   (const SweepItem *)p.d_items_f, p.n_long_f, (const SweepItem *)p.d_items_b, p.n_long_b, p.warmup,
+		if (p.n_wl_f + p.n_wl_b <= 0) return;
+		hipLaunchKernelGGL(k_walk1_struct, dim3(p.n_wl_f + p.n_wl_b), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+		                   (const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup,
 		                   p.tile_len, p.d_entry, p.d_bentry, p.d_bexit);
 		return;
 	}
-	const int nb = (p.n_long_f + 3) / 4 + (p.n_long_b + 3) / 4;
+	const int nb = (p.n_wl_f + 3) / 4 + (p.n_wl_b + 3) / 4;
 	if (nb <= 0) return;
 #define PSMC_LW(NPL) hipLaunchKernelGGL(k_walk_struct<NPL>, dim3(nb), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
-		(const SweepItem *)p.d_items_f, p.n_long_f, (const SweepItem *)p.d_items_b, p.n_long_b, p.warmup, p.tile_len, \
+		(const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup, p.tile_len, \
 		p.d_entry, p.d_bentry, p.d_bexit)
 	if (p.ns == 128) PSMC_LW(8); else PSMC_LW(4);
 #undef PSMC_LW

@@ -29,7 +29,7 @@ struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged;
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
 	hipStream_t stream, stream2, stream3; // forward chain (main), backward chain, early expect
-	hipEvent_t evx[8];           // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
+	hipEvent_t evx[10];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
 	int overlap;
 	int rep_impl, expect_impl, n_states;
 	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)
@@ -49,7 +49,11 @@ struct EstepLaunch {
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
-	hipStream_t stream4;
+	hipStream_t stream4, stream5;
+	// walks: heads of the chain runs (count 1) followed by the short runs; transfer-matrix chains of the long runs
+	const int *d_wl_f, *d_wl_b; int n_wl_f, n_wl_b;
+	const int *d_kc, *d_kruns; int n_kc, n_chain_f, n_chain_b; // KcTile[n_kc], KcRun[n_chain_f + n_chain_b]
+	double *d_Kcol, *d_Kexp;                                  // [n_kc][64][64], [n_kc][64]
 	int *d_ritems_f, *d_ritems_b;     // [n_chunks][2] flagged tiles of the current repair round as one-tile items
 	int *h_ritems;                    // host view of pinned, device-mapped [2][n_chunks][2]: the same lists, so that the host can learn the groups
 	int *m_ritems, *m_cnt;            // device views of the mapped h_ritems / h_cnt (written by k_compact, no copy commands)
@@ -90,6 +94,7 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 void launch_walks(const EstepLaunch &p, hipStream_t st);
+void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols);
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb);
 void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
 void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n);

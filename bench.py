@@ -227,6 +227,19 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(a, e, a0, segs, args.cpu_sample)
+        if world == 1 and mode == hip.MODE_FAST and diag.get("structured"):
+            try:  # the same E-step without the N x N counts: what the psmc binary uses with the O(N) objective
+                for _ in range(3):
+                    es.estep_factored(a, e, a0)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    es.estep_factored(a, e, a0)
+                dtf = (time.perf_counter() - t1) / 5
+                out["factored_stats"] = {"value": bins / dtf, "unit": "bins/s", "ms_per_step": dtf * 1e3, "kernels_ms": es.timing(),
+                                         "note": "psmc_hip_estep_factored: triangular sums of A, E, LL from the backward sweep in O(N) "
+                                                 "per bin (no counts GEMM, no bt table); blocking call incl. read-back"}
+            except Exception as ex_:
+                out["factored_stats"] = {"error": str(ex_)}
         if world == 1 and args.exact_extra > 0 and mode == hip.MODE_FAST:
             try:
                 es.close(); del es

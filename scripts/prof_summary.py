@@ -12,7 +12,7 @@ def short(nm):
     for k in ('k_fwd_fast', 'k_bwd_fast', 'k_fwd_struct', 'k_bwd_struct'):
         if k in nm: return k + ('<repair>' if rep else '<speculate>')
     if 'k_verify' in nm: return 'k_verify' + ('<bwd>' if rep else '<fwd>')
-    m = re.search(r'psmc::(k_[a-z0-9_]+)', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)E', nm)
+    m = re.search(r'psmc::(k_[a-z0-9_]+)', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)(?:IL|E)', nm)
     return m.group(1) if m else nm.split('(')[0][:40]
 
 db = os.path.join(ROOT, "gpurun_out", "prof", "bench_results.db")

@@ -656,9 +656,14 @@ static int build_items(psmc_hip_ctx *c)
 		int &nw = bwd ? c->n_wl_b : c->n_wl_f;
 		std::vector<int> &rv = bwd ? runs_b : runs_f;
 		int *w = wl.data() + (bwd ? (size_t)2 * nc : 0);
+		// a transfer matrix costs 16 tile sweeps: keep them for the longest runs (the list is sorted longest first)
+		// and let the rest walk -- at most 1/16 of the tiles, i.e. about one more bulk sweep of work
+		int budget = std::max(64, nc / 16);
 		for (int i = 0; i < n_long; ++i) {
 			int first = k[i].second.first, count = k[i].second.second;
-			if (chains && count >= c->kc_min && !bwd && c->chunks[first].lo == 1) {
+			const bool chain = chains && count >= c->kc_min && count - 1 <= budget;
+			if (chain) budget -= count - 1;
+			if (chain && !bwd && c->chunks[first].lo == 1) {
 				// position 1 is an initial condition, not a step: there is no X_0 for a transfer matrix to start from.
 				// Walk through the first tile as well and chain from the second one.
 				w[2 * nw] = first; w[2 * nw + 1] = 2; ++nw;
@@ -667,7 +672,7 @@ static int build_items(psmc_hip_ctx *c)
 					rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
 					for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
 				}
-			} else if (chains && count >= c->kc_min) {
+			} else if (chain) {
 				w[2 * nw] = bwd ? first + count - 1 : first; w[2 * nw + 1] = 1; ++nw; // head tile only
 				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
 				if (!bwd) for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }

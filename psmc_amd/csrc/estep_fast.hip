@@ -273,7 +273,7 @@ __device__ __forceinline__ bool tile_touched(const Chunk *__restrict__ chunks, i
 // S = 128 (the fast path of -p "64*2"): C is cut into (S/64)^2 quadrants of 64x64, one wave each; every
 // wave still reduces G over all S states.  blockIdx.x = partial * (S/64)^2 + quadrant.
 template <int S>
-__global__ __launch_bounds__(64, S == 64 ? 2 : 1) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
+__global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__ chunks, int n_sub,
                                                          const uint8_t *__restrict__ obs, const double *__restrict__ f,
                                                          const double *__restrict__ bt, const double *__restrict__ sb,
                                                          const double *__restrict__ re, double *__restrict__ Cpart,
@@ -322,7 +322,9 @@ __global__ __launch_bounds__(64, S == 64 ? 2 : 1) void k_expect_mfma(const Chunk
 			double FN[NB], BN[4] = {0, 0, 0, 0}, BQ[NB], scn = 1.0; int symn = 2; bool okn = false;
 #pragma unroll
 			for (int m = 0; m < NB; ++m) { FN[m] = 0.0; BQ[m] = 0.0; }
-			if (p + 4 <= p1) load(p + 4, FN, BN, BQ, scn, symn, okn);
+			// S = 64: the next group's operands are fetched a group ahead; S = 128 has no registers to spare for that and
+			// relies on the second wave of the SIMD instead (the loads are issued after the MFMAs)
+			if (S == 64 && p + 4 <= p1) load(p + 4, FN, BN, BQ, scn, symn, okn);
 			// per-position normaliser: row group t reduces its own position over the S states
 			double g[NB], G = 0.0;
 #pragma unroll
@@ -351,11 +353,15 @@ __global__ __launch_bounds__(64, S == 64 ? 2 : 1) void k_expect_mfma(const Chunk
 #pragma unroll
 				for (int nn = 0; nn < 4; ++nn)
 					acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(FM[m], BM[nn], acc[m][nn], 0, 0, 0);
+			if (S != 64 && p + 4 <= p1) load(p + 4, FA, BM, BP, sc, sym, ok);
+			else if (S != 64) ok = false;
+			if (S == 64) {
 #pragma unroll
-			for (int m = 0; m < NB; ++m) { FA[m] = FN[m]; BP[m] = BQ[m]; }
+				for (int m = 0; m < NB; ++m) { FA[m] = FN[m]; BP[m] = BQ[m]; }
 #pragma unroll
-			for (int m = 0; m < 4; ++m) BM[m] = BN[m];
-			sc = scn; sym = symn; ok = okn;
+				for (int m = 0; m < 4; ++m) BM[m] = BN[m];
+				sc = scn; sym = symn; ok = okn;
+			}
 		}
 	}
 	const double mult = (double)c.mult;

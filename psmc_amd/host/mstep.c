@@ -113,6 +113,7 @@ double psmc_hooke_jeeves(psmc_objective f, int n, double *x, void *data, double 
 
 typedef struct {
 	psmc_model *m; const double *A, *E; double Q0; int calls;
+	int simd;          /* the CPU has AVX2: vectorised log factors (fastq.c) */
 	double *sums, *lf; /* fast objective: SL | SU | DG | CL | CU (5N, from A, once per round); 7N log factors per call */
 } q_ctx;
 
@@ -126,7 +127,7 @@ static double neg_Q_fast(int n, double *x, void *data)
 	const int N = c->m->pat.n_states;
 	++c->calls;
 	for (int i = 0; i < n; ++i) c->m->params[i] = fabs(x[i]);
-	if (!psmc_model_logfactors(c->m, c->lf)) return -Q_MINUS_INF;
+	if (!(c->simd ? psmc_model_logfactors_simd(c->m, c->lf) : psmc_model_logfactors(c->m, c->lf))) return -Q_MINUS_INF;
 	const double *lFL = c->lf, *lFU = lFL + N, *lD = lFU + N, *lqa = lD + N, *lc = lqa + N, *le0 = lc + N, *le1 = le0 + N;
 	const double *SL = c->sums, *SU = SL + N, *DG = SU + N, *CL = DG + N, *CU = CL + N;
 	double sum = 0.0;
@@ -164,6 +165,7 @@ int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, F
 	c.m = m; c.A = A; c.E = E; c.calls = 0;
 	c.Q0 = factored ? 0.0 : psmc_Q0(N, A, E); /* a constant of the search; needs the full matrix (only printed: QD line) */
 	c.sums = c.lf = 0;
+	c.simd = __builtin_cpu_supports("avx2") && !getenv("PSMC_NO_SIMD");
 	if (factored) {
 		c.sums = sums; c.lf = (double *)calloc((size_t)7 * N, sizeof(double));
 	} else if (m->fast_mstep) {

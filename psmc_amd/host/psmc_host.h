@@ -72,6 +72,7 @@ void psmc_model_free(psmc_model *m);
 void psmc_model_update(psmc_model *m);                       /* psmc_update_hmm, core.c:61-133 */
 void psmc_model_avg_t(const psmc_model *m, double *avg_t);   /* psmc_avg_t, core.c:135-162 */
 int  psmc_model_logfactors(psmc_model *m, double *out7N);    /* logs of the factors of a[][] and e[][] (fast M-step) */
+int  psmc_model_logfactors_simd(psmc_model *m, double *out7N); /* the same, vectorised (fastq.c; AVX2 + libmvec) */
 void psmc_model_cap(psmc_model *m, int k0);                  /* psmc_cap_matrix, aux.c:115-127 */
 
 /* ---- M-step pieces (khmm.c:326-382, kmin.c:48-107, em.c:15-25) */

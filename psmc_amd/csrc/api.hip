@@ -713,7 +713,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep: no segments loaded");
 	int rc;
-	if ((rc = ensure_tables(c, true))) return rc;
+	if ((rc = ensure_tables(c, !c->want_factored))) return rc; // the factored statistics never store the backward table
 	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
 	if (c->ns == 128 && !c->use_struct)
 		return fail(c, PSMC_HIP_ENOTSUP, "fast mode beyond 64 states needs a transition matrix of the PSMC form (structured sweeps)");

@@ -1,4 +1,8 @@
-// estep_fast.hip -- FAST mode of the PSMC E-step for gfx950.
+// estep_fast.hip -- FAST mode of the PSMC E-step for gfx950: the protocol (speculate / verify / repair,
+// streams, reductions: launch_fast), the kernels every variant shares (k_verify, k_expect_mfma, k_ll,
+// k_reduce*) and the DENSE sweeps for arbitrary transition matrices.  Matrices of the PSMC form take the
+// O(N) sweeps of estep_struct.hip instead (default whenever they apply); estep_fused.hip and
+// estep_factored.hip are alternative back halves (counts fused into the backward sweep / no N x N counts).
 //
 // Same mathematics as khmm.c's hmm_forward / hmm_backward / hmm_expect
 // (lh3/psmc khmm.c:145-190, 210-241, 297-324) but re-associated for the GPU:

@@ -56,7 +56,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront), "learn" (1: tiles
  * that needed a repair are glued to their neighbour for the following E-steps of this context;
  * results then depend on the call history within the stated tolerance), "group_cap" (bins), "fuse" (1: with the structured sweeps, backward sweep and counts
- * in one kernel -- bt never stored, half the HBM traffic, FP64-issue bound; default 0). */
+ * in one kernel -- bt never stored, half the HBM traffic, FP64-issue bound; default 0), "ckpt" (1, default:
+ * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
@@ -140,6 +141,17 @@ int psmc_hip_microbench(int device, double *out, int n);
  * launches) to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the access
  * width the kernels use; *ms_out = average duration of one launch. */
 int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out);
+
+/* Diagnostic: what plain streaming kernels reach on this device with 16-byte accesses over two
+ * buffers of `bytes` each: gbps_out[0] fill, [1] read, [2] copy (read + write), [3] the store
+ * pattern of the structured sweeps (four 512-byte-per-step streams per wave).  GB/s. */
+int psmc_hip_hbm_probe(int device, long long bytes, double *gbps_out);
+
+/* Diagnostic: the structured sweep step (no memory traffic) on n_waves wavefronts at once, `steps`
+ * steps each: out[0] kernel ms, [1] mean / [2] max shader cycles per step of a wave, [3] mean shader
+ * clock in MHz the waves saw -- how far FP64 issue and clocks hold up when the whole device is busy.
+ * steps < 0: |steps| steps of the eight-tiles-per-wave form of the step (8 lanes x 8 states). */
+int psmc_hip_load_probe(int device, int n_waves, int steps, double *out);
 
 /* Wall time in ms of the last E-step measured with HIP events on the streams the
  * kernels ran on.  Exact mode: [0] total, [1] forward, [2] backward, [3] expect,

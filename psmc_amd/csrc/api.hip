@@ -28,11 +28,13 @@ struct psmc_hip_ctx {
 	bool use_struct = false, planned_struct = false;
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
+	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
 	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
 	double *d_Kcol = nullptr; size_t kcol_cap = 0;
 	hipStream_t stream5 = nullptr;
-	int fuse = 0;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip); off: same speed, see DESIGN.md
+	int ckpt = 1;              // "ckpt": factored statistics recompute X from checkpoints every 8 positions instead of reading the table
+	int fuse = 1;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip): structured matrices, up to 64 states
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
 	int group_cap = 131072;    // "group_cap": longest run of glued tiles, in bins
 	int *d_items = nullptr;    // items_f | items_b | ritems_f | ritems_b, 2*n_chunks ints each
@@ -211,7 +213,9 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
+	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
+	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->plan_dirty = true; }
@@ -401,6 +405,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.d_sp = c->d_par + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
+	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
 	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
 	if (c->ns == 128) {
@@ -658,7 +663,7 @@ static int build_items(psmc_hip_ctx *c)
 		int *w = wl.data() + (bwd ? (size_t)2 * nc : 0);
 		// a transfer matrix costs 16 tile sweeps: keep them for the longest runs (the list is sorted longest first)
 		// and let the rest walk -- at most 1/16 of the tiles, i.e. about one more bulk sweep of work
-		int budget = std::max(64, nc / 16);
+		int budget = std::max(64, nc / c->kc_div);
 		for (int i = 0; i < n_long; ++i) {
 			int first = k[i].second.first, count = k[i].second.second;
 			const bool chain = chains && count >= c->kc_min && count - 1 <= budget;
@@ -693,6 +698,9 @@ static int build_items(psmc_hip_ctx *c)
 		if (need > c->kcol_cap) { int rc; if ((rc = dev_alloc(c, &c->d_Kcol, need))) return rc; c->kcol_cap = need; }
 	}
 	c->items_dirty = false;
+	if (getenv("PSMC_HIP_DEBUG"))
+		fprintf(stderr, "[psmc_hip] items: %d tiles of %d bins, fwd %d items (%d runs, %d run tiles, %d walks, %d chains), bwd %d items (%d runs, %d run tiles, %d walks, %d chains), %d transfer matrices\n",
+		        nc, c->chunk_used, c->n_items_f, c->n_long_f, c->n_mem_f, c->n_wl_f, c->n_chain_f, c->n_items_b, c->n_long_b, c->n_mem_b, c->n_wl_b, c->n_chain_b, c->n_kc);
 	return 0;
 }
 
@@ -959,5 +967,63 @@ extern "C" int psmc_hip_stream_probe(int device, long long n_doubles, double *ms
 	if (rc == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { if (ms_out) *ms_out = ms / 4; rc = PSMC_HIP_OK; }
 	else rc = PSMC_HIP_EDEVICE;
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+	return rc;
+}
+
+extern "C" int psmc_hip_hbm_probe(int device, long long bytes, double *gbps_out)
+{
+	int nd = psmc_hip_device_count();
+	if (bytes < (1 << 24) || !gbps_out) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	bytes &= ~(long long)((1 << 23) - 1); // whole 8 MB: four 2 MB streams per wave in the sweep-store probe
+	double *a = nullptr, *b = nullptr;
+	if (hipMalloc((void **)&a, (size_t)bytes) != hipSuccess) return PSMC_HIP_ENOMEM;
+	if (hipMalloc((void **)&b, (size_t)bytes) != hipSuccess) { (void)hipFree(a); return PSMC_HIP_ENOMEM; }
+	(void)hipMemset(a, 0, (size_t)bytes); (void)hipMemset(b, 0, (size_t)bytes);
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	int rc = 0;
+	for (int which = 0; which < 4 && rc == 0; ++which) {
+		rc = run_hbm_probe(nullptr, which, a, b, (size_t)bytes); // warm
+		(void)hipEventRecord(e0, nullptr);
+		for (int i = 0; i < 3 && rc == 0; ++i) rc = run_hbm_probe(nullptr, which, a, b, (size_t)bytes);
+		(void)hipEventRecord(e1, nullptr);
+		float ms = 0;
+		if (rc == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+			gbps_out[which] = (which == 2 ? 2.0 : 1.0) * (double)bytes / (ms / 3 * 1e-3) / 1e9;
+		else rc = PSMC_HIP_EDEVICE;
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+	return rc ? PSMC_HIP_EDEVICE : PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_load_probe(int device, int n_waves, int steps, double *out)
+{
+	int nd = psmc_hip_device_count();
+	const bool h8 = steps < 0; // negative: the 8-lanes-per-tile variant of the step (eight tiles per wave)
+	if (h8) steps = -steps;
+	if (n_waves < 1 || n_waves > (1 << 20) || steps < 4 || !out) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	double *d = nullptr;
+	if (hipMalloc((void **)&d, sizeof(double) * 2 * (size_t)n_waves) != hipSuccess) return PSMC_HIP_ENOMEM;
+	std::vector<double> h((size_t)2 * n_waves);
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	const int arg = h8 ? -(steps & ~3) : (steps & ~3);
+	int rc = run_load_probe(nullptr, d, n_waves, arg); // warm
+	(void)hipEventRecord(e0, nullptr);
+	if (rc == 0) rc = run_load_probe(nullptr, d, n_waves, arg);
+	(void)hipEventRecord(e1, nullptr);
+	float ms = 0;
+	if (rc == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
+	    hipMemcpy(h.data(), d, sizeof(double) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+		double cyc = 0, mhz = 0, cmax = 0;
+		for (int i = 0; i < n_waves; ++i) { cyc += h[2 * (size_t)i]; mhz += h[2 * (size_t)i + 1]; cmax = std::max(cmax, h[2 * (size_t)i]); }
+		out[0] = ms; out[1] = cyc / n_waves; out[2] = cmax; out[3] = mhz / n_waves;
+		rc = PSMC_HIP_OK;
+	} else rc = PSMC_HIP_EDEVICE;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
 	return rc;
 }

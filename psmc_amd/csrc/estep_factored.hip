@@ -28,6 +28,65 @@ __device__ __forceinline__ int64_t readlane_i64a(int64_t v, int lane) {
 	return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
 
+// One position p of one row: x = bt_{p+1} on entry, bt_p on exit; X = X_p.  NORM: p % NORM_EVERY == 0.
+template <bool NORM>
+__device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const double *lds_e, const double *lds_re, int k0, int sym,
+                                         const double (&X)[NPLA], double (&x)[NPLA], double (&acc)[NACC][NPLA])
+{
+	double ev[NPLA], rv[NPLA];
+	loadN<NPLA>(lds_e + sym * SA + k0, ev);
+	loadN<NPLA>(lds_re + sym * SA + k0, rv);
+	double sbv = 1.0;
+	if (NORM) { // sb_p = 1/sum(bt_{p+1})
+		sbv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
+#pragma unroll
+		for (int i = 0; i < NPLA; ++i) ev[i] *= sbv;
+	}
+	// lane-local inclusive scans: z.c / z.qa (the backward step) and X.P / X.R (the column sums)
+	double su[NPLA + 1], pv[NPLA + 1], sx[NPLA + 1], px[NPLA + 1];
+	su[NPLA] = 0.0; sx[NPLA] = 0.0; pv[0] = 0.0; px[0] = 0.0; // pv / px are shifted by one: pv[i+1] = inclusive at i
+#pragma unroll
+	for (int i = NPLA - 1; i >= 0; --i) { su[i] = __builtin_fma(x[i], sc.mS[i], su[i + 1]); sx[i] = __builtin_fma(X[i], sc.wP[i], sx[i + 1]); }
+#pragma unroll
+	for (int i = 0; i < NPLA; ++i) { pv[i + 1] = __builtin_fma(x[i], sc.mP[i], pv[i]); px[i + 1] = __builtin_fma(X[i], sc.wS[i], px[i]); }
+	const double ES = row_excl_suffix(su[0]), EP = row_excl_prefix(pv[NPLA]);
+	const double EX = row_excl_suffix(sx[0]), PX = row_excl_prefix(px[NPLA]);
+	double bt[NPLA], gk[NPLA], G = 0.0;
+#pragma unroll
+	for (int i = 0; i < NPLA; ++i) {
+		const double t = __builtin_fma(sc.wS[i], su[i], __builtin_fma(sc.wP[i], pv[i + 1], sc.dd[i] * x[i]));
+		bt[i] = __builtin_fma(sc.wS[i], ES, __builtin_fma(sc.wP[i], EP, t)) * ev[i];
+		gk[i] = X[i] * bt[i] * rv[i];
+		G += gk[i];
+	}
+	const double iG = rcp_newton(row_sum16(G)), wgt = sbv * iG;
+	const double h0 = sym == 0 ? iG : 0.0, h1 = sym == 1 ? iG : 0.0;
+#pragma unroll
+	for (int i = 0; i < NPLA; ++i) {
+		const double wx = wgt * X[i], wz = wgt * x[i];
+		acc[0][i] = __builtin_fma(wx, EP + pv[i], acc[0][i]);     // SL: strictly below k
+		acc[1][i] = __builtin_fma(wx, ES + su[i + 1], acc[1][i]); // SU: strictly above k
+		acc[2][i] = __builtin_fma(wx, x[i], acc[2][i]);           // DG
+		acc[3][i] = __builtin_fma(wz, EX + sx[i + 1], acc[3][i]); // CL: rows k > l
+		acc[4][i] = __builtin_fma(wz, PX + px[i], acc[4][i]);     // CU: rows k < l
+		acc[5][i] = __builtin_fma(gk[i], h0, acc[5][i]);
+		acc[6][i] = __builtin_fma(gk[i], h1, acc[6][i]);
+		x[i] = bt[i];
+	}
+}
+// scaled partials of one tile: the constant factors of the five sums and the multiplicity
+__device__ __forceinline__ void acc_store(const StructParN<NPLA> &sc, double mult, double (&acc)[NACC][NPLA], double *out)
+{
+#pragma unroll
+	for (int i = 0; i < NPLA; ++i) {
+		const double akk = sc.dd[i] + sc.wP[i] * sc.mP[i] + sc.wS[i] * sc.mS[i]; // a[k][k]
+		acc[0][i] *= sc.wP[i] * mult; acc[1][i] *= sc.wS[i] * mult; acc[2][i] *= akk * mult;
+		acc[3][i] *= sc.mP[i] * mult; acc[4][i] *= sc.mS[i] * mult; acc[5][i] *= mult; acc[6][i] *= mult;
+	}
+#pragma unroll
+	for (int q = 0; q < NACC; ++q) storeN<NPLA>(out + q * SA, acc[q]);
+}
+
 // mode 0: tiles items[0..n) from bentry;  mode 1: flagged tiles items[0..n) from the exit vector of the tile
 // above (which becomes their bentry);  mode 2: every tile b < n whose X a forward repair rewrote, from bentry.
 __global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restrict__ sp, const double *__restrict__ e,
@@ -100,47 +159,8 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restri
 				const int p = 4 * g + j + 1;
 				if (p > top || p < lo) continue;
 				const int sym = (int)((w >> (8 * j)) & 3u);
-				double ev[NPLA], rv[NPLA];
-				loadN<NPLA>(lds_e + sym * SA + k0, ev);
-				loadN<NPLA>(lds_re + sym * SA + k0, rv);
-				double sbv = 1.0;
-				if (j == 3) { // sb_p = 1/sum(bt_{p+1})
-					sbv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
-#pragma unroll
-					for (int i = 0; i < NPLA; ++i) ev[i] *= sbv;
-				}
-				const double(&X)[NPLA] = Xg[j];
-				// lane-local inclusive scans: z.c / z.qa (the backward step) and X.P / X.R (the column sums)
-				double su[NPLA + 1], pv[NPLA + 1], sx[NPLA + 1], px[NPLA + 1];
-				su[NPLA] = 0.0; sx[NPLA] = 0.0; pv[0] = 0.0; px[0] = 0.0; // pv / px are shifted by one: pv[i+1] = inclusive at i
-#pragma unroll
-				for (int i = NPLA - 1; i >= 0; --i) { su[i] = x[i] * sc.mS[i] + su[i + 1]; sx[i] = X[i] * sc.wP[i] + sx[i + 1]; }
-#pragma unroll
-				for (int i = 0; i < NPLA; ++i) { pv[i + 1] = pv[i] + x[i] * sc.mP[i]; px[i + 1] = px[i] + X[i] * sc.wS[i]; }
-				const double ES = row_excl_suffix(su[0]), EP = row_excl_prefix(pv[NPLA]);
-				const double EX = row_excl_suffix(sx[0]), PX = row_excl_prefix(px[NPLA]);
-				double bt[NPLA], gk[NPLA], G = 0.0;
-#pragma unroll
-				for (int i = 0; i < NPLA; ++i) {
-					const double t = __builtin_fma(sc.wS[i], su[i], __builtin_fma(sc.wP[i], pv[i + 1], sc.dd[i] * x[i]));
-					bt[i] = __builtin_fma(sc.wS[i], ES, __builtin_fma(sc.wP[i], EP, t)) * ev[i];
-					gk[i] = X[i] * bt[i] * rv[i];
-					G += gk[i];
-				}
-				const double iG = rcp_newton(row_sum16(G)), wgt = sbv * iG;
-				const double h0 = sym == 0 ? iG : 0.0, h1 = sym == 1 ? iG : 0.0;
-#pragma unroll
-				for (int i = 0; i < NPLA; ++i) {
-					const double wx = wgt * X[i], wz = wgt * x[i];
-					acc[0][i] = __builtin_fma(wx, EP + pv[i], acc[0][i]);     // SL: strictly below k
-					acc[1][i] = __builtin_fma(wx, ES + su[i + 1], acc[1][i]); // SU: strictly above k
-					acc[2][i] = __builtin_fma(wx, x[i], acc[2][i]);           // DG
-					acc[3][i] = __builtin_fma(wz, EX + sx[i + 1], acc[3][i]); // CL: rows k > l
-					acc[4][i] = __builtin_fma(wz, PX + px[i], acc[4][i]);     // CU: rows k < l
-					acc[5][i] = __builtin_fma(gk[i], h0, acc[5][i]);
-					acc[6][i] = __builtin_fma(gk[i], h1, acc[6][i]);
-					x[i] = bt[i];
-				}
+				if (j == 3) acc_step<true>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
+				else acc_step<false>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
 				if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
 			}
 #pragma unroll
@@ -150,17 +170,137 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restri
 		}
 	}
 	if (valid) {
-		const double mult = (double)c.mult;
-		double *out = part + (int64_t)tile * (NACC * SA) + k0;
-#pragma unroll
-		for (int i = 0; i < NPLA; ++i) {
-			const double akk = sc.dd[i] + sc.wP[i] * sc.mP[i] + sc.wS[i] * sc.mS[i]; // a[k][k]
-			acc[0][i] *= sc.wP[i] * mult; acc[1][i] *= sc.wS[i] * mult; acc[2][i] *= akk * mult;
-			acc[3][i] *= sc.mP[i] * mult; acc[4][i] *= sc.mS[i] * mult; acc[5][i] *= mult; acc[6][i] *= mult;
-		}
-#pragma unroll
-		for (int q = 0; q < NACC; ++q) storeN<NPLA>(out + q * SA, acc[q]);
+		acc_store(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
 	}
+}
+
+// The same without the X table: the forward sweep left only the checkpoints X_p, p % 8 == 0 (SWEEP_CKPT in
+// estep_struct.hip), and the row recomputes the eight X of a block from the checkpoint below it before it walks
+// the block backwards -- 84 more VALU instructions per step in exchange for 7/8 of the table traffic
+// (HBM per bin: 8N/8 written + 8N/8 read).  The first block of a tile starts from the tile's own start vector
+// `entry` (what its checkpoints were computed from; position 1: X_1 itself, which the sweep stores), so a forward
+// repair of the tile below never races with this kernel; X of any scale will do (G_p carries the same factor).
+// Needs tile_len % 8 == 0 (every lo = 1 mod 8): only the top block of a segment's last tile is partial.
+__device__ __forceinline__ void fwd_recompute_step(const StructParN<NPLA> &sc, const double *lds_e, int k0, int sym, double (&x)[NPLA])
+{	// forward roles of the five vectors: mS = P (bwd wP), wS = qa (bwd mP), mP = R (bwd wS), wP = c (bwd mS)
+	double ev[NPLA], su[NPLA], pv[NPLA];
+	loadN<NPLA>(lds_e + sym * SA + k0, ev);
+	su[NPLA - 1] = x[NPLA - 1] * sc.wP[NPLA - 1];
+#pragma unroll
+	for (int i = NPLA - 2; i >= 0; --i) su[i] = __builtin_fma(x[i], sc.wP[i], su[i + 1]);
+	pv[0] = x[0] * sc.wS[0];
+#pragma unroll
+	for (int i = 1; i < NPLA; ++i) pv[i] = __builtin_fma(x[i], sc.wS[i], pv[i - 1]);
+	const double ES = row_excl_suffix(su[0]), EP = row_excl_prefix(pv[NPLA - 1]);
+#pragma unroll
+	for (int i = 0; i < NPLA; ++i) {
+		const double t = __builtin_fma(sc.mP[i], su[i], __builtin_fma(sc.mS[i], pv[i], sc.dd[i] * x[i]));
+		x[i] = __builtin_fma(sc.mP[i], ES, __builtin_fma(sc.mS[i], EP, t)) * ev[i];
+	}
+}
+
+__global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict__ sp, const double *__restrict__ e,
+                                                          const double *__restrict__ re, const uint8_t *__restrict__ obs,
+                                                          const Chunk *__restrict__ chunks, const SweepItemA *__restrict__ items,
+                                                          int n, int mode, const double *__restrict__ f,
+                                                          const double *__restrict__ entry, double *__restrict__ bentry,
+                                                          double *__restrict__ bexit, double *__restrict__ part,
+                                                          const int *__restrict__ touch_f, int *__restrict__ touch_b)
+{
+	__shared__ double lds_e[4 * SA], lds_re[4 * SA];
+	__shared__ double lds_x[4 * 8 * SA]; // the block's X, private to the lane that wrote it: [row][j][half][2 m + i]
+	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLA * m;
+	lds_e[lane] = e[lane]; lds_e[SA + lane] = e[SA + lane]; lds_e[2 * SA + lane] = 1.0; lds_e[3 * SA + lane] = 1.0;
+	lds_re[lane] = re[lane]; lds_re[SA + lane] = re[SA + lane]; lds_re[2 * SA + lane] = 1.0; lds_re[3 * SA + lane] = 1.0;
+	__syncthreads();
+	double *xs = lds_x + row * (8 * SA) + 2 * m;
+	const int slot = blockIdx.x * 4 + row;
+	int tile; bool valid = slot < n;
+	if (mode == 2) { tile = valid ? slot : 0; valid = valid && touch_f[tile] != 0; }
+	else tile = items[valid ? slot : 0].first;
+	if (!__any(valid)) return;
+	if (mode == 1) __builtin_amdgcn_s_setprio(3);
+	const Chunk c = chunks[tile];
+	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
+	const bool work = valid && top >= lo;
+	const double *fo = f + c.off * SA + k0;
+	StructParN<NPLA> sc; // backward: mS = c, wS = R, mP = qa, wP = P
+	loadN<NPLA>(sp + 3 * SA + k0, sc.mS); loadN<NPLA>(sp + SA + k0, sc.wS);
+	loadN<NPLA>(sp + 2 * SA + k0, sc.mP); loadN<NPLA>(sp + k0, sc.wP); loadN<NPLA>(sp + 4 * SA + k0, sc.dd);
+	double x[NPLA];
+	if (mode == 1) {
+		loadN<NPLA>(bexit + (int64_t)(tile + 1) * SA + k0, x);
+		if (work) { storeN<NPLA>(bentry + (int64_t)tile * SA + k0, x); if (m == 0) touch_b[tile] = 1; }
+	} else {
+		loadN<NPLA>(bentry + (int64_t)tile * SA + k0, x);
+	}
+	double acc[NACC][NPLA];
+#pragma unroll
+	for (int q = 0; q < NACC; ++q)
+#pragma unroll
+		for (int i = 0; i < NPLA; ++i) acc[q][i] = 0.0;
+	// blocks of eight positions 8b+1 .. 8b+8 (indices 8b .. 8b+7), highest first
+	const int b_hi = work ? (top - 1) >> 3 : -1, b_lo = work ? (lo - 1) >> 3 : 0;
+	const int nb = b_hi - b_lo + 1;
+	const int64_t off0 = readlane_i64a(c.off, 0), off1 = readlane_i64a(c.off, 16), off2 = readlane_i64a(c.off, 32), off3 = readlane_i64a(c.off, 48);
+	const int bh0 = __builtin_amdgcn_readlane(b_hi, 0), bh1 = __builtin_amdgcn_readlane(b_hi, 16), bh2 = __builtin_amdgcn_readlane(b_hi, 32), bh3 = __builtin_amdgcn_readlane(b_hi, 48);
+	const int n0 = __builtin_amdgcn_readlane(nb, 0), n1 = __builtin_amdgcn_readlane(nb, 16), n2 = __builtin_amdgcn_readlane(nb, 32), n3 = __builtin_amdgcn_readlane(nb, 48);
+	const int nb_max = max(max(n0, n1), max(n2, n3));
+	// start vector of block b: X_{8b}; the tile's first block: its entry vector, or X_1 itself when lo == 1
+	const double *ck_first = lo > 1 ? entry + (int64_t)tile * SA + k0 : fo;
+	auto load_ck = [&](int b, double (&ck)[NPLA]) {
+		const double *src = b <= b_lo ? ck_first : fo + (int64_t)(8 * b - 1) * SA;
+		loadN<NPLA>(src, ck);
+	};
+	double ck[NPLA], ckn[NPLA];
+	load_ck(max(b_hi, b_lo), ck);
+	for (int bi = 0; bi < nb_max; ++bi) {
+		// the block's eight symbols of every row: scalar loads (see estep_struct.hip row_symbols)
+		const uint2 w0 = *reinterpret_cast<const uint2 *>(obs + off0 + 8 * (int64_t)max(bh0 - min(bi, max(n0 - 1, 0)), 0));
+		const uint2 w1 = *reinterpret_cast<const uint2 *>(obs + off1 + 8 * (int64_t)max(bh1 - min(bi, max(n1 - 1, 0)), 0));
+		const uint2 w2 = *reinterpret_cast<const uint2 *>(obs + off2 + 8 * (int64_t)max(bh2 - min(bi, max(n2 - 1, 0)), 0));
+		const uint2 w3 = *reinterpret_cast<const uint2 *>(obs + off3 + 8 * (int64_t)max(bh3 - min(bi, max(n3 - 1, 0)), 0));
+		const unsigned wa = row == 0 ? w0.x : (row == 1 ? w1.x : (row == 2 ? w2.x : w3.x));
+		const unsigned wb = row == 0 ? w0.y : (row == 1 ? w1.y : (row == 2 ? w2.y : w3.y));
+		if (bi < nb) {
+			const int b = b_hi - bi;
+			if (bi + 1 < nb) load_ck(b - 1, ckn);
+			// ---- forward: X of the block's positions from the checkpoint below them
+			const bool is_x1 = b == b_lo && lo == 1; // the start vector IS position 8b+1 = 1
+			double t[NPLA];
+#pragma unroll
+			for (int i = 0; i < NPLA; ++i) t[i] = ck[i];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const int sym = (int)(((j < 4 ? wa : wb) >> (8 * (j & 3))) & 3u);
+				if (j == 0) {
+					double u[NPLA];
+#pragma unroll
+					for (int i = 0; i < NPLA; ++i) u[i] = t[i];
+					fwd_recompute_step(sc, lds_e, k0, sym, u);
+#pragma unroll
+					for (int i = 0; i < NPLA; ++i) t[i] = is_x1 ? t[i] : u[i];
+				} else fwd_recompute_step(sc, lds_e, k0, sym, t);
+				*reinterpret_cast<d2v_t *>(xs + j * SA) = (d2v_t){t[0], t[1]};
+				*reinterpret_cast<d2v_t *>(xs + j * SA + 32) = (d2v_t){t[2], t[3]};
+			}
+			// ---- backward through the block
+#pragma unroll
+			for (int j = 7; j >= 0; --j) {
+				const int p = 8 * b + j + 1;
+				if (p > top || p < lo) continue;
+				const int sym = (int)(((j < 4 ? wa : wb) >> (8 * (j & 3))) & 3u);
+				const d2v_t xa = *reinterpret_cast<const d2v_t *>(xs + j * SA), xb = *reinterpret_cast<const d2v_t *>(xs + j * SA + 32);
+				const double X[NPLA] = {xa.x, xa.y, xb.x, xb.y};
+				if ((j & 3) == 3) acc_step<true>(sc, lds_e, lds_re, k0, sym, X, x, acc);
+				else acc_step<false>(sc, lds_e, lds_re, k0, sym, X, x, acc);
+				if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
+			}
+#pragma unroll
+			for (int i = 0; i < NPLA; ++i) ck[i] = ckn[i];
+		}
+	}
+	if (valid) acc_store(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
 }
 
 // Fixed-order two-stage sum over the tiles: stage[y][q*64+k] = sum of the tiles j = y (mod RED_ROWS), then
@@ -205,8 +345,13 @@ void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, 
 {
 	if (n <= 0) return;
 	const SweepItemA *items = (const SweepItemA *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
-	hipLaunchKernelGGL(k_bwd_acc_struct, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
-	                   which == 1 ? 1 : (which == 2 ? 2 : 0), p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
+	const int mode = which == 1 ? 1 : (which == 2 ? 2 : 0);
+	if (p.ckpt)
+		hipLaunchKernelGGL(k_bwd_acc_ckpt, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+		                   mode, p.d_f, p.d_entry, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
+	else
+		hipLaunchKernelGGL(k_bwd_acc_struct, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
 }
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st)
 {

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, con
 // Fixed-order two-stage reduction of the per-wave partials (deterministic).
 template <int S>
 __global__ __launch_bounds__(256) void k_reduce1(const double *__restrict__ Cpart, const double *__restrict__ Spart,
-                                                   int nC, const double *__restrict__ LLpart, int nchunks,
+                                                   int nC, int nS, const double *__restrict__ LLpart, int nchunks,
                                                    double *__restrict__ stage)
 {
 	constexpr int SL = S * S + 3 * S + 1; // C | S-counts | LL of one stage row
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_reduce1(const double *__restrict__ Cpar
 	} else {
 		for (int i = tid; i < 3 * S; i += 256) {
 			double s = 0.0;
-			for (int j = y; j < nC; j += RED_ROWS) s += Spart[(int64_t)j * (3 * S) + i];
+			for (int j = y; j < nS; j += RED_ROWS) s += Spart[(int64_t)j * (3 * S) + i];
 			st[S * S + i] = s;
 		}
 		if (tid == 255) {
@@ -609,8 +609,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (ov) (void)hipStreamWaitEvent(sk, p.fused ? p.evx[7] : p.evx[6], 0); // fused: the backward pass reads the run tiles' X
 		if (lb) {
 			if (p.fused == 2) launch_bwd_acc(p, sk, 3, 0, p.n_mem_b);
-			else if (p.fused) launch_bwd_count(p, sk, 3, 0, p.n_mem_b);
-			else launch_bwd_struct(p, sk, 3, 0, p.n_mem_b);
+			else if (!p.fused) launch_bwd_struct(p, sk, 3, 0, p.n_mem_b); // fused: the one pass over all tile groups below covers them
 		}
 		(void)hipEventRecord(p.evx[9], sk);
 	}
@@ -634,7 +633,11 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0);
 		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
-		if (p.fused == 2) launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0); else launch_bwd_count(p, sa, 0, nb0, p.n_items_b - nb0);
+		if (p.fused == 2) launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0);
+		else {
+			if (lw && ov) (void)hipStreamWaitEvent(sa, p.evx[7], 0); // boundary vectors and X of the run tiles
+			launch_bwd_count(p, sa, 0);
+		}
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sa);
 		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
 	} else {
@@ -695,7 +698,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 			} else {
 				rep->bwd_rounds++; rep->bwd_tiles += nd;
 				if (p.fused == 2) launch_bwd_acc(p, c.st, 1, 0, nd);
-				else if (p.fused) launch_bwd_count(p, c.st, 1, 0, nd);
+				else if (p.fused) launch_bwd_struct(p, c.st, 5, 0, nd); // boundary vectors only; the counts follow below
 				else if (p.structured) launch_bwd_struct(p, c.st, 1, 0, nd);
 				else launch_bwd<true>(p, c.st);
 			}
@@ -712,7 +715,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 		// tiles whose X a forward repair rewrote after their counts were taken
-		if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else launch_bwd_count(p, sm, 2, 0, p.n_chunks);
+		if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else launch_bwd_count(p, sm, 2);
 	} else if (ov) {
 		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // backward chain done
 		(void)hipStreamWaitEvent(sm, p.evx[3], 0);                                     // early expect done
@@ -725,16 +728,16 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sm);
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
-	const int nC = p.n_chunks * p.n_sub;
+	const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_chunks + 3) / 4 : nS; // fused: one C partial per group of four tiles
 	if (p.fused == 2) {
 		launch_reduce_factored(p, sm);
 	} else if (p.ns == 128) {
-		hipLaunchKernelGGL(k_reduce1<128>, dim3(128 * 128 / 256 + 1, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
+		hipLaunchKernelGGL(k_reduce1<128>, dim3(128 * 128 / 256 + 1, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, nS, p.d_LLpart,
 		                   p.n_chunks, p.d_stage);
 		hipLaunchKernelGGL(k_reduce2<128>, dim3((128 * 128 + 3 * 128 + 1 + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
 		                   p.tiny_total, p.n_states, p.d_stats);
 	} else {
-		hipLaunchKernelGGL(k_reduce1<64>, dim3(17, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, p.d_LLpart,
+		hipLaunchKernelGGL(k_reduce1<64>, dim3(17, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, nS, p.d_LLpart,
 		                   p.n_chunks, p.d_stage);
 		hipLaunchKernelGGL(k_reduce2<64>, dim3((STATS_LEN + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
 		                   p.tiny_total, p.n_states, p.d_stats);

@@ -1,178 +1,218 @@
 // estep_fused.hip -- FAST mode, structured matrices: backward sweep and expected counts in ONE kernel.
 //
 // The counts kernel of estep_fast.hip reads X and bt back from HBM (1 KB per bin) after the backward
-// sweep wrote bt (0.5 KB per bin).  With O(N) sweep steps (estep_struct.hip) the E-step is HBM-bound,
-// so here the wave that walks a tile backwards feeds its bt vectors straight into the f64 matrix
-// cores: bt never goes to memory, HBM traffic per bin drops from 2.1 KB to 1.0 KB (write X, read X).
+// sweep wrote bt (0.5 KB per bin).  Here the wave that walks its tiles backwards feeds the bt vectors
+// straight into the f64 matrix cores: bt never goes to memory, HBM traffic per bin drops from 2.1 KB to
+// 1.0 KB (write X, read X), and the separate counts pass disappears.
 //
-// One wave per tile, lane = state for the sweep (struct_step1: two 64-lane scans), and the MFMA
-// layout of k_expect_mfma for the counts: a group is four consecutive positions 4j..4j+3, row group
-// t = lane>>4 holds position 4j+t; the sweep writes bt_p into a small LDS ring (slot p & 7) and the
-// count stage reads bt_P, bt_{P+1} back in operand layout.  Only position 4j of a group carries a
-// scale factor sb (lagged, sparse normalisation as everywhere else).
-//   g_P[k] = X_P[k] bt_P[k] / e[o_P][k],  G_P = sum_k g_P[k]
-//   S[o_P][k] += g_P[k] / G_P,   C[k][l] += (sb_P / G_P) X_P[k] bt_{P+1}[l],   A = a .* C  (k_reduce2)
-// The tile's start vector bt_{top+1} comes from `bentry` (left there by the warm-up-only pass of
-// k_bwd_struct or by a walk) or, for a repair, from the exit vector of the tile above; the exit
-// vector bt_lo goes to `bexit` for the verify kernel.  Speculate / verify / repair as in estep_fast.hip.
+// The wave keeps the layout of the structured sweeps (estep_struct.hip): four tiles, one per 16-lane row,
+// four adjacent states per lane.  That register layout already IS an operand layout of
+// v_mfma_f64_16x16x4: lane (t, i) supplies A[M = i][K = t] and B[K = t][N = i], so with
+//   A_j = w X[4i + j]  (j = 0..3: the lane's j-th state),   B_j' = bt_{p+1}[4i + j']
+// the K dimension of the instruction runs over the wave's FOUR TILES (one position each) instead of four
+// positions of one tile -- legitimate because the counts of all tiles are summed anyway:
+//   C[4M + j][4N + j'] += sum_t  w^(t) X^(t)[4M + j] bt^(t)[4N + j'],     16 instructions per step.
+// Per position p of a tile (z = bt_{p+1}, sb_p the lagged scale factor of p % 4 == 0):
+//   g_p[k] = X_p[k] bt_p[k] / e[o_p][k],  G_p = sum_k g_p[k],  w = mult sb_p / G_p
+//   E[o_p][k] += mult g_p[k] / G_p,   C[k][l] += w X_p[k] z[l],   A = a .* C (k_reduce2)
+// A group of four consecutive tiles shares one partial C (Cpart[group]); E partials are per tile.  A tile whose
+// X or start vector a repair changed makes its whole group recompute (mode 2), which overwrites the partial.
+// The backward repair rounds themselves only move boundary vectors (launch_bwd_struct, which = 5).
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
 #include "struct_prims.h"
+#include <type_traits>
 #include "psmc_hip_internal.h"
 
 namespace psmc {
 
 typedef double d4f_t __attribute__((ext_vector_type(4)));
-struct SweepItemF { int first, count; };
+constexpr int NPLF = 4, SF = 64;
 
-// mode 0: tiles items[0..n) from bentry;  mode 1: flagged tiles items[0..n) from the exit vector of the
-// tile above (which also becomes their bentry);  mode 2: every tile b < n whose X a forward repair
-// rewrote (touch_f), from bentry.
-__global__ __launch_bounds__(64, 2) void k_bwd_count_struct(const double *__restrict__ sp, const double *__restrict__ e,
-                                                              const double *__restrict__ re, const uint8_t *__restrict__ obs,
-                                                              const Chunk *__restrict__ chunks, const SweepItemF *__restrict__ items,
-                                                              int n, int mode, const double *__restrict__ f,
-                                                              double *__restrict__ bentry, double *__restrict__ bexit,
-                                                              double *__restrict__ Cpart, double *__restrict__ Spart,
-                                                              const int *__restrict__ touch_f, int *__restrict__ touch_b)
-{
-	__shared__ double lds_bt[8 * 64];
-	__shared__ double lds_sc[8];
-	const int lane = threadIdx.x, t = lane >> 4, i = lane & 15;
-	int tile;
-	if (mode == 2) { tile = blockIdx.x; if (!touch_f[tile]) return; }
-	else tile = items[blockIdx.x].first;
-	const Chunk c = chunks[tile];
-	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
-	d4f_t acc[4][4];
-	double S[3][4];
-#pragma unroll
-	for (int m = 0; m < 4; ++m) {
-#pragma unroll
-		for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (d4f_t){0.0, 0.0, 0.0, 0.0};
-		S[0][m] = S[1][m] = S[2][m] = 0.0;
-	}
-	if (top >= lo) { // a tile holding only position L owns no transition: its partials are zero
-		if (mode == 1) __builtin_amdgcn_s_setprio(3);
-		const uint8_t *o = obs + c.off;
-		const double *fo = f + c.off * 64 + i;
-		StructPar1 sc1; // backward: SUF over z.c weighted by R, PRE over z.qa weighted by P
-		sc1.mS = sp[192 + lane]; sc1.wS = sp[64 + lane]; sc1.mP = sp[128 + lane]; sc1.wP = sp[lane]; sc1.dd = sp[256 + lane];
-		const WaveScanMasks wm = wave_scan_masks(lane);
-		const double e0 = e[lane], e1 = e[64 + lane];
-		double re0[4], re1[4]; // 1/e[b][16m+i]
-#pragma unroll
-		for (int m = 0; m < 4; ++m) { re0[m] = re[16 * m + i]; re1[m] = re[64 + 16 * m + i]; }
-		double x; // bt_{p+1}, natural layout
-		if (mode == 1) {
-			x = bexit[(int64_t)(tile + 1) * 64 + lane];
-			bentry[(int64_t)tile * 64 + lane] = x;
-			if (lane == 0) touch_b[tile] = 1;
-		} else {
-			x = bentry[(int64_t)tile * 64 + lane];
-		}
-		lds_bt[((top + 1) & 7) * 64 + lane] = x;
-		// operands of a group: X rows and symbols of the positions 4j+t (clamped into the tile)
-		auto load = [&](int j, double (&FA)[4], int &sym, bool &ok) {
-			const int P = 4 * j + t;
-			ok = P >= lo && P <= top;
-			const int64_t idx = (int64_t)min(max(P, lo), top) - 1;
-			const double *fr = fo + idx * 64;
-#pragma unroll
-			for (int m = 0; m < 4; ++m) FA[m] = fr[16 * m];
-			sym = o[idx];
-		};
-		const int j_top = top >> 2, j_lo = lo >> 2;
-		double FA[4]; int sym; bool ok;
-		load(j_top, FA, sym, ok);
-		for (int j = j_top; j >= j_lo; --j) {
-			double FN[4] = {0, 0, 0, 0}; int symn = 2; bool okn = false;
-			if (j > j_lo) load(j - 1, FN, symn, okn);
-			// ---- sweep through the group's positions, highest first
-#pragma unroll
-			for (int tt = 3; tt >= 0; --tt) {
-				const int p = 4 * j + tt;
-				if (p > top || p < lo) continue; // wave-uniform
-				const int s_p = __builtin_amdgcn_readlane(sym, 16 * tt);
-				double ev = s_p == 0 ? e0 : (s_p == 1 ? e1 : 1.0);
-				if (tt == 0) { // p % NORM_EVERY == 0: sb_p = 1/sum(bt_{p+1}), off the critical path
-					const double s = rcp_newton(first_lane_f64(wave_sum_nat(x)));
-					ev *= s;
-					if (lane == 0) lds_sc[j & 7] = s;
-				}
-				x = struct_step1(sc1, x, wm) * ev;
-				lds_bt[(p & 7) * 64 + lane] = x;
-				if (p == lo) bexit[(int64_t)tile * 64 + lane] = x;
-			}
-			// ---- counts of the group (row group t = position 4j+t)
-			const int P = 4 * j + t;
-			double BP[4], BM[4];
-#pragma unroll
-			for (int m = 0; m < 4; ++m) {
-				BP[m] = lds_bt[(P & 7) * 64 + 16 * m + i];
-				BM[m] = lds_bt[((P + 1) & 7) * 64 + 16 * m + i];
-			}
-			const double sc = (t == 0 && 4 * j >= lo) ? lds_sc[j & 7] : 1.0;
-			double g[4], G = 0.0;
-#pragma unroll
-			for (int m = 0; m < 4; ++m) {
-				const double r = sym == 0 ? re0[m] : (sym == 1 ? re1[m] : 1.0);
-				g[m] = ok ? FA[m] * BP[m] * r : 0.0;
-				G += g[m];
-			}
-			G = G + dpp_mov<0xB1>(G);  // quad_perm:[1,0,3,2]
-			G = G + dpp_mov<0x4E>(G);  // quad_perm:[2,3,0,1]
-			G = G + dpp_mov<0x124>(G); // row_ror:4
-			G = G + dpp_mov<0x128>(G); // row_ror:8
-			const double iG = ok ? rcp_newton(G) : 0.0; // rows outside the tile contribute nothing
-			const double w0 = sym == 0 ? iG : 0.0, w1 = sym == 1 ? iG : 0.0, w2 = sym == 2 ? iG : 0.0, wa = sc * iG;
-#pragma unroll
-			for (int m = 0; m < 4; ++m) {
-				S[0][m] = __builtin_fma(g[m], w0, S[0][m]);
-				S[1][m] = __builtin_fma(g[m], w1, S[1][m]);
-				S[2][m] = __builtin_fma(g[m], w2, S[2][m]);
-				FA[m] = ok ? FA[m] * wa : 0.0;
-				if (!ok) BM[m] = 0.0; // never multiply stale LDS contents (0 * NaN)
-			}
-#pragma unroll
-			for (int m = 0; m < 4; ++m)
-#pragma unroll
-				for (int nn = 0; nn < 4; ++nn)
-					acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[m], BM[nn], acc[m][nn], 0, 0, 0);
-#pragma unroll
-			for (int m = 0; m < 4; ++m) FA[m] = FN[m];
-			sym = symn; ok = okn;
-		}
-	}
-	const double mult = (double)c.mult;
-	double *out = Cpart + (int64_t)tile * 4096;
-#pragma unroll
-	for (int m = 0; m < 4; ++m)
-#pragma unroll
-		for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-			for (int r = 0; r < 4; ++r) out[(16 * m + t + 4 * r) * 64 + 16 * nn + i] = acc[m][nn][r] * mult;
-	double *os = Spart + (int64_t)tile * 192;
-#pragma unroll
-	for (int b = 0; b < 3; ++b)
-#pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			double v = S[b][m];
-			v += __shfl_xor(v, 16, 64);
-			v += __shfl_xor(v, 32, 64);
-			if (t == 0) os[b * 64 + 16 * m + i] = v * mult;
-		}
+__device__ __forceinline__ int64_t readlane_i64f(int64_t v, int lane) {
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
+	return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
 
-// which: 0 = bulk single tiles of the backward item list, 1 = flagged tiles of the current repair round,
-//        2 = every tile a forward repair touched, 3 = the tiles of the glued runs (boundary vectors from the walk)
-void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which, int first, int n)
+// One position of every row: x = bt_{p+1} on entry, bt_p on exit; X = X_p.  NORM: p % NORM_EVERY == 0.
+// MASKED: rows with !active contribute nothing and keep their x (no divergent branch: the matrix
+// instructions run with all lanes enabled).
+template <bool NORM, bool MASKED>
+__device__ __forceinline__ void count4_step(const StructParN<NPLF> &sc, const double *lds_e, const double *lds_re, int k0, int sym,
+                                            const double (&X)[NPLF], double (&x)[NPLF], bool active, double mult,
+                                            d4f_t (&acc)[4][4], double (&S)[2][NPLF])
 {
-	if (n <= 0) return;
-	const SweepItemF *items = (const SweepItemF *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
-	hipLaunchKernelGGL(k_bwd_count_struct, dim3(n), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
-	                   which == 1 ? 1 : (which == 2 ? 2 : 0), p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f,
-	                   p.d_touch_b);
+	double ev[NPLF], rv[NPLF];
+	loadN<NPLF>(lds_e + sym * SF + k0, ev);
+	loadN<NPLF>(lds_re + sym * SF + k0, rv);
+	double sbv = 1.0;
+	if (NORM) { // sb_p = 1/sum(bt_{p+1})
+		sbv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
+#pragma unroll
+		for (int i = 0; i < NPLF; ++i) ev[i] *= sbv;
+	}
+	double bt[NPLF], gk[NPLF], G = 0.0;
+#pragma unroll
+	for (int i = 0; i < NPLF; ++i) bt[i] = x[i];
+	struct_step<NPLF>(sc, bt);
+#pragma unroll
+	for (int i = 0; i < NPLF; ++i) {
+		bt[i] *= ev[i];
+		gk[i] = X[i] * bt[i] * rv[i];
+		if (MASKED) gk[i] = active ? gk[i] : 0.0; // an idle row may hold anything
+		G += gk[i];
+	}
+	const double iG = rcp_newton(row_sum16(G));
+	double h = iG * mult, wgt = sbv * h;
+	if (MASKED) { h = active ? h : 0.0; wgt = active ? wgt : 0.0; }
+	const double h0 = sym == 0 ? h : 0.0, h1 = sym == 1 ? h : 0.0;
+	double FA[NPLF], FB[NPLF];
+#pragma unroll
+	for (int i = 0; i < NPLF; ++i) {
+		S[0][i] = __builtin_fma(gk[i], h0, S[0][i]);
+		S[1][i] = __builtin_fma(gk[i], h1, S[1][i]);
+		FA[i] = MASKED ? (active ? wgt * X[i] : 0.0) : wgt * X[i];
+		FB[i] = MASKED ? (active ? x[i] : 0.0) : x[i];
+		x[i] = MASKED ? (active ? bt[i] : x[i]) : bt[i];
+	}
+	// The accumulators are pinned to the accumulation registers ("+a"): left to the register allocator they
+	// migrate between VGPRs and AGPRs on every loop iteration (250 v_accvgpr moves per four steps).
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+#pragma unroll
+		for (int j2 = 0; j2 < 4; ++j2)
+#ifdef PSMC_MFMA_ASM
+			asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[j][j2]) : "v"(FA[j]), "v"(FB[j2]));
+#else
+			acc[j][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[j2], acc[j][j2], 0, 0, 0);
+#endif
+}
+
+// Group g = tiles 4g .. 4g+3, each from its start vector bentry (left by the warm-up-only pass of k_bwd_struct,
+// by a walk / transfer-matrix chain, or by a boundary-only repair).  mode 0: every group;  mode 2: only groups
+// holding a tile whose X (touch_f) or start vector (touch_b) changed after the first pass.
+__global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                               const double *__restrict__ re, const uint8_t *__restrict__ obs,
+                                                               const Chunk *__restrict__ chunks, int n_tiles, int mode,
+                                                               const double *__restrict__ f, const double *__restrict__ bentry,
+                                                               double *__restrict__ bexit, double *__restrict__ Cpart,
+                                                               double *__restrict__ Epart, const int *__restrict__ touch_f,
+                                                               const int *__restrict__ touch_b)
+{
+	__shared__ double lds_e[4 * SF], lds_re[4 * SF]; // e / 1/e rows: hom, het, 1, 1
+	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLF * m;
+	lds_e[lane] = e[lane]; lds_e[SF + lane] = e[SF + lane]; lds_e[2 * SF + lane] = 1.0; lds_e[3 * SF + lane] = 1.0;
+	lds_re[lane] = re[lane]; lds_re[SF + lane] = re[SF + lane]; lds_re[2 * SF + lane] = 1.0; lds_re[3 * SF + lane] = 1.0;
+	__syncthreads();
+	const int group = blockIdx.x;
+	const bool valid = 4 * group + row < n_tiles;
+	const int tile = valid ? 4 * group + row : n_tiles - 1;
+	if (mode == 2 && !__any(valid && (touch_f[tile] | touch_b[tile]) != 0)) return;
+	const Chunk c = chunks[tile];
+	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
+	const bool work = valid && top >= lo; // a tile holding only position L owns no transition
+	const double *fo = f + c.off * SF + k0;
+	const double mult = (double)c.mult;
+	StructParN<NPLF> sc; // backward: mS = c, wS = R, mP = qa, wP = P
+	loadN<NPLF>(sp + 3 * SF + k0, sc.mS); loadN<NPLF>(sp + SF + k0, sc.wS);
+	loadN<NPLF>(sp + 2 * SF + k0, sc.mP); loadN<NPLF>(sp + k0, sc.wP); loadN<NPLF>(sp + 4 * SF + k0, sc.dd);
+	double x[NPLF];
+	loadN<NPLF>(bentry + (int64_t)tile * SF + k0, x);
+	d4f_t acc[4][4];
+	double S[2][NPLF];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+#pragma unroll
+		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0};
+		S[0][j] = S[1][j] = 0.0;
+	}
+	// groups of four positions 4g+1 .. 4g+4 (indices 4g .. 4g+3), highest first; the group's last
+	// position (p % 4 == 0) carries the scale factor
+	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
+	const int ng = g_hi - g_lo + 1;
+	const int64_t off0 = readlane_i64f(c.off, 0), off1 = readlane_i64f(c.off, 16), off2 = readlane_i64f(c.off, 32), off3 = readlane_i64f(c.off, 48);
+	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
+	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
+	const int ng_max = max(max(n0, n1), max(n2, n3));
+	const int p_min = lo, p_max = max(top, lo);
+	auto load_row = [&](int g, int j, double (&Xq)[NPLF]) { // X of position 4g + j + 1, clamped into the tile
+		const int p = min(max(4 * g + j + 1, p_min), p_max);
+		loadN<NPLF>(fo + (int64_t)(p - 1) * SF, Xq);
+	};
+	// X of the current group; every row is reloaded for the next group as soon as its step has used it
+	// (a second buffer would push the kernel past 256 VGPRs, and spills go through the AGPRs the counts live in)
+	double Xg[4][NPLF];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) load_row(max(g_hi, 0), j, Xg[j]);
+	// One group of four positions of every row.  Three loops instead of one loop with two paths: with both paths
+	// in one loop body the register allocator moves the 128 accumulation registers back and forth on every
+	// iteration.  `full` groups (every row has all four positions inside its tile) need no masks.
+	int gi = 0;
+	// the four symbols of group number gi_ of every row: scalar loads (see estep_struct.hip row_symbols), all four
+	// issued before the per-row select (left alone the compiler branches per row and waits for each load in turn);
+	// fetched one group ahead
+	auto row_word = [&](int gi_) {
+		unsigned w0 = *reinterpret_cast<const unsigned *>(obs + off0 + 4 * (int64_t)max(gh0 - min(gi_, max(n0 - 1, 0)), 0));
+		unsigned w1 = *reinterpret_cast<const unsigned *>(obs + off1 + 4 * (int64_t)max(gh1 - min(gi_, max(n1 - 1, 0)), 0));
+		unsigned w2 = *reinterpret_cast<const unsigned *>(obs + off2 + 4 * (int64_t)max(gh2 - min(gi_, max(n2 - 1, 0)), 0));
+		unsigned w3 = *reinterpret_cast<const unsigned *>(obs + off3 + 4 * (int64_t)max(gh3 - min(gi_, max(n3 - 1, 0)), 0));
+		asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
+		return row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
+	};
+	unsigned w_cur = row_word(0);
+	auto all_full = [&](int gi_) {
+		const int g = max(g_hi - gi_, g_lo);
+		return __all(gi_ < ng && 4 * g + 1 >= lo && 4 * g + 4 <= top) != 0;
+	};
+	auto do_group = [&](auto masked_tag) {
+		constexpr bool MASKED = decltype(masked_tag)::value;
+		const unsigned w = w_cur;
+		const unsigned wn = row_word(gi + 1); // issued now, selected after the four steps
+		const int g = max(g_hi - gi, g_lo); // rows that are done idle on their last group
+		const bool in_tile = gi < ng;
+		const int s3 = (int)((w >> 24) & 3u), s2 = (int)((w >> 16) & 3u), s1 = (int)((w >> 8) & 3u), s0 = (int)(w & 3u);
+		const int pb = 4 * g + 1;
+#define PSMC_C4(NORM, J, SYM)                                                                                                   \
+		count4_step<NORM, MASKED>(sc, lds_e, lds_re, k0, SYM, Xg[J], x, in_tile && pb + J <= top && pb + J >= lo, mult, acc, S); \
+		load_row(g - 1, J, Xg[J]);                                                                                          \
+		__builtin_amdgcn_sched_barrier(0);
+		PSMC_C4(true, 3, s3) PSMC_C4(false, 2, s2) PSMC_C4(false, 1, s1) PSMC_C4(false, 0, s0)
+#undef PSMC_C4
+		if (in_tile && g == g_lo) storeN<NPLF>(bexit + (int64_t)tile * SF + k0, x); // x = bt_lo: the group holding lo is the row's last
+		w_cur = wn;
+	};
+	for (; gi < ng_max && !all_full(gi); ++gi) do_group(std::true_type{});  // a top that is not a multiple of 4
+	for (; gi < ng_max && all_full(gi); ++gi) do_group(std::false_type{});
+	for (; gi < ng_max; ++gi) do_group(std::true_type{});                    // rows of unequal length, a lo that is not 1 mod 4
+	// the matrix-core results are not interlocked against plain reads: let the last instructions drain
+	asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
+	             : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+	               "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
+	               "+a"(acc[3][2]), "+a"(acc[3][3]));
+	// C[4 M + j][4 N + j2], M = row + 4 r, N = m: four adjacent columns per lane
+	double *out = Cpart + (int64_t)group * (SF * SF);
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const double v[NPLF] = {acc[j][0][r], acc[j][1][r], acc[j][2][r], acc[j][3][r]};
+			storeN<NPLF>(out + (4 * (row + 4 * r) + j) * SF + k0, v);
+		}
+	if (valid) {
+		double *os = Epart + (int64_t)tile * (3 * SF) + k0;
+		const double zero[NPLF] = {0.0, 0.0, 0.0, 0.0};
+		storeN<NPLF>(os, S[0]); storeN<NPLF>(os + SF, S[1]); storeN<NPLF>(os + 2 * SF, zero); // missing symbols are not counted (khmm.c:355)
+	}
+}
+
+// which: 0 = every group of four tiles, 2 = the groups a repair touched
+void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which)
+{
+	const int n_groups = (p.n_chunks + 3) / 4;
+	if (n_groups <= 0) return;
+	hipLaunchKernelGGL(k_bwd_count4_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, p.n_chunks,
+	                   which == 2 ? 2 : 0, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
 }
 
 } // namespace psmc

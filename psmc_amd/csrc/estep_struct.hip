@@ -84,6 +84,8 @@ constexpr int SWEEP_WALK = 1;       // leave only the boundary vectors (entry / 
 constexpr int SWEEP_TOP_ONLY = 4;   // backward: stop once the top tile's start vector (bentry) is stored: the warm-up alone
 constexpr int SWEEP_NO_TOUCH = 8;   // REPAIR kernels: do not flag the tile for the redo pass of the counts
 constexpr int SWEEP_FROM_ENTRY = 2; // REPAIR kernels: start from the boundary vector a walk left instead of the neighbour's table row
+constexpr int SWEEP_CKPT = 16;     // forward: store X only at the positions p % 8 == 0 (and the item's last one): the
+                                   // factored counts recompute the rest from these checkpoints (estep_factored.hip)
 
 // ------------------------------------------------------------------ forward
 // per-row bookkeeping of the tile boundary the sweep crosses next
@@ -94,8 +96,9 @@ struct FwdCursor { int next_lo, tile; };
 template <int MODE, int J, int NPL>
 __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
-                                         double *fo, double *io, double *entry)
+                                         double *fo, double *io, double *entry, int ckg)
 {
+	// ckg (wave-uniform): 0 = every X is stored, 1 / 2 = checkpoints only, group ends at p % 8 == 0 / 4
 	// base = index of the group's first position (multiple of 4), J = step inside the group;
 	// lo0 = first position whose X is stored (INT_MAX for a walk, which only leaves the boundary vectors)
 	const int p = base + J + 1, idx = base + J;
@@ -116,23 +119,24 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double 
 	struct_step<NPL>(c, x);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
-	if (MODE == 1 || (MODE == 0 && p >= lo0)) storeN<NPL>(fo + (int64_t)idx * S, x);
+	if (MODE == 1) { if (ckg == 0 || (J == 3 && ckg == 1)) storeN<NPL>(fo + (int64_t)idx * S, x); }
+	else if (MODE == 0 && p >= lo0 && (ckg == 0 || (p & 7) == 0 || p == p_last)) storeN<NPL>(fo + (int64_t)idx * S, x);
 }
 template <int MODE, int NPL>
 __device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
-                                          double *fo, double *io, double *entry)
+                                          double *fo, double *io, double *entry, bool ckpt)
 {
 	// four groups of four unrolled steps: 16 fully unrolled steps x 3 modes x 2 directions overflow the
 	// instruction cache once the forward, backward and count kernels run side by side
 #pragma unroll 1
 	for (int g = 0; g < 4; ++g) {
 		const unsigned w = sym_word(sv, g);
-		const int pb = base + 4 * g;
-		fwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
-		fwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
-		fwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
-		fwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry);
+		const int pb = base + 4 * g, ckg = ckpt ? 2 - (g & 1) : 0;
+		fwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		fwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		fwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		fwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
 	}
 }
 
@@ -147,7 +151,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
                                                 double *__restrict__ invd, double *__restrict__ entry,
                                                 int *__restrict__ touch_f)
 {
-	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
+	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0, ckpt = (flags & SWEEP_CKPT) != 0;
 	constexpr int S = 16 * NPL;
 	__shared__ double lds_e[4 * S]; // e[0], e[1], 1, 1
 	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
@@ -213,9 +217,9 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 			}
 			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
 			const int mode = !full ? 0 : (base + 1 >= lo_store ? 1 : 2);
-			if (__all(mode == 1)) fwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else if (__all(mode == 2)) fwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else fwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			if (__all(mode == 1)) fwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
+			else if (__all(mode == 2)) fwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
+			else fwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
 		}
 	}
 }
@@ -614,13 +618,15 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 // which: 0 = the sweep items [first, first+n), 1 = flagged tiles of the current repair round,
 //        2 = walks over the glued runs [0, n) (boundary vectors only), 3 = every tile of the glued
 //        runs, recomputed from the boundary vector its walk left, 4 (backward) = warm-up only: leave
-//        the start vector of every item's top tile in bentry (fused backward + counts)
+//        the start vector of every item's top tile in bentry (fused backward + counts), 5 (backward) = flagged
+//        tiles of the current repair round, boundary vectors only (fused: no bt table to repair)
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
-	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0); // run tiles are done before the counts start
+	const int flags = (which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0)) // run tiles are done before the counts start
+	                  | (p.ckpt ? SWEEP_CKPT : 0);
 #define PSMC_LF(REP, NPL) hipLaunchKernelGGL((k_fwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
 	const bool rep = !(which == 0 || which == 2);
@@ -632,8 +638,8 @@ void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 {
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
-	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
-	const int flags = which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? SWEEP_TOP_ONLY : 0));
+	const SweepItem *items = (const SweepItem *)(which == 1 || which == 5 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
+	const int flags = which == 2 || which == 5 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? SWEEP_TOP_ONLY : 0));
 #define PSMC_LB(REP, NPL) hipLaunchKernelGGL((k_bwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, \
 		n_items, p.warmup, p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b)
 	const bool rep = !(which == 0 || which == 2 || which == 4);

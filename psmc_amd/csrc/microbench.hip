@@ -69,6 +69,31 @@ __global__ __launch_bounds__(64) void k_microbench(double *out, double seed)
 		t1 = __builtin_readcyclecounter();
 		if (lane == 0) out[13] = (double)(t1 - t0) / (N_ITER * 16 * 4);
 		sink += c0[0] + c1[1] + c2[2] + c3[3];
+		// do FP64 vector instructions of the same wave overlap with its matrix instructions?  Per group: 4 MFMA
+		// (independent accumulators) followed by 32 independent v_fma_f64 (8 chains) / 32 v_mov_b32_dpp
+		double f0 = x, f1 = x + 1, f2 = x + 2, f3 = x + 3, f4 = x + 4, f5 = x + 5, f6 = x + 6, f7 = x + 7;
+#define MB_MFMA4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c1, 0, 0, 0); \
+		 c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c3, 0, 0, 0);
+#define MB_FMA8 f0 = __builtin_fma(f0, m, x); f1 = __builtin_fma(f1, m, x); f2 = __builtin_fma(f2, m, x); f3 = __builtin_fma(f3, m, x); \
+		f4 = __builtin_fma(f4, m, x); f5 = __builtin_fma(f5, m, x); f6 = __builtin_fma(f6, m, x); f7 = __builtin_fma(f7, m, x);
+		t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER; ++it) { REPEAT16(MB_MFMA4 __builtin_amdgcn_sched_barrier(0); MB_FMA8 MB_FMA8 MB_FMA8 MB_FMA8 __builtin_amdgcn_sched_barrier(0);) }
+		t1 = __builtin_readcyclecounter();
+		if (lane == 0) out[18] = (double)(t1 - t0) / (N_ITER * 16);
+		sink += c0[0] + c1[1] + c2[2] + c3[3] + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
+		int i0 = lane, i1 = lane + 1, i2 = lane + 2, i3 = lane + 3;
+#define MB_DPP8 i0 = __builtin_amdgcn_update_dpp(0, i0, 0x111, 0xf, 0xf, true); i1 = __builtin_amdgcn_update_dpp(0, i1, 0x111, 0xf, 0xf, true); \
+		i2 = __builtin_amdgcn_update_dpp(0, i2, 0x111, 0xf, 0xf, true); i3 = __builtin_amdgcn_update_dpp(0, i3, 0x111, 0xf, 0xf, true); \
+		i0 = __builtin_amdgcn_update_dpp(0, i0, 0x101, 0xf, 0xf, true); i1 = __builtin_amdgcn_update_dpp(0, i1, 0x101, 0xf, 0xf, true); \
+		i2 = __builtin_amdgcn_update_dpp(0, i2, 0x101, 0xf, 0xf, true); i3 = __builtin_amdgcn_update_dpp(0, i3, 0x101, 0xf, 0xf, true);
+		t0 = __builtin_readcyclecounter();
+		for (int it = 0; it < N_ITER; ++it) { REPEAT16(MB_MFMA4 __builtin_amdgcn_sched_barrier(0); MB_DPP8 MB_DPP8 MB_DPP8 MB_DPP8 __builtin_amdgcn_sched_barrier(0);) }
+		t1 = __builtin_readcyclecounter();
+		if (lane == 0) out[19] = (double)(t1 - t0) / (N_ITER * 16);
+		sink += c0[0] + c1[1] + c2[2] + c3[3] + (double)(i0 + i1 + i2 + i3);
+#undef MB_MFMA4
+#undef MB_FMA8
+#undef MB_DPP8
 	}
 	{ // structured O(N) sweep step (estep_struct.hip): dependent chain, 4 tiles per wave
 		StructPar c;
@@ -130,6 +155,114 @@ __global__ __launch_bounds__(256) void k_stream_copy8(const double *__restrict__
 int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n)
 {
 	hipLaunchKernelGGL(k_stream_copy8, dim3(8192), dim3(256), 0, stream, src, dst, n);
+	return (int)hipGetLastError();
+}
+
+// Achievable-HBM probes, 16 bytes per lane like the table traffic of the E-step kernels: [0] fill, [1] read,
+// [2] copy, [3] the store pattern of the structured sweeps (a wave appends 512 B per step to each of four
+// streams, two 16-byte stores per lane 32 bytes apart).  The roofline of DESIGN.md quotes the nominal 8 TB/s;
+// these are what a plain streaming kernel reaches on the same box.
+typedef double pd2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_hbm_fill(pd2_t *__restrict__ dst, size_t n)
+{
+	const pd2_t v = {1.0, 2.0};
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = v;
+}
+__global__ __launch_bounds__(256) void k_hbm_read(const pd2_t *__restrict__ src, size_t n, double *__restrict__ sink)
+{
+	double s = 0.0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const pd2_t v = src[i]; s += v.x + v.y; }
+	if (s == 123.456) sink[0] = s;
+}
+__global__ __launch_bounds__(256) void k_hbm_copy(const pd2_t *__restrict__ src, pd2_t *__restrict__ dst, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(64) void k_hbm_sweepstore(double *__restrict__ dst, size_t steps_per_stream)
+{
+	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15;
+	double *o = dst + ((size_t)blockIdx.x * 4 + row) * steps_per_stream * 64 + 4 * m;
+	pd2_t a = {1.0, 2.0}, b = {3.0, 4.0};
+	for (size_t t = 0; t < steps_per_stream; ++t) {
+		reinterpret_cast<pd2_t *>(o)[0] = a; reinterpret_cast<pd2_t *>(o)[1] = b;
+		o += 64; a.x += 1.0; b.y += 1.0;
+	}
+}
+int run_hbm_probe(hipStream_t stream, int which, double *a, double *b, size_t bytes)
+{
+	const size_t n16 = bytes / 16;
+	if (which == 0) hipLaunchKernelGGL(k_hbm_fill, dim3(16384), dim3(256), 0, stream, (pd2_t *)a, n16);
+	else if (which == 1) hipLaunchKernelGGL(k_hbm_read, dim3(16384), dim3(256), 0, stream, (const pd2_t *)a, n16, b);
+	else if (which == 2) hipLaunchKernelGGL(k_hbm_copy, dim3(16384), dim3(256), 0, stream, (const pd2_t *)a, (pd2_t *)b, n16);
+	else { // 4096-step streams (2 MB each)
+		const size_t steps = 4096, streams = bytes / (steps * 512);
+		hipLaunchKernelGGL(k_hbm_sweepstore, dim3((unsigned)(streams / 4)), dim3(64), 0, stream, a, steps);
+	}
+	return (int)hipGetLastError();
+}
+
+// The structured step (4 tiles per wave) on n_waves wavefronts at once: per wave the cycles per step and the
+// shader clock it saw (cycle counter against the 100 MHz constant clock).  One wave alone runs at the peak
+// clock; a full device of FP64 work may not.
+__global__ __launch_bounds__(64) void k_load_probe(double *__restrict__ out, int steps, double seed)
+{
+	const int lane = threadIdx.x;
+	StructPar c;
+	double xv[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		c.mS[i] = 0.01 + 1e-4 * (lane + i) + seed * 1e-9; c.wS[i] = 0.012 - 1e-5 * lane; c.mP[i] = 0.009 + 1e-5 * i;
+		c.wP[i] = 0.011; c.dd[i] = 0.3; xv[i] = 1.0 + 0.01 * (lane & 15) + 0.001 * i;
+	}
+	const unsigned long long w0 = wall_clock64(), t0 = __builtin_readcyclecounter();
+	for (int it = 0; it < steps; it += 4) {
+		struct_step(c, xv); struct_step(c, xv); struct_step(c, xv);
+		const double inv = rcp_newton(row_sum16((xv[0] + xv[1]) + (xv[2] + xv[3])));
+		struct_step(c, xv);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) xv[i] *= inv;
+	}
+	const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+	if (lane == 0) {
+		out[2 * blockIdx.x] = (double)(t1 - t0) / steps;
+		out[2 * blockIdx.x + 1] = (double)(t1 - t0) / (double)(w1 - w0) * 100.0;
+	}
+	if (xv[0] + xv[1] + xv[2] + xv[3] == 123.456) out[0] = 0.0;
+}
+// the same with eight tiles per wave (8 lanes x 8 states)
+__global__ __launch_bounds__(64) void k_load_probe_h8(double *__restrict__ out, int steps, double seed)
+{
+	const int lane = threadIdx.x;
+	StructParN<8> c;
+	double xv[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		c.mS[i] = 0.01 + 1e-4 * (lane + i) + seed * 1e-9; c.wS[i] = 0.012 - 1e-5 * lane; c.mP[i] = 0.009 + 1e-5 * i;
+		c.wP[i] = 0.011; c.dd[i] = 0.3; xv[i] = 1.0 + 0.01 * (lane & 7) + 0.001 * i;
+	}
+	const Half8Masks k = half8_masks(lane);
+	const unsigned long long w0 = wall_clock64(), t0 = __builtin_readcyclecounter();
+	for (int it = 0; it < steps; it += 4) {
+		struct_step_h8(c, xv, k); struct_step_h8(c, xv, k); struct_step_h8(c, xv, k);
+		const double inv = rcp_newton(half8_sum(((xv[0] + xv[1]) + (xv[2] + xv[3])) + ((xv[4] + xv[5]) + (xv[6] + xv[7]))));
+		struct_step_h8(c, xv, k);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) xv[i] *= inv;
+	}
+	const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+	if (lane == 0) {
+		out[2 * blockIdx.x] = (double)(t1 - t0) / steps;
+		out[2 * blockIdx.x + 1] = (double)(t1 - t0) / (double)(w1 - w0) * 100.0;
+	}
+	double sum = 0.0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) sum += xv[i];
+	if (sum == 123.456) out[0] = 0.0;
+}
+int run_load_probe(hipStream_t stream, double *d_out, int n_waves, int steps)
+{
+	if (steps < 0) { hipLaunchKernelGGL(k_load_probe_h8, dim3(n_waves), dim3(64), 0, stream, d_out, -steps, 0.37); return (int)hipGetLastError(); }
+	hipLaunchKernelGGL(k_load_probe, dim3(n_waves), dim3(64), 0, stream, d_out, steps, 0.37);
 	return (int)hipGetLastError();
 }
 

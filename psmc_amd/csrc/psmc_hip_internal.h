@@ -44,6 +44,7 @@ struct EstepLaunch {
 	int walk_impl;       // 1: one wave per glued run, one state per lane (k_walk1_struct); 0: four runs per wave
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
+	int ckpt;            // fused == 2: the forward sweep stores X at p % 8 == 0 only, the counts recompute the rest
 	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)
 	int n_items_f, n_items_b, tile_len;
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
@@ -96,7 +97,7 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 void launch_walks(const EstepLaunch &p, hipStream_t st);
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols);
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb);
-void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
+void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which);
 void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
@@ -104,5 +105,7 @@ int launch_post_decode(hipStream_t st, const double *f, const double *b, const d
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 int run_microbench(hipStream_t stream, double *d_out);
 int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n);
+int run_hbm_probe(hipStream_t stream, int which, double *a, double *b, size_t bytes);
+int run_load_probe(hipStream_t stream, double *d_out, int n_waves, int steps);
 
 } // namespace psmc

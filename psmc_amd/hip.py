@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
-    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe",
+    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe",
 ]
 
 
@@ -259,7 +259,9 @@ MICROBENCH_NAMES = ["fmac_dpp dependent", "v_fma_f64 dependent", "v_add_f64 depe
                     "v_mul_f64 8 indep (per op)", "f64 division dependent", "mfma_f64_16x16x4 dependent",
                     "mfma_f64_16x16x4 4 accumulators (per op)", "structured step dependent (per step)",
                     "structured step + emission + norm/4 (per step)", "cycle counter MHz (vs 100 MHz wall clock)",
-                    "one-state-per-lane structured step + emission + norm/4 (per step)"]
+                    "one-state-per-lane structured step + emission + norm/4 (per step)",
+                    "4 mfma_f64 + 32 independent v_fma_f64 (per group; 4 mfma alone: 4x the 4-accumulator figure)",
+                    "4 mfma_f64 + 32 v_mov_b32_dpp (per group)"]
 
 
 def microbench(device=0):
@@ -270,6 +272,28 @@ def microbench(device=0):
     if rc != 0:
         raise HipError("microbench: %s" % lib.psmc_hip_strerror(rc).decode())
     return dict(zip(MICROBENCH_NAMES, out.tolist()))
+
+
+def hbm_probe(nbytes=8 << 30, device=0):
+    """Achievable HBM rates of plain streaming kernels (GB/s): fill, read, copy, sweep-like stores."""
+    lib = load_library()
+    lib.psmc_hip_hbm_probe.argtypes = [C.c_int, C.c_longlong, _dp]
+    out = np.zeros(4)
+    rc = lib.psmc_hip_hbm_probe(int(device), int(nbytes), _p(out))
+    if rc != 0:
+        raise HipError("hbm_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+    return dict(zip(["fill", "read", "copy", "sweep_store"], out.tolist()))
+
+
+def load_probe(n_waves, steps=20000, device=0):
+    """The structured step on n_waves waves at once: kernel ms, mean / max cycles per step, mean shader MHz."""
+    lib = load_library()
+    lib.psmc_hip_load_probe.argtypes = [C.c_int, C.c_int, C.c_int, _dp]
+    out = np.zeros(4)
+    rc = lib.psmc_hip_load_probe(int(device), int(n_waves), int(steps), _p(out))
+    if rc != 0:
+        raise HipError("load_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+    return dict(zip(["ms", "cycles_per_step", "max_cycles_per_step", "mhz"], out.tolist()))
 
 
 def stream_probe(n_doubles=1 << 27, device=0):

@@ -348,10 +348,13 @@ def tri_sums(A):
     return np.stack([lo.sum(1), up.sum(1), np.diag(A).copy(), lo.sum(0), up.sum(0)])
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0)])
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
+                                  dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0)])
 def test_fast_factored_statistics(hip, golden, oracle, opts):
     """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
-    (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset."""
+    (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset.
+    Default: X recomputed from checkpoints every 8 positions (tile lengths that are multiples of 8);
+    ckpt=0 or any other tile length reads the full X table."""
     for key in ("n64_curve", "n23_flat"):
         p = golden.params(key)
         n = p["a"].shape[0]

@@ -34,7 +34,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_STATES = 64
 BYTES_PER_BIN = 16 * N_STATES + 18   # obs x2, f write+read, s write+read
-HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (psmc_hip_hbm_probe: 5.3-5.9 TB/s streaming on this box)
+F64_PEAK_TFLOPS = 78.6               # dense FP64, vector or v_mfma_f64_16x16x4 (they share the pipe: psmc_hip_microbench)
 
 
 def log(*a):
@@ -178,7 +179,9 @@ def main():
     if rank == 0:
         # dominant KERNEL (one launch): the speculative forward / backward sweep or the expect kernel
         if mode == hip.MODE_FAST:
-            if diag.get("structured"):  # both bulk sweeps are ONE launch (k_sweep_struct): 2 x (8n+9) bytes per bin
+            if diag.get("back_half") == 1:  # forward sweep, then backward sweep + counts in one kernel (estep_fused.hip)
+                cand = {"k_fwd_struct<speculate>": kern["fwd_sweep"], "k_bwd_count4_struct": kern["expect"]}
+            elif diag.get("structured"):  # both bulk sweeps are ONE launch (k_sweep_struct): 2 x (8n+9) bytes per bin
                 cand = {"k_sweep_struct": kern["fwd_sweep"], "k_expect_mfma": kern["expect"]}
             else:
                 cand = {"k_fwd_fast<speculate>": kern["fwd_sweep"], "k_bwd_fast<speculate>": kern["bwd_sweep"], "k_expect_mfma": kern["expect"]}
@@ -191,7 +194,12 @@ def main():
         # counts: read X and bt (+ scales, obs); k_sweep_struct: write X and bt (+ scales), read obs twice; one sweep: half
         alg_b = (16 * N_STATES + 17) if dom == "k_expect_mfma" else ((16 * N_STATES + 18) if dom == "k_sweep_struct" else (8 * N_STATES + 9))
         ach = bins * alg_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        pipe = bins * BYTES_PER_BIN / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
+        fused = diag.get("back_half") == 1
+        bytes_per_bin = (2 * (8 * N_STATES + 9)) if fused else BYTES_PER_BIN  # fused: X written once, read once; bt never stored
+        pipe = bins * bytes_per_bin / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
+        # FP64 work of the fused kernel per bin: the counts (2 n^2 flop on v_mfma_f64_16x16x4) plus the O(n) backward step
+        flop_b = 2 * N_STATES * N_STATES + 24 * N_STATES
+        tfl = bins * flop_b / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic = None
         try:  # HBM bytes per launch from the rocprofv3 PMC pass of this same command (profiles/, scripts/gpu_pmc.sh)
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -214,15 +222,21 @@ def main():
                            "repair_rounds": [diag.get("fwd_rounds"), diag.get("bwd_rounds")],
                            "repaired_tiles": [diag.get("fwd_tiles"), diag.get("bwd_tiles")],
                            "boundary_err": max(diag.get("warm_err_fwd", 0), diag.get("warm_err_bwd", 0))} if diag else {})},
-            "roofline": {"bound": "hbm", "kernel": dom,
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "alg_bytes_per_bin": alg_b, "kernel_ms": dom_ms,
-                         "pipeline": {"alg_bytes_per_bin": BYTES_PER_BIN, "ms": kern["total"], "achieved": pipe,
+            "roofline": {**({"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tfl / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop_b,
+                             "hbm": {"alg_bytes_per_bin": 8 * N_STATES + 9, "achieved_GBs": bins * (8 * N_STATES + 9) / (dom_ms * 1e-3) / 1e9}}
+                            if dom == "k_bwd_count4_struct" else
+                            {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_bin": alg_b}),
+                         "traffic": traffic, "kernel_ms": dom_ms,
+                         "pipeline": {"alg_bytes_per_bin": bytes_per_bin, "ms": kern["total"], "achieved": pipe,
                                       "frac": pipe / HBM_PEAK_GBS},
                          "kernels_ms": kern,
-                         "fp64_note": "forward and backward sweep kernels run side by side and share the HBM; the counts "
-                                      "kernel (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) reaches %.1f of 78.6 TFLOP/s" %
+                         "fp64_note": ("the backward sweep feeds the counts (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) in the same "
+                                       "wave; f64 matrix and vector instructions share the FP64 pipe (78.6 TFLOP/s dense either way): "
+                                       "%.1f TFLOP/s of counts + O(n) sweep work in that kernel" if fused else
+                                       "forward and backward sweep kernels run side by side and share the HBM; the counts "
+                                       "kernel (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) reaches %.1f of 78.6 TFLOP/s") %
                                       (bins * 2 * N_STATES * N_STATES / (kern["expect"] * 1e-3) / 1e12 if kern.get("expect", 0) > 0 else 0.0)},
         }
         if world == 1 and args.cpu_sample > 0:

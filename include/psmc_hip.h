@@ -55,9 +55,13 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * "expect_impl" (0 VALU, 1 MFMA f64), "structured" (1 auto / 0 always dense sweeps),
  * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront), "learn" (1: tiles
  * that needed a repair are glued to their neighbour for the following E-steps of this context;
- * results then depend on the call history within the stated tolerance), "group_cap" (bins), "fuse" (1: with the structured sweeps, backward sweep and counts
- * in one kernel -- bt never stored, half the HBM traffic, FP64-issue bound; default 0), "ckpt" (1, default:
- * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table). */
+ * results then depend on the call history within the stated tolerance), "group_cap" (bins), "fuse" (1, default: with the
+ * structured sweeps and up to 64 states the backward sweep feeds the counts' matrix instructions directly -- bt never
+ * stored, half the HBM traffic; 0: bt table + separate counts kernel), "ckpt" (1, default:
+ * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table),
+ * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kc_min" (runs of at least this
+ * many tiles get their boundary vectors from a chain of tile transfer matrices instead of a walk; 0: never),
+ * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
@@ -110,15 +114,17 @@ int psmc_hip_estep_factored(psmc_hip_ctx *ctx, const double *a, const double *e,
                             double *E, double *LL);
 
 /* Diagnostic: out = {structured sweeps used (0/1), tile length in bins, forward sweep items,
- * backward sweep items} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured sweeps
- *  are chosen automatically when a[][] has the two rank-1
+ * backward sweep items, back half (0: bt table + counts kernel, 1: backward sweep fused with the counts, 2: factored
+ * statistics), checkpointed X (0/1)} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured
+ * sweeps are chosen automatically when a[][] has the two rank-1
  * triangles psmc_update_hmm builds (core.c:112-122); otherwise the dense sweeps run. */
-int psmc_hip_fast_info(psmc_hip_ctx *ctx, int out[4]);
+int psmc_hip_fast_info(psmc_hip_ctx *ctx, int out[6]);
 
 /* Copies the forward/backward tables of one loaded segment to the host after
  * an E-step (replaces reading hd->f, hd->b, hd->s: aux.c:159-200).  f,b: L*n,
  * s: L.  Exact mode: the reference's values bit for bit.  Fast mode (diagnostic):
- * f = X, b = bt = e[o_p]*B_p, s = 1/d_p at p % 4 == 0. */
+ * f = X, b = bt = e[o_p]*B_p, s = 1/d_p at p % 4 == 0; b only
+ * with "fuse" = 0 (the fused back half never stores bt), all of f only without checkpointing. */
 int psmc_hip_get_tables(psmc_hip_ctx *ctx, int seg, double *f, double *b, double *s);
 
 /* Posterior decoding of one segment on the device after an exact E-step: replaces

@@ -26,6 +26,7 @@ struct psmc_hip_ctx {
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
 	int struct_tiles = 8192;   // "struct_tiles": tiles aimed at when the structured sweeps are used (4 per wave)
 	bool use_struct = false, planned_struct = false;
+	int last_fused = 0, last_ckpt = 0; // what the last fast E-step ran: EstepLaunch::fused / ckpt
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
@@ -406,6 +407,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
+	c->last_fused = p.fused; c->last_ckpt = p.ckpt;
 	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
 	if (c->ns == 128) {
@@ -820,11 +822,12 @@ extern "C" int psmc_hip_estep_factored(psmc_hip_ctx *c, const double *a, const d
 	return PSMC_HIP_OK;
 }
 
-extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[4])
+extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[6])
 {
 	if (!c || !out) return PSMC_HIP_EINVAL;
 	out[0] = c->use_struct ? 1 : 0; out[1] = c->chunk_used; out[2] = c->use_struct ? c->n_items_f : (int)c->chunks.size();
 	out[3] = c->use_struct ? c->n_items_b : (int)c->chunks.size();
+	out[4] = c->last_fused; out[5] = c->last_ckpt;
 	return PSMC_HIP_OK;
 }
 
@@ -1025,5 +1028,37 @@ extern "C" int psmc_hip_load_probe(int device, int n_waves, int steps, double *o
 		rc = PSMC_HIP_OK;
 	} else rc = PSMC_HIP_EDEVICE;
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+	return rc;
+}
+
+// Diagnostic (not in the public header): load_probe with the table stores of a sweep; mode 1 / 2 see microbench.hip
+extern "C" int psmc_hip_load_probe_st(int device, int n_waves, int steps, int store_steps, int mode, double *out)
+{
+	int nd = psmc_hip_device_count();
+	if (n_waves < 1 || n_waves > (1 << 16) || steps < 4 || store_steps < 4 || store_steps > steps || !out) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	steps &= ~3; store_steps &= ~3;
+	double *d = nullptr, *tbl = nullptr;
+	const size_t tb = (size_t)n_waves * 4 * (size_t)store_steps * 512;
+	if (hipMalloc((void **)&d, sizeof(double) * 2 * (size_t)n_waves) != hipSuccess) return PSMC_HIP_ENOMEM;
+	if (hipMalloc((void **)&tbl, tb) != hipSuccess) { (void)hipFree(d); return PSMC_HIP_ENOMEM; }
+	(void)hipMemset(tbl, 0, tb);
+	std::vector<double> h((size_t)2 * n_waves);
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+	int rc = run_load_probe_st(nullptr, d, n_waves, steps, tbl, store_steps, mode);
+	(void)hipEventRecord(e0, nullptr);
+	if (rc == 0) rc = run_load_probe_st(nullptr, d, n_waves, steps, tbl, store_steps, mode);
+	(void)hipEventRecord(e1, nullptr);
+	float ms = 0;
+	if (rc == 0 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
+	    hipMemcpy(h.data(), d, sizeof(double) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+		double cyc = 0, mhz = 0, cmax = 0;
+		for (int i = 0; i < n_waves; ++i) { cyc += h[2 * (size_t)i]; mhz += h[2 * (size_t)i + 1]; cmax = std::max(cmax, h[2 * (size_t)i]); }
+		out[0] = ms; out[1] = cyc / n_waves; out[2] = cmax; out[3] = mhz / n_waves; out[4] = (double)tb / (ms * 1e-3) / 1e9;
+		rc = PSMC_HIP_OK;
+	} else rc = PSMC_HIP_EDEVICE;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); (void)hipFree(tbl);
 	return rc;
 }

@@ -217,11 +217,13 @@ __global__ __launch_bounds__(64) void k_bwd_fast(const double *__restrict__ aT, 
 // max_k |x/|x| - y/|y|| / max_k (y/|y|) over S = 64 or 128 states (lane and lane + 64), |.| = sum: boundary
 // vectors are compared as DIRECTIONS (a vector from the transfer-matrix chain has an arbitrary scale; every
 // consumer -- per-position normaliser of the counts, k_ll -- is scale-free)
-template <int S> __device__ __forceinline__ double rel_mismatch_vec(const double *x, const double *y, int lane) {
+template <int S> __device__ __forceinline__ double rel_mismatch_vec(const double *x, const double *y, int lane, bool with_scale = false) {
 	double xv = x[lane], yv = y[lane], xw = 0.0, yw = 0.0;
 	if (S == 128) { xw = x[64 + lane]; yw = y[64 + lane]; }
-	const double ix = 1.0 / wave_add(xv + xw), iy = 1.0 / wave_add(yv + yw);
+	const double sx = wave_add(xv + xw), sy = wave_add(yv + yw);
+	const double ix = 1.0 / sx, iy = 1.0 / sy;
 	double num = fabs(xv * ix - yv * iy), den = fabs(yv * iy);
+	if (with_scale) num = fmax(num, fabs(sx - sy) * iy * den); // the two vectors themselves, not only their directions
 	bool bad = (xv != xv) || (yv != yv) || (ix != ix) || (iy != iy);
 	if (S == 128) {
 		num = fmax(num, fabs(xw * ix - yw * iy)); den = fmax(den, fabs(yw * iy));
@@ -234,8 +236,12 @@ template <bool BWD, int S>
 __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks, int n_chunks, double tol,
                                                  const double *__restrict__ f, const double *__restrict__ mine,
                                                  const double *__restrict__ bexit, int *__restrict__ dirty,
-                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm)
+                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm, int with_scale)
 {
+	// with_scale (backward, bt table in use): row lo-1 of the table is written by the tile below as ITS start vector
+	// and read by this tile's counts next to its own bt[lo+1], so the two tiles must agree on the scale as well.  A
+	// warm-up of at least one normalising position leaves the natural scale; without one (warmup < 4) a start vector
+	// can have the right direction and the wrong length.
 	const int lane = threadIdx.x, b = blockIdx.x;
 	const Chunk c = chunks[b];
 	double m = 0.0;
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 		if (check) m = rel_mismatch_vec<S>(mine + (int64_t)b * S, f + (c.off + c.lo - 2) * S, lane);
 	} else {
 		check = !(c.flags & (CHUNK_ANCHOR_B | CHUNK_LAST)) && min(c.hi, c.L - 1) >= c.lo && b + 1 < n_chunks;
-		if (check) m = rel_mismatch_vec<S>(mine + (int64_t)b * S, bexit + (int64_t)(b + 1) * S, lane);
+		if (check) m = rel_mismatch_vec<S>(mine + (int64_t)b * S, bexit + (int64_t)(b + 1) * S, lane, with_scale != 0);
 	}
 	if (lane == 0) {
 		const int bad = check && !(m <= tol);
@@ -664,7 +670,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		(void)hipMemsetAsync(p.d_cnt + c.slot, 0, sizeof(int), c.st);
 		(void)hipMemsetAsync(p.d_warm + c.slot, 0, sizeof(unsigned long long), c.st);
 #define PSMC_LV(BW, S, MINE, DIRTY, CNT) hipLaunchKernelGGL((k_verify<BW, S>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, \
-			MINE, p.d_bexit, DIRTY, CNT, p.d_warm)
+			MINE, p.d_bexit, DIRTY, CNT, p.d_warm, (BW && !p.fused) ? 1 : 0)
 		if (!c.bwd) { if (p.ns == 128) PSMC_LV(false, 128, p.d_entry, p.d_dirty, p.d_cnt); else PSMC_LV(false, 64, p.d_entry, p.d_dirty, p.d_cnt); }
 		else { if (p.ns == 128) PSMC_LV(true, 128, p.d_bentry, p.d_dirty_b, p.d_cnt + 1); else PSMC_LV(true, 64, p.d_bentry, p.d_dirty_b, p.d_cnt + 1); }
 #undef PSMC_LV

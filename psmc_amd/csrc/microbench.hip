@@ -229,6 +229,54 @@ __global__ __launch_bounds__(64) void k_load_probe(double *__restrict__ out, int
 	}
 	if (xv[0] + xv[1] + xv[2] + xv[3] == 123.456) out[0] = 0.0;
 }
+// the 16x4 step with the table stores of a sweep: every wave appends 512 B per step to each of four streams
+// (mode 1: two 16-byte stores per lane and step;  mode 2: the same bytes, written as 2 KB per stream every 4th step)
+template <int MODE>
+__global__ __launch_bounds__(64) void k_load_probe_st(double *__restrict__ out, int steps, double seed, double *__restrict__ tbl,
+                                                        int store_steps)
+{
+	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15;
+	StructPar c;
+	double xv[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		c.mS[i] = 0.01 + 1e-4 * (lane + i) + seed * 1e-9; c.wS[i] = 0.012 - 1e-5 * lane; c.mP[i] = 0.009 + 1e-5 * i;
+		c.wP[i] = 0.011; c.dd[i] = 0.3; xv[i] = 1.0 + 0.01 * (lane & 15) + 0.001 * i;
+	}
+	double *o = tbl + ((size_t)blockIdx.x * 4 + row) * (size_t)store_steps * 64 + 4 * m;
+	const unsigned long long w0 = wall_clock64(), t0 = __builtin_readcyclecounter();
+	double keep[3][4];
+	for (int it = 0; it < steps; it += 4) {
+		const bool st = it >= steps - store_steps;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (j == 3) {
+				const double inv = rcp_newton(row_sum16((xv[0] + xv[1]) + (xv[2] + xv[3])));
+#pragma unroll
+				for (int i = 0; i < 4; ++i) xv[i] *= inv;
+			}
+			struct_step(c, xv);
+			if (MODE == 1) { if (st) { store4(o, xv); o += 64; } }
+			else if (j < 3) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) keep[j][i] = xv[i];
+			} else if (st) { store4(o, keep[0]); store4(o + 64, keep[1]); store4(o + 128, keep[2]); store4(o + 192, xv); o += 256; }
+		}
+	}
+	const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+	if (lane == 0) {
+		out[2 * blockIdx.x] = (double)(t1 - t0) / steps;
+		out[2 * blockIdx.x + 1] = (double)(t1 - t0) / (double)(w1 - w0) * 100.0;
+	}
+	if (xv[0] + xv[1] + xv[2] + xv[3] == 123.456) out[0] = 0.0;
+}
+int run_load_probe_st(hipStream_t stream, double *d_out, int n_waves, int steps, double *tbl, int store_steps, int mode)
+{
+	if (mode == 2) hipLaunchKernelGGL(k_load_probe_st<2>, dim3(n_waves), dim3(64), 0, stream, d_out, steps, 0.37, tbl, store_steps);
+	else hipLaunchKernelGGL(k_load_probe_st<1>, dim3(n_waves), dim3(64), 0, stream, d_out, steps, 0.37, tbl, store_steps);
+	return (int)hipGetLastError();
+}
+
 // the same with eight tiles per wave (8 lanes x 8 states)
 __global__ __launch_bounds__(64) void k_load_probe_h8(double *__restrict__ out, int steps, double seed)
 {

@@ -107,5 +107,6 @@ int run_microbench(hipStream_t stream, double *d_out);
 int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n);
 int run_hbm_probe(hipStream_t stream, int which, double *a, double *b, size_t bytes);
 int run_load_probe(hipStream_t stream, double *d_out, int n_waves, int steps);
+int run_load_probe_st(hipStream_t stream, double *d_out, int n_waves, int steps, double *tbl, int store_steps, int mode);
 
 } // namespace psmc

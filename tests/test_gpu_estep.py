@@ -217,7 +217,7 @@ def test_fast_small_golden(hip, golden, key, expect_impl):
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=1024), dict(chunk=256, n_sub=1), dict(chunk=4096, rep_impl=0),
                                   dict(chunk=2048, expect_impl=0), dict(chunk=1024, overlap=0), dict(chunk=512, warmup=128, overlap=3), dict(chunk=512, warmup=128, overlap=1),
-                                  dict(chunk=512, warmup=128, overlap=0)])
+                                  dict(chunk=512, warmup=128, overlap=0), dict(chunk=1024, fuse=0), dict(chunk=512, warmup=128, overlap=0, fuse=0)])
 def test_fast_mid_golden(hip, golden, opts):
     key = "n64_curve"
     p = golden.params(key)
@@ -231,7 +231,7 @@ def test_fast_mid_golden(hip, golden, opts):
     es.close()
 
 
-@pytest.mark.parametrize("opts", [dict(chunk=1024, warmup=64), dict(chunk=512, warmup=0), dict(chunk=2048, warmup=256, rep_impl=0)])
+@pytest.mark.parametrize("opts", [dict(chunk=1024, warmup=64), dict(chunk=512, warmup=0), dict(chunk=2048, warmup=256, rep_impl=0), dict(chunk=512, warmup=0, fuse=0)])
 def test_fast_speculation_is_repaired(hip, golden, opts):
     """A speculative overlap far below the chain's memory leaves tile boundaries that disagree;
     verify flags them and repair re-runs only those tiles until the statistics are right."""
@@ -293,15 +293,18 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0)])
-def test_fast_fused_backward_counts(hip, golden, oracle, opts):
-    """fuse=1: the wave that walks a tile backwards feeds bt straight into the f64 matrix cores (bt is never
-    stored).  Same tolerance, with speculation failures repaired (first call) and with learned runs (second)."""
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
+    """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is
+    never stored); fuse=0: bt table + separate counts kernel.  Same tolerance, with speculation failures repaired
+    (first call) and with learned runs (second)."""
     p = golden.params("n64_curve")
     o = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid)
-    es = hip.HipEStep(64, mode=hip.MODE_FAST, fuse=1, **opts)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, fuse=fuse, **opts)
     es.load_segments(golden.segs_mid)
     for it in range(3):
         check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+        assert es.fast_diag()["back_half"] == fuse
     es.select([5, 4, 5, 3, 5])
     check_fast(es.estep(p["a"], p["e"], p["a0"]), oracle.estep(p["a"], p["e"], p["a0"], [golden.segs_mid[i] for i in (5, 4, 5, 3, 5)]))
     es.close()
@@ -328,7 +331,7 @@ def test_fast_n128(hip, golden, oracle, opts):
 
 
 @pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, walk_impl=0),
-                                  dict(chunk=64, warmup=0, fuse=1), dict(chunk=5000, warmup=16, overlap=0)])
+                                  dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=5000, warmup=16, overlap=0)])
 def test_fast_odd_tilings(hip, golden, oracle, opts):
     """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
     everything is repaired / learned into runs and stays inside the tolerance."""

@@ -61,7 +61,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table),
  * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kc_min" (runs of at least this
  * many tiles get their boundary vectors from a chain of tile transfer matrices instead of a walk; 0: never),
- * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix). */
+ * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (1, default, fused back
+ * half only: tiles with an odd index inside their segment do not speculate but start, in a second phase, from the
+ * exact boundary vector their neighbour left -- half of the warm-up work; 0: every tile speculates). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:

@@ -24,11 +24,13 @@ struct psmc_hip_ctx {
 	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
 	double warm_tol = 1e-12;
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
+	bool struct_tiles_set = false; // the caller chose struct_tiles: no adaptation to small inputs
 	int struct_tiles = 8192;   // "struct_tiles": tiles aimed at when the structured sweeps are used (4 per wave)
 	bool use_struct = false, planned_struct = false;
 	int last_fused = 0, last_ckpt = 0; // what the last fast E-step ran: EstepLaunch::fused / ckpt
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
+	int two_phase = 1;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
 	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
@@ -82,8 +84,11 @@ struct psmc_hip_ctx {
 	       *d_LLpart = nullptr;
 	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
 	hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;
-	hipEvent_t evx[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t evx[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	int n_long_f = 0, n_long_b = 0, n_mem_f = 0, n_mem_b = 0;
+	int n_B_f = 0, n_B_b = 0, n_list_a = 0, n_list_b = 0; // two-phase plan: trailing single items of phase B; tile lists of the fused back half
+	int items_two_phase = -1;  // what the current item lists were built for
+	int *d_ftiles = nullptr;   // [2 * (n_tiles + 4)] tile lists A | B of the fused back half (bit 30: start from the tile above)
 	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
 	unsigned long long *d_warm = nullptr;
@@ -164,7 +169,7 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream5, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	for (int i = 0; i < 10; ++i)
+	for (int i = 0; i < 12; ++i)
 		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
@@ -189,13 +194,13 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items, c->d_Kcol};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_ritems) (void)hipHostFree(c->h_ritems);
 	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	for (int i = 0; i < 10; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+	for (int i = 0; i < 12; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
 	if (c->stream4) (void)hipStreamDestroy(c->stream4);
 	if (c->stream5) (void)hipStreamDestroy(c->stream5);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -214,12 +219,13 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
+	else if (k == "two_phase") { c->two_phase = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
-	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->plan_dirty = true; }
+	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
@@ -550,7 +556,9 @@ static int plan_fast(psmc_hip_ctx *c)
 	int T = c->chunk;
 	const bool st = c->use_struct;
 	if (T <= 0) { // auto: about target_waves (dense: 1 tile per wave) or struct_tiles (4 per wave) tiles, never below 256 bins
-		const int want = st ? c->struct_tiles : c->target_waves;
+		int want = st ? c->struct_tiles : c->target_waves;
+		// small inputs: a tile far shorter than its warm-up is mostly overhead; one wave per SIMD (4 tiles each) is enough
+		if (st && !c->struct_tiles_set && bins / want < 1536) want /= 2;
 		T = (int)((bins + want - 1) / want);
 		T = std::max(256, (T + 63) & ~63);
 	}
@@ -584,6 +592,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_items, (size_t)24 * nc + 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_ftiles, (size_t)2 * (nc + 4)))) return rc;
 		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
 		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
 		    hipHostGetDevicePointer((void **)&c->m_ritems, c->h_ritems, 0) != hipSuccess)
@@ -609,17 +618,27 @@ static int plan_fast(psmc_hip_ctx *c)
 
 // Sweep items of the structured kernels: maximal runs of glued tiles (one segment, at most group_cap
 // bins), ordered by step count so that the four rows of a wave finish together (longest first).
-static int build_items(psmc_hip_ctx *c)
+static int build_items(psmc_hip_ctx *c, bool two_phase)
 {
 	const int nc = (int)c->chunks.size(), W = c->warmup;
-	// key: glued runs first (launched apart from the bulk), then longest first
+	// Two-phase plan (fused back half): a single tile with an odd index inside its segment does not speculate.
+	// Forward it starts from the exact X_{lo-1} its (even) neighbour left in the table, backward from that
+	// neighbour's exit vector, in a second phase -- half of the warm-up work disappears and the phases overlap
+	// (forward B beside backward A).  Verify / repair / learning are unchanged: such a tile trivially agrees with
+	// its neighbour unless a later repair changes that neighbour.
+	std::vector<int> odd(nc, 0);
+	for (int b = 1; b < nc; ++b) if (c->chunks[b].off == c->chunks[b - 1].off) odd[b] = !odd[b - 1];
+	// key: glued runs first (launched apart from the bulk), then phase A longest first, then phase B
 	std::vector<std::pair<long long, std::pair<int, int>>> kf, kb; // (key, (first, count))
-	auto key = [](int steps, int count) { return (count > 1 ? -(1ll << 40) : 0ll) - steps; };
+	auto key = [](int steps, int count, bool phase_b) { return (count > 1 ? -(1ll << 40) : (phase_b ? (1ll << 40) : 0ll)) - steps; };
+	std::vector<char> fwd_b(nc, 0), from_above(nc, 0);
 	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
 		int e = b + 1;
 		while (e < nc && c->glue_f[e] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
 		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
-		kf.push_back({key(l.hi - std::max(1, h.lo - W) + 1, e - b), {b, e - b}});
+		const bool pb = two_phase && e - b == 1 && odd[b]; // odd => a predecessor tile exists in the segment
+		if (pb) fwd_b[b] = 1;
+		kf.push_back({key(l.hi - std::max(1, h.lo - W) + 1, e - b, pb), {b, e - b}});
 		b = e;
 	}
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
@@ -628,7 +647,10 @@ static int build_items(psmc_hip_ctx *c)
 		       c->chunks[e].lo < c->chunks[e].L) // a last tile holding only position L owns no transition: never a group's top
 			++e;
 		const Chunk &lo = c->chunks[b], &top = c->chunks[e - 1];
-		kb.push_back({key(std::min(top.hi + W + 1, top.L) - lo.lo, e - b), {b, e - b}});
+		// from above: the tile over it must exist in the segment and own a transition (it leaves an exit vector)
+		const bool pb = two_phase && e - b == 1 && odd[b] && b + 1 < nc && c->chunks[b + 1].off == lo.off && c->chunks[b + 1].lo < c->chunks[b + 1].L;
+		if (pb) from_above[b] = 1;
+		kb.push_back({key(std::min(top.hi + W + 1, top.L) - lo.lo, e - b, pb), {b, e - b}});
 		b = e;
 	}
 	std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
@@ -651,6 +673,25 @@ static int build_items(psmc_hip_ctx *c)
 	c->n_long_f = c->n_long_b = 0; // glued runs sort first (more steps than any single tile)
 	while (c->n_long_f < c->n_items_f && kf[c->n_long_f].second.second > 1) ++c->n_long_f;
 	while (c->n_long_b < c->n_items_b && kb[c->n_long_b].second.second > 1) ++c->n_long_b;
+	c->n_B_f = c->n_B_b = 0; // phase-B singles sort last
+	for (int b = 0; b < nc; ++b) { c->n_B_f += fwd_b[b]; c->n_B_b += from_above[b]; }
+	{ // tile lists of the fused back half: A = every tile whose X and start vector exist after phase A, B = the rest
+		// B must hold the tiles of phase B; A must hold the tile above every from-above tile; the rest (run tiles, ...)
+		// can go to either and balance the two launches (each should fit the device in one round of waves)
+		std::vector<int> la, lb, freet;
+		for (int b = 0; b < nc; ++b) {
+			if (fwd_b[b] || from_above[b]) lb.push_back(b | (from_above[b] ? (1 << 30) : 0));
+			else if (b > 0 && from_above[b - 1]) la.push_back(b);
+			else freet.push_back(b);
+		}
+		for (int b : freet) { if (la.size() <= lb.size()) la.push_back(b); else lb.push_back(b); }
+		c->n_list_a = (int)la.size(); c->n_list_b = (int)lb.size();
+		while (la.size() % 4) la.push_back(-1);
+		while (lb.size() % 4) lb.push_back(-1);
+		la.insert(la.end(), lb.begin(), lb.end());
+		if (!la.empty()) HIPCHK(c, hipMemcpy(c->d_ftiles, la.data(), sizeof(int) * la.size(), hipMemcpyHostToDevice));
+	}
+	c->items_two_phase = two_phase ? 1 : 0;
 	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
 	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": only its head tile is walked
@@ -701,8 +742,8 @@ static int build_items(psmc_hip_ctx *c)
 	}
 	c->items_dirty = false;
 	if (getenv("PSMC_HIP_DEBUG"))
-		fprintf(stderr, "[psmc_hip] items: %d tiles of %d bins, fwd %d items (%d runs, %d run tiles, %d walks, %d chains), bwd %d items (%d runs, %d run tiles, %d walks, %d chains), %d transfer matrices\n",
-		        nc, c->chunk_used, c->n_items_f, c->n_long_f, c->n_mem_f, c->n_wl_f, c->n_chain_f, c->n_items_b, c->n_long_b, c->n_mem_b, c->n_wl_b, c->n_chain_b, c->n_kc);
+		fprintf(stderr, "[psmc_hip] items: %d tiles of %d bins, fwd %d items (%d runs, %d run tiles, %d walks, %d chains, %d phase B), bwd %d items (%d runs, %d run tiles, %d walks, %d chains, %d from above), %d transfer matrices, fused lists %d + %d\n",
+		        nc, c->chunk_used, c->n_items_f, c->n_long_f, c->n_mem_f, c->n_wl_f, c->n_chain_f, c->n_B_f, c->n_items_b, c->n_long_b, c->n_mem_b, c->n_wl_b, c->n_chain_b, c->n_B_b, c->n_kc, c->n_list_a, c->n_list_b);
 	return 0;
 }
 
@@ -733,7 +774,9 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	EstepLaunch p;
 	fill_common(c, p, st);
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub_used;
-	if (c->use_struct && c->items_dirty && (rc = build_items(c))) return rc;
+	const bool two_phase = c->two_phase && p.fused == 1;
+	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase ? 1 : 0)) && (rc = build_items(c, two_phase))) return rc;
+	p.n_B_f = c->n_B_f; p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
 	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;
 	p.n_items_f = c->n_items_f; p.n_items_b = c->n_items_b; p.tile_len = c->chunk_used; p.h_ritems = c->h_ritems; p.m_ritems = c->m_ritems; p.m_cnt = c->m_cnt;
@@ -749,7 +792,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
 	p.d_Kcol = c->d_Kcol; p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * 4096 : nullptr; p.stream5 = c->stream5;
-	for (int i = 0; i < 10; ++i) p.evx[i] = c->evx[i];
+	for (int i = 0; i < 12; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
 	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());

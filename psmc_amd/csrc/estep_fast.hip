@@ -625,10 +625,15 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[7]) (void)hipEventRecord(p.ev[7], sm);
 		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0);
 		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sm);
-	} else if (p.structured) launch_fwd_struct(p, sm, 0, ff0, p.n_items_f - ff0);
+	} else if (p.structured) launch_fwd_struct(p, sm, 0, ff0, p.n_items_f - ff0 - p.n_B_f);
 	else launch_fwd<false>(p, sm);
-	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	(void)hipEventRecord(p.evx[1], sm);
+	if (p.n_B_f > 0) { // two-phase plan: the odd tiles, each from the X_{lo-1} its neighbour (phase A or a run tile) stored
+		if (lw && ov) (void)hipStreamWaitEvent(sm, p.evx[7], 0);
+		launch_fwd_struct(p, sm, 6, p.n_items_f - p.n_B_f, p.n_B_f);
+		(void)hipEventRecord(p.evx[10], sm);
+	}
+	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	if (one && ov) (void)hipStreamWaitEvent(sa, p.evx[1], 0); // the backward chain follows the same launch
 	if (!one && p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
 	if (p.fused) {
@@ -636,13 +641,17 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		// every bulk tile's start vector (beside the forward sweep, which is HBM-bound and leaves the VALUs
 		// idle); then one wave per tile walks it backwards and feeds the matrix cores.  bt never reaches HBM.
 		const int nb0 = lb ? p.n_long_b : 0;
-		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0);
-		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles
+		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0 - p.n_B_b);
+		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles (phase A)
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
 		if (p.fused == 2) launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0);
 		else {
 			if (lw && ov) (void)hipStreamWaitEvent(sa, p.evx[7], 0); // boundary vectors and X of the run tiles
-			launch_bwd_count(p, sa, 0);
+			launch_bwd_count(p, sa, 0, false);
+			if (p.n_list_b > 0) { // beside it: the forward sweep of phase B; then its tiles, from the exit vectors list A left
+				if (p.n_B_f > 0 && ov) (void)hipStreamWaitEvent(sa, p.evx[10], 0);
+				launch_bwd_count(p, sa, 1, false);
+			}
 		}
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sa);
 		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sa);
@@ -721,7 +730,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 		// tiles whose X a forward repair rewrote after their counts were taken
-		if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else launch_bwd_count(p, sm, 2);
+		if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else { launch_bwd_count(p, sm, 0, true); launch_bwd_count(p, sm, 1, true); }
 	} else if (ov) {
 		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // backward chain done
 		(void)hipStreamWaitEvent(sm, p.evx[3], 0);                                     // early expect done
@@ -734,7 +743,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sm);
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
-	const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_chunks + 3) / 4 : nS; // fused: one C partial per group of four tiles
+	const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_list_a + 3) / 4 + (p.n_list_b + 3) / 4 : nS; // fused: one C partial per group of four tiles
 	if (p.fused == 2) {
 		launch_reduce_factored(p, sm);
 	} else if (p.ns == 128) {

@@ -26,6 +26,12 @@
 
 namespace psmc {
 
+#ifdef PSMC_NO_SB
+#define PSMC_SB
+#else
+#define PSMC_SB __builtin_amdgcn_sched_barrier(0);
+#endif
+
 typedef double d4f_t __attribute__((ext_vector_type(4)));
 constexpr int NPLF = 4, SF = 64;
 
@@ -89,14 +95,17 @@ __device__ __forceinline__ void count4_step(const StructParN<NPLF> &sc, const do
 #endif
 }
 
-// Group g = tiles 4g .. 4g+3, each from its start vector bentry (left by the warm-up-only pass of k_bwd_struct,
-// by a walk / transfer-matrix chain, or by a boundary-only repair).  mode 0: every group;  mode 2: only groups
-// holding a tile whose X (touch_f) or start vector (touch_b) changed after the first pass.
+// Group g = the tiles tiles[4g .. 4g+3] (-1: none), each from its start vector bentry (left by the warm-up-only pass
+// of k_bwd_struct, by a walk / transfer-matrix chain, or by a boundary-only repair) or, with bit 30 set in the list
+// entry and mode 0, from the exit vector of the tile above it (two-phase plan: that tile belongs to the list that
+// ran before; the vector becomes this tile's bentry).  mode 0: every group;  mode 2: only groups holding a tile
+// whose X (touch_f) or start vector (touch_b) changed after the first pass, every tile from its bentry.
 __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                                const double *__restrict__ re, const uint8_t *__restrict__ obs,
-                                                               const Chunk *__restrict__ chunks, int n_tiles, int mode,
-                                                               const double *__restrict__ f, const double *__restrict__ bentry,
-                                                               double *__restrict__ bexit, double *__restrict__ Cpart,
+                                                               const Chunk *__restrict__ chunks, const int *__restrict__ tiles,
+                                                               int group0, int mode, const double *__restrict__ f,
+                                                               double *__restrict__ bentry, double *__restrict__ bexit,
+                                                               double *__restrict__ Cpart,
                                                                double *__restrict__ Epart, const int *__restrict__ touch_f,
                                                                const int *__restrict__ touch_b)
 {
@@ -105,9 +114,10 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 	lds_e[lane] = e[lane]; lds_e[SF + lane] = e[SF + lane]; lds_e[2 * SF + lane] = 1.0; lds_e[3 * SF + lane] = 1.0;
 	lds_re[lane] = re[lane]; lds_re[SF + lane] = re[SF + lane]; lds_re[2 * SF + lane] = 1.0; lds_re[3 * SF + lane] = 1.0;
 	__syncthreads();
-	const int group = blockIdx.x;
-	const bool valid = 4 * group + row < n_tiles;
-	const int tile = valid ? 4 * group + row : n_tiles - 1;
+	const int group = group0 + blockIdx.x;
+	const int entry = tiles[4 * blockIdx.x + row];
+	const bool valid = entry >= 0, from_above = valid && mode == 0 && (entry & (1 << 30)) != 0;
+	const int tile = valid ? (entry & ~(1 << 30)) : 0;
 	if (mode == 2 && !__any(valid && (touch_f[tile] | touch_b[tile]) != 0)) return;
 	const Chunk c = chunks[tile];
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
@@ -118,7 +128,8 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 	loadN<NPLF>(sp + 3 * SF + k0, sc.mS); loadN<NPLF>(sp + SF + k0, sc.wS);
 	loadN<NPLF>(sp + 2 * SF + k0, sc.mP); loadN<NPLF>(sp + k0, sc.wP); loadN<NPLF>(sp + 4 * SF + k0, sc.dd);
 	double x[NPLF];
-	loadN<NPLF>(bentry + (int64_t)tile * SF + k0, x);
+	loadN<NPLF>((from_above ? bexit + (int64_t)(tile + 1) * SF : bentry + (int64_t)tile * SF) + k0, x);
+	if (from_above) storeN<NPLF>(bentry + (int64_t)tile * SF + k0, x); // what verify compares and a redo starts from
 	d4f_t acc[4][4];
 	double S[2][NPLF];
 #pragma unroll
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 #define PSMC_C4(NORM, J, SYM)                                                                                                   \
 		count4_step<NORM, MASKED>(sc, lds_e, lds_re, k0, SYM, Xg[J], x, in_tile && pb + J <= top && pb + J >= lo, mult, acc, S); \
 		load_row(g - 1, J, Xg[J]);                                                                                          \
-		__builtin_amdgcn_sched_barrier(0);
+		PSMC_SB
 		PSMC_C4(true, 3, s3) PSMC_C4(false, 2, s2) PSMC_C4(false, 1, s1) PSMC_C4(false, 0, s0)
 #undef PSMC_C4
 		if (in_tile && g == g_lo) storeN<NPLF>(bexit + (int64_t)tile * SF + k0, x); // x = bt_lo: the group holding lo is the row's last
@@ -206,13 +217,15 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 	}
 }
 
-// which: 0 = every group of four tiles, 2 = the groups a repair touched
-void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which)
+// list 0 / 1: tile list A / B of the plan (api.hip build_items);  redo: only the groups a repair touched
+void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo)
 {
-	const int n_groups = (p.n_chunks + 3) / 4;
+	const int ga = (p.n_list_a + 3) / 4, gb = (p.n_list_b + 3) / 4;
+	const int n_groups = list == 0 ? ga : gb;
 	if (n_groups <= 0) return;
-	hipLaunchKernelGGL(k_bwd_count4_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, p.n_chunks,
-	                   which == 2 ? 2 : 0, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+	hipLaunchKernelGGL(k_bwd_count4_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks,
+	                   p.d_ftiles + (list == 0 ? 0 : 4 * ga), list == 0 ? 0 : ga, redo ? 2 : 0, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart,
+	                   p.d_Epart, p.d_touch_f, p.d_touch_b);
 }
 
 } // namespace psmc

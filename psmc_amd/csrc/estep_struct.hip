@@ -619,13 +619,14 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 //        2 = walks over the glued runs [0, n) (boundary vectors only), 3 = every tile of the glued
 //        runs, recomputed from the boundary vector its walk left, 4 (backward) = warm-up only: leave
 //        the start vector of every item's top tile in bentry (fused backward + counts), 5 (backward) = flagged
-//        tiles of the current repair round, boundary vectors only (fused: no bt table to repair)
+//        tiles of the current repair round, boundary vectors only (fused: no bt table to repair), 6 (forward) =
+//        phase-B items [first, first+n) of the two-phase plan: each from the X_{lo-1} its neighbour stored
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
-	const int flags = (which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0)) // run tiles are done before the counts start
+	const int flags = (which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 6 ? SWEEP_NO_TOUCH : 0))) // run tiles are done before the counts start
 	                  | (p.ckpt ? SWEEP_CKPT : 0);
 #define PSMC_LF(REP, NPL) hipLaunchKernelGGL((k_fwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)

@@ -29,7 +29,7 @@ struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged;
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
 	hipStream_t stream, stream2, stream3; // forward chain (main), backward chain, early expect
-	hipEvent_t evx[10];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
+	hipEvent_t evx[12];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
 	int overlap;
 	int rep_impl, expect_impl, n_states;
 	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)
@@ -50,6 +50,8 @@ struct EstepLaunch {
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
+	int n_B_f, n_B_b;                 // trailing single items of phase B (two-phase plan): forward from the neighbour's X, backward from above
+	const int *d_ftiles; int n_list_a, n_list_b; // fused back half: tile lists A | B (each padded to a multiple of 4 with -1)
 	hipStream_t stream4, stream5;
 	// walks: heads of the chain runs (count 1) followed by the short runs; transfer-matrix chains of the long runs
 	const int *d_wl_f, *d_wl_b; int n_wl_f, n_wl_b;
@@ -97,7 +99,7 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 void launch_walks(const EstepLaunch &p, hipStream_t st);
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols);
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb);
-void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int which);
+void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo);
 void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,

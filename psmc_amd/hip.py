@@ -36,7 +36,8 @@ class HipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libpsmc_hip.so")
+    """psmc_amd/libpsmc_hip.so; PSMC_HIP_LIB names another build of the same library (A/B timing of a kernel variant)."""
+    return os.environ.get("PSMC_HIP_LIB") or os.path.join(_HERE, "libpsmc_hip.so")
 
 
 def _share_torch_hip_runtime():

@@ -292,7 +292,8 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
     es.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0)])
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
+                                  dict(chunk=256, warmup=512, two_phase=0), dict(chunk=768, warmup=256, two_phase=0, overlap=0)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is
@@ -331,7 +332,7 @@ def test_fast_n128(hip, golden, oracle, opts):
 
 
 @pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, walk_impl=0),
-                                  dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=5000, warmup=16, overlap=0)])
+                                  dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, two_phase=0), dict(chunk=5000, warmup=16, overlap=0)])
 def test_fast_odd_tilings(hip, golden, oracle, opts):
     """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
     everything is repaired / learned into runs and stays inside the tolerance."""

@@ -618,7 +618,7 @@ static int plan_fast(psmc_hip_ctx *c)
 
 // Sweep items of the structured kernels: maximal runs of glued tiles (one segment, at most group_cap
 // bins), ordered by step count so that the four rows of a wave finish together (longest first).
-static int build_items(psmc_hip_ctx *c, bool two_phase)
+static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 {
 	const int nc = (int)c->chunks.size(), W = c->warmup;
 	// Two-phase plan (fused back half): a single tile with an odd index inside its segment does not speculate.
@@ -648,7 +648,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase)
 			++e;
 		const Chunk &lo = c->chunks[b], &top = c->chunks[e - 1];
 		// from above: the tile over it must exist in the segment and own a transition (it leaves an exit vector)
-		const bool pb = two_phase && e - b == 1 && odd[b] && b + 1 < nc && c->chunks[b + 1].off == lo.off && c->chunks[b + 1].lo < c->chunks[b + 1].L;
+		const bool pb = two_phase_bwd && e - b == 1 && odd[b] && b + 1 < nc && c->chunks[b + 1].off == lo.off && c->chunks[b + 1].lo < c->chunks[b + 1].L;
 		if (pb) from_above[b] = 1;
 		kb.push_back({key(std::min(top.hi + W + 1, top.L) - lo.lo, e - b, pb), {b, e - b}});
 		b = e;
@@ -691,7 +691,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase)
 		la.insert(la.end(), lb.begin(), lb.end());
 		if (!la.empty()) HIPCHK(c, hipMemcpy(c->d_ftiles, la.data(), sizeof(int) * la.size(), hipMemcpyHostToDevice));
 	}
-	c->items_two_phase = two_phase ? 1 : 0;
+	c->items_two_phase = (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0);
 	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
 	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": only its head tile is walked
@@ -774,8 +774,9 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	EstepLaunch p;
 	fill_common(c, p, st);
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub_used;
-	const bool two_phase = c->two_phase && p.fused == 1;
-	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase ? 1 : 0)) && (rc = build_items(c, two_phase))) return rc;
+	// the fused back half takes both directions of the two-phase plan, the factored one (item lists, two waves per SIMD) the forward one
+	const bool two_phase = c->two_phase && p.fused >= 1, two_phase_bwd = c->two_phase && p.fused == 1;
+	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase, two_phase_bwd))) return rc;
 	p.n_B_f = c->n_B_f; p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
 	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;

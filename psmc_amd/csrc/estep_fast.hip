@@ -644,8 +644,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0 - p.n_B_b);
 		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles (phase A)
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
-		if (p.fused == 2) launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0);
-		else {
+		if (p.fused == 2) {
+			if (p.n_B_f > 0 && ov) (void)hipStreamWaitEvent(sa, p.evx[10], 0); // X of the phase-B tiles
+			launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0);
+		} else {
 			if (lw && ov) (void)hipStreamWaitEvent(sa, p.evx[7], 0); // boundary vectors and X of the run tiles
 			launch_bwd_count(p, sa, 0, false);
 			if (p.n_list_b > 0) { // beside it: the forward sweep of phase B; then its tiles, from the exit vectors list A left

@@ -222,9 +222,13 @@ def main():
                            "repair_rounds": [diag.get("fwd_rounds"), diag.get("bwd_rounds")],
                            "repaired_tiles": [diag.get("fwd_tiles"), diag.get("bwd_tiles")],
                            "boundary_err": max(diag.get("warm_err_fwd", 0), diag.get("warm_err_bwd", 0))} if diag else {})},
-            "roofline": {**({"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {**({"bound": "mfma", "kernel": dom, "launches_per_step": diag.get("fused_launches", 1),
+                             "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tfl / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop_b,
-                             "hbm": {"alg_bytes_per_bin": 8 * N_STATES + 9, "achieved_GBs": bins * (8 * N_STATES + 9) / (dom_ms * 1e-3) / 1e9}}
+                             "hbm": {"alg_bytes_per_bin": 8 * N_STATES + 9, "achieved_GBs": bins * (8 * N_STATES + 9) / (dom_ms * 1e-3) / 1e9,
+                                     "alg_bytes_per_launch": bins * (8 * N_STATES + 9) / max(1, diag.get("fused_launches", 1))},
+                             "note": "kernel_ms = the launches of one E-step summed (two-phase plan: tile lists A and B, half of the tiles each); "
+                                     "traffic = PMC bytes of the larger launch"}
                             if dom == "k_bwd_count4_struct" else
                             {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_bin": alg_b}),

@@ -61,9 +61,10 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table),
  * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kc_min" (runs of at least this
  * many tiles get their boundary vectors from a chain of tile transfer matrices instead of a walk; 0: never),
- * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (1, default, fused back
- * half only: tiles with an odd index inside their segment do not speculate but start, in a second phase, from the
- * exact boundary vector their neighbour left -- half of the warm-up work; 0: every tile speculates). */
+ * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (1: tiles with an odd
+ * index inside their segment do not speculate but start, in a second phase, from the exact boundary vector their
+ * neighbour left -- half of the warm-up work, two dependent phases; default 0: every tile speculates; measured equal),
+ * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
@@ -117,10 +118,11 @@ int psmc_hip_estep_factored(psmc_hip_ctx *ctx, const double *a, const double *e,
 
 /* Diagnostic: out = {structured sweeps used (0/1), tile length in bins, forward sweep items,
  * backward sweep items, back half (0: bt table + counts kernel, 1: backward sweep fused with the counts, 2: factored
- * statistics), checkpointed X (0/1)} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured
+ * statistics), checkpointed X (0/1), launches of the fused back half (2 with the two-phase plan), forward tiles of
+ * phase B} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured
  * sweeps are chosen automatically when a[][] has the two rank-1
  * triangles psmc_update_hmm builds (core.c:112-122); otherwise the dense sweeps run. */
-int psmc_hip_fast_info(psmc_hip_ctx *ctx, int out[6]);
+int psmc_hip_fast_info(psmc_hip_ctx *ctx, int out[8]);
 
 /* Copies the forward/backward tables of one loaded segment to the host after
  * an E-step (replaces reading hd->f, hd->b, hd->s: aux.c:159-200).  f,b: L*n,
@@ -165,7 +167,8 @@ int psmc_hip_load_probe(int device, int n_waves, int steps, double *out);
  * kernels ran on.  Exact mode: [0] total, [1] forward, [2] backward, [3] expect,
  * [4] host-copy tail.  Fast mode: [0] total, [1] both sweep chains (speculate +
  * repair rounds; forward and backward run concurrently), [2] LL + redo of the
- * counts after the chains, [3] the full expect kernel alone, [4] reductions, [5] the
+ * counts after the chains, [3] the full expect kernel alone (fused back half: its one or two
+ * launches, summed), [4] reductions, [5] the
  * speculative forward sweep kernel alone, [6] the speculative backward sweep alone. */
 int psmc_hip_last_timing(psmc_hip_ctx *ctx, double ms[7]);
 

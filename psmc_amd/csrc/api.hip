@@ -30,7 +30,8 @@ struct psmc_hip_ctx {
 	int last_fused = 0, last_ckpt = 0; // what the last fast E-step ran: EstepLaunch::fused / ckpt
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
-	int two_phase = 1;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
+	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
+	int two_phase = 0;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
 	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
@@ -84,7 +85,8 @@ struct psmc_hip_ctx {
 	       *d_LLpart = nullptr;
 	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
 	hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;
-	hipEvent_t evx[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t evx[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	bool timing_two_launches = false; // the fused back half ran as two launches (lists A and B): evx[11] / evx[12] sit between them
 	int n_long_f = 0, n_long_b = 0, n_mem_f = 0, n_mem_b = 0;
 	int n_B_f = 0, n_B_b = 0, n_list_a = 0, n_list_b = 0; // two-phase plan: trailing single items of phase B; tile lists of the fused back half
 	int items_two_phase = -1;  // what the current item lists were built for
@@ -169,7 +171,7 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	if (hipStreamCreateWithFlags(&c->stream5, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	for (int i = 0; i < 12; ++i)
+	for (int i = 0; i < 14; ++i)
 		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
@@ -200,7 +202,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_ritems) (void)hipHostFree(c->h_ritems);
 	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	for (int i = 0; i < 12; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
+	for (int i = 0; i < 14; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
 	if (c->stream4) (void)hipStreamDestroy(c->stream4);
 	if (c->stream5) (void)hipStreamDestroy(c->stream5);
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -219,6 +221,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
+	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
 	else if (k == "two_phase") { c->two_phase = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
@@ -413,7 +416,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
-	c->last_fused = p.fused; c->last_ckpt = p.ckpt;
+	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order;
 	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
 	if (c->ns == 128) {
@@ -438,7 +441,11 @@ static void collect_timing(psmc_hip_ctx *c)
 	if (c->mode == PSMC_HIP_MODE_FAST) {
 		el(c->ev[0], c->ev[1], c->last_ms[1]);  // both sweep chains (speculate + repairs), run concurrently
 		el(c->ev[1], c->ev[3], c->last_ms[2]);  // LL + what is left of the counts after the chains
-		el(c->ev[8], c->ev[9], c->last_ms[3]);  // the full expect pass (kernel alone)
+		if (c->timing_two_launches) { // lists A and B of the fused back half: the sum of the two launches, not the wait between them
+			double a = 0, b = 0;
+			el(c->ev[8], c->evx[11], a); el(c->evx[12], c->ev[9], b);
+			c->last_ms[3] = a + b;
+		} else el(c->ev[8], c->ev[9], c->last_ms[3]);  // the full expect pass (kernel alone)
 		el(c->ev[3], c->ev[4], c->last_ms[4]);
 		el(c->ev[0], c->ev[5], c->last_ms[5]);  // speculative forward sweep kernel
 		el(c->ev[7], c->ev[6], c->last_ms[6]);  // speculative backward sweep kernel
@@ -778,6 +785,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	const bool two_phase = c->two_phase && p.fused >= 1, two_phase_bwd = c->two_phase && p.fused == 1;
 	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase, two_phase_bwd))) return rc;
 	p.n_B_f = c->n_B_f; p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
+	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
 	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;
 	p.n_items_f = c->n_items_f; p.n_items_b = c->n_items_b; p.tile_len = c->chunk_used; p.h_ritems = c->h_ritems; p.m_ritems = c->m_ritems; p.m_cnt = c->m_cnt;
@@ -793,7 +801,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
 	p.d_Kcol = c->d_Kcol; p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * 4096 : nullptr; p.stream5 = c->stream5;
-	for (int i = 0; i < 12; ++i) p.evx[i] = c->evx[i];
+	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
 	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
@@ -866,12 +874,12 @@ extern "C" int psmc_hip_estep_factored(psmc_hip_ctx *c, const double *a, const d
 	return PSMC_HIP_OK;
 }
 
-extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[6])
+extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[8])
 {
 	if (!c || !out) return PSMC_HIP_EINVAL;
 	out[0] = c->use_struct ? 1 : 0; out[1] = c->chunk_used; out[2] = c->use_struct ? c->n_items_f : (int)c->chunks.size();
 	out[3] = c->use_struct ? c->n_items_b : (int)c->chunks.size();
-	out[4] = c->last_fused; out[5] = c->last_ckpt;
+	out[4] = c->last_fused; out[5] = c->last_ckpt; out[6] = c->timing_two_launches ? 2 : 1; out[7] = c->n_B_f;
 	return PSMC_HIP_OK;
 }
 

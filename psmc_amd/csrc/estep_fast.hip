@@ -643,15 +643,21 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		const int nb0 = lb ? p.n_long_b : 0;
 		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0 - p.n_B_b);
 		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles (phase A)
-		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
 		if (p.fused == 2) {
 			if (p.n_B_f > 0 && ov) (void)hipStreamWaitEvent(sa, p.evx[10], 0); // X of the phase-B tiles
+			if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
 			launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0);
 		} else {
 			if (lw && ov) (void)hipStreamWaitEvent(sa, p.evx[7], 0); // boundary vectors and X of the run tiles
+			// list A could start beside the forward sweep of phase B; both are bound by FP64 issue, so side by side
+			// each just takes longer (4.9 + 3.6 ms against 1.0 + 3.5 + 3.5 one after the other)
+			if (p.n_B_f > 0 && ov && p.fuse_order == 0) (void)hipStreamWaitEvent(sa, p.evx[10], 0);
+			if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
 			launch_bwd_count(p, sa, 0, false);
-			if (p.n_list_b > 0) { // beside it: the forward sweep of phase B; then its tiles, from the exit vectors list A left
+			if (p.n_list_b > 0) { // its tiles start from the exit vectors list A left
+				(void)hipEventRecord(p.evx[11], sa);
 				if (p.n_B_f > 0 && ov) (void)hipStreamWaitEvent(sa, p.evx[10], 0);
+				(void)hipEventRecord(p.evx[12], sa);
 				launch_bwd_count(p, sa, 1, false);
 			}
 		}

@@ -29,7 +29,7 @@ struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged;
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
 	hipStream_t stream, stream2, stream3; // forward chain (main), backward chain, early expect
-	hipEvent_t evx[12];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
+	hipEvent_t evx[14];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
 	int overlap;
 	int rep_impl, expect_impl, n_states;
 	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)
@@ -44,6 +44,7 @@ struct EstepLaunch {
 	int walk_impl;       // 1: one wave per glued run, one state per lane (k_walk1_struct); 0: four runs per wave
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
+	int fuse_order;      // fused == 1, two-phase plan: 0 = list A after the forward sweep of phase B, 1 = beside it
 	int ckpt;            // fused == 2: the forward sweep stores X at p % 8 == 0 only, the counts recompute the rest
 	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)
 	int n_items_f, n_items_b, tile_len;

@@ -220,11 +220,12 @@ class HipEStep:
         self._chk(self.lib.psmc_hip_fast_diag(self.h, C.byref(wf), C.byref(wb), C.byref(nc), C.byref(wu)), "fast_diag")
         rp = (C.c_int * 4)()
         self._chk(self.lib.psmc_hip_fast_repairs(self.h, rp), "fast_repairs")
-        fi = (C.c_int * 6)()
+        fi = (C.c_int * 8)()
         self._chk(self.lib.psmc_hip_fast_info(self.h, fi), "fast_info")
         return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value,
                     fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3],
-                    structured=bool(fi[0]), tile_len=fi[1], items_fwd=fi[2], items_bwd=fi[3], back_half=fi[4], ckpt=bool(fi[5]))
+                    structured=bool(fi[0]), tile_len=fi[1], items_fwd=fi[2], items_bwd=fi[3], back_half=fi[4], ckpt=bool(fi[5]),
+                    fused_launches=fi[6], phase_b_tiles=fi[7])
 
     def tables(self, seg, want_b=True):
         L = int(self.lens[seg])

@@ -243,6 +243,16 @@ def main():
                                        "kernel (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) reaches %.1f of 78.6 TFLOP/s") %
                                       (bins * 2 * N_STATES * N_STATES / (kern["expect"] * 1e-3) / 1e12 if kern.get("expect", 0) > 0 else 0.0)},
         }
+        if world == 1:
+            try:  # what plain kernels reach on this box (context for the fractions above; diagnostics of the library)
+                hb = hip.hbm_probe(4 << 30, device=local)
+                lp = hip.load_probe(2048, 8000, device=local)
+                out["roofline"]["device_probes"] = {
+                    "hbm_GBs": {k: round(v) for k, v in hb.items()},
+                    "structured_step": {"waves": 2048, "cycles_per_step": round(lp["cycles_per_step"], 1), "shader_MHz_under_load": round(lp["mhz"])},
+                    "note": "streaming fill/read/copy and the sweeps' store pattern; the O(N) step on 2 waves per SIMD (FP64 issue) and the clock it sustains"}
+            except Exception as ex_:
+                out["roofline"]["device_probes"] = {"error": str(ex_)}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(a, e, a0, segs, args.cpu_sample)
         if world == 1 and mode == hip.MODE_FAST and diag.get("structured"):

@@ -35,6 +35,18 @@ def random_hmm(rng, n):
     return a, e, a0
 
 
+def test_device_probes(hip):
+    """The diagnostic entry points behind DESIGN.md section 5: finite, plausible numbers."""
+    hb = hip.hbm_probe(1 << 28)
+    assert all(100.0 < v < 20000.0 for v in hb.values()), hb
+    lp = hip.load_probe(256, 400)
+    assert 100.0 < lp["cycles_per_step"] < 2000.0 and 500.0 < lp["mhz"] < 4000.0, lp
+    lp8 = hip.load_probe(256, -400)  # eight tiles per wave
+    assert lp8["cycles_per_step"] / 8 < lp["cycles_per_step"] / 4, (lp, lp8)
+    mb = hip.microbench()
+    assert len(mb) == len(hip.MICROBENCH_NAMES) and all(v > 0 for v in mb.values())
+
+
 def test_device_primitives(hip):
     """row replication (ds_bpermute and v_permlane*_swap), row_newbcast DPP, ordered and tree
     sums, exact / FMA dot products, f64 MFMA lane mapping -- all against plain LDS indexing."""

@@ -771,8 +771,10 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep: no segments loaded");
 	int rc;
-	if ((rc = ensure_tables(c, !c->want_factored))) return rc; // the factored statistics never store the backward table
+	if ((rc = ensure_tables(c, false))) return rc;
 	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
+	// the backward table: only for the unfused back half (the fused and the factored one never store bt)
+	if (!c->want_factored && !(c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) && (rc = ensure_tables(c, true))) return rc;
 	if (c->ns == 128 && !c->use_struct)
 		return fail(c, PSMC_HIP_ENOTSUP, "fast mode beyond 64 states needs a transition matrix of the PSMC form (structured sweeps)");
 	if (c->want_factored && !(c->use_struct && c->ns == 64))
@@ -927,6 +929,7 @@ extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *
 		double *dst = which == 0 ? f : b;
 		const double *src = which == 0 ? c->d_f : c->d_b;
 		if (!dst) continue;
+		if (which == 1 && !c->have_b) return fail(c, PSMC_HIP_ESTATE, "get_tables: no backward table (the fused and factored back halves never store bt; set fuse=0)");
 		HIPCHK(c, hipMemcpy(tmp.data(), src + off * S, sizeof(double) * (size_t)L * S, hipMemcpyDeviceToHost));
 		for (int u = 0; u < L; ++u) memcpy(dst + (size_t)u * n, &tmp[(size_t)u * S], sizeof(double) * n);
 	}

@@ -163,15 +163,25 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 	// the four symbols of group number gi_ of every row: scalar loads (see estep_struct.hip row_symbols), all four
 	// issued before the per-row select (left alone the compiler branches per row and waits for each load in turn);
 	// fetched one group ahead
-	auto row_word = [&](int gi_) {
-		unsigned w0 = *reinterpret_cast<const unsigned *>(obs + off0 + 4 * (int64_t)max(gh0 - min(gi_, max(n0 - 1, 0)), 0));
-		unsigned w1 = *reinterpret_cast<const unsigned *>(obs + off1 + 4 * (int64_t)max(gh1 - min(gi_, max(n1 - 1, 0)), 0));
-		unsigned w2 = *reinterpret_cast<const unsigned *>(obs + off2 + 4 * (int64_t)max(gh2 - min(gi_, max(n2 - 1, 0)), 0));
-		unsigned w3 = *reinterpret_cast<const unsigned *>(obs + off3 + 4 * (int64_t)max(gh3 - min(gi_, max(n3 - 1, 0)), 0));
-		asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
-		return row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
+	// With one wave per SIMD nothing hides a scalar-load round trip, and hipcc sinks a plain load to its use: the
+	// four s_load_dword are written out and waited for by hand a whole group later (outstanding scalar loads only make
+	// the compiler's own lgkmcnt waits for its in-order LDS reads longer, never shorter).
+	struct Words { unsigned w0, w1, w2, w3; };
+	auto load_words = [&](int gi_) {
+		Words q;
+		const uint8_t *p0 = obs + off0 + 4 * (int64_t)max(gh0 - min(gi_, max(n0 - 1, 0)), 0);
+		const uint8_t *p1 = obs + off1 + 4 * (int64_t)max(gh1 - min(gi_, max(n1 - 1, 0)), 0);
+		const uint8_t *p2 = obs + off2 + 4 * (int64_t)max(gh2 - min(gi_, max(n2 - 1, 0)), 0);
+		const uint8_t *p3 = obs + off3 + 4 * (int64_t)max(gh3 - min(gi_, max(n3 - 1, 0)), 0);
+		asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0"
+		             : "=&s"(q.w0), "=&s"(q.w1), "=&s"(q.w2), "=&s"(q.w3) : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
+		return q;
 	};
-	unsigned w_cur = row_word(0);
+	auto select_word = [&](Words q) {
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.w0), "+s"(q.w1), "+s"(q.w2), "+s"(q.w3));
+		return row == 0 ? q.w0 : (row == 1 ? q.w1 : (row == 2 ? q.w2 : q.w3));
+	};
+	unsigned w_cur = select_word(load_words(0));
 	auto all_full = [&](int gi_) {
 		const int g = max(g_hi - gi_, g_lo);
 		return __all(gi_ < ng && 4 * g + 1 >= lo && 4 * g + 4 <= top) != 0;
@@ -179,7 +189,8 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 	auto do_group = [&](auto masked_tag) {
 		constexpr bool MASKED = decltype(masked_tag)::value;
 		const unsigned w = w_cur;
-		const unsigned wn = row_word(gi + 1); // issued now, selected after the four steps
+		const Words wn = load_words(gi + 1); // issued now (the scheduling barriers between the steps keep it here), selected after the four steps
+		__builtin_amdgcn_sched_barrier(0);
 		const int g = max(g_hi - gi, g_lo); // rows that are done idle on their last group
 		const bool in_tile = gi < ng;
 		const int s3 = (int)((w >> 24) & 3u), s2 = (int)((w >> 16) & 3u), s1 = (int)((w >> 8) & 3u), s0 = (int)(w & 3u);
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 		PSMC_C4(true, 3, s3) PSMC_C4(false, 2, s2) PSMC_C4(false, 1, s1) PSMC_C4(false, 0, s0)
 #undef PSMC_C4
 		if (in_tile && g == g_lo) storeN<NPLF>(bexit + (int64_t)tile * SF + k0, x); // x = bt_lo: the group holding lo is the row's last
-		w_cur = wn;
+		w_cur = select_word(wn);
 	};
 	for (; gi < ng_max && !all_full(gi); ++gi) do_group(std::true_type{});  // a top that is not a multiple of 4
 	for (; gi < ng_max && all_full(gi); ++gi) do_group(std::false_type{});

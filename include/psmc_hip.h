@@ -64,7 +64,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (1: tiles with an odd
  * index inside their segment do not speculate but start, in a second phase, from the exact boundary vector their
  * neighbour left -- half of the warm-up work, two dependent phases; default 0: every tile speculates; measured equal),
- * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B). */
+ * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B),
+ * "lanes8" (1: the bulk forward sweep and the backward warm-up of 64-state models run eight tiles per wave, 8 lanes x
+ * 8 states, instead of four; fewer instructions per step, half the waves; default 0). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:

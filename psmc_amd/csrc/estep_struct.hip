@@ -54,9 +54,27 @@ __device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, co
 	v.w = row == 0 ? s0.w : (row == 1 ? s1.w : (row == 2 ? s2.w : s3.w));
 	return v;
 }
+// eight rows (8 lanes per tile)
+__device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, const int64_t (&roff)[8], const int (&bb)[8],
+                                             int row)
+{
+	uint4 v = *reinterpret_cast<const uint4 *>(obs + roff[0] + ((int64_t)bb[0] << 4));
+#pragma unroll
+	for (int r = 1; r < 8; ++r) {
+		const uint4 s = *reinterpret_cast<const uint4 *>(obs + roff[r] + ((int64_t)bb[r] << 4));
+		v.x = row == r ? s.x : v.x; v.y = row == r ? s.y : v.y; v.z = row == r ? s.z : v.z; v.w = row == r ? s.w : v.w;
+	}
+	return v;
+}
+// Tile geometry of a sweep wave: LPT lanes per tile (16: four tiles per wave, a tile is a DPP row; 8: eight tiles per
+// wave, 8 lanes x 8 states -- 64 states only; the cross-lane part of a scan is a level shorter and shared by twice
+// as many states, see struct_prims.h), NPL adjacent states per lane.
+template <int NPL, int LPT> __device__ __forceinline__ void tile_step(const StructParN<NPL> &c, double (&x)[NPL], const Half8Masks &hm) {
+	if constexpr (LPT == 8) struct_step_h8(c, x, hm); else struct_step<NPL>(c, x);
+}
 
-template <int NPL> __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructParN<NPL> &c) {
-	constexpr int S = 16 * NPL; // sp = P | R | qa | c | dd, S each
+template <int NPL, int LPT = 16> __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructParN<NPL> &c) {
+	constexpr int S = LPT * NPL; // sp = P | R | qa | c | dd, S each
 	loadN<NPL>(sp + (fwd ? 0 : 3 * S) + k0, c.mS);  // forward: P,  backward: c
 	loadN<NPL>(sp + (fwd ? 2 * S : S) + k0, c.wS);  // forward: qa, backward: R
 	loadN<NPL>(sp + (fwd ? S : 2 * S) + k0, c.mP);  // forward: R,  backward: qa
@@ -67,6 +85,10 @@ template <int NPL> __device__ __forceinline__ double lane_sum(const double (&x)[
 	double t = (x[0] + x[1]) + (x[2] + x[3]);
 	if constexpr (NPL == 8) t = t + ((x[4] + x[5]) + (x[6] + x[7]));
 	return t;
+}
+// sum over the states of the lane's tile, identical in all of its lanes
+template <int NPL, int LPT> __device__ __forceinline__ double tile_sum(const double (&x)[NPL]) {
+	if constexpr (LPT == 8) return half8_sum(lane_sum<NPL>(x)); else return row_sum16(lane_sum<NPL>(x));
 }
 // e[0] | e[1] | 1 | 1 (rows of S) for the per-symbol emission fetch
 template <int S> __device__ __forceinline__ void fill_lds_e(double *lds_e, const double *__restrict__ e, int lane) {
@@ -93,8 +115,8 @@ struct FwdCursor { int next_lo, tile; };
 
 // MODE 0: per-step range / store / boundary predicates;  MODE 1: all 16 positions are computed and
 // stored and no tile starts inside the block;  MODE 2: warm-up, nothing stored.
-template <int MODE, int J, int NPL>
-__device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
+template <int MODE, int J, int NPL, int LPT>
+__device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                          double *fo, double *io, double *entry, int ckg)
 {
@@ -103,7 +125,7 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double 
 	// lo0 = first position whose X is stored (INT_MAX for a walk, which only leaves the boundary vectors)
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p >= p_first && p <= p_last)) return;
-	constexpr int S = 16 * NPL;
+	constexpr int S = LPT * NPL;
 	if (MODE == 0 && p == cur.next_lo) { // the X_{lo-1} this tile builds on
 		storeN<NPL>(entry + (int64_t)cur.tile * S + k0, x);
 		cur.tile += 1; cur.next_lo += T;
@@ -111,19 +133,19 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double 
 	double ev[NPL];
 	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
 	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}), off the critical path
-		const double inv = rcp_newton(row_sum16(lane_sum<NPL>(x)));
+		const double inv = rcp_newton(tile_sum<NPL, LPT>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= inv;
 		if ((MODE == 1 || (MODE == 0 && p >= lo0)) && m == 0) io[idx] = inv;
 	}
-	struct_step<NPL>(c, x);
+	tile_step<NPL, LPT>(c, x, hm);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 	if (MODE == 1) { if (ckg == 0 || (J == 3 && ckg == 1)) storeN<NPL>(fo + (int64_t)idx * S, x); }
 	else if (MODE == 0 && p >= lo0 && (ckg == 0 || (p & 7) == 0 || p == p_last)) storeN<NPL>(fo + (int64_t)idx * S, x);
 }
-template <int MODE, int NPL>
-__device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int NPL, int LPT>
+__device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                           double *fo, double *io, double *entry, bool ckpt)
 {
@@ -133,17 +155,17 @@ __device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double
 	for (int g = 0; g < 4; ++g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g, ckg = ckpt ? 2 - (g & 1) : 0;
-		fwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
-		fwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
-		fwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
-		fwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		fwd_step<MODE, 0, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		fwd_step<MODE, 1, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		fwd_step<MODE, 2, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		fwd_step<MODE, 3, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
 	}
 }
 
 // items[4*blockIdx.x + row] = work of this row.  REPAIR: the list holds the flagged tiles (count 1); a
 // row starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel
 // then decides whether the next tile has to follow).  No vector-memory load inside the sweep.
-template <bool REPAIR, int NPL>
+template <bool REPAIR, int NPL, int LPT = 16>
 __device__ __forceinline__ void fwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                 const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -152,12 +174,13 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
                                                 int *__restrict__ touch_f)
 {
 	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0, ckpt = (flags & SWEEP_CKPT) != 0;
-	constexpr int S = 16 * NPL;
+	constexpr int S = LPT * NPL, R = 64 / LPT; // R tiles per wave
 	__shared__ double lds_e[4 * S]; // e[0], e[1], 1, 1
-	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
+	const int lane = threadIdx.x, m = lane & (LPT - 1), k0 = NPL * m;
+	const Half8Masks hm = half8_masks(lane);
 	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
-	const int slot = block * 4 + (lane >> 4);
+	const int slot = block * R + lane / LPT;
 	const bool valid = slot < n_items;
 	const SweepItem it = items[valid ? slot : 0];
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
@@ -166,7 +189,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	const uint8_t *o = obs + c.off;
 	double *fo = f + c.off * S + k0, *io = invd + c.off;
 	StructParN<NPL> sc;
-	load_struct_par<NPL>(sp, k0, true, sc);
+	load_struct_par<NPL, LPT>(sp, k0, true, sc);
 	double x[NPL];
 	int p_first;
 	if (REPAIR && valid && m == 0 && !(flags & SWEEP_NO_TOUCH)) touch_f[it.first] = 1; // X / inv_d of this tile change
@@ -196,19 +219,20 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	const int b_first = (p_first - 1) >> 4;
 	const int nblk = (valid && p_last >= p_first) ? ((p_last - 1) >> 4) - b_first + 1 : 0;
 	// row-uniform scalars (lane 16r speaks for row r)
-	int64_t roff[4]; int rbf[4], rnb[4];
+	int64_t roff[R]; int rbf[R], rnb[R];
+	int nb_max = 0;
 #pragma unroll
-	for (int r = 0; r < 4; ++r) {
-		roff[r] = readlane_i64(c.off, 16 * r);
-		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
-		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
+	for (int r = 0; r < R; ++r) {
+		roff[r] = readlane_i64(c.off, LPT * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, LPT * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, LPT * r);
+		nb_max = max(nb_max, rnb[r]);
 	}
-	const int nb_max = max(max(rnb[0], rnb[1]), max(rnb[2], rnb[3]));
 	for (int bi = 0; bi < nb_max; ++bi) {
-		int bb[4];
+		int bb[R];
 #pragma unroll
-		for (int r = 0; r < 4; ++r) bb[r] = rbf[r] + min(bi, max(rnb[r] - 1, 0));
-		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
+		for (int r = 0; r < R; ++r) bb[r] = rbf[r] + min(bi, max(rnb[r] - 1, 0));
+		const uint4 sv = row_symbols(obs, roff, bb, lane / LPT);
 		if (bi < nblk) {
 			const int base = (b_first + bi) << 4;
 			if (cur.next_lo == base + 1 && base + 1 >= p_first && base + 1 <= p_last) { // a tile starts exactly at this block
@@ -217,14 +241,14 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 			}
 			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
 			const int mode = !full ? 0 : (base + 1 >= lo_store ? 1 : 2);
-			if (__all(mode == 1)) fwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
-			else if (__all(mode == 2)) fwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
-			else fwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
+			if (__all(mode == 1)) fwd_block<1, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
+			else if (__all(mode == 2)) fwd_block<2, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
+			else fwd_block<0, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
 		}
 	}
 }
 
-template <bool REPAIR, int NPL>
+template <bool REPAIR, int NPL, int LPT = 16>
 __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -232,7 +256,7 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ invd, double *__restrict__ entry,
                                                      int *__restrict__ touch_f)
 {
-	fwd_struct_body<REPAIR, NPL>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
+	fwd_struct_body<REPAIR, NPL, LPT>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
 }
 
 // ------------------------------------------------------------------ backward
@@ -243,18 +267,18 @@ struct BwdCursor { int lo, top, tile; bool store; }; // store: false for a walk,
 
 // MODE 1: every position of the block is strictly inside (lo, top) of the current tile;
 // MODE 2: warm-up above the top tile's top;  MODE 0: general.
-template <int MODE, int J, int NPL>
-__device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
+template <int MODE, int J, int NPL, int LPT>
+__device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                          double *sbo, double *bentry, double *bexit)
 {
-	constexpr int S = 16 * NPL;
+	constexpr int S = LPT * NPL;
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p <= p_first && p >= p_low)) return;
 	double ev[NPL];
 	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
 	if (J == 3) { // sb_p = 1/sum(bt_{p+1}), off the critical path
-		const double s = rcp_newton(row_sum16(lane_sum<NPL>(x)));
+		const double s = rcp_newton(tile_sum<NPL, LPT>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= s;
 		if ((MODE == 1 || (MODE == 0 && p <= cur.top && cur.store)) && m == 0) sbo[idx] = s;
@@ -263,7 +287,7 @@ __device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double 
 		if (cur.store) storeN<NPL>(bto + (int64_t)cur.top * S, x); // bt[top+1]
 		storeN<NPL>(bentry + (int64_t)cur.tile * S + k0, x);
 	}
-	struct_step<NPL>(c, x);
+	tile_step<NPL, LPT>(c, x, hm);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 	if (MODE == 1) storeN<NPL>(bto + (int64_t)idx * S, x);
@@ -275,8 +299,8 @@ __device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double 
 		}
 	}
 }
-template <int MODE, int NPL>
-__device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int NPL, int LPT>
+__device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                           double *sbo, double *bentry, double *bexit)
 {
@@ -284,15 +308,15 @@ __device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const double
 	for (int g = 3; g >= 0; --g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g;
-		bwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 3, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 2, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 1, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 0, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 	}
 }
 
 // items: tiles first .. first+count-1, walked from the highest down.
-template <bool REPAIR, int NPL>
+template <bool REPAIR, int NPL, int LPT = 16>
 __device__ __forceinline__ void bwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                 const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -300,12 +324,13 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
                                                 double *__restrict__ bentry, double *__restrict__ bexit,
                                                 int *__restrict__ touch_b)
 {
-	constexpr int S = 16 * NPL;
+	constexpr int S = LPT * NPL, R = 64 / LPT;
 	__shared__ double lds_e[4 * S];
-	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
+	const int lane = threadIdx.x, m = lane & (LPT - 1), k0 = NPL * m;
+	const Half8Masks hm = half8_masks(lane);
 	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
-	const int slot = block * 4 + (lane >> 4);
+	const int slot = block * R + lane / LPT;
 	const SweepItem it = items[slot < n_items ? slot : 0];
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	const int t_top = it.first + it.count - 1;
@@ -320,7 +345,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	const uint8_t *o = obs + c.off;
 	double *bto = bt + c.off * S + k0, *sbo = sb + c.off;
 	StructParN<NPL> sc;
-	load_struct_par<NPL>(sp, k0, false, sc);
+	load_struct_par<NPL, LPT>(sp, k0, false, sc);
 	double x[NPL]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
 	int p_first;
 	if (REPAIR) { // continue from the value the tile above computed at our top boundary
@@ -335,31 +360,32 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	}
 	const int b_first = (p_first - 1) >> 4; // highest block
 	const int nblk = valid ? b_first - ((p_low - 1) >> 4) + 1 : 0;
-	int64_t roff[4]; int rbf[4], rnb[4];
+	int64_t roff[R]; int rbf[R], rnb[R];
+	int nb_max = 0;
 #pragma unroll
-	for (int r = 0; r < 4; ++r) {
-		roff[r] = readlane_i64(c.off, 16 * r);
-		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
-		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
+	for (int r = 0; r < R; ++r) {
+		roff[r] = readlane_i64(c.off, LPT * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, LPT * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, LPT * r);
+		nb_max = max(nb_max, rnb[r]);
 	}
-	const int nb_max = max(max(rnb[0], rnb[1]), max(rnb[2], rnb[3]));
 	for (int bi = 0; bi < nb_max; ++bi) {
-		int bb[4];
+		int bb[R];
 #pragma unroll
-		for (int r = 0; r < 4; ++r) bb[r] = rbf[r] - min(bi, max(rnb[r] - 1, 0));
-		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
+		for (int r = 0; r < R; ++r) bb[r] = rbf[r] - min(bi, max(rnb[r] - 1, 0));
+		const uint4 sv = row_symbols(obs, roff, bb, lane / LPT);
 		if (bi < nblk) {
 			const int base = (b_first - bi) << 4;
 			int mode = (base + 1 > cur.lo && base + 16 < cur.top) ? 1 : ((base + 1 > cur.top && base + 16 <= p_first) ? 2 : 0);
 			if (walk && mode == 1) mode = 2;
-			if (__all(mode == 1)) bwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else if (__all(mode == 2)) bwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else bwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			if (__all(mode == 1)) bwd_block<1, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else if (__all(mode == 2)) bwd_block<2, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else bwd_block<0, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 		}
 	}
 }
 
-template <bool REPAIR, int NPL>
+template <bool REPAIR, int NPL, int LPT = 16>
 __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                      const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -367,7 +393,7 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ bentry, double *__restrict__ bexit,
                                                      int *__restrict__ touch_b)
 {
-	bwd_struct_body<REPAIR, NPL>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
+	bwd_struct_body<REPAIR, NPL, LPT>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
 }
 
 // Both directions' walks over the glued runs in ONE launch (blocks [0, nbf) forward, the rest backward):
@@ -624,27 +650,39 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
-	const dim3 g((n_items + 3) / 4), b(64);
+	// throughput-bound bulk launches of 64-state models: eight tiles per wave (latency-bound ones keep four: a step of
+	// the 8 x 8 form takes 1.5x as long)
+	const bool l8 = p.lanes8 && p.ns == 64 && (which == 0 || which == 6);
+	const dim3 g(l8 ? (n_items + 7) / 8 : (n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
 	const int flags = (which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 6 ? SWEEP_NO_TOUCH : 0))) // run tiles are done before the counts start
 	                  | (p.ckpt ? SWEEP_CKPT : 0);
 #define PSMC_LF(REP, NPL) hipLaunchKernelGGL((k_fwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
 	const bool rep = !(which == 0 || which == 2);
-	if (p.ns == 128) { if (rep) PSMC_LF(true, 8); else PSMC_LF(false, 8); }
+	if (l8) {
+#define PSMC_LF8(REP) hipLaunchKernelGGL((k_fwd_struct<REP, 8, 8>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
+		if (rep) PSMC_LF8(true); else PSMC_LF8(false);
+#undef PSMC_LF8
+	} else if (p.ns == 128) { if (rep) PSMC_LF(true, 8); else PSMC_LF(false, 8); }
 	else { if (rep) PSMC_LF(true, 4); else PSMC_LF(false, 4); }
 #undef PSMC_LF
 }
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
-	const dim3 g((n_items + 3) / 4), b(64);
+	const bool l8 = p.lanes8 && p.ns == 64 && which == 4; // the warm-up-only pass of the fused / factored back half
+	const dim3 g(l8 ? (n_items + 7) / 8 : (n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 || which == 5 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
 	const int flags = which == 2 || which == 5 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? SWEEP_TOP_ONLY : 0));
 #define PSMC_LB(REP, NPL) hipLaunchKernelGGL((k_bwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, \
 		n_items, p.warmup, p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b)
 	const bool rep = !(which == 0 || which == 2 || which == 4);
-	if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
+	if (l8)
+		hipLaunchKernelGGL((k_bwd_struct<false, 8, 8>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup,
+		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+	else if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
 	else { if (rep) PSMC_LB(true, 4); else PSMC_LB(false, 4); }
 #undef PSMC_LB
 }

@@ -305,7 +305,8 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
-                                  dict(two_phase=1), dict(chunk=256, warmup=512, two_phase=1), dict(chunk=768, warmup=256, two_phase=1, overlap=0), dict(chunk=768, warmup=64, two_phase=1, fuse_order=1)])
+                                  dict(two_phase=1), dict(chunk=256, warmup=512, two_phase=1), dict(chunk=768, warmup=256, two_phase=1, overlap=0), dict(chunk=768, warmup=64, two_phase=1, fuse_order=1),
+                                  dict(lanes8=1), dict(chunk=256, warmup=512, lanes8=1), dict(chunk=1000, warmup=100, lanes8=1, overlap=0), dict(chunk=768, warmup=256, lanes8=1, two_phase=1)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is
@@ -344,7 +345,8 @@ def test_fast_n128(hip, golden, oracle, opts):
 
 
 @pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, walk_impl=0),
-                                  dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, two_phase=1), dict(chunk=100, warmup=30, two_phase=1), dict(chunk=5000, warmup=16, overlap=0)])
+                                  dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, two_phase=1), dict(chunk=100, warmup=30, two_phase=1), dict(chunk=5000, warmup=16, overlap=0),
+                                  dict(chunk=100, warmup=30, lanes8=1), dict(chunk=37, warmup=5, group_cap=3000, lanes8=1), dict(chunk=64, warmup=0, lanes8=1)])
 def test_fast_odd_tilings(hip, golden, oracle, opts):
     """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
     everything is repaired / learned into runs and stays inside the tolerance."""
@@ -365,7 +367,7 @@ def tri_sums(A):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
-                                  dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, two_phase=1)])
+                                  dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, two_phase=1), dict(lanes8=1), dict(chunk=1001, warmup=100, lanes8=1), dict(chunk=264, warmup=300, lanes8=1)])
 def test_fast_factored_statistics(hip, golden, oracle, opts):
     """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
     (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset.

@@ -115,12 +115,13 @@ struct FwdCursor { int next_lo, tile; };
 
 // MODE 0: per-step range / store / boundary predicates;  MODE 1: all 16 positions are computed and
 // stored and no tile starts inside the block;  MODE 2: warm-up, nothing stored.
-template <int MODE, int J, int NPL, int LPT>
+template <int MODE, int J, int NPL, int LPT, bool CK>
 __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
-                                         double *fo, double *io, double *entry, int ckg)
+                                         double *fo, double *io, double *entry, int g, double &inv_keep)
 {
-	// ckg (wave-uniform): 0 = every X is stored, 1 / 2 = checkpoints only, group ends at p % 8 == 0 / 4
+	// CK: checkpoints only (X at p % 8 == 0 and the item's last position); g (wave-uniform): the group's number in its block
+	// inv_keep: lane m < 4 of a tile keeps the scale factor of group m; the block stores the four together (MODE 1)
 	// base = index of the group's first position (multiple of 4), J = step inside the group;
 	// lo0 = first position whose X is stored (INT_MAX for a walk, which only leaves the boundary vectors)
 	const int p = base + J + 1, idx = base + J;
@@ -136,36 +137,39 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Ma
 		const double inv = rcp_newton(tile_sum<NPL, LPT>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= inv;
-		if ((MODE == 1 || (MODE == 0 && p >= lo0)) && m == 0) io[idx] = inv;
+		if (MODE == 1) inv_keep = m == g ? inv : inv_keep; // one 32-byte store per tile and block instead of four 8-byte ones
+		else if (MODE == 0 && p >= lo0 && m == 0) io[idx] = inv;
 	}
 	tile_step<NPL, LPT>(c, x, hm);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
-	if (MODE == 1) { if (ckg == 0 || (J == 3 && ckg == 1)) storeN<NPL>(fo + (int64_t)idx * S, x); }
-	else if (MODE == 0 && p >= lo0 && (ckg == 0 || (p & 7) == 0 || p == p_last)) storeN<NPL>(fo + (int64_t)idx * S, x);
+	if (MODE == 1) { if (!CK || (J == 3 && (g & 1))) storeN<NPL>(fo + (int64_t)idx * S, x); }
+	else if (MODE == 0 && p >= lo0 && (!CK || (p & 7) == 0 || p == p_last)) storeN<NPL>(fo + (int64_t)idx * S, x);
 }
-template <int MODE, int NPL, int LPT>
+template <int MODE, int NPL, int LPT, bool CK>
 __device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
-                                          double *fo, double *io, double *entry, bool ckpt)
+                                          double *fo, double *io, double *entry)
 {
+	double inv_keep = 1.0;
 	// four groups of four unrolled steps: 16 fully unrolled steps x 3 modes x 2 directions overflow the
 	// instruction cache once the forward, backward and count kernels run side by side
 #pragma unroll 1
 	for (int g = 0; g < 4; ++g) {
 		const unsigned w = sym_word(sv, g);
-		const int pb = base + 4 * g, ckg = ckpt ? 2 - (g & 1) : 0;
-		fwd_step<MODE, 0, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
-		fwd_step<MODE, 1, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
-		fwd_step<MODE, 2, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
-		fwd_step<MODE, 3, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, ckg);
+		const int pb = base + 4 * g;
+		fwd_step<MODE, 0, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 1, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 2, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 3, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
 	}
+	if (MODE == 1 && m < 4) io[base + 4 * m + 3] = inv_keep; // 1/d_p of the block's four normalising positions
 }
 
 // items[4*blockIdx.x + row] = work of this row.  REPAIR: the list holds the flagged tiles (count 1); a
 // row starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel
 // then decides whether the next tile has to follow).  No vector-memory load inside the sweep.
-template <bool REPAIR, int NPL, int LPT = 16>
+template <bool REPAIR, int NPL, int LPT = 16, bool CK = false>
 __device__ __forceinline__ void fwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                 const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -173,7 +177,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
                                                 double *__restrict__ invd, double *__restrict__ entry,
                                                 int *__restrict__ touch_f)
 {
-	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0, ckpt = (flags & SWEEP_CKPT) != 0;
+	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0; // SWEEP_CKPT: the CK instantiation
 	constexpr int S = LPT * NPL, R = 64 / LPT; // R tiles per wave
 	__shared__ double lds_e[4 * S]; // e[0], e[1], 1, 1
 	const int lane = threadIdx.x, m = lane & (LPT - 1), k0 = NPL * m;
@@ -241,14 +245,14 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 			}
 			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
 			const int mode = !full ? 0 : (base + 1 >= lo_store ? 1 : 2);
-			if (__all(mode == 1)) fwd_block<1, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
-			else if (__all(mode == 2)) fwd_block<2, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
-			else fwd_block<0, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry, ckpt);
+			if (__all(mode == 1)) fwd_block<1, NPL, LPT, CK>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else if (__all(mode == 2)) fwd_block<2, NPL, LPT, CK>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else fwd_block<0, NPL, LPT, CK>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 		}
 	}
 }
 
-template <bool REPAIR, int NPL, int LPT = 16>
+template <bool REPAIR, int NPL, int LPT = 16, bool CK = false>
 __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ invd, double *__restrict__ entry,
                                                      int *__restrict__ touch_f)
 {
-	fwd_struct_body<REPAIR, NPL, LPT>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
+	fwd_struct_body<REPAIR, NPL, LPT, CK>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
 }
 
 // ------------------------------------------------------------------ backward
@@ -660,13 +664,15 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 #define PSMC_LF(REP, NPL) hipLaunchKernelGGL((k_fwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
 	const bool rep = !(which == 0 || which == 2);
-	if (l8) {
-#define PSMC_LF8(REP) hipLaunchKernelGGL((k_fwd_struct<REP, 8, 8>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+#define PSMC_LFX(REP, NPL, LPT, CK) hipLaunchKernelGGL((k_fwd_struct<REP, NPL, LPT, CK>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
-		if (rep) PSMC_LF8(true); else PSMC_LF8(false);
-#undef PSMC_LF8
-	} else if (p.ns == 128) { if (rep) PSMC_LF(true, 8); else PSMC_LF(false, 8); }
+	if (p.ckpt && p.ns == 64) { // checkpoint stores are a compile-time variant: no per-step branches in the full-table kernels
+		if (l8) { if (rep) PSMC_LFX(true, 8, 8, true); else PSMC_LFX(false, 8, 8, true); }
+		else { if (rep) PSMC_LFX(true, 4, 16, true); else PSMC_LFX(false, 4, 16, true); }
+	} else if (l8) { if (rep) PSMC_LFX(true, 8, 8, false); else PSMC_LFX(false, 8, 8, false); }
+	else if (p.ns == 128) { if (rep) PSMC_LF(true, 8); else PSMC_LF(false, 8); }
 	else { if (rep) PSMC_LF(true, 4); else PSMC_LF(false, 4); }
+#undef PSMC_LFX
 #undef PSMC_LF
 }
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)

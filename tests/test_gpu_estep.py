@@ -450,6 +450,29 @@ def test_fast_vs_oracle_random(hip, oracle, n):
     es.close()
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(fuse=0), dict(two_phase=1, lanes8=1)])
+def test_fast_many_small_segments(hip, golden, oracle, opts):
+    """Hundreds of short segments (lengths 1 .. 3000, some all-missing): tiles of different segments share a wave and
+    a group of the fused kernel, most tiles are a segment's first and last at once.  Full matrix, factored
+    statistics and a resampled multiset against the oracle."""
+    p = golden.params("n64_curve")
+    rng = np.random.default_rng(77)
+    lens = np.concatenate([rng.integers(1, 3000, size=260), [1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 2999, 3000, 3001]])
+    segs = [rng.choice(3, size=int(L), p=[0.88, 0.08, 0.04]).astype(np.uint8) for L in lens]
+    segs[5][:] = 2; segs[17][:] = 2  # all-missing segments
+    o = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
+    es.load_segments(segs)
+    for it in range(2):
+        check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+    r = es.estep_factored(p["a"], p["e"], p["a0"])
+    assert relmax(r["sums"], tri_sums(o["A"])) < FAST_TOL_STATS and relmax(r["E"], o["E"]) < FAST_TOL_STATS
+    sel = rng.integers(0, len(segs), size=len(segs)).tolist()
+    es.select(sel)
+    check_fast(es.estep(p["a"], p["e"], p["a0"]), oracle.estep(p["a"], p["e"], p["a0"], [segs[i] for i in sel]))
+    es.close()
+
+
 def test_fast_full_size_properties(hip, golden):
     """Size-independent invariants on a genome-sized batch (no oracle at this size):
     sum A = sum_seg (L-1); sum E = number of non-missing positions among 1..L-1;

@@ -10,7 +10,11 @@ bins = int(sys.argv[2]) if len(sys.argv) > 2 else 30000003
 def short(nm):
     rep = ('true>' in nm) or ('Lb1' in nm)
     for k in ('k_fwd_fast', 'k_bwd_fast', 'k_fwd_struct', 'k_bwd_struct'):
-        if k in nm: return k + ('<repair>' if rep else '<speculate>')
+        if k in nm:
+            m = re.search(k + r'(?:IL[bi]\d+E)*?ILb([01])E', nm) or re.search(k + r'<(true|false)', nm)  # the FIRST bool argument is REPAIR
+            if m: rep = m.group(1) in ('1', 'true')
+            ck = bool(re.search(k + r'ILb[01]ELi\d+ELi\d+ELb1', nm) or re.search(k + r'<(?:true|false), \d+, \d+, true', nm))
+            return k + ('<repair>' if rep else '<speculate>') + ('<ckpt>' if ck else '')
     if 'k_verify' in nm: return 'k_verify' + ('<bwd>' if rep else '<fwd>')
     m = re.search(r'psmc::(k_[a-z0-9_]+)', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)(?:IL|E)', nm)
     return m.group(1) if m else nm.split('(')[0][:40]

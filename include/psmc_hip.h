@@ -66,7 +66,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * neighbour left -- half of the warm-up work, two dependent phases; default 0: every tile speculates; measured equal),
  * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B),
  * "lanes8" (1: the bulk forward sweep and the backward warm-up of 64-state models run eight tiles per wave, 8 lanes x
- * 8 states, instead of four; fewer instructions per step, half the waves; default 0). */
+ * 8 states, instead of four; fewer instructions per step, half the waves; default 0), "exact_lds" (exact mode, up
+ * to 64 states: 1 = operands of the ordered sums broadcast through LDS instead of DPP rows; bit-identical, slower; default 0). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:

@@ -30,6 +30,7 @@ struct psmc_hip_ctx {
 	int last_fused = 0, last_ckpt = 0; // what the last fast E-step ran: EstepLaunch::fused / ckpt
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
+	int exact_lds = 0;         // "exact_lds": exact mode (<= 64 states) broadcasts the operands of its ordered sums through LDS instead of DPP rows; measured slower (905 vs 779 ms)
 	int lanes8 = 0;            // "lanes8": eight tiles per wave in the bulk forward sweep and the backward warm-up of the fused / factored back half
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
 	int two_phase = 0;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
@@ -222,6 +223,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
+	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
 	else if (k == "lanes8") { c->lanes8 = v != 0 ? 1 : 0; }
 	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
 	else if (k == "two_phase") { c->two_phase = v != 0 ? 1 : 0; c->items_dirty = true; }
@@ -418,7 +420,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
-	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.lanes8 = c->lanes8;
+	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.lanes8 = c->lanes8; p.exact_lds = c->exact_lds;
 	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
 	if (c->ns == 128) {

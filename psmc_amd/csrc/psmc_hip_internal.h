@@ -44,6 +44,7 @@ struct EstepLaunch {
 	int walk_impl;       // 1: one wave per glued run, one state per lane (k_walk1_struct); 0: four runs per wave
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
+	int exact_lds;       // exact mode, up to 64 states: operands of the ordered chains broadcast through LDS instead of DPP
 	int lanes8;          // 64 states: the throughput-bound bulk sweeps (forward, backward warm-up) run eight tiles per wave (8 lanes x 8 states)
 	int fuse_order;      // fused == 1, two-phase plan: 0 = list A after the forward sweep of phase B, 1 = beside it
 	int ckpt;            // fused == 2: the forward sweep stores X at p % 8 == 0 only, the counts recompute the rest

@@ -54,12 +54,12 @@ def test_device_primitives(hip):
 
 
 # ------------------------------------------------------------------ exact mode
-@pytest.mark.parametrize("rep", [1, 0])
+@pytest.mark.parametrize("rep", [1, 0, 2])  # 1 / 0: DPP rows from permlane swaps (default) / ds_bpermute; 2: operands broadcast through LDS (exact_lds)
 @pytest.mark.parametrize("key", ["n64_curve", "n64_flat", "n23_curve", "n23_flat"])
 def test_exact_small_golden(hip, golden, key, rep):
     p = golden.params(key)
     n = p["a"].shape[0]
-    es = hip.HipEStep(n, mode=hip.MODE_EXACT, rep_impl=rep)
+    es = hip.HipEStep(n, mode=hip.MODE_EXACT, rep_impl=min(rep, 1), exact_lds=1 if rep == 2 else 0)
     es.load_segments(golden.segs_small)
     r = es.estep(p["a"], p["e"], p["a0"])
     g = golden.small

@@ -61,9 +61,10 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table),
  * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kc_min" (runs of at least this
  * many tiles get their boundary vectors from a chain of tile transfer matrices instead of a walk; 0: never),
- * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (1: tiles with an odd
- * index inside their segment do not speculate but start, in a second phase, from the exact boundary vector their
- * neighbour left -- half of the warm-up work, two dependent phases; default 0: every tile speculates; measured equal),
+ * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (tiles with an odd
+ * index inside their segment do not speculate but start from the exact boundary vector their neighbour left: 2,
+ * default: backward only, in the second launch of the fused back half; 1: forward as well, in a second forward
+ * launch; 0: every tile speculates),
  * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B),
  * "lanes8" (1: the bulk forward sweep and the backward warm-up of 64-state models run eight tiles per wave, 8 lanes x
  * 8 states, instead of four; fewer instructions per step, half the waves; default 0), "exact_lds" (exact mode, up

@@ -33,7 +33,7 @@ struct psmc_hip_ctx {
 	int exact_lds = 0;         // "exact_lds": exact mode (<= 64 states) broadcasts the operands of its ordered sums through LDS instead of DPP rows; measured slower (905 vs 779 ms)
 	int lanes8 = 0;            // "lanes8": eight tiles per wave in the bulk forward sweep and the backward warm-up of the fused / factored back half
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
-	int two_phase = 0;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
+	int two_phase = 2;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
 	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
@@ -226,7 +226,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
 	else if (k == "lanes8") { c->lanes8 = v != 0 ? 1 : 0; }
 	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
-	else if (k == "two_phase") { c->two_phase = v != 0 ? 1 : 0; c->items_dirty = true; }
+	else if (k == "two_phase") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
@@ -788,7 +788,9 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	fill_common(c, p, st);
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub_used;
 	// the fused back half takes both directions of the two-phase plan, the factored one (item lists, two waves per SIMD) the forward one
-	const bool two_phase = c->two_phase && p.fused >= 1, two_phase_bwd = c->two_phase && p.fused == 1;
+	// 1: both directions; 2: backward only (the fused back half runs as two launches anyway, so its second list can start
+	// from the exit vectors of the first at no cost in scheduling, and half of the backward warm-up pass disappears)
+	const bool two_phase = c->two_phase == 1 && p.fused >= 1, two_phase_bwd = c->two_phase >= 1 && p.fused == 1;
 	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase, two_phase_bwd))) return rc;
 	p.n_B_f = c->n_B_f; p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;

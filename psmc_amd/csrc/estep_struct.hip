@@ -188,6 +188,8 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	const bool valid = slot < n_items;
 	const SweepItem it = items[valid ? slot : 0];
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
+	else __builtin_amdgcn_s_setprio(1); // ahead of the backward warm-up and the rest of phase 1: once its warm-up is done this sweep
+	                                    // is paced by its stores and leaves the vector units to them
 	const Chunk c = chunks[it.first];
 	const int p_last = chunks[it.first + it.count - 1].hi;
 	const uint8_t *o = obs + c.off;
@@ -513,6 +515,9 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
 	const int j = blockIdx.x >> 4, col = 4 * (blockIdx.x & 15) + (lane >> 4);
+	// the transfer matrices head the longest dependency chain of the first phase (columns -> chain -> run tiles ->
+	// the fused back half may start): ahead of the bulk sweeps, behind the walks
+	__builtin_amdgcn_s_setprio(2);
 	const KcTile kt = kc[j];
 	const Chunk c = chunks[kt.tile];
 	const bool fwd = kt.dir == 0;

@@ -305,7 +305,7 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
-                                  dict(two_phase=1), dict(chunk=256, warmup=512, two_phase=1), dict(chunk=768, warmup=256, two_phase=1, overlap=0), dict(chunk=768, warmup=64, two_phase=1, fuse_order=1),
+                                  dict(two_phase=0), dict(chunk=256, warmup=512, two_phase=0), dict(two_phase=1), dict(chunk=256, warmup=512, two_phase=1), dict(chunk=768, warmup=256, two_phase=1, overlap=0), dict(chunk=768, warmup=64, two_phase=1, fuse_order=1),
                                   dict(lanes8=1), dict(chunk=256, warmup=512, lanes8=1), dict(chunk=1000, warmup=100, lanes8=1, overlap=0), dict(chunk=768, warmup=256, lanes8=1, two_phase=1)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):

@@ -14,7 +14,8 @@ rows = list(cur.execute("select %s from %s d join %s s on d.kernel_id = s.id ord
 def short(nm):
     m = re.search(r'psmc::(k_[a-z0-9_]+)(<[^>]*>)?', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)I?L?b?(\d?)E', nm)
     return (m.group(1) + (m.group(2) or "")) if m else nm.split('(')[0][:30]
-ends = [i for i, r in enumerate(rows) if "k_reduce2" in r[2]]
+key = sys.argv[2] if len(sys.argv) > 2 else "k_reduce2"
+ends = [i for i, r in enumerate(rows) if key in r[2]]
 if len(ends) < 2: print("not enough E-steps"); sys.exit(0)
 lo, hi = ends[-2] + 1, ends[-1]
 t0 = min(r[0] for r in rows[lo:hi + 1])

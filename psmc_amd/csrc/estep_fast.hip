@@ -575,6 +575,13 @@ static void launch_expect(const EstepLaunch &p, hipStream_t st, int redo)
 //   main: fwd speculate | fwd verify/repair ...          | k_ll | expect(redo) reduce
 //   aux : bwd speculate | bwd verify/repair ...          |
 //   exp :               | expect (all tiles)             |
+// With the fused back half (p.fused == 1, the default for PSMC-form matrices up to 64 states) there is no
+// backward table and no separate counts pass:
+//   main : fwd sweep (all tiles, or list A then B)          | fwd verify/repair ... | k_ll | redo of touched groups, reduce
+//   aux  : bwd warm-up only (start vectors) | fused bwd + counts, list A | list B     | bwd verify / boundary-only repairs
+//   walk : walks of the glued runs | chain of transfer matrices | run tiles (fwd)     -> their vectors gate the fused launch
+//   cols : transfer-matrix columns (wave priority 2: they head the longest dependency chain)
+// and p.fused == 2 (psmc_hip_estep_factored) puts the O(N) statistics kernel where the fused one is.
 // p.overlap == 0 runs the same kernels back to back on one stream (bit-identical result).
 int launch_fast(const EstepLaunch &p, FastReport *rep)
 {

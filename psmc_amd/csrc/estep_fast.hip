@@ -744,13 +744,15 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (p.fused) {
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
-		// tiles whose X a forward repair rewrote after their counts were taken
-		if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else { launch_bwd_count(p, sm, 0, true); launch_bwd_count(p, sm, 1, true); }
+		// tiles whose X a forward repair rewrote after their counts were taken (only repairs set the touch flags)
+		if (rep->fwd_rounds + rep->bwd_rounds > 0) {
+			if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else { launch_bwd_count(p, sm, 0, true); launch_bwd_count(p, sm, 1, true); }
+		}
 	} else if (ov) {
 		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // backward chain done
 		(void)hipStreamWaitEvent(sm, p.evx[3], 0);                                     // early expect done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
-		launch_expect(p, sm, 1); // only tiles a repair rewrote
+		if (rep->fwd_rounds + rep->bwd_rounds > 0) launch_expect(p, sm, 1); // only tiles a repair rewrote
 	} else {
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sm);

@@ -64,3 +64,15 @@ def test_exact_kernels_have_no_fma():
     # each IEEE f64 division expands to v_div_scale x2, v_rcp, 5-6 v_fma, v_div_fmas, v_div_fixup
     assert n_fma <= 7 * n_div, (n_fma, n_div)
     assert "v_mfma" not in txt and "v_pk_fma" not in txt
+
+
+def test_every_option_is_documented():
+    """Each key psmc_hip_set_option accepts is described in include/psmc_hip.h (the ABI's only documentation)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "psmc_amd", "csrc", "api.hip")).read()
+    hdr = open(os.path.join(root, "include", "psmc_hip.h")).read()
+    keys = re.findall(r'k == "([a-z_0-9]+)"', api)
+    assert len(keys) >= 20
+    missing = [k for k in keys if '"%s"' % k not in hdr]
+    assert not missing, missing

@@ -4,17 +4,28 @@
 Metric (BASELINE.json): genome bins/sec through forward-backward at n=64 states.
 A "step" is one E-step pass (forward sweep, backward sweep, expected counts,
 reduction, and for N>1 the all-reduce of the sufficient statistics) over one
-synthetic whole-genome batch (~30 M bins, 90 segments shaped like human
-chromosomes + scaffolds, drawn from a 64-state PSMC model).  Observations are
-resident in HBM before the timed region; per step only the 33 KB of HMM
-parameters cross PCIe, exactly as in an EM iteration.
+synthetic whole-genome batch (config 3: ~30 M bins, 90 segments shaped like the
+human autosomes + scaffolds, longest 2.49e6 bins, drawn from a 64-state PSMC
+model).  Observations are resident in HBM before the timed region; per step only
+the 33 KB of HMM parameters cross PCIe, exactly as in an EM iteration.
 
-    python bench.py [--gpus N --steps K --warmup W]
+THE PARAMETERS MOVE: every step gets the next parameter set of a trajectory taken
+from a real EM run (tests/golden/traj_n64.json: PA lines of `psmc -N25` on this
+workload, mapped to (a, e, a0) by the host library), cycling through the 25 rounds --
+as in an EM run, the tile plan a context learned meets new parameters every
+iteration.  The headline `value` is measured that way; `steady_state` (the same
+parameters every step: the best case, what round 1 of this repo reported) is
+given beside it.
+
+    python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Weak scaling: every rank holds its own genome-sized shard (segments are
-independent given the parameters, em.c:36-55); the one exchange per step is the
-RCCL all-reduce of n*n+2n+1 doubles that replaces hmm_add_expect (khmm.c:346).
+Scaling.  Segments are independent given the parameters (em.c:36-55); the one
+exchange per step is the RCCL all-reduce of n*n+2n+1 doubles that replaces
+hmm_add_expect (khmm.c:346).  Default "weak": every rank holds its own
+genome-sized shard.  `--scaling strong` is config 3 proper: ONE 30 M-bin genome,
+its segments spread over the ranks by longest-processing-time-first; with N>1 the
+default run also reports that as `strong_scaling` beside the headline.
 """
 import argparse
 import json
@@ -33,6 +44,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_STATES = 64
+PATTERN = "4+25*2+4+6"               # README:12 of the reference: 64 states, 28 free lambdas
 BYTES_PER_BIN = 16 * N_STATES + 18   # obs x2, f write+read, s write+read
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (psmc_hip_hbm_probe: 5.3-5.9 TB/s streaming on this box)
 F64_PEAK_TFLOPS = 78.6               # dense FP64, vector or v_mfma_f64_16x16x4 (they share the pipe: psmc_hip_microbench)
@@ -45,6 +57,15 @@ def log(*a):
 def load_params():
     g = np.load(os.path.join(ROOT, "tests", "golden", "hmm_params.npz"))
     return g["n64_curve.a"], g["n64_curve.e"], g["n64_curve.a0"]
+
+
+def load_trajectory(path, n_sets=25):
+    """Parameter sets of consecutive EM rounds (rounds 1..n_sets of the run the file records) -> [(a, e, a0)]."""
+    from psmc_amd import hostlib
+    tj = json.load(open(path))
+    assert tj["pattern"] == PATTERN
+    rounds = [r for r in tj["rounds"] if r["round"] >= 1][:n_sets]
+    return [hostlib.hmm_params(PATTERN, r["params"]) for r in rounds], tj.get("source", path)
 
 
 def cpu_baseline(a, e, a0, segs, sample_bins):
@@ -70,21 +91,50 @@ def cpu_baseline(a, e, a0, segs, sample_bins):
             "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
 
 
+class Shard:
+    """One rank's segments resident in HBM + the E-step context over them."""
+
+    def __init__(self, hip, torch, segs, n_states, device, mode, opts):
+        lens = np.array([len(s) for s in segs], dtype=np.int32)
+        off = np.concatenate([[0], np.cumsum((lens.astype(np.int64) + 63) // 64 * 64)])
+        host = np.full(int(off[-1]) + 256, 2, dtype=np.uint8)
+        for s, o in zip(segs, off[:-1]):
+            host[o:o + len(s)] = s
+        self.d_obs = torch.from_numpy(host).cuda()
+        self.es = hip.HipEStep(n_states, device=device, mode=mode)
+        for kv in opts:
+            k, v = kv.split("=")
+            self.es.set_option(k, float(v))
+        self.es.load_segments_device(self.d_obs.data_ptr(), off[:-1], lens, keepalive=self.d_obs)
+        self.bins = int(lens.sum())
+        self.stats = torch.zeros(n_states * n_states + 2 * n_states + 1, dtype=torch.float64, device="cuda")
+
+    def close(self):
+        self.es.close()
+        self.es = None; self.d_obs = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bins", type=int, default=30_000_000, help="bins per GPU (whole human genome ~ 3e7)")
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--bins", type=int, default=30_000_000, help="bins per genome (whole human genome ~ 3e7)")
     ap.add_argument("--segments", type=int, default=90)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: one genome per GPU; strong: one genome, its segments LPT-sharded over the GPUs (config 3)")
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--traj", default=os.path.join(ROOT, "tests", "golden", "traj_n64.json"))
+    ap.add_argument("--fixed-params", type=int, default=0, help="1: the same parameters every step (steady state) as the headline")
     ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="bins for the CPU baseline (0 = skip)")
     ap.add_argument("--exact-extra", type=int, default=1, help="also time 1 exact-mode step (0 = skip)")
+    ap.add_argument("--n128-extra", type=int, default=1, help="also time config 5 (128 states, same genome) (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (chunk, warmup, ...)")
     args = ap.parse_args()
 
     import torch
     from psmc_amd import hip, sim
+    from psmc_amd.dist import partition_segments
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,41 +156,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     a, e, a0 = load_params()
+    traj, traj_src = load_trajectory(args.traj)
     lens = sim.human_like_lengths(args.bins, n_seg=args.segments)
-    t0 = time.perf_counter()
-    segs = sim.simulate_genome(a, e, a0, lens, seed=43 + rank)
-    bins = int(sum(len(s) for s in segs))
-    log("[rank %d] synthetic genome: %d segments, %d bins, longest %d (%.1f s)"
-        % (rank, len(segs), bins, int(lens.max()), time.perf_counter() - t0))
-
-    # observations -> HBM once
-    off = np.concatenate([[0], np.cumsum((lens.astype(np.int64) + 63) // 64 * 64)])
-    host = np.full(int(off[-1]) + 256, 2, dtype=np.uint8)
-    for s, o in zip(segs, off[:-1]):
-        host[o:o + len(s)] = s
-    d_obs = torch.from_numpy(host).cuda()
     mode = hip.MODE_FAST if args.mode == "fast" else hip.MODE_EXACT
-    es = hip.HipEStep(N_STATES, device=local, mode=mode)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        es.set_option(k, float(v))
-    es.load_segments_device(d_obs.data_ptr(), off[:-1], lens, keepalive=d_obs)
-    stats = torch.zeros(N_STATES * N_STATES + 2 * N_STATES + 1, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
 
-    def step():
-        if mode == hip.MODE_FAST:
-            es.estep_device(a, e, a0, stats.data_ptr(), stream.cuda_stream)
-            if dist is not None and not single_gpu_test:
-                dist.all_reduce(stats)           # RCCL over xGMI: replaces hmm_add_expect across shards
-            elif dist is not None:
-                t = stats.cpu(); dist.all_reduce(t); stats.copy_(t)
-        else:
-            r = es.estep(a, e, a0)               # exact: ordered host sum (bit-identical to khmm.c)
-            if dist is not None:
-                t = torch.from_numpy(np.concatenate([r["A"].ravel(), r["E"].ravel(), [r["LL"]]]))
-                t = t if single_gpu_test else t.cuda()
-                dist.all_reduce(t)
+    def workload(scaling):
+        """(this rank's segments, bins of the whole job)"""
+        t0 = time.perf_counter()
+        if scaling == "weak" or world == 1:
+            segs = sim.simulate_genome(a, e, a0, lens, seed=43 + rank)
+            total = int(lens.sum()) * world
+        else:  # one genome for the whole job; every rank draws it (1.8 s) and keeps its LPT share
+            full = sim.simulate_genome(a, e, a0, lens, seed=43)
+            mine = partition_segments(lens, world)[rank]
+            segs = [full[i] for i in mine]
+            total = int(lens.sum())
+        log("[rank %d] %s: %d segments, %d bins here, longest %d (%.1f s)"
+            % (rank, scaling, len(segs), sum(len(s) for s in segs), max(len(s) for s in segs), time.perf_counter() - t0))
+        return segs, total
 
     def sync():
         torch.cuda.synchronize()
@@ -148,32 +182,69 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def make_step(sh):
+        def step(par):
+            pa, pe, p0 = par
+            if mode == hip.MODE_FAST:
+                sh.es.estep_device(pa, pe, p0, sh.stats.data_ptr(), stream.cuda_stream)
+                if dist is not None and not single_gpu_test:
+                    dist.all_reduce(sh.stats)        # RCCL over xGMI: replaces hmm_add_expect across shards
+                elif dist is not None:
+                    t = sh.stats.cpu(); dist.all_reduce(t); sh.stats.copy_(t)
+            else:
+                r = sh.es.estep(pa, pe, p0)          # exact: ordered host sum (bit-identical to khmm.c)
+                if dist is not None:
+                    t = torch.from_numpy(np.concatenate([r["A"].ravel(), r["E"].ravel(), [r["LL"]]]))
+                    t = t if single_gpu_test else t.cuda()
+                    dist.all_reduce(t)
+        return step
+
+    def timed(step, params, steps, warmup):
+        """K steps cycling through `params`, barrier + synchronize on both sides, MAX over ranks -> seconds."""
+        for i in range(warmup):
+            step(params[i % len(params)])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(params[(warmup + i) % len(params)])
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_gpu_test else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    moving = traj if not args.fixed_params else [(a, e, a0)]
+    segs, total_bins = workload(args.scaling)
+    sh = Shard(hip, torch, segs, N_STATES, local, mode, args.opt)
+    es = sh.es
+    step = make_step(sh)
+    first_ms = None
     if mode == hip.MODE_FAST:
-        es.estep(a, e, a0)   # blocking form once: validates / widens the tile warm-up before timing
-    for _ in range(args.warmup):
-        step()
-    sync()
+        t0 = time.perf_counter()
+        es.estep(*moving[0])   # blocking form once: allocates the tables, plans, learns the slow regions
+        first_ms = (time.perf_counter() - t0) * 1e3
+    dt = timed(step, moving, args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    value = total_bins / (dt / args.steps)
+    # per-kernel durations (HIP events recorded by the library on the streams the kernels ran on); measured on separate
+    # steps of the same cycle so that the event reads do not perturb the timed region
     kern = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if single_gpu_test else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    # per-kernel durations (HIP events recorded by the library on the stream the kernels ran on);
-    # measured on separate, identical steps so that the event reads do not perturb the timed region
-    nk = max(1, min(args.steps, 5)) if mode == hip.MODE_FAST else 1
-    for _ in range(nk):
-        step(); torch.cuda.synchronize()
+    nk = max(1, min(args.steps, len(moving))) if mode == hip.MODE_FAST else 1
+    for i in range(nk):
+        step(moving[i % len(moving)]); torch.cuda.synchronize()
         t = es.timing()
         for k in t:
             kern[k] = kern.get(k, 0.0) + t[k] / nk
     diag = es.fast_diag() if mode == hip.MODE_FAST else {}
-    ms_per_step = dt / args.steps * 1e3
-    value = bins * world / (dt / args.steps)
+    # steady state: the same parameters every step (the plan has seen them: no repairs, nothing to learn)
+    steady = None
+    if mode == hip.MODE_FAST and not args.fixed_params:
+        dts = timed(step, [(a, e, a0)], args.steps, max(2, args.warmup // 2))
+        steady = {"ms_per_step": dts / args.steps * 1e3, "value": total_bins / (dts / args.steps), "unit": "bins/s",
+                  "note": "same (a, e, a0) every step -- what BENCH_r01 measured; the headline cycles through %d parameter sets" % len(moving)}
+    bins = sh.bins
 
     out = None
     if rank == 0:
@@ -210,12 +281,15 @@ def main():
         out = {
             "metric": "genome bins/sec through forward-backward (n=64)",
             "value": value, "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: whole-genome .psmcfa-like batch, %d bins x %d states in %d segments "
-                                   "per GPU, -p 4+25*2+4+6, one E-step (EM iteration) per step" % (bins, N_STATES, len(segs)),
-                       "mode": args.mode, "bins_per_gpu": bins, "n_states": N_STATES, "segments": len(segs),
-                       "sharding": "segments/GPU + 1 RCCL all-reduce(%d f64)/step" % stats.numel() if world > 1 else "single GPU",
+                                   "%s, -p %s, one E-step (EM iteration) per step, parameters of a different EM round every step"
+                                   % (int(lens.sum()), N_STATES, len(lens), "per GPU" if args.scaling == "weak" else "sharded over the GPUs", PATTERN),
+                       "mode": args.mode, "bins_per_gpu": bins, "bins_total": total_bins, "n_states": N_STATES, "segments": len(segs),
+                       "longest_segment": int(lens.max()),
+                       "parameters": ("fixed (n64_curve)" if args.fixed_params else "cycle of %d EM rounds: %s" % (len(moving), traj_src)),
+                       "sharding": ("segments/GPU + 1 RCCL all-reduce(%d f64)/step" % sh.stats.numel()) if world > 1 else "single GPU",
                        **({"tiles": diag.get("n_chunks"), "speculative_overlap_bins": diag.get("warmup"),
                            "structured_sweeps": diag.get("structured"), "tile_bins": diag.get("tile_len"),
                            "sweep_items": [diag.get("items_fwd"), diag.get("items_bwd")],
@@ -243,6 +317,10 @@ def main():
                                        "kernel (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) reaches %.1f of 78.6 TFLOP/s") %
                                       (bins * 2 * N_STATES * N_STATES / (kern["expect"] * 1e-3) / 1e12 if kern.get("expect", 0) > 0 else 0.0)},
         }
+        if steady is not None:
+            out["steady_state"] = steady
+        if first_ms is not None:
+            out["first_call_ms"] = first_ms
         if world == 1:
             try:  # what plain kernels reach on this box (context for the fractions above; diagnostics of the library)
                 hb = hip.hbm_probe(4 << 30, device=local)
@@ -257,30 +335,70 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, e, a0, segs, args.cpu_sample)
         if world == 1 and mode == hip.MODE_FAST and diag.get("structured"):
             try:  # the same E-step without the N x N counts: what the psmc binary uses with the O(N) objective
-                for _ in range(3):
-                    es.estep_factored(a, e, a0)
+                for i in range(len(moving)):
+                    es.estep_factored(*moving[i])
                 t1 = time.perf_counter()
-                for _ in range(5):
-                    es.estep_factored(a, e, a0)
-                dtf = (time.perf_counter() - t1) / 5
+                nf = 2 * len(moving)
+                for i in range(nf):
+                    es.estep_factored(*moving[i % len(moving)])
+                dtf = (time.perf_counter() - t1) / nf
                 out["factored_stats"] = {"value": bins / dtf, "unit": "bins/s", "ms_per_step": dtf * 1e3, "kernels_ms": es.timing(),
                                          "note": "psmc_hip_estep_factored: triangular sums of A, E, LL from the backward sweep in O(N) "
-                                                 "per bin (no counts GEMM, no bt table); blocking call incl. read-back"}
+                                                 "per bin (no counts GEMM, no bt table); blocking call incl. read-back; moving parameters"}
             except Exception as ex_:
                 out["factored_stats"] = {"error": str(ex_)}
-        if world == 1 and args.exact_extra > 0 and mode == hip.MODE_FAST:
-            try:
-                es.close(); del es
-                ex = hip.HipEStep(N_STATES, device=local, mode=hip.MODE_EXACT)
-                ex.load_segments_device(d_obs.data_ptr(), off[:-1], lens, keepalive=d_obs)
-                ex.estep(a, e, a0)
-                t1 = time.perf_counter(); ex.estep(a, e, a0); dte = time.perf_counter() - t1
-                out["exact_mode"] = {"value": bins / dte, "unit": "bins/s", "ms_per_step": dte * 1e3,
-                                     "kernels_ms": ex.timing(),
-                                     "note": "bit-identical to khmm.c; one wave per segment, critical path = longest segment"}
-                ex.close()
-            except Exception as ex_:  # the headline number must survive an extra's failure
-                out["exact_mode"] = {"error": str(ex_)}
+    # ---- config 3 proper beside a weak-scaling headline: ONE genome sharded over the ranks
+    if world > 1 and args.scaling == "weak" and mode == hip.MODE_FAST:
+        sh.close()
+        segs_s, total_s = workload("strong")
+        sh = Shard(hip, torch, segs_s, N_STATES, local, mode, args.opt)
+        step = make_step(sh)
+        sh.es.estep(*moving[0])
+        dts = timed(step, moving, args.steps, args.warmup)
+        if rank == 0:
+            out["strong_scaling"] = {"value": total_s / (dts / args.steps), "unit": "bins/s", "ms_per_step": dts / args.steps * 1e3,
+                                     "bins_total": total_s, "bins_this_rank": sh.bins,
+                                     "note": "config 3: one %d-bin genome, segments LPT-sharded over %d GPUs, 1 all-reduce per step; "
+                                             "MAX over ranks like the headline" % (total_s, world)}
+    if rank == 0 and world == 1 and args.exact_extra > 0 and mode == hip.MODE_FAST:
+        try:
+            lens_l = np.array([len(s) for s in segs], dtype=np.int32)
+            off = np.concatenate([[0], np.cumsum((lens_l.astype(np.int64) + 63) // 64 * 64)])
+            d_obs = sh.d_obs
+            sh.es.close()
+            ex = hip.HipEStep(N_STATES, device=local, mode=hip.MODE_EXACT)
+            ex.load_segments_device(d_obs.data_ptr(), off[:-1], lens_l, keepalive=d_obs)
+            ex.estep(a, e, a0)
+            t1 = time.perf_counter(); ex.estep(*moving[1 % len(moving)]); dte = time.perf_counter() - t1
+            out["exact_mode"] = {"value": bins / dte, "unit": "bins/s", "ms_per_step": dte * 1e3,
+                                 "kernels_ms": ex.timing(),
+                                 "note": "bit-identical to khmm.c; one wave per segment, critical path = longest segment (%d bins)" % int(lens_l.max())}
+            ex.close()
+        except Exception as ex_:  # the headline number must survive an extra's failure
+            out["exact_mode"] = {"error": str(ex_)}
+    if rank == 0 and world == 1 and args.n128_extra > 0 and mode == hip.MODE_FAST:
+        try:  # config 5: -p "64*2", 128 states, the same genome
+            g = np.load(os.path.join(ROOT, "tests", "golden", "estep_n128.npz"))
+            a8, e8, a08 = g["n128_curve.a"], g["n128_curve.e"], g["n128_curve.a0"]
+            sh.close()
+            s8 = Shard(hip, torch, segs, 128, local, hip.MODE_FAST, args.opt)
+            t1 = time.perf_counter(); s8.es.estep(a8, e8, a08); f8 = (time.perf_counter() - t1) * 1e3
+            st8 = torch.zeros(128 * 128 + 2 * 128 + 1, dtype=torch.float64, device="cuda")
+            for _ in range(2):
+                s8.es.estep_device(a8, e8, a08, st8.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                s8.es.estep_device(a8, e8, a08, st8.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            d8 = (time.perf_counter() - t1) / 5
+            out["n128"] = {"value": bins / d8, "unit": "bins/s", "ms_per_step": d8 * 1e3, "first_call_ms": f8, "kernels_ms": s8.es.timing(),
+                           "config": "configs[4]: -p 64*2 (128 states), %d bins in %d segments, fast mode, fixed parameters" % (bins, len(segs)),
+                           "alg_bytes_per_bin": 16 * 128 + 18, "alg_flop_per_bin_counts": 2 * 128 * 128}
+            s8.close()
+        except Exception as ex_:
+            out["n128"] = {"error": str(ex_)}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

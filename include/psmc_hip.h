@@ -167,6 +167,12 @@ int psmc_hip_hbm_probe(int device, long long bytes, double *gbps_out);
  * steps < 0: |steps| steps of the eight-tiles-per-wave form of the step (8 lanes x 8 states). */
 int psmc_hip_load_probe(int device, int n_waves, int steps, double *out);
 
+/* Diagnostic: psmc_hip_load_probe with the table stores of a forward sweep: each wave appends 512 bytes per tile and
+ * step during the last `store_steps` of its `steps` steps.  mode 1: two 16-byte stores per lane and step (what
+ * k_fwd_struct does), 2: the same bytes written as 2 KB per tile every 4th step.  out[0..3] as psmc_hip_load_probe,
+ * out[4] = GB/s of the stores over the whole kernel. */
+int psmc_hip_load_probe_st(int device, int n_waves, int steps, int store_steps, int mode, double *out);
+
 /* Wall time in ms of the last E-step measured with HIP events on the streams the
  * kernels ran on.  Exact mode: [0] total, [1] forward, [2] backward, [3] expect,
  * [4] host-copy tail.  Fast mode: [0] total, [1] both sweep chains (speculate +

@@ -77,7 +77,7 @@ struct psmc_hip_ctx {
 	int64_t tab_bins = 0; bool have_b = false;
 	// exact outputs
 	double *d_segA = nullptr, *d_segE = nullptr, *d_segA0 = nullptr, *d_chk = nullptr;
-	int seg_cap = 0;
+	int seg_cap = 0, chk_cap = 0;
 	std::vector<double> h_segA, h_segE, h_segA0, h_chk, h_s;
 	// fast
 	std::vector<Chunk> chunks;
@@ -480,12 +480,15 @@ static int run_exact(psmc_hip_ctx *c, const double *a, const double *e, const do
 	if ((rc = ensure_tables(c, true))) return rc;
 	const int nw = (int)c->work.size();
 	const size_t S = (size_t)c->ns;
-	if (c->seg_cap < nw || !c->d_chk) {
+	if (c->seg_cap < nw) {
 		if ((rc = dev_alloc(c, &c->d_segA, (size_t)nw * S * S))) return rc;
 		if ((rc = dev_alloc(c, &c->d_segE, (size_t)nw * 3 * S))) return rc;
 		if ((rc = dev_alloc(c, &c->d_segA0, (size_t)nw * S))) return rc;
-		if ((rc = dev_alloc(c, &c->d_chk, (size_t)c->n_seg))) return rc;
 		c->seg_cap = nw;
+	}
+	if (c->chk_cap < c->n_seg) { // indexed by segment id, not by work item: its own capacity
+		if ((rc = dev_alloc(c, &c->d_chk, (size_t)c->n_seg))) return rc;
+		c->chk_cap = c->n_seg;
 	}
 	if ((rc = stage_params(c, a, e, a0, c->stream))) return rc;
 	EstepLaunch p;
@@ -560,6 +563,26 @@ static int estep_exact(psmc_hip_ctx *c, const double *a, const double *e, const 
 }
 
 // ---------------------------------------------------------------- fast mode
+// Buffers that do not depend on the tiling (reduction staging, result vector, read-back words).  Kept apart from
+// plan_fast so that an entry point can make sure its result buffer exists BEFORE the first E-step without planning:
+// the plan depends on whether the matrix has the PSMC form, which only stage_params() finds out.
+static int ensure_fast_buffers(psmc_hip_ctx *c)
+{
+	if (c->d_stage && c->d_stats && c->d_warm && c->d_cnt && c->h_cnt) return 0;
+	int rc;
+	const size_t sl = (size_t)c->ns * c->ns + 3 * (size_t)c->ns + 1;
+	if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * sl))) return rc;
+	if ((rc = dev_alloc(c, &c->d_stats, sl))) return rc;
+	if ((rc = dev_alloc(c, &c->d_warm, (size_t)2))) return rc;
+	if ((rc = dev_alloc(c, &c->d_cnt, (size_t)4))) return rc;
+	if (!c->h_cnt && (hipHostMalloc((void **)&c->h_cnt, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+	                  hipHostGetDevicePointer((void **)&c->m_cnt, c->h_cnt, 0) != hipSuccess)) {
+		c->h_cnt = nullptr;
+		return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
+	}
+	return 0;
+}
+
 static int plan_fast(psmc_hip_ctx *c)
 {
 	int64_t bins = 0;
@@ -612,16 +635,7 @@ static int plan_fast(psmc_hip_ctx *c)
 	}
 	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub_used * c->ns * c->ns))) return rc;
 	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub_used * 3 * c->ns))) return rc;
-	if (!c->d_stage) {
-		const size_t sl = (size_t)c->ns * c->ns + 3 * (size_t)c->ns + 1;
-		if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * sl))) return rc;
-		if ((rc = dev_alloc(c, &c->d_stats, sl))) return rc;
-		if ((rc = dev_alloc(c, &c->d_warm, (size_t)2))) return rc;
-		if ((rc = dev_alloc(c, &c->d_cnt, (size_t)4))) return rc;
-		if (hipHostMalloc((void **)&c->h_cnt, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
-		    hipHostGetDevicePointer((void **)&c->m_cnt, c->h_cnt, 0) != hipSuccess)
-			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
-	}
+	if ((rc = ensure_fast_buffers(c))) return rc;
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
 	c->plan_dirty = false;
 	return 0;
@@ -866,7 +880,7 @@ extern "C" int psmc_hip_estep_factored(psmc_hip_ctx *c, const double *a, const d
 	if (c->mode != PSMC_HIP_MODE_FAST) return fail(c, PSMC_HIP_ENOTSUP, "estep_factored: fast mode only");
 	HIPCHK(c, hipSetDevice(c->device));
 	int rc;
-	if (c->plan_dirty && (rc = plan_fast(c))) return rc; // d_stats must exist before the first enqueue
+	if ((rc = ensure_fast_buffers(c))) return rc; // d_stats must exist before the first enqueue (the plan follows stage_params)
 	c->want_factored = true;
 	rc = enqueue_fast(c, a, e, a0, c->d_stats, c->stream);
 	c->want_factored = false;
@@ -914,11 +928,9 @@ extern "C" int psmc_hip_estep(psmc_hip_ctx *c, const double *a, const double *e,
 {
 	if (!c || !a || !e || !a0) return fail(c, PSMC_HIP_EINVAL, "estep: bad argument");
 	if (c->mode == PSMC_HIP_MODE_EXACT) return estep_exact(c, a, e, a0, A, E, A0, LL, chk);
-	if (c->plan_dirty) { // d_stats must exist before the first enqueue
-		HIPCHK(c, hipSetDevice(c->device));
-		int rc = plan_fast(c);
-		if (rc) return rc;
-	}
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = ensure_fast_buffers(c); // d_stats must exist before the first enqueue (the plan follows stage_params)
+	if (rc) return rc;
 	return estep_fast(c, a, e, a0, A, E, A0, LL, chk);
 }
 
@@ -1092,7 +1104,7 @@ extern "C" int psmc_hip_load_probe(int device, int n_waves, int steps, double *o
 	return rc;
 }
 
-// Diagnostic (not in the public header): load_probe with the table stores of a sweep; mode 1 / 2 see microbench.hip
+// Diagnostic: load_probe with the table stores of a sweep; modes: see include/psmc_hip.h and microbench.hip
 extern "C" int psmc_hip_load_probe_st(int device, int n_waves, int steps, int store_steps, int mode, double *out)
 {
 	int nd = psmc_hip_device_count();

@@ -54,32 +54,64 @@ class ShardedEStep:
         self.parts = partition_segments(lens, self.world)
         self.mine = self.parts[self.rank]
         local = [segs[i] for i in self.mine]
+        self.device = None      # set when the engine is the HIP library: this rank's GPU
+        self._stats = None      # device-resident [A | E | LL] the collective runs on (HIP engine, fast mode)
         if make_engine is None:
+            import os
+            import torch
             from . import hip
+            if device is None:  # one process per GPU: torchrun's LOCAL_RANK, else round-robin over the visible devices
+                nd = max(1, torch.cuda.device_count())
+                device = int(os.environ.get("LOCAL_RANK", self.rank % nd)) % nd
+            self.device = int(device)
+            torch.cuda.set_device(self.device)
 
             def make_engine(n, local_segs, mode_):
-                es = hip.HipEStep(n, device=device if device is not None else 0,
-                                  mode=hip.MODE_FAST if mode_ == "fast" else hip.MODE_EXACT)
+                es = hip.HipEStep(n, device=self.device, mode=hip.MODE_FAST if mode_ == "fast" else hip.MODE_EXACT)
                 if local_segs:
                     es.load_segments(local_segs)
                 return es
         self.engine = make_engine(self.n, local, mode) if local else None
 
+    def _estep_fast_device(self, a, e, a0):
+        """HIP engine: the E-step leaves [A | E | LL] in HBM and the collective reduces that buffer in place (RCCL over
+        xGMI with the nccl backend); nothing but the 34 KB result crosses PCIe, once, after the all-reduce."""
+        import torch
+        n = self.n
+        dev = torch.device("cuda", self.device)
+        if self._stats is None:
+            self._stats = torch.zeros(n * n + 2 * n + 1, dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream(dev)
+        if self.engine is not None:
+            self.engine.estep_device(a, e, a0, self._stats.data_ptr(), st.cuda_stream)
+        else:
+            self._stats.zero_()
+        if self.world > 1:
+            if self.dist.get_backend() == "nccl":
+                self.dist.all_reduce(self._stats)  # replaces hmm_add_expect across shards (khmm.c:346-359)
+            else:                                  # gloo (tests on one GPU / CPU rendezvous): reduce a host copy
+                st.synchronize()
+                t = self._stats.cpu()
+                self.dist.all_reduce(t)
+                self._stats.copy_(t)
+        st.synchronize()
+        return self._stats.cpu().numpy()
+
     def estep(self, a, e, a0):
         import torch
         n = self.n
         if self.mode == "fast":
-            vec = np.zeros(n * n + 2 * n + 1)
-            if self.engine is not None:
-                r = self.engine.estep(a, e, a0)
-                vec = np.concatenate([r["A"].ravel(), r["E"].ravel(), [r["LL"]]])
-            t = torch.from_numpy(vec)
-            if self.world > 1:
-                dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
-                t = t.to(dev)
-                self.dist.all_reduce(t)  # replaces hmm_add_expect across shards
-                t = t.cpu()
-            v = t.numpy()
+            if self.device is not None:
+                v = self._estep_fast_device(a, e, a0)
+            else:  # injected engine (CPU tests): host vectors
+                vec = np.zeros(n * n + 2 * n + 1)
+                if self.engine is not None:
+                    r = self.engine.estep(a, e, a0)
+                    vec = np.concatenate([r["A"].ravel(), r["E"].ravel(), [r["LL"]]])
+                t = torch.from_numpy(vec)
+                if self.world > 1:
+                    self.dist.all_reduce(t)  # replaces hmm_add_expect across shards
+                v = t.numpy()
             return dict(A=v[:n * n].reshape(n, n).copy(), E=v[n * n:n * n + 2 * n].reshape(2, n).copy(), LL=float(v[-1]))
         # exact: gather every segment's own statistics, add in input order on every rank
         mine = dict(idx=self.mine, seg_A=np.zeros((0, n, n)), seg_E=np.zeros((0, 3, n)), seg_LL=np.zeros(0))

@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
-    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe",
+    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st",
 ]
 
 

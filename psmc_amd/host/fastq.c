@@ -3,15 +3,24 @@
  * The scalar version (model.c) spends its time in ~9N libm calls per objective evaluation.  Here the
  * recurrences (alpha, beta, sum_t) are scalar scans and everything else is a loop over independent k, which
  * gcc vectorises with glibc's libmvec (4 logs / exps per call with AVX2).  This file is compiled with
- * -O3 -mavx2 -mfma -ffast-math -fopenmp-simd (see Makefile; no isnan() here: finite-math-only); results agree with the
+ * -O3 -mavx2 -mfma -ffast-math -fopenmp-simd (see Makefile and the note on finite-math-only below); results agree with the
  * scalar version to ~1e-15 relative.  Same formulas as psmc_update_hmm, lh3/psmc core.c:61-133.
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include "psmc_host.h"
 
 #define NMAX 136 /* 128 states + slack */
+
+/* This file is compiled with -ffast-math (glibc only offers the libmvec variants of log / exp under __FAST_MATH__), and
+ * that implies -ffinite-math-only: the compiler may assume NaN and infinity never occur and fold floating-point tests
+ * that only they can fail.  Trial points of the direct search do produce them (lambda -> 0, 0/0 in sigma_k ...), so
+ * every accept / reject decision below is taken on the BIT PATTERN, which no floating-point assumption can remove. */
+static inline uint64_t bits_of(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline int is_finite_bits(double x) { return ((bits_of(x) >> 52) & 0x7ff) != 0x7ff; }
+static inline int pos_finite_bits(double x) { const uint64_t u = bits_of(x); return (u >> 63) == 0 && u != 0 && (u >> 52) != 0x7ff; }
 
 int psmc_model_logfactors_simd(psmc_model *m, double *out)
 {
@@ -65,18 +74,21 @@ int psmc_model_logfactors_simd(psmc_model *m, double *out)
 	}
 #pragma omp simd
 	for (int k = 0; k <= n; ++k) {
-		double avg = arg[k] > 0.0 ? -log(arg[k]) * irho : -1.0; /* NaN in the reference <=> arg <= 0 */
-		if (!(avg >= sum_t[k] && avg <= sum_t[k] + tau[k])) avg = alt[k];
+		const int arg_ok = pos_finite_bits(arg[k]);
+		double avg = -log(arg_ok ? arg[k] : 1.0) * irho;      /* NaN in the reference <=> arg <= 0 */
+		const int inside = arg_ok && is_finite_bits(avg) && avg >= sum_t[k] && avg <= sum_t[k] + tau[k];
+		if (!inside) avg = alt[k];
 		X[k] = -theta * (avg + dt);
 	}
 #pragma omp simd
 	for (int k = 0; k <= n; ++k) E1[k] = 1.0 - exp(X[k]);
 #pragma omp simd
 	for (int k = 0; k <= n; ++k)
-		okv[k] = (D[k] > 0.0 && FL[k] > 0.0 && FU[k] > 0.0 && QA[k] > 0.0 && CC[k] > 0.0 && E1[k] > 0.0 && X[k] > -700.0) ? 0.0 : 1.0;
-	double bad = 0.0;
-	for (int k = 0; k <= n; ++k) bad += okv[k];
-	if (bad != 0.0) { memset(out, 0, sizeof(double) * (size_t)(7 * N)); return 0; }
+		okv[k] = (pos_finite_bits(D[k]) && pos_finite_bits(FL[k]) && pos_finite_bits(FU[k]) && pos_finite_bits(QA[k]) &&
+		          pos_finite_bits(CC[k]) && pos_finite_bits(E1[k]) && is_finite_bits(X[k]) && X[k] > -700.0) ? 0.0 : 1.0;
+	int bad = 0;
+	for (int k = 0; k <= n; ++k) bad += okv[k] != 0.0;
+	if (bad) { memset(out, 0, sizeof(double) * (size_t)(7 * N)); return 0; }
 #pragma omp simd
 	for (int k = 0; k <= n; ++k) {
 		lD[k] = log(D[k]); lFL[k] = log(FL[k]); lFU[k] = log(FU[k]); lqa[k] = log(QA[k]); lc[k] = log(CC[k]);

@@ -35,14 +35,26 @@ def simulate_segment(a, e, a0, L, rng, miss_rate=0.0004, miss_lo=10, miss_hi=90)
     return seq
 
 
+# hg19 autosome lengths in Mb (public assembly statistics): the shape of a whole-genome .psmcfa
+_AUTOSOMES_MB = [249.25, 243.20, 198.02, 191.15, 180.92, 171.12, 159.14, 146.36, 141.21, 135.53, 135.01, 133.85,
+                 115.17, 107.35, 102.53, 90.35, 81.20, 78.08, 59.13, 63.03, 48.13, 51.30]
+
+
 def human_like_lengths(total_bins, n_seg=90, longest_frac=0.083):
-    """n_seg segment lengths summing to ~total_bins, shaped like human chromosomes
-    plus scaffolds: 24 large ones decaying from the longest, the rest small."""
-    big = np.linspace(1.0, 0.19, 24)
-    small = np.linspace(0.02, 0.002, max(n_seg - 24, 0))
-    w = np.concatenate([big, small])[:n_seg]
-    w = w / w.sum()
-    L = np.maximum(1, np.round(w * total_bins).astype(np.int64))
+    """n_seg segment lengths summing to ~total_bins, shaped like a human genome in 100-bp bins: the 22 autosomes in
+    hg19 proportions with the longest at longest_frac of the total (3e7 bins -> chr1 = 2.49e6, SURVEY.md section 8(d)
+    config 3), the remainder spread over small scaffolds of linearly decaying size."""
+    chrom = np.array(_AUTOSOMES_MB[:min(n_seg, len(_AUTOSOMES_MB))])
+    chrom = chrom / chrom[0] * (longest_frac * total_bins)
+    n_small = n_seg - len(chrom)
+    rest = total_bins - chrom.sum()
+    if n_small <= 0 or rest <= n_small:     # no room (or no wish) for scaffolds: the chromosomes alone, rescaled
+        chrom = chrom * (total_bins / chrom.sum())
+        small = np.zeros(0)
+    else:
+        w = np.linspace(1.0, 0.1, n_small)
+        small = w / w.sum() * rest
+    L = np.maximum(1, np.round(np.concatenate([chrom, small])).astype(np.int64))
     return L.astype(np.int32)
 
 

@@ -151,6 +151,17 @@ int psmc_hip_selftest(int device);
  * wave; see psmc_amd/csrc/microbench.hip for the meaning of out[0..13]. */
 int psmc_hip_microbench(int device, double *out, int n);
 
+/* Diagnostic: do the f64 matrix instructions of one wave overlap with the f64 vector instructions of another wave
+ * on the same SIMD?  One work-group on one CU, waves go to its four SIMDs round robin; a "matrix wave" issues 64
+ * v_mfma_f64_16x16x4 per round, a "vector wave" 1024 v_fma_f64 (8 chains) -- ~4100 cycles of issue either way.
+ * out[8*c + w] = shader cycles per round of wave w in configuration c (0 where the configuration has no wave w):
+ *   c=0: 4 matrix waves (one per SIMD)      c=1: 4 vector waves         c=2: 8 matrix waves (two per SIMD)
+ *   c=3: 8 vector waves                     c=4: waves 0-3 matrix, 4-7 vector (one of each per SIMD)
+ *   c=5: even waves matrix, odd waves vector (SIMDs 0 and 2 hold two matrix waves, 1 and 3 two vector waves).
+ * Separate pipes would give c=4 the times of c=0 / c=1; one shared pipe gives it their sum.  n >= 48. */
+#define PSMC_HIP_PIPE_PROBE_CONFIGS 6
+int psmc_hip_pipe_probe(int device, double *out, int n);
+
 /* Diagnostic: an 8-byte-per-lane streaming copy (reads and writes 8*n_doubles bytes, 5
  * launches) to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the access
  * width the kernels use; *ms_out = average duration of one launch. */

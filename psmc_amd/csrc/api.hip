@@ -1023,6 +1023,30 @@ extern "C" int psmc_hip_microbench(int device, double *out, int n)
 	return rc;
 }
 
+extern "C" int psmc_hip_pipe_probe(int device, double *out, int n)
+{
+	// configurations: (waves, mask of matrix waves)
+	static const struct { int waves; unsigned mask; } cfg[PSMC_HIP_PIPE_PROBE_CONFIGS] = {
+		{4, 0xFu}, {4, 0x0u}, {8, 0xFFu}, {8, 0x00u}, {8, 0x0Fu}, {8, 0x55u}};
+	int nd = psmc_hip_device_count();
+	if (!out || n < PSMC_HIP_PIPE_PROBE_CONFIGS * 8) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	double *d = nullptr;
+	if (hipMalloc((void **)&d, sizeof(double) * 8) != hipSuccess) return PSMC_HIP_ENOMEM;
+	int rc = 0;
+	for (int i = 0; i < PSMC_HIP_PIPE_PROBE_CONFIGS && rc == 0; ++i) {
+		(void)hipMemset(d, 0, sizeof(double) * 8);
+		rc = run_pipe_probe(nullptr, d, cfg[i].waves, cfg[i].mask, 8);        // warm: clocks, instruction cache
+		if (rc == 0) rc = run_pipe_probe(nullptr, d, cfg[i].waves, cfg[i].mask, 64);
+		if (rc == 0 && (hipDeviceSynchronize() != hipSuccess ||
+		                hipMemcpy(out + 8 * i, d, sizeof(double) * 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = 1;
+		for (int w = cfg[i].waves; w < 8; ++w) out[8 * i + w] = 0.0;
+	}
+	(void)hipFree(d);
+	return rc ? PSMC_HIP_EDEVICE : PSMC_HIP_OK;
+}
+
 extern "C" int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out)
 {
 	int nd = psmc_hip_device_count();

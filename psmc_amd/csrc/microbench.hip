@@ -314,6 +314,41 @@ int run_load_probe(hipStream_t stream, double *d_out, int n_waves, int steps)
 	return (int)hipGetLastError();
 }
 
+// Do f64 matrix instructions of ONE wave overlap with f64 vector instructions of ANOTHER wave on the same SIMD?
+// (Within a wave they do not: out[18] of k_microbench.)  One work-group of n_waves waves on one CU; bit w of `mask`
+// makes wave w a matrix wave (64 independent-accumulator v_mfma_f64_16x16x4 per round), the others vector waves
+// (1024 v_fma_f64 in 8 chains per round) -- about 4100 cycles of issue each when alone on a SIMD.  out[w] = shader
+// cycles per round of wave w.  Waves of a work-group go to the CU's four SIMDs round robin (w % 4).
+__global__ __launch_bounds__(512) void k_pipe_probe(double *out, double seed, unsigned mask, int rounds)
+{
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const double x = seed + 1e-3 * lane, m = 1.0 + 1e-9 * lane;
+	const bool matrix = (mask >> w) & 1u;
+	d4m_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+	double f0 = x, f1 = x + 1, f2 = x + 2, f3 = x + 3, f4 = x + 4, f5 = x + 5, f6 = x + 6, f7 = x + 7;
+	__syncthreads();
+	const unsigned long long t0 = __builtin_readcyclecounter();
+	if (matrix) {
+		for (int it = 0; it < rounds; ++it) {
+			REPEAT16(c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c1, 0, 0, 0);
+			         c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c3, 0, 0, 0);)
+		}
+	} else {
+		for (int it = 0; it < rounds * 8; ++it) {
+			REPEAT16(f0 = __builtin_fma(f0, m, x); f1 = __builtin_fma(f1, m, x); f2 = __builtin_fma(f2, m, x); f3 = __builtin_fma(f3, m, x);
+			         f4 = __builtin_fma(f4, m, x); f5 = __builtin_fma(f5, m, x); f6 = __builtin_fma(f6, m, x); f7 = __builtin_fma(f7, m, x);)
+		}
+	}
+	const unsigned long long t1 = __builtin_readcyclecounter();
+	if (lane == 0) out[w] = (double)(t1 - t0) / rounds;
+	if (c0[0] + c1[1] + c2[2] + c3[3] + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 == 123.456) out[0] = 0.0;
+}
+int run_pipe_probe(hipStream_t stream, double *d_out, int n_waves, unsigned mask, int rounds)
+{
+	hipLaunchKernelGGL(k_pipe_probe, dim3(1), dim3(64 * n_waves), 0, stream, d_out, 0.37, mask, rounds);
+	return (int)hipGetLastError();
+}
+
 int run_microbench(hipStream_t stream, double *d_out)
 {
 	hipLaunchKernelGGL(k_microbench, dim3(1), dim3(64), 0, stream, d_out, 0.37);

@@ -109,6 +109,7 @@ int launch_post_decode(hipStream_t st, const double *f, const double *b, const d
                        int ns, int32_t *path, double *maxp);
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 int run_microbench(hipStream_t stream, double *d_out);
+int run_pipe_probe(hipStream_t stream, double *d_out, int n_waves, unsigned mask, int rounds);
 int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n);
 int run_hbm_probe(hipStream_t stream, int which, double *a, double *b, size_t bytes);
 int run_load_probe(hipStream_t stream, double *d_out, int n_waves, int steps);

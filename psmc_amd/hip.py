@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
-    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st",
+    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
 ]
 
 
@@ -307,3 +307,18 @@ def stream_probe(n_doubles=1 << 27, device=0):
     if rc != 0:
         raise HipError("stream_probe: %s" % lib.psmc_hip_strerror(rc).decode())
     return ms.value, 16.0 * n_doubles / (ms.value * 1e-3) / 1e9
+
+
+PIPE_PROBE_CONFIGS = ["4 matrix waves (1/SIMD)", "4 vector waves (1/SIMD)", "8 matrix waves (2/SIMD)", "8 vector waves (2/SIMD)",
+                      "waves 0-3 matrix + 4-7 vector (one of each per SIMD)", "even waves matrix, odd vector (SIMDs not mixed)"]
+
+
+def pipe_probe(device=0):
+    """Cross-wave overlap of f64 matrix and f64 vector instructions on one SIMD: {configuration: cycles per round of each wave}."""
+    lib = load_library()
+    lib.psmc_hip_pipe_probe.argtypes = [C.c_int, _dp, C.c_int]
+    out = np.zeros(8 * len(PIPE_PROBE_CONFIGS))
+    rc = lib.psmc_hip_pipe_probe(int(device), _p(out), len(out))
+    if rc != 0:
+        raise HipError("pipe_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+    return {name: [round(v, 1) for v in out[8 * i:8 * i + 8] if v > 0] for i, name in enumerate(PIPE_PROBE_CONFIGS)}

@@ -256,7 +256,7 @@ FULL = os.path.join(ROOT, "tests", "golden", "full")
 # profiles/r02_em_parity.json): the statistics agree to 1e-10, but the Hooke-Jeeves search is driven by `<` between
 # nearly equal Q values, so the reference itself only reproduces lambda_k to ~1e-4 across compiler flags
 # (SURVEY.md section 7.1).  Bounds on the worst round of the run, relative:
-EM_TOL = {"LK": 1e-7, "theta": 2e-4, "rho": 2e-3, "lam": 5e-3}
+EM_TOL = {"LK": 1e-8, "theta": 2e-5, "rho": 2e-5, "lam": 1e-4}
 
 
 def _rounds(text):

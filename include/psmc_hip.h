@@ -130,7 +130,8 @@ int psmc_hip_fast_info(psmc_hip_ctx *ctx, int out[8]);
 
 /* Copies the forward/backward tables of one loaded segment to the host after
  * an E-step (replaces reading hd->f, hd->b, hd->s: aux.c:159-200).  f,b: L*n,
- * s: L.  Exact mode: the reference's values bit for bit.  Fast mode (diagnostic):
+ * s: L; any of them may be NULL (the PR line of `-s`, aux.c:159-164, needs s only: 8 bytes per bin).
+ * Exact mode: the reference's values bit for bit.  Fast mode (diagnostic):
  * f = X, b = bt = e[o_p]*B_p, s = 1/d_p at p % 4 == 0; b only
  * with "fuse" = 0 (the fused back half never stores bt), all of f only without checkpointing. */
 int psmc_hip_get_tables(psmc_hip_ctx *ctx, int seg, double *f, double *b, double *s);
@@ -140,6 +141,20 @@ int psmc_hip_get_tables(psmc_hip_ctx *ctx, int seg, double *f, double *b, double
  * path[u-1] = argmax_k f[u][k]*b[u][k]*s[u] (first maximum wins), maxp[u-1] = its value;
  * 12 bytes per bin leave the GPU instead of the 2*8*n of the tables. */
 int psmc_hip_decode(psmc_hip_ctx *ctx, int seg, int32_t *path, double *maxp);
+
+/* Full posterior decoding of one segment on the device after an exact E-step: replaces the -D branch of psmc_decode
+ * (aux.c:183-200).  post[(u-1)*n + l] = f[u][l]*b[u][l]*s[u] (hmm_post_state, khmm.c:285-292); recomb[u-1] = 1 -
+ * sum_l f[u][l]*a[l][l]*b[u+1][l]*e[o_{u+1}][l] for u < L and 0 at u = L (aux.c:189-193) -- every product left to
+ * right, the sum in state order: the reference's doubles.  Either output may be NULL.  8*(n+1) bytes per bin leave the
+ * GPU instead of the 16*n + 8 of the tables. */
+int psmc_hip_posterior(psmc_hip_ctx *ctx, int seg, double *post, double *recomb);
+
+/* Posterior-weighted counts of one segment on the device: replaces the -c branch of psmc_decode (aux.c:202-219).
+ * cnt1 = the segment's record of a cntcpg file (l positions x n_cnt int32, utils/cntcpg.c); cnt (n*n_cnt, in/out)
+ * are the running totals, cnt[k*n_cnt + j] += post[u][k] * cnt1[(u-1)*n_cnt + j] for u = 1..min(L, l) in position
+ * order -- call once per segment in input order with the same cnt, as the reference's loop does.  Only
+ * 4*n_cnt bytes per bin go to the GPU and n*n_cnt doubles come back. */
+int psmc_hip_post_counts(psmc_hip_ctx *ctx, int seg, const int32_t *cnt1, int32_t l, int32_t n_cnt, double *cnt);
 
 /* Built-in check of the cross-lane primitives on the device (row replication
  * variants, DPP broadcasts, f64 MFMA layout).  Returns 0 when all agree;

@@ -177,6 +177,41 @@ void orc_post_decode(int n, int L, const double *f, const double *b,
 	}
 }
 
+/* aux.c:183-200 (full decoding) with hmm_post_state khmm.c:285-292 */
+void orc_post_full(int n, const double *a, const double *e, int L, const uint8_t *seq, const double *f,
+                   const double *b, const double *s, double *post, double *recomb)
+{
+	for (int k = 1; k <= L; ++k) {
+		double p;
+		if (k < L) {                                               /* aux.c:189-193 */
+			const double *fu = f + (size_t)k * n, *bu1 = b + (size_t)(k + 1) * n;
+			const double *eu1 = e + (size_t)seq[k] * n;            /* hd->seq[k+1]: 1-indexed there, 0-indexed here */
+			p = 0.0;
+			for (int l = 0; l < n; ++l) p += fu[l] * a[(size_t)l * n + l] * bu1[l] * eu1[l];
+			p = 1.0 - p;
+		} else p = 0.0;
+		if (recomb) recomb[k] = p;
+		if (post) {                                                /* khmm.c:288-291 */
+			const double ss = s[k], *fu = f + (size_t)k * n, *bu = b + (size_t)k * n;
+			for (int l = 0; l < n; ++l) post[(size_t)k * n + l] = fu[l] * bu[l] * ss;
+		}
+	}
+}
+
+/* aux.c:202-219 */
+void orc_post_counts(int n, int L, const double *f, const double *b, const double *s, const int32_t *cnt1,
+                     int32_t l1, int32_t n_cnt, double *cnt)
+{
+	const int min_l = L < l1 ? L : l1;
+	for (int k = 1; k <= min_l; ++k) {
+		const double ss = s[k], *fu = f + (size_t)k * n, *bu = b + (size_t)k * n;
+		for (int l = 0; l < n; ++l) {
+			const double prob = fu[l] * bu[l] * ss;                /* hmm_post_state */
+			for (int j = 0; j < n_cnt; ++j) cnt[(size_t)l * n_cnt + j] += prob * cnt1[(size_t)(k - 1) * n_cnt + j];
+		}
+	}
+}
+
 /* khmm.c:326-342  hmm_Q0 (m = 2 symbols) */
 double orc_Q0(int n, const double *A, const double *E)
 {

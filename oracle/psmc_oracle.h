@@ -54,6 +54,13 @@ void   orc_estep(int n, const double *a, const double *e, const double *a0,
 /* Posterior decoding pieces used by aux.c:150-200 (row "next" f-3). */
 void   orc_post_decode(int n, int L, const double *f, const double *b,
                        const double *s, int32_t *path /*L+1*/, double *maxp /*L+1*/);
+/* -D branch of psmc_decode, aux.c:183-200: post (L+1)*n, row u = hmm_post_state (khmm.c:285-292);
+ * recomb[u] = 1 - sum_l f[u][l]*a[l][l]*b[u+1][l]*e[seq[u+1]][l] for u < L, 0 at u = L (L+1 entries, [0] unused). */
+void   orc_post_full(int n, const double *a, const double *e, int L, const uint8_t *seq, const double *f,
+                     const double *b, const double *s, double *post, double *recomb);
+/* -c branch of psmc_decode, aux.c:202-219: cnt[l*n_cnt+j] += post[u][l]*cnt1[(u-1)*n_cnt+j], u = 1..min(L, l1). */
+void   orc_post_counts(int n, int L, const double *f, const double *b, const double *s, const int32_t *cnt1,
+                       int32_t l1, int32_t n_cnt, double *cnt);
 /* Q0 / Q as consumed by the M-step (khmm.c:326-342, 363-382); E is 2*n. */
 double orc_Q0(int n, const double *A, const double *E);
 double orc_Q(int n, const double *a, const double *e, const double *A,

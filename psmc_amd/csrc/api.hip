@@ -974,6 +974,48 @@ extern "C" int psmc_hip_decode(psmc_hip_ctx *c, int seg, int32_t *path, double *
 	return PSMC_HIP_OK;
 }
 
+extern "C" int psmc_hip_posterior(psmc_hip_ctx *c, int seg, double *post, double *recomb)
+{
+	if (!c || seg < 0 || seg >= c->n_seg || (!post && !recomb)) return fail(c, PSMC_HIP_EINVAL, "posterior: bad argument");
+	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "posterior: exact mode only");
+	if (!c->d_f || !c->have_b) return fail(c, PSMC_HIP_ESTATE, "posterior: no E-step yet");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int L = c->L[seg], n = c->n;
+	double *dp = nullptr, *dr = nullptr;
+	if (post && hipMalloc((void **)&dp, sizeof(double) * (size_t)L * n) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipMalloc");
+	if (recomb && hipMalloc((void **)&dr, sizeof(double) * (size_t)L) != hipSuccess) { if (dp) (void)hipFree(dp); return fail(c, PSMC_HIP_ENOMEM, "hipMalloc"); }
+	const double *d_e = c->ns == 128 ? c->d_par + 32768 : c->d_par + 4 * 4096;
+	int rc = launch_post_full(c->stream, c->d_par, d_e, c->d_obs, c->d_f, c->d_b, c->d_s, c->off[seg], L, n, c->ns, dp, dr);
+	hipError_t e1 = post ? hipMemcpyAsync(post, dp, sizeof(double) * (size_t)L * n, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+	hipError_t e2 = recomb ? hipMemcpyAsync(recomb, dr, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+	hipError_t e3 = hipStreamSynchronize(c->stream);
+	if (dp) (void)hipFree(dp);
+	if (dr) (void)hipFree(dr);
+	if (rc || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, PSMC_HIP_EDEVICE, "posterior");
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_post_counts(psmc_hip_ctx *c, int seg, const int32_t *cnt1, int32_t l, int32_t n_cnt, double *cnt)
+{
+	if (!c || seg < 0 || seg >= c->n_seg || !cnt || l < 0 || n_cnt < 1 || (l > 0 && !cnt1)) return fail(c, PSMC_HIP_EINVAL, "post_counts: bad argument");
+	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "post_counts: exact mode only");
+	if (!c->d_f || !c->have_b) return fail(c, PSMC_HIP_ESTATE, "post_counts: no E-step yet");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int L = c->L[seg], n = c->n, min_l = L < l ? L : l;
+	if (min_l == 0) return PSMC_HIP_OK;
+	int32_t *d1 = nullptr; double *dc = nullptr;
+	if (hipMalloc((void **)&d1, sizeof(int32_t) * (size_t)min_l * n_cnt) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipMalloc");
+	if (hipMalloc((void **)&dc, sizeof(double) * (size_t)n * n_cnt) != hipSuccess) { (void)hipFree(d1); return fail(c, PSMC_HIP_ENOMEM, "hipMalloc"); }
+	hipError_t e0 = hipMemcpyAsync(d1, cnt1, sizeof(int32_t) * (size_t)min_l * n_cnt, hipMemcpyHostToDevice, c->stream);
+	hipError_t e1 = hipMemcpyAsync(dc, cnt, sizeof(double) * (size_t)n * n_cnt, hipMemcpyHostToDevice, c->stream);
+	int rc = launch_post_counts(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], min_l, d1, n_cnt, n, c->ns, dc);
+	hipError_t e2 = hipMemcpyAsync(cnt, dc, sizeof(double) * (size_t)n * n_cnt, hipMemcpyDeviceToHost, c->stream);
+	hipError_t e3 = hipStreamSynchronize(c->stream);
+	(void)hipFree(d1); (void)hipFree(dc);
+	if (rc || e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, PSMC_HIP_EDEVICE, "post_counts");
+	return PSMC_HIP_OK;
+}
+
 extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[7])
 {
 	if (!c || !ms) return PSMC_HIP_EINVAL;

@@ -322,6 +322,91 @@ int launch_post_decode(hipStream_t st, const double *f, const double *b, const d
 	return (int)hipGetLastError();
 }
 
+template <int S> __device__ __forceinline__ double ordered_sum_states(double t0, double t1);
+
+// Full posterior decoding of one segment (psmc_decode's -D branch, aux.c:183-200) on the resident tables:
+//   post[u][l]  = f[u][l]*b[u][l]*s[u]                                         (hmm_post_state, khmm.c:285-292)
+//   recomb[u]   = 1 - sum_l f[u][l]*a[l][l]*b[u+1][l]*e[o_{u+1}][l]  (u < L),  0 at u = L      (aux.c:189-193)
+// every product left to right and the sum in state order like the reference's loop, so the doubles are the
+// reference's.  One wave per 64 positions, lane = state (S == 128: states 2*lane, 2*lane+1).
+template <int S>
+__global__ __launch_bounds__(64) void k_post_full(const double *__restrict__ a, const double *__restrict__ e,
+                                                    const uint8_t *__restrict__ obs, const double *__restrict__ f,
+                                                    const double *__restrict__ b, const double *__restrict__ s, int64_t off,
+                                                    int L, int n, double *__restrict__ post, double *__restrict__ recomb)
+{
+	constexpr int PER = S / 64;
+	const int lane = threadIdx.x;
+	const int u0 = blockIdx.x * 64, u1 = min(L, u0 + 64);
+	double dg[PER];
+#pragma unroll
+	for (int j = 0; j < PER; ++j) { const int k = PER * lane + j; dg[j] = a[(int64_t)k * S + k]; }
+	for (int u = u0; u < u1; ++u) {
+		const int64_t g = off + u;
+		const double ss = s[g];
+		double fu[PER], t[PER] = {};
+#pragma unroll
+		for (int j = 0; j < PER; ++j) {
+			const int k = PER * lane + j;
+			fu[j] = f[g * S + k];
+			if (post && k < n) post[(int64_t)u * n + k] = fu[j] * b[g * S + k] * ss;
+		}
+		if (!recomb) continue;
+		double pr = 0.0;
+		if (u < L - 1) {
+			const int sym = obs[g + 1];
+#pragma unroll
+			for (int j = 0; j < PER; ++j) {
+				const int k = PER * lane + j;
+				t[j] = fu[j] * dg[j] * b[(g + 1) * S + k] * e[sym * S + k]; // fu[l] * a[l][l] * bu1[l] * eu1[l]
+			}
+			pr = 1.0 - ordered_sum_states<S>(t[0], PER > 1 ? t[PER - 1] : 0.0);
+		}
+		if (lane == 0) recomb[u] = pr;
+	}
+}
+
+// Posterior-weighted counts (psmc_decode's -c branch, aux.c:202-219): cnt[l][j] += post[u][l] * cnt1[u][j] for
+// u = 1..min_l IN POSITION ORDER, continuing the caller's running totals (the reference keeps one accumulator per
+// (state, column) across all segments).  One wave per count column j, lane = state; 16 positions are loaded at a
+// time, the accumulation itself is sequential.
+template <int S>
+__global__ __launch_bounds__(64) void k_post_counts(const double *__restrict__ f, const double *__restrict__ b,
+                                                      const double *__restrict__ s, int64_t off, int min_l,
+                                                      const int32_t *__restrict__ cnt1, int n_cnt, int n,
+                                                      double *__restrict__ cnt)
+{
+	constexpr int PER = S / 64, BLK = 16;
+	const int lane = threadIdx.x, j = blockIdx.x;
+	double acc[PER];
+#pragma unroll
+	for (int q = 0; q < PER; ++q) { const int k = PER * lane + q; acc[q] = k < n ? cnt[(int64_t)k * n_cnt + j] : 0.0; }
+	for (int k0 = 0; k0 < min_l; k0 += BLK) {
+		const int nb = min(BLK, min_l - k0);
+		const int mine = min(k0 + min(lane, BLK - 1), min_l - 1);
+		const double sv = s[off + mine];
+		const int cv = cnt1[(int64_t)mine * n_cnt + j];
+		double fu[BLK][PER], bu[BLK][PER];
+#pragma unroll
+		for (int t = 0; t < BLK; ++t) {
+			const int64_t r = (off + min(k0 + t, min_l - 1)) * S + PER * lane;
+#pragma unroll
+			for (int q = 0; q < PER; ++q) { fu[t][q] = f[r + q]; bu[t][q] = b[r + q]; }
+		}
+#pragma unroll
+		for (int t = 0; t < BLK; ++t) {
+			if (t < nb) {
+				const double ss = readlane_f64(sv, t);
+				const double c = (double)__builtin_amdgcn_readlane(cv, t);
+#pragma unroll
+				for (int q = 0; q < PER; ++q) acc[q] += fu[t][q] * bu[t][q] * ss * c; // cnt += prob[l] * cnt1
+			}
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < PER; ++q) { const int k = PER * lane + q; if (k < n) cnt[(int64_t)k * n_cnt + j] = acc[q]; }
+}
+
 // ---------------------------------------------------------------- 65..128 states
 // Same recursions with two ADJACENT states per lane (k = 2*lane and 2*lane + 1;
 // `-p "64*2"` of the reference's README gives 128).  The 128x128 transition matrix
@@ -540,6 +625,41 @@ template <int REP> static int launch_exact128_t(const EstepLaunch &p)
 	                   p.d_obs, p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
 	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);
 	if (p.ev[4]) hipEventRecord(p.ev[4], p.stream);
+	return (int)hipGetLastError();
+}
+
+// strict state-order sums for the decoding kernels above: ((0 + t_0) + t_1) + ... like `p += ...` in aux.c:191-192
+template <> __device__ __forceinline__ double ordered_sum_states<64>(double t0, double)
+{
+	double r[4];
+	rep_rows<1>(t0, r);
+	return seq_sum_rep(r);
+}
+template <> __device__ __forceinline__ double ordered_sum_states<128>(double t0, double t1)
+{
+	double q0[4], q1[4];
+	rep_rows<1>(t0, q0); rep_rows<1>(t1, q1);
+	return seq_sum_rep2(q0, q1);
+}
+
+int launch_post_full(hipStream_t st, const double *a, const double *e, const uint8_t *obs, const double *f, const double *b,
+                     const double *s, int64_t off, int L, int n, int ns, double *post, double *recomb)
+{
+	if (ns == 128)
+		hipLaunchKernelGGL(k_post_full<128>, dim3((L + 63) / 64), dim3(64), 0, st, a, e, obs, f, b, s, off, L, n, post, recomb);
+	else
+		hipLaunchKernelGGL(k_post_full<64>, dim3((L + 63) / 64), dim3(64), 0, st, a, e, obs, f, b, s, off, L, n, post, recomb);
+	return (int)hipGetLastError();
+}
+
+int launch_post_counts(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int min_l,
+                       const int32_t *cnt1, int n_cnt, int n, int ns, double *cnt)
+{
+	if (min_l <= 0 || n_cnt <= 0) return 0;
+	if (ns == 128)
+		hipLaunchKernelGGL(k_post_counts<128>, dim3(n_cnt), dim3(64), 0, st, f, b, s, off, min_l, cnt1, n_cnt, n, cnt);
+	else
+		hipLaunchKernelGGL(k_post_counts<64>, dim3(n_cnt), dim3(64), 0, st, f, b, s, off, min_l, cnt1, n_cnt, n, cnt);
 	return (int)hipGetLastError();
 }
 

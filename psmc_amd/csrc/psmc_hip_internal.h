@@ -107,6 +107,10 @@ void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, 
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,
                        int ns, int32_t *path, double *maxp);
+int launch_post_full(hipStream_t st, const double *a, const double *e, const uint8_t *obs, const double *f, const double *b,
+                     const double *s, int64_t off, int L, int n, int ns, double *post, double *recomb);
+int launch_post_counts(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int min_l,
+                       const int32_t *cnt1, int n_cnt, int n, int ns, double *cnt);
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 int run_microbench(hipStream_t stream, double *d_out);
 int run_pipe_probe(hipStream_t stream, double *d_out, int n_waves, unsigned mask, int rounds);

@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
-    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
+    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
 ]
 
 
@@ -240,6 +240,23 @@ class HipEStep:
         path = np.zeros(L, dtype=np.int32); mp = np.zeros(L)
         self._chk(self.lib.psmc_hip_decode(self.h, int(seg), path.ctypes.data_as(_i32p), _p(mp)), "decode")
         return path, mp
+
+    def posterior(self, seg, want_post=True, want_recomb=True):
+        """(post (L, n), recomb (L,)): full posterior and the DF line's recombination probability (aux.c:183-200), exact mode."""
+        L = int(self.lens[seg])
+        post = np.zeros((L, self.n)) if want_post else None
+        rec = np.zeros(L) if want_recomb else None
+        self.lib.psmc_hip_posterior.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        self._chk(self.lib.psmc_hip_posterior(self.h, int(seg), _p(post), _p(rec)), "posterior")
+        return post, rec
+
+    def post_counts(self, seg, cnt1, cnt):
+        """cnt (n, n_cnt) += posterior-weighted counts of segment `seg` (cnt1: (l, n_cnt) int32), aux.c:202-219; in place."""
+        cnt1 = np.ascontiguousarray(cnt1, dtype=np.int32)
+        assert cnt.dtype == np.float64 and cnt.flags.c_contiguous and cnt.shape == (self.n, cnt1.shape[1])
+        self.lib.psmc_hip_post_counts.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_int32, C.c_int32, _dp]
+        self._chk(self.lib.psmc_hip_post_counts(self.h, int(seg), cnt1.ctypes.data_as(_i32p), cnt1.shape[0], cnt1.shape[1], _p(cnt)), "post_counts")
+        return cnt
 
     def timing(self):
         ms = np.zeros(7)

@@ -53,6 +53,8 @@ static int hb_estep_factored(void *self, const double *a, const double *e, const
 }
 static int hb_tables(void *self, int seg, double *f, double *b, double *s) { return psmc_hip_get_tables(((hip_be *)self)->ctx, seg, f, b, s); }
 static int hb_decode(void *self, int seg, int32_t *path, double *maxp) { return psmc_hip_decode(((hip_be *)self)->ctx, seg, path, maxp); }
+static int hb_posterior(void *self, int seg, double *post, double *recomb) { return psmc_hip_posterior(((hip_be *)self)->ctx, seg, post, recomb); }
+static int hb_post_counts(void *self, int seg, const int32_t *cnt1, int32_t l, int32_t n_cnt, double *cnt) { return psmc_hip_post_counts(((hip_be *)self)->ctx, seg, cnt1, l, n_cnt, cnt); }
 static const char *hb_error(void *self) { return psmc_hip_last_error(((hip_be *)self)->ctx); }
 static void hb_destroy(void *self) { hip_be *h = (hip_be *)self; psmc_hip_destroy(h->ctx); free(h->chk); }
 
@@ -92,7 +94,7 @@ int main(int argc, char *argv[])
 	/* the factored E-step goes with the O(N) objective: fast mode, n <= 64 (PSMC_FACTORED=0 keeps the full counts) */
 	const char *fs = getenv("PSMC_FACTORED");
 	const int use_factored = o.fast_mstep && mode == PSMC_HIP_MODE_FAST && n_states <= 64 && !(fs && atoi(fs) == 0);
-	psmc_estep_backend be = {&h, hb_load, hb_estep, hb_tables, hb_decode, use_factored ? hb_estep_factored : 0, hb_error, hb_destroy};
+	psmc_estep_backend be = {&h, hb_load, hb_estep, hb_tables, hb_decode, use_factored ? hb_estep_factored : 0, hb_error, hb_destroy, hb_posterior, hb_post_counts};
 	int status = psmc_run(&o, &be);
 	be.destroy(be.self);
 	psmc_options_free(&o);

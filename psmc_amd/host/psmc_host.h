@@ -88,7 +88,7 @@ typedef struct psmc_estep_backend {
 	/* em.c:33-55: A n*n, E 2*n (hom, het), LL; returns 0 or an error code */
 	int  (*estep)(void *self, const double *a, const double *e, const double *a0, double *A, double *E, double *LL,
 	              double *chk);
-	/* hd->f, hd->b, hd->s of one segment, L*n / L*n / L (aux.c:157-158) */
+	/* hd->f, hd->b, hd->s of one segment, L*n / L*n / L (aux.c:157-158); any of the three may be NULL */
 	int  (*tables)(void *self, int seg, double *f, double *b, double *s);
 	/* optional (may be NULL): posterior argmax path[L] and its probability maxp[L] (khmm.c:264-281) */
 	int  (*decode)(void *self, int seg, int32_t *path, double *maxp);
@@ -97,6 +97,10 @@ typedef struct psmc_estep_backend {
 	int  (*estep_factored)(void *self, const double *a, const double *e, const double *a0, double *sums, double *E, double *LL);
 	const char *(*error)(void *self);
 	void (*destroy)(void *self);
+	/* optional (may be NULL): full posterior post[L*n] and the DF line's recombination probability recomb[L] (aux.c:183-200) */
+	int  (*posterior)(void *self, int seg, double *post, double *recomb);
+	/* optional (may be NULL): cnt[n*n_cnt] += posterior-weighted counts of one segment's cntcpg record (aux.c:202-219) */
+	int  (*post_counts)(void *self, int seg, const int32_t *cnt1, int32_t l, int32_t n_cnt, double *cnt);
 } psmc_estep_backend;
 
 /* ---- run state + driver (main.c, em.c, aux.c) */

@@ -71,6 +71,27 @@ def to_psmcfa(segs, names=None):
     return '\n'.join(out) + '\n'
 
 
+def cnt_file_bytes(lengths, n_cnt=5, seed=5, short_by=None):
+    """A cntcpg-style count file (utils/cntcpg.c:55-92 of the reference: int32 n_cnt, then per sequence int32 length
+    and length*n_cnt int32 counts) with seeded pseudo-random counts; short_by[i] bins are cut off record i so that the
+    reader's length-mismatch path (aux.c:206-210) is exercised."""
+    rng = np.random.default_rng(seed)
+    out = [np.array([n_cnt], dtype=np.int32).tobytes()]
+    for i, L in enumerate(lengths):
+        l = int(L) - (short_by or {}).get(i, 0)
+        out.append(np.array([l], dtype=np.int32).tobytes())
+        out.append(rng.integers(0, 40, size=(l, n_cnt), dtype=np.int32).tobytes())
+    return b"".join(out)
+
+
+def cli_decode_c_cases(cli, segs):
+    """-c goldens (psmc_decode's CT lines, aux.c:202-231): counts alone, and together with -d."""
+    with open(os.path.join(cli, "small.cnt"), "wb") as fh:
+        fh.write(cnt_file_bytes([len(segs[8]), len(segs[9]), len(segs[3])], short_by={1: 7}))
+    return {"small_decode_c": ["-N1", "-c", "small.cnt", "small.psmcfa"],
+            "small_decode_dc": ["-N1", "-d", "-c", "small.cnt", "small.psmcfa"]}
+
+
 def run_ref(args, cwd):
     r = subprocess.run([orc.REF_BIN] + args, cwd=cwd, capture_output=True, text=True, check=True)
     return r.stdout, r.stderr
@@ -154,6 +175,7 @@ def main():
         "small_decode_s": ["-N1", "-s", "small.psmcfa"],
         "small_T": ["-N2", "-T", "0.5", "small.psmcfa"],
     }
+    runs.update(cli_decode_c_cases(cli, segs))
     for name, args in runs.items():
         out, err = run_ref(args, cli)
         if len(out) > 65536:   # the -D dump is large: keep it gzipped

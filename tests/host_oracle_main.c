@@ -60,8 +60,9 @@ static int ob_tables(void *self, int seg, double *f, double *b, double *s)
 	orc_pre_backward(n, o->a, o->e, ae);
 	orc_forward(n, o->a, o->e, o->a0, L, o->sym[seg], ff, ss);
 	orc_backward(n, ae, o->e, o->a0, L, o->sym[seg], ss, bb);
-	memcpy(f, ff + n, sizeof(double) * (size_t)L * n); memcpy(b, bb + n, sizeof(double) * (size_t)L * n);
-	memcpy(s, ss + 1, sizeof(double) * (size_t)L);
+	if (f) memcpy(f, ff + n, sizeof(double) * (size_t)L * n);
+	if (b) memcpy(b, bb + n, sizeof(double) * (size_t)L * n);
+	if (s) memcpy(s, ss + 1, sizeof(double) * (size_t)L);
 	free(ae); free(ff); free(bb); free(ss);
 	return 0;
 }
@@ -83,6 +84,6 @@ int main(int argc, char **argv)
 	ob.n = pat.n_states;
 	ob.a = (double *)malloc(sizeof(double) * ob.n * ob.n); ob.e = (double *)malloc(sizeof(double) * 3 * ob.n); ob.a0 = (double *)malloc(sizeof(double) * ob.n);
 	const int fac = o.fast_mstep && getenv("PSMC_FACTORED") && atoi(getenv("PSMC_FACTORED")) != 0;
-	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, 0, fac ? ob_estep_factored : 0, ob_error, ob_destroy};
+	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, 0, fac ? ob_estep_factored : 0, ob_error, ob_destroy, 0, 0};
 	return psmc_run(&o, &be);
 }

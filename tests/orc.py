@@ -111,6 +111,23 @@ class Oracle(_Lib):
                                  path.ctypes.data_as(c_i32p), _dp(mp))
         return path, mp
 
+    def post_full(self, a, e, seg, f, b, s):
+        """post ((L+1, n)), recomb (L+1,) of aux.c:183-200; row / entry 0 unused."""
+        L, n = f.shape[0] - 1, f.shape[1]
+        seg = np.ascontiguousarray(seg, dtype=np.uint8)
+        post = np.zeros((L + 1, n)); rec = np.zeros(L + 1)
+        self.lib.orc_post_full(C.c_int(n), _dp(np.ascontiguousarray(a)), _dp(np.ascontiguousarray(e)), C.c_int(L),
+                               seg.ctypes.data_as(c_u8p), _dp(f), _dp(b), _dp(s), _dp(post), _dp(rec))
+        return post, rec
+
+    def post_counts(self, f, b, s, cnt1, cnt):
+        """cnt (n, n_cnt) += posterior-weighted counts (aux.c:202-219); in place."""
+        L, n = f.shape[0] - 1, f.shape[1]
+        cnt1 = np.ascontiguousarray(cnt1, dtype=np.int32)
+        self.lib.orc_post_counts(C.c_int(n), C.c_int(L), _dp(f), _dp(b), _dp(s), cnt1.ctypes.data_as(c_i32p),
+                                 C.c_int32(cnt1.shape[0]), C.c_int32(cnt1.shape[1]), _dp(cnt))
+        return cnt
+
     def Q0(self, A, E):
         self.lib.orc_Q0.restype = C.c_double
         return self.lib.orc_Q0(C.c_int(A.shape[0]), _dp(np.ascontiguousarray(A)),

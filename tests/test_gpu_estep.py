@@ -185,6 +185,44 @@ def test_exact_device_decode(hip, golden, oracle):
         es.close()
 
 
+@pytest.mark.parametrize("key", ["n64_curve", "n23_flat", "n128_curve"])
+def test_exact_device_posterior_and_counts(hip, golden, oracle, key):
+    """psmc_hip_posterior / psmc_hip_post_counts: the -D and -c branches of psmc_decode (aux.c:183-231) on the resident
+    tables, bit for bit against the oracle (same products left to right, sums in state / position order); running
+    count totals carried across segments, a count record shorter and one longer than its segment."""
+    if key == "n128_curve":
+        g = golden.n128
+        a, e, a0 = g[key + ".a"], g[key + ".e"], g[key + ".a0"]
+    else:
+        p = golden.params(key)
+        a, e, a0 = p["a"], p["e"], p["a0"]
+    n = a.shape[0]
+    segs = golden.segs_small
+    es = hip.HipEStep(n, mode=hip.MODE_EXACT)
+    es.load_segments(segs)
+    es.estep(a, e, a0)
+    rng = np.random.default_rng(9)
+    cnt_dev = np.zeros((n, 5)); cnt_orc = np.zeros((n, 5))
+    for seg in (0, 1, 3, 5, 8, 9, 11, 12):
+        L = len(segs[seg])
+        f, b, s, lk, chk = oracle.fwd_bwd(a, e, a0, segs[seg])
+        post, rec = oracle.post_full(a, e, segs[seg], f, b, s)
+        gp, gr = es.posterior(seg)
+        assert bits_equal(gp, post[1:]) and bits_equal(gr, rec[1:]), seg
+        gp2, _ = es.posterior(seg, want_recomb=False)
+        _, gr2 = es.posterior(seg, want_post=False)
+        assert bits_equal(gp2, gp) and bits_equal(gr2, gr)
+        l1 = max(0, L + (-3 if seg == 9 else 5 if seg == 8 else 0))
+        c1 = rng.integers(0, 50, size=(l1, 5), dtype=np.int32)
+        oracle.post_counts(f, b, s, c1, cnt_orc)
+        es.post_counts(seg, c1, cnt_dev)
+        assert bits_equal(cnt_dev, cnt_orc), seg
+    ft, bt, st = es.tables(5)
+    f2, b2, s2 = es.tables(5, want_b=False)
+    assert b2 is None and bits_equal(f2, ft) and bits_equal(s2, st)
+    es.close()
+
+
 def test_errors(hip):
     es = hip.HipEStep(8, mode=hip.MODE_EXACT)
     a, e, a0 = random_hmm(np.random.default_rng(0), 8)

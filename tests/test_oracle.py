@@ -94,3 +94,35 @@ def test_oracle_vs_reference_random(reference, oracle):
         rr = reference.estep(a, e, a0, segs, per_seg=True)
         for k in ro:
             assert bits_equal(np.asarray(ro[k]), np.asarray(rr[k])), (n, k)
+
+
+def test_oracle_decode_branches_match_plain_restatement(oracle, golden):
+    """orc_post_full / orc_post_counts (aux.c:183-231) against a loop-for-loop Python restatement (IEEE doubles, no
+    FMA, same order) on a 65-bin segment; the CLI goldens small_decode_D / small_decode_c pin the same code against the
+    reference binary's printed output (tests/test_host_cli.py)."""
+    p = golden.params("n23_flat")
+    a, e, a0 = p["a"], p["e"], p["a0"]
+    seg = golden.segs_small[5]
+    f, b, s, lk, chk = oracle.fwd_bwd(a, e, a0, seg)
+    post, rec = oracle.post_full(a, e, seg, f, b, s)
+    L, n = len(seg), a.shape[0]
+    rng = np.random.default_rng(3)
+    c1 = rng.integers(0, 30, size=(L - 2, 3), dtype=np.int32)
+    cnt = np.zeros((n, 3)); want = [[0.0] * 3 for _ in range(n)]
+    oracle.post_counts(f, b, s, c1, cnt)
+    for k in range(1, L + 1):
+        if k < L:
+            pr = 0.0
+            for l in range(n):
+                pr += float(f[k][l]) * float(a[l][l]) * float(b[k + 1][l]) * float(e[seg[k]][l])
+            pr = 1.0 - pr
+        else:
+            pr = 0.0
+        assert pr == rec[k]
+        for l in range(n):
+            q = float(f[k][l]) * float(b[k][l]) * float(s[k])
+            assert q == post[k][l]
+            if k <= L - 2:
+                for j in range(3):
+                    want[l][j] += q * int(c1[k - 1][j])
+    assert np.array_equal(cnt, np.array(want))

@@ -255,8 +255,10 @@ FULL = os.path.join(ROOT, "tests", "golden", "full")
 # Stated end-to-end tolerance of PSMC_HIP_MODE=fast against the reference over 25 EM rounds (DESIGN.md section 3,
 # profiles/r02_em_parity.json): the statistics agree to 1e-10, but the Hooke-Jeeves search is driven by `<` between
 # nearly equal Q values, so the reference itself only reproduces lambda_k to ~1e-4 across compiler flags
-# (SURVEY.md section 7.1).  Bounds on the worst round of the run, relative:
-EM_TOL = {"LK": 1e-8, "theta": 2e-5, "rho": 2e-5, "lam": 1e-4}
+# (SURVEY.md section 7.1).  Measured on this input, three fast configurations: LK <= 3.9e-9, theta/rho <= 6.1e-6,
+# lambda_k <= 8.0e-5 in the worst round.  Bounds, relative: every round / the final round (what RS lines users plot).
+EM_TOL = {"LK": 1e-8, "theta": 2e-5, "rho": 2e-5, "lam": 2e-4}
+EM_TOL_FINAL_LAMBDA = 1e-4
 
 
 def _rounds(text):
@@ -294,10 +296,15 @@ def test_config2_full_size_fast_mode_bound(env):
     assert len(got) == len(want) == 26
     worst = dict(LK=0.0, theta=0.0, rho=0.0, lam=0.0)
     for g, w in zip(got, want):
-        worst["LK"] = max(worst["LK"], abs(g["LK"] - w["LK"]) / abs(w["LK"]))
+        worst["LK"] = max(worst["LK"], abs(g["LK"] - w["LK"]) / max(abs(w["LK"]), 1.0))   # RD 0 prints LK 0
         worst["theta"] = max(worst["theta"], abs(g["theta"] - w["theta"]) / w["theta"])
         worst["rho"] = max(worst["rho"], abs(g["rho"] - w["rho"]) / w["rho"])
         worst["lam"] = max(worst["lam"], max(abs(x - y) / y for x, y in zip(g["lam"], w["lam"])))
         assert len(g["rs_lam"]) == 64
     for k, tol in EM_TOL.items():
         assert worst[k] <= tol, (k, worst)
+    final = max(abs(x - y) / y for x, y in zip(got[-1]["lam"], want[-1]["lam"]))
+    assert final <= EM_TOL_FINAL_LAMBDA, final
+    # the RS lines themselves (6 decimals): lambda_k column of the last round
+    for x, y in zip(got[-1]["rs_lam"], want[-1]["rs_lam"]):
+        assert abs(x - y) <= EM_TOL_FINAL_LAMBDA * y + 1e-6

@@ -68,7 +68,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B),
  * "lanes8" (1: the bulk forward sweep and the backward warm-up of 64-state models run eight tiles per wave, 8 lanes x
  * 8 states, instead of four; fewer instructions per step, half the waves; default 0), "exact_lds" (exact mode, up
- * to 64 states: 1 = operands of the ordered sums broadcast through LDS instead of DPP rows; bit-identical, slower; default 0). */
+ * to 64 states: 1 = operands of the ordered sums broadcast through LDS instead of DPP rows; bit-identical, slower; default 0),
+ * "batch_bins" (psmc_hip_estep_batch, exact mode: table bins per launch group; 0, default: what fits the free device memory).
+ * Setting any option drops the per-replicate plans a fast-mode batch has learned. */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
@@ -90,6 +92,23 @@ int psmc_hip_select(psmc_hip_ctx *ctx, int n_sel, const int32_t *seg_idx);
  *   chk      n_sel values of the khmm.c:237-238 underflow check (may be NULL) */
 int psmc_hip_estep(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, double *A, double *E,
                    double *A0, double *LL, double *chk);
+
+/* Config 4 (bootstrap): n_rep E-steps over ONE loaded segment set in a single call -- replicate r has its own
+ * parameters a[r] (n*n), e[r] (2*n), a0[r] (n) and its own multiset sel_idx[sel_off[r] .. sel_off[r+1]) of loaded
+ * segments (psmc_resamp, aux.c:8-47: repeats allowed, order matters for the exact sum).  Replaces n_rep runs of
+ * em.c:33-55, i.e. what README:57-62 of the reference farms out with xargs.  Outputs, any may be NULL but one of
+ * A / sums is needed: A n_rep*n*n, sums n_rep*5n (SL|SU|DG|CL|CU as psmc_hip_estep_factored), E n_rep*2n, LL n_rep.
+ *   exact mode: the sweeps of all replicates that fit the table memory run in ONE grid per kernel (replicate-major;
+ *     one wave per (replicate, unique segment)), so the device holds hundreds of sweeps instead of one replicate's
+ *     dozens; results are bit-identical to n_rep separate psmc_hip_select + psmc_hip_estep calls.  "batch_bins"
+ *     (psmc_hip_set_option) caps the table bins per group; default: what fits the free memory.
+ *   fast mode: one replicate fills the device, so they run back to back, each on its own learned tile plan (kept in
+ *     a per-replicate child context that shares this context's observations and tables); sums = factored statistics.
+ * Segment tables are in batch layout afterwards: decode / get_tables need a single E-step first. */
+int psmc_hip_estep_batch(psmc_hip_ctx *ctx, int n_rep, const double *a, const double *e, const double *a0,
+                         const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL);
+/* Diagnostic: out = {launch groups of the last exact batch (fast: replicates run), replicate contexts alive}. */
+int psmc_hip_batch_info(psmc_hip_ctx *ctx, int out[2]);
 
 /* Exact mode, for multi-process sharding: per selected segment the reference's
  * own `he` (em.c:49) and hmm_lk, so that the caller can add them in the global

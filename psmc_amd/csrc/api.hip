@@ -77,7 +77,7 @@ struct psmc_hip_ctx {
 	int64_t tab_bins = 0; bool have_b = false;
 	// exact outputs
 	double *d_segA = nullptr, *d_segE = nullptr, *d_segA0 = nullptr, *d_chk = nullptr;
-	int seg_cap = 0, chk_cap = 0;
+	int seg_cap = 0;
 	std::vector<double> h_segA, h_segE, h_segA0, h_chk, h_s;
 	// fast
 	std::vector<Chunk> chunks;
@@ -102,6 +102,16 @@ struct psmc_hip_ctx {
 	hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	double last_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 	bool timing_valid = false;
+	// batch (psmc_hip_estep_batch)
+	int64_t batch_bins = 0;            // "batch_bins": table bins per launch group of the exact batch (0 = from free memory)
+	int32_t *d_bw_seg = nullptr, *d_bw_par = nullptr; int64_t *d_bw_tab = nullptr; size_t bw_cap = 0; // work list of a group
+	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_par][PAR_LEN] parameter blocks of a group
+	int last_batch_groups = 0;
+	bool tables_batch = false;         // the tables hold the slots of a batch group, not the segments at their own offsets
+	// fast batch: one plan-holding child per replicate; children share the parent's streams, events, parameter
+	// staging, observations and TABLES (they run one after the other)
+	psmc_hip_ctx *parent = nullptr;
+	std::vector<psmc_hip_ctx *> kids;
 };
 
 static int fail(psmc_hip_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -132,6 +142,8 @@ template <class T> static int dev_alloc(psmc_hip_ctx *c, T **p, size_t n)
 // kernel then waits for an unrelated one.  Ask for 8 before the runtime starts (no effect, and no harm,
 // if the host program initialised HIP earlier or set the variable itself).
 __attribute__((constructor)) static void psmc_hip_more_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+static void destroy_kids(psmc_hip_ctx *c);
 
 extern "C" int psmc_hip_device_count(void)
 {
@@ -186,10 +198,26 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	return PSMC_HIP_OK;
 }
 
+static void destroy_kids(psmc_hip_ctx *c)
+{
+	for (psmc_hip_ctx *k : c->kids) psmc_hip_destroy(k);
+	c->kids.clear();
+}
+
 extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
+	destroy_kids(c);
+	if (c->parent) { // a batch child owns its plan only: streams, events, staging, observations and tables are the parent's
+		void *mine[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
+		                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_items, c->d_ftiles, c->d_Kcol};
+		for (void *p : mine) if (p) (void)hipFree(p);
+		if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+		if (c->h_ritems) (void)hipHostFree(c->h_ritems);
+		delete c;
+		return;
+	}
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if (c->stream3) (void)hipStreamSynchronize(c->stream3);
@@ -198,7 +226,8 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol};
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol,
+	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -217,6 +246,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 {
 	if (!c || !key) return PSMC_HIP_EINVAL;
 	std::string k(key);
+	destroy_kids(c); // replicate contexts of a batch copied the options when they were made: start them afresh
 	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
 	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
 	else if (k == "max_rounds") c->max_rounds = (int)v;
@@ -233,6 +263,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
+	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
@@ -245,6 +276,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 
 static int set_segments_common(psmc_hip_ctx *c, int n_seg, const int32_t *L)
 {
+	destroy_kids(c); // batch children hold plans over the previous segments
 	c->n_seg = n_seg;
 	c->L.assign(L, L + n_seg);
 	int rc;
@@ -350,12 +382,12 @@ static bool factor_structure(int n, int S, const double *a /* stride S */, doubl
 
 // pad the HMM parameters to 64 states and build aeT[b][l*64+k] = e[b][l]*a[k][l]
 // (hmm_pre_backward, khmm.c:194-206: one rounding per product), then upload.
-static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, hipStream_t st)
+// host part: one parameter block (PAR_LEN doubles) at dst; returns whether the matrix has the PSMC form (fast mode)
+static bool fill_params(const psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *dst)
 {
 	const int n = c->n;
 	if (c->ns == 128) { // a | aT | e(3) | a0, stride 128; the e*a products are formed on the device
-		double *pa = c->h_par, *pt = pa + 16384, *pe = pt + 16384, *pa0 = pe + 384;
-		HIPCHK(c, hipStreamSynchronize(st));
+		double *pa = dst, *pt = pa + 16384, *pe = pt + 16384, *pa0 = pe + 384;
 		memset(pa, 0, psmc_hip_ctx::PAR_LEN * sizeof(double));
 		for (int k = 0; k < n; ++k) {
 			for (int l = 0; l < n; ++l) { pa[k * 128 + l] = a[k * n + l]; pt[l * 128 + k] = a[k * n + l]; }
@@ -366,13 +398,11 @@ static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const
 		if (c->mode == PSMC_HIP_MODE_FAST) {
 			double *pre = pa + psmc_hip_ctx::RE128_OFF;
 			for (int i = 0; i < 384; ++i) pre[i] = pe[i] > 0.0 ? 1.0 / pe[i] : 0.0;
-			c->use_struct = c->struct_opt && factor_structure(n, 128, pa, pa + psmc_hip_ctx::SP128_OFF);
+			return c->struct_opt && factor_structure(n, 128, pa, pa + psmc_hip_ctx::SP128_OFF);
 		}
-		HIPCHK(c, hipMemcpyAsync(c->d_par, pa, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
-		return 0;
+		return false;
 	}
-	double *pa = c->h_par, *pae = pa + 4096, *pe = pae + 3 * 4096, *pa0 = pe + 3 * 64, *pre = pa0 + 64;
-	HIPCHK(c, hipStreamSynchronize(st)); // previous async copy out of the pinned staging buffer
+	double *pa = dst, *pae = pa + 4096, *pe = pae + 3 * 4096, *pa0 = pe + 3 * 64, *pre = pa0 + 64;
 	memset(pa, 0, psmc_hip_ctx::PAR_LEN * sizeof(double));
 	for (int k = 0; k < n; ++k) {
 		for (int l = 0; l < n; ++l) pa[k * 64 + l] = a[k * n + l];
@@ -384,14 +414,26 @@ static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const
 	for (int b = 0; b < 3; ++b)
 		for (int l = 0; l < 64; ++l)
 			for (int k = 0; k < 64; ++k) pae[b * 4096 + l * 64 + k] = pe[b * 64 + l] * pa[k * 64 + l];
-	c->use_struct = c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, 64, pa, pa + psmc_hip_ctx::SP_OFF);
-	HIPCHK(c, hipMemcpyAsync(c->d_par, pa, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
+	return c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, 64, pa, pa + psmc_hip_ctx::SP_OFF);
+}
+
+static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, hipStream_t st)
+{
+	HIPCHK(c, hipStreamSynchronize(st)); // previous async copy out of the pinned staging buffer
+	c->use_struct = fill_params(c, a, e, a0, c->h_par);
+	HIPCHK(c, hipMemcpyAsync(c->d_par, c->h_par, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
 	return 0;
 }
 
-static int ensure_tables(psmc_hip_ctx *c, bool need_b)
+static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0)
 {
-	const int64_t bins = c->total + 128;
+	if (c->parent) { // a batch child works in its parent's tables (same segments, one E-step at a time)
+		int rc = ensure_tables(c->parent, need_b);
+		c->d_f = c->parent->d_f; c->d_b = c->parent->d_b; c->d_s = c->parent->d_s; c->d_sb = c->parent->d_sb;
+		c->tab_bins = c->parent->tab_bins; c->have_b = c->parent->have_b;
+		return rc;
+	}
+	const int64_t bins = std::max(c->total, want_bins) + 128;
 	if (c->tab_bins < bins) {
 		int rc;
 		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * c->ns))) return rc;
@@ -409,14 +451,15 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b)
 	return 0;
 }
 
-static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
+static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const double *par_base = nullptr)
 {
 	memset(&p, 0, sizeof(p));
 	p.stream = st;
 	p.rep_impl = c->rep_impl; p.expect_impl = c->expect_impl; p.n_states = c->n;
-	p.d_a = c->d_par; p.d_aeT = c->d_par + 4096; p.d_e = c->d_par + 4 * 4096; p.d_a0 = c->d_par + 4 * 4096 + 192;
-	p.d_re = c->d_par + 4 * 4096 + 192 + 64;
-	p.d_sp = c->d_par + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
+	const double *pb = par_base ? par_base : c->d_par; // parameter block (batch: the first of the group's blocks)
+	p.d_a = pb; p.d_aeT = pb + 4096; p.d_e = pb + 4 * 4096; p.d_a0 = pb + 4 * 4096 + 192;
+	p.d_re = pb + 4 * 4096 + 192 + 64;
+	p.d_sp = pb + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
@@ -424,8 +467,8 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st)
 	p.walk_impl = c->walk_impl;
 	p.ns = c->ns;
 	if (c->ns == 128) {
-		p.d_aeT = c->d_par + 16384; p.d_e = c->d_par + 32768; p.d_a0 = c->d_par + 32768 + 384;
-		p.d_re = c->d_par + psmc_hip_ctx::RE128_OFF; p.d_sp = c->d_par + psmc_hip_ctx::SP128_OFF;
+		p.d_aeT = pb + 16384; p.d_e = pb + 32768; p.d_a0 = pb + 32768 + 384;
+		p.d_re = pb + psmc_hip_ctx::RE128_OFF; p.d_sp = pb + psmc_hip_ctx::SP128_OFF;
 	}
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
@@ -472,6 +515,20 @@ static double host_lk(const double *s, int L)
 }
 
 // ---------------------------------------------------------------- exact mode
+// per-entry outputs of the exact kernels: he->A, he->E, he->A0 and the underflow check value, one slot per work item
+static int ensure_seg_outputs(psmc_hip_ctx *c, int nw)
+{
+	if (c->seg_cap >= nw) return 0;
+	const size_t S = (size_t)c->ns;
+	int rc;
+	if ((rc = dev_alloc(c, &c->d_segA, (size_t)nw * S * S))) return rc;
+	if ((rc = dev_alloc(c, &c->d_segE, (size_t)nw * 3 * S))) return rc;
+	if ((rc = dev_alloc(c, &c->d_segA0, (size_t)nw * S))) return rc;
+	if ((rc = dev_alloc(c, &c->d_chk, (size_t)nw))) return rc;
+	c->seg_cap = nw;
+	return 0;
+}
+
 static int run_exact(psmc_hip_ctx *c, const double *a, const double *e, const double *a0)
 {
 	HIPCHK(c, hipSetDevice(c->device));
@@ -480,27 +537,19 @@ static int run_exact(psmc_hip_ctx *c, const double *a, const double *e, const do
 	if ((rc = ensure_tables(c, true))) return rc;
 	const int nw = (int)c->work.size();
 	const size_t S = (size_t)c->ns;
-	if (c->seg_cap < nw) {
-		if ((rc = dev_alloc(c, &c->d_segA, (size_t)nw * S * S))) return rc;
-		if ((rc = dev_alloc(c, &c->d_segE, (size_t)nw * 3 * S))) return rc;
-		if ((rc = dev_alloc(c, &c->d_segA0, (size_t)nw * S))) return rc;
-		c->seg_cap = nw;
-	}
-	if (c->chk_cap < c->n_seg) { // indexed by segment id, not by work item: its own capacity
-		if ((rc = dev_alloc(c, &c->d_chk, (size_t)c->n_seg))) return rc;
-		c->chk_cap = c->n_seg;
-	}
+	if ((rc = ensure_seg_outputs(c, nw))) return rc;
 	if ((rc = stage_params(c, a, e, a0, c->stream))) return rc;
+	c->tables_batch = false;
 	EstepLaunch p;
 	fill_common(c, p, c->stream);
 	p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
 	if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact", hipGetLastError());
 	c->h_segA.resize((size_t)nw * S * S); c->h_segE.resize((size_t)nw * 3 * S); c->h_segA0.resize((size_t)nw * S);
-	c->h_chk.resize(c->n_seg); c->h_s.resize((size_t)c->total);
+	c->h_chk.resize(nw); c->h_s.resize((size_t)c->total);
 	HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->h_segA0.data(), c->d_segA0, sizeof(double) * nw * S, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipMemcpyAsync(c->h_chk.data(), c->d_chk, sizeof(double) * c->n_seg, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_chk.data(), c->d_chk, sizeof(double) * nw, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->h_s.data(), c->d_s, sizeof(double) * c->total, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	collect_timing(c);
@@ -526,7 +575,7 @@ extern "C" int psmc_hip_estep_segments(psmc_hip_ctx *c, const double *a, const d
 				memcpy(segE + ((size_t)i * 3 + b) * n, &c->h_segE[(size_t)w * 3 * S + b * S], sizeof(double) * n);
 		if (segA0) memcpy(segA0 + (size_t)i * n, &c->h_segA0[(size_t)w * S], sizeof(double) * n);
 		if (segLL) segLL[i] = host_lk(&c->h_s[(size_t)c->off[seg]], c->L[seg]);
-		if (chk) chk[i] = c->h_chk[seg];
+		if (chk) chk[i] = c->h_chk[w];
 	}
 	return PSMC_HIP_OK;
 }
@@ -553,7 +602,7 @@ static int estep_exact(psmc_hip_ctx *c, const double *a, const double *e, const 
 		}
 		for (int b = 0; b < 2; ++b)
 			for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * S + l];
-		if (chk) chk[i] = c->h_chk[c->sel[i]];
+		if (chk) chk[i] = c->h_chk[w];
 	}
 	if (A) memcpy(A, sA.data(), sizeof(double) * n * n);
 	if (E) memcpy(E, sE.data(), sizeof(double) * 2 * n);
@@ -790,6 +839,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep: no segments loaded");
 	int rc;
 	if ((rc = ensure_tables(c, false))) return rc;
+	c->tables_batch = false;
 	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
 	// the backward table: only for the unfused back half (the fused and the factored one never store bt)
 	if (!c->want_factored && !(c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) && (rc = ensure_tables(c, true))) return rc;
@@ -934,10 +984,208 @@ extern "C" int psmc_hip_estep(psmc_hip_ctx *c, const double *a, const double *e,
 	return estep_fast(c, a, e, a0, A, E, A0, LL, chk);
 }
 
+// ---------------------------------------------------------------- batch (bootstrap replicates)
+namespace {
+struct RepSel { std::vector<int32_t> work, sel2work; int64_t bins = 0; }; // unique segments in order of first appearance
+}
+
+static int batch_selections(psmc_hip_ctx *c, int n_rep, const int32_t *sel_off, const int32_t *sel_idx, std::vector<RepSel> &reps)
+{
+	std::vector<int32_t> pos(c->n_seg);
+	reps.assign(n_rep, RepSel());
+	for (int r = 0; r < n_rep; ++r) {
+		const int n_sel = sel_off[r + 1] - sel_off[r];
+		if (n_sel < 1) return fail(c, PSMC_HIP_EINVAL, "estep_batch: empty selection");
+		std::fill(pos.begin(), pos.end(), -1);
+		RepSel &R = reps[r];
+		R.sel2work.resize(n_sel);
+		for (int i = 0; i < n_sel; ++i) {
+			const int32_t sg = sel_idx[sel_off[r] + i];
+			if (sg < 0 || sg >= c->n_seg) return fail(c, PSMC_HIP_EINVAL, "estep_batch: index out of range");
+			if (pos[sg] < 0) { pos[sg] = (int32_t)R.work.size(); R.work.push_back(sg); R.bins += ((int64_t)c->L[sg] + 63) & ~(int64_t)63; }
+			R.sel2work[i] = pos[sg];
+		}
+	}
+	return 0;
+}
+
+// Exact mode: the sweeps of ALL replicates of a group in one launch each (forward, backward, expect), replicate-major;
+// every (replicate, unique segment) entry has its own table slot and reads its replicate's parameter block.  Groups =
+// as many consecutive replicates as fit the table memory.  Statistics are added per replicate in selection order on
+// the host, exactly like psmc_hip_estep: bit-identical to n_rep separate calls.
+static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0, const int32_t *sel_off,
+                       const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+{
+	const int n = c->n;
+	const size_t S = (size_t)c->ns, PL = psmc_hip_ctx::PAR_LEN;
+	std::vector<RepSel> reps;
+	int rc;
+	if ((rc = batch_selections(c, n_rep, sel_off, sel_idx, reps))) return rc;
+	// how many table bins fit: what is free now plus what the context already holds
+	int64_t cap = c->batch_bins;
+	if (cap <= 0) {
+		size_t fr = 0, tot = 0;
+		HIPCHK(c, hipMemGetInfo(&fr, &tot));
+		const double per_bin = (double)S * 8.0 * 2.0 + 8.0;
+		const double held = (double)c->tab_bins * ((double)S * 8.0 * (c->have_b ? 2.0 : 1.0) + 8.0);
+		cap = (int64_t)(((double)fr * 0.9 + held) / per_bin) - 256;
+	}
+	size_t n_entries_all = 0;
+	for (const RepSel &R : reps) n_entries_all += R.work.size();
+	const int align = c->ns == 128 ? (n_entries_all <= 256 ? 1 : (n_entries_all <= 512 ? 2 : 4)) : 4; // sweeps per block sharing one parameter set in LDS
+	c->last_batch_groups = 0;
+	std::vector<int32_t> wseg, wpar; std::vector<int64_t> wtab; std::vector<int> first;
+	std::vector<double> hp, lk;
+	for (int r0 = 0; r0 < n_rep;) {
+		if (reps[r0].bins > cap) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: the tables of one replicate do not fit the device memory (batch_bins)");
+		int r1 = r0; int64_t bins = 0;
+		while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ++r1; }
+		const int ng = r1 - r0;
+		wseg.clear(); wpar.clear(); wtab.clear(); first.assign(ng, 0);
+		int64_t run = 0;
+		for (int r = r0; r < r1; ++r) {
+			first[r - r0] = (int)wseg.size();
+			for (int32_t sg : reps[r].work) { wseg.push_back(sg); wpar.push_back(r - r0); wtab.push_back(run); run += ((int64_t)c->L[sg] + 63) & ~(int64_t)63; }
+			while (wseg.size() % align) { wseg.push_back(-1); wpar.push_back(r - r0); wtab.push_back(0); }
+		}
+		const int nw = (int)wseg.size();
+		if ((rc = ensure_tables(c, true, run))) return rc;
+		if ((rc = ensure_seg_outputs(c, nw))) return rc;
+		if (c->bw_cap < (size_t)nw) {
+			if ((rc = dev_alloc(c, &c->d_bw_seg, (size_t)nw))) return rc;
+			if ((rc = dev_alloc(c, &c->d_bw_par, (size_t)nw))) return rc;
+			if ((rc = dev_alloc(c, &c->d_bw_tab, (size_t)nw))) return rc;
+			c->bw_cap = (size_t)nw;
+		}
+		if (c->bpar_cap < (size_t)ng) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)ng * PL))) return rc; c->bpar_cap = (size_t)ng; }
+		hp.resize((size_t)ng * PL);
+		for (int r = r0; r < r1; ++r) (void)fill_params(c, a + (size_t)r * n * n, e + (size_t)r * 2 * n, a0 + (size_t)r * n, hp.data() + (size_t)(r - r0) * PL);
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipMemcpy(c->d_bw_seg, wseg.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_bw_par, wpar.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_bw_tab, wtab.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_bpar, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+		c->tables_batch = true;
+		EstepLaunch p;
+		fill_common(c, p, c->stream, c->d_bpar);
+		p.d_work = c->d_bw_seg; p.n_work = nw; p.d_work_par = c->d_bw_par; p.d_work_tab = c->d_bw_tab; p.par_stride = (int64_t)PL; p.work_align = align;
+		p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
+		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch)", hipGetLastError());
+		c->h_segA.resize((size_t)nw * S * S); c->h_segE.resize((size_t)nw * 3 * S); c->h_s.resize((size_t)run);
+		HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->h_s.data(), c->d_s, sizeof(double) * (size_t)run, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		collect_timing(c);
+		// hmm_add_expect in selection order per replicate (khmm.c:346-359), he_sum starting from zeros; LL += hmm_lk (em.c:48)
+		std::vector<double> sA((size_t)n * n), sE((size_t)2 * n);
+		for (int r = r0; r < r1; ++r) {
+			const RepSel &R = reps[r];
+			const int f0 = first[r - r0];
+			lk.resize(R.work.size());
+			for (size_t j = 0; j < R.work.size(); ++j) lk[j] = host_lk(&c->h_s[(size_t)wtab[f0 + j]], c->L[R.work[j]]);
+			std::fill(sA.begin(), sA.end(), 0.0); std::fill(sE.begin(), sE.end(), 0.0);
+			double ll = 0.0;
+			for (size_t i = 0; i < R.sel2work.size(); ++i) {
+				const int w = f0 + R.sel2work[i];
+				const double *hA = &c->h_segA[(size_t)w * S * S], *hE = &c->h_segE[(size_t)w * 3 * S];
+				ll += lk[R.sel2work[i]];
+				for (int k = 0; k < n; ++k)
+					for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * S + l];
+				for (int b = 0; b < 2; ++b)
+					for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * S + l];
+			}
+			if (A) memcpy(A + (size_t)r * n * n, sA.data(), sizeof(double) * n * n);
+			if (E) memcpy(E + (size_t)r * 2 * n, sE.data(), sizeof(double) * 2 * n);
+			if (LL) LL[r] = ll;
+			if (sums) { // SL | SU | DG | CL | CU of the summed matrix, for callers with the O(N) objective
+				double *q = sums + (size_t)r * 5 * n;
+				memset(q, 0, sizeof(double) * 5 * n);
+				for (int k = 0; k < n; ++k)
+					for (int l = 0; l < n; ++l) {
+						const double v = sA[(size_t)k * n + l];
+						if (l < k) { q[k] += v; q[3 * n + l] += v; } else if (l > k) { q[n + k] += v; q[4 * n + l] += v; } else q[2 * n + k] = v;
+					}
+			}
+		}
+		++c->last_batch_groups;
+		r0 = r1;
+	}
+	return PSMC_HIP_OK;
+}
+
+// Fast mode: a single replicate already fills the device, so the replicates run one after the other -- but each
+// keeps ITS OWN tile plan (tiling of its selection, learned glued runs, transfer-matrix lists) in a child context,
+// so nothing is re-planned or re-learned from one EM iteration to the next.  Children share the parent's tables.
+static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
+{
+	while ((int)c->kids.size() <= r) {
+		psmc_hip_ctx *k = new (std::nothrow) psmc_hip_ctx();
+		if (!k) return nullptr;
+		k->n = c->n; k->ns = c->ns; k->device = c->device; k->mode = c->mode; k->parent = c;
+		k->chunk = c->chunk; k->warmup = c->warmup; k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
+		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
+		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->lanes8 = c->lanes8;
+		k->fuse_order = c->fuse_order; k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
+		k->learn = c->learn; k->group_cap = c->group_cap;
+		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
+		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
+		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];
+		k->h_par = c->h_par; k->d_par = c->d_par;
+		c->kids.push_back(k);
+		// same segments, same offsets, the parent's copy of the observations
+		k->d_obs = c->d_obs; k->obs_borrowed = true; k->off = c->off; k->total = c->total;
+		if (set_segments_common(k, c->n_seg, c->L.data()) != 0) return nullptr;
+	}
+	return c->kids[r];
+}
+
+static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0, const int32_t *sel_off,
+                      const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+{
+	const int n = c->n;
+	for (int r = 0; r < n_rep; ++r) {
+		psmc_hip_ctx *k = batch_child(c, r);
+		if (!k) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: cannot create the replicate context");
+		const int n_sel = sel_off[r + 1] - sel_off[r];
+		if (n_sel < 1) return fail(c, PSMC_HIP_EINVAL, "estep_batch: empty selection");
+		const int32_t *idx = sel_idx + sel_off[r];
+		int rc = 0;
+		if ((int)k->sel.size() != n_sel || memcmp(k->sel.data(), idx, sizeof(int32_t) * n_sel) != 0) rc = psmc_hip_select(k, n_sel, idx);
+		const double *ar = a + (size_t)r * n * n, *er = e + (size_t)r * 2 * n, *a0r = a0 + (size_t)r * n;
+		if (rc == 0) {
+			if (A) rc = psmc_hip_estep(k, ar, er, a0r, A + (size_t)r * n * n, E ? E + (size_t)r * 2 * n : nullptr, nullptr, LL ? LL + r : nullptr, nullptr);
+			if (rc == 0 && sums) rc = psmc_hip_estep_factored(k, ar, er, a0r, sums + (size_t)r * 5 * n, E ? E + (size_t)r * 2 * n : nullptr, LL ? LL + r : nullptr);
+		}
+		if (rc) { c->err = "replicate " + std::to_string(r) + ": " + k->err; return rc; }
+	}
+	c->tables_batch = true;
+	c->last_batch_groups = n_rep;
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_estep_batch(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0,
+                                    const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+{
+	if (!c || n_rep < 1 || !a || !e || !a0 || !sel_off || !sel_idx || (!A && !sums)) return fail(c, PSMC_HIP_EINVAL, "estep_batch: bad argument");
+	if (c->parent) return fail(c, PSMC_HIP_EINVAL, "estep_batch: not on a replicate context");
+	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep_batch: no segments loaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->mode == PSMC_HIP_MODE_EXACT) return batch_exact(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
+	return batch_fast(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
+}
+
+extern "C" int psmc_hip_batch_info(psmc_hip_ctx *c, int out[2])
+{
+	if (!c || !out) return PSMC_HIP_EINVAL;
+	out[0] = c->last_batch_groups; out[1] = (int)c->kids.size();
+	return PSMC_HIP_OK;
+}
+
 extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *b, double *s)
 {
 	if (!c || seg < 0 || seg >= c->n_seg) return fail(c, PSMC_HIP_EINVAL, "get_tables: bad argument");
-	if (!c->d_f) return fail(c, PSMC_HIP_ESTATE, "get_tables: no E-step yet");
+	if (!c->d_f || c->tables_batch) return fail(c, PSMC_HIP_ESTATE, "get_tables: no single E-step yet");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int n = c->n, L = c->L[seg];
 	const int64_t off = c->off[seg];
@@ -959,7 +1207,7 @@ extern "C" int psmc_hip_decode(psmc_hip_ctx *c, int seg, int32_t *path, double *
 {
 	if (!c || seg < 0 || seg >= c->n_seg || !path) return fail(c, PSMC_HIP_EINVAL, "decode: bad argument");
 	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "decode: exact mode only");
-	if (!c->d_f || !c->have_b) return fail(c, PSMC_HIP_ESTATE, "decode: no E-step yet");
+	if (!c->d_f || !c->have_b || c->tables_batch) return fail(c, PSMC_HIP_ESTATE, "decode: no single E-step yet");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->L[seg];
 	int32_t *dp = nullptr; double *dm = nullptr;
@@ -978,7 +1226,7 @@ extern "C" int psmc_hip_posterior(psmc_hip_ctx *c, int seg, double *post, double
 {
 	if (!c || seg < 0 || seg >= c->n_seg || (!post && !recomb)) return fail(c, PSMC_HIP_EINVAL, "posterior: bad argument");
 	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "posterior: exact mode only");
-	if (!c->d_f || !c->have_b) return fail(c, PSMC_HIP_ESTATE, "posterior: no E-step yet");
+	if (!c->d_f || !c->have_b || c->tables_batch) return fail(c, PSMC_HIP_ESTATE, "posterior: no single E-step yet");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->L[seg], n = c->n;
 	double *dp = nullptr, *dr = nullptr;
@@ -999,7 +1247,7 @@ extern "C" int psmc_hip_post_counts(psmc_hip_ctx *c, int seg, const int32_t *cnt
 {
 	if (!c || seg < 0 || seg >= c->n_seg || !cnt || l < 0 || n_cnt < 1 || (l > 0 && !cnt1)) return fail(c, PSMC_HIP_EINVAL, "post_counts: bad argument");
 	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "post_counts: exact mode only");
-	if (!c->d_f || !c->have_b) return fail(c, PSMC_HIP_ESTATE, "post_counts: no E-step yet");
+	if (!c->d_f || !c->have_b || c->tables_batch) return fail(c, PSMC_HIP_ESTATE, "post_counts: no single E-step yet");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->L[seg], n = c->n, min_l = L < l ? L : l;
 	if (min_l == 0) return PSMC_HIP_OK;

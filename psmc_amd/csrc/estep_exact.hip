@@ -28,20 +28,22 @@ template <int REP>
 __global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, const double *__restrict__ e,
                                                     const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                     const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
-                                                    const int32_t *__restrict__ work, double *__restrict__ f,
+                                                    const ExWork wl, double *__restrict__ f,
                                                     double *__restrict__ s)
 {
 	__shared__ double lds_x[2 * 64]; // REP == 2: the state vector and the unnormalised one, broadcast through LDS
 	const int lane = threadIdx.x;
-	const int seg = work[blockIdx.x];
-	const int64_t off = seg_off[seg];
+	const int seg = wl.seg[blockIdx.x];
+	if (seg < 0) return; // padding entry of a batch
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[blockIdx.x] : off;
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x] * wl.par_stride : 0; a += po; e += po; a0 += po; }
 	const int L = seg_len[seg];
 	double col[64]; // at[k][l] = a[l][k] (khmm.c:162-166)
 #pragma unroll
 	for (int l = 0; l < 64; ++l) col[l] = a[l * 64 + lane];
 	const double e0 = e[lane], e1 = e[64 + lane];
 	const uint8_t *o = obs + off;
-	double *fo = f + off * 64, *so = s + off;
+	double *fo = f + toff * 64, *so = s + toff;
 
 	int symv = o[lane]; // obs is padded by >= 64 bytes at the end
 	double x;
@@ -81,27 +83,30 @@ template <int REP>
 __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ aeT, const double *__restrict__ e,
                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                      const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
-                                                     const int32_t *__restrict__ work, int n_work,
+                                                     const ExWork wl,
                                                      const double *__restrict__ s, double *__restrict__ b,
                                                      double *__restrict__ chk)
 {
 	__shared__ double lds_ae[2 * 4096]; // [0]: het (b=1), [1]: missing (b=2); [l*64+k]
 	__shared__ double lds_xb[4 * 64];   // REP == 2: each wave's b vector, broadcast through LDS
+	// the four sweeps of a block share the LDS copy: a batch keeps the items of one parameter set block-aligned
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x * 4] * wl.par_stride : 0; aeT += po; e += po; a0 += po; }
 	for (int i = threadIdx.x; i < 2 * 4096; i += 256) lds_ae[i] = aeT[4096 + i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	double *xs = lds_xb + (threadIdx.x >> 6) * 64;
 	const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (w >= n_work) return;
-	const int seg = work[w];
-	const int64_t off = seg_off[seg];
+	if (w >= wl.n) return;
+	const int seg = wl.seg[w];
+	if (seg < 0) return; // padding entry of a batch
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[w] : off;
 	const int L = seg_len[seg];
 	double row0[64];
 #pragma unroll
 	for (int l = 0; l < 64; ++l) row0[l] = aeT[l * 64 + lane];
 	const uint8_t *o = obs + off;
-	const double *so = s + off;
-	double *bo = b + off * 64;
+	const double *so = s + toff;
+	double *bo = b + toff * 64;
 
 	// b[L][k] = 1/s[L] (khmm.c:226)
 	double x = 1.0 / so[L - 1];
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 		double c;
 		if (REP == 2) { __builtin_amdgcn_wave_barrier(); xs[lane] = t; __builtin_amdgcn_wave_barrier(); c = seq_sum_lds(xs); }
 		else { double r[4]; rep_rows<REP == 2 ? 1 : REP>(t, r); c = seq_sum_rep(r); }
-		if (lane == 0) chk[seg] = c;
+		if (lane == 0) chk[w] = c;
 	}
 }
 
@@ -178,18 +183,20 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
                                                        const double *__restrict__ e,
                                                        const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                        const int64_t *__restrict__ seg_off,
-                                                       const int32_t *__restrict__ seg_len, const int32_t *__restrict__ work,
+                                                       const int32_t *__restrict__ seg_len, const ExWork wl,
                                                        const double *__restrict__ f, const double *__restrict__ b,
                                                        const double *__restrict__ s, double *__restrict__ segA,
                                                        double *__restrict__ segE, double *__restrict__ segA0)
 {
 	constexpr int H = S / 64, NA = (S / 4) * H;
 	const int lane = threadIdx.x;
-	const int seg = work[blockIdx.x];
-	const int64_t off = seg_off[seg];
+	const int seg = wl.seg[blockIdx.x];
+	if (seg < 0) return; // padding entry of a batch
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[blockIdx.x] : off;
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x] * wl.par_stride : 0; a += po; aeT += po; e += po; a0 += po; }
 	const int L = seg_len[seg];
 	const uint8_t *o = obs + off;
-	const double *fo = f + off * S, *bo = b + off * S, *so = s + off;
+	const double *fo = f + toff * S, *bo = b + toff * S, *so = s + toff;
 	constexpr int BLK = 16;
 	if (blockIdx.y < NA) {
 		const int k0 = (blockIdx.y / H) * 4;
@@ -503,21 +510,24 @@ template <int REP>
 __global__ __launch_bounds__(256) void k_fwd_exact128(const double *__restrict__ a, const double *__restrict__ e,
                                                         const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                         const int64_t *__restrict__ seg_off,
-                                                        const int32_t *__restrict__ seg_len, const int32_t *__restrict__ work,
-                                                        int n_work, double *__restrict__ f, double *__restrict__ s)
+                                                        const int32_t *__restrict__ seg_len, const ExWork wl,
+                                                        double *__restrict__ f, double *__restrict__ s)
 {
 	extern __shared__ double lds_m[]; // a[l*128+k]: at[k][l] of khmm.c:162-166 read column-wise
+	// the sweeps of a block share the LDS copy of the matrix: a batch keeps the items of one parameter set block-aligned
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x * (blockDim.x >> 6)] * wl.par_stride : 0; a += po; e += po; a0 += po; }
 	for (int i = threadIdx.x; i < S2 * S2; i += blockDim.x) lds_m[i] = a[i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (w >= n_work) return;
-	const int seg = work[w];
-	const int64_t off = seg_off[seg];
+	if (w >= wl.n) return;
+	const int seg = wl.seg[w];
+	if (seg < 0) return; // padding entry of a batch
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[w] : off;
 	const int L = seg_len[seg];
 	const double e0[2] = {e[2 * lane], e[2 * lane + 1]}, e1[2] = {e[S2 + 2 * lane], e[S2 + 2 * lane + 1]};
 	const uint8_t *o = obs + off;
-	double *fo = f + off * S2, *so = s + off;
+	double *fo = f + toff * S2, *so = s + toff;
 	int symv = o[lane]; // obs is padded by >= 64 bytes at the end
 	double x[2];
 	const double no_e[4] = {0, 0, 0, 0};
@@ -553,23 +563,25 @@ template <int REP>
 __global__ __launch_bounds__(256) void k_bwd_exact128(const double *__restrict__ aT, const double *__restrict__ e,
                                                         const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                         const int64_t *__restrict__ seg_off,
-                                                        const int32_t *__restrict__ seg_len, const int32_t *__restrict__ work,
-                                                        int n_work, const double *__restrict__ s, double *__restrict__ b,
+                                                        const int32_t *__restrict__ seg_len, const ExWork wl,
+                                                        const double *__restrict__ s, double *__restrict__ b,
                                                         double *__restrict__ chk)
 {
 	extern __shared__ double lds_m[]; // aT[l*128+k] = a[k][l], then e[0][*], e[1][*], e[2][*]
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x * (blockDim.x >> 6)] * wl.par_stride : 0; aT += po; e += po; a0 += po; }
 	for (int i = threadIdx.x; i < S2 * S2; i += blockDim.x) lds_m[i] = aT[i];
 	for (int i = threadIdx.x; i < 3 * S2; i += blockDim.x) lds_m[S2 * S2 + i] = e[i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (w >= n_work) return;
-	const int seg = work[w];
-	const int64_t off = seg_off[seg];
+	if (w >= wl.n) return;
+	const int seg = wl.seg[w];
+	if (seg < 0) return; // padding entry of a batch
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[w] : off;
 	const int L = seg_len[seg];
 	const uint8_t *o = obs + off;
-	const double *so = s + off;
-	double *bo = b + off * S2;
+	const double *so = s + toff;
+	double *bo = b + toff * S2;
 	double x[2];
 	x[0] = x[1] = 1.0 / so[L - 1]; // b[L][k] = 1/s[L] (khmm.c:226)
 	{ d2_t v; v.x = x[0]; v.y = x[1]; reinterpret_cast<d2_t *>(bo + (int64_t)(L - 1) * S2)[lane] = v; }
@@ -600,7 +612,7 @@ __global__ __launch_bounds__(256) void k_bwd_exact128(const double *__restrict__
 		double q0[4], q1[4];
 		rep_rows<REP>(t0, q0); rep_rows<REP>(t1, q1);
 		const double c = seq_sum_rep2(q0, q1);
-		if (lane == 0) chk[seg] = c;
+		if (lane == 0) chk[w] = c;
 	}
 }
 
@@ -612,17 +624,19 @@ template <int REP> static int launch_exact128_t(const EstepLaunch &p)
 	    hipFuncSetAttribute((const void *)k_bwd_exact128<REP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
 		return (int)hipGetLastError();
 	// the sweeps are LDS-bandwidth bound: spread the segments over all 256 CUs before stacking waves on one
-	const int wpb = p.n_work <= 256 ? 1 : (p.n_work <= 512 ? 2 : 4);
+	// (a batch list is padded per parameter set to p.work_align entries: that many waves per block at most)
+	const int wpb = p.work_align > 0 ? p.work_align : (p.n_work <= 256 ? 1 : (p.n_work <= 512 ? 2 : 4));
 	const int nb = (p.n_work + wpb - 1) / wpb;
+	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.n_work, p.par_stride};
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
 	hipLaunchKernelGGL(k_fwd_exact128<REP>, dim3(nb), dim3(64 * wpb), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
-	                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_f, p.d_s);
+	                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
 	hipLaunchKernelGGL(k_bwd_exact128<REP>, dim3(nb), dim3(64 * wpb), lds, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
-	                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
+	                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
 	hipLaunchKernelGGL(k_expect_exact<128>, dim3(p.n_work, 66), dim3(64), 0, p.stream, p.d_a, p.d_aeT, p.d_e, p.d_a0,
-	                   p.d_obs, p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+	                   p.d_obs, p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
 	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);
 	if (p.ev[4]) hipEventRecord(p.ev[4], p.stream);
 	return (int)hipGetLastError();
@@ -669,30 +683,31 @@ int launch_exact(const EstepLaunch &p)
 	const int rep = p.rep_impl;
 	if (p.n_work <= 0) return 0;
 	if (p.ns == 128) return rep == 0 ? launch_exact128_t<0>(p) : launch_exact128_t<1>(p);
+	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.n_work, p.par_stride};
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
 	if (p.exact_lds)
 		hipLaunchKernelGGL(k_fwd_exact<2>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_s);
+		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	else if (rep == 0)
 		hipLaunchKernelGGL(k_fwd_exact<0>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_s);
+		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	else
 		hipLaunchKernelGGL(k_fwd_exact<1>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_s);
+		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
 	const int nb = (p.n_work + 3) / 4;
 	if (p.exact_lds)
 		hipLaunchKernelGGL(k_bwd_exact<2>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
+		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	else if (rep == 0)
 		hipLaunchKernelGGL(k_bwd_exact<0>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
+		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	else
 		hipLaunchKernelGGL(k_bwd_exact<1>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, p.d_work, p.n_work, p.d_s, p.d_b, p.d_chk);
+		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
 	hipLaunchKernelGGL(k_expect_exact<64>, dim3(p.n_work, 17), dim3(64), 0, p.stream, p.d_a, p.d_aeT, p.d_e, p.d_a0,
-	                   p.d_obs, p.d_seg_off, p.d_seg_len, p.d_work, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+	                   p.d_obs, p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
 	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);
 	if (p.ev[4]) hipEventRecord(p.ev[4], p.stream);
 	return (int)hipGetLastError();

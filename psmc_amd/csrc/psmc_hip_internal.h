@@ -24,6 +24,17 @@ constexpr int CHUNK_ANCHOR_F = 1; // forward speculation started at the true seg
 constexpr int CHUNK_ANCHOR_B = 2; // backward speculation started at the true segment end: exact
 constexpr int CHUNK_LAST = 4;     // last tile of its segment
 
+// Exact mode: the list of sweeps of one launch, one entry per (parameter set, segment).  A single E-step has one
+// parameter set and keeps every segment's tables at the segment's own offset (par == tab == nullptr); a batch
+// (psmc_hip_estep_batch) gives each entry its parameter-set index and its own table slot.
+struct ExWork {
+	const int32_t *seg;  // [n] segment id; < 0: padding entry (keeps the entries of one parameter set block-aligned)
+	const int32_t *par;  // [n] parameter-set index, or nullptr: all 0
+	const int64_t *tab;  // [n] offset of the entry's f/b/s tables in bins, or nullptr: seg_off[seg]
+	int n;
+	int64_t par_stride;  // doubles between consecutive parameter sets
+};
+
 struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged; };
 
 // Everything a launch needs (device pointers unless noted).
@@ -68,8 +79,9 @@ struct EstepLaunch {
 	const uint8_t *d_obs;
 	const int64_t *d_seg_off;
 	const int32_t *d_seg_len;
-	const int32_t *d_work; // exact: unique selected segment ids
+	const int32_t *d_work; // exact: unique selected segment ids (batch: segment of every entry, -1 = padding)
 	int n_work;
+	const int32_t *d_work_par; const int64_t *d_work_tab; int64_t par_stride; int work_align; // exact batch, see ExWork (single E-step: null, null, 0, 0)
 	double *d_f, *d_b, *d_s; // exact: f,b tables + s; fast: f = X (lag-normalised), d_b = bt, d_s = inv_d
 	// exact outputs
 	double *d_segA, *d_segE, *d_segA0, *d_chk;

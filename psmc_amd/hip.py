@@ -26,7 +26,7 @@ EXPORTS = [
     "psmc_hip_device_count", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
-    "psmc_hip_estep_segments", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
+    "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
 ]
 
@@ -197,6 +197,36 @@ class HipEStep:
         self._chk(self.lib.psmc_hip_estep_segments(self.h, _p(a), _p(e), _p(a0), _p(sA), _p(sE), _p(sA0), _p(sLL),
                                                    _p(chk)), "estep_segments")
         return dict(seg_A=sA, seg_E=sE, seg_A0=sA0, seg_LL=sLL, chk=chk)
+
+    def estep_batch(self, params, selections, want="A"):
+        """Config 4: one call for n_rep replicates.  params: list of (a, e, a0); selections: list of index lists
+        (bootstrap multisets over the loaded segments).  want: "A" (full counts), "sums" (5 triangular sums) or "both".
+        -> dict(A (R,n,n) | sums (R,5,n), E (R,2,n), LL (R,))."""
+        R, n = len(params), self.n
+        assert len(selections) == R
+        a = np.ascontiguousarray(np.stack([np.asarray(p[0], dtype=np.float64) for p in params]))
+        e = np.ascontiguousarray(np.stack([np.asarray(p[1], dtype=np.float64)[:2] for p in params]))
+        a0 = np.ascontiguousarray(np.stack([np.asarray(p[2], dtype=np.float64) for p in params]))
+        assert a.shape == (R, n, n) and e.shape == (R, 2, n) and a0.shape == (R, n)
+        off = np.concatenate([[0], np.cumsum([len(x) for x in selections])]).astype(np.int32)
+        idx = np.concatenate([np.asarray(x, dtype=np.int32) for x in selections]).astype(np.int32)
+        A = np.zeros((R, n, n)) if want in ("A", "both") else None
+        sums = np.zeros((R, 5, n)) if want in ("sums", "both") else None
+        E = np.zeros((R, 2, n)); LL = np.zeros(R)
+        self.lib.psmc_hip_estep_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _i32p, _dp, _dp, _dp, _dp]
+        self._chk(self.lib.psmc_hip_estep_batch(self.h, R, _p(a), _p(e), _p(a0), off.ctypes.data_as(_i32p), idx.ctypes.data_as(_i32p),
+                                                _p(A), _p(sums), _p(E), _p(LL)), "estep_batch")
+        out = dict(E=E, LL=LL)
+        if A is not None:
+            out["A"] = A
+        if sums is not None:
+            out["sums"] = sums
+        return out
+
+    def batch_info(self):
+        o = (C.c_int * 2)()
+        self._chk(self.lib.psmc_hip_batch_info(self.h, o), "batch_info")
+        return dict(groups=o[0], replicate_contexts=o[1])
 
     def estep_device(self, a, e, a0, d_stats_ptr, stream_ptr=0):
         """Fast mode, asynchronous: [A | E | LL] (n*n+2n+1 doubles) into device memory on `stream`."""

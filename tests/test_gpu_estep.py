@@ -561,3 +561,96 @@ def test_fast_device_resident_io(hip, golden):
     check_fast(dict(A=h[:4096].reshape(64, 64), E=h[4096:4224].reshape(2, 64), LL=h[4224]),
                dict(A=g["n64_curve.A"], E=g["n64_curve.E"], LL=float(g["n64_curve.LL"])))
     es.close()
+
+
+# ------------------------------------------------------------------ config 4: batch of bootstrap replicates
+def _traj_params(n_sets):
+    import json
+    from psmc_amd import hostlib
+    tj = json.load(open(os.path.join(ROOT, "tests", "golden", "traj_n64.json")))
+    return [hostlib.hmm_params(tj["pattern"], r["params"]) for r in tj["rounds"][1:1 + n_sets]]
+
+
+@pytest.mark.parametrize("batch_bins", [0, 40000])
+def test_exact_batch_is_bit_identical_to_separate_calls(hip, golden, batch_bins):
+    """psmc_hip_estep_batch, exact mode: 8 replicates (own parameters, own bootstrap multiset with repeats) in one grid
+    per kernel == 8 x (psmc_hip_select + psmc_hip_estep), bit for bit; with a table budget that forces several launch
+    groups as well."""
+    segs = golden.segs_small + golden.segs_mid[2:]
+    rng = np.random.default_rng(4)
+    params = _traj_params(8)
+    sels = [rng.integers(0, len(segs), size=rng.integers(1, 2 * len(segs))).tolist() for _ in range(8)]
+    sels[3] = [10, 10, 10]           # one segment, three times
+    sels[5] = list(range(len(segs)))  # everything once, in order
+    es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=batch_bins)
+    es.load_segments(segs)
+    want = []
+    for (a, e, a0), sel in zip(params, sels):
+        es.select(sel)
+        want.append(es.estep(a, e, a0))
+    got = es.estep_batch(params, sels, want="both")
+    info = es.batch_info()
+    assert info["groups"] >= (2 if batch_bins else 1), info
+    for r, w in enumerate(want):
+        assert bits_equal(got["A"][r], w["A"]) and bits_equal(got["E"][r], w["E"]) and got["LL"][r] == w["LL"], r
+        lo, up = np.tril(w["A"], -1), np.triu(w["A"], 1)
+        ts = np.stack([lo.sum(1), up.sum(1), np.diag(w["A"]).copy(), lo.sum(0), up.sum(0)])
+        assert relmax(got["sums"][r], ts) < 1e-14
+    es.select(list(range(len(segs))))   # a single E-step after a batch: tables back in segment layout
+    r = es.estep(*params[0])
+    f, b, s = es.tables(5)
+    ex2 = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    ex2.load_segments(segs)
+    r2 = ex2.estep(*params[0])
+    f2, b2, s2 = ex2.tables(5)
+    assert bits_equal(r["A"], r2["A"]) and bits_equal(f, f2) and bits_equal(b, b2)
+    es.close(); ex2.close()
+
+
+def test_exact_batch_n128(hip, golden, oracle):
+    """Two states per lane, the matrix of a block's parameter set in LDS: three replicates, each against the oracle."""
+    g, k = golden.n128, "n128_curve"
+    a, e, a0 = g[k + ".a"], g[k + ".e"], g[k + ".a0"]
+    a2 = a[:100, :100] / a[:100, :100].sum(1, keepdims=True)
+    segs = golden.segs_small
+    sels = [[7, 0, 3, 7, 5], [9, 9, 8], [12, 1, 2, 6]]
+    for n, pars in ((128, [(a, e, a0)] * 3), (100, [(a2, e[:, :100], a0[:100] / a0[:100].sum())] * 3)):
+        es = hip.HipEStep(n, mode=hip.MODE_EXACT)
+        es.load_segments(segs)
+        got = es.estep_batch(pars, sels)
+        for r, sel in enumerate(sels):
+            o = oracle.estep(pars[r][0], pars[r][1], pars[r][2], [segs[i] for i in sel])
+            assert bits_equal(got["A"][r], o["A"]) and bits_equal(got["E"][r], o["E"]) and got["LL"][r] == o["LL"]
+        es.close()
+
+
+def test_fast_batch_keeps_a_plan_per_replicate(hip, golden, oracle):
+    """Fast mode: the replicates run back to back on per-replicate child contexts (own tiling of their selection, own
+    learned runs) sharing one set of tables.  Within tolerance of the oracle, and bit-identical to fresh contexts fed
+    the same call history; the repair rounds disappear from the second EM iteration on."""
+    segs = golden.segs_mid
+    params = _traj_params(4)
+    sels = [[5, 4, 5, 3, 5], [0, 1, 2], [2, 2, 1, 0, 4], list(range(6))]
+    opts = dict(chunk=768, warmup=256, group_cap=200000)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
+    es.load_segments(segs)
+    fresh = []
+    for sel in sels:
+        f = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
+        f.load_segments(segs); f.select(sel)
+        fresh.append(f)
+    for it in range(3):
+        got = es.estep_batch(params, sels, want="both")
+        assert es.batch_info()["replicate_contexts"] == 4
+        for r, sel in enumerate(sels):
+            a, e, a0 = params[r]
+            o = oracle.estep(a, e, a0, [segs[i] for i in sel])
+            check_fast(dict(A=got["A"][r], E=got["E"][r], LL=got["LL"][r]), o)
+            lo, up = np.tril(o["A"], -1), np.triu(o["A"], 1)
+            assert relmax(got["sums"][r], np.stack([lo.sum(1), up.sum(1), np.diag(o["A"]).copy(), lo.sum(0), up.sum(0)])) < FAST_TOL_STATS
+            w = fresh[r].estep(a, e, a0)
+            wf = fresh[r].estep_factored(a, e, a0)
+            assert bits_equal(got["A"][r], w["A"]) and got["LL"][r] == wf["LL"] and bits_equal(got["sums"][r], wf["sums"])
+    for f in fresh:
+        f.close()
+    es.close()

@@ -1,0 +1,134 @@
+/* boot.c -- config 4: the bootstrap farm of lh3/psmc (README:57-62 there: `seq 100 | xargs -i echo psmc -N25 ... -b
+ * -o round-{}.psmc split.fa | sh`) as ONE process that keeps the trunks in HBM once and runs all replicates' EM
+ * iterations in lock step: per iteration the E-steps of every replicate go to the device(s) as one batch each
+ * (psmc_hip_estep_batch: exact mode packs hundreds of trunk sweeps into one grid; fast mode keeps a learned tile plan
+ * per replicate), then the Hooke-Jeeves M-steps (host, em.c:56-68) run on host threads, one replicate each.
+ *
+ * Replicate r is `PSMC_SEED=<seed0+r> psmc -b <options>`: the same srand48 seed, hence the same psmc_resamp draw
+ * (aux.c:8-47) and the same -I initial parameters, the same .psmc stream -- byte for byte in exact mode
+ * (tests/test_host_cli.py).  Replicates are independent whole EM runs: no collective; with several devices they are
+ * dealt round robin, one host thread driving each device.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "psmc_host.h"
+
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
+typedef struct {
+	psmc_model *m;
+	int32_t *idx; int n_idx;       /* the drawn trunks, in order, repeats allowed */
+	int64_t sum_called, sum_het;
+	FILE *out;
+	double *A, *E, *sums, LL;
+} replicate;
+
+int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_pattern, psmc_batch_backend *bb)
+{
+	psmc_setup su;
+	psmc_input in;
+	int status = 1;
+	if (n_rep < 1 || !out_pattern || !strstr(out_pattern, "%d")) { fprintf(stderr, "psmc_boot: need a replicate count and an output pattern with %%d\n"); return 1; }
+	if (o->decode || o->cnt_file || o->print_prob || o->simulate) { fprintf(stderr, "psmc_boot: decoding / simulation options make no sense on bootstrap replicates\n"); return 1; }
+	if (psmc_setup_begin(o, &su)) return 1;
+	const int N = su.pat.n_states;
+	if (psmc_input_read(o->in_file, &in) || in.n_seg == 0) { fprintf(stderr, "psmc_boot: no sequence in %s\n", o->in_file); psmc_setup_end(&su); return 1; }
+	for (int i = 0; i < in.n_seg; ++i)
+		if (in.seg[i].L < 1) { fprintf(stderr, "psmc_boot: empty sequence '%s'\n", in.seg[i].name); goto done_input; }
+	{ /* the trunks go to every device once */
+		const size_t ns = (size_t)(in.n_seg > 0 ? in.n_seg : 1);
+		const uint8_t **ptr = (const uint8_t **)malloc(sizeof(void *) * ns);
+		int32_t *len = (int32_t *)malloc(sizeof(int32_t) * ns);
+		for (int i = 0; i < in.n_seg; ++i) { ptr[i] = in.seg[i].sym; len[i] = in.seg[i].L; }
+		int rc = 0;
+		for (int d = 0; d < bb->n_dev && rc == 0; ++d) {
+			rc = bb->load(bb->self, d, in.n_seg, ptr, len);
+			if (rc) fprintf(stderr, "psmc_boot: cannot load the trunks on device %d: %s\n", d, bb->error(bb->self, d));
+		}
+		free(ptr); free(len);
+		if (rc) goto done_input;
+	}
+	replicate *rep = (replicate *)calloc((size_t)n_rep, sizeof(replicate));
+	const int factored = o->fast_mstep && bb->can_factor && N <= 64;
+	for (int r = 0; r < n_rep; ++r) { /* serial: drand48 is one global stream, re-seeded per replicate like a fresh process */
+		replicate *R = &rep[r];
+		char fn[4096];
+		snprintf(fn, sizeof fn, out_pattern, r);
+		R->out = fopen(fn, "w");
+		if (!R->out) { fprintf(stderr, "psmc_boot: cannot write %s\n", fn); goto done_rep; }
+		srand48(seed0 + r);                                     /* main.c:11 with PSMC_SEED */
+		psmc_print_header(o, &su.pat, R->out);
+		R->n_idx = psmc_input_resample_idx(&in, &R->idx);       /* -b: aux.c:8-47 */
+		for (int i = 0; i < R->n_idx; ++i) { R->sum_called += in.seg[R->idx[i]].L_called; R->sum_het += in.seg[R->idx[i]].n_het; }
+		fprintf(R->out, "MM\tn_seqs:%d, sum_L:%lld, sum_n:%d\n", R->n_idx, (long long)R->sum_called, (int)R->sum_het);
+		R->m = psmc_model_start(o, &su, R->sum_called, R->sum_het);
+		fprintf(R->out, "RD\t0\n");
+		psmc_print_round(R->m, R->sum_called, R->out);
+		R->A = factored ? 0 : (double *)calloc((size_t)N * N, sizeof(double));
+		R->sums = factored ? (double *)calloc((size_t)5 * N, sizeof(double)) : 0;
+		R->E = (double *)calloc((size_t)2 * N, sizeof(double));
+	}
+	const int timing = getenv("PSMC_TIMING") != 0;
+	int failed = 0;
+	for (int it = 0; it != o->n_iters && !failed; ++it) { /* main.c:16-20, all replicates in lock step */
+		const double t0 = now_ms();
+		/* E-steps: one batch per device */
+#pragma omp parallel for schedule(static, 1) num_threads(bb->n_dev) reduction(| : failed)
+		for (int d = 0; d < bb->n_dev; ++d) {
+			int cnt = 0, tot = 0;
+			for (int r = d; r < n_rep; r += bb->n_dev) { ++cnt; tot += rep[r].n_idx; }
+			if (cnt == 0) continue;
+			double *a = (double *)malloc(sizeof(double) * (size_t)cnt * N * N), *e = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N);
+			double *a0 = (double *)malloc(sizeof(double) * (size_t)cnt * N);
+			double *A = factored ? 0 : (double *)malloc(sizeof(double) * (size_t)cnt * N * N);
+			double *S5 = factored ? (double *)malloc(sizeof(double) * (size_t)cnt * 5 * N) : 0;
+			double *E = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N), *LL = (double *)malloc(sizeof(double) * (size_t)cnt);
+			int32_t *off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cnt + 1)), *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)tot);
+			int j = 0; off[0] = 0;
+			for (int r = d; r < n_rep; r += bb->n_dev, ++j) {
+				const psmc_model *m = rep[r].m;
+				memcpy(a + (size_t)j * N * N, m->a, sizeof(double) * (size_t)N * N);
+				memcpy(e + (size_t)j * 2 * N, m->e, sizeof(double) * (size_t)2 * N); /* rows hom, het; the missing row is implied */
+				memcpy(a0 + (size_t)j * N, m->a0, sizeof(double) * (size_t)N);
+				memcpy(idx + off[j], rep[r].idx, sizeof(int32_t) * (size_t)rep[r].n_idx);
+				off[j + 1] = off[j] + rep[r].n_idx;
+			}
+			const int rc = bb->estep_batch(bb->self, d, cnt, a, e, a0, off, idx, A, S5, E, LL);
+			if (rc) { fprintf(stderr, "psmc_boot: E-step batch failed on device %d: %s\n", d, bb->error(bb->self, d)); failed |= 1; }
+			j = 0;
+			for (int r = d; r < n_rep && !rc; r += bb->n_dev, ++j) {
+				if (A) memcpy(rep[r].A, A + (size_t)j * N * N, sizeof(double) * (size_t)N * N);
+				if (S5) memcpy(rep[r].sums, S5 + (size_t)j * 5 * N, sizeof(double) * (size_t)5 * N);
+				memcpy(rep[r].E, E + (size_t)j * 2 * N, sizeof(double) * (size_t)2 * N);
+				rep[r].LL = LL[j];
+			}
+			free(a); free(e); free(a0); free(A); free(S5); free(E); free(LL); free(off); free(idx);
+		}
+		if (failed) break;
+		const double t1 = now_ms();
+		/* M-steps: independent models, one host thread each (em.c:56-74), then the round's output */
+#pragma omp parallel for schedule(dynamic, 1)
+		for (int r = 0; r < n_rep; ++r) {
+			replicate *R = &rep[r];
+			psmc_em_mstep(R->m, R->A, R->E, R->sums, R->LL, R->out);
+			fprintf(R->out, "RD\t%d\n", it + 1);
+			psmc_print_round(R->m, R->sum_called, R->out);
+		}
+		if (timing)
+			fprintf(stderr, "[psmc_boot] iteration %d: %d E-steps %.1f ms on %d device(s), M-steps %.1f ms\n", it + 1, n_rep, t1 - t0, bb->n_dev, now_ms() - t1);
+	}
+	status = failed ? 1 : 0;
+done_rep:
+	for (int r = 0; r < n_rep; ++r) {
+		if (rep[r].out) fclose(rep[r].out);
+		if (rep[r].m) psmc_model_free(rep[r].m);
+		free(rep[r].idx); free(rep[r].A); free(rep[r].E); free(rep[r].sums);
+	}
+	free(rep);
+done_input:
+	psmc_input_free(&in);
+	psmc_setup_end(&su);
+	return status;
+}

@@ -1,0 +1,104 @@
+/* boot_main.c -- the `psmc_boot` executable: all bootstrap replicates of lh3/psmc's README:57-62 in one process on
+ * the MI355X(s) of the node.
+ *
+ *   psmc_boot -R <replicates> [-S <first seed>] -O <out pattern with %d> -- <psmc options> split.psmcfa
+ *
+ * e.g.  psmc_boot -R 100 -S 1 -O round-%d.psmc -- -N25 -t15 -r5 -p "4+25*2+4+6" split.psmcfa
+ * writes what  for r in 0..99: PSMC_SEED=$((1+r)) psmc -N25 -t15 -r5 -b -p ... -o round-$r.psmc split.psmcfa  would
+ * (-b is implied).  PSMC_HIP_MODE=exact|fast and PSMC_FAST_MSTEP as for psmc; PSMC_HIP_DEVICES=0,1,.. (default: all
+ * visible devices); OMP_NUM_THREADS bounds the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr.
+ * There is no CPU E-step in this binary. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "psmc_host.h"
+#include "psmc_hip.h"
+
+#define MAX_DEV 64
+typedef struct { int n_dev, n_states; psmc_hip_ctx *ctx[MAX_DEV]; } hip_bb;
+
+static int bb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L)
+{
+	return psmc_hip_load_segments(((hip_bb *)self)->ctx[dev], n_seg, sym, L);
+}
+static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
+                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+{
+	return psmc_hip_estep_batch(((hip_bb *)self)->ctx[dev], n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
+}
+static const char *bb_error(void *self, int dev) { return psmc_hip_last_error(((hip_bb *)self)->ctx[dev]); }
+static void bb_destroy(void *self) { hip_bb *h = (hip_bb *)self; for (int d = 0; d < h->n_dev; ++d) psmc_hip_destroy(h->ctx[d]); }
+
+static void usage(void)
+{
+	fprintf(stderr, "Usage: psmc_boot -R <replicates> [-S <first seed>] -O <output pattern with %%d> -- <psmc options> input.psmcfa\n"
+	                "       (replicate r = `PSMC_SEED=<seed+r> psmc -b <psmc options> -o <pattern %% r>`; PSMC_HIP_MODE, PSMC_HIP_DEVICES)\n");
+}
+
+int main(int argc, char *argv[])
+{
+	int n_rep = 0, i = 1;
+	long seed0 = 1;
+	const char *pattern = 0;
+	for (; i < argc; ++i) {
+		if (!strcmp(argv[i], "--")) { ++i; break; }
+		if (!strcmp(argv[i], "-R") && i + 1 < argc) n_rep = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-S") && i + 1 < argc) seed0 = atol(argv[++i]);
+		else if (!strcmp(argv[i], "-O") && i + 1 < argc) pattern = argv[++i];
+		else { usage(); return 1; }
+	}
+	if (n_rep < 1 || !pattern || i >= argc) { usage(); return 1; }
+	psmc_options o;
+	psmc_options_default(&o);
+	{ /* psmc's own option parser on the rest of the command line */
+		char **av = (char **)malloc(sizeof(char *) * (size_t)(argc - i + 2));
+		av[0] = argv[0];
+		for (int k = i; k < argc; ++k) av[k - i + 1] = argv[k];
+		const int rc = psmc_options_parse(&o, argc - i + 1, av);
+		free(av);
+		if (rc) { psmc_options_free(&o); return 1; }
+	}
+	o.bootstrap = 1;
+	psmc_pattern pat;
+	int n_states = 0;
+	if (o.param_file) {
+		FILE *fp = fopen(o.param_file, "r"); char str[256];
+		if (fp && fscanf(fp, "%255s", str) == 1 && psmc_pattern_parse(str, &pat) == 0) { n_states = pat.n_states; psmc_pattern_free(&pat); }
+		if (fp) fclose(fp);
+	} else if (psmc_pattern_parse(o.pattern_text ? o.pattern_text : "4+5*3+4", &pat) == 0) { n_states = pat.n_states; psmc_pattern_free(&pat); }
+	if (n_states < 1) { fprintf(stderr, "psmc_boot: malformed pattern\n"); return 1; }
+	const char *mode_s = getenv("PSMC_HIP_MODE"), *devs = getenv("PSMC_HIP_DEVICES"), *fm = getenv("PSMC_FAST_MSTEP");
+	const int mode = (mode_s && strcmp(mode_s, "fast") == 0) ? PSMC_HIP_MODE_FAST : PSMC_HIP_MODE_EXACT;
+	o.fast_mstep = fm ? atoi(fm) != 0 : (mode == PSMC_HIP_MODE_FAST);
+	hip_bb h;
+	memset(&h, 0, sizeof h);
+	h.n_states = n_states;
+	int list[MAX_DEV], n_list = 0;
+	if (devs && *devs) {
+		char *dup = strdup(devs);
+		for (char *t = strtok(dup, ","); t && n_list < MAX_DEV; t = strtok(0, ",")) list[n_list++] = atoi(t);
+		free(dup);
+	} else {
+		n_list = psmc_hip_device_count();
+		if (n_list > MAX_DEV) n_list = MAX_DEV;
+		for (int d = 0; d < n_list; ++d) list[d] = d;
+	}
+	if (n_list > n_rep) n_list = n_rep;
+	if (n_list < 1) { fprintf(stderr, "psmc_boot: no MI355X visible; this build has no CPU path\n"); psmc_options_free(&o); return 2; }
+	for (int d = 0; d < n_list; ++d) {
+		const int rc = psmc_hip_create(&h.ctx[d], n_states, list[d], mode);
+		if (rc) {
+			fprintf(stderr, "psmc_boot: cannot start the E-step on device %d (%s); this build has no CPU path\n", list[d], psmc_hip_strerror(rc));
+			for (int k = 0; k < d; ++k) psmc_hip_destroy(h.ctx[k]);
+			psmc_options_free(&o);
+			return 2;
+		}
+		h.n_dev = d + 1;
+	}
+	const char *fs = getenv("PSMC_FACTORED");
+	psmc_batch_backend bb = {&h, h.n_dev, bb_load, bb_estep_batch, bb_error, bb_destroy, mode == PSMC_HIP_MODE_FAST && !(fs && atoi(fs) == 0)};
+	const int status = psmc_boot_run(&o, n_rep, seed0, pattern, &bb);
+	bb.destroy(bb.self);
+	psmc_options_free(&o);
+	return status;
+}

@@ -102,24 +102,41 @@ int psmc_input_read(const char *path, psmc_input *in)
 
 /* -b: draw segments with replacement until the total length is as close as
  * possible to the original (aux.c:8-47); same drand48 stream, same accept rule. */
-void psmc_input_resample(psmc_input *in)
-{
+int psmc_input_resample_idx(const psmc_input *in, int32_t **idx_out)
+{	/* the draw itself: which segments, in which order (the multiset psmc_hip_select / psmc_hip_estep_batch take) */
 	int64_t have = 0, want = 0;
-	psmc_input out;
-	memset(&out, 0, sizeof out);
+	int n = 0, cap = in->n_seg + 16;
+	int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
 	for (int i = 0; i < in->n_seg; ++i) want += in->seg[i].L;
 	for (;;) {
-		const psmc_segment *s = &in->seg[(int)(in->n_seg * drand48())];
+		const int pick = (int)(in->n_seg * drand48());
+		const psmc_segment *s = &in->seg[pick];
 		const int missing = (int)(want - have);          /* tmp1: still to fill   (int like aux.c:16) */
 		const int excess = (int)(have + s->L - want);    /* tmp2: overshoot if taken */
 		if (excess <= 0 || (excess > 0 && missing > 0 && excess < missing)) {
-			uint8_t *sym = (uint8_t *)malloc(s->L ? (size_t)s->L : 1);
-			memcpy(sym, s->sym, (size_t)s->L);
-			push_segment(&out, strdup(s->name), sym, s->L, s->L_called, s->n_het);
+			if (n == cap) idx = (int32_t *)realloc(idx, sizeof(int32_t) * (size_t)(cap *= 2));
+			idx[n++] = pick;
 			have += s->L;
 		}
 		if (missing >= 0 && excess >= 0) break;
 	}
+	*idx_out = idx;
+	return n;
+}
+
+void psmc_input_resample(psmc_input *in)
+{
+	int32_t *idx = 0;
+	const int n = psmc_input_resample_idx(in, &idx);
+	psmc_input out;
+	memset(&out, 0, sizeof out);
+	for (int i = 0; i < n; ++i) {
+		const psmc_segment *s = &in->seg[idx[i]];
+		uint8_t *sym = (uint8_t *)malloc(s->L ? (size_t)s->L : 1);
+		memcpy(sym, s->sym, (size_t)s->L);
+		push_segment(&out, strdup(s->name), sym, s->L, s->L_called, s->n_het);
+	}
+	free(idx);
 	psmc_input_free(in);
 	*in = out;
 	recount(in);

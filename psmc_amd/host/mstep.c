@@ -160,6 +160,22 @@ int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, F
 	                  : be->estep(be->self, m->a, m->e, m->a0, A, E, &LL, 0);
 	const double t_e1 = now_ms();
 	if (rc) { free(A); free(E); free(sums); return rc; }
+	const int calls = psmc_em_mstep(m, factored ? 0 : A, E, sums, LL, out);
+	if (getenv("PSMC_TIMING")) /* stderr only: the .psmc stream stays byte-identical */
+		fprintf(stderr, "[psmc] E-step %.1f ms, M-step %.1f ms (%d objective calls%s)\n", t_e1 - t_e0, now_ms() - t_e1, calls,
+		        m->fast_mstep ? ", O(N) objective" : "");
+	free(A); free(E); free(sums);
+	return 0;
+}
+
+/* The M-step half of psmc_em (em.c:56-74) given the sufficient statistics of the E-step: A n*n (or NULL when the
+ * five triangular sums are given instead: fast M-step only), E 2*n, LL.  Prints the IT line; returns the number of
+ * objective calls.  Touches nothing but *m: replicates can run it concurrently on their own models. */
+int psmc_em_mstep(psmc_model *m, const double *A, const double *E, const double *sums_in, double LL, FILE *out)
+{
+	const int N = m->pat.n_states;
+	const int factored = A == 0;
+	double *sums = (double *)sums_in;
 	/* M-step: em.c:56-68 */
 	q_ctx c;
 	c.m = m; c.A = A; c.E = E; c.calls = 0;
@@ -186,10 +202,7 @@ int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, F
 		const int keep = c.calls; m->Q0 = -neg_Q_fast(m->n_params, xx, &c); c.calls = keep; free(xx);
 	} else m->Q0 = psmc_Q(N, m->a, m->e, A, E, c.Q0);
 	m->Q1 = -psmc_hooke_jeeves(m->fast_mstep ? neg_Q_fast : neg_Q, m->n_params, x, &c, HJ_RADIUS, HJ_EPS, HJ_MAXCALL);
-	if (m->fast_mstep) { psmc_model_update(m); free(c.sums); free(c.lf); } /* a/e/a0/sigma of the LAST trial point, like em.c:21-22 */
-	if (getenv("PSMC_TIMING")) /* stderr only: the .psmc stream stays byte-identical */
-		fprintf(stderr, "[psmc] E-step %.1f ms, M-step %.1f ms (%d objective calls%s)\n", t_e1 - t_e0, now_ms() - t_e1, c.calls,
-		        m->fast_mstep ? ", O(N) objective" : "");
+	if (m->fast_mstep) { psmc_model_update(m); if (!factored) free(c.sums); free(c.lf); } /* a/e/a0/sigma of the LAST trial point, like em.c:21-22 */
 	fprintf(out, "IT\t%d\n", c.calls);
 	free(x);
 	{ /* posterior state occupancy, em.c:69-74 */
@@ -197,6 +210,5 @@ int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, F
 		for (int k = 0; k < N; ++k) sum += E[k] + E[N + k];
 		for (int k = 0; k < N; ++k) m->post_sigma[k] = (E[k] + E[N + k]) / sum;
 	}
-	free(A); free(E);
-	return 0;
+	return c.calls;
 }

@@ -46,6 +46,7 @@ typedef struct {
 } psmc_input;
 int  psmc_input_read(const char *path, psmc_input *in); /* path "-" = stdin; gz or plain */
 void psmc_input_resample(psmc_input *in);                /* -b, aux.c:8-47 (drand48) */
+int  psmc_input_resample_idx(const psmc_input *in, int32_t **idx); /* the same draw as a list of segment indices (caller frees); returns its length */
 void psmc_input_free(psmc_input *in);
 uint8_t psmc_symbol_of(unsigned char c);                 /* the 256-entry table of cli.c:15-32 */
 
@@ -132,6 +133,34 @@ int psmc_run(psmc_options *o, psmc_estep_backend *be);
 
 /* one EM round (psmc_em, em.c:27-78); prints the IT line to out */
 int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, FILE *out);
+/* its M-step half (em.c:56-74) from given statistics: A n*n, or NULL with the five triangular sums `sums` (5n, fast
+ * M-step only); E 2n; LL.  Prints IT, returns the number of objective calls.  Re-entrant per model. */
+int psmc_em_mstep(psmc_model *m, const double *A, const double *E, const double *sums, double LL, FILE *out);
+
+/* what comes before the first model: pattern or -i parameter file */
+typedef struct { psmc_pattern pat; double *inp_pa, *inp_ti; int has_dt; } psmc_setup;
+int  psmc_setup_begin(psmc_options *o, psmc_setup *su); /* 0 ok */
+void psmc_setup_end(psmc_setup *su);
+void psmc_print_header(const psmc_options *o, const psmc_pattern *pat, FILE *f); /* CC / MM lines, cli.c:200-224 */
+psmc_model *psmc_model_start(const psmc_options *o, const psmc_setup *su, int64_t sum_called, int64_t sum_het); /* core.c:21-50 */
+
+/* ---- bootstrap driver (config 4): n_rep replicates of `psmc -b` in one process.  Replicate r draws its trunks and
+ * its initial parameters from srand48(seed0 + r) exactly as `PSMC_SEED=<seed0+r> psmc -b ...` does, and writes the
+ * same .psmc stream to the file named by out_pattern (one %d = r).  Per EM iteration the E-steps of all replicates
+ * go to the device(s) as batches, the M-steps run on host threads. */
+typedef struct psmc_batch_backend {
+	void *self;
+	int  n_dev; /* replicates are dealt round robin over the devices; one host thread drives each device */
+	int  (*load)(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L);
+	/* n_rep E-steps over the loaded trunks: parameters a n_rep*n*n, e n_rep*2*n (rows hom, het), a0 n_rep*n;
+	 * multisets sel_idx[sel_off[r] .. sel_off[r+1]); outputs A n_rep*n*n or NULL, sums n_rep*5n or NULL, E n_rep*2n, LL */
+	int  (*estep_batch)(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
+	                    const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL);
+	const char *(*error)(void *self, int dev);
+	void (*destroy)(void *self);
+	int  can_factor; /* estep_batch can produce the triangular sums directly */
+} psmc_batch_backend;
+int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_pattern, psmc_batch_backend *bb);
 void psmc_print_round(const psmc_model *m, int64_t sum_called, FILE *out); /* psmc_print_data, aux.c:49-82 */
 
 /* synthetic data for benchmarks: hmm_simulate-like draw (khmm.c:386-423) with our own RNG */

@@ -95,6 +95,30 @@ def test_fast_mstep_logfactors_reject_alike(pattern):
     assert int(n_acc) > 5000 and float(maxrel) < 1e-9
 
 
+@pytest.mark.parametrize("fast_mstep", ["0", "1"])
+def test_boot_driver_equals_single_bootstrap_runs(oracle_psmc, tmp_path, fast_mstep):
+    """psmc_boot's driver (boot.c) with the oracle as batch backend on two pretend devices: replicate r's file is byte
+    for byte what `PSMC_SEED=<seed+r> psmc -b` writes -- same psmc_resamp draw (aux.c:8-47), same -I initial
+    parameters, same rounds -- for 5 replicates dealt over the devices, M-steps on threads."""
+    exe = os.path.join(BUILD, "psmc_oracle_boot")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-o", exe, os.path.join(ROOT, "tests", "host_oracle_boot_main.c"),
+                    "-I" + HOST, "-I" + os.path.join(ROOT, "oracle"), "-L" + HOST, "-lpsmc_host",
+                    "-L" + os.path.join(ROOT, "oracle"), "-lpsmc_oracle",
+                    "-Wl,-rpath," + HOST, "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lz", "-lm"], check=True)
+    args = ["-N2", "-I", "0.3", os.path.join(CLI, "mid.psmcfa.gz")]
+    env = dict(os.environ, PSMC_FAST_MSTEP=fast_mstep, PSMC_FACTORED=fast_mstep)
+    r = subprocess.run([exe, "5", "17", str(tmp_path / "boot-%d.psmc")] + args, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    seen = set()
+    for k in range(5):
+        one = subprocess.run([oracle_psmc, "-b"] + args, capture_output=True, text=True, env=dict(env, PSMC_SEED=str(17 + k)))
+        assert one.returncode == 0, one.stderr
+        got = open(tmp_path / ("boot-%d.psmc" % k)).read()
+        assert got == one.stdout, k
+        seen.add(got)
+    assert len(seen) == 5   # the replicates really differ
+
+
 @pytest.fixture(scope="module")
 def host():
     subprocess.run(["make", "-s", "-C", HOST, "libpsmc_host.so"], check=True)
@@ -308,3 +332,38 @@ def test_config2_full_size_fast_mode_bound(env):
     # the RS lines themselves (6 decimals): lambda_k column of the last round
     for x, y in zip(got[-1]["rs_lam"], want[-1]["rs_lam"]):
         assert abs(x - y) <= EM_TOL_FINAL_LAMBDA * y + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern", ["4+25*2+4+6", "64*2"])
+def test_psmc_boot_binary_equals_single_runs_on_gpu(tmp_path, pattern):
+    """Config 4 through the product binaries: psmc_boot (batched exact E-steps in one grid, M-steps on threads) writes
+    for every replicate the bytes `PSMC_SEED=<seed+r> psmc -b` writes."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "psmc_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    args = ["-N2", "-t15", "-r5", "-I", "0.2", "-p", pattern, os.path.join(CLI, "mid.psmcfa.gz")]
+    r = subprocess.run([os.path.join(HOST, "psmc_boot"), "-R", "6", "-S", "40", "-O", str(tmp_path / "b-%d.psmc"), "--"] + args,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for k in range(6):
+        one = subprocess.run([os.path.join(HOST, "psmc"), "-b"] + args, capture_output=True, text=True, env=dict(os.environ, PSMC_SEED=str(40 + k)))
+        assert one.returncode == 0, one.stderr
+        assert open(tmp_path / ("b-%d.psmc" % k)).read() == one.stdout, k
+
+
+@pytest.mark.gpu
+def test_psmc_boot_binary_fast_mode_close(tmp_path):
+    """PSMC_HIP_MODE=fast: per-replicate tile plans + factored statistics + O(N) objective; LK of every round within
+    1e-6 of the exact-mode replicate (two rounds: the chaotic search has not had time to separate the runs)."""
+    args = ["-N2", "-t15", "-r5", "-p", "4+25*2+4+6", os.path.join(CLI, "mid.psmcfa.gz")]
+    outs = {}
+    for mode in ("exact", "fast"):
+        r = subprocess.run([os.path.join(HOST, "psmc_boot"), "-R", "3", "-S", "5", "-O", str(tmp_path / (mode + "-%d.psmc")), "--"] + args,
+                           capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_MODE=mode))
+        assert r.returncode == 0, r.stderr
+        outs[mode] = [_rounds(open(tmp_path / ("%s-%d.psmc" % (mode, k))).read()) for k in range(3)]
+    for ex, fa in zip(outs["exact"], outs["fast"]):
+        assert len(ex) == len(fa) == 3
+        for a, b in zip(ex[1:], fa[1:]):
+            assert abs(a["LK"] - b["LK"]) <= 1e-6 * abs(a["LK"])
+            assert max(abs(x - y) / y for x, y in zip(b["lam"], a["lam"])) < 1e-3

@@ -175,6 +175,37 @@ int psmc_hip_posterior(psmc_hip_ctx *ctx, int seg, double *post, double *recomb)
  * 4*n_cnt bytes per bin go to the GPU and n*n_cnt doubles come back. */
 int psmc_hip_post_counts(psmc_hip_ctx *ctx, int seg, const int32_t *cnt1, int32_t l, int32_t n_cnt, double *cnt);
 
+/* ---- one E-step sharded over several GPUs of the node (replaces em.c:36-55 + the serial
+ * hmm_add_expect of khmm.c:346-359 by per-device E-steps and ONE exchange per EM iteration).  One process; devices[]
+ * lists the HIP devices (a device may appear twice: two shards on one GPU, for testing).  Segments are dealt to the
+ * shards longest-first (LPT by length).  fast mode: RCCL all-reduce (sum, f64) of the n*n + 2n + 1 doubles each
+ * device's reduction kernel left in HBM, over xGMI; exact mode: per-segment statistics gathered and added on the host
+ * in the global input order -- bit-identical to the single-GPU result and to khmm.c.  librccl is opened on first use.
+ * Options: every psmc_hip_set_option key (applied to all shards) and "rccl" (-1 auto: RCCL when the devices are
+ * distinct and more than one shard holds segments, else the host adds the shards' vectors in shard order; 0 never;
+ * 1 always, e.g. a one-device group as a smoke test of the RCCL path). */
+typedef struct psmc_hip_group psmc_hip_group;
+int  psmc_hip_group_create(psmc_hip_group **g, int n_states, int n_dev, const int *devices, int mode);
+void psmc_hip_group_destroy(psmc_hip_group *g);
+const char *psmc_hip_group_last_error(const psmc_hip_group *g);
+int  psmc_hip_group_set_option(psmc_hip_group *g, const char *key, double value);
+int  psmc_hip_group_load_segments(psmc_hip_group *g, int n_seg, const uint8_t *const *seq, const int32_t *L);
+/* as psmc_hip_estep / psmc_hip_estep_factored, over all shards; chk has n_seg entries in input order */
+int  psmc_hip_group_estep(psmc_hip_group *g, const double *a, const double *e, const double *a0, double *A, double *E,
+                          double *A0, double *LL, double *chk);
+int  psmc_hip_group_estep_factored(psmc_hip_group *g, const double *a, const double *e, const double *a0, double *sums,
+                                   double *E, double *LL);
+/* shard_of_seg: n_seg entries (may be NULL); last_reduce: 0 none (one shard), 1 RCCL all-reduce, 2 host sum of the
+ * shards' vectors, 3 ordered per-segment sum (exact mode) */
+int  psmc_hip_group_info(psmc_hip_group *g, int *n_shards, int32_t *shard_of_seg, int *last_reduce);
+/* the context and local index holding segment `seg` after a group E-step, for psmc_hip_get_tables / _decode /
+ * _posterior / _post_counts (psmc_decode, aux.c:150-231) */
+int  psmc_hip_group_route(psmc_hip_group *g, int seg, psmc_hip_ctx **ctx, int *local_seg);
+/* psmc_hip_estep_factored with the result left in HBM: [SL|SU|DG|CL|CU | E | LL], 7n + 1 doubles, asynchronous on
+ * `stream` like psmc_hip_estep_device */
+int  psmc_hip_estep_factored_device(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, void *d_stats,
+                                    void *stream);
+
 /* Built-in check of the cross-lane primitives on the device (row replication
  * variants, DPP broadcasts, f64 MFMA layout).  Returns 0 when all agree;
  * a positive bitmask of failed primitives otherwise. */

@@ -946,6 +946,20 @@ extern "C" int psmc_hip_estep_factored(psmc_hip_ctx *c, const double *a, const d
 	return PSMC_HIP_OK;
 }
 
+// the factored statistics left in HBM: [SL | SU | DG | CL | CU | E(2n) | LL], 7n + 1 doubles (what the sharded
+// E-step of group.hip reduces over the devices)
+extern "C" int psmc_hip_estep_factored_device(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, void *d_stats, void *stream)
+{
+	if (!c || !a || !e || !a0 || !d_stats) return fail(c, PSMC_HIP_EINVAL, "estep_factored_device: bad argument");
+	if (c->mode != PSMC_HIP_MODE_FAST) return fail(c, PSMC_HIP_ENOTSUP, "estep_factored_device: fast mode only");
+	HIPCHK(c, hipSetDevice(c->device));
+	c->timing_valid = false;
+	c->want_factored = true;
+	const int rc = enqueue_fast(c, a, e, a0, (double *)d_stats, (hipStream_t)stream);
+	c->want_factored = false;
+	return rc;
+}
+
 extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[8])
 {
 	if (!c || !out) return PSMC_HIP_EINVAL;

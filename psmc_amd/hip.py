@@ -28,6 +28,9 @@ EXPORTS = [
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
+    "psmc_hip_group_create", "psmc_hip_group_destroy", "psmc_hip_group_last_error", "psmc_hip_group_set_option",
+    "psmc_hip_group_load_segments", "psmc_hip_group_estep", "psmc_hip_group_estep_factored", "psmc_hip_group_info",
+    "psmc_hip_group_route", "psmc_hip_estep_factored_device",
 ]
 
 
@@ -369,3 +372,80 @@ def pipe_probe(device=0):
     if rc != 0:
         raise HipError("pipe_probe: %s" % lib.psmc_hip_strerror(rc).decode())
     return {name: [round(v, 1) for v in out[8 * i:8 * i + 8] if v > 0] for i, name in enumerate(PIPE_PROBE_CONFIGS)}
+
+
+class HipGroup:
+    """One E-step sharded over several GPUs inside the C library (psmc_hip_group_*): LPT partition of the segments,
+    per-device E-steps on host threads, RCCL all-reduce of [A | E | LL] (fast) or ordered per-segment sum (exact)."""
+
+    def __init__(self, n_states, devices, mode=MODE_FAST, **options):
+        self.lib = load_library()
+        if self.lib.psmc_hip_device_count() <= 0:
+            raise HipError("no HIP device visible: libpsmc_hip needs an AMD GPU (no CPU fallback)")
+        self.n = int(n_states); self.mode = mode
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        g = C.c_void_p()
+        self.lib.psmc_hip_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+        rc = self.lib.psmc_hip_group_create(C.byref(g), self.n, len(devices), devs, int(mode))
+        if rc != 0:
+            raise HipError("psmc_hip_group_create: %s" % self.lib.psmc_hip_strerror(rc).decode())
+        self.g = g
+        self.lib.psmc_hip_group_last_error.restype = C.c_char_p
+        self.lib.psmc_hip_group_last_error.argtypes = [C.c_void_p]
+        self.lib.psmc_hip_group_destroy.argtypes = [C.c_void_p]
+        self.lib.psmc_hip_group_destroy.restype = None
+        self.lib.psmc_hip_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        self.lib.psmc_hip_group_load_segments.argtypes = [C.c_void_p, C.c_int, C.POINTER(_u8p), _i32p]
+        self.lib.psmc_hip_group_estep.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        self.lib.psmc_hip_group_estep_factored.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_double)]
+        self.lib.psmc_hip_group_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), _i32p, C.POINTER(C.c_int)]
+        self.n_seg = 0
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise HipError("%s: %s (%s)" % (what, self.lib.psmc_hip_strerror(rc).decode(), self.lib.psmc_hip_group_last_error(self.g).decode()))
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.lib.psmc_hip_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self._chk(self.lib.psmc_hip_group_set_option(self.g, key.encode(), float(value)), "group_set_option(%s)" % key)
+
+    def load_segments(self, segs):
+        segs = [np.ascontiguousarray(s, dtype=np.uint8) for s in segs]
+        n = len(segs)
+        ptrs = (_u8p * n)(*[s.ctypes.data_as(_u8p) for s in segs])
+        lens = np.array([len(s) for s in segs], dtype=np.int32)
+        self._chk(self.lib.psmc_hip_group_load_segments(self.g, n, ptrs, lens.ctypes.data_as(_i32p)), "group_load_segments")
+        self.n_seg = n
+
+    def estep(self, a, e, a0):
+        a = np.ascontiguousarray(a, dtype=np.float64); e = np.ascontiguousarray(np.asarray(e, dtype=np.float64)[:2])
+        a0 = np.ascontiguousarray(a0, dtype=np.float64)
+        n = self.n
+        A = np.zeros((n, n)); E = np.zeros((2, n)); A0 = np.zeros(n); LL = C.c_double(0); chk = np.zeros(self.n_seg)
+        self._chk(self.lib.psmc_hip_group_estep(self.g, _p(a), _p(e), _p(a0), _p(A), _p(E), _p(A0), C.byref(LL), _p(chk)), "group_estep")
+        return dict(A=A, E=E, A0=A0, LL=LL.value, chk=chk)
+
+    def estep_factored(self, a, e, a0):
+        a = np.ascontiguousarray(a, dtype=np.float64); e = np.ascontiguousarray(np.asarray(e, dtype=np.float64)[:2])
+        a0 = np.ascontiguousarray(a0, dtype=np.float64)
+        n = self.n
+        sums = np.zeros((5, n)); E = np.zeros((2, n)); LL = C.c_double(0)
+        self._chk(self.lib.psmc_hip_group_estep_factored(self.g, _p(a), _p(e), _p(a0), _p(sums), _p(E), C.byref(LL)), "group_estep_factored")
+        return dict(sums=sums, E=E, LL=LL.value)
+
+    def info(self):
+        ns = C.c_int(0); lr = C.c_int(0); so = np.zeros(max(self.n_seg, 1), dtype=np.int32)
+        self._chk(self.lib.psmc_hip_group_info(self.g, C.byref(ns), so.ctypes.data_as(_i32p), C.byref(lr)), "group_info")
+        return dict(n_shards=ns.value, shard_of_seg=so[:self.n_seg].tolist(), last_reduce=lr.value)

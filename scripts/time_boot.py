@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Config 4 at its stated size on the MI355X box: 100 bootstrap replicates over splitfa-like trunks of a 30 M-bin genome
+(utils/splitfa.c:20-35 of the reference: 500,000-bin trunks, a tail shorter than 1.5 trunks stays whole), n = 64,
+`psmc_boot -R 100 ... -- -N<iters> -t15 -r5 -p "4+25*2+4+6"`, exact and fast mode, with PSMC_TIMING per-iteration
+times; next to it two single `psmc -b` runs (what the reference's xargs farm would start 100 times).
+Writes JSON to argv[1] (default gpurun_out/r02_boot_timing.json)."""
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HOST = os.path.join(ROOT, "psmc_amd", "host")
+
+
+def main():
+    out_json = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r02_boot_timing.json")
+    n_rep = int(os.environ.get("BOOT_REPLICATES", "100"))
+    iters = int(os.environ.get("BOOT_ITERS", "3"))
+    from psmc_amd import sim
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hmm_params.npz"))
+    a, e, a0 = g["n64_curve.a"], g["n64_curve.e"], g["n64_curve.a0"]
+    lens = sim.human_like_lengths(30_000_000, n_seg=22)
+    segs = sim.simulate_genome(a, e, a0, lens, seed=43)
+    trunks = []
+    for s in segs:            # splitfa: 500k-bin trunks, merge a tail < 1.5 trunks into the last one
+        L, pos = len(s), 0
+        while L - pos >= 750_000:
+            trunks.append(s[pos:pos + 500_000]); pos += 500_000
+        trunks.append(s[pos:])
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    path = os.path.join(tmp, "split.psmcfa")
+    conv = np.frombuffer(b"TKN", dtype=np.uint8)
+    with open(path, "wb") as fh:
+        for i, s in enumerate(trunks):
+            fh.write((">t%d\n" % i).encode())
+            t = conv[s]
+            n60 = len(t) // 60 * 60
+            fh.write(np.concatenate([t[:n60].reshape(-1, 60), np.full((n60 // 60, 1), 10, np.uint8)], axis=1).tobytes())
+            if n60 < len(t):
+                fh.write(t[n60:].tobytes() + b"\n")
+    res = dict(workload="%d trunks (%d bins, longest %d), %d replicates, -N%d -t15 -r5 -p 4+25*2+4+6" % (len(trunks), sum(len(t) for t in trunks), max(len(t) for t in trunks), n_rep, iters), runs={})
+    args = ["-N%d" % iters, "-t15", "-r5", "-p", "4+25*2+4+6", path]
+    for mode in ("exact", "fast"):
+        env = dict(os.environ, PSMC_HIP_MODE=mode, PSMC_TIMING="1")
+        t0 = time.time()
+        r = subprocess.run([os.path.join(HOST, "psmc_boot"), "-R", str(n_rep), "-S", "1000", "-O", os.path.join(tmp, "boot_%s-%%d.psmc" % mode), "--"] + args,
+                           capture_output=True, text=True, env=env)
+        wall = time.time() - t0
+        its = [(float(m.group(1)), float(m.group(2))) for m in re.finditer(r"E-steps ([0-9.]+) ms on \d+ device\(s\), M-steps ([0-9.]+) ms", r.stderr)]
+        res["runs"]["psmc_boot_" + mode] = dict(rc=r.returncode, wall_s=round(wall, 2), per_iteration_ms=[dict(esteps=x, msteps=y) for x, y in its],
+                                               stderr_tail=r.stderr[-400:] if r.returncode else "")
+        sys.stderr.write("[time_boot] %s: %.1f s, iterations %s\n" % (mode, wall, its))
+        t0 = time.time()
+        one = subprocess.run([os.path.join(HOST, "psmc"), "-b"] + args, capture_output=True, text=True, env=dict(env, PSMC_SEED="1000"))
+        w1 = time.time() - t0
+        ts = [(float(m.group(1)), float(m.group(2))) for m in re.finditer(r"E-step ([0-9.]+) ms, M-step ([0-9.]+) ms", one.stderr)]
+        same = None
+        try:
+            same = open(os.path.join(tmp, "boot_%s-0.psmc" % mode)).read() == one.stdout
+        except Exception:
+            pass
+        res["runs"]["single_psmc_b_" + mode] = dict(rc=one.returncode, wall_s=round(w1, 2), per_iteration_ms=[dict(estep=x, mstep=y) for x, y in ts],
+                                                  replicate0_identical_to_psmc_boot=same)
+    json.dump(res, open(out_json, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -654,3 +654,48 @@ def test_fast_batch_keeps_a_plan_per_replicate(hip, golden, oracle):
     for f in fresh:
         f.close()
     es.close()
+
+
+# ------------------------------------------------------------------ multi-GPU inside the C library (one box: shards share the GPU)
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_group_exact_is_bit_identical_to_one_context(hip, golden, devices):
+    """psmc_hip_group_*: segments LPT-dealt over shards, per-shard E-steps on host threads, per-segment statistics added
+    in the GLOBAL input order -> the single-context (= khmm.c) result bit for bit, whatever the number of shards."""
+    p = golden.params("n64_curve")
+    segs = golden.segs_small + golden.segs_mid[2:]
+    one = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    one.load_segments(segs)
+    w = one.estep(p["a"], p["e"], p["a0"])
+    g = hip.HipGroup(64, devices, mode=hip.MODE_EXACT)
+    g.load_segments(segs)
+    for it in range(2):
+        r = g.estep(p["a"], p["e"], p["a0"])
+        assert bits_equal(r["A"], w["A"]) and bits_equal(r["E"], w["E"]) and bits_equal(r["A0"], w["A0"]) and r["LL"] == w["LL"]
+        assert bits_equal(r["chk"], w["chk"])
+    info = g.info()
+    assert info["n_shards"] == len(devices) and info["last_reduce"] == 3
+    assert sorted(set(info["shard_of_seg"])) == list(range(len(devices)))
+    lens = np.array([len(s) for s in segs]); load = np.array([lens[np.array(info["shard_of_seg"]) == s].sum() for s in range(len(devices))])
+    assert load.max() - load.min() <= lens.max()   # LPT: no shard is more than one segment ahead
+    g.close(); one.close()
+
+
+@pytest.mark.parametrize("devices,rccl", [([0, 0], -1), ([0], 1), ([0, 0, 0, 0], 0)])
+def test_group_fast_reduction(hip, golden, oracle, devices, rccl):
+    """Fast mode: every shard's reduction kernel leaves [A | E | LL] in HBM; shards on distinct devices are summed by
+    ONE RCCL all-reduce (here: a one-device communicator, rccl=1, exercises that path -- library open, communicator,
+    grouped call on the E-step's stream), shards sharing a GPU by the host in shard order.  Full counts and factored
+    statistics against the oracle."""
+    p = golden.params("n64_curve")
+    segs = golden.segs_mid
+    o = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    g = hip.HipGroup(64, devices, mode=hip.MODE_FAST, rccl=rccl, chunk=1024)
+    g.load_segments(segs)
+    for it in range(2):
+        check_fast(g.estep(p["a"], p["e"], p["a0"]), o)
+    assert g.info()["last_reduce"] == (1 if rccl == 1 else (2 if len(devices) > 1 else 0))
+    f = g.estep_factored(p["a"], p["e"], p["a0"])
+    lo, up = np.tril(o["A"], -1), np.triu(o["A"], 1)
+    assert relmax(f["sums"], np.stack([lo.sum(1), up.sum(1), np.diag(o["A"]).copy(), lo.sum(0), up.sum(0)])) < FAST_TOL_STATS
+    assert relmax(f["E"], o["E"]) < FAST_TOL_STATS and abs(f["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
+    g.close()

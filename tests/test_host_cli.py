@@ -367,3 +367,30 @@ def test_psmc_boot_binary_fast_mode_close(tmp_path):
         for a, b in zip(ex[1:], fa[1:]):
             assert abs(a["LK"] - b["LK"]) <= 1e-6 * abs(a["LK"])
             assert max(abs(x - y) / y for x, y in zip(b["lam"], a["lam"])) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mid_n64_N4", "small_decode_d", "small_decode_D", "small_decode_dc", "small_n128_N2"])
+def test_psmc_binary_sharded_is_byte_identical(name):
+    """PSMC_HIP_DEVICES=0,0,0: the same binary with every E-step sharded over three shards (LPT partition in C, ordered
+    per-segment sum, decoding routed to the shard that holds the segment) writes the reference's bytes."""
+    args = open(os.path.join(CLI, name + ".args")).read().split()
+    r = subprocess.run([os.path.join(HOST, "psmc")] + args, cwd=CLI, capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_DEVICES="0,0,0"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == golden_text(name)
+
+
+@pytest.mark.gpu
+def test_psmc_binary_sharded_fast_mode_equals_unsharded_tolerance():
+    """Fast mode, two shards on one GPU (host sum of the two device vectors): LK of every round within 1e-9 of the
+    one-context fast run in round 1 and 1e-6 later (the chaotic search), same layout."""
+    args = open(os.path.join(CLI, "mid_n64_N4.args")).read().split()
+    outs = []
+    for devs in ("0", "0,0"):
+        r = subprocess.run([os.path.join(HOST, "psmc")] + args, cwd=CLI, capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_MODE="fast", PSMC_HIP_DEVICES=devs))
+        assert r.returncode == 0, r.stderr
+        outs.append(_rounds(r.stdout))
+    assert len(outs[0]) == len(outs[1]) == 5
+    assert abs(outs[0][1]["LK"] - outs[1][1]["LK"]) <= 1e-9 * abs(outs[0][1]["LK"])
+    for x, y in zip(outs[0][2:], outs[1][2:]):
+        assert abs(x["LK"] - y["LK"]) <= 1e-6 * abs(x["LK"])

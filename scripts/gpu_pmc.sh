@@ -9,7 +9,7 @@ mkdir -p $R/gpurun_out/pmc
 python -c "import __graft_entry__ as g; g.build()" > $R/gpurun_out/build.log 2>&1 || { tail -30 $R/gpurun_out/build.log; exit 1; }
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc -o bench_$C -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --exact-extra 0 > $R/gpurun_out/pmc/bench_$C.json 2> $R/gpurun_out/pmc/bench_$C.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc -o bench_$C -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --exact-extra 0 --n128-extra 0 > $R/gpurun_out/pmc/bench_$C.json 2> $R/gpurun_out/pmc/bench_$C.err
   echo "bench $C exit $?"
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc -o calib_$C -- python -c "
 import sys; sys.path.insert(0, '$R')

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --cpu-sample 0 --exact-extra 0 ${BENCH_ARGS:-} > $GRAFT_REPO_ROOT/gpurun_out/prof/bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof/bench.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --cpu-sample 0 --exact-extra 0 --n128-extra 0 ${BENCH_ARGS:-} > $GRAFT_REPO_ROOT/gpurun_out/prof/bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof/bench.err
 echo "rocprof exit $?"
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; 

@@ -11,8 +11,8 @@
  * reference code it replaces.  Plain C types only; every function returns 0 or
  * a negative PSMC_HIP_E* code, never aborts, never prints.
  *
- * Conventions: n = number of hidden states (psmc's n+1; <= 128; fast mode beyond 64 needs a
- * matrix of the PSMC form, i.e. the structured sweeps);
+ * Conventions: n = number of hidden states (psmc's n+1; <= 128; fast mode beyond 64 states runs the structured
+ * sweeps for matrices of the PSMC form and psmc_hip_estep falls back to the exact kernels for any other matrix);
  * row-major FP64; a[k*n+l]=P(k->l) (khmm.h:34); e[b*n+k], b=0 hom / 1 het
  * (khmm.h:34; the missing-data row e[2][*]=1 of khmm.c:21 is implied);
  * a0[k] (khmm.h:36); observations are bytes 0/1/2 exactly as psmc_read_seq
@@ -32,7 +32,7 @@ extern "C" {
 #define PSMC_HIP_EINVAL   -1 /* bad argument (NULL, n out of range, empty segment ...) */
 #define PSMC_HIP_ENOMEM   -2 /* host or device allocation failed */
 #define PSMC_HIP_EDEVICE  -3 /* HIP runtime error; see psmc_hip_last_error() */
-#define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (n > 128; fast mode, n > 64, generic matrix) */
+#define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (n > 128; the device-resident / factored fast entry points with n > 64 and a matrix without the PSMC form) */
 #define PSMC_HIP_ESTATE   -5 /* call order violated (no segments loaded ...) */
 #define PSMC_HIP_ECONVERGE -6 /* fast mode: tile boundaries did not converge within max_rounds */
 
@@ -131,7 +131,7 @@ int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err
 /* How much repair the speculation needed: verify/repair rounds and the total
  * number of tile re-runs, forward and backward; out[0..3]. */
 int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
-/* Fast mode, matrices of the PSMC form (two rank-1 triangles, core.c:112-122), n <= 64: the E-step without the
+/* Fast mode, matrices of the PSMC form (two rank-1 triangles, core.c:112-122), any n <= 128: the E-step without the
  * N x N counts.  The EM objective needs of A only  SL_k = sum_{l<k} A[k][l],  SU_k = sum_{l>k} A[k][l],
  * DG_k = A[k][k],  CL_l = sum_{k>l} A[k][l],  CU_l = sum_{k<l} A[k][l]  (psmc_amd/host/mstep.c); they come out
  * of the backward sweep in O(N) per bin.  sums = SL | SU | DG | CL | CU (5n), E as in psmc_hip_estep (2n).

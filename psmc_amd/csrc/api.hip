@@ -845,8 +845,8 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	if (!c->want_factored && !(c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) && (rc = ensure_tables(c, true))) return rc;
 	if (c->ns == 128 && !c->use_struct)
 		return fail(c, PSMC_HIP_ENOTSUP, "fast mode beyond 64 states needs a transition matrix of the PSMC form (structured sweeps)");
-	if (c->want_factored && !(c->use_struct && c->ns == 64))
-		return fail(c, PSMC_HIP_ENOTSUP, "factored statistics need a transition matrix of the PSMC form and at most 64 states");
+	if (c->want_factored && !c->use_struct)
+		return fail(c, PSMC_HIP_ENOTSUP, "factored statistics need a transition matrix of the PSMC form");
 	if ((c->plan_dirty || c->planned_struct != c->use_struct) && (rc = plan_fast(c))) return rc;
 	EstepLaunch p;
 	fill_common(c, p, st);
@@ -995,7 +995,12 @@ extern "C" int psmc_hip_estep(psmc_hip_ctx *c, const double *a, const double *e,
 	HIPCHK(c, hipSetDevice(c->device));
 	int rc = ensure_fast_buffers(c); // d_stats must exist before the first enqueue (the plan follows stage_params)
 	if (rc) return rc;
-	return estep_fast(c, a, e, a0, A, E, A0, LL, chk);
+	rc = estep_fast(c, a, e, a0, A, E, A0, LL, chk);
+	// 65..128 states and a matrix without the two rank-1 triangles (psmc_cap_matrix, a foreign HMM): the tiled dense
+	// sweeps keep one lane per state, so the dense fallback there is the exact path (two states per lane, the matrix in
+	// LDS, one wave per segment) -- slower, any matrix, and trivially inside the fast-mode tolerance
+	if (rc == PSMC_HIP_ENOTSUP && c->ns == 128 && !c->use_struct) return estep_exact(c, a, e, a0, A, E, A0, LL, chk);
+	return rc;
 }
 
 // ---------------------------------------------------------------- batch (bootstrap replicates)

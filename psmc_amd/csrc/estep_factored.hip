@@ -20,7 +20,7 @@
 namespace psmc {
 
 struct SweepItemA { int first, count; };
-constexpr int NPLA = 4, SA = 64, NACC = 7; // SL SU DG CL CU E0 E1
+constexpr int NACC = 7; // SL SU DG CL CU E0 E1
 
 __device__ __forceinline__ int64_t readlane_i64a(int64_t v, int lane) {
 	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
@@ -28,17 +28,25 @@ __device__ __forceinline__ int64_t readlane_i64a(int64_t v, int lane) {
 	return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
 
+template <int NPL> __device__ __forceinline__ double lane_sum_a(const double (&x)[NPL]) {
+	double t = (x[0] + x[1]) + (x[2] + x[3]);
+	if constexpr (NPL == 8) t = t + ((x[4] + x[5]) + (x[6] + x[7]));
+	return t;
+}
+
 // One position p of one row: x = bt_{p+1} on entry, bt_p on exit; X = X_p.  NORM: p % NORM_EVERY == 0.
-template <bool NORM>
+// NPLA_ states per lane: 4 (up to 64 states) or 8 (up to 128, `-p "64*2"`); 16 lanes = one tile either way.
+template <bool NORM, int NPLA = 4>
 __device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const double *lds_e, const double *lds_re, int k0, int sym,
                                          const double (&X)[NPLA], double (&x)[NPLA], double (&acc)[NACC][NPLA])
 {
+	constexpr int SA = 16 * NPLA;
 	double ev[NPLA], rv[NPLA];
 	loadN<NPLA>(lds_e + sym * SA + k0, ev);
 	loadN<NPLA>(lds_re + sym * SA + k0, rv);
 	double sbv = 1.0;
 	if (NORM) { // sb_p = 1/sum(bt_{p+1})
-		sbv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
+		sbv = rcp_newton(row_sum16(lane_sum_a<NPLA>(x)));
 #pragma unroll
 		for (int i = 0; i < NPLA; ++i) ev[i] *= sbv;
 	}
@@ -75,8 +83,10 @@ __device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const doubl
 	}
 }
 // scaled partials of one tile: the constant factors of the five sums and the multiplicity
+template <int NPLA = 4>
 __device__ __forceinline__ void acc_store(const StructParN<NPLA> &sc, double mult, double (&acc)[NACC][NPLA], double *out)
 {
+	constexpr int SA = 16 * NPLA;
 #pragma unroll
 	for (int i = 0; i < NPLA; ++i) {
 		const double akk = sc.dd[i] + sc.wP[i] * sc.mP[i] + sc.wS[i] * sc.mS[i]; // a[k][k]
@@ -89,7 +99,8 @@ __device__ __forceinline__ void acc_store(const StructParN<NPLA> &sc, double mul
 
 // mode 0: tiles items[0..n) from bentry;  mode 1: flagged tiles items[0..n) from the exit vector of the tile
 // above (which becomes their bentry);  mode 2: every tile b < n whose X a forward repair rewrote, from bentry.
-__global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restrict__ sp, const double *__restrict__ e,
+template <int NPLA>
+__global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                             const double *__restrict__ re, const uint8_t *__restrict__ obs,
                                                             const Chunk *__restrict__ chunks, const SweepItemA *__restrict__ items,
                                                             int n, int mode, const double *__restrict__ f,
@@ -97,10 +108,14 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restri
                                                             double *__restrict__ part, const int *__restrict__ touch_f,
                                                             int *__restrict__ touch_b)
 {
+	constexpr int SA = 16 * NPLA;
 	__shared__ double lds_e[4 * SA], lds_re[4 * SA]; // e / 1/e rows: hom, het, 1, 1
 	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLA * m;
-	lds_e[lane] = e[lane]; lds_e[SA + lane] = e[SA + lane]; lds_e[2 * SA + lane] = 1.0; lds_e[3 * SA + lane] = 1.0;
-	lds_re[lane] = re[lane]; lds_re[SA + lane] = re[SA + lane]; lds_re[2 * SA + lane] = 1.0; lds_re[3 * SA + lane] = 1.0;
+#pragma unroll
+	for (int i = lane; i < SA; i += 64) {
+		lds_e[i] = e[i]; lds_e[SA + i] = e[SA + i]; lds_e[2 * SA + i] = 1.0; lds_e[3 * SA + i] = 1.0;
+		lds_re[i] = re[i]; lds_re[SA + i] = re[SA + i]; lds_re[2 * SA + i] = 1.0; lds_re[3 * SA + i] = 1.0;
+	}
 	__syncthreads();
 	const int slot = blockIdx.x * 4 + row;
 	int tile; bool valid = slot < n;
@@ -142,8 +157,39 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restri
 			loadN<NPLA>(fo + (int64_t)(p - 1) * SA, X[j]);
 		}
 	};
-	double Xg[4][NPLA], Xn[4][NPLA];
+	double Xg[4][NPLA];
 	load_group(max(g_hi, 0), Xg);
+	if constexpr (NPLA == 8) {
+		// 128 states: 7 x 8 accumulators and 5 x 8 constants per lane leave no room for a second X buffer -- every row
+		// is reloaded for the next group as soon as its step has used it (as in estep_fused.hip)
+		for (int gi = 0; gi < ng_max; ++gi) {
+			const unsigned w0 = *reinterpret_cast<const unsigned *>(obs + off0 + 4 * (int64_t)max(gh0 - min(gi, max(n0 - 1, 0)), 0));
+			const unsigned w1 = *reinterpret_cast<const unsigned *>(obs + off1 + 4 * (int64_t)max(gh1 - min(gi, max(n1 - 1, 0)), 0));
+			const unsigned w2 = *reinterpret_cast<const unsigned *>(obs + off2 + 4 * (int64_t)max(gh2 - min(gi, max(n2 - 1, 0)), 0));
+			const unsigned w3 = *reinterpret_cast<const unsigned *>(obs + off3 + 4 * (int64_t)max(gh3 - min(gi, max(n3 - 1, 0)), 0));
+			const unsigned w = row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
+			if (gi < ng) {
+				const int g = g_hi - gi;
+#pragma unroll
+				for (int j = 3; j >= 0; --j) {
+					const int p = 4 * g + j + 1;
+					if (p <= top && p >= lo) {
+						const int sym = (int)((w >> (8 * j)) & 3u);
+						if (j == 3) acc_step<true, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
+						else acc_step<false, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
+						if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
+					}
+					if (gi + 1 < ng) { // this row of the next group (positions 4(g-1)+j+1), clamped into the tile
+						const int pn = min(max(4 * (g - 1) + j + 1, lo), max(top, lo));
+						loadN<NPLA>(fo + (int64_t)(pn - 1) * SA, Xg[j]);
+					}
+				}
+			}
+		}
+		if (valid) acc_store<NPLA>(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
+		return;
+	}
+	double Xn[4][NPLA];
 	for (int gi = 0; gi < ng_max; ++gi) {
 		// the group's four symbols of every row: scalar loads (see estep_struct.hip row_symbols)
 		const unsigned w0 = *reinterpret_cast<const unsigned *>(obs + off0 + 4 * (int64_t)max(gh0 - min(gi, max(n0 - 1, 0)), 0));
@@ -159,8 +205,8 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restri
 				const int p = 4 * g + j + 1;
 				if (p > top || p < lo) continue;
 				const int sym = (int)((w >> (8 * j)) & 3u);
-				if (j == 3) acc_step<true>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
-				else acc_step<false>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
+				if (j == 3) acc_step<true, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
+				else acc_step<false, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
 				if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
 			}
 #pragma unroll
@@ -170,9 +216,11 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_struct(const double *__restri
 		}
 	}
 	if (valid) {
-		acc_store(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
+		acc_store<NPLA>(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
 	}
 }
+
+constexpr int NPLA = 4, SA = 64; // the checkpointed variant below is the 64-state one
 
 // The same without the X table: the forward sweep left only the checkpoints X_p, p % 8 == 0 (SWEEP_CKPT in
 // estep_struct.hip), and the row recomputes the eight X of a block from the checkpoint below it before it walks
@@ -306,10 +354,11 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 // Fixed-order two-stage sum over the tiles: stage[y][q*64+k] = sum of the tiles j = y (mod RED_ROWS), then
 // out (unpadded) = SL | SU | DG | CL | CU | E0 | E1 | LL; the HMM_TINY seeds of khmm.c:305-308 are added per
 // cell (k cells below the diagonal of row k, ...).
-constexpr int FSL = NACC * SA + 1;
-__global__ __launch_bounds__(64) void k_reduce_factored1(const double *__restrict__ part, int n_tiles,
+template <int SA>
+__global__ __launch_bounds__(SA) void k_reduce_factored1(const double *__restrict__ part, int n_tiles,
                                                            const double *__restrict__ LLpart, double *__restrict__ stage)
 {
+	constexpr int FSL = NACC * SA + 1;
 	const int k = threadIdx.x, q = blockIdx.x, y = blockIdx.y;
 	if (q < NACC) {
 		double s = 0.0;
@@ -321,9 +370,11 @@ __global__ __launch_bounds__(64) void k_reduce_factored1(const double *__restric
 		stage[(int64_t)y * FSL + NACC * SA] = s;
 	}
 }
-__global__ __launch_bounds__(64) void k_reduce_factored2(const double *__restrict__ stage, double tiny_total, int n,
+template <int SA>
+__global__ __launch_bounds__(SA) void k_reduce_factored2(const double *__restrict__ stage, double tiny_total, int n,
                                                            double *__restrict__ out)
 {
+	constexpr int FSL = NACC * SA + 1;
 	const int k = threadIdx.x, q = blockIdx.x;
 	if (q == NACC) {
 		if (k == 0) {
@@ -349,14 +400,22 @@ void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, 
 	if (p.ckpt)
 		hipLaunchKernelGGL(k_bwd_acc_ckpt, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_entry, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
+	else if (p.ns == 128)
+		hipLaunchKernelGGL(k_bwd_acc_struct<8>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
 	else
-		hipLaunchKernelGGL(k_bwd_acc_struct, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+		hipLaunchKernelGGL(k_bwd_acc_struct<4>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
 }
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_reduce_factored1, dim3(NACC + 1, RED_ROWS), dim3(64), 0, st, p.d_Cpart, p.n_chunks, p.d_LLpart, p.d_stage);
-	hipLaunchKernelGGL(k_reduce_factored2, dim3(NACC + 1), dim3(64), 0, st, p.d_stage, p.tiny_total, p.n_states, p.d_stats);
+	if (p.ns == 128) {
+		hipLaunchKernelGGL(k_reduce_factored1<128>, dim3(NACC + 1, RED_ROWS), dim3(128), 0, st, p.d_Cpart, p.n_chunks, p.d_LLpart, p.d_stage);
+		hipLaunchKernelGGL(k_reduce_factored2<128>, dim3(NACC + 1), dim3(128), 0, st, p.d_stage, p.tiny_total, p.n_states, p.d_stats);
+		return;
+	}
+	hipLaunchKernelGGL(k_reduce_factored1<64>, dim3(NACC + 1, RED_ROWS), dim3(64), 0, st, p.d_Cpart, p.n_chunks, p.d_LLpart, p.d_stage);
+	hipLaunchKernelGGL(k_reduce_factored2<64>, dim3(NACC + 1), dim3(64), 0, st, p.d_stage, p.tiny_total, p.n_states, p.d_stats);
 }
 
 } // namespace psmc

@@ -51,7 +51,7 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		if (rc) goto done_input;
 	}
 	replicate *rep = (replicate *)calloc((size_t)n_rep, sizeof(replicate));
-	const int factored = o->fast_mstep && bb->can_factor && N <= 64;
+	const int factored = o->fast_mstep && bb->can_factor && N <= 128;
 	for (int r = 0; r < n_rep; ++r) { /* serial: drand48 is one global stream, re-seeded per replicate like a fresh process */
 		replicate *R = &rep[r];
 		char fn[4096];

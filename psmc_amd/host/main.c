@@ -127,9 +127,9 @@ int main(int argc, char *argv[])
 		psmc_options_free(&o);
 		return 2;
 	}
-	/* the factored E-step goes with the O(N) objective: fast mode, n <= 64 (PSMC_FACTORED=0 keeps the full counts) */
+	/* the factored E-step goes with the O(N) objective: fast mode (PSMC_FACTORED=0 keeps the full counts) */
 	const char *fs = getenv("PSMC_FACTORED");
-	const int use_factored = o.fast_mstep && mode == PSMC_HIP_MODE_FAST && n_states <= 64 && !(fs && atoi(fs) == 0);
+	const int use_factored = o.fast_mstep && mode == PSMC_HIP_MODE_FAST && n_states <= 128 && !(fs && atoi(fs) == 0);
 	psmc_estep_backend be = {&h, hb_load, hb_estep, hb_tables, hb_decode, use_factored ? hb_estep_factored : 0, hb_error, hb_destroy, hb_posterior, hb_post_counts};
 	int status = psmc_run(&o, &be);
 	be.destroy(be.self);

@@ -238,11 +238,11 @@ def test_errors(hip):
     with pytest.raises(hip.HipError):
         hip.HipEStep(129)                        # exact mode: at most 128 states (two per lane)
     es.close()
-    es = hip.HipEStep(65, mode=hip.MODE_FAST)    # beyond 64 states the fast mode has the structured sweeps only
+    es = hip.HipEStep(65, mode=hip.MODE_FAST)    # beyond 64 states the tiled fast sweeps are the structured ones only
     a, e, a0 = random_hmm(np.random.default_rng(1), 65)
     es.load_segments([np.array([0, 1, 2, 0, 0], np.uint8)])
     with pytest.raises(hip.HipError):
-        es.estep(a, e, a0)                       # a random matrix does not have the PSMC form
+        es.estep_factored(a, e, a0)              # a random matrix does not have the PSMC form
     es.close()
 
 
@@ -374,11 +374,24 @@ def test_fast_n128(hip, golden, oracle, opts):
     for it in range(2):
         check_fast(es.estep(a, e, a0), o)
     assert es.fast_diag()["structured"]
+    for it in range(2):  # the O(N) statistics with eight states per lane (k_bwd_acc_struct<8>)
+        r = es.estep_factored(a, e, a0)
+        assert relmax(r["sums"], tri_sums(o["A"])) < FAST_TOL_STATS and relmax(r["E"], o["E"]) < FAST_TOL_STATS
+        assert abs(r["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
+        assert es.fast_diag()["back_half"] == 2
+    sel = [3, 14, 3, 9]
+    es.select(sel)
+    o2 = oracle.estep(a, e, a0, [segs[i] for i in sel])
+    r = es.estep_factored(a, e, a0)
+    assert relmax(r["sums"], tri_sums(o2["A"])) < FAST_TOL_STATS and relmax(r["E"], o2["E"]) < FAST_TOL_STATS
     es.close()
     es = hip.HipEStep(100, mode=hip.MODE_FAST, **opts)  # a sub-block of the same matrix keeps the two rank-1 triangles
     a2 = a[:100, :100] / a[:100, :100].sum(1, keepdims=True)
     es.load_segments(segs)
-    check_fast(es.estep(a2, e[:, :100], a0[:100] / a0[:100].sum()), oracle.estep(a2, e[:, :100], a0[:100] / a0[:100].sum(), segs))
+    o3 = oracle.estep(a2, e[:, :100], a0[:100] / a0[:100].sum(), segs)
+    check_fast(es.estep(a2, e[:, :100], a0[:100] / a0[:100].sum()), o3)
+    r = es.estep_factored(a2, e[:, :100], a0[:100] / a0[:100].sum())
+    assert relmax(r["sums"], tri_sums(o3["A"])) < FAST_TOL_STATS and abs(r["LL"] - o3["LL"]) <= FAST_TOL_LL * abs(o3["LL"])
     es.close()
 
 
@@ -458,6 +471,28 @@ def test_fast_learns_slow_regions(hip, golden, oracle):
         runs.append(hist)
     for (r1, _, _), (r2, _, _) in zip(*runs):
         assert bits_equal(r1["A"], r2["A"]) and bits_equal(r1["E"], r2["E"]) and r1["LL"] == r2["LL"]
+
+
+@pytest.mark.parametrize("n", [65, 100, 128])
+def test_fast_wide_generic_matrix_falls_back(hip, oracle, golden, n):
+    """Fast mode, 65..128 states, a matrix WITHOUT the PSMC form (random; a capped one, psmc_cap_matrix aux.c:115-127):
+    psmc_hip_estep runs the exact kernels instead of refusing -- any matrix, inside the fast tolerance (bit-exact)."""
+    rng = np.random.default_rng(500 + n)
+    a, e, a0 = random_hmm(rng, n)
+    segs = [rng.choice(3, size=L, p=[0.86, 0.1, 0.04]).astype(np.uint8) for L in (1, 64, 65, 700, 3000)]
+    es = hip.HipEStep(n, mode=hip.MODE_FAST)
+    es.load_segments(segs)
+    r = es.estep(a, e, a0)
+    o = oracle.estep(a, e, a0, segs)
+    assert bits_equal(r["A"], o["A"]) and bits_equal(r["E"], o["E"]) and r["LL"] == o["LL"]
+    if n == 128:  # and the structured path is back as soon as the matrix has the form again
+        g, k = golden.n128, "n128_curve"
+        ac = g[k + ".a"].copy(); ac[:, 90] = ac[:, 90:].sum(1); ac[:, 91:] = 0.0  # capped at state 90
+        check_fast(es.estep(ac, g[k + ".e"], g[k + ".a0"]), oracle.estep(ac, g[k + ".e"], g[k + ".a0"], segs))
+        assert not es.fast_diag()["structured"]
+        check_fast(es.estep(g[k + ".a"], g[k + ".e"], g[k + ".a0"]), oracle.estep(g[k + ".a"], g[k + ".e"], g[k + ".a0"], segs))
+        assert es.fast_diag()["structured"]
+    es.close()
 
 
 def test_fast_deterministic_and_selection(hip, golden, oracle):

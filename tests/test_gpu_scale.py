@@ -102,6 +102,9 @@ def test_config5_full_size_n128(hip, golden, genome):
     check_totals(r, segs)
     r2 = fa.estep(a, e, a0)   # learned plan, same parameters
     assert relmax(r2["A"], r["A"]) < TOL_STATS and abs(r2["LL"] - r["LL"]) <= TOL_LL * abs(r["LL"])
+    f = fa.estep_factored(a, e, a0)   # the O(N) statistics (what the psmc binary uses in fast mode), eight states per lane
+    assert relmax(f["sums"], tri_sums(r["A"])) < TOL_STATS and relmax(f["E"], r["E"]) < TOL_STATS
+    assert abs(f["LL"] - r["LL"]) <= TOL_LL * abs(r["LL"])
     half, other = list(range(0, 90, 2)), list(range(1, 90, 2))
     fa.select(half); ra = fa.estep(a, e, a0)
     fa.select(other); rb = fa.estep(a, e, a0)

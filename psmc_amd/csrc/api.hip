@@ -1055,8 +1055,26 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	c->last_batch_groups = 0;
 	std::vector<int32_t> wseg, wpar; std::vector<int64_t> wtab; std::vector<int> first;
 	std::vector<double> hp, lk;
+	{ // the groups are known before the first launch: size the tables once for the largest of them (no re-allocation in the loop)
+		int64_t worst = 0; size_t worst_entries = 0; int worst_reps = 0;
+		for (int r0 = 0; r0 < n_rep;) {
+			if (reps[r0].bins > cap) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: the tables of one replicate do not fit the device memory (batch_bins)");
+			int r1 = r0; int64_t bins = 0; size_t ent = 0;
+			while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ent += (reps[r1].work.size() + align - 1) / align * align; ++r1; }
+			worst = std::max(worst, bins); worst_entries = std::max(worst_entries, ent); worst_reps = std::max(worst_reps, r1 - r0);
+			r0 = r1;
+		}
+		if ((rc = ensure_tables(c, true, worst))) return rc;
+		if ((rc = ensure_seg_outputs(c, (int)worst_entries))) return rc;
+		if (c->bw_cap < worst_entries) {
+			if ((rc = dev_alloc(c, &c->d_bw_seg, worst_entries))) return rc;
+			if ((rc = dev_alloc(c, &c->d_bw_par, worst_entries))) return rc;
+			if ((rc = dev_alloc(c, &c->d_bw_tab, worst_entries))) return rc;
+			c->bw_cap = worst_entries;
+		}
+		if (c->bpar_cap < (size_t)worst_reps) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)worst_reps * PL))) return rc; c->bpar_cap = (size_t)worst_reps; }
+	}
 	for (int r0 = 0; r0 < n_rep;) {
-		if (reps[r0].bins > cap) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: the tables of one replicate do not fit the device memory (batch_bins)");
 		int r1 = r0; int64_t bins = 0;
 		while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ++r1; }
 		const int ng = r1 - r0;
@@ -1068,15 +1086,6 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 			while (wseg.size() % align) { wseg.push_back(-1); wpar.push_back(r - r0); wtab.push_back(0); }
 		}
 		const int nw = (int)wseg.size();
-		if ((rc = ensure_tables(c, true, run))) return rc;
-		if ((rc = ensure_seg_outputs(c, nw))) return rc;
-		if (c->bw_cap < (size_t)nw) {
-			if ((rc = dev_alloc(c, &c->d_bw_seg, (size_t)nw))) return rc;
-			if ((rc = dev_alloc(c, &c->d_bw_par, (size_t)nw))) return rc;
-			if ((rc = dev_alloc(c, &c->d_bw_tab, (size_t)nw))) return rc;
-			c->bw_cap = (size_t)nw;
-		}
-		if (c->bpar_cap < (size_t)ng) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)ng * PL))) return rc; c->bpar_cap = (size_t)ng; }
 		hp.resize((size_t)ng * PL);
 		for (int r = r0; r < r1; ++r) (void)fill_params(c, a + (size_t)r * n * n, e + (size_t)r * 2 * n, a0 + (size_t)r * n, hp.data() + (size_t)(r - r0) * PL);
 		HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -606,7 +606,7 @@ def _traj_params(n_sets):
     return [hostlib.hmm_params(tj["pattern"], r["params"]) for r in tj["rounds"][1:1 + n_sets]]
 
 
-@pytest.mark.parametrize("batch_bins", [0, 40000])
+@pytest.mark.parametrize("batch_bins", [0, 80000])
 def test_exact_batch_is_bit_identical_to_separate_calls(hip, golden, batch_bins):
     """psmc_hip_estep_batch, exact mode: 8 replicates (own parameters, own bootstrap multiset with repeats) in one grid
     per kernel == 8 x (psmc_hip_select + psmc_hip_estep), bit for bit; with a table budget that forces several launch

@@ -134,6 +134,13 @@ template <class T> static int dev_alloc(psmc_hip_ctx *c, T **p, size_t n)
 	if (n == 0) n = 1;
 	hipError_t e = hipMalloc((void **)p, n * sizeof(T));
 	if (e != hipSuccess) { *p = nullptr; return fail(c, PSMC_HIP_ENOMEM, "hipMalloc", e); }
+	// PSMC_HIP_POISON=1 (tests): fresh device memory is usually zero, recycled memory is not -- fill every allocation with
+	// 0xFF bytes (NaN as double, -1 as int) so that anything that depends on memory nobody wrote shows up at once.
+	// PSMC_HIP_POISON=vary: a different finite garbage value per allocation (bytes 0x3B..0x42: doubles from 1e-23 to 1e5),
+	// so that two contexts with the same call history disagree if anything reads memory nobody wrote
+	static const char *poison = getenv("PSMC_HIP_POISON");
+	static int poison_count = 0;
+	if (poison) (void)hipMemset(*p, strcmp(poison, "vary") == 0 ? 0x3B + (poison_count++ % 8) : 0xFF, n * sizeof(T));
 	return 0;
 }
 
@@ -481,7 +488,9 @@ static void collect_timing(psmc_hip_ctx *c)
 	float t;
 	c->timing_valid = true;
 	auto el = [&](hipEvent_t a, hipEvent_t b, double &out) {
-		if (hipEventElapsedTime(&t, a, b) == hipSuccess) out = t; else { out = 0; c->timing_valid = false; }
+		// an event this path never recorded makes the call fail: that is expected here, and must not stay behind as the
+		// thread's "last error" for the next launch to trip over
+		if (hipEventElapsedTime(&t, a, b) == hipSuccess) out = t; else { out = 0; c->timing_valid = false; (void)hipGetLastError(); }
 	};
 	el(c->ev[0], c->ev[4], c->last_ms[0]);
 	c->last_ms[5] = c->last_ms[6] = 0;

@@ -586,6 +586,7 @@ static void launch_expect(const EstepLaunch &p, hipStream_t st, int redo)
 int launch_fast(const EstepLaunch &p, FastReport *rep)
 {
 	if (p.n_chunks <= 0) return 0;
+	(void)hipGetLastError(); // the value returned at the end must be about THESE launches
 	const dim3 g(p.n_chunks), b(64);
 	const bool ov = p.overlap != 0;
 	hipStream_t sm = p.stream, sa = ov ? p.stream2 : p.stream, sx = ov ? p.stream3 : p.stream;

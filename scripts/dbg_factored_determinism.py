@@ -17,7 +17,11 @@ def beq(x, y):
     return np.array_equal(np.ascontiguousarray(x).view(np.uint64), np.ascontiguousarray(y).view(np.uint64))
 
 
-for opts in (dict(chunk=768, warmup=256, group_cap=200000), dict(chunk=768, warmup=256, group_cap=200000, ckpt=0), dict(chunk=768, warmup=256, learn=0), dict()):
+base = dict(chunk=768, warmup=256, group_cap=200000)
+variants = [base, dict(base, ckpt=0), dict(base, learn=0), dict(base, kc_min=0), dict(base, walk_impl=0), dict(base, two_phase=0), dict(base, overlap=0), dict(base, fuse=0), dict()]
+if len(sys.argv) > 1:
+    variants = variants[:int(sys.argv[1])]
+for opts in variants:
     print("== opts", opts)
     # (1) two fresh contexts, same history: estep, factored, estep, factored ...
     ctx = []

@@ -55,7 +55,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * "expect_impl" (0 VALU, 1 MFMA f64), "structured" (1 auto / 0 always dense sweeps),
  * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront), "learn" (1: tiles
  * that needed a repair are glued to their neighbour for the following E-steps of this context;
- * results then depend on the call history within the stated tolerance), "group_cap" (bins), "fuse" (1, default: with the
+ * results then depend on the call history within the stated tolerance), "warm_shift" (2, default: a tile that needed a
+ * repair is first given a speculative warm-up of warmup << warm_shift bins of its own, and is glued only if that fails
+ * too; 0: glue at once), "group_cap" (bins), "fuse" (1, default: with the
  * structured sweeps and up to 64 states the backward sweep feeds the counts' matrix instructions directly -- bt never
  * stored, half the HBM traffic; 0: bt table + separate counts kernel), "ckpt" (1, default:
  * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table),

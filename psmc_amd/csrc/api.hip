@@ -42,6 +42,8 @@ struct psmc_hip_ctx {
 	int ckpt = 1;              // "ckpt": factored statistics recompute X from checkpoints every 8 positions instead of reading the table
 	int fuse = 1;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip): structured matrices, up to 64 states
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
+	int warm_shift = 2;        // "warm_shift": before that, once, give such a tile a warm-up of warmup << warm_shift bins (0: glue at once)
+	bool chunks_dirty = false; // a tile's warm-up changed: d_chunks is stale
 	int group_cap = 131072;    // "group_cap": longest run of glued tiles, in bins
 	int *d_items = nullptr;    // items_f | items_b | ritems_f | ritems_b, 2*n_chunks ints each
 	int *h_ritems = nullptr;   // pinned + device-mapped, 2 * 2*n_chunks ints
@@ -140,7 +142,10 @@ template <class T> static int dev_alloc(psmc_hip_ctx *c, T **p, size_t n)
 	// so that two contexts with the same call history disagree if anything reads memory nobody wrote
 	static const char *poison = getenv("PSMC_HIP_POISON");
 	static int poison_count = 0;
-	if (poison) (void)hipMemset(*p, strcmp(poison, "vary") == 0 ? 0x3B + (poison_count++ % 8) : 0xFF, n * sizeof(T));
+	if (poison) { // the fill runs on the null stream, the kernels on non-blocking streams: finish it before anybody writes results there
+		(void)hipMemset(*p, strcmp(poison, "vary") == 0 ? 0x3B + (poison_count++ % 8) : 0xFF, n * sizeof(T));
+		(void)hipDeviceSynchronize();
+	}
 	return 0;
 }
 
@@ -259,6 +264,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "max_rounds") c->max_rounds = (int)v;
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
+	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
 	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
 	else if (k == "lanes8") { c->lanes8 = v != 0 ? 1 : 0; }
@@ -660,7 +666,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		for (int32_t lo = 1; lo <= c->L[s]; lo += T) {
 			Chunk ch;
 			ch.off = c->off[s]; ch.L = c->L[s]; ch.lo = lo; ch.hi = std::min(c->L[s], lo + T - 1); ch.mult = c->mult[w];
-			ch.flags = 0; ch.pad_ = 0;
+			ch.flags = 0; ch.wsh = 0;
 			if (ch.lo - c->warmup <= 1) ch.flags |= CHUNK_ANCHOR_F;
 			if ((int64_t)ch.hi + c->warmup + 1 >= ch.L) ch.flags |= CHUNK_ANCHOR_B;
 			if (ch.hi == ch.L) ch.flags |= CHUNK_LAST;
@@ -695,7 +701,7 @@ static int plan_fast(psmc_hip_ctx *c)
 	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub_used * 3 * c->ns))) return rc;
 	if ((rc = ensure_fast_buffers(c))) return rc;
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
-	c->plan_dirty = false;
+	c->plan_dirty = false; c->chunks_dirty = false;
 	return 0;
 }
 
@@ -721,7 +727,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
 		const bool pb = two_phase && e - b == 1 && odd[b]; // odd => a predecessor tile exists in the segment
 		if (pb) fwd_b[b] = 1;
-		kf.push_back({key(l.hi - std::max(1, h.lo - W) + 1, e - b, pb), {b, e - b}});
+		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, e - b, pb), {b, e - b}});
 		b = e;
 	}
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
@@ -733,7 +739,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 		// from above: the tile over it must exist in the segment and own a transition (it leaves an exit vector)
 		const bool pb = two_phase_bwd && e - b == 1 && odd[b] && b + 1 < nc && c->chunks[b + 1].off == lo.off && c->chunks[b + 1].lo < c->chunks[b + 1].L;
 		if (pb) from_above[b] = 1;
-		kb.push_back({key(std::min(top.hi + W + 1, top.L) - lo.lo, e - b, pb), {b, e - b}});
+		kb.push_back({key(std::min(top.hi + chunk_warm_b(top, W) + 1, top.L) - lo.lo, e - b, pb), {b, e - b}});
 		b = e;
 	}
 	std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
@@ -832,13 +838,27 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 
 // Tiles a repair round had to touch start where the chain forgets slowly: glue each to the neighbour it
 // depends on, so that from the next E-step on one row walks the region while the sweep is still running.
+// First a longer warm-up of its own ("warm_shift": warmup << shift bins, 16 K by default -- the chain forgets in 2-4 k bins
+// almost everywhere and in 5-15 k in most of the rest, and a warm-up costs 21 vector instructions per bin against the
+// 1360 per bin of a transfer matrix), and only a tile that fails again is glued.
 static void learn_groups(psmc_hip_ctx *c)
 {
 	const int nc = (int)c->chunks.size();
+	const int step = c->warm_shift;
 	for (int b : c->flagged_f)
-		if (b > 0 && b < nc && !c->glue_f[b] && c->chunks[b - 1].off == c->chunks[b].off) { c->glue_f[b] = 1; c->items_dirty = true; }
+		if (b > 0 && b < nc && !c->glue_f[b] && c->chunks[b - 1].off == c->chunks[b].off) {
+			Chunk &ch = c->chunks[b];
+			if (step > 0 && (ch.wsh & 15) == 0 && ch.lo - c->warmup > 1) { ch.wsh |= step; c->chunks_dirty = true; } // not yet tried, and there is sequence to warm up on
+			else c->glue_f[b] = 1;
+			c->items_dirty = true;
+		}
 	for (int b : c->flagged_b)
-		if (b >= 0 && b + 1 < nc && !c->glue_b[b] && c->chunks[b + 1].off == c->chunks[b].off) { c->glue_b[b] = 1; c->items_dirty = true; }
+		if (b >= 0 && b + 1 < nc && !c->glue_b[b] && c->chunks[b + 1].off == c->chunks[b].off) {
+			Chunk &ch = c->chunks[b];
+			if (step > 0 && ((ch.wsh >> 4) & 15) == 0 && (int64_t)ch.hi + c->warmup + 1 < ch.L) { ch.wsh |= step << 4; c->chunks_dirty = true; }
+			else c->glue_b[b] = 1;
+			c->items_dirty = true;
+		}
 }
 
 static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *d_out,
@@ -864,6 +884,11 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	// 1: both directions; 2: backward only (the fused back half runs as two launches anyway, so its second list can start
 	// from the exit vectors of the first at no cost in scheduling, and half of the backward warm-up pass disappears)
 	const bool two_phase = c->two_phase == 1 && p.fused >= 1, two_phase_bwd = c->two_phase >= 1 && p.fused == 1;
+	if (c->chunks_dirty) { // learned warm-ups (learn_groups) reach the device before the next launch reads them
+		HIPCHK(c, hipStreamSynchronize(st));
+		HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * c->chunks.size(), hipMemcpyHostToDevice));
+		c->chunks_dirty = false;
+	}
 	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase, two_phase_bwd))) return rc;
 	p.n_B_f = c->n_B_f; p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;
@@ -1164,7 +1189,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->lanes8 = c->lanes8;
 		k->fuse_order = c->fuse_order; k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
-		k->learn = c->learn; k->group_cap = c->group_cap;
+		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];

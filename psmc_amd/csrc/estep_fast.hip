@@ -652,6 +652,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0 - p.n_B_b);
 		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles (phase A)
 		if (p.fused == 2) {
+			// X (and the start vectors) of the tiles of forward runs: they are recomputed on the walk stream after the
+			// walks / chains, and a tile of a forward run is an ordinary single tile of THIS pass.  (Missing until round 2:
+			// the pass could read such a tile's X before it was written; found with PSMC_HIP_POISON=vary.)
+			if (lw && ov) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
 			if (p.n_B_f > 0 && ov) (void)hipStreamWaitEvent(sa, p.evx[10], 0); // X of the phase-B tiles
 			if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
 			launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0);

@@ -204,7 +204,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 		else loadN<NPL>(fo + (int64_t)(c.lo - 2) * S, x);
 		p_first = c.lo;
 	} else {
-		const int ws = max(1, c.lo - W);
+		const int ws = max(1, c.lo - chunk_warm_f(c, W));
 		loadN<NPL>(a0 + k0, x);
 		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
 			double ev[NPL];
@@ -360,7 +360,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 		else loadN<NPL>(bexit + (int64_t)(t_top + 1) * S + k0, x);
 		p_first = cur.top;
 	} else {
-		const int q = min(c.hi + W + 1, L); // B_q := 1
+		const int q = min(c.hi + chunk_warm_b(c, W) + 1, L); // B_q := 1
 		loadN<NPL>(lds_e + ((int)o[q - 1] & 3) * S + k0, x);
 		p_first = q - 1;
 	}
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 		StructPar1 s1; s1.mS = sp[lane]; s1.wS = sp[128 + lane]; s1.mP = sp[64 + lane]; s1.wP = sp[192 + lane]; s1.dd = sp[256 + lane];
 		double x = a0[lane];
 		int p_first;
-		const int ws = max(1, c.lo - W);
+		const int ws = max(1, c.lo - chunk_warm_f(c, W));
 		if (ws == 1) { x *= walk_ev((int)o[0] & 3, e0, e1); p_first = 2; } else p_first = ws;
 		int tile = c.lo >= p_first ? it.first : it.first + 1, next_lo = c.lo >= p_first ? c.lo : c.lo + T;
 		// groups of four positions aligned to p % 4 == 1 .. 0 (indices 4g .. 4g+3): the last one normalises
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 		if (top < lo) return;
 		const uint8_t *o = obs + c.off;
 		StructPar1 s1; s1.mS = sp[192 + lane]; s1.wS = sp[64 + lane]; s1.mP = sp[128 + lane]; s1.wP = sp[lane]; s1.dd = sp[256 + lane];
-		const int q = min(c.hi + W + 1, L); // B_q := 1
+		const int q = min(c.hi + chunk_warm_b(c, W) + 1, L); // B_q := 1
 		double x = walk_ev((int)o[q - 1] & 3, e0, e1);
 		const int p_first = q - 1;
 		const int g_first = (p_first - 1) >> 2, g_last = (p_low - 1) >> 2;

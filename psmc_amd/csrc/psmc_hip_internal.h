@@ -18,8 +18,11 @@ struct Chunk {
 	int32_t hi;   // last position owned by the tile
 	int32_t mult; // how many times the segment occurs in the selection (bootstrap)
 	int32_t flags; // CHUNK_*
-	int32_t pad_;
+	int32_t wsh;  // structured sweeps: the tile's speculative warm-up is warmup << shift; bits 0-3 forward, 4-7 backward
 };
+// a tile whose speculation failed gets a longer warm-up before it is glued to its neighbour (api.hip learn_groups)
+__host__ __device__ inline int chunk_warm_f(const Chunk &c, int W) { return W << (c.wsh & 15); }
+__host__ __device__ inline int chunk_warm_b(const Chunk &c, int W) { return W << ((c.wsh >> 4) & 15); }
 constexpr int CHUNK_ANCHOR_F = 1; // forward speculation started at the true segment start: exact
 constexpr int CHUNK_ANCHOR_B = 2; // backward speculation started at the true segment end: exact
 constexpr int CHUNK_LAST = 4;     // last tile of its segment

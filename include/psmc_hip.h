@@ -48,14 +48,14 @@ const char *psmc_hip_strerror(int err);
 const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 
 /* Tunables (all optional): "chunk" (fast-mode tile length in bins, 0 = auto),
- * "warmup" (speculative overlap in bins), "warm_tol" (tile-boundary agreement
+ * "warmup" (speculative overlap in bins, default 3072), "warm_tol" (tile-boundary agreement
  * demanded by verify/repair), "max_rounds", "overlap" (1: forward chain, backward
  * chain and the early counts pass on three streams; 0: one stream), "target_waves", "n_sub" (expect
  * waves per tile), "rep_impl" (0 ds_bpermute, 1 v_permlane*_swap),
  * "expect_impl" (0 VALU, 1 MFMA f64), "structured" (1 auto / 0 always dense sweeps),
  * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront), "learn" (1: tiles
  * that needed a repair are glued to their neighbour for the following E-steps of this context;
- * results then depend on the call history within the stated tolerance), "warm_shift" (2, default: a tile that needed a
+ * results then depend on the call history within the stated tolerance), "warm_shift" (1, default: a tile that needed a
  * repair is first given a speculative warm-up of warmup << warm_shift bins of its own, and is glued only if that fails
  * too; 0: glue at once), "group_cap" (bins), "fuse" (1, default: with the
  * structured sweeps and up to 64 states the backward sweep feeds the counts' matrix instructions directly -- bt never

@@ -21,7 +21,7 @@ struct psmc_hip_ctx {
 	int n = 0, ns = 64, device = 0, mode = PSMC_HIP_MODE_EXACT; // ns: states padded to 64 or 128
 	std::string err;
 	// options
-	int chunk = 0, warmup = 4096, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
+	int chunk = 0, warmup = 3072, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
 	double warm_tol = 1e-12;
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
 	bool struct_tiles_set = false; // the caller chose struct_tiles: no adaptation to small inputs
@@ -42,7 +42,7 @@ struct psmc_hip_ctx {
 	int ckpt = 1;              // "ckpt": factored statistics recompute X from checkpoints every 8 positions instead of reading the table
 	int fuse = 1;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip): structured matrices, up to 64 states
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
-	int warm_shift = 2;        // "warm_shift": before that, once, give such a tile a warm-up of warmup << warm_shift bins (0: glue at once)
+	int warm_shift = 1;        // "warm_shift": before that, once, give such a tile a warm-up of warmup << warm_shift bins (0: glue at once)
 	bool chunks_dirty = false; // a tile's warm-up changed: d_chunks is stale
 	int group_cap = 131072;    // "group_cap": longest run of glued tiles, in bins
 	int *d_items = nullptr;    // items_f | items_b | ritems_f | ritems_b, 2*n_chunks ints each
@@ -838,9 +838,11 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 
 // Tiles a repair round had to touch start where the chain forgets slowly: glue each to the neighbour it
 // depends on, so that from the next E-step on one row walks the region while the sweep is still running.
-// First a longer warm-up of its own ("warm_shift": warmup << shift bins, 16 K by default -- the chain forgets in 2-4 k bins
-// almost everywhere and in 5-15 k in most of the rest, and a warm-up costs 21 vector instructions per bin against the
-// 1360 per bin of a transfer matrix), and only a tile that fails again is glued.
+// First a longer warm-up of its own ("warm_shift": warmup << shift bins, 6144 by default -- the chain forgets in 2-4 k bins
+// almost everywhere, and a warm-up costs 21 vector instructions per bin against the 1360 per bin of a transfer matrix),
+// and only a tile that fails again is glued.  Measured on the benchmark genome (profiles/r02_warm_shift_ab.json): 3072 +
+// one doubling beats the 4096 of round 1 by 3-4 % (full counts) and 12 % (factored statistics); longer second
+// warm-ups (16 K, 32 K) cost more than the runs they avoid, because a 20 k-step item is as long as the whole phase.
 static void learn_groups(psmc_hip_ctx *c)
 {
 	const int nc = (int)c->chunks.size();

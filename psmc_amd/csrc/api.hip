@@ -788,7 +788,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 	//   d_items + 12nc: wl_f (2nc) | wl_b (2nc) | kc tiles (4nc: KcTile) | runs (4nc + : KcRun)
 	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b;
 	c->n_wl_f = c->n_wl_b = 0;
-	const bool chains = c->kc_min >= 2 && c->ns == 64;
+	const bool chains = c->kc_min >= 2; // 64 states: one state per lane in the chain kernel; 128: two
 	auto add_runs = [&](const std::vector<std::pair<long long, std::pair<int, int>>> &k, int n_long, bool bwd) {
 		int &nw = bwd ? c->n_wl_b : c->n_wl_f;
 		std::vector<int> &rv = bwd ? runs_b : runs_f;
@@ -826,7 +826,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 		std::vector<int> runs(runs_f); runs.insert(runs.end(), runs_b.begin(), runs_b.end());
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)16 * nc, kc.data(), sizeof(int) * kc.size(), hipMemcpyHostToDevice));
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)20 * nc, runs.data(), sizeof(int) * runs.size(), hipMemcpyHostToDevice));
-		const size_t need = (size_t)c->n_kc * (4096 + 64);
+		const size_t need = (size_t)c->n_kc * ((size_t)c->ns * c->ns + c->ns); // the matrices, then one exponent per column
 		if (need > c->kcol_cap) { int rc; if ((rc = dev_alloc(c, &c->d_Kcol, need))) return rc; c->kcol_cap = need; }
 	}
 	c->items_dirty = false;
@@ -908,7 +908,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_wl_f = c->d_items + 12 * (size_t)p.n_chunks; p.d_wl_b = c->d_items + 14 * (size_t)p.n_chunks; p.n_wl_f = c->n_wl_f; p.n_wl_b = c->n_wl_b;
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
-	p.d_Kcol = c->d_Kcol; p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * 4096 : nullptr; p.stream5 = c->stream5;
+	p.d_Kcol = c->d_Kcol; p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * c->ns * c->ns : nullptr; p.stream5 = c->stream5;
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;

@@ -504,17 +504,18 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 // with powers of two only (exact) and carrying the exponent.
 struct KcTile { int tile, dir; }; // dir 0: forward (lo..hi), 1: backward (top..lo)
 
+template <int NPL>
 __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                       const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                       const KcTile *__restrict__ kc, double *__restrict__ Kcol,
                                                       double *__restrict__ Kexp)
 {
-	constexpr int NPL = 4, S = 64;
+	constexpr int S = 16 * NPL, BPT = S / 4; // S unit vectors per tile, four per wave: BPT blocks per tile
 	__shared__ double lds_e[4 * S];
 	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
 	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
-	const int j = blockIdx.x >> 4, col = 4 * (blockIdx.x & 15) + (lane >> 4);
+	const int j = blockIdx.x / BPT, col = 4 * (blockIdx.x % BPT) + (lane >> 4);
 	// the transfer matrices head the longest dependency chain of the first phase (columns -> chain -> run tiles ->
 	// the fused back half may start): ahead of the bulk sweeps, behind the walks
 	__builtin_amdgcn_s_setprio(2);
@@ -550,8 +551,8 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 	}
-	storeN<NPL>(Kcol + ((int64_t)j * 64 + col) * 64 + k0, x);
-	if (m == 0) Kexp[(int64_t)j * 64 + col] = (double)E;
+	storeN<NPL>(Kcol + ((int64_t)j * S + col) * S + k0, x);
+	if (m == 0) Kexp[(int64_t)j * S + col] = (double)E;
 }
 
 // run r: forward (r < n_f): entry[first+1 .. first+count-1] from entry[first];  backward: bentry[first+count-2 .. first]
@@ -563,42 +564,94 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 }
 struct KcRun { int first, count, kc0, pad; }; // kc0: index of the run's first transfer matrix in Kcol
 
+// one-state-per-lane step for PER * 64 states: lane L holds states L and (PER == 2) L + 64
+template <int PER>
+__device__ __forceinline__ void struct_step1n(const StructPar1 (&c)[PER], double (&x)[PER], const WaveScanMasks &m)
+{
+	if constexpr (PER == 1) { x[0] = struct_step1(c[0], x[0], m); }
+	else {
+		// inclusive suffix / prefix sums over 128 states: each half scans itself, the lower half adds the total of
+		// the upper one to its suffix sums, the upper half the total of the lower one to its prefix sums
+		const double s1 = wave_suffix_incl(x[1] * c[1].mS, m), s0 = wave_suffix_incl(x[0] * c[0].mS, m);
+		const double p0 = wave_prefix_incl_bc(x[0] * c[0].mP), p1 = wave_prefix_incl_bc(x[1] * c[1].mP);
+		const double tot1 = readlane_f64(s1, 0), tot0 = readlane_f64(p0, 63);
+		const double y0 = __builtin_fma(c[0].wS, s0 + tot1, __builtin_fma(c[0].wP, p0, c[0].dd * x[0]));
+		const double y1 = __builtin_fma(c[1].wS, s1, __builtin_fma(c[1].wP, p1 + tot0, c[1].dd * x[1]));
+		x[0] = y0; x[1] = y1;
+	}
+}
+
+template <int PER>
 __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ runs, int n_f, const double *__restrict__ Kcol,
                                                         const double *__restrict__ Kexp, const double *__restrict__ sp,
                                                         const double *__restrict__ e, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, double *__restrict__ entry,
                                                         double *__restrict__ bentry)
 {
+	constexpr int S = 64 * PER;
 	const int lane = threadIdx.x;
 	const bool fwd = (int)blockIdx.x < n_f;
 	const KcRun r = runs[blockIdx.x];
 	double *vec = fwd ? entry : bentry;
 	int t = fwd ? r.first : r.first + r.count - 1;
-	double x = vec[(int64_t)t * 64 + lane];
+	double x[PER];
 	const WaveScanMasks wm = wave_scan_masks(lane);
-	StructPar1 s1; s1.mS = sp[192 + lane]; s1.wS = sp[64 + lane]; s1.mP = sp[128 + lane]; s1.wP = sp[lane]; s1.dd = sp[256 + lane]; // backward
-	const double e0 = e[lane], e1 = e[64 + lane];
+	StructPar1 s1[PER]; // backward roles: mS = c, wS = R, mP = qa, wP = P (sp = P | R | qa | c | dd, S each)
+	double e0[PER], e1[PER];
+#pragma unroll
+	for (int q = 0; q < PER; ++q) {
+		const int k = lane + 64 * q;
+		x[q] = vec[(int64_t)t * S + k];
+		s1[q].mS = sp[3 * S + k]; s1[q].wS = sp[S + k]; s1[q].mP = sp[2 * S + k]; s1[q].wP = sp[k]; s1[q].dd = sp[4 * S + k];
+		e0[q] = e[k]; e1[q] = e[S + k];
+	}
 	for (int q = 0; q + 1 < r.count; ++q) {
-		const int64_t kb = (int64_t)(r.kc0 + q) * 64;
-		const double ex = Kexp[kb + lane];
-		const double emax = wave_max_f64(x > 0.0 ? ex : -1e300);
-		const double xs = x > 0.0 ? __builtin_amdgcn_ldexp(x, (int)(ex - emax)) : 0.0;
-		double y = 0.0;
-		for (int k = 0; k < 64; ++k) y = __builtin_fma(readlane_f64(xs, k), Kcol[(kb + k) * 64 + lane], y);
-		y *= rcp_newton(first_lane_f64(wave_sum_nat(y)));
+		const int64_t kb = (int64_t)(r.kc0 + q) * S;
+		double ex[PER], xs[PER], y[PER], em = -1e300;
+#pragma unroll
+		for (int h = 0; h < PER; ++h) { ex[h] = Kexp[kb + lane + 64 * h]; em = fmax(em, x[h] > 0.0 ? ex[h] : -1e300); }
+		const double emax = wave_max_f64(em);
+#pragma unroll
+		for (int h = 0; h < PER; ++h) { xs[h] = x[h] > 0.0 ? __builtin_amdgcn_ldexp(x[h], (int)(ex[h] - emax)) : 0.0; y[h] = 0.0; }
+#pragma unroll
+		for (int hs = 0; hs < PER; ++hs)
+			for (int k = 0; k < 64; ++k) {
+				const double v = readlane_f64(xs[hs], k);
+				const double *row = Kcol + (kb + 64 * hs + k) * S + lane;
+#pragma unroll
+				for (int h = 0; h < PER; ++h) y[h] = __builtin_fma(v, row[64 * h], y[h]);
+			}
+		{
+			double tot = y[0];
+			if constexpr (PER == 2) tot += y[1];
+			const double inv = rcp_newton(first_lane_f64(wave_sum_nat(tot)));
+#pragma unroll
+			for (int h = 0; h < PER; ++h) y[h] *= inv;
+		}
 		if (!fwd) { // the tile's last steps p* .. lo with the sweep's own scaling: bt_lo as the sweep leaves it
 			const Chunk c = chunks[t];
 			const int top = min(c.hi, c.L - 1), ps = min((c.lo + 3) & ~3, top);
 			const uint8_t *o = obs + c.off;
 			for (int pp = ps; pp >= c.lo; --pp) {
-				double ev = walk_ev((int)o[pp - 1] & 3, e0, e1);
-				if ((pp & 3) == 0) ev *= rcp_newton(first_lane_f64(wave_sum_nat(y)));
-				y = struct_step1(s1, y, wm) * ev;
+				const int sym = (int)o[pp - 1] & 3;
+				double ev[PER];
+#pragma unroll
+				for (int h = 0; h < PER; ++h) ev[h] = walk_ev(sym, e0[h], e1[h]);
+				if ((pp & 3) == 0) {
+					double tot = y[0];
+					if constexpr (PER == 2) tot += y[1];
+					const double inv = rcp_newton(first_lane_f64(wave_sum_nat(tot)));
+#pragma unroll
+					for (int h = 0; h < PER; ++h) ev[h] *= inv;
+				}
+				struct_step1n<PER>(s1, y, wm);
+#pragma unroll
+				for (int h = 0; h < PER; ++h) y[h] *= ev[h];
 			}
 		}
 		t += fwd ? 1 : -1;
-		vec[(int64_t)t * 64 + lane] = y;
-		x = y;
+#pragma unroll
+		for (int h = 0; h < PER; ++h) { vec[(int64_t)t * S + lane + 64 * h] = y[h]; x[h] = y[h]; }
 	}
 }
 
@@ -717,11 +770,19 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols)
 {
 	if (p.n_kc <= 0) return;
-	hipLaunchKernelGGL(k_kcol_struct, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
-	                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
+	if (p.ns == 128)
+		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kc * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
+		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
+	else
+		hipLaunchKernelGGL(k_kcol_struct<4>, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
+		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
-	hipLaunchKernelGGL(k_kchain_struct, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-	                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry);
+	if (p.ns == 128)
+		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry);
+	else
+		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry);
 }
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {

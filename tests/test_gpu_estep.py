@@ -461,13 +461,13 @@ def test_fast_learns_slow_regions(hip, golden, oracle):
         es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=768, warmup=256, group_cap=200000)
         es.load_segments(golden.segs_mid)
         hist = []
-        for it in range(4):
+        for it in range(8):  # a failing tile first gets a longer warm-up of its own (warm_shift), then is glued: a few E-steps
             r = es.estep(p["a"], p["e"], p["a0"])
             check_fast(r, o)
             d = es.fast_diag()
             hist.append((r, d["fwd_rounds"] + d["bwd_rounds"], d["items_fwd"]))
         es.close()
-        assert hist[0][1] > 0 and hist[3][1] == 0 and hist[3][2] < hist[0][2], [h[1:] for h in hist]
+        assert hist[0][1] > 0 and hist[7][1] == 0 and hist[7][2] < hist[0][2], [h[1:] for h in hist]
         runs.append(hist)
     for (r1, _, _), (r2, _, _) in zip(*runs):
         assert bits_equal(r1["A"], r2["A"]) and bits_equal(r1["E"], r2["E"]) and r1["LL"] == r2["LL"]

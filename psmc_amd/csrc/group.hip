@@ -182,7 +182,7 @@ static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &ou
 	out.assign(len, 0.0);
 	int n_live = 0, first = -1;
 	for (int s = 0; s < g->n_sh; ++s) if (!g->segs_of[s].empty()) { ++n_live; if (first < 0) first = s; }
-	const bool use_rccl = g->want_rccl == 1 || (g->want_rccl < 0 && g->distinct && n_live > 1);
+	const bool use_rccl = g->want_rccl == 1 || (g->want_rccl < 0 && g->distinct && n_live > 1 && n_live == g->n_sh); // auto: every device takes part
 	if (use_rccl && !g->distinct) return gfail(g, PSMC_HIP_EINVAL, "rccl = 1 needs distinct devices");
 	if (use_rccl) {
 		if (n_live != g->n_sh) return gfail(g, PSMC_HIP_ESTATE, "RCCL all-reduce: a shard holds no segment (fewer segments than devices)");

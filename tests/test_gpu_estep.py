@@ -734,3 +734,20 @@ def test_group_fast_reduction(hip, golden, oracle, devices, rccl):
     assert relmax(f["sums"], np.stack([lo.sum(1), up.sum(1), np.diag(o["A"]).copy(), lo.sum(0), up.sum(0)])) < FAST_TOL_STATS
     assert relmax(f["E"], o["E"]) < FAST_TOL_STATS and abs(f["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
     g.close()
+
+
+def test_group_with_more_shards_than_segments(hip, golden, oracle):
+    """Three shards, two segments: one shard stays empty and idles; both modes still give the single-context result."""
+    p = golden.params("n64_curve")
+    segs = golden.segs_mid[:2]
+    o = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    g = hip.HipGroup(64, [0, 0, 0], mode=hip.MODE_EXACT)
+    g.load_segments(segs)
+    r = g.estep(p["a"], p["e"], p["a0"])
+    assert bits_equal(r["A"], o["A"]) and bits_equal(r["E"], o["E"]) and r["LL"] == o["LL"]
+    g.close()
+    g = hip.HipGroup(64, [0, 0, 0], mode=hip.MODE_FAST)
+    g.load_segments(segs)
+    check_fast(g.estep(p["a"], p["e"], p["a0"]), o)
+    assert g.info()["last_reduce"] == 2
+    g.close()

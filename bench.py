@@ -91,6 +91,97 @@ def cpu_baseline(a, e, a0, segs, sample_bins):
             "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
 
 
+def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, diag, value, ms_per_step, traj_src, n_moving, stats_numel):
+    """The JSON line of the contract from what was measured (pure function: tests/test_bench_line.py feeds it fake
+    measurements for every plan the library can report)."""
+    # dominant KERNEL (one launch): the speculative forward / backward sweep or the expect kernel
+    if fast:
+        if diag.get("back_half") == 1:  # forward sweep, then backward sweep + counts in one kernel (estep_fused.hip)
+            cand = {"k_fwd_struct<speculate>": kern["fwd_sweep"], "k_bwd_count4_struct": kern["expect"]}
+        elif diag.get("structured"):  # both bulk sweeps are ONE launch (k_sweep_struct): 2 x (8n+9) bytes per bin
+            cand = {"k_sweep_struct": kern["fwd_sweep"], "k_expect_mfma": kern["expect"]}
+        else:
+            cand = {"k_fwd_fast<speculate>": kern["fwd_sweep"], "k_bwd_fast<speculate>": kern["bwd_sweep"], "k_expect_mfma": kern["expect"]}
+    else:
+        cand = {"k_fwd_exact": kern["forward"], "k_bwd_exact": kern["backward"], "k_expect_exact": kern["expect"]}
+    dom = max(cand, key=lambda k: cand[k])
+    dom_ms = cand[dom]
+    # algorithmic HBM bytes per bin of each phase (SURVEY.md section 8(d): forward writes the table and
+    # the scale, the fused backward+expect reads them back; obs once per sweep)
+    # counts: read X and bt (+ scales, obs); k_sweep_struct: write X and bt (+ scales), read obs twice; one sweep: half
+    def alg_bytes(k):
+        return (16 * N_STATES + 17) if k == "k_expect_mfma" else ((16 * N_STATES + 18) if k == "k_sweep_struct" else (8 * N_STATES + 9))
+    alg_b = alg_bytes(dom)
+    ach = bins * alg_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    fused = diag.get("back_half") == 1
+    bytes_per_bin = (2 * (8 * N_STATES + 9)) if fused else BYTES_PER_BIN  # fused: X written once, read once; bt never stored
+    pipe = bins * bytes_per_bin / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
+    # FP64 work of the fused kernel per bin: the counts (2 n^2 flop on v_mfma_f64_16x16x4) plus the O(n) backward step
+    flop_b = 2 * N_STATES * N_STATES + 24 * N_STATES
+    fused_ms = kern.get("expect", 0.0)
+    tfl = bins * flop_b / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0
+    traffic = None
+    try:  # HBM bytes per launch from the rocprofv3 PMC pass of this same command (profiles/, scripts/gpu_pmc.sh)
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if abs(pj["bins"] - bins) <= 64 and dom in pj["kernels"]:
+            traffic = pj["kernels"][dom]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    out = {
+        "metric": "genome bins/sec through forward-backward (n=64)",
+        "value": value, "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[2]: whole-genome .psmcfa-like batch, %d bins x %d states in %d segments "
+                               "%s, -p %s, one E-step (EM iteration) per step, parameters of a different EM round every step"
+                               % (int(lens.sum()), N_STATES, len(lens), "per GPU" if args.scaling == "weak" else "sharded over the GPUs", PATTERN),
+                   "mode": args.mode, "bins_per_gpu": bins, "bins_total": total_bins, "n_states": N_STATES, "segments": n_local_segs,
+                   "longest_segment": int(lens.max()),
+                   "parameters": ("fixed (n64_curve)" if args.fixed_params else "cycle of %d EM rounds: %s" % (n_moving, traj_src)),
+                   "sharding": ("segments/GPU + 1 RCCL all-reduce(%d f64)/step" % stats_numel) if world > 1 else "single GPU",
+                   **({"tiles": diag.get("n_chunks"), "speculative_overlap_bins": diag.get("warmup"),
+                       "structured_sweeps": diag.get("structured"), "tile_bins": diag.get("tile_len"),
+                       "sweep_items": [diag.get("items_fwd"), diag.get("items_bwd")],
+                       "repair_rounds": [diag.get("fwd_rounds"), diag.get("bwd_rounds")],
+                       "repaired_tiles": [diag.get("fwd_tiles"), diag.get("bwd_tiles")],
+                       "boundary_err": max(diag.get("warm_err_fwd", 0), diag.get("warm_err_bwd", 0))} if diag else {})},
+        "roofline": {**({"bound": "mfma", "kernel": dom, "launches_per_step": diag.get("fused_launches", 1),
+                         "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tfl / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop_b,
+                         "hbm": {"alg_bytes_per_bin": 8 * N_STATES + 9, "achieved_GBs": bins * (8 * N_STATES + 9) / (dom_ms * 1e-3) / 1e9,
+                                 "alg_bytes_per_launch": bins * (8 * N_STATES + 9) / max(1, diag.get("fused_launches", 1))},
+                         "note": "kernel_ms = the launches of one E-step summed (two-phase plan: tile lists A and B, half of the tiles each); "
+                                 "traffic = PMC bytes of the larger launch"}
+                        if dom == "k_bwd_count4_struct" else
+                        {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_bin": alg_b, "alg_bytes_per_launch": bins * alg_b,
+                         "note": "the longest single launch of the step.  Its first 45 % (the speculative warm-up of every tile) stores nothing and is "
+                                 "bound by FP64 issue, shared with the other kernels of phase 1; the table stores all fall into the rest, where they run "
+                                 "at the measured HBM write rate of this box (device_probes.hbm_GBs.sweep_store)"}),
+                     # the other heavy kernel of the step, so that both rooflines are on the line whichever is longer
+                     **({"also": {"bound": "mfma", "kernel": "k_bwd_count4_struct", "launches_per_step": diag.get("fused_launches", 1), "kernel_ms": fused_ms,
+                                  "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop_b,
+                                  "mfma_cycles_frac": (bins / 4 * 16 * 64) / (fused_ms * 1e-3 * 1024 * 2.16e9) if fused_ms > 0 else None,
+                                  "note": "backward sweep + counts, both launches summed; mfma_cycles_frac = 16 x 64-cycle v_mfma_f64_16x16x4 per step of four "
+                                          "tiles over SIMD time at the 2.16 GHz the box sustains (SQ counters: profiles/r02_sq_counters.json)"}}
+                        if fused and dom != "k_bwd_count4_struct" else
+                        ({"also": {"bound": "hbm", "kernel": "k_fwd_struct<speculate>", "kernel_ms": kern["fwd_sweep"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                   "achieved": bins * (8 * N_STATES + 9) / (kern["fwd_sweep"] * 1e-3) / 1e9,
+                                   "frac": bins * (8 * N_STATES + 9) / (kern["fwd_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS}} if fused and kern.get("fwd_sweep", 0) > 0 else {})),
+                     "traffic": traffic, "kernel_ms": dom_ms,
+                     "pipeline": {"alg_bytes_per_bin": bytes_per_bin, "ms": kern["total"], "achieved": pipe,
+                                  "frac": pipe / HBM_PEAK_GBS},
+                     "kernels_ms": kern,
+                     "fp64_note": ("the backward sweep feeds the counts (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) in the same "
+                                   "wave; f64 matrix and vector instructions share the FP64 pipe (78.6 TFLOP/s dense either way): "
+                                   "%.1f TFLOP/s of counts + O(n) sweep work in that kernel" if fused else
+                                   "forward and backward sweep kernels run side by side and share the HBM; the counts "
+                                   "kernel (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) reaches %.1f of 78.6 TFLOP/s") %
+                                  (bins * 2 * N_STATES * N_STATES / (kern["expect"] * 1e-3) / 1e12 if kern.get("expect", 0) > 0 else 0.0)},
+    }
+    return out
+
+
 class Shard:
     """One rank's segments resident in HBM + the E-step context over them."""
 
@@ -248,75 +339,8 @@ def main():
 
     out = None
     if rank == 0:
-        # dominant KERNEL (one launch): the speculative forward / backward sweep or the expect kernel
-        if mode == hip.MODE_FAST:
-            if diag.get("back_half") == 1:  # forward sweep, then backward sweep + counts in one kernel (estep_fused.hip)
-                cand = {"k_fwd_struct<speculate>": kern["fwd_sweep"], "k_bwd_count4_struct": kern["expect"]}
-            elif diag.get("structured"):  # both bulk sweeps are ONE launch (k_sweep_struct): 2 x (8n+9) bytes per bin
-                cand = {"k_sweep_struct": kern["fwd_sweep"], "k_expect_mfma": kern["expect"]}
-            else:
-                cand = {"k_fwd_fast<speculate>": kern["fwd_sweep"], "k_bwd_fast<speculate>": kern["bwd_sweep"], "k_expect_mfma": kern["expect"]}
-        else:
-            cand = {"k_fwd_exact": kern["forward"], "k_bwd_exact": kern["backward"], "k_expect_exact": kern["expect"]}
-        dom = max(cand, key=lambda k: cand[k])
-        dom_ms = cand[dom]
-        # algorithmic HBM bytes per bin of each phase (forward writes the table and
-        # the scale, the fused backward+expect reads them back; obs once per sweep)
-        # counts: read X and bt (+ scales, obs); k_sweep_struct: write X and bt (+ scales), read obs twice; one sweep: half
-        alg_b = (16 * N_STATES + 17) if dom == "k_expect_mfma" else ((16 * N_STATES + 18) if dom == "k_sweep_struct" else (8 * N_STATES + 9))
-        ach = bins * alg_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        fused = diag.get("back_half") == 1
-        bytes_per_bin = (2 * (8 * N_STATES + 9)) if fused else BYTES_PER_BIN  # fused: X written once, read once; bt never stored
-        pipe = bins * bytes_per_bin / (kern["total"] * 1e-3) / 1e9 if kern["total"] > 0 else 0.0
-        # FP64 work of the fused kernel per bin: the counts (2 n^2 flop on v_mfma_f64_16x16x4) plus the O(n) backward step
-        flop_b = 2 * N_STATES * N_STATES + 24 * N_STATES
-        tfl = bins * flop_b / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch from the rocprofv3 PMC pass of this same command (profiles/, scripts/gpu_pmc.sh)
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if abs(pj["bins"] - bins) <= 64 and dom in pj["kernels"]:
-                traffic = pj["kernels"][dom]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        out = {
-            "metric": "genome bins/sec through forward-backward (n=64)",
-            "value": value, "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: whole-genome .psmcfa-like batch, %d bins x %d states in %d segments "
-                                   "%s, -p %s, one E-step (EM iteration) per step, parameters of a different EM round every step"
-                                   % (int(lens.sum()), N_STATES, len(lens), "per GPU" if args.scaling == "weak" else "sharded over the GPUs", PATTERN),
-                       "mode": args.mode, "bins_per_gpu": bins, "bins_total": total_bins, "n_states": N_STATES, "segments": len(segs),
-                       "longest_segment": int(lens.max()),
-                       "parameters": ("fixed (n64_curve)" if args.fixed_params else "cycle of %d EM rounds: %s" % (len(moving), traj_src)),
-                       "sharding": ("segments/GPU + 1 RCCL all-reduce(%d f64)/step" % sh.stats.numel()) if world > 1 else "single GPU",
-                       **({"tiles": diag.get("n_chunks"), "speculative_overlap_bins": diag.get("warmup"),
-                           "structured_sweeps": diag.get("structured"), "tile_bins": diag.get("tile_len"),
-                           "sweep_items": [diag.get("items_fwd"), diag.get("items_bwd")],
-                           "repair_rounds": [diag.get("fwd_rounds"), diag.get("bwd_rounds")],
-                           "repaired_tiles": [diag.get("fwd_tiles"), diag.get("bwd_tiles")],
-                           "boundary_err": max(diag.get("warm_err_fwd", 0), diag.get("warm_err_bwd", 0))} if diag else {})},
-            "roofline": {**({"bound": "mfma", "kernel": dom, "launches_per_step": diag.get("fused_launches", 1),
-                             "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tfl / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop_b,
-                             "hbm": {"alg_bytes_per_bin": 8 * N_STATES + 9, "achieved_GBs": bins * (8 * N_STATES + 9) / (dom_ms * 1e-3) / 1e9,
-                                     "alg_bytes_per_launch": bins * (8 * N_STATES + 9) / max(1, diag.get("fused_launches", 1))},
-                             "note": "kernel_ms = the launches of one E-step summed (two-phase plan: tile lists A and B, half of the tiles each); "
-                                     "traffic = PMC bytes of the larger launch"}
-                            if dom == "k_bwd_count4_struct" else
-                            {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_bin": alg_b}),
-                         "traffic": traffic, "kernel_ms": dom_ms,
-                         "pipeline": {"alg_bytes_per_bin": bytes_per_bin, "ms": kern["total"], "achieved": pipe,
-                                      "frac": pipe / HBM_PEAK_GBS},
-                         "kernels_ms": kern,
-                         "fp64_note": ("the backward sweep feeds the counts (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) in the same "
-                                       "wave; f64 matrix and vector instructions share the FP64 pipe (78.6 TFLOP/s dense either way): "
-                                       "%.1f TFLOP/s of counts + O(n) sweep work in that kernel" if fused else
-                                       "forward and backward sweep kernels run side by side and share the HBM; the counts "
-                                       "kernel (K=bins GEMM, 2*n^2 flop/bin on v_mfma_f64_16x16x4) reaches %.1f of 78.6 TFLOP/s") %
-                                      (bins * 2 * N_STATES * N_STATES / (kern["expect"] * 1e-3) / 1e12 if kern.get("expect", 0) > 0 else 0.0)},
-        }
+        out = make_line(args, mode == hip.MODE_FAST, world, bins, total_bins, lens, len(segs), kern, diag, value, ms_per_step, traj_src,
+                        len(moving), sh.stats.numel())
         if steady is not None:
             out["steady_state"] = steady
         if first_ms is not None:

@@ -5,8 +5,9 @@
  *
  * e.g.  psmc_boot -R 100 -S 1 -O round-%d.psmc -- -N25 -t15 -r5 -p "4+25*2+4+6" split.psmcfa
  * writes what  for r in 0..99: PSMC_SEED=$((1+r)) psmc -N25 -t15 -r5 -b -p ... -o round-$r.psmc split.psmcfa  would
- * (-b is implied).  PSMC_HIP_MODE=exact|fast and PSMC_FAST_MSTEP as for psmc; PSMC_HIP_DEVICES=0,1,.. (default: all
- * visible devices); OMP_NUM_THREADS bounds the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr.
+ * (-b is implied).  PSMC_HIP_MODE=exact|fast and PSMC_FAST_MSTEP as for psmc; PSMC_HIP_DEVICES=0,1,.. (a device may be
+ * listed twice = two contexts on it; default: all visible devices, twice each in fast mode); OMP_NUM_THREADS bounds
+ * the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr.
  * There is no CPU E-step in this binary. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -79,9 +80,13 @@ int main(int argc, char *argv[])
 		for (char *t = strtok(dup, ","); t && n_list < MAX_DEV; t = strtok(0, ",")) list[n_list++] = atoi(t);
 		free(dup);
 	} else {
-		n_list = psmc_hip_device_count();
-		if (n_list > MAX_DEV) n_list = MAX_DEV;
-		for (int d = 0; d < n_list; ++d) list[d] = d;
+		/* all visible devices.  Fast mode: TWO contexts per device, each with its own tables and driver thread -- a fast
+		 * E-step is a chain of short launches with host decisions in between, and the second thread's replicate fills the
+		 * gaps of the first (100 replicates of a 30 M-bin genome: 1.05 s per EM iteration instead of 1.3).  Exact mode
+		 * packs the device with one batch already, and wants all of the memory for its tables. */
+		const int nd = psmc_hip_device_count(), per = mode == PSMC_HIP_MODE_FAST ? 2 : 1;
+		for (int d = 0; d < nd && n_list + per <= MAX_DEV; ++d)
+			for (int k = 0; k < per; ++k) list[n_list++] = d;
 	}
 	if (n_list > n_rep) n_list = n_rep;
 	if (n_list < 1) { fprintf(stderr, "psmc_boot: no MI355X visible; this build has no CPU path\n"); psmc_options_free(&o); return 2; }

@@ -30,6 +30,7 @@ struct psmc_hip_ctx {
 	int last_fused = 0, last_ckpt = 0; // what the last fast E-step ran: EstepLaunch::fused / ckpt
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
 	int walk_impl = 1;         // "walk_impl"
+	int kcol_impl = 1;         // "kcol_impl": 64 states, transfer matrices with one column per lane (1) or as four sweep tiles per wave (0)
 	int exact_lds = 0;         // "exact_lds": exact mode (<= 64 states) broadcasts the operands of its ordered sums through LDS instead of DPP rows; measured slower (905 vs 779 ms)
 	int lanes8 = 0;            // "lanes8": eight tiles per wave in the bulk forward sweep and the backward warm-up of the fused / factored back half
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
@@ -74,6 +75,7 @@ struct psmc_hip_ctx {
 	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128 + 3 * 128 + 5 * 128; // ns=64: ... | re(3) | sp(5) (17152); ns=128: a | aT | e(3) | a0 | re(3) | sp(5)
 	static constexpr size_t RE128_OFF = 2 * 16384 + 3 * 128 + 128, SP128_OFF = RE128_OFF + 3 * 128;
 	static constexpr size_t SP_OFF = 4 * 4096 + 192 + 64 + 192; // structured vectors P | R | qa | c | dd
+	static constexpr size_t KCC_OFF = SP_OFF + 5 * 64;          // 64 states: constant tables of k_kcol2_struct, 2 x (2*64 + 9*64) doubles (the 128-state layout's space, unused here)
 	// tables
 	double *d_f = nullptr, *d_b = nullptr, *d_s = nullptr, *d_sb = nullptr;
 	int64_t tab_bins = 0; bool have_b = false;
@@ -266,6 +268,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
+	else if (k == "kcol_impl") { c->kcol_impl = v != 0 ? 1 : 0; }
 	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
 	else if (k == "lanes8") { c->lanes8 = v != 0 ? 1 : 0; }
 	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
@@ -427,7 +430,21 @@ static bool fill_params(const psmc_hip_ctx *c, const double *a, const double *e,
 	for (int b = 0; b < 3; ++b)
 		for (int l = 0; l < 64; ++l)
 			for (int k = 0; k < 64; ++k) pae[b * 4096 + l * 64 + k] = pe[b * 64 + l] * pa[k * 64 + l];
-	return c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, 64, pa, pa + psmc_hip_ctx::SP_OFF);
+	const bool st = c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, 64, pa, pa + psmc_hip_ctx::SP_OFF);
+	if (st) { // k_kcol2_struct: per direction  mS | mP | { wS.e | wP.e | dd.e } per symbol  (forward: mS = P, wS = qa, mP = R, wP = c; backward: c, R, qa, P)
+		const double *sp = pa + psmc_hip_ctx::SP_OFF, *P = sp, *R = sp + 64, *qa = sp + 128, *cv = sp + 192, *dd = sp + 256;
+		for (int dir = 0; dir < 2; ++dir) {
+			double *t = pa + psmc_hip_ctx::KCC_OFF + (size_t)dir * (2 * 64 + 9 * 64);
+			const double *mS = dir == 0 ? P : cv, *wS = dir == 0 ? qa : R, *mP = dir == 0 ? R : qa, *wP = dir == 0 ? cv : P;
+			for (int k = 0; k < 64; ++k) { t[k] = mS[k]; t[64 + k] = mP[k]; }
+			for (int sy = 0; sy < 3; ++sy)
+				for (int k = 0; k < 64; ++k) {
+					const double ev = pe[sy * 64 + k];
+					t[128 + sy * 192 + k] = wS[k] * ev; t[128 + sy * 192 + 64 + k] = wP[k] * ev; t[128 + sy * 192 + 128 + k] = dd[k] * ev;
+				}
+		}
+	}
+	return st;
 }
 
 static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, hipStream_t st)
@@ -477,7 +494,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const d
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
 	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.lanes8 = c->lanes8; p.exact_lds = c->exact_lds;
-	p.walk_impl = c->walk_impl;
+	p.walk_impl = c->walk_impl; p.kcol_impl = c->kcol_impl; p.d_kcc = pb + psmc_hip_ctx::KCC_OFF;
 	p.ns = c->ns;
 	if (c->ns == 128) {
 		p.d_aeT = pb + 16384; p.d_e = pb + 32768; p.d_a0 = pb + 32768 + 384;
@@ -1191,7 +1208,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->lanes8 = c->lanes8;
 		k->fuse_order = c->fuse_order; k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
-		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift;
+		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kcol_impl = c->kcol_impl;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];

@@ -555,6 +555,78 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 	if (m == 0) Kexp[(int64_t)j * S + col] = (double)E;
 }
 
+// The same transfer matrix with one COLUMN per lane (64 states; "kcol_impl" = 1, default).  In k_kcol_struct a unit
+// vector is a tile of the sweeps: 16 lanes x 4 states, every scan level a DPP round trip -- 85 vector instructions per
+// step for four columns (1360 per step and tile).  Here the 64 states of a column sit in ONE lane's registers, so the
+// prefix / suffix sums are plain serial FMA chains and every matrix constant is the same for all lanes: one LDS
+// broadcast read.  A tile is a work-group of two waves -- wave w holds states 32w .. 32w+31 of all 64 columns -- that
+// exchange two totals per step through LDS (the upper half's suffix total, the lower half's prefix total):
+// 6 vector instructions per state and step, 2 x 192 + the exchange per step and tile.
+//   kcc (host, fill_params): per direction  mS[64] | mP[64] | { wS.e[sym] | wP.e[sym] | dd.e[sym] } for sym = 0, 1, 2
+// Scaling: any power of two both halves agree on will do (the chain kernel reads the exponent): every fourth step
+// both waves take it from the four exchanged totals, which they both hold.
+constexpr int KCC_DIR = 2 * 64 + 3 * 3 * 64; // doubles per direction
+__global__ __launch_bounds__(128) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
+                                                        const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
+                                                        double *__restrict__ Kcol, double *__restrict__ Kexp)
+{
+	__shared__ double xch[2][2][2][64]; // [step parity][wave][S total, P total][column]
+	__shared__ double tab[KCC_DIR];     // this direction's constants: every lane reads the same address (a broadcast read, no
+	                                    // bank conflict); as scalar operands they overflowed the SGPR file (85 spills through v_writelane)
+	const int lane = threadIdx.x & 63;
+	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int j = blockIdx.x;
+	__builtin_amdgcn_s_setprio(2);
+	const KcTile kt = kc[j];
+	const Chunk c = chunks[kt.tile];
+	const bool fwd = kt.dir == 0;
+	for (int i = threadIdx.x; i < KCC_DIR; i += 128) tab[i] = kcc[(fwd ? 0 : KCC_DIR) + i];
+	__syncthreads();
+	const int top = fwd ? c.hi : min(c.hi, c.L - 1);
+	const int lo = fwd ? c.lo : min(((c.lo + 3) & ~3) + 1, top + 1); // as k_kcol_struct: the chain kernel takes the last backward steps
+	const uint8_t *o = obs + c.off;
+	const double *cc = tab + 32 * w; // this wave's half of every table
+	double x[32];
+#pragma unroll
+	for (int k = 0; k < 32; ++k) x[k] = (32 * w + k == lane) ? 1.0 : 0.0; // column `lane` = unit vector e_lane
+	int E = 0;
+	const int n = top - lo + 1;
+	for (int q = 0; q < n; ++q) {
+		const int p = fwd ? lo + q : top - q;
+		const int sym = min((int)o[p - 1] & 3, 2); // wave-uniform: a scalar byte load
+		const double *ce = cc + 128 + sym * 192;     // wS.e | wP.e | dd.e of this symbol
+		double y[32], sS = 0.0, sP = 0.0;
+#pragma unroll
+		for (int k = 31; k >= 0; --k) { sS = __builtin_fma(x[k], cc[k], sS); y[k] = ce[k] * sS; }          // inclusive suffix of x.mS in this half
+#pragma unroll
+		for (int k = 0; k < 32; ++k) {
+			sP = __builtin_fma(x[k], cc[64 + k], sP);                                                          // inclusive prefix of x.mP in this half
+			y[k] = __builtin_fma(ce[128 + k], x[k], __builtin_fma(ce[64 + k], sP, y[k]));
+		}
+		xch[q & 1][w][0][lane] = sS; xch[q & 1][w][1][lane] = sP;
+		__syncthreads();
+		const double S0 = xch[q & 1][0][0][lane], S1 = xch[q & 1][1][0][lane], P0 = xch[q & 1][0][1][lane], P1 = xch[q & 1][1][1][lane];
+		// the lower half's suffix sums lack the upper half's total, the upper half's prefix sums the lower half's
+		const double T = w == 0 ? S1 : P0;
+		const double *cz = ce + (w == 0 ? 0 : 64);
+		if ((p & 3) == 0) { // rescale by a power of two both waves compute alike, remember the exponent
+			const double mag = (S0 + S1) + (P0 + P1);
+			const int ex = mag > 0.0 ? __builtin_amdgcn_frexp_exp(mag) : 0;
+			const double sc = __builtin_amdgcn_ldexp(1.0, -ex);
+#pragma unroll
+			for (int k = 0; k < 32; ++k) x[k] = __builtin_fma(cz[k], T, y[k]) * sc;
+			E += ex;
+		} else {
+#pragma unroll
+			for (int k = 0; k < 32; ++k) x[k] = __builtin_fma(cz[k], T, y[k]);
+		}
+	}
+	double *out = Kcol + ((int64_t)j * 64 + lane) * 64 + 32 * w;
+#pragma unroll
+	for (int k = 0; k < 32; ++k) out[k] = x[k];
+	if (w == 0) Kexp[(int64_t)j * 64 + lane] = (double)E;
+}
+
 // run r: forward (r < n_f): entry[first+1 .. first+count-1] from entry[first];  backward: bentry[first+count-2 .. first]
 // from bentry[first+count-1].  The vectors are left with sum 1 (the verify kernel and k_ll are scale-free).
 __device__ __forceinline__ double wave_max_f64(double v) {
@@ -773,6 +845,9 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 	if (p.ns == 128)
 		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kc * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
+	else if (p.kcol_impl == 1)
+		hipLaunchKernelGGL(k_kcol2_struct, dim3(p.n_kc), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc, p.d_Kcol,
+		                   p.d_Kexp);
 	else
 		hipLaunchKernelGGL(k_kcol_struct<4>, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);

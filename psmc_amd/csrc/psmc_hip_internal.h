@@ -56,6 +56,8 @@ struct EstepLaunch {
 	const double *d_sp;  // structured transition: P | R | qa | c | dd, 64 each (estep_struct.hip); valid when structured
 	int structured;      // a[k][l] = P_k qa_l (l<k), R_k c_l (l>k): O(N) sweeps, 4 tiles per wave
 	int walk_impl;       // 1: one wave per glued run, one state per lane (k_walk1_struct); 0: four runs per wave
+	int kcol_impl;       // 64 states: 1 = transfer matrices with one column per lane (k_kcol2_struct), 0 = four columns per wave as sweep tiles
+	const double *d_kcc; // its constant tables (api.hip fill_params)
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
 	int exact_lds;       // exact mode, up to 64 states: operands of the ordered chains broadcast through LDS instead of DPP

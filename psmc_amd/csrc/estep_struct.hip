@@ -566,18 +566,22 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 // Scaling: any power of two both halves agree on will do (the chain kernel reads the exponent): every fourth step
 // both waves take it from the four exchanged totals, which they both hold.
 constexpr int KCC_DIR = 2 * 64 + 3 * 3 * 64; // doubles per direction
+// One wave pair per tile would be 3 712 dependent steps of ~1 000 cycles: longer than the rest of the phase.  The tile's
+// steps are therefore cut into `sub` consecutive ranges with a transfer matrix each (block j = tile j / sub, range j % sub,
+// in traversal order); the chain kernel applies them one after the other -- `sub` times as many 64 x 64 products in
+// the chain, `sub` times as many waves here.
 __global__ __launch_bounds__(128) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
-                                                        double *__restrict__ Kcol, double *__restrict__ Kexp)
+                                                        double *__restrict__ Kcol, double *__restrict__ Kexp, int sub)
 {
 	__shared__ double xch[2][2][2][64]; // [step parity][wave][S total, P total][column]
 	__shared__ double tab[KCC_DIR];     // this direction's constants: every lane reads the same address (a broadcast read, no
 	                                    // bank conflict); as scalar operands they overflowed the SGPR file (85 spills through v_writelane)
 	const int lane = threadIdx.x & 63;
 	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int j = blockIdx.x;
+	const int j = blockIdx.x, jt = j / sub, js = j % sub;
 	__builtin_amdgcn_s_setprio(2);
-	const KcTile kt = kc[j];
+	const KcTile kt = kc[jt];
 	const Chunk c = chunks[kt.tile];
 	const bool fwd = kt.dir == 0;
 	for (int i = threadIdx.x; i < KCC_DIR; i += 128) tab[i] = kcc[(fwd ? 0 : KCC_DIR) + i];
@@ -591,7 +595,8 @@ __global__ __launch_bounds__(128) void k_kcol2_struct(const double *__restrict__
 	for (int k = 0; k < 32; ++k) x[k] = (32 * w + k == lane) ? 1.0 : 0.0; // column `lane` = unit vector e_lane
 	int E = 0;
 	const int n = top - lo + 1;
-	for (int q = 0; q < n; ++q) {
+	const int q0 = (int)((int64_t)n * js / sub), q1 = (int)((int64_t)n * (js + 1) / sub); // this block's steps, in traversal order
+	for (int q = q0; q < q1; ++q) {
 		const int p = fwd ? lo + q : top - q;
 		const int sym = min((int)o[p - 1] & 3, 2); // wave-uniform: a scalar byte load
 		const double *ce = cc + 128 + sym * 192;     // wS.e | wP.e | dd.e of this symbol
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
                                                         const double *__restrict__ Kexp, const double *__restrict__ sp,
                                                         const double *__restrict__ e, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, double *__restrict__ entry,
-                                                        double *__restrict__ bentry)
+                                                        double *__restrict__ bentry, int sub)
 {
 	constexpr int S = 64 * PER;
 	const int lane = threadIdx.x;
@@ -678,8 +683,10 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 		e0[q] = e[k]; e1[q] = e[S + k];
 	}
 	for (int q = 0; q + 1 < r.count; ++q) {
-		const int64_t kb = (int64_t)(r.kc0 + q) * S;
-		double ex[PER], xs[PER], y[PER], em = -1e300;
+		double y[PER];
+		for (int ss = 0; ss < sub; ++ss) { // the tile's map = the product of its `sub` range maps, applied in traversal order
+		const int64_t kb = ((int64_t)(r.kc0 + q) * sub + ss) * S;
+		double ex[PER], xs[PER], em = -1e300;
 #pragma unroll
 		for (int h = 0; h < PER; ++h) { ex[h] = Kexp[kb + lane + 64 * h]; em = fmax(em, x[h] > 0.0 ? ex[h] : -1e300); }
 		const double emax = wave_max_f64(em);
@@ -698,7 +705,8 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 			if constexpr (PER == 2) tot += y[1];
 			const double inv = rcp_newton(first_lane_f64(wave_sum_nat(tot)));
 #pragma unroll
-			for (int h = 0; h < PER; ++h) y[h] *= inv;
+			for (int h = 0; h < PER; ++h) { y[h] *= inv; x[h] = y[h]; }
+		}
 		}
 		if (!fwd) { // the tile's last steps p* .. lo with the sweep's own scaling: bt_lo as the sweep leaves it
 			const Chunk c = chunks[t];
@@ -846,18 +854,18 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kc * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
 	else if (p.kcol_impl == 1)
-		hipLaunchKernelGGL(k_kcol2_struct, dim3(p.n_kc), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc, p.d_Kcol,
-		                   p.d_Kexp);
+		hipLaunchKernelGGL(k_kcol2_struct, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
+		                   p.d_Kcol, p.d_Kexp, p.kc_sub);
 	else
 		hipLaunchKernelGGL(k_kcol_struct<4>, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
 	if (p.ns == 128)
 		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, 1);
 	else
 		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1);
 }
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {

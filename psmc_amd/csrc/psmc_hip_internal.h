@@ -58,6 +58,7 @@ struct EstepLaunch {
 	int walk_impl;       // 1: one wave per glued run, one state per lane (k_walk1_struct); 0: four runs per wave
 	int kcol_impl;       // 64 states: 1 = transfer matrices with one column per lane (k_kcol2_struct), 0 = four columns per wave as sweep tiles
 	const double *d_kcc; // its constant tables (api.hip fill_params)
+	int kc_sub;          // ... and the number of step ranges (transfer matrices) per tile
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
 	int exact_lds;       // exact mode, up to 64 states: operands of the ordered chains broadcast through LDS instead of DPP

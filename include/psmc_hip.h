@@ -64,7 +64,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kcol_impl" (64 states: 1, default:
  * the transfer matrices of the long runs with one column per lane and the matrix constants as scalar operands; 0: four
  * columns per wave as tiles of the sweeps), "kc_sub" (4: with kcol_impl 1 a tile's steps are cut into this many ranges with a
- * transfer matrix and a pair of waves each), "kc_min" (runs of at least this
+ * transfer matrix and a pair of waves each), "kcol_prio" (2: wave priority of that kernel, 0..2; the bulk forward sweep runs at 1), "kc_min" (runs of at least this
  * many tiles get their boundary vectors from a chain of tile transfer matrices instead of a walk; 0: never),
  * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (tiles with an odd
  * index inside their segment do not speculate but start from the exact boundary vector their neighbour left: 2,

@@ -32,6 +32,7 @@ struct psmc_hip_ctx {
 	int walk_impl = 1;         // "walk_impl"
 	int kcol_impl = 1;         // "kcol_impl": 64 states, transfer matrices with one column per lane (1) or as four sweep tiles per wave (0)
 	int kc_sub = 4;            // "kc_sub": kcol_impl 1 cuts a tile's steps into this many ranges, one matrix (and one pair of waves) each
+	int kcol_prio = 2;         // "kcol_prio": wave priority of k_kcol2_struct
 	int exact_lds = 0;         // "exact_lds": exact mode (<= 64 states) broadcasts the operands of its ordered sums through LDS instead of DPP rows; measured slower (905 vs 779 ms)
 	int lanes8 = 0;            // "lanes8": eight tiles per wave in the bulk forward sweep and the backward warm-up of the fused / factored back half
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
@@ -270,6 +271,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
 	else if (k == "kcol_impl") { c->kcol_impl = v != 0 ? 1 : 0; c->items_dirty = true; }
+	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->items_dirty = true; }
 	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
 	else if (k == "lanes8") { c->lanes8 = v != 0 ? 1 : 0; }
@@ -928,6 +930,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_wl_f = c->d_items + 12 * (size_t)p.n_chunks; p.d_wl_b = c->d_items + 14 * (size_t)p.n_chunks; p.n_wl_f = c->n_wl_f; p.n_wl_b = c->n_wl_b;
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
+	p.kcol_prio = c->kcol_prio;
 	p.d_Kcol = c->d_Kcol; p.kc_sub = (c->ns == 64 && c->kcol_impl == 1) ? c->kc_sub : 1;
 	p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * p.kc_sub * c->ns * c->ns : nullptr; p.stream5 = c->stream5;
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
@@ -1212,7 +1215,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->lanes8 = c->lanes8;
 		k->fuse_order = c->fuse_order; k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
-		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kcol_impl = c->kcol_impl; k->kc_sub = c->kc_sub;
+		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kcol_impl = c->kcol_impl; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];

@@ -572,7 +572,7 @@ constexpr int KCC_DIR = 2 * 64 + 3 * 3 * 64; // doubles per direction
 // the chain, `sub` times as many waves here.
 __global__ __launch_bounds__(128) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
-                                                        double *__restrict__ Kcol, double *__restrict__ Kexp, int sub)
+                                                        double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio)
 {
 	__shared__ double xch[2][2][2][64]; // [step parity][wave][S total, P total][column]
 	__shared__ double tab[KCC_DIR];     // this direction's constants: every lane reads the same address (a broadcast read, no
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(128) void k_kcol2_struct(const double *__restrict__
 	const int lane = threadIdx.x & 63;
 	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int j = blockIdx.x, jt = j / sub, js = j % sub;
-	__builtin_amdgcn_s_setprio(2);
+	if (prio >= 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1); // s_setprio takes an immediate
 	const KcTile kt = kc[jt];
 	const Chunk c = chunks[kt.tile];
 	const bool fwd = kt.dir == 0;
@@ -855,7 +855,7 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
 	else if (p.kcol_impl == 1)
 		hipLaunchKernelGGL(k_kcol2_struct, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
-		                   p.d_Kcol, p.d_Kexp, p.kc_sub);
+		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
 	else
 		hipLaunchKernelGGL(k_kcol_struct<4>, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);

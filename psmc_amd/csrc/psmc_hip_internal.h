@@ -59,6 +59,7 @@ struct EstepLaunch {
 	int kcol_impl;       // 64 states: 1 = transfer matrices with one column per lane (k_kcol2_struct), 0 = four columns per wave as sweep tiles
 	const double *d_kcc; // its constant tables (api.hip fill_params)
 	int kc_sub;          // ... and the number of step ranges (transfer matrices) per tile
+	int kcol_prio;       // ... and its wave priority (0..2; the bulk forward sweep runs at 1, the walks at 3)
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
 	int exact_lds;       // exact mode, up to 64 states: operands of the ordered chains broadcast through LDS instead of DPP

@@ -74,8 +74,8 @@ struct psmc_hip_ctx {
 	bool plan_dirty = true;
 	// parameters
 	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0 | re(3)
-	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128 + 3 * 128 + 5 * 128; // ns=64: ... | re(3) | sp(5) (17152); ns=128: a | aT | e(3) | a0 | re(3) | sp(5)
-	static constexpr size_t RE128_OFF = 2 * 16384 + 3 * 128 + 128, SP128_OFF = RE128_OFF + 3 * 128;
+	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128 + 3 * 128 + 5 * 128 + 2 * 11 * 128; // ns=64: ... | re(3) | sp(5) (17152) | kcc; ns=128: a | aT | e(3) | a0 | re(3) | sp(5) | kcc
+	static constexpr size_t RE128_OFF = 2 * 16384 + 3 * 128 + 128, SP128_OFF = RE128_OFF + 3 * 128, KCC128_OFF = SP128_OFF + 5 * 128;
 	static constexpr size_t SP_OFF = 4 * 4096 + 192 + 64 + 192; // structured vectors P | R | qa | c | dd
 	static constexpr size_t KCC_OFF = SP_OFF + 5 * 64;          // 64 states: constant tables of k_kcol2_struct, 2 x (2*64 + 9*64) doubles (the 128-state layout's space, unused here)
 	// tables
@@ -402,6 +402,25 @@ static bool factor_structure(int n, int S, const double *a /* stride S */, doubl
 
 // pad the HMM parameters to 64 states and build aeT[b][l*64+k] = e[b][l]*a[k][l]
 // (hmm_pre_backward, khmm.c:194-206: one rounding per product), then upload.
+// Constant tables of k_kcol2_struct (transfer matrices with one column per lane): per direction, S = padded states,
+//   mS | mP | { wS.e | wP.e | dd.e } for the symbols 0, 1, 2        (11 S doubles; forward: mS = P, wS = qa, mP = R, wP = c;
+// backward: mS = c, wS = R, mP = qa, wP = P -- the roles load_struct_par gives the five vectors sp = P | R | qa | c | dd)
+static void fill_kcc(int S, const double *sp, const double *e3 /* 3 rows of S */, double *out /* 2 * 11 S */)
+{
+	const double *P = sp, *R = sp + S, *qa = sp + 2 * S, *cv = sp + 3 * S, *dd = sp + 4 * S;
+	for (int dir = 0; dir < 2; ++dir) {
+		double *t = out + (size_t)dir * 11 * S;
+		const double *mS = dir == 0 ? P : cv, *wS = dir == 0 ? qa : R, *mP = dir == 0 ? R : qa, *wP = dir == 0 ? cv : P;
+		for (int k = 0; k < S; ++k) { t[k] = mS[k]; t[S + k] = mP[k]; }
+		for (int sy = 0; sy < 3; ++sy)
+			for (int k = 0; k < S; ++k) {
+				const double ev = e3[sy * S + k];
+				double *u = t + 2 * S + (size_t)sy * 3 * S;
+				u[k] = wS[k] * ev; u[S + k] = wP[k] * ev; u[2 * S + k] = dd[k] * ev;
+			}
+	}
+}
+
 // host part: one parameter block (PAR_LEN doubles) at dst; returns whether the matrix has the PSMC form (fast mode)
 static bool fill_params(const psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *dst)
 {
@@ -418,7 +437,9 @@ static bool fill_params(const psmc_hip_ctx *c, const double *a, const double *e,
 		if (c->mode == PSMC_HIP_MODE_FAST) {
 			double *pre = pa + psmc_hip_ctx::RE128_OFF;
 			for (int i = 0; i < 384; ++i) pre[i] = pe[i] > 0.0 ? 1.0 / pe[i] : 0.0;
-			return c->struct_opt && factor_structure(n, 128, pa, pa + psmc_hip_ctx::SP128_OFF);
+			const bool st = c->struct_opt && factor_structure(n, 128, pa, pa + psmc_hip_ctx::SP128_OFF);
+			if (st) fill_kcc(128, pa + psmc_hip_ctx::SP128_OFF, pe, pa + psmc_hip_ctx::KCC128_OFF);
+			return st;
 		}
 		return false;
 	}
@@ -435,19 +456,7 @@ static bool fill_params(const psmc_hip_ctx *c, const double *a, const double *e,
 		for (int l = 0; l < 64; ++l)
 			for (int k = 0; k < 64; ++k) pae[b * 4096 + l * 64 + k] = pe[b * 64 + l] * pa[k * 64 + l];
 	const bool st = c->mode == PSMC_HIP_MODE_FAST && c->struct_opt && factor_structure(n, 64, pa, pa + psmc_hip_ctx::SP_OFF);
-	if (st) { // k_kcol2_struct: per direction  mS | mP | { wS.e | wP.e | dd.e } per symbol  (forward: mS = P, wS = qa, mP = R, wP = c; backward: c, R, qa, P)
-		const double *sp = pa + psmc_hip_ctx::SP_OFF, *P = sp, *R = sp + 64, *qa = sp + 128, *cv = sp + 192, *dd = sp + 256;
-		for (int dir = 0; dir < 2; ++dir) {
-			double *t = pa + psmc_hip_ctx::KCC_OFF + (size_t)dir * (2 * 64 + 9 * 64);
-			const double *mS = dir == 0 ? P : cv, *wS = dir == 0 ? qa : R, *mP = dir == 0 ? R : qa, *wP = dir == 0 ? cv : P;
-			for (int k = 0; k < 64; ++k) { t[k] = mS[k]; t[64 + k] = mP[k]; }
-			for (int sy = 0; sy < 3; ++sy)
-				for (int k = 0; k < 64; ++k) {
-					const double ev = pe[sy * 64 + k];
-					t[128 + sy * 192 + k] = wS[k] * ev; t[128 + sy * 192 + 64 + k] = wP[k] * ev; t[128 + sy * 192 + 128 + k] = dd[k] * ev;
-				}
-		}
-	}
+	if (st) fill_kcc(64, pa + psmc_hip_ctx::SP_OFF, pe, pa + psmc_hip_ctx::KCC_OFF);
 	return st;
 }
 
@@ -502,7 +511,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const d
 	p.ns = c->ns;
 	if (c->ns == 128) {
 		p.d_aeT = pb + 16384; p.d_e = pb + 32768; p.d_a0 = pb + 32768 + 384;
-		p.d_re = pb + psmc_hip_ctx::RE128_OFF; p.d_sp = pb + psmc_hip_ctx::SP128_OFF;
+		p.d_re = pb + psmc_hip_ctx::RE128_OFF; p.d_sp = pb + psmc_hip_ctx::SP128_OFF; p.d_kcc = pb + psmc_hip_ctx::KCC128_OFF;
 	}
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
@@ -847,7 +856,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 		std::vector<int> runs(runs_f); runs.insert(runs.end(), runs_b.begin(), runs_b.end());
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)16 * nc, kc.data(), sizeof(int) * kc.size(), hipMemcpyHostToDevice));
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)20 * nc, runs.data(), sizeof(int) * runs.size(), hipMemcpyHostToDevice));
-		const size_t nsub = (c->ns == 64 && c->kcol_impl == 1) ? (size_t)c->kc_sub : 1; // k_kcol2_struct: kc_sub matrices per tile
+		const size_t nsub = c->kcol_impl == 1 ? (size_t)c->kc_sub : 1; // k_kcol2_struct: kc_sub matrices per tile
 		const size_t need = (size_t)c->n_kc * nsub * ((size_t)c->ns * c->ns + c->ns); // the matrices, then one exponent per column
 		if (need > c->kcol_cap) { int rc; if ((rc = dev_alloc(c, &c->d_Kcol, need))) return rc; c->kcol_cap = need; }
 	}
@@ -931,7 +940,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
 	p.kcol_prio = c->kcol_prio;
-	p.d_Kcol = c->d_Kcol; p.kc_sub = (c->ns == 64 && c->kcol_impl == 1) ? c->kc_sub : 1;
+	p.d_Kcol = c->d_Kcol; p.kc_sub = c->kcol_impl == 1 ? c->kc_sub : 1;
 	p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * p.kc_sub * c->ns * c->ns : nullptr; p.stream5 = c->stream5;
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;

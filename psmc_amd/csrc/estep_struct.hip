@@ -565,71 +565,93 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 //   kcc (host, fill_params): per direction  mS[64] | mP[64] | { wS.e[sym] | wP.e[sym] | dd.e[sym] } for sym = 0, 1, 2
 // Scaling: any power of two both halves agree on will do (the chain kernel reads the exponent): every fourth step
 // both waves take it from the four exchanged totals, which they both hold.
-constexpr int KCC_DIR = 2 * 64 + 3 * 3 * 64; // doubles per direction
-// One wave pair per tile would be 3 712 dependent steps of ~1 000 cycles: longer than the rest of the phase.  The tile's
-// steps are therefore cut into `sub` consecutive ranges with a transfer matrix each (block j = tile j / sub, range j % sub,
-// in traversal order); the chain kernel applies them one after the other -- `sub` times as many 64 x 64 products in
-// the chain, `sub` times as many waves here.
-__global__ __launch_bounds__(128) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
-                                                        const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
-                                                        double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio)
+// One wave group per tile would be 3 712 dependent steps of ~1 000 cycles: longer than the rest of the phase.  The tile's
+// steps are therefore cut into `sub` consecutive ranges with a transfer matrix each (matrix index = tile * sub + range,
+// ranges in traversal order); the chain kernel applies them one after the other -- `sub` times as many products in the
+// chain, `sub` times as many waves here.
+// NQ = S / 32 waves per work-group, wave w holds states 32w .. 32w+31 of 64 columns (S / 64 column groups per matrix:
+// grid = matrices x column groups).  128 states: four quarters; a wave's suffix sums lack the totals of the quarters
+// above it, its prefix sums those of the quarters below it.
+template <int NQ>
+__global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
+                                                            const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
+                                                            double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio)
 {
-	__shared__ double xch[2][2][2][64]; // [step parity][wave][S total, P total][column]
-	__shared__ double tab[KCC_DIR];     // this direction's constants: every lane reads the same address (a broadcast read, no
-	                                    // bank conflict); as scalar operands they overflowed the SGPR file (85 spills through v_writelane)
+	constexpr int S = 32 * NQ, NCG = S / 64, KD = 11 * S; // KD: doubles per direction = mS | mP | 3 x (wS.e | wP.e | dd.e)
+	__shared__ double xch[2][NQ][2][64]; // [step parity][wave][S total, P total][column]
+	__shared__ double tab[KD];           // this direction's constants: every lane reads the same address (a broadcast read, no
+	                                     // bank conflict); as scalar operands they overflowed the SGPR file (85 spills through v_writelane)
 	const int lane = threadIdx.x & 63;
 	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int j = blockIdx.x, jt = j / sub, js = j % sub;
+	const int j = (int)blockIdx.x / NCG, cg = (int)blockIdx.x % NCG, jt = j / sub, js = j % sub;
+	const int col = 64 * cg + lane;
 	if (prio >= 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1); // s_setprio takes an immediate
 	const KcTile kt = kc[jt];
 	const Chunk c = chunks[kt.tile];
 	const bool fwd = kt.dir == 0;
-	for (int i = threadIdx.x; i < KCC_DIR; i += 128) tab[i] = kcc[(fwd ? 0 : KCC_DIR) + i];
+	for (int i = threadIdx.x; i < KD; i += 64 * NQ) tab[i] = kcc[(fwd ? 0 : KD) + i];
 	__syncthreads();
 	const int top = fwd ? c.hi : min(c.hi, c.L - 1);
 	const int lo = fwd ? c.lo : min(((c.lo + 3) & ~3) + 1, top + 1); // as k_kcol_struct: the chain kernel takes the last backward steps
 	const uint8_t *o = obs + c.off;
-	const double *cc = tab + 32 * w; // this wave's half of every table
+	const double *cc = tab + 32 * w; // this wave's part of every table
 	double x[32];
 #pragma unroll
-	for (int k = 0; k < 32; ++k) x[k] = (32 * w + k == lane) ? 1.0 : 0.0; // column `lane` = unit vector e_lane
+	for (int k = 0; k < 32; ++k) x[k] = (32 * w + k == col) ? 1.0 : 0.0; // column `col` = unit vector e_col
 	int E = 0;
 	const int n = top - lo + 1;
 	const int q0 = (int)((int64_t)n * js / sub), q1 = (int)((int64_t)n * (js + 1) / sub); // this block's steps, in traversal order
 	for (int q = q0; q < q1; ++q) {
 		const int p = fwd ? lo + q : top - q;
 		const int sym = min((int)o[p - 1] & 3, 2); // wave-uniform: a scalar byte load
-		const double *ce = cc + 128 + sym * 192;     // wS.e | wP.e | dd.e of this symbol
+		const double *ce = cc + 2 * S + sym * 3 * S; // wS.e | wP.e | dd.e of this symbol
 		double y[32], sS = 0.0, sP = 0.0;
 #pragma unroll
-		for (int k = 31; k >= 0; --k) { sS = __builtin_fma(x[k], cc[k], sS); y[k] = ce[k] * sS; }          // inclusive suffix of x.mS in this half
+		for (int k = 31; k >= 0; --k) { sS = __builtin_fma(x[k], cc[k], sS); y[k] = ce[k] * sS; }          // inclusive suffix of x.mS in this part
 #pragma unroll
 		for (int k = 0; k < 32; ++k) {
-			sP = __builtin_fma(x[k], cc[64 + k], sP);                                                          // inclusive prefix of x.mP in this half
-			y[k] = __builtin_fma(ce[128 + k], x[k], __builtin_fma(ce[64 + k], sP, y[k]));
+			sP = __builtin_fma(x[k], cc[S + k], sP);                                                           // inclusive prefix of x.mP in this part
+			y[k] = __builtin_fma(ce[2 * S + k], x[k], __builtin_fma(ce[S + k], sP, y[k]));
 		}
 		xch[q & 1][w][0][lane] = sS; xch[q & 1][w][1][lane] = sP;
 		__syncthreads();
-		const double S0 = xch[q & 1][0][0][lane], S1 = xch[q & 1][1][0][lane], P0 = xch[q & 1][0][1][lane], P1 = xch[q & 1][1][1][lane];
-		// the lower half's suffix sums lack the upper half's total, the upper half's prefix sums the lower half's
-		const double T = w == 0 ? S1 : P0;
-		const double *cz = ce + (w == 0 ? 0 : 64);
-		if ((p & 3) == 0) { // rescale by a power of two both waves compute alike, remember the exponent
-			const double mag = (S0 + S1) + (P0 + P1);
-			const int ex = mag > 0.0 ? __builtin_amdgcn_frexp_exp(mag) : 0;
-			const double sc = __builtin_amdgcn_ldexp(1.0, -ex);
+		if constexpr (NQ == 2) {
+			const double S0 = xch[q & 1][0][0][lane], S1 = xch[q & 1][1][0][lane], P0 = xch[q & 1][0][1][lane], P1 = xch[q & 1][1][1][lane];
+			// the lower half's suffix sums lack the upper half's total, the upper half's prefix sums the lower half's
+			const double T = w == 0 ? S1 : P0;
+			const double *cz = ce + (w == 0 ? 0 : S);
+			if ((p & 3) == 0) { // rescale by a power of two both waves compute alike, remember the exponent
+				const double mag = (S0 + S1) + (P0 + P1);
+				const int ex = mag > 0.0 ? __builtin_amdgcn_frexp_exp(mag) : 0;
+				const double sc = __builtin_amdgcn_ldexp(1.0, -ex);
 #pragma unroll
-			for (int k = 0; k < 32; ++k) x[k] = __builtin_fma(cz[k], T, y[k]) * sc;
-			E += ex;
+				for (int k = 0; k < 32; ++k) x[k] = __builtin_fma(cz[k], T, y[k]) * sc;
+				E += ex;
+			} else {
+#pragma unroll
+				for (int k = 0; k < 32; ++k) x[k] = __builtin_fma(cz[k], T, y[k]);
+			}
 		} else {
+			double Ts = 0.0, Tp = 0.0, mag = 0.0; // totals of the parts above / below this one, and of everything (same order in every wave)
 #pragma unroll
-			for (int k = 0; k < 32; ++k) x[k] = __builtin_fma(cz[k], T, y[k]);
+			for (int v = 0; v < NQ; ++v) {
+				const double Sv = xch[q & 1][v][0][lane], Pv = xch[q & 1][v][1][lane];
+				Ts += v > w ? Sv : 0.0; Tp += v < w ? Pv : 0.0; mag += Sv + Pv;
+			}
+			double sc = 1.0;
+			if ((p & 3) == 0) {
+				const int ex = mag > 0.0 ? __builtin_amdgcn_frexp_exp(mag) : 0;
+				sc = __builtin_amdgcn_ldexp(1.0, -ex);
+				E += ex;
+			}
+#pragma unroll
+			for (int k = 0; k < 32; ++k) x[k] = __builtin_fma(ce[k], Ts, __builtin_fma(ce[S + k], Tp, y[k])) * sc;
 		}
 	}
-	double *out = Kcol + ((int64_t)j * 64 + lane) * 64 + 32 * w;
+	double *out = Kcol + ((int64_t)j * S + col) * S + 32 * w;
 #pragma unroll
 	for (int k = 0; k < 32; ++k) out[k] = x[k];
-	if (w == 0) Kexp[(int64_t)j * 64 + lane] = (double)E;
+	if (w == 0) Kexp[(int64_t)j * S + col] = (double)E;
 }
 
 // run r: forward (r < n_f): entry[first+1 .. first+count-1] from entry[first];  backward: bentry[first+count-2 .. first]
@@ -850,11 +872,14 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols)
 {
 	if (p.n_kc <= 0) return;
-	if (p.ns == 128)
+	if (p.ns == 128 && p.kcol_impl == 1)
+		hipLaunchKernelGGL(k_kcol2_struct<4>, dim3(p.n_kc * p.kc_sub * 2), dim3(256), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
+		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
+	else if (p.ns == 128)
 		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kc * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
 	else if (p.kcol_impl == 1)
-		hipLaunchKernelGGL(k_kcol2_struct, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
+		hipLaunchKernelGGL(k_kcol2_struct<2>, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
 		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
 	else
 		hipLaunchKernelGGL(k_kcol_struct<4>, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
@@ -862,7 +887,7 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
 	if (p.ns == 128)
 		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, 1);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1);
 	else
 		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1);

@@ -61,9 +61,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * structured sweeps and up to 64 states the backward sweep feeds the counts' matrix instructions directly -- bt never
  * stored, half the HBM traffic; 0: bt table + separate counts kernel), "ckpt" (1, default:
  * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table),
- * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kcol_impl" (64 states: 1, default:
- * the transfer matrices of the long runs with one column per lane and the matrix constants as scalar operands; 0: four
- * columns per wave as tiles of the sweeps), "kc_sub" (4: with kcol_impl 1 a tile's steps are cut into this many ranges with a
+ * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kcol_impl" (1, default: with up to 64
+ * states the transfer matrices of the long runs are computed with one column per lane, serial scans and the matrix constants
+ * broadcast from LDS; 2: with 65..128 states as well (measured slower there); 0: four columns per wave as tiles of the sweeps), "kc_sub" (4: with kcol_impl 1 a tile's steps are cut into this many ranges with a
  * transfer matrix and a pair of waves each), "kcol_prio" (2: wave priority of that kernel, 0..2; the bulk forward sweep runs at 1), "kc_min" (runs of at least this
  * many tiles get their boundary vectors from a chain of tile transfer matrices instead of a walk; 0: never),
  * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (tiles with an odd

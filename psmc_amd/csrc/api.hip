@@ -270,7 +270,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; }
 	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
-	else if (k == "kcol_impl") { c->kcol_impl = v != 0 ? 1 : 0; c->items_dirty = true; }
+	else if (k == "kcol_impl") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_impl = (int)v; c->items_dirty = true; }
 	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->items_dirty = true; }
 	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
@@ -494,6 +494,10 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0)
 	return 0;
 }
 
+// the column-per-lane transfer-matrix kernel: 64 states by default; 128 states only on request ("kcol_impl" = 2: it
+// takes 2.3x fewer vector instructions there too, but its chain path ends later and the E-step gets slower, 30.6 vs 28.3 ms)
+static bool kcol2_on(const psmc_hip_ctx *c) { return c->kcol_impl == 2 || (c->kcol_impl == 1 && c->ns == 64); }
+
 static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const double *par_base = nullptr)
 {
 	memset(&p, 0, sizeof(p));
@@ -507,7 +511,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const d
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
 	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.lanes8 = c->lanes8; p.exact_lds = c->exact_lds;
-	p.walk_impl = c->walk_impl; p.kcol_impl = c->kcol_impl; p.d_kcc = pb + psmc_hip_ctx::KCC_OFF;
+	p.walk_impl = c->walk_impl; p.kcol_impl = kcol2_on(c) ? 1 : 0; p.d_kcc = pb + psmc_hip_ctx::KCC_OFF;
 	p.ns = c->ns;
 	if (c->ns == 128) {
 		p.d_aeT = pb + 16384; p.d_e = pb + 32768; p.d_a0 = pb + 32768 + 384;
@@ -856,7 +860,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 		std::vector<int> runs(runs_f); runs.insert(runs.end(), runs_b.begin(), runs_b.end());
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)16 * nc, kc.data(), sizeof(int) * kc.size(), hipMemcpyHostToDevice));
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)20 * nc, runs.data(), sizeof(int) * runs.size(), hipMemcpyHostToDevice));
-		const size_t nsub = c->kcol_impl == 1 ? (size_t)c->kc_sub : 1; // k_kcol2_struct: kc_sub matrices per tile
+		const size_t nsub = kcol2_on(c) ? (size_t)c->kc_sub : 1; // k_kcol2_struct: kc_sub matrices per tile
 		const size_t need = (size_t)c->n_kc * nsub * ((size_t)c->ns * c->ns + c->ns); // the matrices, then one exponent per column
 		if (need > c->kcol_cap) { int rc; if ((rc = dev_alloc(c, &c->d_Kcol, need))) return rc; c->kcol_cap = need; }
 	}
@@ -940,7 +944,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
 	p.kcol_prio = c->kcol_prio;
-	p.d_Kcol = c->d_Kcol; p.kc_sub = c->kcol_impl == 1 ? c->kc_sub : 1;
+	p.d_Kcol = c->d_Kcol; p.kc_sub = kcol2_on(c) ? c->kc_sub : 1;
 	p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * p.kc_sub * c->ns * c->ns : nullptr; p.stream5 = c->stream5;
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;

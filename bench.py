@@ -97,7 +97,7 @@ def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, dia
     # dominant KERNEL (one launch): the speculative forward / backward sweep or the expect kernel
     if fast:
         if diag.get("back_half") == 1:  # forward sweep, then backward sweep + counts in one kernel (estep_fused.hip)
-            cand = {"k_fwd_struct<speculate>": kern["fwd_sweep"], "k_bwd_count4_struct": kern["expect"]}
+            cand = {"k_fwd_struct<speculate>": kern["fwd_sweep"], "k_bwd_count4f_struct": kern["expect"]}
         elif diag.get("structured"):  # both bulk sweeps are ONE launch (k_sweep_struct): 2 x (8n+9) bytes per bin
             cand = {"k_sweep_struct": kern["fwd_sweep"], "k_expect_mfma": kern["expect"]}
         else:
@@ -152,19 +152,19 @@ def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, dia
                                  "alg_bytes_per_launch": bins * (8 * N_STATES + 9) / max(1, diag.get("fused_launches", 1))},
                          "note": "kernel_ms = the launches of one E-step summed (two-phase plan: tile lists A and B, half of the tiles each); "
                                  "traffic = PMC bytes of the larger launch"}
-                        if dom == "k_bwd_count4_struct" else
+                        if dom == "k_bwd_count4f_struct" else
                         {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_bin": alg_b, "alg_bytes_per_launch": bins * alg_b,
                          "note": "the longest single launch of the step.  Its first 45 % (the speculative warm-up of every tile) stores nothing and is "
                                  "bound by FP64 issue, shared with the other kernels of phase 1; the table stores all fall into the rest, where they run "
                                  "at the measured HBM write rate of this box (device_probes.hbm_GBs.sweep_store)"}),
                      # the other heavy kernel of the step, so that both rooflines are on the line whichever is longer
-                     **({"also": {"bound": "mfma", "kernel": "k_bwd_count4_struct", "launches_per_step": diag.get("fused_launches", 1), "kernel_ms": fused_ms,
+                     **({"also": {"bound": "mfma", "kernel": "k_bwd_count4f_struct", "launches_per_step": diag.get("fused_launches", 1), "kernel_ms": fused_ms,
                                   "achieved": tfl, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop_b,
                                   "mfma_cycles_frac": (bins / 4 * 16 * 64) / (fused_ms * 1e-3 * 1024 * 2.16e9) if fused_ms > 0 else None,
                                   "note": "backward sweep + counts, both launches summed; mfma_cycles_frac = 16 x 64-cycle v_mfma_f64_16x16x4 per step of four "
                                           "tiles over SIMD time at the 2.16 GHz the box sustains (SQ counters: profiles/r02_sq_counters.json)"}}
-                        if fused and dom != "k_bwd_count4_struct" else
+                        if fused and dom != "k_bwd_count4f_struct" else
                         ({"also": {"bound": "hbm", "kernel": "k_fwd_struct<speculate>", "kernel_ms": kern["fwd_sweep"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                    "achieved": bins * (8 * N_STATES + 9) / (kern["fwd_sweep"] * 1e-3) / 1e9,
                                    "frac": bins * (8 * N_STATES + 9) / (kern["fwd_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS}} if fused and kern.get("fwd_sweep", 0) > 0 else {})),

@@ -35,6 +35,7 @@ struct psmc_hip_ctx {
 	int kcol_prio = 2;         // "kcol_prio": wave priority of k_kcol2_struct
 	int exact_lds = 0;         // "exact_lds": exact mode (<= 64 states) broadcasts the operands of its ordered sums through LDS instead of DPP rows; measured slower (905 vs 779 ms)
 	int lanes8 = 0;            // "lanes8": eight tiles per wave in the bulk forward sweep and the backward warm-up of the fused / factored back half
+	int count_impl = 1;        // "count_impl": variant of the fused back half (0: own normaliser per position; 1: forward-scaled; 2: + interleaved issue, measured slower)
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
 	int two_phase = 2;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
@@ -275,6 +276,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->items_dirty = true; }
 	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
 	else if (k == "lanes8") { c->lanes8 = v != 0 ? 1 : 0; }
+	else if (k == "count_impl") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->count_impl = (int)v; }
 	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
 	else if (k == "two_phase") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
@@ -510,7 +512,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const d
 	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
-	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.lanes8 = c->lanes8; p.exact_lds = c->exact_lds;
+	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.count_impl = c->count_impl; p.lanes8 = c->lanes8; p.exact_lds = c->exact_lds;
 	p.walk_impl = c->walk_impl; p.kcol_impl = kcol2_on(c) ? 1 : 0; p.d_kcc = pb + psmc_hip_ctx::KCC_OFF;
 	p.ns = c->ns;
 	if (c->ns == 128) {

@@ -5,13 +5,21 @@
 //   SL_k = sum_{l<k} A[k][l]   SU_k = sum_{l>k} A[k][l]   DG_k = A[k][k]
 //   CL_l = sum_{k>l} A[k][l]   CU_l = sum_{k<l} A[k][l]
 // and with A[k][l] = a[k][l] sum_p w_p X_p[k] bt_{p+1}[l] every one of them is a scan away from what the
-// backward step computes anyway (z = bt_{p+1}, w_p = sb_p / G_p):
+// backward step computes anyway (z = bt_{p+1}; w_p = 1/I for every p, see below):
 //   SL_k = P_k   sum_p w_p X_p[k] PREexcl_k(z.qa)      SU_k = R_k sum_p w_p X_p[k] SUFexcl_k(z.c)
 //   CL_l = qa_l  sum_p w_p z_l    SUFexcl_l(X_p.P)     CU_l = c_l sum_p w_p z_l    PREexcl_l(X_p.R)
 //   DG_k = a_kk  sum_p w_p X_p[k] z_k
 // So the counts GEMM (2 N^2 flop per bin, 1 KB of table reads per bin, the bt table) disappears: the wave
 // that walks four tiles backwards reads X, keeps bt in registers and accumulates 7 x 4 numbers per lane.
 // HBM per bin: 8N (write X) + 8N (read X).  Entry point psmc_hip_estep_factored (include/psmc_hip.h).
+//
+// Scaling (round 2): the backward recursion takes the FORWARD sweep's scale factors, bt_p = e[o_p] (a bt_{p+1}) inv_p with
+// inv_p = 1/d_p at p % 4 == 0 (the d_s table) and 1 elsewhere, like khmm.c:228-235.  Then I = sum_k X_p[k] (a bt_{p+1})[k]
+// is the same number at every position of a tile (it drifts by rounding only, < 1e-13 over a tile), the posterior
+// weights are 1/I, and nothing has to be normalised per position: no row sum, no reciprocal, no weight
+// multiplications (44 vector instructions per step fewer than with bt's own row sums).  The start vector of a tile has an
+// arbitrary scale, so the tile keeps sum_k X_p[k] y_p[k] = I of the last position it walked and divides its partials by it
+// when it stores them.
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
 #include "struct_prims.h"
@@ -37,18 +45,17 @@ template <int NPL> __device__ __forceinline__ double lane_sum_a(const double (&x
 // One position p of one row: x = bt_{p+1} on entry, bt_p on exit; X = X_p.  NORM: p % NORM_EVERY == 0.
 // NPLA_ states per lane: 4 (up to 64 states) or 8 (up to 128, `-p "64*2"`); 16 lanes = one tile either way.
 template <bool NORM, int NPLA = 4>
-__device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const double *lds_e, const double *lds_re, int k0, int sym,
-                                         const double (&X)[NPLA], double (&x)[NPLA], double (&acc)[NACC][NPLA])
+__device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const double *lds_e, const double *lds_m, int k0, int sym,
+                                         const double (&X)[NPLA], double (&x)[NPLA], double inv, double (&acc)[NACC][NPLA],
+                                         double &I_lane)
 {
 	constexpr int SA = 16 * NPLA;
-	double ev[NPLA], rv[NPLA];
+	double ev[NPLA];
 	loadN<NPLA>(lds_e + sym * SA + k0, ev);
-	loadN<NPLA>(lds_re + sym * SA + k0, rv);
-	double sbv = 1.0;
-	if (NORM) { // sb_p = 1/sum(bt_{p+1})
-		sbv = rcp_newton(row_sum16(lane_sum_a<NPLA>(x)));
+	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
+	if (NORM) { // the forward sweep's 1/d_p
 #pragma unroll
-		for (int i = 0; i < NPLA; ++i) ev[i] *= sbv;
+		for (int i = 0; i < NPLA; ++i) ev[i] *= inv;
 	}
 	// lane-local inclusive scans: z.c / z.qa (the backward step) and X.P / X.R (the column sums)
 	double su[NPLA + 1], pv[NPLA + 1], sx[NPLA + 1], px[NPLA + 1];
@@ -59,28 +66,29 @@ __device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const doubl
 	for (int i = 0; i < NPLA; ++i) { pv[i + 1] = __builtin_fma(x[i], sc.mP[i], pv[i]); px[i + 1] = __builtin_fma(X[i], sc.wS[i], px[i]); }
 	const double ES = row_excl_suffix(su[0]), EP = row_excl_prefix(pv[NPLA]);
 	const double EX = row_excl_suffix(sx[0]), PX = row_excl_prefix(px[NPLA]);
-	double bt[NPLA], gk[NPLA], G = 0.0;
+	double Il = 0.0;
 #pragma unroll
 	for (int i = 0; i < NPLA; ++i) {
 		const double t = __builtin_fma(sc.wS[i], su[i], __builtin_fma(sc.wP[i], pv[i + 1], sc.dd[i] * x[i]));
-		bt[i] = __builtin_fma(sc.wS[i], ES, __builtin_fma(sc.wP[i], EP, t)) * ev[i];
-		gk[i] = X[i] * bt[i] * rv[i];
-		G += gk[i];
+		const double y = __builtin_fma(sc.wS[i], ES, __builtin_fma(sc.wP[i], EP, t)); // (a bt_{p+1})[k]
+		const double gk = X[i] * y;                                                    // I * posterior of state k at p
+		acc[0][i] = __builtin_fma(X[i], EP + pv[i], acc[0][i]);     // SL: strictly below k
+		acc[1][i] = __builtin_fma(X[i], ES + su[i + 1], acc[1][i]); // SU: strictly above k
+		acc[2][i] = __builtin_fma(X[i], x[i], acc[2][i]);           // DG
+		acc[3][i] = __builtin_fma(x[i], EX + sx[i + 1], acc[3][i]); // CL: rows k > l
+		acc[4][i] = __builtin_fma(x[i], PX + px[i], acc[4][i]);     // CU: rows k < l
+		acc[5][i] = __builtin_fma(gk, mk.x, acc[5][i]);
+		acc[6][i] = __builtin_fma(gk, mk.y, acc[6][i]);
+		Il += gk;
+		x[i] = y * ev[i];
 	}
-	const double iG = rcp_newton(row_sum16(G)), wgt = sbv * iG;
-	const double h0 = sym == 0 ? iG : 0.0, h1 = sym == 1 ? iG : 0.0;
-#pragma unroll
-	for (int i = 0; i < NPLA; ++i) {
-		const double wx = wgt * X[i], wz = wgt * x[i];
-		acc[0][i] = __builtin_fma(wx, EP + pv[i], acc[0][i]);     // SL: strictly below k
-		acc[1][i] = __builtin_fma(wx, ES + su[i + 1], acc[1][i]); // SU: strictly above k
-		acc[2][i] = __builtin_fma(wx, x[i], acc[2][i]);           // DG
-		acc[3][i] = __builtin_fma(wz, EX + sx[i + 1], acc[3][i]); // CL: rows k > l
-		acc[4][i] = __builtin_fma(wz, PX + px[i], acc[4][i]);     // CU: rows k < l
-		acc[5][i] = __builtin_fma(gk[i], h0, acc[5][i]);
-		acc[6][i] = __builtin_fma(gk[i], h1, acc[6][i]);
-		x[i] = bt[i];
-	}
+	I_lane = Il; // this lane's share of I at position p
+}
+// 1/I of a tile (n_pos = 0: an empty tile, whose partials are zero anyway)
+__device__ __forceinline__ double tile_inv_I(double I_lane, int n_pos)
+{
+	const double tot = row_sum16(I_lane);
+	return n_pos > 0 ? rcp_newton(tot) : 1.0;
 }
 // scaled partials of one tile: the constant factors of the five sums and the multiplicity
 template <int NPLA = 4>
@@ -101,7 +109,7 @@ __device__ __forceinline__ void acc_store(const StructParN<NPLA> &sc, double mul
 // above (which becomes their bentry);  mode 2: every tile b < n whose X a forward repair rewrote, from bentry.
 template <int NPLA>
 __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const double *__restrict__ sp, const double *__restrict__ e,
-                                                            const double *__restrict__ re, const uint8_t *__restrict__ obs,
+                                                            const double *__restrict__ invd, const uint8_t *__restrict__ obs,
                                                             const Chunk *__restrict__ chunks, const SweepItemA *__restrict__ items,
                                                             int n, int mode, const double *__restrict__ f,
                                                             double *__restrict__ bentry, double *__restrict__ bexit,
@@ -109,13 +117,11 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
                                                             int *__restrict__ touch_b)
 {
 	constexpr int SA = 16 * NPLA;
-	__shared__ double lds_e[4 * SA], lds_re[4 * SA]; // e / 1/e rows: hom, het, 1, 1
+	__shared__ double lds_e[4 * SA], lds_m[8]; // e rows: hom, het, 1, 1;  emission-count masks per symbol
 	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLA * m;
 #pragma unroll
-	for (int i = lane; i < SA; i += 64) {
-		lds_e[i] = e[i]; lds_e[SA + i] = e[SA + i]; lds_e[2 * SA + i] = 1.0; lds_e[3 * SA + i] = 1.0;
-		lds_re[i] = re[i]; lds_re[SA + i] = re[SA + i]; lds_re[2 * SA + i] = 1.0; lds_re[3 * SA + i] = 1.0;
-	}
+	for (int i = lane; i < SA; i += 64) { lds_e[i] = e[i]; lds_e[SA + i] = e[SA + i]; lds_e[2 * SA + i] = 1.0; lds_e[3 * SA + i] = 1.0; }
+	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
 	__syncthreads();
 	const int slot = blockIdx.x * 4 + row;
 	int tile; bool valid = slot < n;
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
 	const bool work = valid && top >= lo; // a tile holding only position L owns no transition: zero partials
 	const double *fo = f + c.off * SA + k0;
+	const double *io = invd + c.off;
 	StructParN<NPLA> sc; // backward: mS = c, wS = R, mP = qa, wP = P
 	loadN<NPLA>(sp + 3 * SA + k0, sc.mS); loadN<NPLA>(sp + SA + k0, sc.wS);
 	loadN<NPLA>(sp + 2 * SA + k0, sc.mP); loadN<NPLA>(sp + k0, sc.wP); loadN<NPLA>(sp + 4 * SA + k0, sc.dd);
@@ -137,11 +144,13 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 	} else {
 		loadN<NPLA>(bentry + (int64_t)tile * SA + k0, x);
 	}
-	double acc[NACC][NPLA];
+	double acc[NACC][NPLA], accI = 1.0;
 #pragma unroll
 	for (int q = 0; q < NACC; ++q)
 #pragma unroll
 		for (int i = 0; i < NPLA; ++i) acc[q][i] = 0.0;
+	const int n_pos = work ? top - lo + 1 : 0;
+	auto load_inv = [&](int g) { return io[min(max(4 * g + 4, lo), max(top, lo)) - 1]; }; // 1/d of the group's position 4g + 4 (unused when that lies outside the tile)
 	// groups of four positions 4g+1 .. 4g+4 (indices 4g .. 4g+3), highest first; the group's last
 	// position (p % 4 == 0) carries the scale factor
 	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
@@ -159,6 +168,7 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 	};
 	double Xg[4][NPLA];
 	load_group(max(g_hi, 0), Xg);
+	double inv_cur = load_inv(max(g_hi, 0));
 	if constexpr (NPLA == 8) {
 		// 128 states: 7 x 8 accumulators and 5 x 8 constants per lane leave no room for a second X buffer -- every row
 		// is reloaded for the next group as soon as its step has used it (as in estep_fused.hip)
@@ -170,13 +180,15 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 			const unsigned w = row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
 			if (gi < ng) {
 				const int g = g_hi - gi;
+				const double inv = inv_cur;
+				if (gi + 1 < ng) inv_cur = load_inv(g - 1);
 #pragma unroll
 				for (int j = 3; j >= 0; --j) {
 					const int p = 4 * g + j + 1;
 					if (p <= top && p >= lo) {
 						const int sym = (int)((w >> (8 * j)) & 3u);
-						if (j == 3) acc_step<true, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
-						else acc_step<false, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
+						if (j == 3) acc_step<true, NPLA>(sc, lds_e, lds_m, k0, sym, Xg[j], x, inv, acc, accI);
+						else acc_step<false, NPLA>(sc, lds_e, lds_m, k0, sym, Xg[j], x, inv, acc, accI);
 						if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
 					}
 					if (gi + 1 < ng) { // this row of the next group (positions 4(g-1)+j+1), clamped into the tile
@@ -186,7 +198,8 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 				}
 			}
 		}
-		if (valid) acc_store<NPLA>(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
+		const double iI = tile_inv_I(accI, n_pos);
+		if (valid) acc_store<NPLA>(sc, (double)c.mult * iI, acc, part + (int64_t)tile * (NACC * SA) + k0);
 		return;
 	}
 	double Xn[4][NPLA];
@@ -199,14 +212,15 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 		const unsigned w = row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
 		if (gi < ng) {
 			const int g = g_hi - gi;
-			if (gi + 1 < ng) load_group(g - 1, Xn);
+			const double inv = inv_cur;
+			if (gi + 1 < ng) { load_group(g - 1, Xn); inv_cur = load_inv(g - 1); }
 #pragma unroll
 			for (int j = 3; j >= 0; --j) {
 				const int p = 4 * g + j + 1;
 				if (p > top || p < lo) continue;
 				const int sym = (int)((w >> (8 * j)) & 3u);
-				if (j == 3) acc_step<true, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
-				else acc_step<false, NPLA>(sc, lds_e, lds_re, k0, sym, Xg[j], x, acc);
+				if (j == 3) acc_step<true, NPLA>(sc, lds_e, lds_m, k0, sym, Xg[j], x, inv, acc, accI);
+				else acc_step<false, NPLA>(sc, lds_e, lds_m, k0, sym, Xg[j], x, inv, acc, accI);
 				if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
 			}
 #pragma unroll
@@ -215,9 +229,8 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 				for (int i = 0; i < NPLA; ++i) Xg[j][i] = Xn[j][i];
 		}
 	}
-	if (valid) {
-		acc_store<NPLA>(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
-	}
+	const double iI = tile_inv_I(accI, n_pos);
+	if (valid) acc_store<NPLA>(sc, (double)c.mult * iI, acc, part + (int64_t)tile * (NACC * SA) + k0);
 }
 
 constexpr int NPLA = 4, SA = 64; // the checkpointed variant below is the 64-state one
@@ -227,12 +240,18 @@ constexpr int NPLA = 4, SA = 64; // the checkpointed variant below is the 64-sta
 // the block backwards -- 84 more VALU instructions per step in exchange for 7/8 of the table traffic
 // (HBM per bin: 8N/8 written + 8N/8 read).  The first block of a tile starts from the tile's own start vector
 // `entry` (what its checkpoints were computed from; position 1: X_1 itself, which the sweep stores), so a forward
-// repair of the tile below never races with this kernel; X of any scale will do (G_p carries the same factor).
+// repair of the tile below never races with this kernel.  The recomputation applies the forward sweep's scale factors
+// at p % 4 == 0 exactly as the sweep did (the backward recursion relies on X and bt sharing them, see the top of the file).
 // Needs tile_len % 8 == 0 (every lo = 1 mod 8): only the top block of a segment's last tile is partial.
-__device__ __forceinline__ void fwd_recompute_step(const StructParN<NPLA> &sc, const double *lds_e, int k0, int sym, double (&x)[NPLA])
+template <bool NORM>
+__device__ __forceinline__ void fwd_recompute_step(const StructParN<NPLA> &sc, const double *lds_e, int k0, int sym, double inv, double (&x)[NPLA])
 {	// forward roles of the five vectors: mS = P (bwd wP), wS = qa (bwd mP), mP = R (bwd wS), wP = c (bwd mS)
 	double ev[NPLA], su[NPLA], pv[NPLA];
 	loadN<NPLA>(lds_e + sym * SA + k0, ev);
+	if (NORM) {
+#pragma unroll
+		for (int i = 0; i < NPLA; ++i) ev[i] *= inv;
+	}
 	su[NPLA - 1] = x[NPLA - 1] * sc.wP[NPLA - 1];
 #pragma unroll
 	for (int i = NPLA - 2; i >= 0; --i) su[i] = __builtin_fma(x[i], sc.wP[i], su[i + 1]);
@@ -248,18 +267,18 @@ __device__ __forceinline__ void fwd_recompute_step(const StructParN<NPLA> &sc, c
 }
 
 __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict__ sp, const double *__restrict__ e,
-                                                          const double *__restrict__ re, const uint8_t *__restrict__ obs,
+                                                          const double *__restrict__ invd, const uint8_t *__restrict__ obs,
                                                           const Chunk *__restrict__ chunks, const SweepItemA *__restrict__ items,
                                                           int n, int mode, const double *__restrict__ f,
                                                           const double *__restrict__ entry, double *__restrict__ bentry,
                                                           double *__restrict__ bexit, double *__restrict__ part,
                                                           const int *__restrict__ touch_f, int *__restrict__ touch_b)
 {
-	__shared__ double lds_e[4 * SA], lds_re[4 * SA];
+	__shared__ double lds_e[4 * SA], lds_m[8];
 	__shared__ double lds_x[4 * 8 * SA]; // the block's X, private to the lane that wrote it: [row][j][half][2 m + i]
 	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLA * m;
 	lds_e[lane] = e[lane]; lds_e[SA + lane] = e[SA + lane]; lds_e[2 * SA + lane] = 1.0; lds_e[3 * SA + lane] = 1.0;
-	lds_re[lane] = re[lane]; lds_re[SA + lane] = re[SA + lane]; lds_re[2 * SA + lane] = 1.0; lds_re[3 * SA + lane] = 1.0;
+	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
 	__syncthreads();
 	double *xs = lds_x + row * (8 * SA) + 2 * m;
 	const int slot = blockIdx.x * 4 + row;
@@ -272,6 +291,7 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
 	const bool work = valid && top >= lo;
 	const double *fo = f + c.off * SA + k0;
+	const double *io = invd + c.off;
 	StructParN<NPLA> sc; // backward: mS = c, wS = R, mP = qa, wP = P
 	loadN<NPLA>(sp + 3 * SA + k0, sc.mS); loadN<NPLA>(sp + SA + k0, sc.wS);
 	loadN<NPLA>(sp + 2 * SA + k0, sc.mP); loadN<NPLA>(sp + k0, sc.wP); loadN<NPLA>(sp + 4 * SA + k0, sc.dd);
@@ -282,11 +302,12 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 	} else {
 		loadN<NPLA>(bentry + (int64_t)tile * SA + k0, x);
 	}
-	double acc[NACC][NPLA];
+	double acc[NACC][NPLA], accI = 1.0;
 #pragma unroll
 	for (int q = 0; q < NACC; ++q)
 #pragma unroll
 		for (int i = 0; i < NPLA; ++i) acc[q][i] = 0.0;
+	const int n_pos = work ? top - lo + 1 : 0;
 	// blocks of eight positions 8b+1 .. 8b+8 (indices 8b .. 8b+7), highest first
 	const int b_hi = work ? (top - 1) >> 3 : -1, b_lo = work ? (lo - 1) >> 3 : 0;
 	const int nb = b_hi - b_lo + 1;
@@ -296,12 +317,15 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 	const int nb_max = max(max(n0, n1), max(n2, n3));
 	// start vector of block b: X_{8b}; the tile's first block: its entry vector, or X_1 itself when lo == 1
 	const double *ck_first = lo > 1 ? entry + (int64_t)tile * SA + k0 : fo;
-	auto load_ck = [&](int b, double (&ck)[NPLA]) {
+	// ... and the forward scale factors of its positions 8b+4 and 8b+8 (anything where those lie above the tile's top: the
+	// recomputed X from there on are not used)
+	auto load_ck = [&](int b, double (&ck)[NPLA], double &i4, double &i8) {
 		const double *src = b <= b_lo ? ck_first : fo + (int64_t)(8 * b - 1) * SA;
 		loadN<NPLA>(src, ck);
+		i4 = io[8 * b + 3]; i8 = io[8 * b + 7];
 	};
-	double ck[NPLA], ckn[NPLA];
-	load_ck(max(b_hi, b_lo), ck);
+	double ck[NPLA], ckn[NPLA], inv4, inv8, inv4n = 1.0, inv8n = 1.0;
+	load_ck(max(b_hi, b_lo), ck, inv4, inv8);
 	for (int bi = 0; bi < nb_max; ++bi) {
 		// the block's eight symbols of every row: scalar loads (see estep_struct.hip row_symbols)
 		const uint2 w0 = *reinterpret_cast<const uint2 *>(obs + off0 + 8 * (int64_t)max(bh0 - min(bi, max(n0 - 1, 0)), 0));
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 		const unsigned wb = row == 0 ? w0.y : (row == 1 ? w1.y : (row == 2 ? w2.y : w3.y));
 		if (bi < nb) {
 			const int b = b_hi - bi;
-			if (bi + 1 < nb) load_ck(b - 1, ckn);
+			if (bi + 1 < nb) load_ck(b - 1, ckn, inv4n, inv8n);
 			// ---- forward: X of the block's positions from the checkpoint below them
 			const bool is_x1 = b == b_lo && lo == 1; // the start vector IS position 8b+1 = 1
 			double t[NPLA];
@@ -325,10 +349,12 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 					double u[NPLA];
 #pragma unroll
 					for (int i = 0; i < NPLA; ++i) u[i] = t[i];
-					fwd_recompute_step(sc, lds_e, k0, sym, u);
+					fwd_recompute_step<false>(sc, lds_e, k0, sym, 1.0, u);
 #pragma unroll
 					for (int i = 0; i < NPLA; ++i) t[i] = is_x1 ? t[i] : u[i];
-				} else fwd_recompute_step(sc, lds_e, k0, sym, t);
+				} else if (j == 3) fwd_recompute_step<true>(sc, lds_e, k0, sym, inv4, t);
+				else if (j == 7) fwd_recompute_step<true>(sc, lds_e, k0, sym, inv8, t);
+				else fwd_recompute_step<false>(sc, lds_e, k0, sym, 1.0, t);
 				*reinterpret_cast<d2v_t *>(xs + j * SA) = (d2v_t){t[0], t[1]};
 				*reinterpret_cast<d2v_t *>(xs + j * SA + 32) = (d2v_t){t[2], t[3]};
 			}
@@ -340,15 +366,17 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 				const int sym = (int)(((j < 4 ? wa : wb) >> (8 * (j & 3))) & 3u);
 				const d2v_t xa = *reinterpret_cast<const d2v_t *>(xs + j * SA), xb = *reinterpret_cast<const d2v_t *>(xs + j * SA + 32);
 				const double X[NPLA] = {xa.x, xa.y, xb.x, xb.y};
-				if ((j & 3) == 3) acc_step<true>(sc, lds_e, lds_re, k0, sym, X, x, acc);
-				else acc_step<false>(sc, lds_e, lds_re, k0, sym, X, x, acc);
+				if ((j & 3) == 3) acc_step<true>(sc, lds_e, lds_m, k0, sym, X, x, j == 7 ? inv8 : inv4, acc, accI);
+				else acc_step<false>(sc, lds_e, lds_m, k0, sym, X, x, 1.0, acc, accI);
 				if (p == lo) storeN<NPLA>(bexit + (int64_t)tile * SA + k0, x);
 			}
 #pragma unroll
 			for (int i = 0; i < NPLA; ++i) ck[i] = ckn[i];
+			inv4 = inv4n; inv8 = inv8n;
 		}
 	}
-	if (valid) acc_store(sc, (double)c.mult, acc, part + (int64_t)tile * (NACC * SA) + k0);
+	const double iI = tile_inv_I(accI, n_pos);
+	if (valid) acc_store(sc, (double)c.mult * iI, acc, part + (int64_t)tile * (NACC * SA) + k0);
 }
 
 // Fixed-order two-stage sum over the tiles: stage[y][q*64+k] = sum of the tiles j = y (mod RED_ROWS), then
@@ -398,13 +426,13 @@ void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, 
 	const SweepItemA *items = (const SweepItemA *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
 	const int mode = which == 1 ? 1 : (which == 2 ? 2 : 0);
 	if (p.ckpt)
-		hipLaunchKernelGGL(k_bwd_acc_ckpt, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+		hipLaunchKernelGGL(k_bwd_acc_ckpt, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_entry, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
 	else if (p.ns == 128)
-		hipLaunchKernelGGL(k_bwd_acc_struct<8>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+		hipLaunchKernelGGL(k_bwd_acc_struct<8>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
 	else
-		hipLaunchKernelGGL(k_bwd_acc_struct<4>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, items, n,
+		hipLaunchKernelGGL(k_bwd_acc_struct<4>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
 }
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st)

@@ -621,11 +621,11 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (lf) launch_fwd_struct(p, sw, 3, 0, p.n_mem_f);
 		(void)hipEventRecord(p.evx[7], sw);
 		if (ov) (void)hipStreamWaitEvent(sk, p.fused ? p.evx[7] : p.evx[6], 0); // fused: the backward pass reads the run tiles' X
-		if (lb) {
-			if (p.fused == 2) launch_bwd_acc(p, sk, 3, 0, p.n_mem_b);
-			else if (!p.fused) launch_bwd_struct(p, sk, 3, 0, p.n_mem_b); // fused: the one pass over all tile groups below covers them
-		}
-		(void)hipEventRecord(p.evx[9], sk);
+		// unfused: the tiles of backward runs need their boundary vectors only.  fused == 1: the one pass over all tile groups
+		// below covers them.  fused == 2: they also read X -- of tiles that may belong to the BULK forward sweep (a tile can
+		// be glued backward only), so that launch follows the sweep, further down.
+		if (lb && !p.fused) launch_bwd_struct(p, sk, 3, 0, p.n_mem_b);
+		if (p.fused != 2) (void)hipEventRecord(p.evx[9], sk);
 	}
 	const int ff0 = lf ? p.n_long_f : 0, fb0 = lb ? p.n_long_b : 0;
 	const bool one = p.structured && !p.fused; // both bulk sweeps in one launch (k_sweep_struct)
@@ -642,6 +642,19 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		(void)hipEventRecord(p.evx[10], sm);
 	}
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
+	if (lw && p.fused == 2) {
+		// Factored statistics of the tiles of backward runs, beside the bulk pass on a stream of their own.  They read the
+		// tiles' X and scale factors, which the bulk forward sweep (or its phase B) writes unless the tile is also part
+		// of a forward run.  (Until round 2 this launch followed the run tiles only: it could read a bulk tile's X of the
+		// PREVIOUS E-step; with the same parameters that is the same direction, and the per-position normaliser of the
+		// old kernels hid the rest.  Found when the forward scale factors became part of the backward recursion.)
+		hipStream_t sk = ov ? p.stream5 : sm;
+		if (lb) {
+			if (ov) { (void)hipStreamWaitEvent(sk, p.evx[1], 0); if (p.n_B_f > 0) (void)hipStreamWaitEvent(sk, p.evx[10], 0); }
+			launch_bwd_acc(p, sk, 3, 0, p.n_mem_b);
+		}
+		(void)hipEventRecord(p.evx[9], sk);
+	}
 	if (one && ov) (void)hipStreamWaitEvent(sa, p.evx[1], 0); // the backward chain follows the same launch
 	if (!one && p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
 	if (p.fused) {

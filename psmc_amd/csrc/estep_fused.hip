@@ -228,15 +228,224 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 	}
 }
 
+// ---- round 2: the same kernel without a per-position normaliser, and with the matrix instructions of a step issued
+// between the vector instructions of the NEXT step.
+//
+// (1) Scaling.  k_bwd_count4_struct normalises bt with its own row sums and then needs G_p = sum_k g_p[k] at every
+// position to turn X_p (x) bt_{p+1} into a posterior: a 16-lane reduction, a reciprocal and 13 multiplications per step.
+// khmm.c scales b with the FORWARD scale factors instead (khmm.c:228-235), which makes sum_k f_u[k] b_u[k] s_u = 1 at every
+// u.  The same holds here: with y_p = a bt_{p+1} and bt_p = e[o_p] y_p inv_p (inv_p = the forward sweep's 1/d_p at
+// p % 4 == 0, else 1 -- the d_s table) the number I_p = sum_k X_p[k] y_p[k] does not depend on p.  The start vector of a
+// tile is scale-free, so one pre-step measures I at the tile's top position and every position takes the same weight
+// rho = mult / I (mult = the segment's multiplicity):
+//   E[o_p][k] += rho X_p[k] y_p[k],    C[k][l] += rho X_p[k] bt_{p+1}[l]
+// I_p drifts by rounding only (a random walk of a few ulp per step: < 1e-13 over a tile; every tile measures its own).
+// The bt recursion itself never sees X or rho, and the forward scale factors are powers of two (struct_prims.h
+// pow2_rcp): the exit vector a tile hands to the tile below (two-phase plan) is the same bit pattern up to a power of
+// two whether or not a forward repair was rewriting the tile's tables while it was read -- the E-step stays
+// reproducible bit for bit (the tile itself is flagged by the repair and recomputed at the end).
+// (2) Issue order.  With one wave per SIMD a step is a chain of dependent vector instructions (row scans: v_add_f64 ->
+// v_mov_b32_dpp -> v_add_f64 ...) whose latencies nothing hides, followed by 16 matrix instructions that occupy the
+// FP64 pipe for 64 cycles each while the wave has nothing else to issue: 1 950 cycles for 1 548 busy.  Here the
+// matrix instructions of step p are held back (their operands FA / FB stay in registers) and interleaved, one after
+// every few vector instructions, with step p-1's sweep: the dependent instruction behind each of them issues when the
+// pipe comes free, long after its operand is ready.
+template <bool NORM, bool MASKED>
+__device__ __forceinline__ void count4f_step(const StructParN<NPLF> &sc, const double *lds_e, const double *lds_m, int k0, int sym,
+                                             const double (&X)[NPLF], double (&x)[NPLF], bool active, double inv, double rho,
+                                             double (&FA)[NPLF], double (&FB)[NPLF], double (&S)[2][NPLF])
+{
+	double ev[NPLF], y[NPLF];
+	loadN<NPLF>(lds_e + sym * SF + k0, ev);
+	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
+	if (NORM) {
+#pragma unroll
+		for (int i = 0; i < NPLF; ++i) ev[i] *= inv;
+	}
+#pragma unroll
+	for (int i = 0; i < NPLF; ++i) y[i] = x[i];
+	struct_step<NPLF>(sc, y);
+#pragma unroll
+	for (int i = 0; i < NPLF; ++i) {
+		FA[i] = rho * X[i];
+		if (MASKED) FA[i] = active ? FA[i] : 0.0; // an idle row may hold anything
+		const double gk = FA[i] * y[i];
+		S[0][i] = __builtin_fma(gk, mk.x, S[0][i]);
+		S[1][i] = __builtin_fma(gk, mk.y, S[1][i]);
+		FB[i] = MASKED ? (active ? x[i] : 0.0) : x[i];
+		const double nb = y[i] * ev[i];
+		x[i] = MASKED ? (active ? nb : x[i]) : nb;
+	}
+}
+__device__ __forceinline__ void count4f_mfma(const double (&FA)[NPLF], const double (&FB)[NPLF], d4f_t (&acc)[4][4])
+{
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+#pragma unroll
+		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[j2], acc[j][j2], 0, 0, 0);
+}
+// one matrix instruction, then VPM vector instructions, 16 times: the order the scheduler is asked for inside a step
+template <int VPM> __device__ __forceinline__ void count4f_order()
+{
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+		__builtin_amdgcn_sched_group_barrier(0x002, VPM, 0); // VALU
+	}
+}
+
+template <bool PIPE>
+__global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                                const double *__restrict__ invd, const uint8_t *__restrict__ obs,
+                                                                const Chunk *__restrict__ chunks, const int *__restrict__ tiles,
+                                                                int group0, int mode, const double *__restrict__ f,
+                                                                double *__restrict__ bentry, double *__restrict__ bexit,
+                                                                double *__restrict__ Cpart,
+                                                                double *__restrict__ Epart, const int *__restrict__ touch_f,
+                                                                const int *__restrict__ touch_b)
+{
+	__shared__ double lds_e[4 * SF], lds_m[8]; // e rows: hom, het, 1, 1;  count masks per symbol
+	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLF * m;
+	lds_e[lane] = e[lane]; lds_e[SF + lane] = e[SF + lane]; lds_e[2 * SF + lane] = 1.0; lds_e[3 * SF + lane] = 1.0;
+	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
+	__syncthreads();
+	const int group = group0 + blockIdx.x;
+	const int entry = tiles[4 * blockIdx.x + row];
+	const bool valid = entry >= 0, from_above = valid && mode == 0 && (entry & (1 << 30)) != 0;
+	const int tile = valid ? (entry & ~(1 << 30)) : 0;
+	if (mode == 2 && !__any(valid && (touch_f[tile] | touch_b[tile]) != 0)) return;
+	const Chunk c = chunks[tile];
+	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
+	const bool work = valid && top >= lo; // a tile holding only position L owns no transition
+	const double *fo = f + c.off * SF + k0;
+	const double *io = invd + c.off;
+	StructParN<NPLF> sc; // backward: mS = c, wS = R, mP = qa, wP = P
+	loadN<NPLF>(sp + 3 * SF + k0, sc.mS); loadN<NPLF>(sp + SF + k0, sc.wS);
+	loadN<NPLF>(sp + 2 * SF + k0, sc.mP); loadN<NPLF>(sp + k0, sc.wP); loadN<NPLF>(sp + 4 * SF + k0, sc.dd);
+	double x[NPLF];
+	loadN<NPLF>((from_above ? bexit + (int64_t)(tile + 1) * SF : bentry + (int64_t)tile * SF) + k0, x);
+	if (from_above) storeN<NPLF>(bentry + (int64_t)tile * SF + k0, x); // what verify compares and a redo starts from
+	const int p_min = lo, p_max = max(top, lo);
+	double rho; // mult / I of this row's tile
+	{ // the pre-step: I = sum_k X_top[k] (a bt_{top+1})[k]
+		double y[NPLF], Xt[NPLF];
+		loadN<NPLF>(fo + (int64_t)(p_max - 1) * SF, Xt);
+#pragma unroll
+		for (int i = 0; i < NPLF; ++i) y[i] = x[i];
+		struct_step<NPLF>(sc, y);
+		const double I = row_sum16((Xt[0] * y[0] + Xt[1] * y[1]) + (Xt[2] * y[2] + Xt[3] * y[3]));
+		rho = work ? (double)c.mult * rcp_newton(I) : 0.0;
+	}
+	d4f_t acc[4][4];
+	double S[2][NPLF], FAp[NPLF], FBp[NPLF];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+#pragma unroll
+		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0};
+		S[0][j] = S[1][j] = 0.0; FAp[j] = FBp[j] = 0.0;
+	}
+	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
+	const int ng = g_hi - g_lo + 1;
+	const int64_t off0 = readlane_i64f(c.off, 0), off1 = readlane_i64f(c.off, 16), off2 = readlane_i64f(c.off, 32), off3 = readlane_i64f(c.off, 48);
+	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
+	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
+	const int ng_max = max(max(n0, n1), max(n2, n3));
+	auto load_row = [&](int g, int j, double (&Xq)[NPLF]) { // X of position 4g + j + 1, clamped into the tile
+		const int p = min(max(4 * g + j + 1, p_min), p_max);
+		loadN<NPLF>(fo + (int64_t)(p - 1) * SF, Xq);
+	};
+	auto load_inv = [&](int g) { // the forward scale factor of the group's normalising position 4g + 4 (anything for a position outside the tile: masked)
+		return io[min(max(4 * g + 4, p_min), p_max) - 1];
+	};
+	double Xg[4][NPLF];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) load_row(max(g_hi, 0), j, Xg[j]);
+	double inv_cur = load_inv(max(g_hi, 0));
+	int gi = 0;
+	struct Words { unsigned w0, w1, w2, w3; };
+	auto load_words = [&](int gi_) { // see k_bwd_count4_struct
+		Words q;
+		const uint8_t *p0 = obs + off0 + 4 * (int64_t)max(gh0 - min(gi_, max(n0 - 1, 0)), 0);
+		const uint8_t *p1 = obs + off1 + 4 * (int64_t)max(gh1 - min(gi_, max(n1 - 1, 0)), 0);
+		const uint8_t *p2 = obs + off2 + 4 * (int64_t)max(gh2 - min(gi_, max(n2 - 1, 0)), 0);
+		const uint8_t *p3 = obs + off3 + 4 * (int64_t)max(gh3 - min(gi_, max(n3 - 1, 0)), 0);
+		asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0"
+		             : "=&s"(q.w0), "=&s"(q.w1), "=&s"(q.w2), "=&s"(q.w3) : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
+		return q;
+	};
+	auto select_word = [&](Words q) {
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.w0), "+s"(q.w1), "+s"(q.w2), "+s"(q.w3));
+		return row == 0 ? q.w0 : (row == 1 ? q.w1 : (row == 2 ? q.w2 : q.w3));
+	};
+	unsigned w_cur = select_word(load_words(0));
+	auto all_full = [&](int gi_) {
+		const int g = max(g_hi - gi_, g_lo);
+		return __all(gi_ < ng && 4 * g + 1 >= lo && 4 * g + 4 <= top) != 0;
+	};
+	auto do_group = [&](auto masked_tag) {
+		constexpr bool MASKED = decltype(masked_tag)::value;
+		const unsigned w = w_cur;
+		const Words wn = load_words(gi + 1);
+		__builtin_amdgcn_sched_barrier(0);
+		const int g = max(g_hi - gi, g_lo); // rows that are done idle on their last group
+		const bool in_tile = gi < ng;
+		const int s3 = (int)((w >> 24) & 3u), s2 = (int)((w >> 16) & 3u), s1 = (int)((w >> 8) & 3u), s0 = (int)(w & 3u);
+		const int pb = 4 * g + 1;
+		const double inv = inv_cur;
+		double FAn[NPLF], FBn[NPLF];
+#define PSMC_C4F(NORM, J, SYM)                                                                                                   \
+		count4f_step<NORM, MASKED>(sc, lds_e, lds_m, k0, SYM, Xg[J], x, in_tile && pb + J <= top && pb + J >= lo, inv, rho, FAn, FBn, S); \
+		if (PIPE) { count4f_mfma(FAp, FBp, acc); count4f_order<5>(); } else count4f_mfma(FAn, FBn, acc);                   \
+		_Pragma("unroll") for (int i = 0; i < NPLF; ++i) { FAp[i] = FAn[i]; FBp[i] = FBn[i]; }                               \
+		load_row(g - 1, J, Xg[J]);                                                                                          \
+		if (J == 3) inv_cur = load_inv(g - 1);                                                                              \
+		__builtin_amdgcn_sched_barrier(0);
+		PSMC_C4F(true, 3, s3) PSMC_C4F(false, 2, s2) PSMC_C4F(false, 1, s1) PSMC_C4F(false, 0, s0)
+#undef PSMC_C4F
+		if (in_tile && g == g_lo) storeN<NPLF>(bexit + (int64_t)tile * SF + k0, x); // x = bt_lo: the group holding lo is the row's last
+		w_cur = select_word(wn);
+	};
+	for (; gi < ng_max && !all_full(gi); ++gi) do_group(std::true_type{});  // a top that is not a multiple of 4
+	for (; gi < ng_max && all_full(gi); ++gi) do_group(std::false_type{});
+	for (; gi < ng_max; ++gi) do_group(std::true_type{});                    // rows of unequal length, a lo that is not 1 mod 4
+	if (PIPE) count4f_mfma(FAp, FBp, acc); // the last step's
+	// the matrix-core results are not interlocked against plain reads: let the last instructions drain
+	asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
+	             : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+	               "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
+	               "+a"(acc[3][2]), "+a"(acc[3][3]));
+	double *out = Cpart + (int64_t)group * (SF * SF);
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const double v[NPLF] = {acc[j][0][r], acc[j][1][r], acc[j][2][r], acc[j][3][r]};
+			storeN<NPLF>(out + (4 * (row + 4 * r) + j) * SF + k0, v);
+		}
+	if (valid) {
+		double *os = Epart + (int64_t)tile * (3 * SF) + k0;
+		const double zero[NPLF] = {0.0, 0.0, 0.0, 0.0};
+		storeN<NPLF>(os, S[0]); storeN<NPLF>(os + SF, S[1]); storeN<NPLF>(os + 2 * SF, zero); // missing symbols are not counted (khmm.c:355)
+	}
+}
+
 // list 0 / 1: tile list A / B of the plan (api.hip build_items);  redo: only the groups a repair touched
 void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo)
 {
 	const int ga = (p.n_list_a + 3) / 4, gb = (p.n_list_b + 3) / 4;
 	const int n_groups = list == 0 ? ga : gb;
 	if (n_groups <= 0) return;
-	hipLaunchKernelGGL(k_bwd_count4_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks,
-	                   p.d_ftiles + (list == 0 ? 0 : 4 * ga), list == 0 ? 0 : ga, redo ? 2 : 0, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart,
-	                   p.d_Epart, p.d_touch_f, p.d_touch_b);
+	const int *tl = p.d_ftiles + (list == 0 ? 0 : 4 * ga);
+	const int g0 = list == 0 ? 0 : ga, md = redo ? 2 : 0;
+	if (p.count_impl == 2)
+		hipLaunchKernelGGL(k_bwd_count4f_struct<true>, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
+		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+	else if (p.count_impl == 1)
+		hipLaunchKernelGGL(k_bwd_count4f_struct<false>, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
+		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+	else
+		hipLaunchKernelGGL(k_bwd_count4_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, tl, g0, md,
+		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
 }
 
 } // namespace psmc

@@ -133,8 +133,8 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Ma
 	}
 	double ev[NPL];
 	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
-	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}), off the critical path
-		const double inv = rcp_newton(tile_sum<NPL, LPT>(x));
+	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}) rounded down to a power of two, off the critical path
+		const double inv = pow2_rcp(tile_sum<NPL, LPT>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= inv;
 		if (MODE == 1) inv_keep = m == g ? inv : inv_keep; // one 32-byte store per tile and block instead of four 8-byte ones

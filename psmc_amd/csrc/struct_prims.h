@@ -86,6 +86,16 @@ __device__ __forceinline__ double struct_step1(const StructPar1 &c, double x, co
 	return __builtin_fma(c.wS, SI, __builtin_fma(c.wP, PI, c.dd * x));
 }
 
+// 2^-E for x = 1.m * 2^E (x positive, normal): x * pow2_rcp(x) lies in [1, 2).  The forward sweep normalises with THIS
+// instead of 1/sum (estep_struct.hip fwd_step): multiplying by a power of two is exact, so the lag-normalised X and
+// everything computed from it are the same numbers whatever the scale factors were -- which makes the back halves
+// that take the forward scale factors (estep_fused.hip, estep_factored.hip) reproducible bit for bit even when they
+// read a scale factor a forward repair is just rewriting (old or new: the two differ by a power of two).
+__device__ __forceinline__ double pow2_rcp(double x) {
+	const unsigned hi = (unsigned)((unsigned long long)__builtin_bit_cast(long long, x) >> 32);
+	const unsigned r = 0x7FE00000u - (hi & 0x7FF00000u);
+	return __builtin_bit_cast(double, (long long)((unsigned long long)r << 32));
+}
 __device__ __forceinline__ double rcp_newton(double x) {
 	double r = __builtin_amdgcn_rcp(x);
 	double t = __builtin_fma(-x, r, 1.0);

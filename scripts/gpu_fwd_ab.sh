@@ -14,6 +14,6 @@ d = collections.defaultdict(list)
 for r in csv.DictReader(open('/tmp/ab%s/run_kernel_trace.csv' % v)):
     m = re.search(r'(k_[a-z0-9_]+)', r['Kernel_Name']); k = (m.group(1) if m else '?') + ('<rep>' if 'Lb1' in r['Kernel_Name'] else '')
     d[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
-print("%-8s" % (v or "base"), " ".join("%s %.2f" % (k, max(x)) for k, x in d.items() if k in ('k_fwd_struct', 'k_bwd_struct', 'k_bwd_count4_struct', 'k_kcol_struct')))
+print("%-8s" % (v or "base"), " ".join("%s %.2f" % (k, max(x)) for k, x in d.items() if k in ('k_fwd_struct', 'k_bwd_struct', 'k_bwd_count4f_struct', 'k_kcol_struct')))
 PY
 done

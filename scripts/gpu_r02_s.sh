@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 2, GPU call S: tile-length sweep on the new back halves; the once-flaky lanes8 test in a loop
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for i in 1 2 3 4 5 6; do
+PSMC_HIP_POISON=vary timeout 200 python -m pytest tests/test_gpu_estep.py -m gpu -q -x -k "fused_backward_counts and 1-opts1" 2>&1 | tail -1
+done
+for cfg in "chunk=3712" "chunk=5568" "chunk=7424" "chunk=3712 warmup=2048" "chunk=2784"; do
+  tag=$(echo $cfg | tr ' =' '__')
+  opts=""; for kv in $cfg; do opts="$opts --opt $kv"; done
+  timeout 200 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --exact-extra 0 --n128-extra 0 $opts > gpurun_out/s_bench_$tag.json 2> gpurun_out/s_bench_$tag.err
+  echo "bench [$cfg] rc=$?"
+  python - <<PY
+import json
+r=json.load(open("gpurun_out/s_bench_$tag.json"))
+k=r["roofline"]["kernels_ms"]; fk=r["factored_stats"].get("kernels_ms") or {}
+print("   moving %.2f ms  steady %.2f ms  factored %.2f ms  fwd_sweep %.2f expect %.2f | factored fwd %.2f acc %.2f | repairs %s" % (r["ms_per_step"], r["steady_state"]["ms_per_step"], r["factored_stats"]["ms_per_step"], k["fwd_sweep"], k["expect"], fk.get("fwd_sweep",0), fk.get("expect",0), r["config"].get("repair_rounds")))
+PY
+done

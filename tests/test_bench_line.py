@@ -41,9 +41,9 @@ def test_bench_line_contract(case):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     if case == "fused_fwd_longest":
-        assert r["kernel"] == "k_fwd_struct<speculate>" and r["bound"] == "hbm" and r["also"]["kernel"] == "k_bwd_count4_struct"
+        assert r["kernel"] == "k_fwd_struct<speculate>" and r["bound"] == "hbm" and r["also"]["kernel"] == "k_bwd_count4f_struct"
         assert 0.3 < r["also"]["frac"] < 0.7 and 0.3 < r["also"]["mfma_cycles_frac"] < 0.7
         assert abs(r["achieved"] - bins * 521 / 7.2e-3 / 1e9) < 1e-6
     if case == "fused_counts_longest":
-        assert r["kernel"] == "k_bwd_count4_struct" and r["bound"] == "mfma" and r["also"]["kernel"].startswith("k_fwd_struct")
+        assert r["kernel"] == "k_bwd_count4f_struct" and r["bound"] == "mfma" and r["also"]["kernel"].startswith("k_fwd_struct")
         assert abs(r["achieved"] - bins * (2 * 64 * 64 + 24 * 64) / 6.8e-3 / 1e12) < 1e-9

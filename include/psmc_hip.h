@@ -70,6 +70,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * index inside their segment do not speculate but start from the exact boundary vector their neighbour left: 2,
  * default: backward only, in the second launch of the fused back half; 1: forward as well, in a second forward
  * launch; 0: every tile speculates),
+ * "fuse128" (1, default: the fused back half for 65..128 states as well, four waves per group of four tiles; 0: bt table +
+ * separate counts kernel),
  * "count_impl" (fused back half; 1, default: the backward recursion takes the forward sweep's scale factors, so no position is
  * normalised on its own; 2: the same with the matrix instructions of a step issued between the vector instructions of the
  * next one (measured slower); 0: round 1's kernel with a normaliser per position),

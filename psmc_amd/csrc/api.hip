@@ -45,6 +45,7 @@ struct psmc_hip_ctx {
 	hipStream_t stream5 = nullptr;
 	int ckpt = 1;              // "ckpt": factored statistics recompute X from checkpoints every 8 positions instead of reading the table
 	int fuse = 1;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip): structured matrices, up to 64 states
+	int fuse128 = 1;           // "fuse128": the same with 65..128 states (k_bwd_count8_struct: four waves per group of four tiles)
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
 	int warm_shift = 1;        // "warm_shift": before that, once, give such a tile a warm-up of warmup << warm_shift bins (0: glue at once)
 	bool chunks_dirty = false; // a tile's warm-up changed: d_chunks is stale
@@ -283,6 +284,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
+	else if (k == "fuse128") { c->fuse128 = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
@@ -496,6 +498,9 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0)
 	return 0;
 }
 
+// fused backward sweep + counts: structured matrices; 64 states, or 128 with "fuse128"
+static bool fused_counts(const psmc_hip_ctx *c) { return c->fuse && c->expect_impl == 1 && (c->ns == 64 || (c->ns == 128 && c->fuse128)); }
+
 // the column-per-lane transfer-matrix kernel: 64 states by default; 128 states only on request ("kcol_impl" = 2: it
 // takes 2.3x fewer vector instructions there too, but its chain path ends later and the E-step gets slower, 30.6 vs 28.3 ms)
 static bool kcol2_on(const psmc_hip_ctx *c) { return c->kcol_impl == 2 || (c->kcol_impl == 1 && c->ns == 64); }
@@ -509,7 +514,7 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const d
 	p.d_a = pb; p.d_aeT = pb + 4096; p.d_e = pb + 4 * 4096; p.d_a0 = pb + 4 * 4096 + 192;
 	p.d_re = pb + 4 * 4096 + 192 + 64;
 	p.d_sp = pb + psmc_hip_ctx::SP_OFF; p.structured = c->use_struct ? 1 : 0;
-	p.fused = (c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) ? 1 : 0;
+	p.fused = (c->use_struct && fused_counts(c)) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
 	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.count_impl = c->count_impl; p.lanes8 = c->lanes8; p.exact_lds = c->exact_lds;
@@ -713,7 +718,7 @@ static int plan_fast(psmc_hip_ctx *c)
 	c->chunk_used = T;
 	c->planned_struct = st;
 	// the counts kernel splits a tile over n_sub waves: keep about the same number of partial blocks
-	c->n_sub_used = st ? (c->fuse && c->expect_impl == 1 && c->ns == 64 ? 1 : std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1)))) : c->n_sub;
+	c->n_sub_used = st ? (fused_counts(c) ? 1 : std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1)))) : c->n_sub;
 	c->glue_f.assign(nc, 0); c->glue_b.assign(nc, 0); // a new tiling forgets what was learned
 	c->items_dirty = true;
 	int rc;
@@ -910,7 +915,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	c->tables_batch = false;
 	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
 	// the backward table: only for the unfused back half (the fused and the factored one never store bt)
-	if (!c->want_factored && !(c->use_struct && c->fuse && c->expect_impl == 1 && c->ns == 64) && (rc = ensure_tables(c, true))) return rc;
+	if (!c->want_factored && !(c->use_struct && fused_counts(c)) && (rc = ensure_tables(c, true))) return rc;
 	if (c->ns == 128 && !c->use_struct)
 		return fail(c, PSMC_HIP_ENOTSUP, "fast mode beyond 64 states needs a transition matrix of the PSMC form (structured sweeps)");
 	if (c->want_factored && !c->use_struct)

@@ -362,18 +362,21 @@ def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     es.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(chunk=512, warmup=256), dict(chunk=1000, warmup=100, overlap=0, learn=0)])
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=512, warmup=256), dict(chunk=1000, warmup=100, overlap=0, learn=0),
+                                  dict(chunk=264, warmup=300, two_phase=0), dict(chunk=768, warmup=64, two_phase=1),
+                                  dict(fuse128=0), dict(fuse128=0, chunk=512, warmup=256), dict(fuse128=0, chunk=1000, warmup=100, overlap=0, learn=0)])
 def test_fast_n128(hip, golden, oracle, opts):
-    """-p "64*2" in fast mode: 8 states per lane in the structured sweeps, the counts in four 64x64 quadrants."""
+    """-p "64*2" in fast mode: 8 states per lane in the structured sweeps; the counts fused with the backward sweep, four
+    waves per group of four tiles (default), or from the bt table in four 64x64 quadrants (fuse128=0)."""
     g, k = golden.n128, "n128_curve"
     a, e, a0 = g[k + ".a"], g[k + ".e"], g[k + ".a0"]
     segs = golden.segs_small + golden.segs_mid[2:]
     o = oracle.estep(a, e, a0, segs)
     es = hip.HipEStep(128, mode=hip.MODE_FAST, **opts)
     es.load_segments(segs)
-    for it in range(2):
+    for it in range(3):
         check_fast(es.estep(a, e, a0), o)
-    assert es.fast_diag()["structured"]
+    assert es.fast_diag()["structured"] and es.fast_diag()["back_half"] == opts.get("fuse128", 1)
     for it in range(2):  # the O(N) statistics with eight states per lane (k_bwd_acc_struct<8>)
         r = es.estep_factored(a, e, a0)
         assert relmax(r["sums"], tri_sums(o["A"])) < FAST_TOL_STATS and relmax(r["E"], o["E"]) < FAST_TOL_STATS

@@ -39,6 +39,7 @@ struct psmc_hip_ctx {
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
 	int two_phase = 2;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
+	int walk_heads = 0;        // "walk_heads": 1 = the walk of a chain run also goes through its head tile (as before round 2's last build)
 	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
 	double *d_Kcol = nullptr; size_t kcol_cap = 0;
@@ -271,7 +272,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; }
-	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; }
+	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; c->items_dirty = true; } // the walk lists depend on the kernel (count 0 items)
 	else if (k == "kcol_impl") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_impl = (int)v; c->items_dirty = true; }
 	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->items_dirty = true; }
@@ -281,6 +282,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
 	else if (k == "two_phase") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
+	else if (k == "walk_heads") { c->walk_heads = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
@@ -824,12 +826,16 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 	c->items_two_phase = (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0);
 	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
-	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": only its head tile is walked
-	// (from the usual speculative warm-up); the boundary vectors of its other tiles come from the transfer matrices.
+	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": a walk delivers the start vector
+	// of its head tile (the usual speculative warm-up, nothing more: walk item with count <= 0, see k_walk1_struct; round 1
+	// and most of round 2 also walked THROUGH the head tile, 3712 dependent steps whose result nobody read -- measured
+	// neutral all the same, 12.95 vs 13.07 ms: the longest walk is a head with a doubled warm-up, 6144 steps), and the
+	// boundary vectors of its other tiles come from the transfer matrices, the head's first.
 	//   d_items + 12nc: wl_f (2nc) | wl_b (2nc) | kc tiles (4nc: KcTile) | runs (4nc + : KcRun)
 	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b;
 	c->n_wl_f = c->n_wl_b = 0;
 	const bool chains = c->kc_min >= 2; // 64 states: one state per lane in the chain kernel; 128: two
+	const int head_count = (c->ns == 64 && c->walk_impl == 1 && c->walk_heads == 0) ? 0 : 1; // k_walk1_struct knows count 0; the four-runs-per-wave walk does not
 	auto add_runs = [&](const std::vector<std::pair<long long, std::pair<int, int>>> &k, int n_long, bool bwd) {
 		int &nw = bwd ? c->n_wl_b : c->n_wl_f;
 		std::vector<int> &rv = bwd ? runs_b : runs_f;
@@ -844,14 +850,14 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 			if (chain && !bwd && c->chunks[first].lo == 1) {
 				// position 1 is an initial condition, not a step: there is no X_0 for a transfer matrix to start from.
 				// Walk through the first tile as well and chain from the second one.
-				w[2 * nw] = first; w[2 * nw + 1] = 2; ++nw;
+				w[2 * nw] = first; w[2 * nw + 1] = (head_count == 0 && count - 1 >= 2) ? -1 : 2; ++nw; // -1: through the first tile, up to the head's start vector
 				first += 1; count -= 1;
 				if (count >= 2) {
 					rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
 					for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
 				}
 			} else if (chain) {
-				w[2 * nw] = bwd ? first + count - 1 : first; w[2 * nw + 1] = 1; ++nw; // head tile only
+				w[2 * nw] = bwd ? first + count - 1 : first; w[2 * nw + 1] = head_count; ++nw; // the head tile's start vector
 				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
 				if (!bwd) for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
 				else for (int t = first + count - 1; t > first; --t) { kc.push_back(t); kc.push_back(1); }
@@ -1233,9 +1239,10 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->n = c->n; k->ns = c->ns; k->device = c->device; k->mode = c->mode; k->parent = c;
 		k->chunk = c->chunk; k->warmup = c->warmup; k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
-		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->lanes8 = c->lanes8;
+		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->walk_heads = c->walk_heads; k->lanes8 = c->lanes8;
 		k->fuse_order = c->fuse_order; k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
 		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kcol_impl = c->kcol_impl; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
+		k->count_impl = c->count_impl; k->fuse128 = c->fuse128;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];

@@ -441,7 +441,12 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 	if ((int)blockIdx.x < n_f) { // ---------------- forward
 		const SweepItem it = items_f[blockIdx.x];
 		const Chunk c = chunks[it.first];
-		const int p_last = chunks[it.first + it.count - 1].hi;
+		// count = -k <= 0: walk through k tiles and stop where tile first + k, the head of a transfer-matrix chain, starts --
+		// only its start vector is wanted (k = 0: the warm-up alone; k = 1: a segment's first tile, which has no X_0 for
+		// a matrix to start from); the head tile itself is the first matrix of the chain
+		const bool warm_only = it.count <= 0;
+		const int thru = warm_only ? -it.count : it.count;
+		const int p_last = thru == 0 ? c.lo - 1 : chunks[it.first + thru - 1].hi;
 		const uint8_t *o = obs + c.off;
 		StructPar1 s1; s1.mS = sp[lane]; s1.wS = sp[128 + lane]; s1.mP = sp[64 + lane]; s1.wP = sp[192 + lane]; s1.dd = sp[256 + lane];
 		double x = a0[lane];
@@ -465,12 +470,14 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 			}
 			w = wn;
 		}
+		if (warm_only) entry[(int64_t)(it.first + thru) * 64 + lane] = x;
 	} else { // ---------------- backward
 		const SweepItem it = items_b[blockIdx.x - n_f];
-		int tile = it.first + it.count - 1;
+		const bool warm_only = it.count == 0; // the head (top tile) of a chain: only bt_{top+1}
+		int tile = it.first + max(it.count, 1) - 1;
 		const Chunk c = chunks[tile];
-		const int L = c.L, p_low = chunks[it.first].lo;
-		int lo = c.lo, top = min(c.hi, L - 1);
+		int lo = c.lo, top = min(c.hi, c.L - 1);
+		const int L = c.L, p_low = warm_only ? top + 1 : chunks[it.first].lo;
 		if (top < lo) return;
 		const uint8_t *o = obs + c.off;
 		StructPar1 s1; s1.mS = sp[192 + lane]; s1.wS = sp[64 + lane]; s1.mP = sp[128 + lane]; s1.wP = sp[lane]; s1.dd = sp[256 + lane];
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 			}
 			w = wn;
 		}
+		if (warm_only) bentry[(int64_t)tile * 64 + lane] = x;
 	}
 }
 

@@ -879,6 +879,10 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 	}
 	c->items_dirty = false;
 	if (getenv("PSMC_HIP_DEBUG"))
+		fprintf(stderr, "[psmc_hip] buffers: obs %p (+%lld) chunks %p (%d) items %p entry %p bentry %p bexit %p f %p b %p s %p sb %p Cpart %p Epart %p ftiles %p touch %p par %p Kcol %p\n",
+		        (void *)c->d_obs, (long long)c->total + 256, (void *)c->d_chunks, nc, (void *)c->d_items, (void *)c->d_entry, (void *)c->d_bentry, (void *)c->d_bexit,
+		        (void *)c->d_f, (void *)c->d_b, (void *)c->d_s, (void *)c->d_sb, (void *)c->d_Cpart, (void *)c->d_Epart, (void *)c->d_ftiles, (void *)c->d_touch, (void *)c->d_par, (void *)c->d_Kcol);
+	if (getenv("PSMC_HIP_DEBUG"))
 		fprintf(stderr, "[psmc_hip] items: %d tiles of %d bins, fwd %d items (%d runs, %d run tiles, %d walks, %d chains, %d phase B), bwd %d items (%d runs, %d run tiles, %d walks, %d chains, %d from above), %d transfer matrices, fused lists %d + %d\n",
 		        nc, c->chunk_used, c->n_items_f, c->n_long_f, c->n_mem_f, c->n_wl_f, c->n_chain_f, c->n_B_f, c->n_items_b, c->n_long_b, c->n_mem_b, c->n_wl_b, c->n_chain_b, c->n_B_b, c->n_kc, c->n_list_a, c->n_list_b);
 	return 0;
@@ -1295,6 +1299,61 @@ extern "C" int psmc_hip_batch_info(psmc_hip_ctx *c, int out[2])
 	if (!c || !out) return PSMC_HIP_EINVAL;
 	out[0] = c->last_batch_groups; out[1] = (int)c->kids.size();
 	return PSMC_HIP_OK;
+}
+
+// Diagnostic, not part of the ABI (tests and scripts only): after a fast E-step with the fused back half (64 states), check the start
+// vector of every tile against a plain dense backward recursion on the host and name the tiles that are off (stderr).
+extern "C" int psmcdbg_check_bentry(psmc_hip_ctx *c)
+{
+	if (!c || c->ns != 64 || !c->d_bentry || !c->d_ftiles) return -1;
+	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize();
+	const int nc = (int)c->chunks.size();
+	const int ga = (c->n_list_a + 3) / 4, gb = (c->n_list_b + 3) / 4, ng = ga + gb;
+	std::vector<int> tl(4 * (size_t)ng), tf(nc), tb(nc);
+	const std::vector<Chunk> &ch = c->chunks;
+	(void)hipMemcpy(tl.data(), c->d_ftiles, sizeof(int) * tl.size(), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(tf.data(), c->d_touch, sizeof(int) * tf.size(), hipMemcpyDeviceToHost);
+	(void)hipMemcpy(tb.data(), c->d_touch + nc, sizeof(int) * tb.size(), hipMemcpyDeviceToHost);
+	const double *d_e = c->d_par + 4 * 4096; // 64 states: a | aeT[3] | e[3] | a0 | 1/e (fill_common)
+	{ // the start vector of every tile against a plain dense backward recursion on the host
+			std::vector<double> ha(64 * 64), he(3 * 64), hb((size_t)nc * 64), hx((size_t)nc * 64);
+			(void)hipMemcpy(ha.data(), c->d_par, sizeof(double) * ha.size(), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(he.data(), d_e, sizeof(double) * he.size(), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(hb.data(), c->d_bentry, sizeof(double) * hb.size(), hipMemcpyDeviceToHost);
+			(void)hipMemcpy(hx.data(), c->d_bexit, sizeof(double) * hx.size(), hipMemcpyDeviceToHost);
+			for (int k = 0; k < 64; ++k) he[128 + k] = 1.0;
+			std::vector<int> from_above(nc, 0), in_list(nc, 0);
+			for (size_t i = 0; i < tl.size(); ++i) if (tl[i] >= 0) { from_above[tl[i] & ~(1 << 30)] = (tl[i] >> 30) & 1; in_list[tl[i] & ~(1 << 30)] = i < 4 * (size_t)ga ? 1 : 2; }
+			for (int b0 = 0; b0 < nc;) {
+				int b1 = b0; while (b1 + 1 < nc && ch[b1 + 1].off == ch[b0].off) ++b1; // tiles b0..b1 of one segment
+				const int L = ch[b0].L;
+				std::vector<uint8_t> o(L);
+				(void)hipMemcpy(o.data(), c->d_obs + ch[b0].off, (size_t)L, hipMemcpyDeviceToHost);
+				std::vector<double> bt(64), y(64);
+				for (int k = 0; k < 64; ++k) bt[k] = he[(o[L - 1] & 3) * 64 + k]; // bt_L = e[o_L] . 1
+				int b = b1;
+				for (int pp = L - 1; pp >= 1; --pp) { // bt = bt_{pp+1}
+					while (b >= b0 && std::min(ch[b].hi, L - 1) < ch[b].lo) --b; // tiles without a transition
+					if (b >= b0 && pp == std::min(ch[b].hi, L - 1)) { // bentry[b] should be bt_{top+1} up to a factor
+						double sx = 0, sy = 0, num = 0, den = 0;
+						for (int k = 0; k < 64; ++k) { sx += hb[(size_t)b * 64 + k]; sy += bt[k]; }
+						for (int k = 0; k < 64; ++k) { num = std::max(num, std::fabs(hb[(size_t)b * 64 + k] / sx - bt[k] / sy)); den = std::max(den, bt[k] / sy); }
+						if (!(num / den < 1e-9))
+							fprintf(stderr, "[psmc_hip] RECHECK bentry of tile %d (lo %d hi %d L %d list %d from_above %d tf %d tb %d; above: tf %d tb %d list %d) off by %.2e, sum %.3e; rounds %d/%d\n",
+							        b, ch[b].lo, ch[b].hi, L, in_list[b], from_above[b], tf[b], tb[b], b + 1 <= b1 ? tf[b + 1] : -1, b + 1 <= b1 ? tb[b + 1] : -1, b + 1 <= b1 ? in_list[b + 1] : -1, num / den, sx,
+							        c->report.fwd_rounds, c->report.bwd_rounds);
+						--b;
+					}
+					double tot = 0;
+					for (int k = 0; k < 64; ++k) { double acc = 0; for (int l = 0; l < 64; ++l) acc += ha[k * 64 + l] * bt[l]; y[k] = acc; }
+					for (int k = 0; k < 64; ++k) { bt[k] = he[(o[pp - 1] & 3) * 64 + k] * y[k]; tot += bt[k]; }
+					for (int k = 0; k < 64; ++k) bt[k] /= tot;
+				}
+				b0 = b1 + 1;
+			}
+		}
+	return 0;
 }
 
 extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *b, double *s)

@@ -13,13 +13,18 @@
 // that walks four tiles backwards reads X, keeps bt in registers and accumulates 7 x 4 numbers per lane.
 // HBM per bin: 8N (write X) + 8N (read X).  Entry point psmc_hip_estep_factored (include/psmc_hip.h).
 //
-// Scaling (round 2): the backward recursion takes the FORWARD sweep's scale factors, bt_p = e[o_p] (a bt_{p+1}) inv_p with
-// inv_p = 1/d_p at p % 4 == 0 (the d_s table) and 1 elsewhere, like khmm.c:228-235.  Then I = sum_k X_p[k] (a bt_{p+1})[k]
-// is the same number at every position of a tile (it drifts by rounding only, < 1e-13 over a tile), the posterior
-// weights are 1/I, and nothing has to be normalised per position: no row sum, no reciprocal, no weight
-// multiplications (44 vector instructions per step fewer than with bt's own row sums).  The start vector of a tile has an
-// arbitrary scale, so the tile keeps sum_k X_p[k] y_p[k] = I of the last position it walked and divides its partials by it
-// when it stores them.
+// Scaling (round 2).  With y_p = a bt_{p+1} the number I_p = sum_k X_p[k] y_p[k] is what turns X_p (x) bt_{p+1} into a posterior,
+// and it is NOT a new number at every position: between two normalising positions it is constant (an algebraic identity of
+// the two recursions), and across one it changes by a known factor, I_{p-1} = I_p sb_p / inv_p (sb_p = 1/sum(bt_{p+1}), bt's own
+// scale factor; inv_p = the forward sweep's, a power of two from the d_s table).  So nothing is normalised per position
+// (no row sum of g, no reciprocal, no weight multiplications: round 1's step had all three): the partial sums are kept in
+// units of the current I, rescaled by sb_p / inv_p at the normalising positions (p % 4 == 0), and divided by the I of the
+// last position when the tile stores them.  bt itself keeps its own scaling: an earlier version of this step let bt follow
+// the forward scale factors as khmm.c:228-235 does (I is then constant over the whole tile and even the rescaling
+// goes away), but then the exit vector a tile hands on depends on a forward table, and a table that a forward
+// repair is rewriting can be read torn -- different lanes of a row saw different scale factors, the exit vector
+// came out bent, and the boundary repair of the tile below copied it (1 E-step in 1 500 off by up to 3e-2 in a stress
+// of tiny tiles, scripts/dbg_flaky_tiling.py; never with this version).
 #include <hip/hip_runtime.h>
 #include "wave_prims.h"
 #include "struct_prims.h"
@@ -53,9 +58,16 @@ __device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const doubl
 	double ev[NPLA];
 	loadN<NPLA>(lds_e + sym * SA + k0, ev);
 	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
-	if (NORM) { // the forward sweep's 1/d_p
+	double f = 1.0;
+	if (NORM) {
+		// bt keeps its OWN scaling, sb_p = 1/sum(bt_{p+1}): the vectors handed from tile to tile (bexit) must not depend on a
+		// forward table that a repair may be rewriting.  I then changes at this position, I_{p-1} = I_p sb_p / inv_p (inv_p = the
+		// forward sweep's scale factor, a power of two): the partial sums, kept in units of the current I, are rescaled below.
+		const double tot = row_sum16(lane_sum_a<NPLA>(x));
+		const double sb = rcp_newton(tot);
 #pragma unroll
-		for (int i = 0; i < NPLA; ++i) ev[i] *= inv;
+		for (int i = 0; i < NPLA; ++i) ev[i] *= sb;
+		f = sb * pow2_rcp(inv);
 	}
 	// lane-local inclusive scans: z.c / z.qa (the backward step) and X.P / X.R (the column sums)
 	double su[NPLA + 1], pv[NPLA + 1], sx[NPLA + 1], px[NPLA + 1];
@@ -83,6 +95,13 @@ __device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const doubl
 		x[i] = y * ev[i];
 	}
 	I_lane = Il; // this lane's share of I at position p
+	if (NORM) { // ... now in units of I_{p-1}
+#pragma unroll
+		for (int q = 0; q < NACC; ++q)
+#pragma unroll
+			for (int i = 0; i < NPLA; ++i) acc[q][i] *= f;
+		I_lane *= f;
+	}
 }
 // 1/I of a tile (n_pos = 0: an empty tile, whose partials are zero anyway)
 __device__ __forceinline__ double tile_inv_I(double I_lane, int n_pos)
@@ -434,6 +453,7 @@ void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, 
 	else
 		hipLaunchKernelGGL(k_bwd_acc_struct<4>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
+	PSMC_DBG("launch_bwd_acc", which, first, n);
 }
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st)
 {

@@ -37,6 +37,8 @@
 // HBM layout (g = seg_off + p - 1): X[g*64+k] (d_f), bt[g*64+k] (d_b),
 // inv_d[g] = 1/d_p (d_s) and sb[g] (d_sb), both written at p % 4 == 0 only, obs[g].
 #include <hip/hip_runtime.h>
+#include <cmath>
+#include <algorithm>
 #include "wave_prims.h"
 #include "psmc_hip_internal.h"
 
@@ -722,6 +724,16 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		return 0;
 	};
 	if (lw && ov) { (void)hipStreamWaitEvent(sm, p.evx[7], 0); (void)hipStreamWaitEvent(sa, p.evx[9], 0); } // run tiles done
+	// the log-likelihood needs the forward tables only: it is launched the moment the forward chain has converged, beside
+	// the back half, instead of in the tail of the E-step
+	bool ll_done = false;
+	auto launch_ll = [&]() {
+		if (ll_done) return;
+		ll_done = true;
+		if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
+		else hipLaunchKernelGGL(k_ll<64>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
+		PSMC_DBG("k_ll", p.n_chunks, 0, 0);
+	};
 	if (post_verify(ch[0]) || post_verify(ch[1])) return -1;
 	while (!(ch[0].done && ch[1].done)) {
 		bool progressed = false;
@@ -733,8 +745,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 			if (q != hipSuccess) return -1;
 			c.pending = false; progressed = true;
 			const int nd = p.h_cnt[c.slot];
-			if (nd == 0) { c.done = true; continue; }
-			if (c.round >= p.max_rounds) { rep->converged = 0; c.done = true; continue; }
+			if (nd == 0) { c.done = true; if (!c.bwd) launch_ll(); continue; }
+			if (c.round >= p.max_rounds) { rep->converged = 0; c.done = true; if (!c.bwd) launch_ll(); continue; }
 			++c.round;
 			if (p.structured) {
 				std::vector<int> *fl = c.bwd ? p.flagged_b : p.flagged_f;
@@ -756,9 +768,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	}
 	if (hipStreamSynchronize(sm) != hipSuccess) return -1;
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
-	// ---- counts + log-likelihood from the final tables
-	if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
-	else hipLaunchKernelGGL(k_ll<64>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
+	// ---- counts from the final tables (the log-likelihood was launched when the forward chain converged)
+	launch_ll();
 	if (p.fused) {
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
@@ -776,6 +787,42 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sm);
 		launch_expect(p, sm, 0);
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sm);
+	}
+	if (p.fused == 1 && getenv("PSMC_HIP_DEBUG_RECHECK")) {
+		// diagnostic: recompute EVERY group from the final tables and start vectors and name the groups whose partial differs
+		// from what the protocol (first pass + redo of the touched groups) left
+		const int ga = (p.n_list_a + 3) / 4, gb = (p.n_list_b + 3) / 4, ng = ga + gb;
+		const size_t gs = (size_t)p.ns * p.ns;
+		std::vector<double> c0(gs * ng), c1(gs * ng);
+		std::vector<int> tl(4 * (size_t)ng), tf(p.n_chunks), tb(p.n_chunks);
+		std::vector<Chunk> ch(p.n_chunks);
+		(void)hipDeviceSynchronize();
+		(void)hipMemcpy(c0.data(), p.d_Cpart, sizeof(double) * c0.size(), hipMemcpyDeviceToHost);
+		{ // the reference: round 1's kernel (own normaliser per position), every tile from its bentry
+			EstepLaunch q = p; q.count_impl = 0;
+			launch_bwd_count(q, sm, 0, false, true); launch_bwd_count(q, sm, 1, false, true);
+		}
+		(void)hipDeviceSynchronize();
+		(void)hipMemcpy(c1.data(), p.d_Cpart, sizeof(double) * c1.size(), hipMemcpyDeviceToHost);
+		(void)hipMemcpy(tl.data(), p.d_ftiles, sizeof(int) * tl.size(), hipMemcpyDeviceToHost);
+		(void)hipMemcpy(tf.data(), p.d_touch_f, sizeof(int) * tf.size(), hipMemcpyDeviceToHost);
+		(void)hipMemcpy(tb.data(), p.d_touch_b, sizeof(int) * tb.size(), hipMemcpyDeviceToHost);
+		(void)hipMemcpy(ch.data(), p.d_chunks, sizeof(Chunk) * ch.size(), hipMemcpyDeviceToHost);
+		for (int g2 = 0; g2 < ng; ++g2) {
+			double worst = 0.0, big = 0.0;
+			for (size_t i = 0; i < gs; ++i) { big = std::max(big, std::fabs(c1[g2 * gs + i])); worst = std::max(worst, std::fabs(c0[g2 * gs + i] - c1[g2 * gs + i])); }
+			if (worst > 1e-9 * big) {
+				fprintf(stderr, "[psmc_hip] RECHECK group %d (list %c) differs by %.2e of %.2e; rounds %d/%d; tiles:", g2, g2 < ga ? 'A' : 'B', worst, big, rep->fwd_rounds, rep->bwd_rounds);
+				for (int r = 0; r < 4; ++r) {
+					const int en = tl[4 * (size_t)g2 + r];
+					if (en < 0) { fprintf(stderr, " -"); continue; }
+					const int t = en & ~(1 << 30);
+					fprintf(stderr, " %d%s[lo %d hi %d L %d off %lld mult %d flags %d wsh %d tf %d tb %d; above tf %d tb %d]", t, (en & (1 << 30)) ? "^" : "", ch[t].lo, ch[t].hi, ch[t].L, (long long)ch[t].off,
+					        (int)ch[t].mult, (int)ch[t].flags, (int)ch[t].wsh, tf[t], tb[t], t + 1 < p.n_chunks ? tf[t + 1] : -1, t + 1 < p.n_chunks ? tb[t + 1] : -1);
+				}
+				fprintf(stderr, "\n");
+			}
+		}
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
 	const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_list_a + 3) / 4 + (p.n_list_b + 3) / 4 : nS; // fused: one C partial per group of four tiles

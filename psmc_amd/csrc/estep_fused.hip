@@ -231,19 +231,21 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 // ---- round 2: the same kernel without a per-position normaliser, and with the matrix instructions of a step issued
 // between the vector instructions of the NEXT step.
 //
-// (1) Scaling.  k_bwd_count4_struct normalises bt with its own row sums and then needs G_p = sum_k g_p[k] at every
-// position to turn X_p (x) bt_{p+1} into a posterior: a 16-lane reduction, a reciprocal and 13 multiplications per step.
-// khmm.c scales b with the FORWARD scale factors instead (khmm.c:228-235), which makes sum_k f_u[k] b_u[k] s_u = 1 at every
-// u.  The same holds here: with y_p = a bt_{p+1} and bt_p = e[o_p] y_p inv_p (inv_p = the forward sweep's 1/d_p at
-// p % 4 == 0, else 1 -- the d_s table) the number I_p = sum_k X_p[k] y_p[k] does not depend on p.  The start vector of a
-// tile is scale-free, so one pre-step measures I at the tile's top position and every position takes the same weight
-// rho = mult / I (mult = the segment's multiplicity):
-//   E[o_p][k] += rho X_p[k] y_p[k],    C[k][l] += rho X_p[k] bt_{p+1}[l]
-// I_p drifts by rounding only (a random walk of a few ulp per step: < 1e-13 over a tile; every tile measures its own).
-// The bt recursion itself never sees X or rho, and the forward scale factors are powers of two (struct_prims.h
-// pow2_rcp): the exit vector a tile hands to the tile below (two-phase plan) is the same bit pattern up to a power of
-// two whether or not a forward repair was rewriting the tile's tables while it was read -- the E-step stays
-// reproducible bit for bit (the tile itself is flagged by the repair and recomputed at the end).
+// (1) Scaling.  k_bwd_count4_struct needs G_p = sum_k g_p[k] at every position to turn X_p (x) bt_{p+1} into a posterior:
+// a 16-lane reduction, a reciprocal and 13 multiplications per step.  But with y_p = a bt_{p+1} the normaliser
+// I_p = sum_k X_p[k] y_p[k] is not a new number at every position: between two normalising positions it is constant (an
+// algebraic identity of the forward and the backward recursion), and across one it changes by a known factor,
+// I_{p-1} = I_p sb_p / inv_p (sb_p = 1/sum(bt_{p+1}): bt's own scale factor; inv_p: the forward sweep's, from the d_s table).
+// So one pre-step measures I at the tile's top position, rho = mult / I (mult = the segment's multiplicity), and
+//   E[o_p][k] += rho X_p[k] y_p[k],    C[k][l] += rho X_p[k] bt_{p+1}[l],    rho <- rho inv_p / sb_p at p % 4 == 0.
+// rho drifts by rounding only (a few ulp per normalising position; every tile measures its own).
+// bt keeps ITS OWN scaling, as in round 1.  The first version of this kernel let bt follow the forward scale factors
+// (khmm.c:228-235: I is then constant over the whole tile) -- but then the exit vector a tile hands to the tile below, and
+// to the boundary repairs, is computed from a forward table, and a forward REPAIR may be rewriting that table while it is
+// read (by design: the repair flags the tile, which is recomputed at the end).  The 16 lanes of a row could see different
+// scale factors, the exit vector came out bent instead of merely rescaled, and the repair of the tile below adopted it:
+// 1 E-step in 1 500 off by up to 3e-2 in a stress of tiny tiles (scripts/dbg_flaky_tiling.py), caught first as a flaky
+// test_fast_odd_tilings.  The vectors that travel between tiles must depend on the observations and the parameters only.
 // (2) Issue order.  With one wave per SIMD a step is a chain of dependent vector instructions (row scans: v_add_f64 ->
 // v_mov_b32_dpp -> v_add_f64 ...) whose latencies nothing hides, followed by 16 matrix instructions that occupy the
 // FP64 pipe for 64 cycles each while the wave has nothing else to issue: 1 950 cycles for 1 548 busy.  Here the
@@ -252,15 +254,20 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 // pipe comes free, long after its operand is ready.
 template <bool NORM, bool MASKED>
 __device__ __forceinline__ void count4f_step(const StructParN<NPLF> &sc, const double *lds_e, const double *lds_m, int k0, int sym,
-                                             const double (&X)[NPLF], double (&x)[NPLF], bool active, double inv, double rho,
+                                             const double (&X)[NPLF], double (&x)[NPLF], bool active, double inv, double &rho,
                                              double (&FA)[NPLF], double (&FB)[NPLF], double (&S)[2][NPLF])
 {
 	double ev[NPLF], y[NPLF];
 	loadN<NPLF>(lds_e + sym * SF + k0, ev);
 	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
-	if (NORM) {
+	double rho_next = rho;
+	if (NORM) { // bt keeps its OWN scaling (sb_p = 1/sum(bt_{p+1})): the vectors handed from tile to tile must not depend on a forward table
+		const double tot = row_sum16((x[0] + x[1]) + (x[2] + x[3]));
+		const double sb = rcp_newton(tot);
 #pragma unroll
-		for (int i = 0; i < NPLF; ++i) ev[i] *= inv;
+		for (int i = 0; i < NPLF; ++i) ev[i] *= sb;
+		rho_next = rho * (inv * tot); // 1/I_{p-1} = (1/I_p) inv_p / sb_p: the weight follows both scale factors
+		if (MASKED) rho_next = active ? rho_next : rho;
 	}
 #pragma unroll
 	for (int i = 0; i < NPLF; ++i) y[i] = x[i];
@@ -276,6 +283,7 @@ __device__ __forceinline__ void count4f_step(const StructParN<NPLF> &sc, const d
 		const double nb = y[i] * ev[i];
 		x[i] = MASKED ? (active ? nb : x[i]) : nb;
 	}
+	rho = rho_next;
 }
 __device__ __forceinline__ void count4f_mfma(const double (&FA)[NPLF], const double (&FB)[NPLF], d4f_t (&acc)[4][4])
 {
@@ -442,15 +450,23 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 constexpr int NPL8 = 8, S8 = 128;
 template <bool NORM, bool MASKED>
 __device__ __forceinline__ void count8_step(const StructParN<NPL8> &sc, const double *lds_e, const double *lds_m, int k0, int sym, int q,
-                                            const double (&Xq)[2], double (&x)[NPL8], bool active, double inv, double rho,
+                                            const double (&Xq)[2], double (&x)[NPL8], bool active, double inv, double &rho,
                                             d4f_t (&acc)[2][NPL8], double (&S)[2][2])
 {
 	double ev[NPL8], y[NPL8], FA[2], FB[NPL8];
 	loadN<NPL8>(lds_e + sym * S8 + k0, ev);
 	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
-	if (NORM) {
+	double rho_next = rho;
+	if (NORM) { // bt keeps its own scaling, the weight follows both scale factors (see count4f_step)
+		double t = 0.0;
 #pragma unroll
-		for (int i = 0; i < NPL8; ++i) ev[i] *= inv;
+		for (int i = 0; i < NPL8; ++i) t += x[i];
+		const double tot = row_sum16(t);
+		const double sb = rcp_newton(tot);
+#pragma unroll
+		for (int i = 0; i < NPL8; ++i) ev[i] *= sb;
+		rho_next = rho * (inv * tot);
+		if (MASKED) rho_next = active ? rho_next : rho;
 	}
 #pragma unroll
 	for (int i = 0; i < NPL8; ++i) y[i] = x[i];
@@ -474,6 +490,7 @@ __device__ __forceinline__ void count8_step(const StructParN<NPL8> &sc, const do
 	for (int j = 0; j < 2; ++j)
 #pragma unroll
 		for (int j2 = 0; j2 < NPL8; ++j2) acc[j][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[j2], acc[j][j2], 0, 0, 0);
+	rho = rho_next;
 }
 
 __global__ __launch_bounds__(256, 1) void k_bwd_count8_struct(const double *__restrict__ sp, const double *__restrict__ e,
@@ -597,16 +614,17 @@ __global__ __launch_bounds__(256, 1) void k_bwd_count8_struct(const double *__re
 }
 
 // list 0 / 1: tile list A / B of the plan (api.hip build_items);  redo: only the groups a repair touched
-void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo)
+void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo, bool all_from_bentry)
 {
 	const int ga = (p.n_list_a + 3) / 4, gb = (p.n_list_b + 3) / 4;
 	const int n_groups = list == 0 ? ga : gb;
 	if (n_groups <= 0) return;
 	const int *tl = p.d_ftiles + (list == 0 ? 0 : 4 * ga);
-	const int g0 = list == 0 ? 0 : ga, md = redo ? 2 : 0;
+	const int g0 = list == 0 ? 0 : ga, md = all_from_bentry ? 3 : (redo ? 2 : 0); // 3 (diagnostic): every group, every tile from its bentry
 	if (p.ns == 128) {
 		hipLaunchKernelGGL(k_bwd_count8_struct, dim3(n_groups), dim3(256), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
 		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+		PSMC_DBG("launch_bwd_count (128 states)", list, redo, n_groups);
 		return;
 	}
 	if (p.count_impl == 2)
@@ -618,6 +636,7 @@ void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo)
 	else
 		hipLaunchKernelGGL(k_bwd_count4_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, tl, g0, md,
 		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+	PSMC_DBG("launch_bwd_count", list, redo, n_groups);
 }
 
 } // namespace psmc

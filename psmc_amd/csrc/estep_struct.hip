@@ -364,7 +364,11 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 		loadN<NPL>(lds_e + ((int)o[q - 1] & 3) * S + k0, x);
 		p_first = q - 1;
 	}
-	const int b_first = (p_first - 1) >> 4; // highest block
+	// highest block.  A tile that holds only position L (not valid: it owns no transition) has p_first = L - 1, which is 0 for a
+	// one-bin segment: block -1 would be read 16 bytes BELOW the segment's observations -- for the first segment below the
+	// allocation (harmless in value, the row is idle, but a page fault whenever nothing is mapped there; found with
+	// scripts/dbg_flaky_tiling.py, which recycles device memory between contexts)
+	const int b_first = max((p_first - 1) >> 4, 0);
 	const int nblk = valid ? b_first - ((p_low - 1) >> 4) + 1 : 0;
 	int64_t roff[R]; int rbf[R], rnb[R];
 	int nb_max = 0;
@@ -840,6 +844,7 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	} else if (l8) { if (rep) PSMC_LFX(true, 8, 8, false); else PSMC_LFX(false, 8, 8, false); }
 	else if (p.ns == 128) { if (rep) PSMC_LF(true, 8); else PSMC_LF(false, 8); }
 	else { if (rep) PSMC_LF(true, 4); else PSMC_LF(false, 4); }
+	PSMC_DBG("launch_fwd_struct", which, first, n_items);
 #undef PSMC_LFX
 #undef PSMC_LF
 }
@@ -858,6 +863,7 @@ void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
 	else if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
 	else { if (rep) PSMC_LB(true, 4); else PSMC_LB(false, 4); }
+	PSMC_DBG("launch_bwd_struct", which, first, n_items);
 #undef PSMC_LB
 }
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
@@ -865,6 +871,7 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
 	hipLaunchKernelGGL(k_compact, dim3(1), dim3(64), 0, st, bwd ? p.d_dirty_b : p.d_dirty, p.n_chunks,
 	                   (SweepItem *)(bwd ? p.d_ritems_b : p.d_ritems_f),
 	                   (SweepItem *)(p.m_ritems ? p.m_ritems + (size_t)(bwd ? 1 : 0) * 2 * p.n_chunks : nullptr), p.m_cnt + (bwd ? 1 : 0));
+	PSMC_DBG("verify + launch_compact", bwd, p.n_chunks, 0);
 }
 // bulk of both sweeps: forward items [ff, ff+nf) and backward items [fb, fb+nb)
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb)
@@ -875,6 +882,7 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, \
 		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit)
 	if (p.ns == 128) PSMC_LS(8); else PSMC_LS(4);
+	PSMC_DBG("launch_sweeps", nf, nb, 0);
 #undef PSMC_LS
 }
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols)
@@ -899,6 +907,7 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 	else
 		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1);
+	PSMC_DBG("launch_kchain", p.n_kc, p.n_chain_f, p.n_chain_b);
 }
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {
@@ -907,6 +916,7 @@ void launch_walks(const EstepLaunch &p, hipStream_t st)
 		hipLaunchKernelGGL(k_walk1_struct, dim3(p.n_wl_f + p.n_wl_b), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
 		                   (const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup,
 		                   p.tile_len, p.d_entry, p.d_bentry, p.d_bexit);
+		PSMC_DBG("launch_walks", p.n_wl_f, p.n_wl_b, 0);
 		return;
 	}
 	const int nb = (p.n_wl_f + 3) / 4 + (p.n_wl_b + 3) / 4;
@@ -915,6 +925,7 @@ void launch_walks(const EstepLaunch &p, hipStream_t st)
 		(const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup, p.tile_len, \
 		p.d_entry, p.d_bentry, p.d_bexit)
 	if (p.ns == 128) PSMC_LW(8); else PSMC_LW(4);
+	PSMC_DBG("launch_walks (four per wave)", p.n_wl_f, p.n_wl_b, 0);
 #undef PSMC_LW
 }
 

@@ -1,5 +1,7 @@
 // psmc_hip_internal.h -- shared between api.hip and the kernel translation units.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
@@ -113,6 +115,12 @@ struct EstepLaunch {
 	                            // 5 fwd sweep end, 7/6 bwd sweep start/end, 8/9 full expect pass start/end
 };
 
+// PSMC_HIP_DEBUG_SYNC=1: synchronise the device after every launcher of the fast E-step and name it on stderr -- the last name
+// before a "Memory access fault" is the kernel that did it (diagnostic; serialises everything)
+inline bool dbg_sync_on() { static const bool on = getenv("PSMC_HIP_DEBUG_SYNC") != nullptr; return on; }
+#define PSMC_DBG(NAME, A, B, C) do { if (psmc::dbg_sync_on()) { hipError_t e_ = hipDeviceSynchronize(); \
+	fprintf(stderr, "[psmc_hip] %s(%d, %d, %d): %s\n", NAME, (int)(A), (int)(B), (int)(C), hipGetErrorString(e_)); fflush(stderr); } } while (0)
+
 constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
@@ -123,7 +131,7 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 void launch_walks(const EstepLaunch &p, hipStream_t st);
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols);
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb);
-void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo);
+void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo, bool all_from_bentry = false);
 void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st);
 int launch_post_decode(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n,

@@ -694,6 +694,39 @@ def test_fast_batch_keeps_a_plan_per_replicate(hip, golden, oracle):
     es.close()
 
 
+def test_fast_stress_tiny_tiles_recycled_memory(hip, golden, oracle):
+    """Tiny tiles, no or little warm-up: dozens of repair rounds per E-step beside the back half, plans that change from call
+    to call, contexts created and destroyed in between so that device memory comes back with plausible stale contents.
+    Every E-step (full counts and factored statistics) stays inside the tolerance.  This is the stress that found (1) exit
+    vectors computed from a forward table under repair (about one E-step in 1 500 off by up to 3e-2 in that build) and
+    (2) a symbol block read below the first segment's observations by an idle backward row (a page fault with the right
+    allocation history); scripts/dbg_flaky_tiling.py is the long version."""
+    import random
+    p = golden.params("n64_curve")
+    segs = golden.segs_small + golden.segs_mid[3:]
+    o = oracle.estep(p["a"], p["e"], p["a0"], segs)
+    want = tri_sums(o["A"])
+    opts_list = [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, walk_impl=0), dict(chunk=64, warmup=0),
+                 dict(chunk=64, warmup=0, two_phase=1), dict(chunk=100, warmup=30, two_phase=1), dict(chunk=37, warmup=5, group_cap=3000, lanes8=1)]
+    rng = random.Random(7)
+    bad = []
+    for rep in range(12):
+        order = list(range(len(opts_list))); rng.shuffle(order)
+        live = []
+        for oi in order:
+            es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts_list[oi])
+            es.load_segments(segs)
+            for it in range(3):
+                r = es.estep(p["a"], p["e"], p["a0"])
+                f = es.estep_factored(p["a"], p["e"], p["a0"])
+                err = max(relmax(r["A"], o["A"]), relmax(r["E"], o["E"]), relmax(f["sums"], want), relmax(f["E"], o["E"]))
+                if not err < FAST_TOL_STATS or abs(r["LL"] - o["LL"]) > FAST_TOL_LL * abs(o["LL"]): bad.append((rep, oi, it, err))
+            live.append(es)
+            if len(live) > 2: live.pop(rng.randrange(len(live))).close()
+        for es in live: es.close()
+    assert not bad, bad
+
+
 # ------------------------------------------------------------------ multi-GPU inside the C library (one box: shards share the GPU)
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
 def test_group_exact_is_bit_identical_to_one_context(hip, golden, devices):

@@ -70,6 +70,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * index inside their segment do not speculate but start from the exact boundary vector their neighbour left: 2,
  * default: backward only, in the second launch of the fused back half; 1: forward as well, in a second forward
  * launch; 0: every tile speculates),
+ * "kc_warm" (default 0; 64 states, 1: the start vector of a transfer-matrix chain from matrices of its warm-up range instead of a
+ * walk -- parity-green, measured slower: 13.45 vs 13.0 ms, factored 11.35 vs 10.8),
  * "walk_heads" (1: the walk that delivers the start vector of a transfer-matrix chain also runs through the chain's head tile, as
  * it did until the last build of round 2; default 0: it stops at the start vector),
  * "fuse128" (1, default: the fused back half for 65..128 states as well, four waves per group of four tiles; 0: bt table +

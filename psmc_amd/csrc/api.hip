@@ -39,6 +39,7 @@ struct psmc_hip_ctx {
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
 	int two_phase = 2;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
+	int kc_warm = 0;           // "kc_warm" (experimental): the start vector of a chain run from transfer matrices of its warm-up range instead of a walk
 	int walk_heads = 0;        // "walk_heads": 1 = the walk of a chain run also goes through its head tile (as before round 2's last build)
 	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
@@ -282,6 +283,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
 	else if (k == "two_phase") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
+	else if (k == "kc_warm") { c->kc_warm = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "walk_heads") { c->walk_heads = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
@@ -836,6 +838,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 	c->n_wl_f = c->n_wl_b = 0;
 	const bool chains = c->kc_min >= 2; // 64 states: one state per lane in the chain kernel; 128: two
 	const int head_count = (c->ns == 64 && c->walk_impl == 1 && c->walk_heads == 0) ? 0 : 1; // k_walk1_struct knows count 0; the four-runs-per-wave walk does not
+	const bool warm_mats = c->kc_warm && c->ns == 64 && kcol2_on(c); // k_kcol2_struct<2> / k_kchain_struct<1> know warm-up ranges
 	auto add_runs = [&](const std::vector<std::pair<long long, std::pair<int, int>>> &k, int n_long, bool bwd) {
 		int &nw = bwd ? c->n_wl_b : c->n_wl_f;
 		std::vector<int> &rv = bwd ? runs_b : runs_f;
@@ -856,6 +859,16 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 					rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
 					for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
 				}
+			} else if (chain && warm_mats) {
+				// no walk at all: the warm-up range of the head as nparts more transfer matrices (each part at most a tile long)
+				const int head = bwd ? first + count - 1 : first;
+				const int wl = bwd ? chunk_warm_b(c->chunks[head], W) : chunk_warm_f(c->chunks[head], W);
+				const int nparts = std::min(255, std::max(1, (wl + c->chunk_used - 1) / std::max(c->chunk_used, 1)));
+				budget -= nparts;
+				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(nparts);
+				for (int part = 0; part < nparts; ++part) { kc.push_back(head); kc.push_back((bwd ? 3 : 2) | (part << 8) | (nparts << 16)); }
+				if (!bwd) for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
+				else for (int t = first + count - 1; t > first; --t) { kc.push_back(t); kc.push_back(1); }
 			} else if (chain) {
 				w[2 * nw] = bwd ? first + count - 1 : first; w[2 * nw + 1] = head_count; ++nw; // the head tile's start vector
 				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
@@ -1246,7 +1259,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->walk_heads = c->walk_heads; k->lanes8 = c->lanes8;
 		k->fuse_order = c->fuse_order; k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
 		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kcol_impl = c->kcol_impl; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
-		k->count_impl = c->count_impl; k->fuse128 = c->fuse128;
+		k->count_impl = c->count_impl; k->fuse128 = c->fuse128; k->kc_warm = c->kc_warm;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];

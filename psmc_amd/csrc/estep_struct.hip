@@ -514,7 +514,24 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 // vectors swept through the tile, 4 per wave, all tiles of all runs at once -- and a tiny chain kernel then
 // applies the K_t one after the other (a 64 x 64 product each).  Columns are kept comparable by scaling
 // with powers of two only (exact) and carrying the exponent.
-struct KcTile { int tile, dir; }; // dir 0: forward (lo..hi), 1: backward (top..lo)
+// dir bit 0: 0 forward (lo..hi), 1 backward (top..lo).  bit 1 ("kc_warm", experimental): not the tile itself but the
+// speculative WARM-UP range in front of it (forward: lo - warm .. lo - 1; backward: top + warm .. top + 1), cut into
+// nparts = bits 16..23 parts of which this entry is part number bits 8..15 -- the start vector of a chain run as a
+// product of transfer matrices instead of a walk
+struct KcTile { int tile, dir; };
+__host__ __device__ inline void kc_range(const Chunk &c, int dir, int W, int &lo, int &top) // the positions a KcTile's matrices cover
+{
+	const bool fwd = (dir & 1) == 0;
+	if (!(dir & 2)) {
+		top = fwd ? c.hi : min(c.hi, c.L - 1);
+		lo = fwd ? c.lo : min(((c.lo + 3) & ~3) + 1, top + 1); // backward: the chain kernel takes the tile's last steps itself
+	} else if (fwd) {
+		const int ws = max(1, c.lo - chunk_warm_f(c, W));
+		lo = ws == 1 ? 2 : ws; top = c.lo - 1; // ws == 1: position 1 is the start vector a0.e[o_1] itself
+	} else {
+		lo = min(c.hi, c.L - 1) + 1; top = min(c.hi + chunk_warm_b(c, W) + 1, c.L) - 1; // from B_q = 1 down to top + 1
+	}
+}
 
 template <int NPL>
 __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ sp, const double *__restrict__ e,
@@ -587,7 +604,7 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 template <int NQ>
 __global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
                                                             const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
-                                                            double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio)
+                                                            double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio, int W)
 {
 	constexpr int S = 32 * NQ, NCG = S / 64, KD = 11 * S; // KD: doubles per direction = mS | mP | 3 x (wS.e | wP.e | dd.e)
 	__shared__ double xch[2][NQ][2][64]; // [step parity][wave][S total, P total][column]
@@ -600,19 +617,20 @@ __global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restri
 	if (prio >= 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1); // s_setprio takes an immediate
 	const KcTile kt = kc[jt];
 	const Chunk c = chunks[kt.tile];
-	const bool fwd = kt.dir == 0;
+	const bool fwd = (kt.dir & 1) == 0;
 	for (int i = threadIdx.x; i < KD; i += 64 * NQ) tab[i] = kcc[(fwd ? 0 : KD) + i];
 	__syncthreads();
-	const int top = fwd ? c.hi : min(c.hi, c.L - 1);
-	const int lo = fwd ? c.lo : min(((c.lo + 3) & ~3) + 1, top + 1); // as k_kcol_struct: the chain kernel takes the last backward steps
+	int top, lo;
+	kc_range(c, kt.dir, W, lo, top);
+	const int part = (kt.dir >> 8) & 255, nparts = max((kt.dir >> 16) & 255, 1); // warm-up ranges come in parts of at most a tile's length
 	const uint8_t *o = obs + c.off;
 	const double *cc = tab + 32 * w; // this wave's part of every table
 	double x[32];
 #pragma unroll
 	for (int k = 0; k < 32; ++k) x[k] = (32 * w + k == col) ? 1.0 : 0.0; // column `col` = unit vector e_col
 	int E = 0;
-	const int n = top - lo + 1;
-	const int q0 = (int)((int64_t)n * js / sub), q1 = (int)((int64_t)n * (js + 1) / sub); // this block's steps, in traversal order
+	const int n = max(top - lo + 1, 0);
+	const int q0 = (int)((int64_t)n * (part * sub + js) / (nparts * sub)), q1 = (int)((int64_t)n * (part * sub + js + 1) / (nparts * sub)); // this block's steps, in traversal order
 	for (int q = q0; q < q1; ++q) {
 		const int p = fwd ? lo + q : top - q;
 		const int sym = min((int)o[p - 1] & 3, 2); // wave-uniform: a scalar byte load
@@ -673,7 +691,7 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 	for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
 	return v;
 }
-struct KcRun { int first, count, kc0, pad; }; // kc0: index of the run's first transfer matrix in Kcol
+struct KcRun { int first, count, kc0, n_warm; }; // kc0: index of the run's first KcTile; n_warm: that many of them are the parts of the head's warm-up range
 
 // one-state-per-lane step for PER * 64 states: lane L holds states L and (PER == 2) L + 64
 template <int PER>
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
                                                         const double *__restrict__ Kexp, const double *__restrict__ sp,
                                                         const double *__restrict__ e, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, double *__restrict__ entry,
-                                                        double *__restrict__ bentry, int sub)
+                                                        double *__restrict__ bentry, int sub, const double *__restrict__ a0, int W)
 {
 	constexpr int S = 64 * PER;
 	const int lane = threadIdx.x;
@@ -716,10 +734,19 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 		s1[q].mS = sp[3 * S + k]; s1[q].wS = sp[S + k]; s1[q].mP = sp[2 * S + k]; s1[q].wP = sp[k]; s1[q].dd = sp[4 * S + k];
 		e0[q] = e[k]; e1[q] = e[S + k];
 	}
-	for (int q = 0; q + 1 < r.count; ++q) {
+	if (r.n_warm > 0) { // the head's start vector: the prior pushed through the transfer matrices of its warm-up range
+		const Chunk c = chunks[t];
+		const uint8_t *o = obs + c.off;
+#pragma unroll
+		for (int q = 0; q < PER; ++q) {
+			if (fwd) { x[q] = a0[lane + 64 * q]; if (c.lo - chunk_warm_f(c, W) <= 1) x[q] *= walk_ev((int)o[0] & 3, e0[q], e1[q]); }
+			else x[q] = walk_ev((int)o[min(c.hi + chunk_warm_b(c, W) + 1, c.L) - 1] & 3, e0[q], e1[q]);
+		}
+	}
+	for (int q = -r.n_warm; q + 1 < r.count; ++q) { // q < 0: the parts of the warm-up range
 		double y[PER];
 		for (int ss = 0; ss < sub; ++ss) { // the tile's map = the product of its `sub` range maps, applied in traversal order
-		const int64_t kb = ((int64_t)(r.kc0 + q) * sub + ss) * S;
+		const int64_t kb = ((int64_t)(r.kc0 + r.n_warm + q) * sub + ss) * S;
 		double ex[PER], xs[PER], em = -1e300;
 #pragma unroll
 		for (int h = 0; h < PER; ++h) { ex[h] = Kexp[kb + lane + 64 * h]; em = fmax(em, x[h] > 0.0 ? ex[h] : -1e300); }
@@ -741,6 +768,13 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 #pragma unroll
 			for (int h = 0; h < PER; ++h) { y[h] *= inv; x[h] = y[h]; }
 		}
+		}
+		if (q < 0) { // still in front of the head tile: its start vector is complete after the last part
+			if (q == -1) {
+#pragma unroll
+				for (int h = 0; h < PER; ++h) vec[(int64_t)t * S + lane + 64 * h] = y[h];
+			}
+			continue;
 		}
 		if (!fwd) { // the tile's last steps p* .. lo with the sweep's own scaling: bt_lo as the sweep leaves it
 			const Chunk c = chunks[t];
@@ -890,23 +924,23 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 	if (p.n_kc <= 0) return;
 	if (p.ns == 128 && p.kcol_impl == 1)
 		hipLaunchKernelGGL(k_kcol2_struct<4>, dim3(p.n_kc * p.kc_sub * 2), dim3(256), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
-		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
+		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio, p.warmup);
 	else if (p.ns == 128)
 		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kc * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
 	else if (p.kcol_impl == 1)
 		hipLaunchKernelGGL(k_kcol2_struct<2>, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
-		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
+		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio, p.warmup);
 	else
 		hipLaunchKernelGGL(k_kcol_struct<4>, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
 	if (p.ns == 128)
 		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1, p.d_a0, p.warmup);
 	else
 		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1, p.d_a0, p.warmup);
 	PSMC_DBG("launch_kchain", p.n_kc, p.n_chain_f, p.n_chain_b);
 }
 void launch_walks(const EstepLaunch &p, hipStream_t st)

@@ -76,9 +76,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  * it did until the last build of round 2; default 0: it stops at the start vector),
  * "fuse128" (1, default: the fused back half for 65..128 states as well, four waves per group of four tiles; 0: bt table +
  * separate counts kernel),
- * "count_impl" (fused back half; 1, default: the backward recursion takes the forward sweep's scale factors, so no position is
- * normalised on its own; 2: the same with the matrix instructions of a step issued between the vector instructions of the
- * next one (measured slower); 0: round 1's kernel with a normaliser per position),
+ * "count_impl" (fused back half; 1, default: no position is normalised on its own, the posterior weight of a tile is measured once
+ * and carried through the forward and the backward scale factors; 2: the same with the matrix instructions of a step issued
+ * between the vector instructions of the next one (measured slower); 0: round 1's kernel with a normaliser per position),
  * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B),
  * "lanes8" (1: the bulk forward sweep and the backward warm-up of 64-state models run eight tiles per wave, 8 lanes x
  * 8 states, instead of four; fewer instructions per step, half the waves; default 0), "exact_lds" (exact mode, up

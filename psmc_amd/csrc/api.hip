@@ -35,7 +35,7 @@ struct psmc_hip_ctx {
 	int kcol_prio = 2;         // "kcol_prio": wave priority of k_kcol2_struct
 	int exact_lds = 0;         // "exact_lds": exact mode (<= 64 states) broadcasts the operands of its ordered sums through LDS instead of DPP rows; measured slower (905 vs 779 ms)
 	int lanes8 = 0;            // "lanes8": eight tiles per wave in the bulk forward sweep and the backward warm-up of the fused / factored back half
-	int count_impl = 1;        // "count_impl": variant of the fused back half (0: own normaliser per position; 1: forward-scaled; 2: + interleaved issue, measured slower)
+	int count_impl = 1;        // "count_impl": variant of the fused back half (0: a normaliser per position, round 1; 1: the weight carried through both scale factors; 2: + interleaved issue, measured slower)
 	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
 	int two_phase = 2;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)

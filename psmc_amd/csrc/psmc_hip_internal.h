@@ -66,7 +66,7 @@ struct EstepLaunch {
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
 	int exact_lds;       // exact mode, up to 64 states: operands of the ordered chains broadcast through LDS instead of DPP
 	int lanes8;          // 64 states: the throughput-bound bulk sweeps (forward, backward warm-up) run eight tiles per wave (8 lanes x 8 states)
-	int count_impl;      // fused == 1: 0 = k_bwd_count4_struct, 1 = forward-scaled variant (no per-position normaliser), 2 = that with the matrix
+	int count_impl;      // fused == 1: 0 = k_bwd_count4_struct, 1 = no per-position normaliser: the weight is carried through both scale factors, 2 = that with the matrix
 	                     // instructions of a step interleaved with the next step's vector instructions (estep_fused.hip)
 	int fuse_order;      // fused == 1, two-phase plan: 0 = list A after the forward sweep of phase B, 1 = beside it
 	int ckpt;            // fused == 2: the forward sweep stores X at p % 8 == 0 only, the counts recompute the rest

@@ -47,44 +47,57 @@ void psmc_hip_destroy(psmc_hip_ctx *ctx);
 const char *psmc_hip_strerror(int err);
 const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 
-/* Tunables (all optional): "chunk" (fast-mode tile length in bins, 0 = auto),
- * "warmup" (speculative overlap in bins, default 3072), "warm_tol" (tile-boundary agreement
- * demanded by verify/repair), "max_rounds", "overlap" (1: forward chain, backward
- * chain and the early counts pass on three streams; 0: one stream), "target_waves", "n_sub" (expect
- * waves per tile), "rep_impl" (0 ds_bpermute, 1 v_permlane*_swap),
- * "expect_impl" (0 VALU, 1 MFMA f64), "structured" (1 auto / 0 always dense sweeps),
- * "struct_tiles" (tiles aimed at by the structured sweeps, 4 per wavefront), "learn" (1: tiles
- * that needed a repair are glued to their neighbour for the following E-steps of this context;
- * results then depend on the call history within the stated tolerance), "warm_shift" (1, default: a tile that needed a
- * repair is first given a speculative warm-up of warmup << warm_shift bins of its own, and is glued only if that fails
- * too; 0: glue at once), "group_cap" (bins), "fuse" (1, default: with the
- * structured sweeps and up to 64 states the backward sweep feeds the counts' matrix instructions directly -- bt never
- * stored, half the HBM traffic; 0: bt table + separate counts kernel), "ckpt" (1, default:
- * psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest; 0: full X table),
- * "walk_impl" (1: one wave per glued run, one state per lane; 0: four runs per wave), "kcol_impl" (1, default: with up to 64
- * states the transfer matrices of the long runs are computed with one column per lane, serial scans and the matrix constants
- * broadcast from LDS; 2: with 65..128 states as well (measured slower there); 0: four columns per wave as tiles of the sweeps), "kc_sub" (4: with kcol_impl 1 a tile's steps are cut into this many ranges with a
- * transfer matrix and a pair of waves each), "kcol_prio" (2: wave priority of that kernel, 0..2; the bulk forward sweep runs at 1), "kc_min" (runs of at least this
- * many tiles get their boundary vectors from a chain of tile transfer matrices instead of a walk; 0: never),
- * "kc_div" (at most n_tiles / kc_div tiles per direction get a transfer matrix), "two_phase" (tiles with an odd
- * index inside their segment do not speculate but start from the exact boundary vector their neighbour left: 2,
- * default: backward only, in the second launch of the fused back half; 1: forward as well, in a second forward
- * launch; 0: every tile speculates),
- * "kc_warm" (default 0; 64 states, 1: the start vector of a transfer-matrix chain from matrices of its warm-up range instead of a
- * walk -- parity-green, measured slower: 13.45 vs 13.0 ms, factored 11.35 vs 10.8),
- * "walk_heads" (1: the walk that delivers the start vector of a transfer-matrix chain also runs through the chain's head tile, as
- * it did until the last build of round 2; default 0: it stops at the start vector),
- * "fuse128" (1, default: the fused back half for 65..128 states as well, four waves per group of four tiles; 0: bt table +
- * separate counts kernel),
- * "count_impl" (fused back half; 1, default: no position is normalised on its own, the posterior weight of a tile is measured once
- * and carried through the forward and the backward scale factors; 2: the same with the matrix instructions of a step issued
- * between the vector instructions of the next one (measured slower); 0: round 1's kernel with a normaliser per position),
- * "fuse_order" (two_phase only; 1: first launch of the fused back half beside the forward sweep of phase B),
- * "lanes8" (1: the bulk forward sweep and the backward warm-up of 64-state models run eight tiles per wave, 8 lanes x
- * 8 states, instead of four; fewer instructions per step, half the waves; default 0), "exact_lds" (exact mode, up
- * to 64 states: 1 = operands of the ordered sums broadcast through LDS instead of DPP rows; bit-identical, slower; default 0),
- * "batch_bins" (psmc_hip_estep_batch, exact mode: table bins per launch group; 0, default: what fits the free device memory).
- * Setting any option drops the per-replicate plans a fast-mode batch has learned. */
+/* Options.  None is needed: the defaults are what bench.py and the psmc binary run, and the plan adapts to the input
+ * (see "auto").  PSMC_HIP_OPTIONS="key=value,key=value" in the environment sets them for every context of a process.
+ * Unknown keys and out-of-range values return PSMC_HIP_EINVAL.  Setting any option drops the per-replicate plans a
+ * fast-mode batch has learned.  Exact mode reads only "rep_impl" and "batch_bins".
+ *
+ *  key             default  meaning
+ *  --- plan of the fast mode (tiles, speculation) ---------------------------------------------------------------
+ *  "chunk"         0        tile length in bins; 0 = auto: two ROUNDS of the fused back half (8192 tiles, one wave per
+ *                           SIMD and four tiles per wave in each of two launches) for genome-sized inputs, ONE round
+ *                           (4096 tiles, every tile speculating in both directions, one launch) below 8192 x warmup
+ *                           bins (25 M) -- a single chromosome, one rank's share of a genome at 2/4/8 GPUs
+ *  "struct_tiles"  8192     tiles aimed at when chunk = 0 (fixes the plan: no adaptation to the input size)
+ *  "warmup"        3072     bins a tile starts outside itself (from the stationary vector) in each direction
+ *  "warm_tol"      1e-12    agreement demanded between the vector a tile built on and what its neighbour computed
+ *  "max_rounds"    4096     verify / repair rounds before PSMC_HIP_ECONVERGE
+ *  "learn"         1        tiles that needed a repair are treated differently in the following E-steps of the context
+ *                           (longer warm-up, then glued to their neighbour); results then depend on the call history
+ *                           within the stated tolerance, two contexts with the same history agree bit for bit
+ *  "warm_shift"    auto     such a tile first gets a warm-up of warmup << warm_shift bins of its own and is glued only
+ *                           if that fails too; 0 = glue at once.  auto: 1 with the two-round plan, 0 with one round
+ *  "group_cap"     131072   longest run of glued tiles, in bins
+ *  "two_phase"     auto     2: the fused back half runs as two launches, odd tiles of the second list start from the exit
+ *                           vector of the tile above instead of speculating backward; 0: every tile speculates, one
+ *                           launch when the tiles fit one round.  auto: 2 with two rounds, 0 with one
+ *  "merge1"        auto     1: bulk forward sweep and backward warm-up pass in ONE grid, so that the dispatcher puts
+ *                           their waves on distinct SIMDs, and the dependent chain walks -> chains -> run tiles -> back
+ *                           half on one stream; 0: side by side on streams of their own.  auto: 1 with one round
+ *  --- glued runs ---------------------------------------------------------------------------------------------------
+ *  "kc_min"        4        runs of at least this many tiles get their boundary vectors from a chain of tile transfer
+ *                           matrices instead of a walk; 0 = never
+ *  "kc_div"        16       at most n_tiles / kc_div tiles per direction get a transfer matrix
+ *  "kc_sub"        auto     64 states: a tile's steps are cut into this many ranges with a matrix (and a pair of
+ *                           waves) each; auto: ranges of about (tile + warmup) / 8 steps, at most 4
+ *  "kcol_prio"     2        wave priority of the transfer-matrix kernel (0..2; the bulk forward sweep runs at 1)
+ *  --- back half ----------------------------------------------------------------------------------------------------
+ *  "fuse"          1        structured sweeps, up to 64 states: the backward sweep feeds the counts' matrix
+ *                           instructions directly, bt never stored; 0: bt table + separate counts kernel
+ *  "fuse128"       1        the same with 65..128 states (four waves per group of four tiles)
+ *  "ckpt"          1        psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest
+ *  "structured"    1        1 = O(N) sweeps when a[][] has the PSMC form (checked per call), 0 = always the dense sweeps
+ *  "overlap"       1        forward chain, backward chain, counts and walks on streams of their own; 0: one stream
+ *  --- dense sweeps / unfused counts (any matrix up to 64 states) ----------------------------------------------------
+ *  "target_waves"  1536     tiles aimed at by the dense sweeps (one per wave)
+ *  "n_sub"         6        waves per tile in the separate counts kernel
+ *  "expect_impl"   1        separate counts kernel: 1 v_mfma_f64_16x16x4, 0 vector instructions (cross-check)
+ *  --- exact mode ---------------------------------------------------------------------------------------------------
+ *  "rep_impl"      1        row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical)
+ *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch group; 0 = what fits the free device memory
+ *
+ * Removed in round 3 after losing their A/B (DESIGN.md section 3 keeps the measurements): "count_impl", "kc_warm",
+ * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "lanes8", "exact_lds", and the value 1 of "two_phase". */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
@@ -103,7 +116,10 @@ int psmc_hip_select(psmc_hip_ctx *ctx, int n_sel, const int32_t *seg_idx);
  *   A  n*n   he_sum->A            E  2*n  he_sum->E[0..1] (khmm.c:355)
  *   A0 n     he_sum->A0 (may be NULL; unused downstream)
  *   LL       sum of hmm_lk over segments (em.c:48)
- *   chk      n_sel values of the khmm.c:237-238 underflow check (may be NULL) */
+ *   chk      n_sel values of the khmm.c:237-238 underflow check (may be NULL)
+ * Fast mode computes neither A0 (nothing downstream reads it: khmm.c:321-322 fills it, hmm_Q never uses it) nor the
+ * self-check (its speculation has its own verify / repair net): A0 comes back as zeros and chk as 1.0, from this call
+ * and from psmc_hip_group_estep alike.  Exact mode returns the reference's values. */
 int psmc_hip_estep(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, double *A, double *E,
                    double *A0, double *LL, double *chk);
 
@@ -155,8 +171,8 @@ int psmc_hip_estep_factored(psmc_hip_ctx *ctx, const double *a, const double *e,
 
 /* Diagnostic: out = {structured sweeps used (0/1), tile length in bins, forward sweep items,
  * backward sweep items, back half (0: bt table + counts kernel, 1: backward sweep fused with the counts, 2: factored
- * statistics), checkpointed X (0/1), launches of the fused back half (2 with the two-phase plan), forward tiles of
- * phase B} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured
+ * statistics), checkpointed X (0/1), launches of the fused back half (2 with the two-phase plan), phase 1 as one grid
+ * ("merge1": 0/1)} of the last fast-mode E-step (items = runs of glued tiles).  The O(N) structured
  * sweeps are chosen automatically when a[][] has the two rank-1
  * triangles psmc_update_hmm builds (core.c:112-122); otherwise the dense sweeps run. */
 int psmc_hip_fast_info(psmc_hip_ctx *ctx, int out[8]);
@@ -196,8 +212,9 @@ int psmc_hip_post_counts(psmc_hip_ctx *ctx, int seg, const int32_t *cnt1, int32_
  * device's reduction kernel left in HBM, over xGMI; exact mode: per-segment statistics gathered and added on the host
  * in the global input order -- bit-identical to the single-GPU result and to khmm.c.  librccl is opened on first use.
  * Options: every psmc_hip_set_option key (applied to all shards) and "rccl" (-1 auto: RCCL when the devices are
- * distinct and more than one shard holds segments, else the host adds the shards' vectors in shard order; 0 never;
- * 1 always, e.g. a one-device group as a smoke test of the RCCL path). */
+ * distinct and more than one shard holds segments, else the host adds the shards' vectors in shard order -- also when
+ * librccl cannot be opened or refuses the communicator; 0 never; 1 always, e.g. a one-device group as a smoke test of
+ * the RCCL path: a missing RCCL is then an error). */
 typedef struct psmc_hip_group psmc_hip_group;
 int  psmc_hip_group_create(psmc_hip_group **g, int n_states, int n_dev, const int *devices, int mode);
 void psmc_hip_group_destroy(psmc_hip_group *g);
@@ -209,6 +226,14 @@ int  psmc_hip_group_estep(psmc_hip_group *g, const double *a, const double *e, c
                           double *A0, double *LL, double *chk);
 int  psmc_hip_group_estep_factored(psmc_hip_group *g, const double *a, const double *e, const double *a0, double *sums,
                                    double *E, double *LL);
+/* First contact with a multi-GPU node, callable before any segment is loaded: every listed device answers, the
+ * exchange the E-steps will use comes up (RCCL communicator, or the host sum) and adds correctly in stream order (shard
+ * s puts s + 1 into its vector with an asynchronous copy on its E-step stream, the reduction follows on the same stream,
+ * every device must then hold n(n+1)/2).  out (may be NULL) = {shards, path as last_reduce below (1 RCCL, 2 host sum,
+ * 0 single shard, 3 exact mode: nothing to exchange), communicator up (0/1), RCCL wanted but unusable (0/1; the reason
+ * is then in psmc_hip_group_last_error although the call succeeds, auto mode falls back to the host sum)}.  A failure
+ * names the step that failed.  bench.py --engine group calls this first. */
+int  psmc_hip_group_selfcheck(psmc_hip_group *g, int out[4]);
 /* shard_of_seg: n_seg entries (may be NULL); last_reduce: 0 none (one shard), 1 RCCL all-reduce, 2 host sum of the
  * shards' vectors, 3 ordered per-segment sum (exact mode) */
 int  psmc_hip_group_info(psmc_hip_group *g, int *n_shards, int32_t *shard_of_seg, int *last_reduce);
@@ -241,6 +266,22 @@ int psmc_hip_microbench(int device, double *out, int n);
 #define PSMC_HIP_PIPE_PROBE_CONFIGS 6
 int psmc_hip_pipe_probe(int device, double *out, int n);
 
+/* Diagnostic, second edition of the pipe probe: which instructions of one wave overlap with another wave's
+ * v_mfma_f64 on the same SIMD?  One work-group of up to 8 waves on one CU (wave w -> SIMD w % 4); kinds8[w] says what
+ * wave w issues per round (~4 k cycles of issue when alone): 0 idle, 1 v_mfma_f64_16x16x4 x 64, 2 v_fma_f64 x 1024,
+ * 3 v_mov_b32_dpp x 1024, 4 DPP scan levels (2 v_mov_b32_dpp + v_add_f64, as the sweeps' row scans) ~ 1024 in all,
+ * 5 ds_read_b128 x 512, 6 s_load_dwordx4 x 256 + v_readlane_b32 x 512, 7 v_add_u32 x 1024, 8 v_fma_f32 x 1024,
+ * 9 v_add_f64 x 1024.  out8[w] = shader cycles per round of wave w (0 for idle waves). */
+int psmc_hip_pipe_probe2(int device, const int *kinds8, int rounds, double *out8);
+
+/* Diagnostic: where do the waves of a launch smaller than the device land?  n_kernels (1..4) launches of n_waves waves
+ * of the structured sweep step (no memory traffic), in work-groups of waves_per_block (1..4) waves, side by side on
+ * streams of their own.  out[3*(k*n_waves_padded + w) + 0..2] = shader cycles per step of wave w of launch k, its
+ * HW_ID register (SIMD bits 5:4, CU 11:8, SH 12, SE 15:13) and its XCC_ID; n_waves_padded = n_waves rounded up to a
+ * multiple of waves_per_block.  *ms_out = the slowest launch.  A shard-sized E-step has fewer waves than the device
+ * has SIMDs: if they are stacked on the same SIMDs, every step costs a multiple of its latency. */
+int psmc_hip_place_probe(int device, int n_waves, int waves_per_block, int n_kernels, int steps, double *out, double *ms_out);
+
 /* Diagnostic: an 8-byte-per-lane streaming copy (reads and writes 8*n_doubles bytes, 5
  * launches) to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the access
  * width the kernels use; *ms_out = average duration of one launch. */
@@ -254,7 +295,7 @@ int psmc_hip_hbm_probe(int device, long long bytes, double *gbps_out);
 /* Diagnostic: the structured sweep step (no memory traffic) on n_waves wavefronts at once, `steps`
  * steps each: out[0] kernel ms, [1] mean / [2] max shader cycles per step of a wave, [3] mean shader
  * clock in MHz the waves saw -- how far FP64 issue and clocks hold up when the whole device is busy.
- * steps < 0: |steps| steps of the eight-tiles-per-wave form of the step (8 lanes x 8 states). */
+ */
 int psmc_hip_load_probe(int device, int n_waves, int steps, double *out);
 
 /* Diagnostic: psmc_hip_load_probe with the table stores of a forward sweep: each wave appends 512 bytes per tile and

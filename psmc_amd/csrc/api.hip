@@ -29,18 +29,16 @@ struct psmc_hip_ctx {
 	bool use_struct = false, planned_struct = false;
 	int last_fused = 0, last_ckpt = 0; // what the last fast E-step ran: EstepLaunch::fused / ckpt
 	bool want_factored = false; // this call asked for the factored statistics (psmc_hip_estep_factored)
-	int walk_impl = 1;         // "walk_impl"
-	int kcol_impl = 1;         // "kcol_impl": 64 states, transfer matrices with one column per lane (1) or as four sweep tiles per wave (0)
-	int kc_sub = 4;            // "kc_sub": kcol_impl 1 cuts a tile's steps into this many ranges, one matrix (and one pair of waves) each
+	int kc_sub = 4;            // "kc_sub": k_kcol2_struct cuts a tile's steps into this many ranges, one matrix (and one pair of waves) each; default: by the plan
 	int kcol_prio = 2;         // "kcol_prio": wave priority of k_kcol2_struct
-	int exact_lds = 0;         // "exact_lds": exact mode (<= 64 states) broadcasts the operands of its ordered sums through LDS instead of DPP rows; measured slower (905 vs 779 ms)
-	int lanes8 = 0;            // "lanes8": eight tiles per wave in the bulk forward sweep and the backward warm-up of the fused / factored back half
-	int count_impl = 1;        // "count_impl": variant of the fused back half (0: a normaliser per position, round 1; 1: the weight carried through both scale factors; 2: + interleaved issue, measured slower)
-	int fuse_order = 0;        // "fuse_order": 1 = first launch of the fused back half beside the forward sweep of phase B instead of after it
-	int two_phase = 2;         // "two_phase": odd tiles start from their neighbour's exact boundary vector in a second phase (fused back half)
+	int two_phase = -1;        // "two_phase": 2 = the fused back half runs as two launches and the tiles of the second list with an odd index start from
+	                           // the exit vector of the tile above instead of speculating; 0 = every tile speculates; -1 = by the plan
+	int two_phase_used = 2;    // what plan_fast chose
+	int merge1 = -1;           // "merge1": bulk forward sweep + backward warm-up pass in one grid (k_sweep_struct); -1 = by the plan (shard-sized inputs)
+	int merge1_used = 0;
+	bool warm_shift_set = false, kc_sub_set = false;
+	int warm_shift_used = 1, kc_sub_used = 4;
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
-	int kc_warm = 0;           // "kc_warm" (experimental): the start vector of a chain run from transfer matrices of its warm-up range instead of a walk
-	int walk_heads = 0;        // "walk_heads": 1 = the walk of a chain run also goes through its head tile (as before round 2's last build)
 	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
 	double *d_Kcol = nullptr; size_t kcol_cap = 0;
@@ -100,7 +98,7 @@ struct psmc_hip_ctx {
 	hipEvent_t evx[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool timing_two_launches = false; // the fused back half ran as two launches (lists A and B): evx[11] / evx[12] sit between them
 	int n_long_f = 0, n_long_b = 0, n_mem_f = 0, n_mem_b = 0;
-	int n_B_f = 0, n_B_b = 0, n_list_a = 0, n_list_b = 0; // two-phase plan: trailing single items of phase B; tile lists of the fused back half
+	int n_B_b = 0, n_list_a = 0, n_list_b = 0; // two-phase plan: trailing backward items that start from above; tile lists of the fused back half
 	int items_two_phase = -1;  // what the current item lists were built for
 	int *d_ftiles = nullptr;   // [2 * (n_tiles + 4)] tile lists A | B of the fused back half (bit 30: start from the tile above)
 	FastReport report = {0, 0, 0, 0, 1};
@@ -214,6 +212,23 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 		psmc_hip_destroy(c);
 		return PSMC_HIP_ENOMEM;
 	}
+	// PSMC_HIP_OPTIONS="key=value,key=value": options for every context of the process (A/B of a whole program or test
+	// run under another plan without touching its code; unknown keys are an error so that a typo cannot pass for a result)
+	if (const char *env = getenv("PSMC_HIP_OPTIONS")) {
+		std::string all(env);
+		size_t at = 0;
+		while (at < all.size()) {
+			size_t end = all.find(',', at);
+			if (end == std::string::npos) end = all.size();
+			const std::string kv = all.substr(at, end - at);
+			const size_t eq = kv.find('=');
+			if (!kv.empty() && (eq == std::string::npos || psmc_hip_set_option(c, kv.substr(0, eq).c_str(), atof(kv.c_str() + eq + 1)) != PSMC_HIP_OK)) {
+				psmc_hip_destroy(c);
+				return PSMC_HIP_EINVAL;
+			}
+			at = end + 1;
+		}
+	}
 	*out = c;
 	return PSMC_HIP_OK;
 }
@@ -230,8 +245,10 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	(void)hipSetDevice(c->device);
 	destroy_kids(c);
 	if (c->parent) { // a batch child owns its plan only: streams, events, staging, observations and tables are the parent's
+		// (d_seg*: a child that took the exact fallback of psmc_hip_estep -- 65..128 states, a matrix without the PSMC form)
 		void *mine[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-		                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_items, c->d_ftiles, c->d_Kcol};
+		                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_items, c->d_ftiles, c->d_Kcol,
+		                c->d_segA, c->d_segE, c->d_segA0, c->d_chk};
 		for (void *p : mine) if (p) (void)hipFree(p);
 		if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 		if (c->h_ritems) (void)hipHostFree(c->h_ritems);
@@ -272,19 +289,12 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "max_rounds") c->max_rounds = (int)v;
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
-	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; }
-	else if (k == "walk_impl") { c->walk_impl = v != 0 ? 1 : 0; c->items_dirty = true; } // the walk lists depend on the kernel (count 0 items)
-	else if (k == "kcol_impl") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_impl = (int)v; c->items_dirty = true; }
+	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
+	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
 	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
-	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->items_dirty = true; }
-	else if (k == "exact_lds") { c->exact_lds = v != 0 ? 1 : 0; }
-	else if (k == "lanes8") { c->lanes8 = v != 0 ? 1 : 0; }
-	else if (k == "count_impl") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->count_impl = (int)v; }
-	else if (k == "fuse_order") { c->fuse_order = v != 0 ? 1 : 0; }
-	else if (k == "two_phase") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->items_dirty = true; }
+	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->kc_sub_set = true; c->plan_dirty = true; c->items_dirty = true; }
+	else if (k == "two_phase") { if (v != -1 && v != 0 && v != 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
-	else if (k == "kc_warm") { c->kc_warm = v != 0 ? 1 : 0; c->items_dirty = true; }
-	else if (k == "walk_heads") { c->walk_heads = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
@@ -505,9 +515,9 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0)
 // fused backward sweep + counts: structured matrices; 64 states, or 128 with "fuse128"
 static bool fused_counts(const psmc_hip_ctx *c) { return c->fuse && c->expect_impl == 1 && (c->ns == 64 || (c->ns == 128 && c->fuse128)); }
 
-// the column-per-lane transfer-matrix kernel: 64 states by default; 128 states only on request ("kcol_impl" = 2: it
-// takes 2.3x fewer vector instructions there too, but its chain path ends later and the E-step gets slower, 30.6 vs 28.3 ms)
-static bool kcol2_on(const psmc_hip_ctx *c) { return c->kcol_impl == 2 || (c->kcol_impl == 1 && c->ns == 64); }
+// the column-per-lane transfer-matrix kernel (k_kcol2_struct): 64 states.  With 65..128 states it takes 2.3x fewer vector
+// instructions too, but its chain path ends later and the E-step got slower (30.6 vs 28.3 ms, round 2): not built.
+static bool kcol2_on(const psmc_hip_ctx *c) { return c->ns == 64; }
 
 static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const double *par_base = nullptr)
 {
@@ -521,8 +531,8 @@ static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const d
 	p.fused = (c->use_struct && fused_counts(c)) ? 1 : 0;
 	if (c->want_factored) p.fused = 2;
 	p.ckpt = (c->want_factored && c->ckpt && c->use_struct && c->ns == 64 && c->chunk_used % 8 == 0) ? 1 : 0;
-	c->last_fused = p.fused; c->last_ckpt = p.ckpt; p.fuse_order = c->fuse_order; p.count_impl = c->count_impl; p.lanes8 = c->lanes8; p.exact_lds = c->exact_lds;
-	p.walk_impl = c->walk_impl; p.kcol_impl = kcol2_on(c) ? 1 : 0; p.d_kcc = pb + psmc_hip_ctx::KCC_OFF;
+	c->last_fused = p.fused; c->last_ckpt = p.ckpt;
+	p.d_kcc = pb + psmc_hip_ctx::KCC_OFF;
 	p.ns = c->ns;
 	if (c->ns == 128) {
 		p.d_aeT = pb + 16384; p.d_e = pb + 32768; p.d_a0 = pb + 32768 + 384;
@@ -698,10 +708,23 @@ static int plan_fast(psmc_hip_ctx *c)
 	for (int32_t s : c->work) bins += c->L[s];
 	int T = c->chunk;
 	const bool st = c->use_struct;
+	// One ROUND of the fused back half = 1024 SIMDs x one wave x four tiles = 4096 tiles.  The default plan of a genome-sized
+	// input is two rounds (8192 tiles, two launches, the second list starting from the exit vectors of the first:
+	// two_phase = 2).  A shard-sized input -- one rank's share of the genome at 2/4/8 GPUs, a single chromosome -- is planned
+	// as ONE round instead ("shard-sized inputs"): with T the tile of the two-round plan, phase 1 costs
+	// (T + W) steps at three waves per SIMD there and (2T + W) steps at two waves per SIMD here, the counts the same 2T
+	// steps either way -- one round wins while T < W, i.e. below 8192 * warmup bins (25 M).  All tiles speculate in both
+	// directions (no second list to wait for), phase 1 is ONE grid (merge1) so that its waves land on distinct SIMDs, and a
+	// tile that fails is glued at once instead of getting a doubled warm-up first (a 6144-step item would be the critical
+	// path of a phase that is otherwise (T + W) steps long).
+	const int64_t ROUND = 4096;
+	bool one_round = false;
 	if (T <= 0) { // auto: about target_waves (dense: 1 tile per wave) or struct_tiles (4 per wave) tiles, never below 256 bins
-		int want = st ? c->struct_tiles : c->target_waves;
-		// small inputs: a tile far shorter than its warm-up is mostly overhead; one wave per SIMD (4 tiles each) is enough
-		if (st && !c->struct_tiles_set && bins / want < 1536) want /= 2;
+		int64_t want = st ? c->struct_tiles : c->target_waves;
+		if (st && !c->struct_tiles_set && bins < 2 * ROUND * (int64_t)std::max(c->warmup, 1)) {
+			want = std::max<int64_t>(ROUND - (int64_t)c->work.size(), ROUND / 2); // every segment ends in a ragged tile: stay inside the round
+			one_round = true;
+		}
 		T = (int)((bins + want - 1) / want);
 		T = std::max(256, (T + 63) & ~63);
 	}
@@ -721,6 +744,15 @@ static int plan_fast(psmc_hip_ctx *c)
 	const int nc = (int)c->chunks.size();
 	c->chunk_used = T;
 	c->planned_struct = st;
+	one_round = st && nc <= ROUND; // also when the caller chose the tile length
+	c->two_phase_used = c->two_phase >= 0 ? c->two_phase : (one_round ? 0 : 2);
+	c->merge1_used = c->merge1 >= 0 ? c->merge1 : (one_round ? 1 : 0);
+	c->warm_shift_used = c->warm_shift_set ? c->warm_shift : (one_round ? 0 : 1);
+	// transfer matrices: a tile's steps are cut into ranges of about 1000 steps (one wave pair each), so that the column
+	// kernel is no longer than a bulk sweep; short tiles need fewer ranges -- and every range is one more 64 x 64 product
+	// in the sequential chain that follows
+	// (ranges of about an eighth of a bulk item, T + W steps: 4-5 at the genome plan's 3712-bin tiles, 2 at 960, 1 at 256)
+	c->kc_sub_used = c->kc_sub_set ? c->kc_sub : std::max(1, std::min(4, (int)((8 * (int64_t)T + T + c->warmup - 1) / std::max(T + c->warmup, 1))));
 	// the counts kernel splits a tile over n_sub waves: keep about the same number of partial blocks
 	c->n_sub_used = st ? (fused_counts(c) ? 1 : std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1)))) : c->n_sub;
 	c->glue_f.assign(nc, 0); c->glue_b.assign(nc, 0); // a new tiling forgets what was learned
@@ -752,27 +784,26 @@ static int plan_fast(psmc_hip_ctx *c)
 
 // Sweep items of the structured kernels: maximal runs of glued tiles (one segment, at most group_cap
 // bins), ordered by step count so that the four rows of a wave finish together (longest first).
-static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
+static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 {
 	const int nc = (int)c->chunks.size(), W = c->warmup;
-	// Two-phase plan (fused back half): a single tile with an odd index inside its segment does not speculate.
-	// Forward it starts from the exact X_{lo-1} its (even) neighbour left in the table, backward from that
-	// neighbour's exit vector, in a second phase -- half of the warm-up work disappears and the phases overlap
-	// (forward B beside backward A).  Verify / repair / learning are unchanged: such a tile trivially agrees with
-	// its neighbour unless a later repair changes that neighbour.
+	// Two-phase plan (fused back half, two launches): a single tile with an odd index inside its segment does not
+	// speculate backward.  It is in the second list and starts from the exit vector its neighbour above left in the
+	// first launch -- half of the backward warm-up work disappears.  Verify / repair / learning are unchanged: such a
+	// tile trivially agrees with its neighbour unless a later repair changes that neighbour.  (A forward counterpart --
+	// odd tiles from the X_{lo-1} of their neighbour in a second forward launch -- was built in round 2, measured equal
+	// and removed in round 3: the dependency costs what the saved warm-ups gain.)
 	std::vector<int> odd(nc, 0);
 	for (int b = 1; b < nc; ++b) if (c->chunks[b].off == c->chunks[b - 1].off) odd[b] = !odd[b - 1];
 	// key: glued runs first (launched apart from the bulk), then phase A longest first, then phase B
 	std::vector<std::pair<long long, std::pair<int, int>>> kf, kb; // (key, (first, count))
 	auto key = [](int steps, int count, bool phase_b) { return (count > 1 ? -(1ll << 40) : (phase_b ? (1ll << 40) : 0ll)) - steps; };
-	std::vector<char> fwd_b(nc, 0), from_above(nc, 0);
+	std::vector<char> from_above(nc, 0);
 	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
 		int e = b + 1;
 		while (e < nc && c->glue_f[e] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
 		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
-		const bool pb = two_phase && e - b == 1 && odd[b]; // odd => a predecessor tile exists in the segment
-		if (pb) fwd_b[b] = 1;
-		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, e - b, pb), {b, e - b}});
+		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, e - b, false), {b, e - b}});
 		b = e;
 	}
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
@@ -807,25 +838,26 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 	c->n_long_f = c->n_long_b = 0; // glued runs sort first (more steps than any single tile)
 	while (c->n_long_f < c->n_items_f && kf[c->n_long_f].second.second > 1) ++c->n_long_f;
 	while (c->n_long_b < c->n_items_b && kb[c->n_long_b].second.second > 1) ++c->n_long_b;
-	c->n_B_f = c->n_B_b = 0; // phase-B singles sort last
-	for (int b = 0; b < nc; ++b) { c->n_B_f += fwd_b[b]; c->n_B_b += from_above[b]; }
+	c->n_B_b = 0; // from-above singles sort last
+	for (int b = 0; b < nc; ++b) c->n_B_b += from_above[b];
 	{ // tile lists of the fused back half: A = every tile whose X and start vector exist after phase A, B = the rest
 		// B must hold the tiles of phase B; A must hold the tile above every from-above tile; the rest (run tiles, ...)
 		// can go to either and balance the two launches (each should fit the device in one round of waves)
 		std::vector<int> la, lb, freet;
 		for (int b = 0; b < nc; ++b) {
-			if (fwd_b[b] || from_above[b]) lb.push_back(b | (from_above[b] ? (1 << 30) : 0));
+			if (from_above[b]) lb.push_back(b | (1 << 30));
 			else if (b > 0 && from_above[b - 1]) la.push_back(b);
 			else freet.push_back(b);
 		}
-		for (int b : freet) { if (la.size() <= lb.size()) la.push_back(b); else lb.push_back(b); }
+		const bool single = lb.empty() && nc <= 4096; // one round of waves holds every tile: one launch, nothing to balance
+		for (int b : freet) { if (single || la.size() <= lb.size()) la.push_back(b); else lb.push_back(b); }
 		c->n_list_a = (int)la.size(); c->n_list_b = (int)lb.size();
 		while (la.size() % 4) la.push_back(-1);
 		while (lb.size() % 4) lb.push_back(-1);
 		la.insert(la.end(), lb.begin(), lb.end());
 		if (!la.empty()) HIPCHK(c, hipMemcpy(c->d_ftiles, la.data(), sizeof(int) * la.size(), hipMemcpyHostToDevice));
 	}
-	c->items_two_phase = (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0);
+	c->items_two_phase = two_phase_bwd ? 2 : 0;
 	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
 	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": a walk delivers the start vector
@@ -837,8 +869,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b;
 	c->n_wl_f = c->n_wl_b = 0;
 	const bool chains = c->kc_min >= 2; // 64 states: one state per lane in the chain kernel; 128: two
-	const int head_count = (c->ns == 64 && c->walk_impl == 1 && c->walk_heads == 0) ? 0 : 1; // k_walk1_struct knows count 0; the four-runs-per-wave walk does not
-	const bool warm_mats = c->kc_warm && c->ns == 64 && kcol2_on(c); // k_kcol2_struct<2> / k_kchain_struct<1> know warm-up ranges
+	const int head_count = c->ns == 64 ? 0 : 1; // k_walk1_struct knows count 0 (stop at the head's start vector); the four-runs-per-wave walk of 65..128 states walks through the head tile
 	auto add_runs = [&](const std::vector<std::pair<long long, std::pair<int, int>>> &k, int n_long, bool bwd) {
 		int &nw = bwd ? c->n_wl_b : c->n_wl_f;
 		std::vector<int> &rv = bwd ? runs_b : runs_f;
@@ -859,16 +890,6 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 					rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
 					for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
 				}
-			} else if (chain && warm_mats) {
-				// no walk at all: the warm-up range of the head as nparts more transfer matrices (each part at most a tile long)
-				const int head = bwd ? first + count - 1 : first;
-				const int wl = bwd ? chunk_warm_b(c->chunks[head], W) : chunk_warm_f(c->chunks[head], W);
-				const int nparts = std::min(255, std::max(1, (wl + c->chunk_used - 1) / std::max(c->chunk_used, 1)));
-				budget -= nparts;
-				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(nparts);
-				for (int part = 0; part < nparts; ++part) { kc.push_back(head); kc.push_back((bwd ? 3 : 2) | (part << 8) | (nparts << 16)); }
-				if (!bwd) for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
-				else for (int t = first + count - 1; t > first; --t) { kc.push_back(t); kc.push_back(1); }
 			} else if (chain) {
 				w[2 * nw] = bwd ? first + count - 1 : first; w[2 * nw + 1] = head_count; ++nw; // the head tile's start vector
 				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
@@ -886,7 +907,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 		std::vector<int> runs(runs_f); runs.insert(runs.end(), runs_b.begin(), runs_b.end());
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)16 * nc, kc.data(), sizeof(int) * kc.size(), hipMemcpyHostToDevice));
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)20 * nc, runs.data(), sizeof(int) * runs.size(), hipMemcpyHostToDevice));
-		const size_t nsub = kcol2_on(c) ? (size_t)c->kc_sub : 1; // k_kcol2_struct: kc_sub matrices per tile
+		const size_t nsub = kcol2_on(c) ? (size_t)c->kc_sub_used : 1; // k_kcol2_struct: kc_sub matrices per tile
 		const size_t need = (size_t)c->n_kc * nsub * ((size_t)c->ns * c->ns + c->ns); // the matrices, then one exponent per column
 		if (need > c->kcol_cap) { int rc; if ((rc = dev_alloc(c, &c->d_Kcol, need))) return rc; c->kcol_cap = need; }
 	}
@@ -896,8 +917,8 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 		        (void *)c->d_obs, (long long)c->total + 256, (void *)c->d_chunks, nc, (void *)c->d_items, (void *)c->d_entry, (void *)c->d_bentry, (void *)c->d_bexit,
 		        (void *)c->d_f, (void *)c->d_b, (void *)c->d_s, (void *)c->d_sb, (void *)c->d_Cpart, (void *)c->d_Epart, (void *)c->d_ftiles, (void *)c->d_touch, (void *)c->d_par, (void *)c->d_Kcol);
 	if (getenv("PSMC_HIP_DEBUG"))
-		fprintf(stderr, "[psmc_hip] items: %d tiles of %d bins, fwd %d items (%d runs, %d run tiles, %d walks, %d chains, %d phase B), bwd %d items (%d runs, %d run tiles, %d walks, %d chains, %d from above), %d transfer matrices, fused lists %d + %d\n",
-		        nc, c->chunk_used, c->n_items_f, c->n_long_f, c->n_mem_f, c->n_wl_f, c->n_chain_f, c->n_B_f, c->n_items_b, c->n_long_b, c->n_mem_b, c->n_wl_b, c->n_chain_b, c->n_B_b, c->n_kc, c->n_list_a, c->n_list_b);
+		fprintf(stderr, "[psmc_hip] items: %d tiles of %d bins, fwd %d items (%d runs, %d run tiles, %d walks, %d chains), bwd %d items (%d runs, %d run tiles, %d walks, %d chains, %d from above), %d transfer matrices, fused lists %d + %d\n",
+		        nc, c->chunk_used, c->n_items_f, c->n_long_f, c->n_mem_f, c->n_wl_f, c->n_chain_f, c->n_items_b, c->n_long_b, c->n_mem_b, c->n_wl_b, c->n_chain_b, c->n_B_b, c->n_kc, c->n_list_a, c->n_list_b);
 	return 0;
 }
 
@@ -911,7 +932,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase, bool two_phase_bwd)
 static void learn_groups(psmc_hip_ctx *c)
 {
 	const int nc = (int)c->chunks.size();
-	const int step = c->warm_shift;
+	const int step = c->warm_shift_used;
 	for (int b : c->flagged_f)
 		if (b > 0 && b < nc && !c->glue_f[b] && c->chunks[b - 1].off == c->chunks[b].off) {
 			Chunk &ch = c->chunks[b];
@@ -950,14 +971,15 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	// the fused back half takes both directions of the two-phase plan, the factored one (item lists, two waves per SIMD) the forward one
 	// 1: both directions; 2: backward only (the fused back half runs as two launches anyway, so its second list can start
 	// from the exit vectors of the first at no cost in scheduling, and half of the backward warm-up pass disappears)
-	const bool two_phase = c->two_phase == 1 && p.fused >= 1, two_phase_bwd = c->two_phase >= 1 && p.fused == 1;
+	const bool two_phase_bwd = c->two_phase_used >= 1 && p.fused == 1; // the fused back half only: the factored one is a single pass over item lists
+	p.merge1 = c->merge1_used;
 	if (c->chunks_dirty) { // learned warm-ups (learn_groups) reach the device before the next launch reads them
 		HIPCHK(c, hipStreamSynchronize(st));
 		HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * c->chunks.size(), hipMemcpyHostToDevice));
 		c->chunks_dirty = false;
 	}
-	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase ? 1 : 0) + (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase, two_phase_bwd))) return rc;
-	p.n_B_f = c->n_B_f; p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
+	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase_bwd))) return rc;
+	p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
 	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;
@@ -974,7 +996,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
 	p.kcol_prio = c->kcol_prio;
-	p.d_Kcol = c->d_Kcol; p.kc_sub = kcol2_on(c) ? c->kc_sub : 1;
+	p.d_Kcol = c->d_Kcol; p.kc_sub = kcol2_on(c) ? c->kc_sub_used : 1;
 	p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * p.kc_sub * c->ns * c->ns : nullptr; p.stream5 = c->stream5;
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
@@ -1068,7 +1090,7 @@ extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[8])
 	if (!c || !out) return PSMC_HIP_EINVAL;
 	out[0] = c->use_struct ? 1 : 0; out[1] = c->chunk_used; out[2] = c->use_struct ? c->n_items_f : (int)c->chunks.size();
 	out[3] = c->use_struct ? c->n_items_b : (int)c->chunks.size();
-	out[4] = c->last_fused; out[5] = c->last_ckpt; out[6] = c->timing_two_launches ? 2 : 1; out[7] = c->n_B_f;
+	out[4] = c->last_fused; out[5] = c->last_ckpt; out[6] = c->timing_two_launches ? 2 : 1; out[7] = c->merge1_used;
 	return PSMC_HIP_OK;
 }
 
@@ -1256,18 +1278,19 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->n = c->n; k->ns = c->ns; k->device = c->device; k->mode = c->mode; k->parent = c;
 		k->chunk = c->chunk; k->warmup = c->warmup; k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
-		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles; k->walk_impl = c->walk_impl; k->walk_heads = c->walk_heads; k->lanes8 = c->lanes8;
-		k->fuse_order = c->fuse_order; k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
-		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kcol_impl = c->kcol_impl; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
-		k->count_impl = c->count_impl; k->fuse128 = c->fuse128; k->kc_warm = c->kc_warm;
+		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles;
+		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
+		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
+		k->fuse128 = c->fuse128;
+		k->merge1 = c->merge1; k->warm_shift_set = c->warm_shift_set; k->kc_sub_set = c->kc_sub_set;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];
 		k->h_par = c->h_par; k->d_par = c->d_par;
-		c->kids.push_back(k);
 		// same segments, same offsets, the parent's copy of the observations
 		k->d_obs = c->d_obs; k->obs_borrowed = true; k->off = c->off; k->total = c->total;
-		if (set_segments_common(k, c->n_seg, c->L.data()) != 0) return nullptr;
+		if (set_segments_common(k, c->n_seg, c->L.data()) != 0) { c->err = k->err; psmc_hip_destroy(k); return nullptr; } // never keep a half-built child
+		c->kids.push_back(k);
 	}
 	return c->kids[r];
 }
@@ -1524,6 +1547,54 @@ extern "C" int psmc_hip_pipe_probe(int device, double *out, int n)
 	return rc ? PSMC_HIP_EDEVICE : PSMC_HIP_OK;
 }
 
+extern "C" int psmc_hip_pipe_probe2(int device, const int *kinds8, int rounds, double *out8)
+{
+	int nd = psmc_hip_device_count();
+	if (!kinds8 || !out8 || rounds < 1) return PSMC_HIP_EINVAL;
+	for (int i = 0; i < 8; ++i) if (kinds8[i] < 0 || kinds8[i] > 9) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	double *d = nullptr; void *src = nullptr;
+	if (hipMalloc((void **)&d, sizeof(double) * 8) != hipSuccess || hipMalloc(&src, 4096) != hipSuccess) { if (d) (void)hipFree(d); return PSMC_HIP_ENOMEM; }
+	(void)hipMemset(d, 0, sizeof(double) * 8); (void)hipMemset(src, 1, 4096);
+	int rc = run_pipe_probe2(nullptr, d, kinds8, std::max(1, rounds / 8), src); // warm: clocks, instruction cache
+	if (rc == 0) rc = run_pipe_probe2(nullptr, d, kinds8, rounds, src);
+	if (rc == 0 && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out8, d, sizeof(double) * 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = 1;
+	(void)hipFree(d); (void)hipFree(src);
+	return rc ? PSMC_HIP_EDEVICE : PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_place_probe(int device, int n_waves, int waves_per_block, int n_kernels, int steps, double *out, double *ms_out)
+{
+	int nd = psmc_hip_device_count();
+	if (n_waves < 1 || n_waves > (1 << 16) || waves_per_block < 1 || waves_per_block > 4 || n_kernels < 1 || n_kernels > 4 || steps < 4 || !out) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	const size_t per = (size_t)3 * ((n_waves + waves_per_block - 1) / waves_per_block) * waves_per_block;
+	double *d = nullptr;
+	if (hipMalloc((void **)&d, sizeof(double) * per * n_kernels) != hipSuccess) return PSMC_HIP_ENOMEM;
+	hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t e0, e1[4];
+	int rc = 0;
+	(void)hipEventCreate(&e0);
+	for (int k = 0; k < n_kernels; ++k) { if (hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) != hipSuccess) rc = 1; (void)hipEventCreate(&e1[k]); }
+	for (int pass = 0; pass < 2 && rc == 0; ++pass) { // pass 0 warms clocks and the instruction cache
+		(void)hipDeviceSynchronize();
+		(void)hipEventRecord(e0, st[0]);
+		for (int k = 1; k < n_kernels; ++k) (void)hipStreamWaitEvent(st[k], e0, 0);
+		for (int k = 0; k < n_kernels && rc == 0; ++k) { rc = run_place_probe(st[k], d + per * k, n_waves, waves_per_block, steps & ~3); (void)hipEventRecord(e1[k], st[k]); }
+	}
+	if (rc == 0 && hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, d, sizeof(double) * per * n_kernels, hipMemcpyDeviceToHost) == hipSuccess) {
+		float worst = 0;
+		for (int k = 0; k < n_kernels; ++k) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1[k]); worst = std::max(worst, ms); }
+		if (ms_out) *ms_out = worst;
+	} else rc = 1;
+	(void)hipEventDestroy(e0);
+	for (int k = 0; k < n_kernels; ++k) { (void)hipEventDestroy(e1[k]); if (st[k]) (void)hipStreamDestroy(st[k]); }
+	(void)hipFree(d);
+	return rc ? PSMC_HIP_EDEVICE : PSMC_HIP_OK;
+}
+
 extern "C" int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out)
 {
 	int nd = psmc_hip_device_count();
@@ -1578,8 +1649,6 @@ extern "C" int psmc_hip_hbm_probe(int device, long long bytes, double *gbps_out)
 extern "C" int psmc_hip_load_probe(int device, int n_waves, int steps, double *out)
 {
 	int nd = psmc_hip_device_count();
-	const bool h8 = steps < 0; // negative: the 8-lanes-per-tile variant of the step (eight tiles per wave)
-	if (h8) steps = -steps;
 	if (n_waves < 1 || n_waves > (1 << 20) || steps < 4 || !out) return PSMC_HIP_EINVAL;
 	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
 	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
@@ -1588,7 +1657,7 @@ extern "C" int psmc_hip_load_probe(int device, int n_waves, int steps, double *o
 	std::vector<double> h((size_t)2 * n_waves);
 	hipEvent_t e0, e1;
 	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-	const int arg = h8 ? -(steps & ~3) : (steps & ~3);
+	const int arg = steps & ~3;
 	int rc = run_load_probe(nullptr, d, n_waves, arg); // warm
 	(void)hipEventRecord(e0, nullptr);
 	if (rc == 0) rc = run_load_probe(nullptr, d, n_waves, arg);

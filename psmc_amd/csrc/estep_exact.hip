@@ -31,7 +31,6 @@ __global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, 
                                                     const ExWork wl, double *__restrict__ f,
                                                     double *__restrict__ s)
 {
-	__shared__ double lds_x[2 * 64]; // REP == 2: the state vector and the unnormalised one, broadcast through LDS
 	const int lane = threadIdx.x;
 	const int seg = wl.seg[blockIdx.x];
 	if (seg < 0) return; // padding entry of a batch
@@ -51,8 +50,7 @@ __global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, 
 		const int sym = __builtin_amdgcn_readlane(symv, 0);
 		const double g = a0[lane] * pick_e(sym, e0, e1);
 		double sum;
-		if (REP == 2) { lds_x[64 + lane] = g; __builtin_amdgcn_wave_barrier(); sum = seq_sum_lds(lds_x + 64); __builtin_amdgcn_wave_barrier(); }
-		else { double r[4]; rep_rows<REP == 2 ? 1 : REP>(g, r); sum = seq_sum_rep(r); }
+		{ double r[4]; rep_rows<REP>(g, r); sum = seq_sum_rep(r); }
 		x = g / sum;
 		fo[lane] = x;
 		if (lane == 0) so[0] = sum;
@@ -63,11 +61,9 @@ __global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, 
 		for (int i = (base == 0 ? 1 : 0); i < nb; ++i) { // khmm.c:176-185
 			const int sym = __builtin_amdgcn_readlane(symv, i);
 			double tmp, sum;
-			if (REP == 2) { lds_x[lane] = x; __builtin_amdgcn_wave_barrier(); tmp = xdot64_lds(lds_x, col); }
-			else { double r[4]; rep_rows<REP == 2 ? 1 : REP>(x, r); tmp = xdot64(r, col); }
+			{ double r[4]; rep_rows<REP>(x, r); tmp = xdot64(r, col); }
 			const double g = pick_e(sym, e0, e1) * tmp;
-			if (REP == 2) { lds_x[64 + lane] = g; __builtin_amdgcn_wave_barrier(); sum = seq_sum_lds(lds_x + 64); }
-			else { double q[4]; rep_rows<REP == 2 ? 1 : REP>(g, q); sum = seq_sum_rep(q); }
+			{ double q[4]; rep_rows<REP>(g, q); sum = seq_sum_rep(q); }
 			x = g / sum;
 			fo[(int64_t)(base + i) * 64 + lane] = x;
 			if (lane == 0) so[base + i] = sum;
@@ -88,13 +84,11 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
                                                      double *__restrict__ chk)
 {
 	__shared__ double lds_ae[2 * 4096]; // [0]: het (b=1), [1]: missing (b=2); [l*64+k]
-	__shared__ double lds_xb[4 * 64];   // REP == 2: each wave's b vector, broadcast through LDS
 	// the four sweeps of a block share the LDS copy: a batch keeps the items of one parameter set block-aligned
 	{ const int64_t po = wl.par ? wl.par[blockIdx.x * 4] * wl.par_stride : 0; aeT += po; e += po; a0 += po; }
 	for (int i = threadIdx.x; i < 2 * 4096; i += 256) lds_ae[i] = aeT[4096 + i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	double *xs = lds_xb + (threadIdx.x >> 6) * 64;
 	const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (w >= wl.n) return;
 	const int seg = wl.seg[w];
@@ -122,27 +116,10 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 			const int sym = __builtin_amdgcn_readlane(symv, i);
 			const double su = readlane_f64(sv, i);
 			double r[4];
-			if (REP == 2) { xs[lane] = x; __builtin_amdgcn_wave_barrier(); }
-			else rep_rows<REP == 2 ? 1 : REP>(x, r);
+			rep_rows<REP>(x, r);
 			double tmp;
 			if (sym == 0) {
-				tmp = REP == 2 ? xdot64_lds(xs, row0) : xdot64(r, row0);
-			} else if (REP == 2) {
-				const double *t = lds_ae + (sym - 1) * 4096 + lane;
-				double acc = 0.0;
-#pragma unroll
-				for (int j = 0; j < 4; ++j) { // same order, 16 matrix operands and 8 broadcast reads at a time
-					double m[16];
-#pragma unroll
-					for (int l = 0; l < 16; ++l) m[l] = t[(16 * j + l) * 64];
-#pragma unroll
-					for (int l = 0; l < 16; l += 2) {
-						const wp_d2_t v = *reinterpret_cast<const wp_d2_t *>(xs + 16 * j + l);
-						acc = acc + v.x * m[l];
-						acc = acc + v.y * m[l + 1];
-					}
-				}
-				tmp = acc;
+				tmp = xdot64(r, row0);
 			} else {
 				const double *t = lds_ae + (sym - 1) * 4096 + lane;
 				double acc = 0.0;
@@ -163,8 +140,7 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 		const int sym = o[0];
 		const double t = a0[lane] * x * e[sym * 64 + lane];
 		double c;
-		if (REP == 2) { __builtin_amdgcn_wave_barrier(); xs[lane] = t; __builtin_amdgcn_wave_barrier(); c = seq_sum_lds(xs); }
-		else { double r[4]; rep_rows<REP == 2 ? 1 : REP>(t, r); c = seq_sum_rep(r); }
+		{ double r[4]; rep_rows<REP>(t, r); c = seq_sum_rep(r); }
 		if (lane == 0) chk[w] = c;
 	}
 }
@@ -686,10 +662,7 @@ int launch_exact(const EstepLaunch &p)
 	if (p.ns == 128) return rep == 0 ? launch_exact128_t<0>(p) : launch_exact128_t<1>(p);
 	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.n_work, p.par_stride};
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
-	if (p.exact_lds)
-		hipLaunchKernelGGL(k_fwd_exact<2>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
-	else if (rep == 0)
+	if (rep == 0)
 		hipLaunchKernelGGL(k_fwd_exact<0>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	else
@@ -697,10 +670,7 @@ int launch_exact(const EstepLaunch &p)
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
 	const int nb = (p.n_work + 3) / 4;
-	if (p.exact_lds)
-		hipLaunchKernelGGL(k_bwd_exact<2>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
-		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
-	else if (rep == 0)
+	if (rep == 0)
 		hipLaunchKernelGGL(k_bwd_exact<0>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	else

@@ -602,24 +602,34 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	// ---- both speculative sweeps
 	// Glued runs (structured sweeps only) are long sequential chains.  A WALK leaves only the boundary
 	// vector of every tile it passes (no table stores: pure latency, untouched by the bulk's HBM traffic);
-	// it starts now, beside the bulk, on a stream of its own (the backward one borrows the counts'
-	// stream, which is idle until the bulk is done).  Afterwards all tiles of the runs are recomputed
+	// it starts now, beside the bulk, on a stream of its own.  Afterwards all tiles of the runs are recomputed
 	// in parallel from those boundary vectors; they are flagged for the redo pass of the counts.
 	const bool lw = p.structured && (p.n_long_f > 0 || p.n_long_b > 0) && (ov || p.fused);
 	const bool lf = lw && p.n_long_f > 0, lb = lw && p.n_long_b > 0;
-	hipStream_t sw = ov ? p.stream4 : sm;
-	if (lw) { // both directions in one launch on one extra stream (hardware queues are scarce)
-		if (ov) (void)hipStreamWaitEvent(sw, p.evx[0], 0);
-		launch_walks(p, sw); // short runs, and the head tile of every long run
+	const int ff0 = lf ? p.n_long_f : 0, fb0 = lb ? p.n_long_b : 0;
+	// Shard-sized inputs ("merge1", api.hip plan_fast): the bulk forward sweep and the backward warm-up pass are ONE grid
+	// (k_sweep_struct), so that the dispatcher puts their waves on distinct SIMDs.  The backward chain's stream is then
+	// idle during phase 1 and carries the whole dependent chain walks -> transfer-matrix chain -> run tiles -> back half ->
+	// verify: every hand-over between streams costs 50-70 us (rocprofv3 timelines, profiles/r03_shard_timeline_*.txt),
+	// which is nothing beside a 13 ms genome E-step and a fifth of a 1.5 ms chromosome E-step.
+	const bool mg = p.merge1 && p.structured && p.fused && ov;
+	hipStream_t sw = ov ? (mg ? sa : p.stream4) : sm, sk = ov ? p.stream5 : sm;
+	if (lw) { // the few latency-critical waves first: they get SIMDs of their own before the bulk grid fills the device
+		if (ov && sw != sa) (void)hipStreamWaitEvent(sw, p.evx[0], 0);
+		launch_walks(p, sw); // short runs, and the start vector of every chain run
+	}
+	if (mg) {
+		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0 - p.n_B_b, true);
+		(void)hipEventRecord(p.evx[1], sm);
+	}
+	if (lw) {
 		if (p.n_kc > 0) { // long runs: transfer matrices of their tiles (a stream of their own), then the chain
-			hipStream_t sk = ov ? p.stream5 : sm;
 			if (ov) (void)hipStreamWaitEvent(sk, p.evx[0], 0);
 			launch_kchain(p, sk, sw, p.evx[8]);
 		}
 		(void)hipEventRecord(p.evx[6], sw);
 		// All boundary vectors of the runs exist: recompute their tiles right away, beside the bulk (forward on
 		// the walk stream, backward on the transfer-matrix stream), so that the counts find them finished.
-		hipStream_t sk = ov ? p.stream5 : sm;
 		if (lf) launch_fwd_struct(p, sw, 3, 0, p.n_mem_f);
 		(void)hipEventRecord(p.evx[7], sw);
 		if (ov) (void)hipStreamWaitEvent(sk, p.fused ? p.evx[7] : p.evx[6], 0); // fused: the backward pass reads the run tiles' X
@@ -629,30 +639,25 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (lb && !p.fused) launch_bwd_struct(p, sk, 3, 0, p.n_mem_b);
 		if (p.fused != 2) (void)hipEventRecord(p.evx[9], sk);
 	}
-	const int ff0 = lf ? p.n_long_f : 0, fb0 = lb ? p.n_long_b : 0;
-	const bool one = p.structured && !p.fused; // both bulk sweeps in one launch (k_sweep_struct)
-	if (one) {
+	const bool one = p.structured && !p.fused; // both bulk sweeps in one launch (k_sweep_struct), tables of both directions
+	if (mg) {
+		// launched above
+	} else if (one) {
 		if (p.ev[7]) (void)hipEventRecord(p.ev[7], sm);
-		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0);
+		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0, false);
 		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sm);
-	} else if (p.structured) launch_fwd_struct(p, sm, 0, ff0, p.n_items_f - ff0 - p.n_B_f);
+	} else if (p.structured) launch_fwd_struct(p, sm, 0, ff0, p.n_items_f - ff0);
 	else launch_fwd<false>(p, sm);
-	(void)hipEventRecord(p.evx[1], sm);
-	if (p.n_B_f > 0) { // two-phase plan: the odd tiles, each from the X_{lo-1} its neighbour (phase A or a run tile) stored
-		if (lw && ov) (void)hipStreamWaitEvent(sm, p.evx[7], 0);
-		launch_fwd_struct(p, sm, 6, p.n_items_f - p.n_B_f, p.n_B_f);
-		(void)hipEventRecord(p.evx[10], sm);
-	}
+	if (!mg) (void)hipEventRecord(p.evx[1], sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	if (lw && p.fused == 2) {
 		// Factored statistics of the tiles of backward runs, beside the bulk pass on a stream of their own.  They read the
-		// tiles' X and scale factors, which the bulk forward sweep (or its phase B) writes unless the tile is also part
-		// of a forward run.  (Until round 2 this launch followed the run tiles only: it could read a bulk tile's X of the
-		// PREVIOUS E-step; with the same parameters that is the same direction, and the per-position normaliser of the
-		// old kernels hid the rest.  Found when the forward scale factors became part of the backward recursion.)
-		hipStream_t sk = ov ? p.stream5 : sm;
+		// tiles' X and scale factors, which the bulk forward sweep writes unless the tile is also part of a forward run.
+		// (Until round 2 this launch followed the run tiles only: it could read a bulk tile's X of the PREVIOUS E-step; with
+		// the same parameters that is the same direction, and the per-position normaliser of the old kernels hid the rest.
+		// Found when the forward scale factors became part of the backward recursion.)
 		if (lb) {
-			if (ov) { (void)hipStreamWaitEvent(sk, p.evx[1], 0); if (p.n_B_f > 0) (void)hipStreamWaitEvent(sk, p.evx[10], 0); }
+			if (ov) (void)hipStreamWaitEvent(sk, p.evx[1], 0);
 			launch_bwd_acc(p, sk, 3, 0, p.n_mem_b);
 		}
 		(void)hipEventRecord(p.evx[9], sk);
@@ -661,29 +666,19 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (!one && p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
 	if (p.fused) {
 		// Fused backward + counts (estep_fused.hip): a warm-up-only pass of the 4-tiles-per-wave sweep leaves
-		// every bulk tile's start vector (beside the forward sweep, which is HBM-bound and leaves the VALUs
-		// idle); then one wave per tile walks it backwards and feeds the matrix cores.  bt never reaches HBM.
-		const int nb0 = lb ? p.n_long_b : 0;
-		launch_bwd_struct(p, sa, 4, nb0, p.n_items_b - nb0 - p.n_B_b);
-		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles (phase A)
-		if (p.fused == 2) {
-			// X (and the start vectors) of the tiles of forward runs: they are recomputed on the walk stream after the
-			// walks / chains, and a tile of a forward run is an ordinary single tile of THIS pass.  (Missing until round 2:
-			// the pass could read such a tile's X before it was written; found with PSMC_HIP_POISON=vary.)
-			if (lw && ov) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
-			if (p.n_B_f > 0 && ov) (void)hipStreamWaitEvent(sa, p.evx[10], 0); // X of the phase-B tiles
-			if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
-			launch_bwd_acc(p, sa, 0, nb0, p.n_items_b - nb0);
-		} else {
-			if (lw && ov) (void)hipStreamWaitEvent(sa, p.evx[7], 0); // boundary vectors and X of the run tiles
-			// list A could start beside the forward sweep of phase B; both are bound by FP64 issue, so side by side
-			// each just takes longer (4.9 + 3.6 ms against 1.0 + 3.5 + 3.5 one after the other)
-			if (p.n_B_f > 0 && ov && p.fuse_order == 0) (void)hipStreamWaitEvent(sa, p.evx[10], 0);
-			if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
+		// every bulk tile's start vector (beside the forward sweep, or in its grid); then one wave per group of four
+		// tiles walks them backwards and feeds the matrix cores.  bt never reaches HBM.
+		if (!mg) launch_bwd_struct(p, sa, 4, fb0, p.n_items_b - fb0 - p.n_B_b);
+		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles; merged: and the start vectors of the same grid
+		// boundary vectors and X of the run tiles (fused == 2, missing until round 2: a tile of a forward run is an ordinary
+		// single tile of the bulk pass below, which could read its X before it was written; found with PSMC_HIP_POISON=vary)
+		if (lw && ov && sw != sa) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
+		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
+		if (p.fused == 2) launch_bwd_acc(p, sa, 0, fb0, p.n_items_b - fb0);
+		else {
 			launch_bwd_count(p, sa, 0, false);
 			if (p.n_list_b > 0) { // its tiles start from the exit vectors list A left
 				(void)hipEventRecord(p.evx[11], sa);
-				if (p.n_B_f > 0 && ov) (void)hipStreamWaitEvent(sa, p.evx[10], 0);
 				(void)hipEventRecord(p.evx[12], sa);
 				launch_bwd_count(p, sa, 1, false);
 			}
@@ -723,18 +718,46 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		c.pending = true;
 		return 0;
 	};
-	if (lw && ov) { (void)hipStreamWaitEvent(sm, p.evx[7], 0); (void)hipStreamWaitEvent(sa, p.evx[9], 0); } // run tiles done
-	// the log-likelihood needs the forward tables only: it is launched the moment the forward chain has converged, beside
-	// the back half, instead of in the tail of the E-step
-	bool ll_done = false;
-	auto launch_ll = [&]() {
-		if (ll_done) return;
-		ll_done = true;
+	if (lw && ov) { if (sw != sm) (void)hipStreamWaitEvent(sm, p.evx[7], 0); (void)hipStreamWaitEvent(sa, p.evx[9], 0); } // run tiles done
+	auto launch_ll = [&]() { // the log-likelihood needs the forward tables only
 		if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
 		else hipLaunchKernelGGL(k_ll<64>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
 		PSMC_DBG("k_ll", p.n_chunks, 0, 0);
 	};
+	auto launch_reduce = [&]() {
+		const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_list_a + 3) / 4 + (p.n_list_b + 3) / 4 : nS; // fused: one C partial per group of four tiles
+		if (p.fused == 2) {
+			launch_reduce_factored(p, sm);
+		} else if (p.ns == 128) {
+			hipLaunchKernelGGL(k_reduce1<128>, dim3(128 * 128 / 256 + 1, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, nS, p.d_LLpart,
+			                   p.n_chunks, p.d_stage);
+			hipLaunchKernelGGL(k_reduce2<128>, dim3((128 * 128 + 3 * 128 + 1 + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
+			                   p.tiny_total, p.n_states, p.d_stats);
+		} else {
+			hipLaunchKernelGGL(k_reduce1<64>, dim3(17, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, nS, p.d_LLpart,
+			                   p.n_chunks, p.d_stage);
+			hipLaunchKernelGGL(k_reduce2<64>, dim3((STATS_LEN + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
+			                   p.tiny_total, p.n_states, p.d_stats);
+		}
+		if (p.ev[4]) (void)hipEventRecord(p.ev[4], sm);
+	};
 	if (post_verify(ch[0]) || post_verify(ch[1])) return -1;
+	// OPTIMISTIC TAIL (round 3): after the first E-step of a context the speculation almost never fails (the plan has learned
+	// where it does), so the log-likelihood and the reductions are enqueued NOW, behind the two verify kernels, instead of
+	// after the host has read both flagged-tile counts -- two host round trips (~0.1 ms) leave the critical path.  If a
+	// verify does flag tiles, the repair rounds run as before and the tail is simply enqueued again: it overwrites
+	// d_LLpart, the stage buffer and d_stats from the repaired tables.  (With the fused / factored back half only: the
+	// unfused one takes its counts in a separate pass that has its own dependencies.)
+	const bool optimistic = p.fused != 0 && ov;
+	if (optimistic) {
+		launch_ll();
+		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // back half + backward verify done
+		if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
+		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
+		if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
+		launch_reduce();
+	}
+	bool ll_stale = !optimistic;
 	while (!(ch[0].done && ch[1].done)) {
 		bool progressed = false;
 		for (int d = 0; d < 2; ++d) {
@@ -745,15 +768,15 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 			if (q != hipSuccess) return -1;
 			c.pending = false; progressed = true;
 			const int nd = p.h_cnt[c.slot];
-			if (nd == 0) { c.done = true; if (!c.bwd) launch_ll(); continue; }
-			if (c.round >= p.max_rounds) { rep->converged = 0; c.done = true; if (!c.bwd) launch_ll(); continue; }
+			if (nd == 0) { c.done = true; continue; }
+			if (c.round >= p.max_rounds) { rep->converged = 0; c.done = true; continue; }
 			++c.round;
 			if (p.structured) {
 				std::vector<int> *fl = c.bwd ? p.flagged_b : p.flagged_f;
 				if (fl) for (int i = 0; i < nd; ++i) fl->push_back(p.h_ritems[(size_t)c.slot * 2 * p.n_chunks + 2 * i]);
 			}
 			if (!c.bwd) {
-				rep->fwd_rounds++; rep->fwd_tiles += nd;
+				rep->fwd_rounds++; rep->fwd_tiles += nd; ll_stale = true;
 				if (p.structured) launch_fwd_struct(p, c.st, 1, 0, nd); else launch_fwd<true>(p, c.st);
 			} else {
 				rep->bwd_rounds++; rep->bwd_tiles += nd;
@@ -766,22 +789,24 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		}
 		if (!progressed) __builtin_ia32_pause();
 	}
+	const bool repaired = rep->fwd_rounds + rep->bwd_rounds > 0;
+	if (optimistic && !repaired) return (int)hipGetLastError(); // the tail is already in flight
 	if (hipStreamSynchronize(sm) != hipSuccess) return -1;
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
-	// ---- counts from the final tables (the log-likelihood was launched when the forward chain converged)
-	launch_ll();
+	// ---- counts from the final tables
+	if (ll_stale) launch_ll();
 	if (p.fused) {
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 		// tiles whose X a forward repair rewrote after their counts were taken (only repairs set the touch flags)
-		if (rep->fwd_rounds + rep->bwd_rounds > 0) {
+		if (repaired) {
 			if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else { launch_bwd_count(p, sm, 0, true); launch_bwd_count(p, sm, 1, true); }
 		}
 	} else if (ov) {
 		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // backward chain done
 		(void)hipStreamWaitEvent(sm, p.evx[3], 0);                                     // early expect done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
-		if (rep->fwd_rounds + rep->bwd_rounds > 0) launch_expect(p, sm, 1); // only tiles a repair rewrote
+		if (repaired) launch_expect(p, sm, 1); // only tiles a repair rewrote
 	} else {
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sm);
@@ -789,8 +814,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sm);
 	}
 	if (p.fused == 1 && getenv("PSMC_HIP_DEBUG_RECHECK")) {
-		// diagnostic: recompute EVERY group from the final tables and start vectors and name the groups whose partial differs
-		// from what the protocol (first pass + redo of the touched groups) left
+		// diagnostic: recompute EVERY group from the final tables, every tile from its own start vector, and name the groups
+		// whose partial differs from what the protocol (first pass + redo of the touched groups) left
 		const int ga = (p.n_list_a + 3) / 4, gb = (p.n_list_b + 3) / 4, ng = ga + gb;
 		const size_t gs = (size_t)p.ns * p.ns;
 		std::vector<double> c0(gs * ng), c1(gs * ng);
@@ -798,10 +823,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		std::vector<Chunk> ch(p.n_chunks);
 		(void)hipDeviceSynchronize();
 		(void)hipMemcpy(c0.data(), p.d_Cpart, sizeof(double) * c0.size(), hipMemcpyDeviceToHost);
-		{ // the reference: round 1's kernel (own normaliser per position), every tile from its bentry
-			EstepLaunch q = p; q.count_impl = 0;
-			launch_bwd_count(q, sm, 0, false, true); launch_bwd_count(q, sm, 1, false, true);
-		}
+		launch_bwd_count(p, sm, 0, false, true); launch_bwd_count(p, sm, 1, false, true);
 		(void)hipDeviceSynchronize();
 		(void)hipMemcpy(c1.data(), p.d_Cpart, sizeof(double) * c1.size(), hipMemcpyDeviceToHost);
 		(void)hipMemcpy(tl.data(), p.d_ftiles, sizeof(int) * tl.size(), hipMemcpyDeviceToHost);
@@ -825,21 +847,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		}
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
-	const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_list_a + 3) / 4 + (p.n_list_b + 3) / 4 : nS; // fused: one C partial per group of four tiles
-	if (p.fused == 2) {
-		launch_reduce_factored(p, sm);
-	} else if (p.ns == 128) {
-		hipLaunchKernelGGL(k_reduce1<128>, dim3(128 * 128 / 256 + 1, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, nS, p.d_LLpart,
-		                   p.n_chunks, p.d_stage);
-		hipLaunchKernelGGL(k_reduce2<128>, dim3((128 * 128 + 3 * 128 + 1 + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
-		                   p.tiny_total, p.n_states, p.d_stats);
-	} else {
-		hipLaunchKernelGGL(k_reduce1<64>, dim3(17, RED_ROWS), dim3(256), 0, sm, p.d_Cpart, p.d_Epart, nC, nS, p.d_LLpart,
-		                   p.n_chunks, p.d_stage);
-		hipLaunchKernelGGL(k_reduce2<64>, dim3((STATS_LEN + 255) / 256), dim3(256), 0, sm, p.d_stage, p.d_a, p.d_e,
-		                   p.tiny_total, p.n_states, p.d_stats);
-	}
-	if (p.ev[4]) (void)hipEventRecord(p.ev[4], sm);
+	launch_reduce();
 	return (int)hipGetLastError();
 }
 

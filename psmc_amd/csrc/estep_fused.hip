@@ -41,198 +41,11 @@ __device__ __forceinline__ int64_t readlane_i64f(int64_t v, int lane) {
 	return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
 
-// One position of every row: x = bt_{p+1} on entry, bt_p on exit; X = X_p.  NORM: p % NORM_EVERY == 0.
-// MASKED: rows with !active contribute nothing and keep their x (no divergent branch: the matrix
-// instructions run with all lanes enabled).
-template <bool NORM, bool MASKED>
-__device__ __forceinline__ void count4_step(const StructParN<NPLF> &sc, const double *lds_e, const double *lds_re, int k0, int sym,
-                                            const double (&X)[NPLF], double (&x)[NPLF], bool active, double mult,
-                                            d4f_t (&acc)[4][4], double (&S)[2][NPLF])
-{
-	double ev[NPLF], rv[NPLF];
-	loadN<NPLF>(lds_e + sym * SF + k0, ev);
-	loadN<NPLF>(lds_re + sym * SF + k0, rv);
-	double sbv = 1.0;
-	if (NORM) { // sb_p = 1/sum(bt_{p+1})
-		sbv = rcp_newton(row_sum16((x[0] + x[1]) + (x[2] + x[3])));
-#pragma unroll
-		for (int i = 0; i < NPLF; ++i) ev[i] *= sbv;
-	}
-	double bt[NPLF], gk[NPLF], G = 0.0;
-#pragma unroll
-	for (int i = 0; i < NPLF; ++i) bt[i] = x[i];
-	struct_step<NPLF>(sc, bt);
-#pragma unroll
-	for (int i = 0; i < NPLF; ++i) {
-		bt[i] *= ev[i];
-		gk[i] = X[i] * bt[i] * rv[i];
-		if (MASKED) gk[i] = active ? gk[i] : 0.0; // an idle row may hold anything
-		G += gk[i];
-	}
-	const double iG = rcp_newton(row_sum16(G));
-	double h = iG * mult, wgt = sbv * h;
-	if (MASKED) { h = active ? h : 0.0; wgt = active ? wgt : 0.0; }
-	const double h0 = sym == 0 ? h : 0.0, h1 = sym == 1 ? h : 0.0;
-	double FA[NPLF], FB[NPLF];
-#pragma unroll
-	for (int i = 0; i < NPLF; ++i) {
-		S[0][i] = __builtin_fma(gk[i], h0, S[0][i]);
-		S[1][i] = __builtin_fma(gk[i], h1, S[1][i]);
-		FA[i] = MASKED ? (active ? wgt * X[i] : 0.0) : wgt * X[i];
-		FB[i] = MASKED ? (active ? x[i] : 0.0) : x[i];
-		x[i] = MASKED ? (active ? bt[i] : x[i]) : bt[i];
-	}
-	// The accumulators are pinned to the accumulation registers ("+a"): left to the register allocator they
-	// migrate between VGPRs and AGPRs on every loop iteration (250 v_accvgpr moves per four steps).
-#pragma unroll
-	for (int j = 0; j < 4; ++j)
-#pragma unroll
-		for (int j2 = 0; j2 < 4; ++j2)
-#ifdef PSMC_MFMA_ASM
-			asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[j][j2]) : "v"(FA[j]), "v"(FB[j2]));
-#else
-			acc[j][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[j2], acc[j][j2], 0, 0, 0);
-#endif
-}
-
-// Group g = the tiles tiles[4g .. 4g+3] (-1: none), each from its start vector bentry (left by the warm-up-only pass
-// of k_bwd_struct, by a walk / transfer-matrix chain, or by a boundary-only repair) or, with bit 30 set in the list
-// entry and mode 0, from the exit vector of the tile above it (two-phase plan: that tile belongs to the list that
-// ran before; the vector becomes this tile's bentry).  mode 0: every group;  mode 2: only groups holding a tile
-// whose X (touch_f) or start vector (touch_b) changed after the first pass, every tile from its bentry.
-__global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__restrict__ sp, const double *__restrict__ e,
-                                                               const double *__restrict__ re, const uint8_t *__restrict__ obs,
-                                                               const Chunk *__restrict__ chunks, const int *__restrict__ tiles,
-                                                               int group0, int mode, const double *__restrict__ f,
-                                                               double *__restrict__ bentry, double *__restrict__ bexit,
-                                                               double *__restrict__ Cpart,
-                                                               double *__restrict__ Epart, const int *__restrict__ touch_f,
-                                                               const int *__restrict__ touch_b)
-{
-	__shared__ double lds_e[4 * SF], lds_re[4 * SF]; // e / 1/e rows: hom, het, 1, 1
-	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLF * m;
-	lds_e[lane] = e[lane]; lds_e[SF + lane] = e[SF + lane]; lds_e[2 * SF + lane] = 1.0; lds_e[3 * SF + lane] = 1.0;
-	lds_re[lane] = re[lane]; lds_re[SF + lane] = re[SF + lane]; lds_re[2 * SF + lane] = 1.0; lds_re[3 * SF + lane] = 1.0;
-	__syncthreads();
-	const int group = group0 + blockIdx.x;
-	const int entry = tiles[4 * blockIdx.x + row];
-	const bool valid = entry >= 0, from_above = valid && mode == 0 && (entry & (1 << 30)) != 0;
-	const int tile = valid ? (entry & ~(1 << 30)) : 0;
-	if (mode == 2 && !__any(valid && (touch_f[tile] | touch_b[tile]) != 0)) return;
-	const Chunk c = chunks[tile];
-	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
-	const bool work = valid && top >= lo; // a tile holding only position L owns no transition
-	const double *fo = f + c.off * SF + k0;
-	const double mult = (double)c.mult;
-	StructParN<NPLF> sc; // backward: mS = c, wS = R, mP = qa, wP = P
-	loadN<NPLF>(sp + 3 * SF + k0, sc.mS); loadN<NPLF>(sp + SF + k0, sc.wS);
-	loadN<NPLF>(sp + 2 * SF + k0, sc.mP); loadN<NPLF>(sp + k0, sc.wP); loadN<NPLF>(sp + 4 * SF + k0, sc.dd);
-	double x[NPLF];
-	loadN<NPLF>((from_above ? bexit + (int64_t)(tile + 1) * SF : bentry + (int64_t)tile * SF) + k0, x);
-	if (from_above) storeN<NPLF>(bentry + (int64_t)tile * SF + k0, x); // what verify compares and a redo starts from
-	d4f_t acc[4][4];
-	double S[2][NPLF];
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-#pragma unroll
-		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0};
-		S[0][j] = S[1][j] = 0.0;
-	}
-	// groups of four positions 4g+1 .. 4g+4 (indices 4g .. 4g+3), highest first; the group's last
-	// position (p % 4 == 0) carries the scale factor
-	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
-	const int ng = g_hi - g_lo + 1;
-	const int64_t off0 = readlane_i64f(c.off, 0), off1 = readlane_i64f(c.off, 16), off2 = readlane_i64f(c.off, 32), off3 = readlane_i64f(c.off, 48);
-	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
-	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
-	const int ng_max = max(max(n0, n1), max(n2, n3));
-	const int p_min = lo, p_max = max(top, lo);
-	auto load_row = [&](int g, int j, double (&Xq)[NPLF]) { // X of position 4g + j + 1, clamped into the tile
-		const int p = min(max(4 * g + j + 1, p_min), p_max);
-		loadN<NPLF>(fo + (int64_t)(p - 1) * SF, Xq);
-	};
-	// X of the current group; every row is reloaded for the next group as soon as its step has used it
-	// (a second buffer would push the kernel past 256 VGPRs, and spills go through the AGPRs the counts live in)
-	double Xg[4][NPLF];
-#pragma unroll
-	for (int j = 0; j < 4; ++j) load_row(max(g_hi, 0), j, Xg[j]);
-	// One group of four positions of every row.  Three loops instead of one loop with two paths: with both paths
-	// in one loop body the register allocator moves the 128 accumulation registers back and forth on every
-	// iteration.  `full` groups (every row has all four positions inside its tile) need no masks.
-	int gi = 0;
-	// the four symbols of group number gi_ of every row: scalar loads (see estep_struct.hip row_symbols), all four
-	// issued before the per-row select (left alone the compiler branches per row and waits for each load in turn);
-	// fetched one group ahead
-	// With one wave per SIMD nothing hides a scalar-load round trip, and hipcc sinks a plain load to its use: the
-	// four s_load_dword are written out and waited for by hand a whole group later (outstanding scalar loads only make
-	// the compiler's own lgkmcnt waits for its in-order LDS reads longer, never shorter).
-	struct Words { unsigned w0, w1, w2, w3; };
-	auto load_words = [&](int gi_) {
-		Words q;
-		const uint8_t *p0 = obs + off0 + 4 * (int64_t)max(gh0 - min(gi_, max(n0 - 1, 0)), 0);
-		const uint8_t *p1 = obs + off1 + 4 * (int64_t)max(gh1 - min(gi_, max(n1 - 1, 0)), 0);
-		const uint8_t *p2 = obs + off2 + 4 * (int64_t)max(gh2 - min(gi_, max(n2 - 1, 0)), 0);
-		const uint8_t *p3 = obs + off3 + 4 * (int64_t)max(gh3 - min(gi_, max(n3 - 1, 0)), 0);
-		asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0"
-		             : "=&s"(q.w0), "=&s"(q.w1), "=&s"(q.w2), "=&s"(q.w3) : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
-		return q;
-	};
-	auto select_word = [&](Words q) {
-		asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.w0), "+s"(q.w1), "+s"(q.w2), "+s"(q.w3));
-		return row == 0 ? q.w0 : (row == 1 ? q.w1 : (row == 2 ? q.w2 : q.w3));
-	};
-	unsigned w_cur = select_word(load_words(0));
-	auto all_full = [&](int gi_) {
-		const int g = max(g_hi - gi_, g_lo);
-		return __all(gi_ < ng && 4 * g + 1 >= lo && 4 * g + 4 <= top) != 0;
-	};
-	auto do_group = [&](auto masked_tag) {
-		constexpr bool MASKED = decltype(masked_tag)::value;
-		const unsigned w = w_cur;
-		const Words wn = load_words(gi + 1); // issued now (the scheduling barriers between the steps keep it here), selected after the four steps
-		__builtin_amdgcn_sched_barrier(0);
-		const int g = max(g_hi - gi, g_lo); // rows that are done idle on their last group
-		const bool in_tile = gi < ng;
-		const int s3 = (int)((w >> 24) & 3u), s2 = (int)((w >> 16) & 3u), s1 = (int)((w >> 8) & 3u), s0 = (int)(w & 3u);
-		const int pb = 4 * g + 1;
-#define PSMC_C4(NORM, J, SYM)                                                                                                   \
-		count4_step<NORM, MASKED>(sc, lds_e, lds_re, k0, SYM, Xg[J], x, in_tile && pb + J <= top && pb + J >= lo, mult, acc, S); \
-		load_row(g - 1, J, Xg[J]);                                                                                          \
-		PSMC_SB
-		PSMC_C4(true, 3, s3) PSMC_C4(false, 2, s2) PSMC_C4(false, 1, s1) PSMC_C4(false, 0, s0)
-#undef PSMC_C4
-		if (in_tile && g == g_lo) storeN<NPLF>(bexit + (int64_t)tile * SF + k0, x); // x = bt_lo: the group holding lo is the row's last
-		w_cur = select_word(wn);
-	};
-	for (; gi < ng_max && !all_full(gi); ++gi) do_group(std::true_type{});  // a top that is not a multiple of 4
-	for (; gi < ng_max && all_full(gi); ++gi) do_group(std::false_type{});
-	for (; gi < ng_max; ++gi) do_group(std::true_type{});                    // rows of unequal length, a lo that is not 1 mod 4
-	// the matrix-core results are not interlocked against plain reads: let the last instructions drain
-	asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
-	             : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
-	               "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
-	               "+a"(acc[3][2]), "+a"(acc[3][3]));
-	// C[4 M + j][4 N + j2], M = row + 4 r, N = m: four adjacent columns per lane
-	double *out = Cpart + (int64_t)group * (SF * SF);
-#pragma unroll
-	for (int j = 0; j < 4; ++j)
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const double v[NPLF] = {acc[j][0][r], acc[j][1][r], acc[j][2][r], acc[j][3][r]};
-			storeN<NPLF>(out + (4 * (row + 4 * r) + j) * SF + k0, v);
-		}
-	if (valid) {
-		double *os = Epart + (int64_t)tile * (3 * SF) + k0;
-		const double zero[NPLF] = {0.0, 0.0, 0.0, 0.0};
-		storeN<NPLF>(os, S[0]); storeN<NPLF>(os + SF, S[1]); storeN<NPLF>(os + 2 * SF, zero); // missing symbols are not counted (khmm.c:355)
-	}
-}
-
-// ---- round 2: the same kernel without a per-position normaliser, and with the matrix instructions of a step issued
-// between the vector instructions of the NEXT step.
+// ---- The posterior weight without a normaliser per position (round 2).
 //
-// (1) Scaling.  k_bwd_count4_struct needs G_p = sum_k g_p[k] at every position to turn X_p (x) bt_{p+1} into a posterior:
-// a 16-lane reduction, a reciprocal and 13 multiplications per step.  But with y_p = a bt_{p+1} the normaliser
+// Round 1's kernel computed G_p = sum_k g_p[k] at every position to turn X_p (x) bt_{p+1} into a posterior: a 16-lane
+// reduction, a reciprocal and 13 multiplications per step (removed in round 3; 6.97 vs 6.2 ms per E-step's back half).
+// But with y_p = a bt_{p+1} the normaliser
 // I_p = sum_k X_p[k] y_p[k] is not a new number at every position: between two normalising positions it is constant (an
 // algebraic identity of the forward and the backward recursion), and across one it changes by a known factor,
 // I_{p-1} = I_p sb_p / inv_p (sb_p = 1/sum(bt_{p+1}): bt's own scale factor; inv_p: the forward sweep's, from the d_s table).
@@ -246,12 +59,9 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4_struct(const double *__res
 // scale factors, the exit vector came out bent instead of merely rescaled, and the repair of the tile below adopted it:
 // 1 E-step in 1 500 off by up to 3e-2 in a stress of tiny tiles (scripts/dbg_flaky_tiling.py), caught first as a flaky
 // test_fast_odd_tilings.  The vectors that travel between tiles must depend on the observations and the parameters only.
-// (2) Issue order.  With one wave per SIMD a step is a chain of dependent vector instructions (row scans: v_add_f64 ->
-// v_mov_b32_dpp -> v_add_f64 ...) whose latencies nothing hides, followed by 16 matrix instructions that occupy the
-// FP64 pipe for 64 cycles each while the wave has nothing else to issue: 1 950 cycles for 1 548 busy.  Here the
-// matrix instructions of step p are held back (their operands FA / FB stay in registers) and interleaved, one after
-// every few vector instructions, with step p-1's sweep: the dependent instruction behind each of them issues when the
-// pipe comes free, long after its operand is ready.
+// Tried on top of this and removed: issuing the matrix instructions of step p between the vector instructions of step
+// p-1 (sched_group_barrier pattern, operands held for a step) -- slower, 6.49 vs 6.22 ms: the dependent chains of the scans
+// were never the problem (the compiler already fills them), the instruction count is.
 template <bool NORM, bool MASKED>
 __device__ __forceinline__ void count4f_step(const StructParN<NPLF> &sc, const double *lds_e, const double *lds_m, int k0, int sym,
                                              const double (&X)[NPLF], double (&x)[NPLF], bool active, double inv, double &rho,
@@ -292,17 +102,6 @@ __device__ __forceinline__ void count4f_mfma(const double (&FA)[NPLF], const dou
 #pragma unroll
 		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[j2], acc[j][j2], 0, 0, 0);
 }
-// one matrix instruction, then VPM vector instructions, 16 times: the order the scheduler is asked for inside a step
-template <int VPM> __device__ __forceinline__ void count4f_order()
-{
-#pragma unroll
-	for (int k = 0; k < 16; ++k) {
-		__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-		__builtin_amdgcn_sched_group_barrier(0x002, VPM, 0); // VALU
-	}
-}
-
-template <bool PIPE>
 __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                                 const double *__restrict__ invd, const uint8_t *__restrict__ obs,
                                                                 const Chunk *__restrict__ chunks, const int *__restrict__ tiles,
@@ -345,12 +144,12 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 		rho = work ? (double)c.mult * rcp_newton(I) : 0.0;
 	}
 	d4f_t acc[4][4];
-	double S[2][NPLF], FAp[NPLF], FBp[NPLF];
+	double S[2][NPLF];
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
 #pragma unroll
 		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0};
-		S[0][j] = S[1][j] = 0.0; FAp[j] = FBp[j] = 0.0;
+		S[0][j] = S[1][j] = 0.0;
 	}
 	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
 	const int ng = g_hi - g_lo + 1;
@@ -371,7 +170,7 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 	double inv_cur = load_inv(max(g_hi, 0));
 	int gi = 0;
 	struct Words { unsigned w0, w1, w2, w3; };
-	auto load_words = [&](int gi_) { // see k_bwd_count4_struct
+	auto load_words = [&](int gi_) { // the four rows' symbol words of group gi_ as scalar loads (wave-uniform addresses), issued one group ahead
 		Words q;
 		const uint8_t *p0 = obs + off0 + 4 * (int64_t)max(gh0 - min(gi_, max(n0 - 1, 0)), 0);
 		const uint8_t *p1 = obs + off1 + 4 * (int64_t)max(gh1 - min(gi_, max(n1 - 1, 0)), 0);
@@ -403,8 +202,7 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 		double FAn[NPLF], FBn[NPLF];
 #define PSMC_C4F(NORM, J, SYM)                                                                                                   \
 		count4f_step<NORM, MASKED>(sc, lds_e, lds_m, k0, SYM, Xg[J], x, in_tile && pb + J <= top && pb + J >= lo, inv, rho, FAn, FBn, S); \
-		if (PIPE) { count4f_mfma(FAp, FBp, acc); count4f_order<5>(); } else count4f_mfma(FAn, FBn, acc);                   \
-		_Pragma("unroll") for (int i = 0; i < NPLF; ++i) { FAp[i] = FAn[i]; FBp[i] = FBn[i]; }                               \
+		count4f_mfma(FAn, FBn, acc);                                                                                        \
 		load_row(g - 1, J, Xg[J]);                                                                                          \
 		if (J == 3) inv_cur = load_inv(g - 1);                                                                              \
 		__builtin_amdgcn_sched_barrier(0);
@@ -416,7 +214,6 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 	for (; gi < ng_max && !all_full(gi); ++gi) do_group(std::true_type{});  // a top that is not a multiple of 4
 	for (; gi < ng_max && all_full(gi); ++gi) do_group(std::false_type{});
 	for (; gi < ng_max; ++gi) do_group(std::true_type{});                    // rows of unequal length, a lo that is not 1 mod 4
-	if (PIPE) count4f_mfma(FAp, FBp, acc); // the last step's
 	// the matrix-core results are not interlocked against plain reads: let the last instructions drain
 	asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
 	             : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
@@ -627,15 +424,8 @@ void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo,
 		PSMC_DBG("launch_bwd_count (128 states)", list, redo, n_groups);
 		return;
 	}
-	if (p.count_impl == 2)
-		hipLaunchKernelGGL(k_bwd_count4f_struct<true>, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
-		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
-	else if (p.count_impl == 1)
-		hipLaunchKernelGGL(k_bwd_count4f_struct<false>, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
-		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
-	else
-		hipLaunchKernelGGL(k_bwd_count4_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_re, p.d_obs, p.d_chunks, tl, g0, md,
-		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+	hipLaunchKernelGGL(k_bwd_count4f_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
+	                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
 	PSMC_DBG("launch_bwd_count", list, redo, n_groups);
 }
 

@@ -54,27 +54,8 @@ __device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, co
 	v.w = row == 0 ? s0.w : (row == 1 ? s1.w : (row == 2 ? s2.w : s3.w));
 	return v;
 }
-// eight rows (8 lanes per tile)
-__device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, const int64_t (&roff)[8], const int (&bb)[8],
-                                             int row)
-{
-	uint4 v = *reinterpret_cast<const uint4 *>(obs + roff[0] + ((int64_t)bb[0] << 4));
-#pragma unroll
-	for (int r = 1; r < 8; ++r) {
-		const uint4 s = *reinterpret_cast<const uint4 *>(obs + roff[r] + ((int64_t)bb[r] << 4));
-		v.x = row == r ? s.x : v.x; v.y = row == r ? s.y : v.y; v.z = row == r ? s.z : v.z; v.w = row == r ? s.w : v.w;
-	}
-	return v;
-}
-// Tile geometry of a sweep wave: LPT lanes per tile (16: four tiles per wave, a tile is a DPP row; 8: eight tiles per
-// wave, 8 lanes x 8 states -- 64 states only; the cross-lane part of a scan is a level shorter and shared by twice
-// as many states, see struct_prims.h), NPL adjacent states per lane.
-template <int NPL, int LPT> __device__ __forceinline__ void tile_step(const StructParN<NPL> &c, double (&x)[NPL], const Half8Masks &hm) {
-	if constexpr (LPT == 8) struct_step_h8(c, x, hm); else struct_step<NPL>(c, x);
-}
-
-template <int NPL, int LPT = 16> __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructParN<NPL> &c) {
-	constexpr int S = LPT * NPL; // sp = P | R | qa | c | dd, S each
+template <int NPL> __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructParN<NPL> &c) {
+	constexpr int S = 16 * NPL; // sp = P | R | qa | c | dd, S each
 	loadN<NPL>(sp + (fwd ? 0 : 3 * S) + k0, c.mS);  // forward: P,  backward: c
 	loadN<NPL>(sp + (fwd ? 2 * S : S) + k0, c.wS);  // forward: qa, backward: R
 	loadN<NPL>(sp + (fwd ? S : 2 * S) + k0, c.mP);  // forward: R,  backward: qa
@@ -87,9 +68,7 @@ template <int NPL> __device__ __forceinline__ double lane_sum(const double (&x)[
 	return t;
 }
 // sum over the states of the lane's tile, identical in all of its lanes
-template <int NPL, int LPT> __device__ __forceinline__ double tile_sum(const double (&x)[NPL]) {
-	if constexpr (LPT == 8) return half8_sum(lane_sum<NPL>(x)); else return row_sum16(lane_sum<NPL>(x));
-}
+template <int NPL> __device__ __forceinline__ double tile_sum(const double (&x)[NPL]) { return row_sum16(lane_sum<NPL>(x)); }
 // e[0] | e[1] | 1 | 1 (rows of S) for the per-symbol emission fetch
 template <int S> __device__ __forceinline__ void fill_lds_e(double *lds_e, const double *__restrict__ e, int lane) {
 #pragma unroll
@@ -115,8 +94,8 @@ struct FwdCursor { int next_lo, tile; };
 
 // MODE 0: per-step range / store / boundary predicates;  MODE 1: all 16 positions are computed and
 // stored and no tile starts inside the block;  MODE 2: warm-up, nothing stored.
-template <int MODE, int J, int NPL, int LPT, bool CK>
-__device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, unsigned w, int base,
+template <int MODE, int J, int NPL, bool CK>
+__device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                          double *fo, double *io, double *entry, int g, double &inv_keep)
 {
@@ -126,7 +105,7 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Ma
 	// lo0 = first position whose X is stored (INT_MAX for a walk, which only leaves the boundary vectors)
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p >= p_first && p <= p_last)) return;
-	constexpr int S = LPT * NPL;
+	constexpr int S = 16 * NPL;
 	if (MODE == 0 && p == cur.next_lo) { // the X_{lo-1} this tile builds on
 		storeN<NPL>(entry + (int64_t)cur.tile * S + k0, x);
 		cur.tile += 1; cur.next_lo += T;
@@ -134,20 +113,20 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Ma
 	double ev[NPL];
 	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
 	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}) rounded down to a power of two, off the critical path
-		const double inv = pow2_rcp(tile_sum<NPL, LPT>(x));
+		const double inv = pow2_rcp(tile_sum<NPL>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= inv;
 		if (MODE == 1) inv_keep = m == g ? inv : inv_keep; // one 32-byte store per tile and block instead of four 8-byte ones
 		else if (MODE == 0 && p >= lo0 && m == 0) io[idx] = inv;
 	}
-	tile_step<NPL, LPT>(c, x, hm);
+	struct_step<NPL>(c, x);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 	if (MODE == 1) { if (!CK || (J == 3 && (g & 1))) storeN<NPL>(fo + (int64_t)idx * S, x); }
 	else if (MODE == 0 && p >= lo0 && (!CK || (p & 7) == 0 || p == p_last)) storeN<NPL>(fo + (int64_t)idx * S, x);
 }
-template <int MODE, int NPL, int LPT, bool CK>
-__device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int NPL, bool CK>
+__device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                           double *fo, double *io, double *entry)
 {
@@ -158,10 +137,10 @@ __device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const Half8M
 	for (int g = 0; g < 4; ++g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g;
-		fwd_step<MODE, 0, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
-		fwd_step<MODE, 1, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
-		fwd_step<MODE, 2, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
-		fwd_step<MODE, 3, NPL, LPT, CK>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 0, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 1, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 2, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 3, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
 	}
 	if (MODE == 1 && m < 4) io[base + 4 * m + 3] = inv_keep; // 1/d_p of the block's four normalising positions
 }
@@ -169,7 +148,7 @@ __device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const Half8M
 // items[4*blockIdx.x + row] = work of this row.  REPAIR: the list holds the flagged tiles (count 1); a
 // row starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel
 // then decides whether the next tile has to follow).  No vector-memory load inside the sweep.
-template <bool REPAIR, int NPL, int LPT = 16, bool CK = false>
+template <bool REPAIR, int NPL, bool CK = false>
 __device__ __forceinline__ void fwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                 const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -178,13 +157,12 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
                                                 int *__restrict__ touch_f)
 {
 	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0; // SWEEP_CKPT: the CK instantiation
-	constexpr int S = LPT * NPL, R = 64 / LPT; // R tiles per wave
+	constexpr int S = 16 * NPL, R = 4; // R tiles per wave
 	__shared__ double lds_e[4 * S]; // e[0], e[1], 1, 1
-	const int lane = threadIdx.x, m = lane & (LPT - 1), k0 = NPL * m;
-	const Half8Masks hm = half8_masks(lane);
+	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
 	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
-	const int slot = block * R + lane / LPT;
+	const int slot = block * R + (lane >> 4);
 	const bool valid = slot < n_items;
 	const SweepItem it = items[valid ? slot : 0];
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
@@ -195,7 +173,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	const uint8_t *o = obs + c.off;
 	double *fo = f + c.off * S + k0, *io = invd + c.off;
 	StructParN<NPL> sc;
-	load_struct_par<NPL, LPT>(sp, k0, true, sc);
+	load_struct_par<NPL>(sp, k0, true, sc);
 	double x[NPL];
 	int p_first;
 	if (REPAIR && valid && m == 0 && !(flags & SWEEP_NO_TOUCH)) touch_f[it.first] = 1; // X / inv_d of this tile change
@@ -229,16 +207,16 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	int nb_max = 0;
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		roff[r] = readlane_i64(c.off, LPT * r);
-		rbf[r] = __builtin_amdgcn_readlane(b_first, LPT * r);
-		rnb[r] = __builtin_amdgcn_readlane(nblk, LPT * r);
+		roff[r] = readlane_i64(c.off, 16 * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
 		nb_max = max(nb_max, rnb[r]);
 	}
 	for (int bi = 0; bi < nb_max; ++bi) {
 		int bb[R];
 #pragma unroll
 		for (int r = 0; r < R; ++r) bb[r] = rbf[r] + min(bi, max(rnb[r] - 1, 0));
-		const uint4 sv = row_symbols(obs, roff, bb, lane / LPT);
+		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
 		if (bi < nblk) {
 			const int base = (b_first + bi) << 4;
 			if (cur.next_lo == base + 1 && base + 1 >= p_first && base + 1 <= p_last) { // a tile starts exactly at this block
@@ -247,14 +225,14 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 			}
 			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
 			const int mode = !full ? 0 : (base + 1 >= lo_store ? 1 : 2);
-			if (__all(mode == 1)) fwd_block<1, NPL, LPT, CK>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else if (__all(mode == 2)) fwd_block<2, NPL, LPT, CK>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else fwd_block<0, NPL, LPT, CK>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			if (__all(mode == 1)) fwd_block<1, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else if (__all(mode == 2)) fwd_block<2, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else fwd_block<0, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 		}
 	}
 }
 
-template <bool REPAIR, int NPL, int LPT = 16, bool CK = false>
+template <bool REPAIR, int NPL, bool CK = false>
 __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -262,7 +240,7 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ invd, double *__restrict__ entry,
                                                      int *__restrict__ touch_f)
 {
-	fwd_struct_body<REPAIR, NPL, LPT, CK>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
+	fwd_struct_body<REPAIR, NPL, CK>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
 }
 
 // ------------------------------------------------------------------ backward
@@ -273,18 +251,18 @@ struct BwdCursor { int lo, top, tile; bool store; }; // store: false for a walk,
 
 // MODE 1: every position of the block is strictly inside (lo, top) of the current tile;
 // MODE 2: warm-up above the top tile's top;  MODE 0: general.
-template <int MODE, int J, int NPL, int LPT>
-__device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, unsigned w, int base,
+template <int MODE, int J, int NPL>
+__device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                          double *sbo, double *bentry, double *bexit)
 {
-	constexpr int S = LPT * NPL;
+	constexpr int S = 16 * NPL;
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p <= p_first && p >= p_low)) return;
 	double ev[NPL];
 	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
 	if (J == 3) { // sb_p = 1/sum(bt_{p+1}), off the critical path
-		const double s = rcp_newton(tile_sum<NPL, LPT>(x));
+		const double s = rcp_newton(tile_sum<NPL>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= s;
 		if ((MODE == 1 || (MODE == 0 && p <= cur.top && cur.store)) && m == 0) sbo[idx] = s;
@@ -293,7 +271,7 @@ __device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const Half8Ma
 		if (cur.store) storeN<NPL>(bto + (int64_t)cur.top * S, x); // bt[top+1]
 		storeN<NPL>(bentry + (int64_t)cur.tile * S + k0, x);
 	}
-	tile_step<NPL, LPT>(c, x, hm);
+	struct_step<NPL>(c, x);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 	if (MODE == 1) storeN<NPL>(bto + (int64_t)idx * S, x);
@@ -305,8 +283,8 @@ __device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const Half8Ma
 		}
 	}
 }
-template <int MODE, int NPL, int LPT>
-__device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int NPL>
+__device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                           double *sbo, double *bentry, double *bexit)
 {
@@ -314,15 +292,15 @@ __device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const Half8M
 	for (int g = 3; g >= 0; --g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g;
-		bwd_step<MODE, 3, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 2, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 1, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 0, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 	}
 }
 
 // items: tiles first .. first+count-1, walked from the highest down.
-template <bool REPAIR, int NPL, int LPT = 16>
+template <bool REPAIR, int NPL>
 __device__ __forceinline__ void bwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                 const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -330,13 +308,12 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
                                                 double *__restrict__ bentry, double *__restrict__ bexit,
                                                 int *__restrict__ touch_b)
 {
-	constexpr int S = LPT * NPL, R = 64 / LPT;
+	constexpr int S = 16 * NPL, R = 4;
 	__shared__ double lds_e[4 * S];
-	const int lane = threadIdx.x, m = lane & (LPT - 1), k0 = NPL * m;
-	const Half8Masks hm = half8_masks(lane);
+	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
 	fill_lds_e<S>(lds_e, e, lane);
 	__syncthreads();
-	const int slot = block * R + lane / LPT;
+	const int slot = block * R + (lane >> 4);
 	const SweepItem it = items[slot < n_items ? slot : 0];
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	const int t_top = it.first + it.count - 1;
@@ -351,7 +328,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	const uint8_t *o = obs + c.off;
 	double *bto = bt + c.off * S + k0, *sbo = sb + c.off;
 	StructParN<NPL> sc;
-	load_struct_par<NPL, LPT>(sp, k0, false, sc);
+	load_struct_par<NPL>(sp, k0, false, sc);
 	double x[NPL]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
 	int p_first;
 	if (REPAIR) { // continue from the value the tile above computed at our top boundary
@@ -374,28 +351,28 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	int nb_max = 0;
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		roff[r] = readlane_i64(c.off, LPT * r);
-		rbf[r] = __builtin_amdgcn_readlane(b_first, LPT * r);
-		rnb[r] = __builtin_amdgcn_readlane(nblk, LPT * r);
+		roff[r] = readlane_i64(c.off, 16 * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
 		nb_max = max(nb_max, rnb[r]);
 	}
 	for (int bi = 0; bi < nb_max; ++bi) {
 		int bb[R];
 #pragma unroll
 		for (int r = 0; r < R; ++r) bb[r] = rbf[r] - min(bi, max(rnb[r] - 1, 0));
-		const uint4 sv = row_symbols(obs, roff, bb, lane / LPT);
+		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
 		if (bi < nblk) {
 			const int base = (b_first - bi) << 4;
 			int mode = (base + 1 > cur.lo && base + 16 < cur.top) ? 1 : ((base + 1 > cur.top && base + 16 <= p_first) ? 2 : 0);
 			if (walk && mode == 1) mode = 2;
-			if (__all(mode == 1)) bwd_block<1, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else if (__all(mode == 2)) bwd_block<2, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else bwd_block<0, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			if (__all(mode == 1)) bwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else if (__all(mode == 2)) bwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else bwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 		}
 	}
 }
 
-template <bool REPAIR, int NPL, int LPT = 16>
+template <bool REPAIR, int NPL>
 __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                      const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -403,7 +380,7 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ bentry, double *__restrict__ bexit,
                                                      int *__restrict__ touch_b)
 {
-	bwd_struct_body<REPAIR, NPL, LPT>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
+	bwd_struct_body<REPAIR, NPL>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
 }
 
 // Both directions' walks over the glued runs in ONE launch (blocks [0, nbf) forward, the rest backward):
@@ -438,12 +415,12 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
                                                        double *__restrict__ entry, double *__restrict__ bentry,
                                                        double *__restrict__ bexit)
 {
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x, block = (int)blockIdx.x;
 	__builtin_amdgcn_s_setprio(3);
 	const WaveScanMasks wm = wave_scan_masks(lane);
 	const double e0 = e[lane], e1 = e[64 + lane];
-	if ((int)blockIdx.x < n_f) { // ---------------- forward
-		const SweepItem it = items_f[blockIdx.x];
+	if (block < n_f) { // ---------------- forward
+		const SweepItem it = items_f[block];
 		const Chunk c = chunks[it.first];
 		// count = -k <= 0: walk through k tiles and stop where tile first + k, the head of a transfer-matrix chain, starts --
 		// only its start vector is wanted (k = 0: the warm-up alone; k = 1: a segment's first tile, which has no X_0 for
@@ -476,7 +453,7 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 		}
 		if (warm_only) entry[(int64_t)(it.first + thru) * 64 + lane] = x;
 	} else { // ---------------- backward
-		const SweepItem it = items_b[blockIdx.x - n_f];
+		const SweepItem it = items_b[block - n_f];
 		const bool warm_only = it.count == 0; // the head (top tile) of a chain: only bt_{top+1}
 		int tile = it.first + max(it.count, 1) - 1;
 		const Chunk c = chunks[tile];
@@ -514,23 +491,13 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 // vectors swept through the tile, 4 per wave, all tiles of all runs at once -- and a tiny chain kernel then
 // applies the K_t one after the other (a 64 x 64 product each).  Columns are kept comparable by scaling
 // with powers of two only (exact) and carrying the exponent.
-// dir bit 0: 0 forward (lo..hi), 1 backward (top..lo).  bit 1 ("kc_warm", experimental): not the tile itself but the
-// speculative WARM-UP range in front of it (forward: lo - warm .. lo - 1; backward: top + warm .. top + 1), cut into
-// nparts = bits 16..23 parts of which this entry is part number bits 8..15 -- the start vector of a chain run as a
-// product of transfer matrices instead of a walk
+// dir: 0 forward (lo..hi), 1 backward (top..lo)
 struct KcTile { int tile, dir; };
-__host__ __device__ inline void kc_range(const Chunk &c, int dir, int W, int &lo, int &top) // the positions a KcTile's matrices cover
+__host__ __device__ inline void kc_range(const Chunk &c, int dir, int &lo, int &top) // the positions a KcTile's matrices cover
 {
-	const bool fwd = (dir & 1) == 0;
-	if (!(dir & 2)) {
-		top = fwd ? c.hi : min(c.hi, c.L - 1);
-		lo = fwd ? c.lo : min(((c.lo + 3) & ~3) + 1, top + 1); // backward: the chain kernel takes the tile's last steps itself
-	} else if (fwd) {
-		const int ws = max(1, c.lo - chunk_warm_f(c, W));
-		lo = ws == 1 ? 2 : ws; top = c.lo - 1; // ws == 1: position 1 is the start vector a0.e[o_1] itself
-	} else {
-		lo = min(c.hi, c.L - 1) + 1; top = min(c.hi + chunk_warm_b(c, W) + 1, c.L) - 1; // from B_q = 1 down to top + 1
-	}
+	const bool fwd = dir == 0;
+	top = fwd ? c.hi : min(c.hi, c.L - 1);
+	lo = fwd ? c.lo : min(((c.lo + 3) & ~3) + 1, top + 1); // backward: the chain kernel takes the tile's last steps itself
 }
 
 template <int NPL>
@@ -584,7 +551,8 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 	if (m == 0) Kexp[(int64_t)j * S + col] = (double)E;
 }
 
-// The same transfer matrix with one COLUMN per lane (64 states; "kcol_impl" = 1, default).  In k_kcol_struct a unit
+// The same transfer matrix with one COLUMN per lane (what 64-state models run; 65..128 states keep k_kcol_struct, whose
+// chain path ends earlier there: DESIGN.md section 3).  In k_kcol_struct a unit
 // vector is a tile of the sweeps: 16 lanes x 4 states, every scan level a DPP round trip -- 85 vector instructions per
 // step for four columns (1360 per step and tile).  Here the 64 states of a column sit in ONE lane's registers, so the
 // prefix / suffix sums are plain serial FMA chains and every matrix constant is the same for all lanes: one LDS
@@ -604,7 +572,7 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 template <int NQ>
 __global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
                                                             const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
-                                                            double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio, int W)
+                                                            double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio)
 {
 	constexpr int S = 32 * NQ, NCG = S / 64, KD = 11 * S; // KD: doubles per direction = mS | mP | 3 x (wS.e | wP.e | dd.e)
 	__shared__ double xch[2][NQ][2][64]; // [step parity][wave][S total, P total][column]
@@ -617,12 +585,11 @@ __global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restri
 	if (prio >= 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1); // s_setprio takes an immediate
 	const KcTile kt = kc[jt];
 	const Chunk c = chunks[kt.tile];
-	const bool fwd = (kt.dir & 1) == 0;
+	const bool fwd = kt.dir == 0;
 	for (int i = threadIdx.x; i < KD; i += 64 * NQ) tab[i] = kcc[(fwd ? 0 : KD) + i];
 	__syncthreads();
 	int top, lo;
-	kc_range(c, kt.dir, W, lo, top);
-	const int part = (kt.dir >> 8) & 255, nparts = max((kt.dir >> 16) & 255, 1); // warm-up ranges come in parts of at most a tile's length
+	kc_range(c, kt.dir, lo, top);
 	const uint8_t *o = obs + c.off;
 	const double *cc = tab + 32 * w; // this wave's part of every table
 	double x[32];
@@ -630,7 +597,7 @@ __global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restri
 	for (int k = 0; k < 32; ++k) x[k] = (32 * w + k == col) ? 1.0 : 0.0; // column `col` = unit vector e_col
 	int E = 0;
 	const int n = max(top - lo + 1, 0);
-	const int q0 = (int)((int64_t)n * (part * sub + js) / (nparts * sub)), q1 = (int)((int64_t)n * (part * sub + js + 1) / (nparts * sub)); // this block's steps, in traversal order
+	const int q0 = (int)((int64_t)n * js / sub), q1 = (int)((int64_t)n * (js + 1) / sub); // this block's steps, in traversal order
 	for (int q = q0; q < q1; ++q) {
 		const int p = fwd ? lo + q : top - q;
 		const int sym = min((int)o[p - 1] & 3, 2); // wave-uniform: a scalar byte load
@@ -691,7 +658,7 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 	for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
 	return v;
 }
-struct KcRun { int first, count, kc0, n_warm; }; // kc0: index of the run's first KcTile; n_warm: that many of them are the parts of the head's warm-up range
+struct KcRun { int first, count, kc0, pad; }; // kc0: index of the run's first KcTile
 
 // one-state-per-lane step for PER * 64 states: lane L holds states L and (PER == 2) L + 64
 template <int PER>
@@ -715,7 +682,7 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
                                                         const double *__restrict__ Kexp, const double *__restrict__ sp,
                                                         const double *__restrict__ e, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, double *__restrict__ entry,
-                                                        double *__restrict__ bentry, int sub, const double *__restrict__ a0, int W)
+                                                        double *__restrict__ bentry, int sub)
 {
 	constexpr int S = 64 * PER;
 	const int lane = threadIdx.x;
@@ -734,19 +701,10 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 		s1[q].mS = sp[3 * S + k]; s1[q].wS = sp[S + k]; s1[q].mP = sp[2 * S + k]; s1[q].wP = sp[k]; s1[q].dd = sp[4 * S + k];
 		e0[q] = e[k]; e1[q] = e[S + k];
 	}
-	if (r.n_warm > 0) { // the head's start vector: the prior pushed through the transfer matrices of its warm-up range
-		const Chunk c = chunks[t];
-		const uint8_t *o = obs + c.off;
-#pragma unroll
-		for (int q = 0; q < PER; ++q) {
-			if (fwd) { x[q] = a0[lane + 64 * q]; if (c.lo - chunk_warm_f(c, W) <= 1) x[q] *= walk_ev((int)o[0] & 3, e0[q], e1[q]); }
-			else x[q] = walk_ev((int)o[min(c.hi + chunk_warm_b(c, W) + 1, c.L) - 1] & 3, e0[q], e1[q]);
-		}
-	}
-	for (int q = -r.n_warm; q + 1 < r.count; ++q) { // q < 0: the parts of the warm-up range
+	for (int q = 0; q + 1 < r.count; ++q) {
 		double y[PER];
 		for (int ss = 0; ss < sub; ++ss) { // the tile's map = the product of its `sub` range maps, applied in traversal order
-		const int64_t kb = ((int64_t)(r.kc0 + r.n_warm + q) * sub + ss) * S;
+		const int64_t kb = ((int64_t)(r.kc0 + q) * sub + ss) * S;
 		double ex[PER], xs[PER], em = -1e300;
 #pragma unroll
 		for (int h = 0; h < PER; ++h) { ex[h] = Kexp[kb + lane + 64 * h]; em = fmax(em, x[h] > 0.0 ? ex[h] : -1e300); }
@@ -768,13 +726,6 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 #pragma unroll
 			for (int h = 0; h < PER; ++h) { y[h] *= inv; x[h] = y[h]; }
 		}
-		}
-		if (q < 0) { // still in front of the head tile: its start vector is complete after the last part
-			if (q == -1) {
-#pragma unroll
-				for (int h = 0; h < PER; ++h) vec[(int64_t)t * S + lane + 64 * h] = y[h];
-			}
-			continue;
 		}
 		if (!fwd) { // the tile's last steps p* .. lo with the sweep's own scaling: bt_lo as the sweep leaves it
 			const Chunk c = chunks[t];
@@ -803,15 +754,21 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 	}
 }
 
-// The bulk of both sweeps in ONE launch: even blocks walk forward items, odd blocks backward items (as long
-// as both lists last), so the two table writers share the chip from the first to the last wave and the
-// E-step needs one stream less.  Per launch: 2 x (8n+9) algorithmic bytes per bin.
-template <int NPL>
+// The bulk of both sweeps in ONE grid: even blocks take forward items, odd blocks backward items (as long as both
+// lists last).  Two uses.  (1) The unfused back half (flags 0 / 0): both table writers share the chip from the first
+// to the last wave.  (2) Phase 1 of the fused / factored E-step of a SHARD-SIZED input ("merge1", api.hip plan_fast):
+// the forward sweep (flags_f: SWEEP_CKPT or 0) and the warm-up-only backward pass (flags_b = SWEEP_TOP_ONLY).  Such an
+// E-step has fewer waves than the device has SIMDs (1024), and the dispatcher places the waves of ONE grid on distinct
+// SIMDs but knows nothing about the grids of other streams: two launches of 512 waves side by side leave 268 SIMDs
+// with two waves and 268 idle (psmc_hip_place_probe, profiles/r03_place_probe.json), and every step of a
+// latency-bound sweep then costs 508 cycles instead of 287.  Per launch: 2 x (8n+9) algorithmic bytes per bin in use
+// (1), (8n+9) in use (2).
+template <int NPL, bool CK>
 __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                        const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                        const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
                                                        int n_f, const SweepItem *__restrict__ items_b, int n_b, int W, int T,
-                                                       double *__restrict__ f, double *__restrict__ invd,
+                                                       int flags_f, int flags_b, double *__restrict__ f, double *__restrict__ invd,
                                                        double *__restrict__ entry, double *__restrict__ bt,
                                                        double *__restrict__ sb, double *__restrict__ bentry,
                                                        double *__restrict__ bexit)
@@ -820,8 +777,8 @@ __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ 
 	bool fwd; int blk;
 	if (b < both) { fwd = (b & 1) == 0; blk = b >> 1; }
 	else { fwd = nbf > nbb; blk = b - both + min(nbf, nbb); }
-	if (fwd) fwd_struct_body<false, NPL>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, 0, f, invd, entry, nullptr);
-	else bwd_struct_body<false, NPL>(blk, sp, e, obs, chunks, items_b, n_b, W, T, 0, bt, sb, bentry, bexit, nullptr);
+	if (fwd) fwd_struct_body<false, NPL, CK>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, flags_f, f, invd, entry, nullptr);
+	else bwd_struct_body<false, NPL>(blk, sp, e, obs, chunks, items_b, n_b, W, T, flags_b, bt, sb, bentry, bexit, nullptr);
 }
 
 // ------------------------------------------------------------------ dirty-tile lists
@@ -852,50 +809,36 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 
 // ------------------------------------------------------------------ launchers
 // which: 0 = the sweep items [first, first+n), 1 = flagged tiles of the current repair round,
-//        2 = walks over the glued runs [0, n) (boundary vectors only), 3 = every tile of the glued
-//        runs, recomputed from the boundary vector its walk left, 4 (backward) = warm-up only: leave
-//        the start vector of every item's top tile in bentry (fused backward + counts), 5 (backward) = flagged
-//        tiles of the current repair round, boundary vectors only (fused: no bt table to repair), 6 (forward) =
-//        phase-B items [first, first+n) of the two-phase plan: each from the X_{lo-1} its neighbour stored
+//        3 = every tile of the glued runs, recomputed from the boundary vector its walk / chain left,
+//        4 (backward) = warm-up only: leave the start vector of every item's top tile in bentry (fused backward +
+//        counts), 5 (backward) = flagged tiles of the current repair round, boundary vectors only (fused: no bt table
+//        to repair)
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
-	// throughput-bound bulk launches of 64-state models: eight tiles per wave (latency-bound ones keep four: a step of
-	// the 8 x 8 form takes 1.5x as long)
-	const bool l8 = p.lanes8 && p.ns == 64 && (which == 0 || which == 6);
-	const dim3 g(l8 ? (n_items + 7) / 8 : (n_items + 3) / 4), b(64);
+	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
-	const int flags = (which == 2 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 6 ? SWEEP_NO_TOUCH : 0))) // run tiles are done before the counts start
+	const int flags = (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0) // run tiles are done before the counts start
 	                  | (p.ckpt ? SWEEP_CKPT : 0);
-#define PSMC_LF(REP, NPL) hipLaunchKernelGGL((k_fwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+#define PSMC_LF(REP, NPL, CK) hipLaunchKernelGGL((k_fwd_struct<REP, NPL, CK>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
-	const bool rep = !(which == 0 || which == 2);
-#define PSMC_LFX(REP, NPL, LPT, CK) hipLaunchKernelGGL((k_fwd_struct<REP, NPL, LPT, CK>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
-		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
-	if (p.ckpt && p.ns == 64) { // checkpoint stores are a compile-time variant: no per-step branches in the full-table kernels
-		if (l8) { if (rep) PSMC_LFX(true, 8, 8, true); else PSMC_LFX(false, 8, 8, true); }
-		else { if (rep) PSMC_LFX(true, 4, 16, true); else PSMC_LFX(false, 4, 16, true); }
-	} else if (l8) { if (rep) PSMC_LFX(true, 8, 8, false); else PSMC_LFX(false, 8, 8, false); }
-	else if (p.ns == 128) { if (rep) PSMC_LF(true, 8); else PSMC_LF(false, 8); }
-	else { if (rep) PSMC_LF(true, 4); else PSMC_LF(false, 4); }
+	const bool rep = which != 0;
+	if (p.ns == 128) { if (rep) PSMC_LF(true, 8, false); else PSMC_LF(false, 8, false); }
+	else if (p.ckpt) { if (rep) PSMC_LF(true, 4, true); else PSMC_LF(false, 4, true); } // checkpoint stores are a compile-time variant: no per-step branches in the full-table kernels
+	else { if (rep) PSMC_LF(true, 4, false); else PSMC_LF(false, 4, false); }
 	PSMC_DBG("launch_fwd_struct", which, first, n_items);
-#undef PSMC_LFX
 #undef PSMC_LF
 }
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
-	const bool l8 = p.lanes8 && p.ns == 64 && which == 4; // the warm-up-only pass of the fused / factored back half
-	const dim3 g(l8 ? (n_items + 7) / 8 : (n_items + 3) / 4), b(64);
+	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 || which == 5 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
-	const int flags = which == 2 || which == 5 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? SWEEP_TOP_ONLY : 0));
+	const int flags = which == 5 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? SWEEP_TOP_ONLY : 0));
 #define PSMC_LB(REP, NPL) hipLaunchKernelGGL((k_bwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, \
 		n_items, p.warmup, p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b)
-	const bool rep = !(which == 0 || which == 2 || which == 4);
-	if (l8)
-		hipLaunchKernelGGL((k_bwd_struct<false, 8, 8>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup,
-		                   p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
-	else if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
+	const bool rep = !(which == 0 || which == 4);
+	if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
 	else { if (rep) PSMC_LB(true, 4); else PSMC_LB(false, 4); }
 	PSMC_DBG("launch_bwd_struct", which, first, n_items);
 #undef PSMC_LB
@@ -907,60 +850,53 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
 	                   (SweepItem *)(p.m_ritems ? p.m_ritems + (size_t)(bwd ? 1 : 0) * 2 * p.n_chunks : nullptr), p.m_cnt + (bwd ? 1 : 0));
 	PSMC_DBG("verify + launch_compact", bwd, p.n_chunks, 0);
 }
-// bulk of both sweeps: forward items [ff, ff+nf) and backward items [fb, fb+nb)
-void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb)
+// bulk of both sweeps in one grid: forward items [ff, ff+nf) and backward items [fb, fb+nb); top_only: the backward
+// blocks do the warm-up-only pass of the fused / factored back half (phase 1 of a shard-sized E-step)
+void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb, bool top_only)
 {
 	const int nblk = (nf + 3) / 4 + (nb + 3) / 4;
 	if (nblk <= 0) return;
-#define PSMC_LS(NPL) hipLaunchKernelGGL(k_sweep_struct<NPL>, dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
-		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, \
+	const int flags_f = p.ckpt ? SWEEP_CKPT : 0, flags_b = top_only ? SWEEP_TOP_ONLY : 0;
+#define PSMC_LS(NPL, CK) hipLaunchKernelGGL((k_sweep_struct<NPL, CK>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
 		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit)
-	if (p.ns == 128) PSMC_LS(8); else PSMC_LS(4);
-	PSMC_DBG("launch_sweeps", nf, nb, 0);
+	if (p.ns == 128) PSMC_LS(8, false); else if (p.ckpt) PSMC_LS(4, true); else PSMC_LS(4, false);
+	PSMC_DBG("launch_sweeps", nf, nb, top_only);
 #undef PSMC_LS
 }
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols)
 {
 	if (p.n_kc <= 0) return;
-	if (p.ns == 128 && p.kcol_impl == 1)
-		hipLaunchKernelGGL(k_kcol2_struct<4>, dim3(p.n_kc * p.kc_sub * 2), dim3(256), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
-		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio, p.warmup);
-	else if (p.ns == 128)
+	if (p.ns == 128) // 65..128 states: unit vectors as sweep tiles (the column-per-lane kernel's chain path ends later there)
 		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kc * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
 		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
-	else if (p.kcol_impl == 1)
-		hipLaunchKernelGGL(k_kcol2_struct<2>, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
-		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio, p.warmup);
 	else
-		hipLaunchKernelGGL(k_kcol_struct<4>, dim3(p.n_kc * 16), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
-		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
+		hipLaunchKernelGGL(k_kcol2_struct<2>, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
+		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
 	if (p.ns == 128)
 		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1, p.d_a0, p.warmup);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, 1);
 	else
 		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kcol_impl == 1 ? p.kc_sub : 1, p.d_a0, p.warmup);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kc_sub);
 	PSMC_DBG("launch_kchain", p.n_kc, p.n_chain_f, p.n_chain_b);
 }
+// walks over the glued runs: boundary vectors only.  64 states: one wave per run, one state per lane; 65..128: four runs per wave
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {
-	if (p.walk_impl == 1 && p.ns == 64) { // one wave per run, one state per lane
-		if (p.n_wl_f + p.n_wl_b <= 0) return;
+	if (p.n_wl_f + p.n_wl_b <= 0) return;
+	if (p.ns == 64) {
 		hipLaunchKernelGGL(k_walk1_struct, dim3(p.n_wl_f + p.n_wl_b), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
 		                   (const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup,
 		                   p.tile_len, p.d_entry, p.d_bentry, p.d_bexit);
 		PSMC_DBG("launch_walks", p.n_wl_f, p.n_wl_b, 0);
 		return;
 	}
-	const int nb = (p.n_wl_f + 3) / 4 + (p.n_wl_b + 3) / 4;
-	if (nb <= 0) return;
-#define PSMC_LW(NPL) hipLaunchKernelGGL(k_walk_struct<NPL>, dim3(nb), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
-		(const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup, p.tile_len, \
-		p.d_entry, p.d_bentry, p.d_bexit)
-	if (p.ns == 128) PSMC_LW(8); else PSMC_LW(4);
+	hipLaunchKernelGGL(k_walk_struct<8>, dim3((p.n_wl_f + 3) / 4 + (p.n_wl_b + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
+	                   (const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup, p.tile_len,
+	                   p.d_entry, p.d_bentry, p.d_bexit);
 	PSMC_DBG("launch_walks (four per wave)", p.n_wl_f, p.n_wl_b, 0);
-#undef PSMC_LW
 }
 
 } // namespace psmc

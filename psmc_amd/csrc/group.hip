@@ -11,8 +11,10 @@
 //          the point of that mode.
 // Shards = longest-processing-time-first partition of the segments by length.  librccl is opened on first use, so a
 // single-GPU user of the library never loads it.  A device may be listed more than once (two shards on one GPU: how
-// the tests exercise this file on a 1-GPU box); RCCL needs distinct devices, so such a group -- like one whose RCCL
-// cannot be opened when "rccl" = 0 -- adds the shards' vectors on the host in shard order instead.
+// the tests exercise this file on a 1-GPU box); RCCL needs distinct devices, so such a group adds the shards' vectors
+// on the host in shard order instead -- and so does a group in auto mode ("rccl" = -1) whose librccl cannot be opened
+// or whose communicator cannot be created (the reason is kept: psmc_hip_group_selfcheck reports the path in use).
+// Only "rccl" = 1 makes a missing RCCL an error.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -66,6 +68,7 @@ struct psmc_hip_group {
 	Rccl rccl;
 	std::vector<ncclComm_t> comm;
 	int last_reduce = 0;                         // 0 none (one shard), 1 RCCL all-reduce, 2 host sum in shard order, 3 ordered per-segment sum (exact)
+	std::string rccl_note;                       // auto mode: why RCCL is not in use (library missing, communicator refused)
 };
 
 static int gfail(psmc_hip_group *g, int code, const std::string &what) { if (g) g->err = what; return code; }
@@ -85,7 +88,7 @@ extern "C" int psmc_hip_group_create(psmc_hip_group **out, int n_states, int n_d
 	for (int i = 0; i < n_dev; ++i) {
 		int rc = psmc_hip_create(&g->sh[i], n_states, devices[i], mode);
 		if (rc == 0 && mode == PSMC_HIP_MODE_FAST) {
-			const size_t len = (size_t)n_states * n_states + 2 * (size_t)n_states + 1; // also holds the 7n + 1 of the factored statistics
+			const size_t len = std::max((size_t)n_states * n_states + 2 * (size_t)n_states + 1, (size_t)7 * n_states + 1); // [A | E | LL], or the factored statistics (longer below 5 states)
 			if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc((void **)&g->d_stats[i], sizeof(double) * len) != hipSuccess ||
 			    hipStreamCreateWithFlags(&g->st[i], hipStreamNonBlocking) != hipSuccess) rc = PSMC_HIP_EDEVICE;
 		}
@@ -176,22 +179,34 @@ template <class F> static int for_shards(psmc_hip_group *g, F f)
 	return 0;
 }
 
-// sum of the shards' device vectors into host memory: RCCL all-reduce over the devices, or the host adds them
-static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &out)
+// sum of the live shards' device vectors into host memory: RCCL all-reduce over the devices, or the host adds them
+static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &out, const std::vector<char> &live)
 {
 	out.assign(len, 0.0);
 	int n_live = 0, first = -1;
-	for (int s = 0; s < g->n_sh; ++s) if (!g->segs_of[s].empty()) { ++n_live; if (first < 0) first = s; }
-	const bool use_rccl = g->want_rccl == 1 || (g->want_rccl < 0 && g->distinct && n_live > 1 && n_live == g->n_sh); // auto: every device takes part
+	for (int s = 0; s < g->n_sh; ++s) if (live[s]) { ++n_live; if (first < 0) first = s; }
+	bool use_rccl = g->want_rccl == 1 || (g->want_rccl < 0 && g->distinct && n_live > 1 && n_live == g->n_sh); // auto: every device takes part
 	if (use_rccl && !g->distinct) return gfail(g, PSMC_HIP_EINVAL, "rccl = 1 needs distinct devices");
-	if (use_rccl) {
-		if (n_live != g->n_sh) return gfail(g, PSMC_HIP_ESTATE, "RCCL all-reduce: a shard holds no segment (fewer segments than devices)");
-		if (g->comm.empty()) {
-			if (!g->rccl.open(g->err)) return PSMC_HIP_EDEVICE;
+	if (use_rccl && n_live != g->n_sh) return gfail(g, PSMC_HIP_ESTATE, "RCCL all-reduce: a shard holds no segment (fewer segments than devices)");
+	if (use_rccl && g->comm.empty()) {
+		// auto mode falls back to the host sum when there is no usable RCCL on this node (same result, one more copy per
+		// shard); "rccl" = 1 keeps the hard error
+		std::string why;
+		if (!g->rccl.open(why)) {
+			if (g->want_rccl == 1) return gfail(g, PSMC_HIP_EDEVICE, why);
+			g->rccl_note = why; g->want_rccl = 0; use_rccl = false;
+		} else {
 			g->comm.assign(g->n_sh, nullptr);
 			const ncclResult_t r = g->rccl.CommInitAll(g->comm.data(), g->n_sh, g->dev.data());
-			if (r != ncclSuccess) { g->comm.clear(); return gfail(g, PSMC_HIP_EDEVICE, std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(r)); }
+			if (r != ncclSuccess) {
+				g->comm.clear();
+				why = std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(r);
+				if (g->want_rccl == 1) return gfail(g, PSMC_HIP_EDEVICE, why);
+				g->rccl_note = why; g->want_rccl = 0; use_rccl = false;
+			}
 		}
+	}
+	if (use_rccl) {
 		ncclResult_t r = g->rccl.GroupStart();
 		for (int s = 0; s < g->n_sh && r == ncclSuccess; ++s) {
 			(void)hipSetDevice(g->dev[s]);
@@ -207,7 +222,7 @@ static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &ou
 	}
 	std::vector<double> tmp(len);
 	for (int s = 0; s < g->n_sh; ++s) {
-		if (g->segs_of[s].empty()) continue;
+		if (!live[s]) continue;
 		(void)hipSetDevice(g->dev[s]);
 		if (hipStreamSynchronize(g->st[s]) != hipSuccess || hipMemcpy(tmp.data(), g->d_stats[s], sizeof(double) * len, hipMemcpyDeviceToHost) != hipSuccess)
 			return gfail(g, PSMC_HIP_EDEVICE, "copy of a shard's statistics");
@@ -217,6 +232,47 @@ static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &ou
 	return 0;
 }
 
+static std::vector<char> live_shards(const psmc_hip_group *g)
+{
+	std::vector<char> live(g->n_sh, 0);
+	for (int s = 0; s < g->n_sh; ++s) live[s] = !g->segs_of.empty() && !g->segs_of[s].empty();
+	return live;
+}
+
+// First contact with a multi-GPU node, before any E-step: every shard's device answers, the exchange the E-steps will
+// use comes up (RCCL communicator over the listed devices, or the host sum) and adds correctly IN STREAM ORDER -- shard
+// s writes s + 1 into its vector with an asynchronous copy on its E-step stream, the all-reduce follows on the same
+// stream, and every device must then hold n(n+1)/2.  A failure names the step (psmc_hip_group_last_error).
+extern "C" int psmc_hip_group_selfcheck(psmc_hip_group *g, int out[4])
+{
+	if (!g) return PSMC_HIP_EINVAL;
+	if (out) out[0] = g->n_sh, out[1] = 0, out[2] = 0, out[3] = 0;
+	if (g->mode != PSMC_HIP_MODE_FAST) { if (out) out[1] = 3; return PSMC_HIP_OK; } // exact mode exchanges nothing between devices
+	const int N = g->n_sh;
+	std::vector<double> src(N);
+	for (int s = 0; s < N; ++s) {
+		src[s] = (double)(s + 1);
+		if (hipSetDevice(g->dev[s]) != hipSuccess) return gfail(g, PSMC_HIP_EDEVICE, "selfcheck: hipSetDevice(" + std::to_string(g->dev[s]) + ")");
+		if (hipMemcpyAsync(g->d_stats[s], &src[s], sizeof(double), hipMemcpyHostToDevice, g->st[s]) != hipSuccess)
+			return gfail(g, PSMC_HIP_EDEVICE, "selfcheck: copy to device " + std::to_string(g->dev[s]));
+	}
+	std::vector<double> v;
+	const int rc = reduce_vectors(g, 1, v, std::vector<char>(N, 1));
+	if (rc) { g->err = "selfcheck: " + g->err; return rc; }
+	const double want = 0.5 * N * (N + 1);
+	if (v[0] != want) return gfail(g, PSMC_HIP_EDEVICE, "selfcheck: the exchange returned " + std::to_string(v[0]) + ", expected " + std::to_string(want));
+	if (g->last_reduce == 1) // after an all-reduce EVERY device holds the sum
+		for (int s = 0; s < N; ++s) {
+			double x = 0.0;
+			(void)hipSetDevice(g->dev[s]);
+			if (hipMemcpy(&x, g->d_stats[s], sizeof(double), hipMemcpyDeviceToHost) != hipSuccess || x != want)
+				return gfail(g, PSMC_HIP_EDEVICE, "selfcheck: device " + std::to_string(g->dev[s]) + " holds " + std::to_string(x) + " after the all-reduce, expected " + std::to_string(want));
+		}
+	if (out) { out[1] = g->last_reduce; out[2] = g->comm.empty() ? 0 : 1; out[3] = g->rccl_note.empty() ? 0 : 1; }
+	if (!g->rccl_note.empty()) g->err = "RCCL not in use: " + g->rccl_note; // informational; the call succeeded
+	return PSMC_HIP_OK;
+}
+
 extern "C" int psmc_hip_group_estep(psmc_hip_group *g, const double *a, const double *e, const double *a0, double *A, double *E,
                                     double *A0, double *LL, double *chk)
 {
@@ -224,18 +280,32 @@ extern "C" int psmc_hip_group_estep(psmc_hip_group *g, const double *a, const do
 	if (g->n_seg < 1) return gfail(g, PSMC_HIP_ESTATE, "group_estep: no segments loaded");
 	const int n = g->n;
 	if (g->mode == PSMC_HIP_MODE_FAST) {
-		int rc = for_shards(g, [&](int s) {
-			int r = psmc_hip_estep_device(g->sh[s], a, e, a0, g->d_stats[s], g->st[s]);
-			return r;
-		});
-		if (rc) return rc;
+		int rc = for_shards(g, [&](int s) { return psmc_hip_estep_device(g->sh[s], a, e, a0, g->d_stats[s], g->st[s]); });
 		std::vector<double> v;
-		if ((rc = reduce_vectors(g, (size_t)n * n + 2 * n + 1, v))) return rc;
+		if (rc == PSMC_HIP_ENOTSUP) {
+			// 65..128 states and a matrix without the PSMC form (e.g. after psmc_cap_matrix): the device-resident entry point
+			// has no kernels for it, psmc_hip_estep falls back to the exact ones -- do the same per shard and add the host
+			// vectors in shard order, so that a command that works on one GPU works on a device list
+			const size_t len = (size_t)n * n + 2 * n + 1;
+			std::vector<std::vector<double>> hv(g->n_sh, std::vector<double>(len, 0.0));
+			rc = for_shards(g, [&](int s) { return psmc_hip_estep(g->sh[s], a, e, a0, hv[s].data(), hv[s].data() + (size_t)n * n, nullptr, &hv[s][len - 1], nullptr); });
+			if (rc) return rc;
+			v.assign(len, 0.0);
+			int n_live = 0;
+			for (int s = 0; s < g->n_sh; ++s) {
+				if (g->segs_of[s].empty()) continue;
+				if (n_live++ == 0) v = hv[s]; else for (size_t i = 0; i < len; ++i) v[i] += hv[s][i];
+			}
+			g->last_reduce = n_live > 1 ? 2 : 0;
+		} else {
+			if (rc) return rc;
+			if ((rc = reduce_vectors(g, (size_t)n * n + 2 * n + 1, v, live_shards(g)))) return rc;
+		}
 		if (A) memcpy(A, v.data(), sizeof(double) * n * n);
 		if (E) memcpy(E, v.data() + (size_t)n * n, sizeof(double) * 2 * n);
 		if (LL) *LL = v[(size_t)n * n + 2 * n];
-		if (A0) memset(A0, 0, sizeof(double) * n);
-		if (chk) for (int i = 0; i < g->n_seg; ++i) chk[i] = 1.0;
+		if (A0) memset(A0, 0, sizeof(double) * n);                 // fast mode does not compute A0 (unused downstream, khmm.c:321-322) ...
+		if (chk) for (int i = 0; i < g->n_seg; ++i) chk[i] = 1.0;  // ... nor the khmm.c:237-238 self-check: as psmc_hip_estep in fast mode (include/psmc_hip.h)
 		return PSMC_HIP_OK;
 	}
 	// exact: per-segment statistics from every shard, added in input order on the host (hmm_add_expect, khmm.c:346-359)
@@ -274,7 +344,7 @@ extern "C" int psmc_hip_group_estep_factored(psmc_hip_group *g, const double *a,
 	int rc = for_shards(g, [&](int s) { return psmc_hip_estep_factored_device(g->sh[s], a, e, a0, g->d_stats[s], g->st[s]); });
 	if (rc) return rc;
 	std::vector<double> v;
-	if ((rc = reduce_vectors(g, (size_t)7 * n + 1, v))) return rc;
+	if ((rc = reduce_vectors(g, (size_t)7 * n + 1, v, live_shards(g)))) return rc;
 	if (sums) memcpy(sums, v.data(), sizeof(double) * 5 * n);
 	if (E) memcpy(E, v.data() + (size_t)5 * n, sizeof(double) * 2 * n);
 	if (LL) *LL = v[(size_t)7 * n];

@@ -277,39 +277,8 @@ int run_load_probe_st(hipStream_t stream, double *d_out, int n_waves, int steps,
 	return (int)hipGetLastError();
 }
 
-// the same with eight tiles per wave (8 lanes x 8 states)
-__global__ __launch_bounds__(64) void k_load_probe_h8(double *__restrict__ out, int steps, double seed)
-{
-	const int lane = threadIdx.x;
-	StructParN<8> c;
-	double xv[8];
-#pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		c.mS[i] = 0.01 + 1e-4 * (lane + i) + seed * 1e-9; c.wS[i] = 0.012 - 1e-5 * lane; c.mP[i] = 0.009 + 1e-5 * i;
-		c.wP[i] = 0.011; c.dd[i] = 0.3; xv[i] = 1.0 + 0.01 * (lane & 7) + 0.001 * i;
-	}
-	const Half8Masks k = half8_masks(lane);
-	const unsigned long long w0 = wall_clock64(), t0 = __builtin_readcyclecounter();
-	for (int it = 0; it < steps; it += 4) {
-		struct_step_h8(c, xv, k); struct_step_h8(c, xv, k); struct_step_h8(c, xv, k);
-		const double inv = rcp_newton(half8_sum(((xv[0] + xv[1]) + (xv[2] + xv[3])) + ((xv[4] + xv[5]) + (xv[6] + xv[7]))));
-		struct_step_h8(c, xv, k);
-#pragma unroll
-		for (int i = 0; i < 8; ++i) xv[i] *= inv;
-	}
-	const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
-	if (lane == 0) {
-		out[2 * blockIdx.x] = (double)(t1 - t0) / steps;
-		out[2 * blockIdx.x + 1] = (double)(t1 - t0) / (double)(w1 - w0) * 100.0;
-	}
-	double sum = 0.0;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) sum += xv[i];
-	if (sum == 123.456) out[0] = 0.0;
-}
 int run_load_probe(hipStream_t stream, double *d_out, int n_waves, int steps)
 {
-	if (steps < 0) { hipLaunchKernelGGL(k_load_probe_h8, dim3(n_waves), dim3(64), 0, stream, d_out, -steps, 0.37); return (int)hipGetLastError(); }
 	hipLaunchKernelGGL(k_load_probe, dim3(n_waves), dim3(64), 0, stream, d_out, steps, 0.37);
 	return (int)hipGetLastError();
 }
@@ -352,6 +321,146 @@ int run_pipe_probe(hipStream_t stream, double *d_out, int n_waves, unsigned mask
 int run_microbench(hipStream_t stream, double *d_out)
 {
 	hipLaunchKernelGGL(k_microbench, dim3(1), dim3(64), 0, stream, d_out, 0.37);
+	return (int)hipGetLastError();
+}
+
+
+// ---- pipe probe, second edition (round 3): what DOES overlap with another wave's v_mfma_f64 on the same SIMD?
+// The first probe paired matrix waves with v_fma_f64 waves only and found one shared FP64 pipe.  The fused step's other
+// instructions are mostly not f64 arithmetic: scan levels (two v_mov_b32_dpp + one v_add_f64), LDS reads of the
+// emission rows, scalar loads of the symbols, v_readlane.  One work-group of up to 8 waves on one CU (wave w -> SIMD
+// w % 4); kinds[w] chooses what wave w issues, ~4 k cycles of issue per round when alone:
+//   0 idle (exits)            1 v_mfma_f64_16x16x4 x 64           2 v_fma_f64 x 1024 (8 chains)
+//   3 v_mov_b32_dpp x 1024    4 scan levels: (2 v_mov_b32_dpp + v_add_f64) x 341, as row_excl_prefix emits them
+//   5 ds_read_b128 x 512      6 s_load_dwordx4 x 256 + v_readlane_b32 x 512
+//   7 v_add_u32 x 1024        8 v_fma_f32 x 1024                  9 v_add_f64 x 1024
+// out[w] = shader cycles per round of wave w.
+struct PipeKinds { int k[8]; };
+__global__ __launch_bounds__(512) void k_pipe_probe2(double *out, double seed, PipeKinds kinds, int rounds, const uint4 *__restrict__ gsrc)
+{
+	__shared__ uint4 lds[1024];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int i = threadIdx.x; i < 1024; i += blockDim.x) lds[i] = make_uint4(i, i + 1, i + 2, i + 3);
+	const int kind = kinds.k[w & 7];
+	const double x = seed + 1e-3 * lane, m = 1.0 + 1e-9 * lane;
+	d4m_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+	double f0 = x, f1 = x + 1, f2 = x + 2, f3 = x + 3, f4 = x + 4, f5 = x + 5, f6 = x + 6, f7 = x + 7;
+	float g0 = (float)x, g1 = g0 + 1, g2 = g0 + 2, g3 = g0 + 3, g4 = g0 + 4, g5 = g0 + 5, g6 = g0 + 6, g7 = g0 + 7;
+	const float gm = 1.0f + 1e-6f * lane;
+	int i0 = lane, i1 = lane + 1, i2 = lane + 2, i3 = lane + 3, i4 = lane + 4, i5 = lane + 5, i6 = lane + 6, i7 = lane + 7;
+	unsigned acc = 0;
+	__syncthreads();
+	const unsigned long long t0 = __builtin_readcyclecounter();
+	if (kind == 1) {
+		for (int it = 0; it < rounds; ++it) {
+			REPEAT16(c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c1, 0, 0, 0);
+			         c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, m, c3, 0, 0, 0);)
+		}
+	} else if (kind == 2) {
+		for (int it = 0; it < rounds * 8; ++it) {
+			REPEAT16(f0 = __builtin_fma(f0, m, x); f1 = __builtin_fma(f1, m, x); f2 = __builtin_fma(f2, m, x); f3 = __builtin_fma(f3, m, x);
+			         f4 = __builtin_fma(f4, m, x); f5 = __builtin_fma(f5, m, x); f6 = __builtin_fma(f6, m, x); f7 = __builtin_fma(f7, m, x);)
+		}
+	} else if (kind == 3) {
+#define PSMC_DPP8 asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+		"v_mov_b32_dpp %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+		"v_mov_b32_dpp %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+		"v_mov_b32_dpp %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+		: "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7));
+		for (int it = 0; it < rounds * 8; ++it) { REPEAT16(PSMC_DPP8) }
+#undef PSMC_DPP8
+	} else if (kind == 4) {
+		// 4 chains x (4 scan levels = 12 instructions) x 21 per round ~ 1008 instructions, two thirds of them DPP moves
+		for (int it = 0; it < rounds * 21; ++it) {
+			f0 = f0 + dpp_z<0x111>(f0); f1 = f1 + dpp_z<0x111>(f1); f2 = f2 + dpp_z<0x111>(f2); f3 = f3 + dpp_z<0x111>(f3);
+			f0 = f0 + dpp_z<0x112>(f0); f1 = f1 + dpp_z<0x112>(f1); f2 = f2 + dpp_z<0x112>(f2); f3 = f3 + dpp_z<0x112>(f3);
+			f0 = f0 + dpp_z<0x114>(f0); f1 = f1 + dpp_z<0x114>(f1); f2 = f2 + dpp_z<0x114>(f2); f3 = f3 + dpp_z<0x114>(f3);
+			f0 = f0 + dpp_z<0x118>(f0); f1 = f1 + dpp_z<0x118>(f1); f2 = f2 + dpp_z<0x118>(f2); f3 = f3 + dpp_z<0x118>(f3);
+			f0 *= 0.03125; f1 *= 0.03125; f2 *= 0.03125; f3 *= 0.03125; // keep the sums finite (4 more v_mul_f64: 1024 in all)
+		}
+	} else if (kind == 5) {
+		const unsigned a = (unsigned)(size_t)lds + 16u * (unsigned)lane; // LDS byte address
+		for (int it = 0; it < rounds * 32; ++it) {
+			uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, ra, rb, rc, rd, re, rf;
+			asm volatile("ds_read_b128 %0, %16\n ds_read_b128 %1, %16 offset:1024\n ds_read_b128 %2, %16 offset:2048\n ds_read_b128 %3, %16 offset:3072\n"
+			             "ds_read_b128 %4, %16 offset:4096\n ds_read_b128 %5, %16 offset:5120\n ds_read_b128 %6, %16 offset:6144\n ds_read_b128 %7, %16 offset:7168\n"
+			             "ds_read_b128 %8, %16 offset:8192\n ds_read_b128 %9, %16 offset:9216\n ds_read_b128 %10, %16 offset:10240\n ds_read_b128 %11, %16 offset:11264\n"
+			             "ds_read_b128 %12, %16 offset:12288\n ds_read_b128 %13, %16 offset:13312\n ds_read_b128 %14, %16 offset:14336\n ds_read_b128 %15, %16 offset:15360\n"
+			             "s_waitcnt lgkmcnt(0)\n"
+			             : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3), "=v"(r4), "=v"(r5), "=v"(r6), "=v"(r7), "=v"(r8), "=v"(r9), "=v"(ra), "=v"(rb), "=v"(rc), "=v"(rd), "=v"(re), "=v"(rf)
+			             : "v"(a) : "memory");
+			acc ^= r0.x ^ rf.w;
+		}
+	} else if (kind == 6) {
+		for (int it = 0; it < rounds * 64; ++it) {
+			uint4 s0, s1, s2, s3; int q0, q1, q2, q3, q4, q5, q6, q7;
+			asm volatile("s_load_dwordx4 %0, %12, 0x0\n s_load_dwordx4 %1, %12, 0x10\n s_load_dwordx4 %2, %12, 0x20\n s_load_dwordx4 %3, %12, 0x30\n"
+			             "v_readlane_b32 %4, %13, 0\n v_readlane_b32 %5, %13, 16\n v_readlane_b32 %6, %13, 32\n v_readlane_b32 %7, %13, 48\n"
+			             "v_readlane_b32 %8, %13, 1\n v_readlane_b32 %9, %13, 17\n v_readlane_b32 %10, %13, 33\n v_readlane_b32 %11, %13, 49\n"
+			             "s_waitcnt lgkmcnt(0)\n"
+			             : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(q0), "=s"(q1), "=s"(q2), "=s"(q3), "=s"(q4), "=s"(q5), "=s"(q6), "=s"(q7)
+			             : "s"(gsrc), "v"(i0) : "memory");
+			acc ^= s0.x ^ s3.w ^ (unsigned)q0 ^ (unsigned)q7;
+		}
+	} else if (kind == 7) {
+		for (int it = 0; it < rounds * 8; ++it) {
+			REPEAT16(asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+			         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(lane));)
+		}
+	} else if (kind == 8) {
+		for (int it = 0; it < rounds * 8; ++it) {
+			REPEAT16(g0 = __builtin_fmaf(g0, gm, gm); g1 = __builtin_fmaf(g1, gm, gm); g2 = __builtin_fmaf(g2, gm, gm); g3 = __builtin_fmaf(g3, gm, gm);
+			         g4 = __builtin_fmaf(g4, gm, gm); g5 = __builtin_fmaf(g5, gm, gm); g6 = __builtin_fmaf(g6, gm, gm); g7 = __builtin_fmaf(g7, gm, gm);)
+		}
+	} else if (kind == 9) {
+		for (int it = 0; it < rounds * 8; ++it) {
+			REPEAT16(f0 = f0 + m; f1 = f1 + m; f2 = f2 + m; f3 = f3 + m; f4 = f4 + m; f5 = f5 + m; f6 = f6 + m; f7 = f7 + m;)
+		}
+	}
+	const unsigned long long t1 = __builtin_readcyclecounter();
+	if (lane == 0 && w < 8) out[w] = kind == 0 ? 0.0 : (double)(t1 - t0) / rounds;
+	if (c0[0] + c1[1] + c2[2] + c3[3] + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7 + g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7 + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7) + (double)acc == 123.456) out[0] = 0.0;
+}
+int run_pipe_probe2(hipStream_t stream, double *d_out, const int *kinds8, int rounds, const void *gsrc)
+{
+	PipeKinds k;
+	int n = 0;
+	for (int i = 0; i < 8; ++i) { k.k[i] = kinds8[i]; if (kinds8[i]) n = i + 1; }
+	if (n == 0) return 0;
+	hipLaunchKernelGGL(k_pipe_probe2, dim3(1), dim3(64 * n), 0, stream, d_out, 0.37, k, rounds, (const uint4 *)gsrc);
+	return (int)hipGetLastError();
+}
+
+// ---- placement probe (round 3): where do the waves of a small launch land?  n_waves waves of the structured step in
+// work-groups of wpb waves; every wave records XCC_ID and HW_ID (SE / CU / SIMD) and its cycles per step.  A shard-sized
+// E-step has fewer waves than the device has SIMDs (1024): if the dispatcher stacks them, a step costs twice its latency.
+__global__ __launch_bounds__(256) void k_place_probe(double *__restrict__ out, int steps, double seed)
+{
+	const int lane = threadIdx.x & 63, w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	StructPar c;
+	double xv[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		c.mS[i] = 0.01 + 1e-4 * (lane + i) + seed * 1e-9; c.wS[i] = 0.012 - 1e-5 * lane; c.mP[i] = 0.009 + 1e-5 * i;
+		c.wP[i] = 0.011; c.dd[i] = 0.3; xv[i] = 1.0 + 0.01 * (lane & 15) + 0.001 * i;
+	}
+	const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+	const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20); // HW_REG_XCC_ID
+	const unsigned long long t0 = __builtin_readcyclecounter();
+	for (int it = 0; it < steps; it += 4) {
+		struct_step(c, xv); struct_step(c, xv); struct_step(c, xv);
+		const double inv = rcp_newton(row_sum16((xv[0] + xv[1]) + (xv[2] + xv[3])));
+		struct_step(c, xv);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) xv[i] *= inv;
+	}
+	const unsigned long long t1 = __builtin_readcyclecounter();
+	if (lane == 0) { out[3 * w] = (double)(t1 - t0) / steps; out[3 * w + 1] = (double)hw; out[3 * w + 2] = (double)xcc; }
+	if (xv[0] + xv[1] + xv[2] + xv[3] == 123.456) out[0] = 0.0;
+}
+int run_place_probe(hipStream_t stream, double *d_out, int n_waves, int wpb, int steps)
+{
+	hipLaunchKernelGGL(k_place_probe, dim3((n_waves + wpb - 1) / wpb), dim3(64 * wpb), 0, stream, d_out, steps, 0.37);
 	return (int)hipGetLastError();
 }
 

@@ -57,25 +57,20 @@ struct EstepLaunch {
 	const double *d_re;  // re[b*64+k] = 1/e[b][k] (0 where e is 0), b=0..2
 	const double *d_sp;  // structured transition: P | R | qa | c | dd, 64 each (estep_struct.hip); valid when structured
 	int structured;      // a[k][l] = P_k qa_l (l<k), R_k c_l (l>k): O(N) sweeps, 4 tiles per wave
-	int walk_impl;       // 1: one wave per glued run, one state per lane (k_walk1_struct); 0: four runs per wave
-	int kcol_impl;       // 64 states: 1 = transfer matrices with one column per lane (k_kcol2_struct), 0 = four columns per wave as sweep tiles
-	const double *d_kcc; // its constant tables (api.hip fill_params)
-	int kc_sub;          // ... and the number of step ranges (transfer matrices) per tile
+	const double *d_kcc; // 64 states: constant tables of the column-per-lane transfer-matrix kernel k_kcol2_struct (api.hip fill_params)
+	int kc_sub;          // ... the number of step ranges (transfer matrices) per tile
 	int kcol_prio;       // ... and its wave priority (0..2; the bulk forward sweep runs at 1, the walks at 3)
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
-	int exact_lds;       // exact mode, up to 64 states: operands of the ordered chains broadcast through LDS instead of DPP
-	int lanes8;          // 64 states: the throughput-bound bulk sweeps (forward, backward warm-up) run eight tiles per wave (8 lanes x 8 states)
-	int count_impl;      // fused == 1: 0 = k_bwd_count4_struct, 1 = no per-position normaliser: the weight is carried through both scale factors, 2 = that with the matrix
-	                     // instructions of a step interleaved with the next step's vector instructions (estep_fused.hip)
-	int fuse_order;      // fused == 1, two-phase plan: 0 = list A after the forward sweep of phase B, 1 = beside it
 	int ckpt;            // fused == 2: the forward sweep stores X at p % 8 == 0 only, the counts recompute the rest
+	int merge1;          // fused != 0: bulk forward sweep and backward warm-up pass in ONE grid (k_sweep_struct) -- the dispatcher spreads
+	                     // the waves of one grid over distinct SIMDs, not those of concurrent grids (shard-sized inputs: api.hip plan_fast)
 	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)
 	int n_items_f, n_items_b, tile_len;
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
-	int n_B_f, n_B_b;                 // trailing single items of phase B (two-phase plan): forward from the neighbour's X, backward from above
+	int n_B_b;                        // trailing backward items of the two-phase plan: they start from the exit vector of the tile above (second list of the fused back half)
 	const int *d_ftiles; int n_list_a, n_list_b; // fused back half: tile lists A | B (each padded to a multiple of 4 with -1)
 	hipStream_t stream4, stream5;
 	// walks: heads of the chain runs (count 1) followed by the short runs; transfer-matrix chains of the long runs
@@ -130,7 +125,7 @@ void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 void launch_walks(const EstepLaunch &p, hipStream_t st);
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols);
-void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb);
+void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb, bool top_only);
 void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo, bool all_from_bentry = false);
 void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n);
 void launch_reduce_factored(const EstepLaunch &p, hipStream_t st);
@@ -143,6 +138,8 @@ int launch_post_counts(hipStream_t st, const double *f, const double *b, const d
 int run_selftest(hipStream_t stream, unsigned *d_flags);
 int run_microbench(hipStream_t stream, double *d_out);
 int run_pipe_probe(hipStream_t stream, double *d_out, int n_waves, unsigned mask, int rounds);
+int run_pipe_probe2(hipStream_t stream, double *d_out, const int *kinds8, int rounds, const void *gsrc);
+int run_place_probe(hipStream_t stream, double *d_out, int n_waves, int wpb, int steps);
 int run_stream_probe(hipStream_t stream, const double *src, double *dst, size_t n);
 int run_hbm_probe(hipStream_t stream, int which, double *a, double *b, size_t bytes);
 int run_load_probe(hipStream_t stream, double *d_out, int n_waves, int steps);

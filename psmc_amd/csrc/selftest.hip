@@ -142,36 +142,6 @@ __global__ __launch_bounds__(64) void k_selftest(unsigned *flags)
 		for (int k = 0; k <= lane; ++k) pre += sh[k];
 		if (fabs(wave_prefix_incl(x, wm) - pre) > 1e-13 * pre || fabs(wave_prefix_incl_bc(x) - pre) > 1e-13 * pre) bad |= 16384u;
 	}
-	{ // the eight-tiles-per-wave form of the step (8 lanes x 8 states: masked 3-level scans) against the same dense product
-		__shared__ double uP[64], uR[64], uq[64], uc[64], ud[64], ux[8][64];
-		uP[lane] = 0.01 + 0.003 * lane; uR[lane] = 0.02 / (1.0 + lane); uq[lane] = 0.5 + 0.01 * lane;
-		uc[lane] = 1.0 / (3.0 + 0.2 * lane); ud[lane] = 0.9 - 0.002 * lane;
-		for (int r = 0; r < 8; ++r) ux[r][lane] = 1.0 / (1.0 + ((lane * 5 + r * 11) % 64)) + 1e-3 * r; // 8 different vectors, one per group
-		__syncthreads();
-		const int grp = lane >> 3, k0 = 8 * (lane & 7);
-		StructParN<8> c;
-		double xv[8];
-		for (int i = 0; i < 8; ++i) {
-			c.mS[i] = uP[k0 + i]; c.wS[i] = uq[k0 + i]; c.mP[i] = uR[k0 + i]; c.wP[i] = uc[k0 + i]; c.dd[i] = ud[k0 + i];
-			xv[i] = ux[grp][k0 + i];
-		}
-		const Half8Masks hm = half8_masks(lane);
-		double tot = 0.0;
-		for (int k = 0; k < 64; ++k) tot += ux[grp][k];
-		double ls = 0.0;
-		for (int i = 0; i < 8; ++i) ls += xv[i];
-		if (fabs(half8_sum(ls) - tot) > 1e-13 * tot) bad |= 32768u;
-		struct_step_h8(c, xv, hm);
-		for (int i = 0; i < 8; ++i) {
-			const int j = k0 + i;
-			double want = 0.0;
-			for (int k = 0; k < 64; ++k) {
-				const double akj = k > j ? uP[k] * uq[j] : (k < j ? uR[k] * uc[j] : ud[j] + uP[j] * uq[j] + uR[j] * uc[j]);
-				want += ux[grp][k] * akj;
-			}
-			if (fabs(xv[i] - want) > 1e-13 * fabs(want)) bad |= 32768u;
-		}
-	}
 	if (bad) atomicOr(flags, bad);
 }
 

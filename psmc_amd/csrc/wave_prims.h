@@ -129,32 +129,6 @@ __device__ __forceinline__ double xdot64(const double (&r)[4], const double (&m)
 	return acc;
 }
 
-// The same two ordered chains with the operands broadcast through LDS: the wave writes its 64 values, every lane
-// reads them back two at a time (one address for all lanes: a broadcast read, no bank conflict).  The reads go
-// through the LDS pipe, so a term costs the multiply and the add instead of v_mov_b64_dpp + multiply + add, and the
-// row replication (80 cycles) disappears.  Same operation order, same roundings.
-typedef double wp_d2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double xdot64_lds(const double *xs, const double (&m)[64]) {
-	double acc = 0.0;
-#pragma unroll
-	for (int l = 0; l < 64; l += 2) {
-		const wp_d2_t v = *reinterpret_cast<const wp_d2_t *>(xs + l);
-		acc = acc + v.x * m[l];
-		acc = acc + v.y * m[l + 1];
-	}
-	return acc;
-}
-__device__ __forceinline__ double seq_sum_lds(const double *xs) {
-	double s = 0.0;
-#pragma unroll
-	for (int l = 0; l < 64; l += 2) {
-		const wp_d2_t v = *reinterpret_cast<const wp_d2_t *>(xs + l);
-		s = s + v.x;
-		s = s + v.y;
-	}
-	return s;
-}
-
 // fast dot product: 4 independent FMA chains (one per row group) interleaved so
 // that consecutive FMAs of one chain are 4 issues apart, then a 2-level add.
 #define PSMC_FDOT4(N)                                                          \

@@ -28,6 +28,7 @@ EXPORTS = [
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
+    "psmc_hip_pipe_probe2", "psmc_hip_place_probe", "psmc_hip_group_selfcheck",
     "psmc_hip_group_create", "psmc_hip_group_destroy", "psmc_hip_group_last_error", "psmc_hip_group_set_option",
     "psmc_hip_group_load_segments", "psmc_hip_group_estep", "psmc_hip_group_estep_factored", "psmc_hip_group_info",
     "psmc_hip_group_route", "psmc_hip_estep_factored_device",
@@ -258,7 +259,7 @@ class HipEStep:
         return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value,
                     fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3],
                     structured=bool(fi[0]), tile_len=fi[1], items_fwd=fi[2], items_bwd=fi[3], back_half=fi[4], ckpt=bool(fi[5]),
-                    fused_launches=fi[6], phase_b_tiles=fi[7])
+                    fused_launches=fi[6], merged_phase1=fi[7])
 
     def tables(self, seg, want_b=True):
         L = int(self.lens[seg])
@@ -372,6 +373,42 @@ def pipe_probe(device=0):
     if rc != 0:
         raise HipError("pipe_probe: %s" % lib.psmc_hip_strerror(rc).decode())
     return {name: [round(v, 1) for v in out[8 * i:8 * i + 8] if v > 0] for i, name in enumerate(PIPE_PROBE_CONFIGS)}
+
+
+PIPE_KINDS = {"idle": 0, "mfma_f64": 1, "fma_f64": 2, "mov_dpp": 3, "scan_levels": 4, "ds_read_b128": 5, "sload_readlane": 6,
+              "add_u32": 7, "fma_f32": 8, "add_f64": 9}
+
+
+def pipe_probe2(kinds, rounds=64, device=0):
+    """Cycles per round of up to 8 waves of one work-group (wave w -> SIMD w % 4), kinds[w] from PIPE_KINDS."""
+    lib = load_library()
+    k = (C.c_int * 8)(*([PIPE_KINDS[x] if isinstance(x, str) else int(x) for x in kinds] + [0] * (8 - len(kinds))))
+    out = np.zeros(8)
+    lib.psmc_hip_pipe_probe2.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, _dp]
+    rc = lib.psmc_hip_pipe_probe2(int(device), k, int(rounds), _p(out))
+    if rc != 0:
+        raise HipError("pipe_probe2: %s" % lib.psmc_hip_strerror(rc).decode())
+    return [float(v) for v in out[:len(kinds)]]
+
+
+def place_probe(n_waves, waves_per_block=1, n_kernels=1, steps=3328, device=0):
+    """Where the waves of small launches land: dict(ms, cycles_per_step mean/max, simds_used, max_waves_per_simd, hist)."""
+    lib = load_library()
+    npad = (n_waves + waves_per_block - 1) // waves_per_block * waves_per_block
+    out = np.zeros(3 * npad * n_kernels); ms = C.c_double(0)
+    lib.psmc_hip_place_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_double)]
+    rc = lib.psmc_hip_place_probe(int(device), int(n_waves), int(waves_per_block), int(n_kernels), int(steps), _p(out), C.byref(ms))
+    if rc != 0:
+        raise HipError("place_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+    o = out.reshape(-1, 3)
+    o = o[o[:, 0] > 0]
+    hw = o[:, 1].astype(np.int64); xcc = o[:, 2].astype(np.int64) & 0xf
+    simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+    key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+    _, cnt = np.unique(key, return_counts=True)
+    cus = len(np.unique(key // 4))
+    return dict(ms=ms.value, cycles_mean=float(o[:, 0].mean()), cycles_max=float(o[:, 0].max()), waves=len(o), simds_used=len(cnt), cus_used=cus,
+                max_waves_per_simd=int(cnt.max()), hist={int(k): int((cnt == k).sum()) for k in np.unique(cnt)})
 
 
 class HipGroup:

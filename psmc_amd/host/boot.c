@@ -30,7 +30,16 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 	psmc_setup su;
 	psmc_input in;
 	int status = 1;
-	if (n_rep < 1 || !out_pattern || !strstr(out_pattern, "%d")) { fprintf(stderr, "psmc_boot: need a replicate count and an output pattern with %%d\n"); return 1; }
+	/* the pattern is the user's string: never a printf format.  Exactly one "%d" (the replicate number); "%%" = a literal % */
+	const char *pat_d = 0;
+	int pat_ok = out_pattern != 0;
+	for (const char *q = out_pattern; pat_ok && *q; ++q) {
+		if (*q != '%') continue;
+		if (q[1] == '%') { ++q; continue; }
+		if (q[1] == 'd' && !pat_d) { pat_d = q; ++q; continue; }
+		pat_ok = 0; /* a second %d, or any other conversion */
+	}
+	if (n_rep < 1 || !pat_ok || !pat_d) { fprintf(stderr, "psmc_boot: need a replicate count and an output pattern with exactly one %%d (and no other conversion)\n"); return 1; }
 	if (o->decode || o->cnt_file || o->print_prob || o->simulate) { fprintf(stderr, "psmc_boot: decoding / simulation options make no sense on bootstrap replicates\n"); return 1; }
 	if (psmc_setup_begin(o, &su)) return 1;
 	const int N = su.pat.n_states;
@@ -55,7 +64,15 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 	for (int r = 0; r < n_rep; ++r) { /* serial: drand48 is one global stream, re-seeded per replicate like a fresh process */
 		replicate *R = &rep[r];
 		char fn[4096];
-		snprintf(fn, sizeof fn, out_pattern, r);
+		{ /* prefix + r + suffix, "%%" -> "%" */
+			size_t w = 0;
+			for (const char *q = out_pattern; *q && w + 16 < sizeof fn; ++q) {
+				if (q == pat_d) { w += (size_t)snprintf(fn + w, sizeof fn - w, "%d", r); ++q; }
+				else if (*q == '%') { fn[w++] = '%'; ++q; }
+				else fn[w++] = *q;
+			}
+			fn[w] = 0;
+		}
 		R->out = fopen(fn, "w");
 		if (!R->out) { fprintf(stderr, "psmc_boot: cannot write %s\n", fn); goto done_rep; }
 		srand48(seed0 + r);                                     /* main.c:11 with PSMC_SEED */

@@ -64,6 +64,10 @@ static double interval_mean_time(double pik, double C_sigma, double sigma_k, dou
 	return avg;
 }
 
+/* model parameters -> HMM (a, e, a0): RESTATED from lh3/psmc core.c:61-133 (psmc_update_hmm), expression shapes kept on
+ * purpose -- every product and quotient rounds where the reference's does, which the byte-identical .psmc contract
+ * needs.  lh3/psmc is Copyright (c) 2007-2009 Genome Research Ltd, 2009-2015 Broad Institute, MIT License; the full
+ * notice is in /NOTICE.  Own here: the flat layout, the O(N) log factors (psmc_model_logfactors) and everything around. */
 void psmc_model_update(psmc_model *m)
 {
 	const int N = m->pat.n_states, n = N - 1;

@@ -56,6 +56,10 @@ double psmc_Q(int n, const double *a, const double *e, const double *A, const do
 	return sum - Q0;
 }
 
+/* ---- Hooke-Jeeves direct search: RESTATED from lh3/psmc kmin.c:48-107, statement order kept on purpose (the search
+ * branches on `<` of nearly equal objective values, so a byte-identical .psmc needs the same evaluation order).
+ * kmin.c is Copyright (c) 2008, by Heng Li <lh3@live.co.uk>, MIT License ("Based on the pseudocodes by Bell and Pike
+ * (CACM 9(9):684-685), and the revision by Tomlin and Smith (CACM 12(11):637-638)"); the full notice is in /NOTICE. */
 /* one exploratory sweep around x1 along every axis (kmin.c:48-66) */
 static double explore(psmc_objective f, int n, double *x1, void *data, double fx1, double *dx, int *calls)
 {

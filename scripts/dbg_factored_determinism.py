@@ -18,7 +18,7 @@ def beq(x, y):
 
 
 base = dict(chunk=768, warmup=256, group_cap=200000)
-variants = [base, dict(base, ckpt=0), dict(base, learn=0), dict(base, kc_min=0), dict(base, walk_impl=0), dict(base, two_phase=0), dict(base, overlap=0), dict(base, fuse=0), dict()]
+variants = [base, dict(base, ckpt=0), dict(base, learn=0), dict(base, kc_min=0), dict(base, merge1=0), dict(base, two_phase=2), dict(base, overlap=0), dict(base, fuse=0), dict()]
 if len(sys.argv) > 1:
     variants = variants[:int(sys.argv[1])]
 for opts in variants:

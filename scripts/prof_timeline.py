@@ -21,5 +21,5 @@ lo, hi = ends[-2] + 1, ends[-1]
 t0 = min(r[0] for r in rows[lo:hi + 1])
 print("%-34s %9s %9s %9s %5s %5s %8s" % ("kernel", "start_ms", "end_ms", "dur_ms", "queue", "strm", "grid"))
 for r in rows[lo:hi + 1]:
-    if (r[1] - r[0]) < 20000 and "struct" not in r[2] and "expect" not in r[2]: continue
+    if (r[1] - r[0]) < 20000 and "struct" not in r[2] and "expect" not in r[2] and "all" not in sys.argv[3:]: continue
     print("%-34s %9.3f %9.3f %9.3f %5s %5s %8s" % (short(r[2])[:34], (r[0] - t0) / 1e6, (r[1] - t0) / 1e6, (r[1] - r[0]) / 1e6, r[3], r[4], r[5]))

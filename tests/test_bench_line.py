@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 KERN = dict(total=14.4, chains=14.3, tail=0.07, expect=6.9, reduce=0.07, fwd_sweep=7.2, bwd_sweep=14.1, forward=14.3, backward=0.07)
 DIAG = dict(warm_err_fwd=5e-13, warm_err_bwd=4e-13, n_chunks=8127, warmup=3072, fwd_rounds=0, bwd_rounds=0, fwd_tiles=0, bwd_tiles=0,
-            structured=True, tile_len=3712, items_fwd=7948, items_bwd=7979, back_half=1, ckpt=False, fused_launches=2, phase_b_tiles=0)
+            structured=True, tile_len=3712, items_fwd=7948, items_bwd=7979, back_half=1, ckpt=False, fused_launches=2, merged_phase1=0)
 
 
 @pytest.mark.parametrize("case", ["fused_fwd_longest", "fused_counts_longest", "unfused_struct", "dense", "exact"])

@@ -53,13 +53,20 @@ def test_device_primitives(hip):
     assert hip.selftest(0) == 0
 
 
+# The inputs of this file are a few thousand bins: the planner gives them the ONE-ROUND plan of shard-sized inputs (every
+# tile speculates, phase 1 as one grid, a failed tile glued at once).  GENOME = the options the two-round plan of a
+# genome-sized input runs with, so that both plans are parity-tested at fixture size (tests/test_gpu_scale.py has them
+# at full size).
+GENOME = dict(two_phase=2, merge1=0, warm_shift=1, kc_sub=4)
+
+
 # ------------------------------------------------------------------ exact mode
-@pytest.mark.parametrize("rep", [1, 0, 2])  # 1 / 0: DPP rows from permlane swaps (default) / ds_bpermute; 2: operands broadcast through LDS (exact_lds)
+@pytest.mark.parametrize("rep", [1, 0])  # DPP rows from permlane swaps (default) / ds_bpermute
 @pytest.mark.parametrize("key", ["n64_curve", "n64_flat", "n23_curve", "n23_flat"])
 def test_exact_small_golden(hip, golden, key, rep):
     p = golden.params(key)
     n = p["a"].shape[0]
-    es = hip.HipEStep(n, mode=hip.MODE_EXACT, rep_impl=min(rep, 1), exact_lds=1 if rep == 2 else 0)
+    es = hip.HipEStep(n, mode=hip.MODE_EXACT, rep_impl=rep)
     es.load_segments(golden.segs_small)
     r = es.estep(p["a"], p["e"], p["a0"])
     g = golden.small
@@ -343,8 +350,8 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
-                                  dict(two_phase=0), dict(chunk=256, warmup=512, two_phase=0), dict(two_phase=1), dict(chunk=256, warmup=512, two_phase=1), dict(chunk=768, warmup=256, two_phase=1, overlap=0), dict(chunk=768, warmup=64, two_phase=1, fuse_order=1),
-                                  dict(lanes8=1), dict(chunk=256, warmup=512, lanes8=1), dict(chunk=1000, warmup=100, lanes8=1, overlap=0), dict(chunk=768, warmup=256, lanes8=1, two_phase=1)])
+                                  dict(two_phase=2), dict(chunk=256, warmup=512, two_phase=2), dict(GENOME), dict(chunk=256, warmup=512, **GENOME), dict(chunk=768, warmup=256, overlap=0, **GENOME), dict(chunk=768, warmup=64, merge1=0),
+                                  dict(merge1=1, two_phase=2), dict(chunk=256, warmup=512, merge1=1, warm_shift=1), dict(chunk=1000, warmup=100, kc_sub=2)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is
@@ -363,7 +370,7 @@ def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=512, warmup=256), dict(chunk=1000, warmup=100, overlap=0, learn=0),
-                                  dict(chunk=264, warmup=300, two_phase=0), dict(chunk=768, warmup=64, two_phase=1),
+                                  dict(chunk=264, warmup=300, **GENOME), dict(chunk=768, warmup=64, two_phase=2),
                                   dict(fuse128=0), dict(fuse128=0, chunk=512, warmup=256), dict(fuse128=0, chunk=1000, warmup=100, overlap=0, learn=0)])
 def test_fast_n128(hip, golden, oracle, opts):
     """-p "64*2" in fast mode: 8 states per lane in the structured sweeps; the counts fused with the backward sweep, four
@@ -398,9 +405,9 @@ def test_fast_n128(hip, golden, oracle, opts):
     es.close()
 
 
-@pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, walk_impl=0),
-                                  dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, two_phase=1), dict(chunk=100, warmup=30, two_phase=1), dict(chunk=5000, warmup=16, overlap=0),
-                                  dict(chunk=100, warmup=30, lanes8=1), dict(chunk=37, warmup=5, group_cap=3000, lanes8=1), dict(chunk=64, warmup=0, lanes8=1)])
+@pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, merge1=0),
+                                  dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=5000, warmup=16, overlap=0),
+                                  dict(chunk=100, warmup=30, two_phase=2), dict(chunk=37, warmup=5, group_cap=3000, **GENOME), dict(chunk=64, warmup=0, warm_shift=1)])
 def test_fast_odd_tilings(hip, golden, oracle, opts):
     """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
     everything is repaired / learned into runs and stays inside the tolerance."""
@@ -421,7 +428,7 @@ def tri_sums(A):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
-                                  dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, two_phase=1), dict(lanes8=1), dict(chunk=1001, warmup=100, lanes8=1), dict(chunk=264, warmup=300, lanes8=1)])
+                                  dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, **GENOME), dict(GENOME), dict(chunk=1001, warmup=100, merge1=0), dict(chunk=264, warmup=300, warm_shift=1)])
 def test_fast_factored_statistics(hip, golden, oracle, opts):
     """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
     (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset.
@@ -526,7 +533,7 @@ def test_fast_vs_oracle_random(hip, oracle, n):
     es.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(fuse=0), dict(two_phase=1, lanes8=1)])
+@pytest.mark.parametrize("opts", [dict(), dict(fuse=0), dict(GENOME)])
 def test_fast_many_small_segments(hip, golden, oracle, opts):
     """Hundreds of short segments (lengths 1 .. 3000, some all-missing): tiles of different segments share a wave and
     a group of the fused kernel, most tiles are a segment's first and last at once.  Full matrix, factored
@@ -706,8 +713,8 @@ def test_fast_stress_tiny_tiles_recycled_memory(hip, golden, oracle):
     segs = golden.segs_small + golden.segs_mid[3:]
     o = oracle.estep(p["a"], p["e"], p["a0"], segs)
     want = tri_sums(o["A"])
-    opts_list = [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, walk_impl=0), dict(chunk=64, warmup=0),
-                 dict(chunk=64, warmup=0, two_phase=1), dict(chunk=100, warmup=30, two_phase=1), dict(chunk=37, warmup=5, group_cap=3000, lanes8=1)]
+    opts_list = [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, merge1=0), dict(chunk=64, warmup=0),
+                 dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=37, warmup=5, group_cap=3000, two_phase=2)]
     rng = random.Random(7)
     bad = []
     for rep in range(12):

@@ -19,6 +19,14 @@ given beside it.
 
     python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --engine group --gpus N        # ONE process: the C library's own sharding (psmc_hip_group_*, what
+                                                   # the psmc binary runs with PSMC_HIP_DEVICES=0,1,..): LPT in C, one host
+                                                   # thread per device, RCCL all-reduce via group.hip
+
+Extras on the same line (N=1): `shard_sweep` (the E-step on rank 0's LPT share of the genome at 1/2/4/8 GPUs and on the
+500 k-bin input of config 2, with the strong-scaling curve those times predict), `group_engine` (the product's own
+multi-GPU path, see above; with N>1 it is measured beside the torch.distributed number), `boot` (config 4 through the
+psmc_boot binary, 16 replicates), `factored_stats`, `exact_mode`, `n128` (config 5).
 
 Scaling.  Segments are independent given the parameters (em.c:36-55); the one
 exchange per step is the RCCL all-reduce of n*n+2n+1 doubles that replaces
@@ -48,6 +56,7 @@ PATTERN = "4+25*2+4+6"               # README:12 of the reference: 64 states, 28
 BYTES_PER_BIN = 16 * N_STATES + 18   # obs x2, f write+read, s write+read
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec (psmc_hip_hbm_probe: 5.3-5.9 TB/s streaming on this box)
 F64_PEAK_TFLOPS = 78.6               # dense FP64, vector or v_mfma_f64_16x16x4 (they share the pipe: psmc_hip_microbench)
+ALLREDUCE_MS = 0.05                  # all-reduce of n*n+2n+1 doubles (34 KB) over xGMI: latency-bound; used only for the PREDICTED strong-scaling curve
 
 
 def log(*a):
@@ -151,7 +160,8 @@ def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, dia
                          "hbm": {"alg_bytes_per_bin": 8 * N_STATES + 9, "achieved_GBs": bins * (8 * N_STATES + 9) / (dom_ms * 1e-3) / 1e9,
                                  "alg_bytes_per_launch": bins * (8 * N_STATES + 9) / max(1, diag.get("fused_launches", 1))},
                          "note": "kernel_ms = the launches of one E-step summed (two-phase plan: tile lists A and B, half of the tiles each); "
-                                 "traffic = PMC bytes of the larger launch"}
+                                 "traffic = PMC bytes of the larger launch, replayed from profiles/pmc_traffic.json (a separate rocprofv3 --pmc pass of this "
+                                 "command: PMC counters cannot be read inside the timed run)"}
                         if dom == "k_bwd_count4f_struct" else
                         {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_bin": alg_b, "alg_bytes_per_launch": bins * alg_b,
@@ -180,6 +190,118 @@ def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, dia
                                   (bins * 2 * N_STATES * N_STATES / (kern["expect"] * 1e-3) / 1e12 if kern.get("expect", 0) > 0 else 0.0)},
     }
     return out
+
+
+def median_ms(fn, n, sync):
+    """median / min wall time in ms of n calls of fn(i), each followed by sync()"""
+    ts = []
+    for i in range(n):
+        t0 = time.perf_counter(); fn(i); sync()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts)), float(min(ts))
+
+
+def shard_sweep_extra(hip, torch, sim, partition_segments, full, lens, a, e, a0, moving, device, opts, stream, t_full_ms):
+    """the E-step on shard-sized inputs.  Rank 0's LPT share of the benchmark genome at N = 2, 4, 8 (the
+    largest share: rank 0 holds the longest segment) and the 500 k-bin single segment of config 2, parameters moving every
+    step like the headline; predicted strong scaling = t(1) / (t(share_N) + all-reduce latency)."""
+    res = {"note": "fast mode, full counts, moving parameters, median of 12 steps after 8; predicted_speedup = headline ms / (share ms + %.2f ms all-reduce of 34 KB, "
+                   "latency-bound on xGMI); what the driver's N>1 strong-scaling run should show if the shards are balanced" % ALLREDUCE_MS, "workloads": []}
+    work = []
+    rng = np.random.default_rng(7)
+    work.append(("config2_chr22like_500k", 1, [sim.simulate_segment(a, e, a0, 500_000, rng)]))
+    for n in (8, 4, 2):
+        mine = partition_segments(lens, n)[0]
+        work.append(("genome_share_1of%d" % n, n, [full[i] for i in mine]))
+    for name, n, segs in work:
+        sh = Shard(hip, torch, segs, N_STATES, device, hip.MODE_FAST, opts)
+        try:
+            sh.es.estep(*moving[0])
+            run = lambda i: sh.es.estep_device(*moving[i % len(moving)], sh.stats.data_ptr(), stream.cuda_stream)
+            for i in range(8):
+                run(i)
+            torch.cuda.synchronize()
+            med, mn = median_ms(lambda i: run(8 + i), 12, torch.cuda.synchronize)
+            d = sh.es.fast_diag()
+            r = {"workload": name, "bins": sh.bins, "segments": len(segs), "ms_per_step": med, "ms_min": mn, "bins_per_s": sh.bins / (med * 1e-3),
+                 "tiles": d["n_chunks"], "tile_bins": d["tile_len"], "merged_phase1": d["merged_phase1"], "fused_launches": d["fused_launches"],
+                 "kernels_ms": {k: round(float(v), 3) for k, v in sh.es.timing().items()}}
+            if name.startswith("genome_share"):
+                r["n_gpus"] = n
+                r["predicted_speedup"] = t_full_ms / (med + ALLREDUCE_MS)
+                r["predicted_efficiency"] = r["predicted_speedup"] / n
+        except Exception as ex_:
+            r = {"workload": name, "error": str(ex_)}
+        res["workloads"].append(r)
+        sh.close()
+    return res
+
+
+def group_engine_run(hip, segs, devices, moving, steps, warmup, mode):
+    """The product's own multi-GPU path (psmc_hip_group_*, group.hip): one process, LPT partition in C, one host thread per
+    device, RCCL all-reduce (or the host sum when devices repeat) -- selfcheck first, so that a failure names itself."""
+    g = hip.HipGroup(N_STATES, devices, mode=mode)
+    try:
+        sc = g.selfcheck()
+        g.load_segments(segs)
+        t0 = time.perf_counter(); g.estep(*moving[0]); first = (time.perf_counter() - t0) * 1e3
+        for i in range(warmup):
+            g.estep(*moving[i % len(moving)])
+        t0 = time.perf_counter()
+        for i in range(steps):
+            g.estep(*moving[(warmup + i) % len(moving)])
+        dt = time.perf_counter() - t0
+        info = g.info()
+        return {"selfcheck": sc, "ms_per_step": dt / steps * 1e3, "first_call_ms": first, "steps": steps, "warmup": warmup, "devices": list(devices),
+                "reduce": {0: "single shard", 1: "RCCL all-reduce (group.hip)", 2: "host sum in shard order", 3: "ordered per-segment sum"}[info["last_reduce"]]}
+    finally:
+        g.close()
+
+
+def boot_extra(sim, a, e, a0, n_rep=16, iters=3):
+    """Config 4 through the product binary: psmc_boot -R 16 -- -N3 over splitfa-like trunks of the benchmark genome
+    (utils/splitfa.c:20-35: 500 k-bin trunks), exact and fast mode, per-iteration times from PSMC_TIMING (the first
+    iterations of the exact mode pay for the first touch of its table memory: the last one is the steady state)."""
+    import re, subprocess, tempfile
+    host = os.path.join(ROOT, "psmc_amd", "host")
+    lens = sim.human_like_lengths(30_000_000, n_seg=22)
+    segs = sim.simulate_genome(a, e, a0, lens, seed=43)
+    trunks = []
+    for s in segs:
+        L, pos = len(s), 0
+        while L - pos >= 750_000:
+            trunks.append(s[pos:pos + 500_000]); pos += 500_000
+        trunks.append(s[pos:])
+    tmp = tempfile.mkdtemp(prefix="psmc_bench_")
+    path = os.path.join(tmp, "split.psmcfa")
+    conv = np.frombuffer(b"TKN", dtype=np.uint8)
+    with open(path, "wb") as fh:
+        for i, s in enumerate(trunks):
+            fh.write((">t%d\n" % i).encode())
+            t = conv[s]
+            n60 = len(t) // 60 * 60
+            fh.write(np.concatenate([t[:n60].reshape(-1, 60), np.full((n60 // 60, 1), 10, np.uint8)], axis=1).tobytes())
+            if n60 < len(t):
+                fh.write(t[n60:].tobytes() + b"\n")
+    res = {"workload": "%d trunks, %d bins, longest %d; %d replicates, -N%d -t15 -r5 -p %s" % (len(trunks), sum(len(t) for t in trunks), max(len(t) for t in trunks), n_rep, iters, PATTERN),
+           "note": "psmc_boot binary (psmc_hip_estep_batch under it): all replicates in lock step, E-steps batched on the device, M-steps on host threads; "
+                   "per_iteration_ms covers ALL replicates"}
+    try:
+        for m in ("exact", "fast"):
+            env = dict(os.environ, PSMC_HIP_MODE=m, PSMC_TIMING="1")
+            t0 = time.perf_counter()
+            r = subprocess.run([os.path.join(host, "psmc_boot"), "-R", str(n_rep), "-S", "1000", "-O", os.path.join(tmp, "b_%s-%%d.psmc" % m), "--",
+                                "-N%d" % iters, "-t15", "-r5", "-p", PATTERN, path], capture_output=True, text=True, env=env, timeout=600)
+            wall = time.perf_counter() - t0
+            its = [(float(x.group(1)), float(x.group(2))) for x in re.finditer(r"E-steps ([0-9.]+) ms on \d+ device\(s\), M-steps ([0-9.]+) ms", r.stderr)]
+            res[m] = {"rc": r.returncode, "wall_s": round(wall, 2), "per_iteration_ms": [{"esteps": x, "msteps": y} for x, y in its],
+                      "esteps_ms_per_replicate_last": (its[-1][0] / n_rep) if its else None}
+            if r.returncode != 0:
+                res[m]["stderr_tail"] = r.stderr[-300:]
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 class Shard:
@@ -220,6 +342,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="bins for the CPU baseline (0 = skip)")
     ap.add_argument("--exact-extra", type=int, default=1, help="also time 1 exact-mode step (0 = skip)")
     ap.add_argument("--n128-extra", type=int, default=1, help="also time config 5 (128 states, same genome) (0 = skip)")
+    ap.add_argument("--engine", default="dist", choices=["dist", "group"],
+                    help="dist: one process per GPU, torch.distributed (RCCL) all-reduce; group: ONE process, psmc_hip_group_* over --gpus devices (the psmc binary's path)")
+    ap.add_argument("--group-devices", default="", help="engine group: explicit device list, e.g. 0,0 (two shards on one GPU, for testing)")
+    ap.add_argument("--shard-extra", type=int, default=1, help="also time shard-sized inputs + the predicted strong-scaling curve (0 = skip)")
+    ap.add_argument("--group-extra", type=int, default=1, help="also time the C library's own multi-GPU engine beside the headline (0 = skip)")
+    ap.add_argument("--boot-extra", type=int, default=1, help="also run config 4 (16 bootstrap replicates, -N2) through psmc_boot (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (chunk, warmup, ...)")
     args = ap.parse_args()
 
@@ -307,6 +435,35 @@ def main():
         return dt
 
     moving = traj if not args.fixed_params else [(a, e, a0)]
+    if args.engine == "group":
+        # ONE process drives all devices through the C library (what `PSMC_HIP_DEVICES=0,1,.. psmc` does): no torch.distributed
+        if world != 1:
+            raise SystemExit("--engine group is one process: start it with plain `python bench.py --engine group --gpus N`")
+        devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else list(range(args.gpus))
+        if args.scaling == "weak":   # one genome per device, dealt by the library's LPT like any other segment list
+            segs = [s for r in range(len(devices)) for s in sim.simulate_genome(a, e, a0, lens, seed=43 + r)]
+        else:
+            segs = sim.simulate_genome(a, e, a0, lens, seed=43)
+        total_bins = int(sum(len(x) for x in segs))
+        res = group_engine_run(hip, segs, devices, moving, args.steps, args.warmup, mode)
+        ms = res["ms_per_step"]
+        gbs = total_bins * BYTES_PER_BIN / (ms * 1e-3) / 1e9
+        out = {"metric": "genome bins/sec through forward-backward (n=64)", "value": total_bins / (ms * 1e-3), "unit": "bins/s", "n_gpus": len(devices),
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[2]: whole-genome .psmcfa-like batch, %d bins x %d states in %d segments %s, -p %s, one E-step per step, "
+                                      "parameters of a different EM round every step" % (int(lens.sum()), N_STATES, len(lens),
+                                                                                       "per GPU" if args.scaling == "weak" else "sharded over the GPUs", PATTERN),
+                          "engine": "group: one process, psmc_hip_group_* (psmc_amd/csrc/group.hip): LPT partition in C, one host thread per device, blocking call incl. the "
+                                    "34 KB read-back", "mode": args.mode, "bins_total": total_bins, "n_states": N_STATES, "segments": len(segs), "devices": devices,
+                          "sharding": res["reduce"], "selfcheck": res["selfcheck"]},
+               "roofline": {"bound": "hbm", "kernel": "whole E-step (per-kernel rooflines: --engine dist)", "achieved": gbs, "peak": HBM_PEAK_GBS * len(set(devices)), "unit": "GB/s",
+                            "frac": gbs / (HBM_PEAK_GBS * len(set(devices))), "alg_bytes_per_bin": BYTES_PER_BIN, "traffic": None},
+               "first_call_ms": res["first_call_ms"]}
+        if len(devices) == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(a, e, a0, segs, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+        return
     segs, total_bins = workload(args.scaling)
     sh = Shard(hip, torch, segs, N_STATES, local, mode, args.opt)
     es = sh.es
@@ -371,6 +528,18 @@ def main():
                                                  "per bin (no counts GEMM, no bt table); blocking call incl. read-back; moving parameters"}
             except Exception as ex_:
                 out["factored_stats"] = {"error": str(ex_)}
+        if world == 1 and mode == hip.MODE_FAST and args.shard_extra > 0 and not args.fixed_params:
+            try:
+                out["shard_sweep"] = shard_sweep_extra(hip, torch, sim, partition_segments, segs, lens, a, e, a0, moving, local, args.opt, stream, ms_per_step)
+            except Exception as ex_:
+                out["shard_sweep"] = {"error": str(ex_)}
+        if world == 1 and args.group_extra > 0:
+            try:  # the product's own multi-GPU engine on this one device: must reproduce the headline (within 2 %)
+                ge = group_engine_run(hip, segs, [local], moving, args.steps, args.warmup, mode)
+                ge["value"] = total_bins / (ge["ms_per_step"] * 1e-3); ge["vs_headline"] = ms_per_step / ge["ms_per_step"]
+                out["group_engine"] = ge
+            except Exception as ex_:
+                out["group_engine"] = {"error": str(ex_)}
     # ---- config 3 proper beside a weak-scaling headline: ONE genome sharded over the ranks
     if world > 1 and args.scaling == "weak" and mode == hip.MODE_FAST:
         sh.close()
@@ -384,6 +553,27 @@ def main():
                                      "bins_total": total_s, "bins_this_rank": sh.bins,
                                      "note": "config 3: one %d-bin genome, segments LPT-sharded over %d GPUs, 1 all-reduce per step; "
                                              "MAX over ranks like the headline" % (total_s, world)}
+    if world > 1 and args.group_extra > 0 and mode == hip.MODE_FAST and not single_gpu_test:
+        # the C library's own sharding over the same N devices, driven by rank 0 alone while the other ranks wait: what the
+        # psmc binary runs with PSMC_HIP_DEVICES=0..N-1 (the driver's scaling run otherwise only sees the Python path)
+        sh.close()
+        torch.cuda.synchronize(); dist.barrier()
+        if rank == 0:
+            ge = {}
+            for sc_name in ("weak", "strong"):
+                try:
+                    if sc_name == "weak":
+                        gsegs = [x for r in range(world) for x in sim.simulate_genome(a, e, a0, lens, seed=43 + r)]
+                    else:
+                        gsegs = sim.simulate_genome(a, e, a0, lens, seed=43)
+                    r_ = group_engine_run(hip, gsegs, list(range(world)), moving, args.steps, args.warmup, mode)
+                    r_["bins_total"] = int(sum(len(x) for x in gsegs)); r_["value"] = r_["bins_total"] / (r_["ms_per_step"] * 1e-3)
+                    ge[sc_name] = r_
+                except Exception as ex_:
+                    ge[sc_name] = {"error": str(ex_)}
+            ge["note"] = "one process (rank 0), psmc_hip_group_* over devices 0..%d: RCCL all-reduce inside group.hip; compare weak with the headline, strong with strong_scaling" % (world - 1)
+            out["group_engine"] = ge
+        dist.barrier()
     if rank == 0 and world == 1 and args.exact_extra > 0 and mode == hip.MODE_FAST:
         try:
             lens_l = np.array([len(s) for s in segs], dtype=np.int32)
@@ -403,37 +593,76 @@ def main():
     if rank == 0 and world == 1 and args.n128_extra > 0 and mode == hip.MODE_FAST:
         try:  # config 5: -p "64*2", 128 states, the same genome
             g = np.load(os.path.join(ROOT, "tests", "golden", "estep_n128.npz"))
-            a8, e8, a08 = g["n128_curve.a"], g["n128_curve.e"], g["n128_curve.a0"]
+            fixed8 = (g["n128_curve.a"], g["n128_curve.e"], g["n128_curve.a0"])
+            tj8 = os.path.join(ROOT, "tests", "golden", "traj_n128.json")
+            if os.path.exists(tj8) and not args.fixed_params:   # parameters of consecutive EM rounds of `psmc -N25 -p 64*2` on this workload
+                from psmc_amd import hostlib
+                t8 = json.load(open(tj8))
+                mov8 = [hostlib.hmm_params(t8["pattern"], r["params"]) for r in t8["rounds"] if r["round"] >= 1][:25]
+                par8 = "cycle of %d EM rounds: %s" % (len(mov8), t8.get("source", "tests/golden/traj_n128.json"))
+            else:
+                mov8, par8 = [fixed8], "fixed (n128_curve)"
             sh.close()
             s8 = Shard(hip, torch, segs, 128, local, hip.MODE_FAST, args.opt)
-            t1 = time.perf_counter(); s8.es.estep(a8, e8, a08); f8 = (time.perf_counter() - t1) * 1e3
+            t1 = time.perf_counter(); s8.es.estep(*mov8[0]); f8 = (time.perf_counter() - t1) * 1e3
             st8 = torch.zeros(128 * 128 + 2 * 128 + 1, dtype=torch.float64, device="cuda")
-            for _ in range(4):  # the tile plan settles within three E-steps of the same parameters
-                s8.es.estep_device(a8, e8, a08, st8.data_ptr(), stream.cuda_stream)
+            NW8, NT8 = 8, 9   # the 5-step mean after 4 warm-ups still held a learning round (35.8 ms in the driver's run against 27 in ours)
+            run8 = lambda i: s8.es.estep_device(*mov8[i % len(mov8)], st8.data_ptr(), stream.cuda_stream)
+            for i in range(NW8):
+                run8(i)
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                s8.es.estep_device(a8, e8, a08, st8.data_ptr(), stream.cuda_stream)
-            torch.cuda.synchronize()
-            d8 = (time.perf_counter() - t1) / 5
-            kern8 = s8.es.timing()
+            d8, d8min = median_ms(lambda i: run8(NW8 + i), NT8, torch.cuda.synchronize)
+            kern8 = {}
+            for i in range(4):
+                run8(NW8 + NT8 + i); torch.cuda.synchronize()
+                for k, v in s8.es.timing().items():
+                    kern8[k] = kern8.get(k, 0.0) + v / 4
+            diag8 = s8.es.fast_diag()
             fac8 = None
             try:  # the E-step without the 128 x 128 counts (psmc_hip_estep_factored: what `psmc -p 64*2` runs in fast mode)
-                for _ in range(2):
-                    s8.es.estep_factored(a8, e8, a08)
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    s8.es.estep_factored(a8, e8, a08)
-                fac8 = {"ms_per_step": (time.perf_counter() - t1) / 5 * 1e3, "kernels_ms": s8.es.timing()}
-                fac8["value"] = bins / (fac8["ms_per_step"] * 1e-3)
+                for i in range(NW8):
+                    s8.es.estep_factored(*mov8[i % len(mov8)])
+                fm, fmin = median_ms(lambda i: s8.es.estep_factored(*mov8[(NW8 + i) % len(mov8)]), NT8, lambda: None)
+                fac8 = {"ms_per_step": fm, "ms_min": fmin, "kernels_ms": s8.es.timing(), "value": bins / (fm * 1e-3),
+                        "note": "blocking call incl. read-back; median of %d after %d warm-up calls" % (NT8, NW8)}
             except Exception as ex_:
                 fac8 = {"error": str(ex_)}
-            out["n128"] = {"value": bins / d8, "unit": "bins/s", "ms_per_step": d8 * 1e3, "first_call_ms": f8, "kernels_ms": kern8, "factored_stats": fac8,
-                           "config": "configs[4]: -p 64*2 (128 states), %d bins in %d segments, fast mode, fixed parameters" % (bins, len(segs)),
-                           "alg_bytes_per_bin": 16 * 128 + 18, "alg_flop_per_bin_counts": 2 * 128 * 128}
+            # roofline of the back half (k_bwd_count8_struct: backward sweep + 128 x 128 counts, four waves per group of four tiles):
+            # 2 n^2 flop per bin on v_mfma_f64_16x16x4 beside four redundant O(n) sweeps
+            flop8 = 2 * 128 * 128 + 4 * 24 * 128
+            tf8 = bins * flop8 / (kern8["expect"] * 1e-3) / 1e12 if kern8.get("expect", 0) > 0 else 0.0
+            traffic8 = None
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_n128.json")))
+                if abs(pj["bins"] - bins) <= 64:
+                    traffic8 = pj["kernels"]
+            except Exception:
+                pass
+            out["n128"] = {"value": bins / (d8 * 1e-3), "unit": "bins/s", "ms_per_step": d8, "ms_min": d8min, "first_call_ms": f8, "kernels_ms": kern8, "factored_stats": fac8,
+                           "config": "configs[4]: -p 64*2 (128 states), %d bins in %d segments, fast mode; parameters: %s; median of %d steps after %d warm-up steps"
+                                     % (bins, len(segs), par8, NT8, NW8),
+                           "tiles": diag8.get("n_chunks"), "tile_bins": diag8.get("tile_len"), "repair_rounds": [diag8.get("fwd_rounds"), diag8.get("bwd_rounds")],
+                           "alg_bytes_per_bin": 16 * 128 + 18, "alg_flop_per_bin_counts": 2 * 128 * 128,
+                           "roofline": {"bound": "mfma", "kernel": "k_bwd_count8_struct", "launches_per_step": diag8.get("fused_launches", 1), "kernel_ms": kern8.get("expect"),
+                                        "achieved": tf8, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf8 / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop8,
+                                        "mfma_only_frac": bins * 2 * 128 * 128 / (kern8["expect"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS if kern8.get("expect", 0) > 0 else None,
+                                        "hbm": {"alg_bytes_per_bin": 8 * 128 + 9, "achieved_GBs": bins * (8 * 128 + 9) / (kern8["expect"] * 1e-3) / 1e9 if kern8.get("expect", 0) > 0 else None},
+                                        "traffic": traffic8,
+                                        "note": "executed flops: 2 n^2 counts + four waves per group each redoing the 24 n sweep; mfma_only_frac counts the 2 n^2 alone; "
+                                                "traffic = PMC bytes per launch from profiles/pmc_traffic_n128.json (a separate rocprofv3 --pmc pass of this command), null if absent"}}
             s8.close()
         except Exception as ex_:
             out["n128"] = {"error": str(ex_)}
+    if rank == 0 and world == 1 and args.boot_extra > 0 and mode == hip.MODE_FAST:
+        try:  # config 4 through the product binary (every context of this process is closed: the exact batch sizes its groups by the free memory)
+            try:
+                sh.close()
+            except Exception:
+                pass
+            torch.cuda.empty_cache()
+            out["boot"] = boot_extra(sim, a, e, a0)
+        except Exception as ex_:
+            out["boot"] = {"error": str(ex_)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

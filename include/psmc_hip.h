@@ -71,6 +71,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "two_phase"     auto     2: the fused back half runs as two launches, odd tiles of the second list start from the exit
  *                           vector of the tile above instead of speculating backward; 0: every tile speculates, one
  *                           launch when the tiles fit one round.  auto: 2 with two rounds, 0 with one
+ *  "runs_late"     1        two launches of the fused back half: every tile of a glued run is in the second list, so that the
+ *                           first launch waits for the bulk sweeps only and the runs' path (walk -> chain -> run tiles)
+ *                           has until the end of that launch; 0: both launches after the runs' path
  *  "merge1"        auto     1: bulk forward sweep and backward warm-up pass in ONE grid, so that the dispatcher puts
  *                           their waves on distinct SIMDs, and the dependent chain walks -> chains -> run tiles -> back
  *                           half on one stream; 0: side by side on streams of their own.  auto: 1 with one round
@@ -161,6 +164,11 @@ int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err
 /* How much repair the speculation needed: verify/repair rounds and the total
  * number of tile re-runs, forward and backward; out[0..3]. */
 int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
+/* Diagnostic: the plan the NEXT fast E-step of this context will run with: out = {tiles, tile length in bins, mean forward
+ * warm-up of the speculating tiles in bins, mean backward warm-up, longest forward, longest backward, tiles glued to their
+ * predecessor (forward), tiles glued to their successor (backward)}. */
+int psmc_hip_fast_plan(psmc_hip_ctx *ctx, double out[8]);
+
 /* Fast mode, matrices of the PSMC form (two rank-1 triangles, core.c:112-122), any n <= 128: the E-step without the
  * N x N counts.  The EM objective needs of A only  SL_k = sum_{l<k} A[k][l],  SU_k = sum_{l>k} A[k][l],
  * DG_k = A[k][k],  CL_l = sum_{k>l} A[k][l],  CU_l = sum_{k<l} A[k][l]  (psmc_amd/host/mstep.c); they come out

@@ -100,6 +100,8 @@ struct psmc_hip_ctx {
 	int n_long_f = 0, n_long_b = 0, n_mem_f = 0, n_mem_b = 0;
 	int n_B_b = 0, n_list_a = 0, n_list_b = 0; // two-phase plan: trailing backward items that start from above; tile lists of the fused back half
 	int items_two_phase = -1;  // what the current item lists were built for
+	int runs_late = 1;         // "runs_late": two-phase plan, 1 = run tiles go to the second launch of the fused back half
+	bool runs_in_b = false;    // two-phase plan: every tile of a glued run is in the second list of the fused back half (build_items)
 	int *d_ftiles = nullptr;   // [2 * (n_tiles + 4)] tile lists A | B of the fused back half (bit 30: start from the tile above)
 	FastReport report = {0, 0, 0, 0, 1};
 	double *d_stage = nullptr, *d_stats = nullptr;
@@ -290,6 +292,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
+	else if (k == "runs_late") { c->runs_late = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
 	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->kc_sub_set = true; c->plan_dirty = true; c->items_dirty = true; }
@@ -717,12 +720,18 @@ static int plan_fast(psmc_hip_ctx *c)
 	// directions (no second list to wait for), phase 1 is ONE grid (merge1) so that its waves land on distinct SIMDs, and a
 	// tile that fails is glued at once instead of getting a doubled warm-up first (a 6144-step item would be the critical
 	// path of a phase that is otherwise (T + W) steps long).
-	const int64_t ROUND = 4096;
+	// (Tried in round 3 and removed: two / four waves per group of four tiles in the fused back half, each owning a half / a
+	// quarter of the 64 x 64 partial, so that a round is 2048 / 1024 tiles of twice / four times the length and phase 1 has
+	// half / a quarter of the warm-ups.  Parity-green and slower at every shard size -- 3.75 M bins: 4.5 / 5.7 ms against
+	// 3.5; 7.5 M: 7.6 / 9.9 against 5.2; profiles/r03_count_waves_sweep.txt -- a step of the back half got 1.0x / 1.9x
+	// faster where the instruction counts promised 1.6x / 2.6x, and phase 1 is bound by the runs' transfer matrices and
+	// walks, not by the bulk warm-ups alone.)
+	const int64_t ROUND1 = 4096;
 	bool one_round = false;
 	if (T <= 0) { // auto: about target_waves (dense: 1 tile per wave) or struct_tiles (4 per wave) tiles, never below 256 bins
 		int64_t want = st ? c->struct_tiles : c->target_waves;
-		if (st && !c->struct_tiles_set && bins < 2 * ROUND * (int64_t)std::max(c->warmup, 1)) {
-			want = std::max<int64_t>(ROUND - (int64_t)c->work.size(), ROUND / 2); // every segment ends in a ragged tile: stay inside the round
+		if (st && !c->struct_tiles_set && bins < 2 * ROUND1 * (int64_t)std::max(c->warmup, 1)) {
+			want = std::max<int64_t>(ROUND1 - (int64_t)c->work.size(), ROUND1 / 2); // every segment ends in a ragged tile: stay inside the round
 			one_round = true;
 		}
 		T = (int)((bins + want - 1) / want);
@@ -734,7 +743,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		for (int32_t lo = 1; lo <= c->L[s]; lo += T) {
 			Chunk ch;
 			ch.off = c->off[s]; ch.L = c->L[s]; ch.lo = lo; ch.hi = std::min(c->L[s], lo + T - 1); ch.mult = c->mult[w];
-			ch.flags = 0; ch.wsh = 0;
+			ch.flags = 0; ch.wf = ch.wb = c->warmup;
 			if (ch.lo - c->warmup <= 1) ch.flags |= CHUNK_ANCHOR_F;
 			if ((int64_t)ch.hi + c->warmup + 1 >= ch.L) ch.flags |= CHUNK_ANCHOR_B;
 			if (ch.hi == ch.L) ch.flags |= CHUNK_LAST;
@@ -744,7 +753,7 @@ static int plan_fast(psmc_hip_ctx *c)
 	const int nc = (int)c->chunks.size();
 	c->chunk_used = T;
 	c->planned_struct = st;
-	one_round = st && nc <= ROUND; // also when the caller chose the tile length
+	one_round = st && nc <= ROUND1; // also when the caller chose the tile length
 	c->two_phase_used = c->two_phase >= 0 ? c->two_phase : (one_round ? 0 : 2);
 	c->merge1_used = c->merge1 >= 0 ? c->merge1 : (one_round ? 1 : 0);
 	c->warm_shift_used = c->warm_shift_set ? c->warm_shift : (one_round ? 0 : 1);
@@ -798,25 +807,43 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	// key: glued runs first (launched apart from the bulk), then phase A longest first, then phase B
 	std::vector<std::pair<long long, std::pair<int, int>>> kf, kb; // (key, (first, count))
 	auto key = [](int steps, int count, bool phase_b) { return (count > 1 ? -(1ll << 40) : (phase_b ? (1ll << 40) : 0ll)) - steps; };
-	std::vector<char> from_above(nc, 0);
+	std::vector<char> from_above(nc, 0), in_run(nc, 0); // in_run: member of a glued run of either direction
 	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
 		int e = b + 1;
 		while (e < nc && c->glue_f[e] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
 		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
 		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, e - b, false), {b, e - b}});
+		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = 1;
 		b = e;
 	}
+	std::vector<std::pair<int, int>> gb; // backward groups (first, count)
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
 		int e = b + 1;
 		while (e < nc && c->glue_b[e - 1] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap &&
 		       c->chunks[e].lo < c->chunks[e].L) // a last tile holding only position L owns no transition: never a group's top
 			++e;
+		gb.push_back({b, e - b});
+		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = 1;
+		b = e;
+	}
+	// Run tiles in the SECOND launch (round 3).  The first launch of the fused back half then waits for the bulk sweeps only
+	// and the runs' path (walk -> transfer-matrix chain -> run tiles, the longest dependency chain of phase 1) has until the
+	// end of that launch to finish.  A tile above a from-above tile must be in the first list, so a tile under a run
+	// member speculates like an even one; and the second list must still fit one round of waves, so from-above tiles
+	// make room for the run members (they speculate again: one more warm-up each in the backward pass of phase 1).
+	int n_run = 0;
+	for (int b = 0; b < nc; ++b) n_run += in_run[b];
+	const int cap_b = (nc + 7) / 8 * 4; // half of the tiles, in whole groups of four
+	c->runs_in_b = two_phase_bwd && c->runs_late && n_run > 0 && n_run <= cap_b / 2;
+	int above_budget = c->runs_in_b ? cap_b - n_run : nc;
+	for (const auto &gr : gb) {
+		const int b = gr.first, e = b + gr.second;
 		const Chunk &lo = c->chunks[b], &top = c->chunks[e - 1];
 		// from above: the tile over it must exist in the segment and own a transition (it leaves an exit vector)
-		const bool pb = two_phase_bwd && e - b == 1 && odd[b] && b + 1 < nc && c->chunks[b + 1].off == lo.off && c->chunks[b + 1].lo < c->chunks[b + 1].L;
-		if (pb) from_above[b] = 1;
+		bool pb = two_phase_bwd && e - b == 1 && odd[b] && b + 1 < nc && c->chunks[b + 1].off == lo.off && c->chunks[b + 1].lo < c->chunks[b + 1].L;
+		if (pb && c->runs_in_b && (in_run[b] || in_run[b + 1] || above_budget <= 0)) pb = false;
+		if (pb) { from_above[b] = 1; --above_budget; }
 		kb.push_back({key(std::min(top.hi + chunk_warm_b(top, W) + 1, top.L) - lo.lo, e - b, pb), {b, e - b}});
-		b = e;
 	}
 	std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
 	// layout of d_items (ints): items_f | items_b | ritems_f | ritems_b | members_f | members_b, 2*nc each
@@ -847,6 +874,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 		for (int b = 0; b < nc; ++b) {
 			if (from_above[b]) lb.push_back(b | (1 << 30));
 			else if (b > 0 && from_above[b - 1]) la.push_back(b);
+			else if (c->runs_in_b && in_run[b]) lb.push_back(b);
 			else freet.push_back(b);
 		}
 		const bool single = lb.empty() && nc <= 4096; // one round of waves holds every tile: one launch, nothing to balance
@@ -922,28 +950,36 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	return 0;
 }
 
-// Tiles a repair round had to touch start where the chain forgets slowly: glue each to the neighbour it
-// depends on, so that from the next E-step on one row walks the region while the sweep is still running.
-// First a longer warm-up of its own ("warm_shift": warmup << shift bins, 6144 by default -- the chain forgets in 2-4 k bins
-// almost everywhere, and a warm-up costs 21 vector instructions per bin against the 1360 per bin of a transfer matrix),
-// and only a tile that fails again is glued.  Measured on the benchmark genome (profiles/r02_warm_shift_ab.json): 3072 +
-// one doubling beats the 4096 of round 1 by 3-4 % (full counts) and 12 % (factored statistics); longer second
+// Tiles a repair round had to touch start where the chain forgets slowly: first a longer warm-up of their own
+// ("warm_shift": up to warmup << shift bins; a tile's warm-up lengths are its own, Chunk::wf / wb), then glue each to the
+// neighbour it depends on, so that from the next E-step on one row walks the region (or a chain of transfer matrices
+// crosses it) while the sweep is still running.  Measured on the benchmark genome (profiles/r02_warm_shift_ab.json):
+// 3072 + one doubling beats the 4096 of round 1 by 3-4 % (full counts) and 12 % (factored statistics); longer second
 // warm-ups (16 K, 32 K) cost more than the runs they avoid, because a 20 k-step item is as long as the whole phase.
+//
+// Tried in round 3 and removed: warm-ups that FOLLOW the measured mismatch of every tile's speculation (k_verify left it
+// in host-mapped memory; log10(err) ~ -w / lambda_t gives the length that lands two decades below the tolerance, a
+// measurement at the rounding floor shrinks the warm-up by an eighth per E-step).  It works as intended -- the mean
+// warm-up of the benchmark genome falls from 3271 to 2200 bins in 17 E-steps, parity-green -- and buys nothing: the
+// steady-state E-step stays at 12.9-13.0 ms (3.75 M-bin share: 2.97 vs 3.0), because phase 1 ends when the runs' path
+// (walk -> transfer-matrix chain -> run tiles) does, not when the bulk warm-ups do; and while it adapts, 5-30 of 8127
+// tiles per E-step overshoot and fail, and ONE repair round costs 8 ms at this size (20-24 ms per E-step for the first
+// 17): profiles/r03_adaptive_warmup_trace.txt.
 static void learn_groups(psmc_hip_ctx *c)
 {
-	const int nc = (int)c->chunks.size();
-	const int step = c->warm_shift_used;
+	const int nc = (int)c->chunks.size(), W = c->warmup;
+	const int cap = W << c->warm_shift_used;
 	for (int b : c->flagged_f)
 		if (b > 0 && b < nc && !c->glue_f[b] && c->chunks[b - 1].off == c->chunks[b].off) {
 			Chunk &ch = c->chunks[b];
-			if (step > 0 && (ch.wsh & 15) == 0 && ch.lo - c->warmup > 1) { ch.wsh |= step; c->chunks_dirty = true; } // not yet tried, and there is sequence to warm up on
+			if (ch.wf < cap && ch.lo - ch.wf > 1) { ch.wf = std::min(cap, std::max(2 * ch.wf, W)); c->chunks_dirty = true; } // not yet at the cap, and there is sequence left to warm up on
 			else c->glue_f[b] = 1;
 			c->items_dirty = true;
 		}
 	for (int b : c->flagged_b)
 		if (b >= 0 && b + 1 < nc && !c->glue_b[b] && c->chunks[b + 1].off == c->chunks[b].off) {
 			Chunk &ch = c->chunks[b];
-			if (step > 0 && ((ch.wsh >> 4) & 15) == 0 && (int64_t)ch.hi + c->warmup + 1 < ch.L) { ch.wsh |= step << 4; c->chunks_dirty = true; }
+			if (ch.wb < cap && (int64_t)ch.hi + ch.wb + 1 < ch.L) { ch.wb = std::min(cap, std::max(2 * ch.wb, W)); c->chunks_dirty = true; }
 			else c->glue_b[b] = 1;
 			c->items_dirty = true;
 		}
@@ -979,7 +1015,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 		c->chunks_dirty = false;
 	}
 	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase_bwd))) return rc;
-	p.n_B_b = c->n_B_b; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
+	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
 	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;
@@ -1091,6 +1127,20 @@ extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[8])
 	out[0] = c->use_struct ? 1 : 0; out[1] = c->chunk_used; out[2] = c->use_struct ? c->n_items_f : (int)c->chunks.size();
 	out[3] = c->use_struct ? c->n_items_b : (int)c->chunks.size();
 	out[4] = c->last_fused; out[5] = c->last_ckpt; out[6] = c->timing_two_launches ? 2 : 1; out[7] = c->merge1_used;
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_fast_plan(psmc_hip_ctx *c, double out[8])
+{
+	if (!c || !out) return PSMC_HIP_EINVAL;
+	const int nc = (int)c->chunks.size();
+	double sf = 0, sb = 0, mf = 0, mb = 0; int nf = 0, nb = 0, gf = 0, gb = 0;
+	for (int b = 0; b < nc; ++b) {
+		const Chunk &ch = c->chunks[b];
+		if (c->glue_f[b]) ++gf; else if (!(ch.flags & CHUNK_ANCHOR_F)) { sf += ch.wf; mf = std::max(mf, (double)ch.wf); ++nf; }
+		if (c->glue_b[b]) ++gb; else if (!(ch.flags & (CHUNK_ANCHOR_B | CHUNK_LAST))) { sb += ch.wb; mb = std::max(mb, (double)ch.wb); ++nb; }
+	}
+	out[0] = nc; out[1] = c->chunk_used; out[2] = nf ? sf / nf : 0.0; out[3] = nb ? sb / nb : 0.0; out[4] = mf; out[5] = mb; out[6] = gf; out[7] = gb;
 	return PSMC_HIP_OK;
 }
 
@@ -1282,7 +1332,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
 		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
 		k->fuse128 = c->fuse128;
-		k->merge1 = c->merge1; k->warm_shift_set = c->warm_shift_set; k->kc_sub_set = c->kc_sub_set;
+		k->merge1 = c->merge1; k->runs_late = c->runs_late; k->warm_shift_set = c->warm_shift_set; k->kc_sub_set = c->kc_sub_set;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];

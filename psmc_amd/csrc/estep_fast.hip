@@ -672,12 +672,14 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles; merged: and the start vectors of the same grid
 		// boundary vectors and X of the run tiles (fused == 2, missing until round 2: a tile of a forward run is an ordinary
 		// single tile of the bulk pass below, which could read its X before it was written; found with PSMC_HIP_POISON=vary)
-		if (lw && ov && sw != sa) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
+		const bool late = p.fused == 1 && p.runs_in_b && p.n_list_b > 0; // every run tile is in the second list: the first launch does not wait for the runs' path
+		if (lw && ov && sw != sa && !late) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
 		if (p.fused == 2) launch_bwd_acc(p, sa, 0, fb0, p.n_items_b - fb0);
 		else {
 			launch_bwd_count(p, sa, 0, false);
 			if (p.n_list_b > 0) { // its tiles start from the exit vectors list A left
+				if (lw && ov && sw != sa && late) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
 				(void)hipEventRecord(p.evx[11], sa);
 				(void)hipEventRecord(p.evx[12], sa);
 				launch_bwd_count(p, sa, 1, false);
@@ -839,8 +841,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 					const int en = tl[4 * (size_t)g2 + r];
 					if (en < 0) { fprintf(stderr, " -"); continue; }
 					const int t = en & ~(1 << 30);
-					fprintf(stderr, " %d%s[lo %d hi %d L %d off %lld mult %d flags %d wsh %d tf %d tb %d; above tf %d tb %d]", t, (en & (1 << 30)) ? "^" : "", ch[t].lo, ch[t].hi, ch[t].L, (long long)ch[t].off,
-					        (int)ch[t].mult, (int)ch[t].flags, (int)ch[t].wsh, tf[t], tb[t], t + 1 < p.n_chunks ? tf[t + 1] : -1, t + 1 < p.n_chunks ? tb[t + 1] : -1);
+					fprintf(stderr, " %d%s[lo %d hi %d L %d off %lld mult %d flags %d warm-up %d/%d tf %d tb %d; above tf %d tb %d]", t, (en & (1 << 30)) ? "^" : "", ch[t].lo, ch[t].hi, ch[t].L, (long long)ch[t].off,
+					        (int)ch[t].mult, (int)ch[t].flags, (int)ch[t].wf, (int)ch[t].wb, tf[t], tb[t], t + 1 < p.n_chunks ? tf[t + 1] : -1, t + 1 < p.n_chunks ? tb[t + 1] : -1);
 				}
 				fprintf(stderr, "\n");
 			}

@@ -61,6 +61,8 @@ struct psmc_hip_group {
 	std::vector<std::vector<int32_t>> segs_of;  // global segment ids of each shard, ascending
 	std::vector<int32_t> shard_of, local_of;     // per global segment
 	std::vector<double *> d_stats;               // per shard: the vector the collective runs on
+	std::vector<double *> h_stats;               // per shard: pinned host copy of it (asynchronous read-back on the shard's stream)
+	size_t stats_len = 0;
 	std::vector<hipStream_t> st;
 	std::string err;
 	int want_rccl = -1;                          // "rccl": -1 auto (distinct devices, more than one shard), 0 never, 1 always
@@ -84,12 +86,14 @@ extern "C" int psmc_hip_group_create(psmc_hip_group **out, int n_states, int n_d
 	g->dev.assign(devices, devices + n_dev);
 	for (int i = 0; i < n_dev; ++i)
 		for (int j = 0; j < i; ++j) if (devices[i] == devices[j]) g->distinct = false;
-	g->sh.assign(n_dev, nullptr); g->d_stats.assign(n_dev, nullptr); g->st.assign(n_dev, nullptr);
+	g->sh.assign(n_dev, nullptr); g->d_stats.assign(n_dev, nullptr); g->h_stats.assign(n_dev, nullptr); g->st.assign(n_dev, nullptr);
 	for (int i = 0; i < n_dev; ++i) {
 		int rc = psmc_hip_create(&g->sh[i], n_states, devices[i], mode);
 		if (rc == 0 && mode == PSMC_HIP_MODE_FAST) {
 			const size_t len = std::max((size_t)n_states * n_states + 2 * (size_t)n_states + 1, (size_t)7 * n_states + 1); // [A | E | LL], or the factored statistics (longer below 5 states)
+			g->stats_len = len;
 			if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc((void **)&g->d_stats[i], sizeof(double) * len) != hipSuccess ||
+			    hipHostMalloc((void **)&g->h_stats[i], sizeof(double) * len, hipHostMallocDefault) != hipSuccess ||
 			    hipStreamCreateWithFlags(&g->st[i], hipStreamNonBlocking) != hipSuccess) rc = PSMC_HIP_EDEVICE;
 		}
 		if (rc) { psmc_hip_group_destroy(g); return rc; }
@@ -106,6 +110,7 @@ extern "C" void psmc_hip_group_destroy(psmc_hip_group *g)
 		if (g->dev.size() > (size_t)i) (void)hipSetDevice(g->dev[i]);
 		if (g->st[i]) { (void)hipStreamSynchronize(g->st[i]); (void)hipStreamDestroy(g->st[i]); }
 		if (g->d_stats[i]) (void)hipFree(g->d_stats[i]);
+		if (g->h_stats[i]) (void)hipHostFree(g->h_stats[i]);
 		if (g->sh[i]) psmc_hip_destroy(g->sh[i]);
 	}
 	delete g;
@@ -169,10 +174,14 @@ template <class F> static int for_shards(psmc_hip_group *g, F f)
 {
 	std::vector<int> rc(g->n_sh, 0);
 	std::vector<std::thread> th;
-	for (int s = 0; s < g->n_sh; ++s) {
-		if (g->segs_of[s].empty()) continue;
-		th.emplace_back([&, s]() { rc[s] = f(s); });
-	}
+	int n_live = 0, only = -1;
+	for (int s = 0; s < g->n_sh; ++s) if (!g->segs_of[s].empty()) { ++n_live; only = s; }
+	if (n_live == 1) rc[only] = f(only); // one shard: the caller's thread (a thread start and join cost as much as the whole tail of an E-step)
+	else
+		for (int s = 0; s < g->n_sh; ++s) {
+			if (g->segs_of[s].empty()) continue;
+			th.emplace_back([&, s]() { rc[s] = f(s); });
+		}
 	for (std::thread &t : th) t.join();
 	for (int s = 0; s < g->n_sh; ++s)
 		if (rc[s]) return gfail(g, rc[s], std::string("shard ") + std::to_string(s) + " (device " + std::to_string(g->dev[s]) + "): " + psmc_hip_last_error(g->sh[s]));
@@ -216,17 +225,24 @@ static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &ou
 		if (r != ncclSuccess || r2 != ncclSuccess) return gfail(g, PSMC_HIP_EDEVICE, std::string("ncclAllReduce: ") + g->rccl.GetErrorString(r != ncclSuccess ? r : r2));
 		for (int s = 0; s < g->n_sh; ++s) { (void)hipSetDevice(g->dev[s]); if (hipStreamSynchronize(g->st[s]) != hipSuccess) return gfail(g, PSMC_HIP_EDEVICE, "stream sync after all-reduce"); }
 		(void)hipSetDevice(g->dev[0]);
-		if (hipMemcpy(out.data(), g->d_stats[0], sizeof(double) * len, hipMemcpyDeviceToHost) != hipSuccess) return gfail(g, PSMC_HIP_EDEVICE, "copy of the reduced statistics");
+		if (hipMemcpyAsync(g->h_stats[0], g->d_stats[0], sizeof(double) * len, hipMemcpyDeviceToHost, g->st[0]) != hipSuccess || hipStreamSynchronize(g->st[0]) != hipSuccess)
+			return gfail(g, PSMC_HIP_EDEVICE, "copy of the reduced statistics");
+		memcpy(out.data(), g->h_stats[0], sizeof(double) * len);
 		g->last_reduce = 1;
 		return 0;
 	}
-	std::vector<double> tmp(len);
+	for (int s = 0; s < g->n_sh; ++s) { // every shard's read-back is queued behind its E-step on its own stream, then waited for in shard order
+		if (!live[s]) continue;
+		(void)hipSetDevice(g->dev[s]);
+		if (hipMemcpyAsync(g->h_stats[s], g->d_stats[s], sizeof(double) * len, hipMemcpyDeviceToHost, g->st[s]) != hipSuccess)
+			return gfail(g, PSMC_HIP_EDEVICE, "copy of a shard's statistics");
+	}
 	for (int s = 0; s < g->n_sh; ++s) {
 		if (!live[s]) continue;
 		(void)hipSetDevice(g->dev[s]);
-		if (hipStreamSynchronize(g->st[s]) != hipSuccess || hipMemcpy(tmp.data(), g->d_stats[s], sizeof(double) * len, hipMemcpyDeviceToHost) != hipSuccess)
-			return gfail(g, PSMC_HIP_EDEVICE, "copy of a shard's statistics");
-		if (s == first) out = tmp; else for (size_t i = 0; i < len; ++i) out[i] += tmp[i];
+		if (hipStreamSynchronize(g->st[s]) != hipSuccess) return gfail(g, PSMC_HIP_EDEVICE, "copy of a shard's statistics");
+		const double *tmp = g->h_stats[s];
+		if (s == first) memcpy(out.data(), tmp, sizeof(double) * len); else for (size_t i = 0; i < len; ++i) out[i] += tmp[i];
 	}
 	g->last_reduce = n_live > 1 ? 2 : 0;
 	return 0;

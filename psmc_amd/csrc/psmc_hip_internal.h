@@ -20,11 +20,11 @@ struct Chunk {
 	int32_t hi;   // last position owned by the tile
 	int32_t mult; // how many times the segment occurs in the selection (bootstrap)
 	int32_t flags; // CHUNK_*
-	int32_t wsh;  // structured sweeps: the tile's speculative warm-up is warmup << shift; bits 0-3 forward, 4-7 backward
+	int32_t wf, wb; // structured sweeps: the tile's own speculative warm-up in bins, forward / backward (api.hip learn_groups:
+	                // starts at the "warmup" option and grows after a failure)
 };
-// a tile whose speculation failed gets a longer warm-up before it is glued to its neighbour (api.hip learn_groups)
-__host__ __device__ inline int chunk_warm_f(const Chunk &c, int W) { return W << (c.wsh & 15); }
-__host__ __device__ inline int chunk_warm_b(const Chunk &c, int W) { return W << ((c.wsh >> 4) & 15); }
+__host__ __device__ inline int chunk_warm_f(const Chunk &c, int) { return c.wf; }
+__host__ __device__ inline int chunk_warm_b(const Chunk &c, int) { return c.wb; }
 constexpr int CHUNK_ANCHOR_F = 1; // forward speculation started at the true segment start: exact
 constexpr int CHUNK_ANCHOR_B = 2; // backward speculation started at the true segment end: exact
 constexpr int CHUNK_LAST = 4;     // last tile of its segment
@@ -72,6 +72,7 @@ struct EstepLaunch {
 	int n_mem_f, n_mem_b;
 	int n_B_b;                        // trailing backward items of the two-phase plan: they start from the exit vector of the tile above (second list of the fused back half)
 	const int *d_ftiles; int n_list_a, n_list_b; // fused back half: tile lists A | B (each padded to a multiple of 4 with -1)
+	int runs_in_b;                    // ... and every tile of a glued run is in list B: only the second launch waits for the runs' path
 	hipStream_t stream4, stream5;
 	// walks: heads of the chain runs (count 1) followed by the short runs; transfer-matrix chains of the long runs
 	const int *d_wl_f, *d_wl_b; int n_wl_f, n_wl_b;

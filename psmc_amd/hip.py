@@ -28,7 +28,7 @@ EXPORTS = [
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
-    "psmc_hip_pipe_probe2", "psmc_hip_place_probe", "psmc_hip_group_selfcheck",
+    "psmc_hip_pipe_probe2", "psmc_hip_place_probe", "psmc_hip_group_selfcheck", "psmc_hip_fast_plan",
     "psmc_hip_group_create", "psmc_hip_group_destroy", "psmc_hip_group_last_error", "psmc_hip_group_set_option",
     "psmc_hip_group_load_segments", "psmc_hip_group_estep", "psmc_hip_group_estep_factored", "psmc_hip_group_info",
     "psmc_hip_group_route", "psmc_hip_estep_factored_device",
@@ -261,6 +261,14 @@ class HipEStep:
                     structured=bool(fi[0]), tile_len=fi[1], items_fwd=fi[2], items_bwd=fi[3], back_half=fi[4], ckpt=bool(fi[5]),
                     fused_launches=fi[6], merged_phase1=fi[7])
 
+    def fast_plan(self):
+        """The plan of the next fast E-step: tiles, tile length, mean / longest warm-ups (bins), glued tiles."""
+        o = np.zeros(8)
+        self.lib.psmc_hip_fast_plan.argtypes = [C.c_void_p, _dp]
+        self._chk(self.lib.psmc_hip_fast_plan(self.h, _p(o)), "fast_plan")
+        return dict(tiles=int(o[0]), tile_len=int(o[1]), warm_fwd_mean=o[2], warm_bwd_mean=o[3], warm_fwd_max=int(o[4]), warm_bwd_max=int(o[5]),
+                    glued_fwd=int(o[6]), glued_bwd=int(o[7]))
+
     def tables(self, seg, want_b=True):
         L = int(self.lens[seg])
         f = np.zeros((L, self.n)); s = np.zeros(L)
@@ -481,6 +489,15 @@ class HipGroup:
         sums = np.zeros((5, n)); E = np.zeros((2, n)); LL = C.c_double(0)
         self._chk(self.lib.psmc_hip_group_estep_factored(self.g, _p(a), _p(e), _p(a0), _p(sums), _p(E), C.byref(LL)), "group_estep_factored")
         return dict(sums=sums, E=E, LL=LL.value)
+
+    def selfcheck(self):
+        """First contact with the devices of the group: dict(shards, path ('rccl' / 'host_sum' / 'single' / 'exact'), communicator,
+        note) -- raises HipError naming the step that failed (psmc_hip_group_selfcheck)."""
+        out = (C.c_int * 4)()
+        self.lib.psmc_hip_group_selfcheck.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._chk(self.lib.psmc_hip_group_selfcheck(self.g, out), "group_selfcheck")
+        note = self.lib.psmc_hip_group_last_error(self.g).decode() if out[3] else ""
+        return dict(shards=out[0], path={0: "single", 1: "rccl", 2: "host_sum", 3: "exact"}[out[1]], communicator=bool(out[2]), note=note)
 
     def info(self):
         ns = C.c_int(0); lr = C.c_int(0); so = np.zeros(max(self.n_seg, 1), dtype=np.int32)

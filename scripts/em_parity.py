@@ -95,7 +95,8 @@ def compare(name, infile, cwd, ref_text=None):
         per = []
         for a, b in zip(outs[cfg], ex):
             per.append(dict(round=a["round"], LK=rel(a["LK"], b["LK"]), theta=rel(a["theta"], b["theta"]), rho=rel(a["rho"], b["rho"]),
-                            lam_max=rel(a["lam"], b["lam"]), lam_median=float(np.median(np.abs(np.array(a["lam"]) - np.array(b["lam"])) / np.array(b["lam"])))))
+                            lam_max=rel(a["lam"], b["lam"]), rs_lam_max=(rel(a["rs_lam"], b["rs_lam"]) if a["rs_lam"] and len(a["rs_lam"]) == len(b["rs_lam"]) else None),
+                            rs_t_max=(rel(a["rs_t"][1:], b["rs_t"][1:]) if len(a["rs_t"]) > 1 and len(a["rs_t"]) == len(b["rs_t"]) else None), lam_median=float(np.median(np.abs(np.array(a["lam"]) - np.array(b["lam"])) / np.array(b["lam"])))))
         res["runs"][cfg]["deviation_vs_exact_per_round"] = per
         res["runs"][cfg]["max_over_rounds"] = {k: max(p[k] for p in per) for k in ("LK", "theta", "rho", "lam_max")}
         res["runs"][cfg]["final_round"] = per[-1]

@@ -79,7 +79,7 @@ def main():
                 r = {"workload": name, "bins": bins, "segments": len(segs), "cfg": cfg, "ms_median": float(np.median(ts)), "ms_min": float(min(ts)),
                      "ms_max": float(max(ts)), "bins_per_s": bins / (float(np.median(ts)) * 1e-3), "tiles": d["n_chunks"], "tile_len": d["tile_len"],
                      "items": [d["items_fwd"], d["items_bwd"]], "repairs": [d["fwd_rounds"], d["bwd_rounds"], d["fwd_tiles"], d["bwd_tiles"]],
-                     "kernels_ms": {k: round(float(v), 3) for k, v in kern.items()}}
+                     "kernels_ms": {k: round(float(v), 3) for k, v in kern.items()}, "plan": es.fast_plan()}
             except Exception as ex:  # one bad option set must not lose the sweep
                 r = {"workload": name, "bins": bins, "cfg": cfg, "error": str(ex)}
             res.append(r)

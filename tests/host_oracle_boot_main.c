@@ -50,7 +50,11 @@ static int ob_estep_batch(void *self, int dev, int n_rep, const double *a, const
 	return 0;
 }
 static const char *ob_error(void *self, int dev) { return "oracle batch backend"; }
-static void ob_destroy(void *self) {}
+static void ob_destroy(void *self)
+{
+	orc_bb *o = (orc_bb *)self;
+	free((void *)o->sym); free(o->L); o->sym = 0; o->L = 0;
+}
 
 int main(int argc, char **argv)
 {	/* host_oracle_boot R SEED PATTERN <psmc options> input */
@@ -69,5 +73,9 @@ int main(int argc, char **argv)
 	orc_bb ob; memset(&ob, 0, sizeof ob);
 	ob.n = pat.n_states;
 	psmc_batch_backend bb = {&ob, 2, ob_load, ob_estep_batch, ob_error, ob_destroy, o.fast_mstep};
-	return psmc_boot_run(&o, n_rep, seed0, pattern, &bb);
+	const int status = psmc_boot_run(&o, n_rep, seed0, pattern, &bb);
+	bb.destroy(bb.self);
+	psmc_pattern_free(&pat);
+	psmc_options_free(&o);
+	return status;
 }

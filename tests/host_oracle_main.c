@@ -67,7 +67,12 @@ static int ob_tables(void *self, int seg, double *f, double *b, double *s)
 	return 0;
 }
 static const char *ob_error(void *self) { return "oracle backend"; }
-static void ob_destroy(void *self) {}
+static void ob_destroy(void *self)
+{
+	orc_be *o = (orc_be *)self;
+	free((void *)o->sym); free(o->L); free(o->a); free(o->e); free(o->a0);
+	o->sym = 0; o->L = 0; o->a = o->e = o->a0 = 0;
+}
 
 int main(int argc, char **argv)
 {
@@ -85,5 +90,9 @@ int main(int argc, char **argv)
 	ob.a = (double *)malloc(sizeof(double) * ob.n * ob.n); ob.e = (double *)malloc(sizeof(double) * 3 * ob.n); ob.a0 = (double *)malloc(sizeof(double) * ob.n);
 	const int fac = o.fast_mstep && getenv("PSMC_FACTORED") && atoi(getenv("PSMC_FACTORED")) != 0;
 	psmc_estep_backend be = {&ob, ob_load, ob_estep, ob_tables, 0, fac ? ob_estep_factored : 0, ob_error, ob_destroy, 0, 0};
-	return psmc_run(&o, &be);
+	const int status = psmc_run(&o, &be);
+	be.destroy(be.self);
+	psmc_pattern_free(&pat);
+	psmc_options_free(&o);
+	return status;
 }

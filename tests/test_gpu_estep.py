@@ -41,10 +41,14 @@ def test_device_probes(hip):
     assert all(100.0 < v < 20000.0 for v in hb.values()), hb
     lp = hip.load_probe(256, 400)
     assert 100.0 < lp["cycles_per_step"] < 2000.0 and 500.0 < lp["mhz"] < 4000.0, lp
-    lp8 = hip.load_probe(256, -400)  # eight tiles per wave
-    assert lp8["cycles_per_step"] / 8 < lp["cycles_per_step"] / 4, (lp, lp8)
     mb = hip.microbench()
     assert len(mb) == len(hip.MICROBENCH_NAMES) and all(v > 0 for v in mb.values())
+    # round 3: nothing of another wave overlaps with v_mfma_f64 on the same SIMD (the matrix wave keeps its time, the pair takes the sum)
+    alone = hip.pipe_probe2(["mfma_f64"] * 4)
+    pair = hip.pipe_probe2(["mfma_f64"] * 4 + ["scan_levels"] * 4)
+    assert 3000 < alone[0] < 6000 and pair[4] > 1.5 * alone[0], (alone, pair)
+    pl = hip.place_probe(512, 1, 1, 400)   # one grid of 512 waves: every wave on a SIMD of its own
+    assert pl["waves"] == 512 and pl["max_waves_per_simd"] == 1, pl
 
 
 def test_device_primitives(hip):
@@ -351,7 +355,8 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
                                   dict(two_phase=2), dict(chunk=256, warmup=512, two_phase=2), dict(GENOME), dict(chunk=256, warmup=512, **GENOME), dict(chunk=768, warmup=256, overlap=0, **GENOME), dict(chunk=768, warmup=64, merge1=0),
-                                  dict(merge1=1, two_phase=2), dict(chunk=256, warmup=512, merge1=1, warm_shift=1), dict(chunk=1000, warmup=100, kc_sub=2)])
+                                  dict(merge1=1, two_phase=2), dict(chunk=256, warmup=512, merge1=1, warm_shift=1), dict(chunk=1000, warmup=100, kc_sub=2),
+                                  dict(chunk=1000, warmup=100, **GENOME)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is
@@ -407,7 +412,8 @@ def test_fast_n128(hip, golden, oracle, opts):
 
 @pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, merge1=0),
                                   dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=5000, warmup=16, overlap=0),
-                                  dict(chunk=100, warmup=30, two_phase=2), dict(chunk=37, warmup=5, group_cap=3000, **GENOME), dict(chunk=64, warmup=0, warm_shift=1)])
+                                  dict(chunk=100, warmup=30, two_phase=2), dict(chunk=37, warmup=5, group_cap=3000, **GENOME), dict(chunk=64, warmup=0, warm_shift=1),
+                                  dict(chunk=64, warmup=0, two_phase=2)])
 def test_fast_odd_tilings(hip, golden, oracle, opts):
     """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
     everything is repaired / learned into runs and stays inside the tolerance."""
@@ -793,4 +799,56 @@ def test_group_with_more_shards_than_segments(hip, golden, oracle):
     g.load_segments(segs)
     check_fast(g.estep(p["a"], p["e"], p["a0"]), o)
     assert g.info()["last_reduce"] == 2
+    g.close()
+
+
+@pytest.mark.parametrize("devices,rccl,path", [([0], -1, "single"), ([0, 0], -1, "host_sum"), ([0], 1, "rccl"), ([0, 0, 0], 0, "host_sum")])
+def test_group_selfcheck(hip, devices, rccl, path):
+    """First contact with a device list before any segment is loaded: shard s puts s + 1 into its vector with an
+    asynchronous copy on its E-step stream, the exchange follows on the same stream and must return n(n+1)/2 -- through
+    the RCCL communicator (rccl=1: a one-device communicator on this box) or the host sum.  What bench.py --engine
+    group calls before it times anything."""
+    g = hip.HipGroup(64, devices, mode=hip.MODE_FAST, rccl=rccl)
+    r = g.selfcheck()
+    assert r["shards"] == len(devices) and r["path"] == path, r
+    assert r["communicator"] == (path == "rccl")
+    g.close()
+    gx = hip.HipGroup(64, devices, mode=hip.MODE_EXACT)
+    assert gx.selfcheck()["path"] == "exact"
+    gx.close()
+
+
+def test_group_fast_wide_generic_matrix_falls_back(hip, oracle):
+    """psmc_hip_estep falls back to the exact kernels for 65..128 states and a matrix without the PSMC
+    form; the device-resident entry point the group uses does not -- the group now does the same per shard and adds the
+    host vectors in shard order, so a command that works on one GPU works on a device list."""
+    rng = np.random.default_rng(77)
+    n = 100
+    a, e, a0 = random_hmm(rng, n)
+    segs = [rng.choice(3, size=L, p=[0.86, 0.1, 0.04]).astype(np.uint8) for L in (1, 64, 65, 700, 3000)]
+    o = oracle.estep(a, e, a0, segs)
+    g = hip.HipGroup(n, [0, 0], mode=hip.MODE_FAST)
+    g.load_segments(segs)
+    r = g.estep(a, e, a0)
+    assert relmax(r["A"], o["A"]) < FAST_TOL_STATS and relmax(r["E"], o["E"]) < FAST_TOL_STATS and abs(r["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
+    assert g.info()["last_reduce"] == 2
+    g.close()
+
+
+@pytest.mark.parametrize("n", [3, 4])
+def test_group_factored_few_states(hip, oracle, n):
+    """the group's device vector holds max(n^2 + 2n + 1, 7n + 1) doubles -- below 5 states the factored
+    statistics (7n + 1) are the longer of the two (3 states: 22 against 16; the structured sweeps need at least 3)."""
+    pat = "%d*1" % n
+    from psmc_amd import hostlib
+    a, e, a0 = hostlib.hmm_params(pat, [0.02, 0.004, 15.0] + [1.0 + 0.3 * i for i in range(n)])
+    rng = np.random.default_rng(5)
+    segs = [rng.choice(3, size=L, p=[0.9, 0.08, 0.02]).astype(np.uint8) for L in (300, 2000)]
+    o = oracle.estep(a, e, a0, segs)
+    g = hip.HipGroup(n, [0, 0], mode=hip.MODE_FAST)
+    g.load_segments(segs)
+    f = g.estep_factored(a, e, a0)
+    lo, up = np.tril(o["A"], -1), np.triu(o["A"], 1)
+    assert relmax(f["sums"], np.stack([lo.sum(1), up.sum(1), np.diag(o["A"]).copy(), lo.sum(0), up.sum(0)])) < FAST_TOL_STATS
+    assert relmax(f["E"], o["E"]) < FAST_TOL_STATS and abs(f["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
     g.close()

@@ -118,3 +118,62 @@ def test_config5_full_size_n128(hip, golden, genome):
     assert relmax(rf["A"], rx["A"]) < TOL_STATS and relmax(rf["E"], rx["E"]) < TOL_STATS
     assert abs(rf["LL"] - rx["LL"]) <= TOL_LL * abs(rx["LL"])
     fa.close(); ex.close()
+
+
+def moving_params():
+    """(a, e, a0) of consecutive EM rounds of `psmc -N25` on the benchmark genome (what bench.py cycles through)."""
+    import json
+    from psmc_amd import hostlib
+    tj = json.load(open(os.path.join(ROOT, "tests", "golden", "traj_n64.json")))
+    return [hostlib.hmm_params(tj["pattern"], r["params"]) for r in tj["rounds"] if r["round"] >= 1]
+
+
+@pytest.mark.parametrize("workload", ["config2_500k", "share_1of8"])
+def test_shard_sized_inputs_one_round_plan(hip, golden, genome, workload):
+    """the sizes a strong-scaling run and config 2 put on one GPU -- rank 0's LPT share of the genome at 8
+    GPUs (3.75 M bins) and one 500 k-bin chromosome.  The planner gives them ONE round of the fused back half (every tile
+    speculating, phase 1 as one grid, one launch of the counts).  Fourteen EM
+    rounds of moving parameters: totals, factored vs full counts every round, fast vs exact (bit-identical to khmm.c)
+    in rounds 0, 6 and 13 -- on everything (500 k) or on the two longest segments (share)."""
+    from psmc_amd import sim
+    from psmc_amd.dist import partition_segments
+    p0 = golden.params("n64_curve")
+    if workload == "config2_500k":
+        segs = [sim.simulate_segment(p0["a"], p0["e"], p0["a0"], 500_000, np.random.default_rng(7))]
+        pick = [0]
+    else:
+        lens = np.array([len(s) for s in genome])
+        segs = [genome[i] for i in partition_segments(lens, 8)[0]]
+        pick = list(np.argsort([-len(s) for s in segs])[:2])
+    fa = hip.HipEStep(64, mode=hip.MODE_FAST)
+    fa.load_segments(segs)
+    fb = fa
+    if len(pick) < len(segs):   # a context of its own for the segments the exact mode checks (a selection would re-plan and forget the learned warm-ups)
+        fb = hip.HipEStep(64, mode=hip.MODE_FAST)
+        fb.load_segments([segs[i] for i in pick])
+    ex = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    ex.load_segments([segs[i] for i in pick])
+    traj = moving_params()
+    w0 = None
+    for it in range(14):
+        a, e, a0 = traj[it]
+        r = fa.estep(a, e, a0)
+        d = fa.fast_diag()
+        assert d["structured"] and d["back_half"] == 1 and d["merged_phase1"] and d["fused_launches"] == 1, d
+        assert d["n_chunks"] <= 4096
+        assert d["warm_err_fwd"] <= 1e-12 and d["warm_err_bwd"] <= 1e-12, d
+        check_totals(r, segs)
+        f = fa.estep_factored(a, e, a0)
+        assert relmax(f["sums"], tri_sums(r["A"])) < TOL_STATS and relmax(f["E"], r["E"]) < TOL_STATS
+        assert abs(f["LL"] - r["LL"]) <= TOL_LL * abs(r["LL"])
+        rf = r if fb is fa else fb.estep(a, e, a0)
+        if it in (0, 6, 13):
+            rx = ex.estep(a, e, a0)
+            assert relmax(rf["A"], rx["A"]) < TOL_STATS and relmax(rf["E"], rx["E"]) < TOL_STATS, (it, relmax(rf["A"], rx["A"]))
+            assert abs(rf["LL"] - rx["LL"]) <= TOL_LL * abs(rx["LL"])
+        pl = fa.fast_plan()
+        w0 = w0 or pl
+    assert pl["tiles"] == d["n_chunks"] and pl["warm_fwd_max"] <= 3072 and pl["warm_bwd_max"] <= 3072, (w0, pl)   # one round: a failed tile is glued, never doubled
+    if fb is not fa:
+        fb.close()
+    fa.close(); ex.close()

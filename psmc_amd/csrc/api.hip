@@ -808,15 +808,14 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	std::vector<std::pair<long long, std::pair<int, int>>> kf, kb; // (key, (first, count))
 	auto key = [](int steps, int count, bool phase_b) { return (count > 1 ? -(1ll << 40) : (phase_b ? (1ll << 40) : 0ll)) - steps; };
 	std::vector<char> from_above(nc, 0), in_run(nc, 0); // in_run: member of a glued run of either direction
+	std::vector<std::pair<int, int>> gf, gb; // forward / backward groups (first, count)
 	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
 		int e = b + 1;
 		while (e < nc && c->glue_f[e] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
-		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
-		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, e - b, false), {b, e - b}});
+		gf.push_back({b, e - b});
 		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = 1;
 		b = e;
 	}
-	std::vector<std::pair<int, int>> gb; // backward groups (first, count)
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
 		int e = b + 1;
 		while (e < nc && c->glue_b[e - 1] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap &&
@@ -845,6 +844,31 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 		if (pb) { from_above[b] = 1; --above_budget; }
 		kb.push_back({key(std::min(top.hi + chunk_warm_b(top, W) + 1, top.L) - lo.lo, e - b, pb), {b, e - b}});
 	}
+	// tile lists of the fused back half: A = every tile whose X and start vector exist after phase A, B = the rest.
+	// B must hold the from-above tiles; A must hold the tile above every from-above tile; the run tiles go to B (above);
+	// the rest can go to either and balance the two launches (each should fit the device in one round of waves)
+	std::vector<int> la, lb;
+	{
+		std::vector<int> freet;
+		for (int b = 0; b < nc; ++b) {
+			if (from_above[b]) lb.push_back(b | (1 << 30));
+			else if (b > 0 && from_above[b - 1]) la.push_back(b);
+			else if (c->runs_in_b && in_run[b]) lb.push_back(b);
+			else freet.push_back(b);
+		}
+		const bool single = lb.empty() && nc <= 4096; // one round of waves holds every tile: one launch, nothing to balance
+		for (int b : freet) { if (single || la.size() <= lb.size()) la.push_back(b); else lb.push_back(b); }
+	}
+	// (Tried in round 3 and removed: the forward sweep of list B's tiles as a SECOND launch beside the first launch of the back
+	// half, which needs the X of list A only -- the counts of A would overlap the warm-ups and table stores of B.  Slower
+	// whatever the wave priorities of the backward warm-up pass, the walks and the transfer-matrix kernel, 12.9-15.1 ms
+	// against 12.7: the half-size forward launch is bound by its dependent chain and by the backward warm-up pass beside it
+	// (3.9 + 5.0 ms), and the counts run 4.1 instead of 3.1 ms beside the second one.  profiles/r03_split_fwd_prio_sweep.txt)
+	for (const auto &gr : gf) {
+		const int b = gr.first, e = b + gr.second;
+		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
+		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, e - b, false), {b, e - b}});
+	}
 	std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
 	// layout of d_items (ints): items_f | items_b | ritems_f | ritems_b | members_f | members_b, 2*nc each
 	std::vector<int> h((size_t)4 * nc, 0), mem((size_t)4 * nc, 0);
@@ -867,18 +891,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	while (c->n_long_b < c->n_items_b && kb[c->n_long_b].second.second > 1) ++c->n_long_b;
 	c->n_B_b = 0; // from-above singles sort last
 	for (int b = 0; b < nc; ++b) c->n_B_b += from_above[b];
-	{ // tile lists of the fused back half: A = every tile whose X and start vector exist after phase A, B = the rest
-		// B must hold the tiles of phase B; A must hold the tile above every from-above tile; the rest (run tiles, ...)
-		// can go to either and balance the two launches (each should fit the device in one round of waves)
-		std::vector<int> la, lb, freet;
-		for (int b = 0; b < nc; ++b) {
-			if (from_above[b]) lb.push_back(b | (1 << 30));
-			else if (b > 0 && from_above[b - 1]) la.push_back(b);
-			else if (c->runs_in_b && in_run[b]) lb.push_back(b);
-			else freet.push_back(b);
-		}
-		const bool single = lb.empty() && nc <= 4096; // one round of waves holds every tile: one launch, nothing to balance
-		for (int b : freet) { if (single || la.size() <= lb.size()) la.push_back(b); else lb.push_back(b); }
+	{
 		c->n_list_a = (int)la.size(); c->n_list_b = (int)lb.size();
 		while (la.size() % 4) la.push_back(-1);
 		while (lb.size() % 4) lb.push_back(-1);

@@ -6,6 +6,12 @@ import csv, collections, json, os, re, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 bins = int(sys.argv[2]) if len(sys.argv) > 2 else 30000003
+# a second workload profiled beside the bench (e.g. config 5): PROF_NAME=n128 reads gpurun_out/prof/n128_results.db and
+# gpurun_out/pmc/n128_*_counter_collection.csv and writes profiles/<tag>_n128_* and profiles/pmc_traffic_n128.json
+NAME = os.environ.get("PROF_NAME", "bench")
+SUFFIX = "" if NAME == "bench" else "_" + NAME
+CMD = os.environ.get("PROF_CMD", "python bench.py --steps 5 --warmup 1 --cpu-sample 0 --exact-extra 0")
+STATES = int(os.environ.get("PROF_STATES", "64"))
 
 def short(nm):
     rep = ('true>' in nm) or ('Lb1' in nm)
@@ -13,32 +19,32 @@ def short(nm):
         if k in nm:
             m = re.search(k + r'(?:IL[bi]\d+E)*?ILb([01])E', nm) or re.search(k + r'<(true|false)', nm)  # the FIRST bool argument is REPAIR
             if m: rep = m.group(1) in ('1', 'true')
-            ck = bool(re.search(k + r'ILb[01]ELi\d+ELi\d+ELb1', nm) or re.search(k + r'<(?:true|false), \d+, \d+, true', nm))
+            ck = bool(re.search(k + r'ILb[01]ELi\d+E(?:Li\d+E)?Lb1', nm) or re.search(k + r'<(?:true|false), \d+(?:, \d+)?, true', nm))
             return k + ('<repair>' if rep else '<speculate>') + ('<ckpt>' if ck else '')
     if 'k_verify' in nm: return 'k_verify' + ('<bwd>' if rep else '<fwd>')
     m = re.search(r'psmc::(k_[a-z0-9_]+)', nm) or re.search(r'_ZN4psmc\d+(k_[a-z0-9_]+?)(?:IL|E)', nm)
     return m.group(1) if m else nm.split('(')[0][:40]
 
-db = os.path.join(ROOT, "gpurun_out", "prof", "bench_results.db")
+db = os.path.join(ROOT, "gpurun_out", "prof", NAME + "_results.db")
 if os.path.exists(db):
     cur = sqlite3.connect(db).cursor()
     q = """select s.kernel_name, (d.end-d.start) from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id"""
     agg = collections.defaultdict(list)
     for nm, dt in cur.execute(q): agg[short(nm)].append(dt)
-    with open(os.path.join(ROOT, "profiles", tag + "_rocprofv3_kernel_stats.txt"), "w") as fh:
-        fh.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --cpu-sample 0 --exact-extra 0\n")
-        fh.write("# MI355X, %d bins x 64 states, fast mode; summary of the rocpd database (ns -> us/ms)\n" % bins)
+    with open(os.path.join(ROOT, "profiles", tag + SUFFIX + "_rocprofv3_kernel_stats.txt"), "w") as fh:
+        fh.write("# rocprofv3 --kernel-trace --stats -- %s\n" % CMD)
+        fh.write("# MI355X, %d bins x %d states, fast mode; summary of the rocpd database (ns -> us/ms)\n" % (bins, STATES))
         fh.write("%-26s %6s %12s %12s %11s %11s\n" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us"))
         for k, v in sorted(agg.items(), key=lambda x: -sum(x[1])):
             fh.write("%-26s %6d %12.3f %12.1f %11.1f %11.1f\n" % (k[:26], len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
-    print(open(os.path.join(ROOT, "profiles", tag + "_rocprofv3_kernel_stats.txt")).read())
+    print(open(os.path.join(ROOT, "profiles", tag + SUFFIX + "_rocprofv3_kernel_stats.txt")).read())
 
 pm = os.path.join(ROOT, "gpurun_out", "pmc")
-if os.path.exists(os.path.join(pm, "bench_FETCH_SIZE_counter_collection.csv")):
+if os.path.exists(os.path.join(pm, NAME + "_FETCH_SIZE_counter_collection.csv")):
     res = {}
     for C, scale in (('FETCH_SIZE', 2 * 1024.0), ('WRITE_SIZE', 1024.0)):
         agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-        for r in csv.DictReader(open(os.path.join(pm, 'bench_%s_counter_collection.csv' % C))):
+        for r in csv.DictReader(open(os.path.join(pm, '%s_%s_counter_collection.csv' % (NAME, C)))):
             k = short(r['Kernel_Name']); v = float(r['Counter_Value'])
             agg[k][0] += 1; agg[k][1] += v; agg[k][2] = max(agg[k][2], v)
         for k, (n, v, mx) in agg.items():
@@ -47,7 +53,7 @@ if os.path.exists(os.path.join(pm, "bench_FETCH_SIZE_counter_collection.csv")):
     for C in ('FETCH_SIZE', 'WRITE_SIZE'):
         rows = [r for r in csv.DictReader(open(os.path.join(pm, 'calib_%s_counter_collection.csv' % C))) if 'k_stream_copy8' in r['Kernel_Name']]
         cal[C] = sum(float(r['Counter_Value']) for r in rows) / len(rows)
-    out = dict(command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --exact-extra 0 (two separate passes)",
+    out = dict(command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- %s (two separate passes)" % CMD,
                bins=bins,
                calibration=dict(kernel="k_stream_copy8: reads 2^30 B and writes 2^30 B per launch, 8 B/lane", raw_FETCH_SIZE=cal['FETCH_SIZE'], raw_WRITE_SIZE=cal['WRITE_SIZE'],
                                 correction="bytes_read = 2 * FETCH_SIZE * 1024 (gfx950 tallies 128-B requests at 64 B: 524296 KB raw for 2^30 B); bytes_written = WRITE_SIZE * 1024 (exact)"),
@@ -56,11 +62,11 @@ if os.path.exists(os.path.join(pm, "bench_FETCH_SIZE_counter_collection.csv")):
     for k, d in sorted(res.items()):
         if not k.startswith('k_'): continue
         rd = d.get('FETCH_SIZE', {}); wr = d.get('WRITE_SIZE', {})
-        full = k in ('k_expect_mfma', 'k_bwd_count4f_struct', 'k_fwd_struct<speculate>')  # several variants per E-step: the full pass
+        full = k in ('k_expect_mfma', 'k_bwd_count4f_struct', 'k_bwd_count8_struct', 'k_fwd_struct<speculate>')  # several variants per E-step: the full pass
         r_b = rd.get('max_bytes' if full else 'bytes_per_launch', 0.0); w_b = wr.get('max_bytes' if full else 'bytes_per_launch', 0.0)
         out['kernels'][k] = dict(launches=rd.get('launches', wr.get('launches')), read_bytes_per_launch=r_b, write_bytes_per_launch=w_b,
                                  hbm_bytes_per_launch=r_b + w_b, bytes_per_bin=(r_b + w_b) / bins)
-    json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json"), "w"), indent=1)
-    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", tag + SUFFIX + "_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic%s.json" % SUFFIX), "w"), indent=1)
     for k, v in out['kernels'].items():
         print("%-24s launches=%3s read=%10.1f MB write=%10.1f MB  per bin %7.1f B" % (k, v['launches'], v['read_bytes_per_launch'] / 1e6, v['write_bytes_per_launch'] / 1e6, v['bytes_per_bin']))

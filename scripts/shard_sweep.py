@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--factored", type=int, default=0)
     ap.add_argument("--n-states", type=int, default=64)
+    ap.add_argument("--repeat", type=int, default=1, help="go through the option sets this many times (A B A B ...): box-level drift shows up as spread between repeats")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import torch
@@ -52,7 +53,7 @@ def main():
         mine = partition_segments(lens, n)[0]
         work.append(("share_1of%d" % n, [full[i] for i in mine]))
     stream = torch.cuda.current_stream()
-    cfgs = args.cfg or [""]
+    cfgs = (args.cfg or [""]) * max(1, args.repeat)
     res = []
     for name, segs in work:
         bins = sum(len(s) for s in segs)

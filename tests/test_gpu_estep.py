@@ -356,7 +356,8 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
                                   dict(two_phase=2), dict(chunk=256, warmup=512, two_phase=2), dict(GENOME), dict(chunk=256, warmup=512, **GENOME), dict(chunk=768, warmup=256, overlap=0, **GENOME), dict(chunk=768, warmup=64, merge1=0),
                                   dict(merge1=1, two_phase=2), dict(chunk=256, warmup=512, merge1=1, warm_shift=1), dict(chunk=1000, warmup=100, kc_sub=2),
-                                  dict(chunk=1000, warmup=100, **GENOME)])
+                                  dict(chunk=1000, warmup=100, **GENOME), dict(chunk=256, warmup=512, runs_late=0, **GENOME),
+                                  dict(chunk=768, warmup=64, runs_late=0, **GENOME)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is

@@ -650,18 +650,6 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	else launch_fwd<false>(p, sm);
 	if (!mg) (void)hipEventRecord(p.evx[1], sm);
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
-	if (lw && p.fused == 2) {
-		// Factored statistics of the tiles of backward runs, beside the bulk pass on a stream of their own.  They read the
-		// tiles' X and scale factors, which the bulk forward sweep writes unless the tile is also part of a forward run.
-		// (Until round 2 this launch followed the run tiles only: it could read a bulk tile's X of the PREVIOUS E-step; with
-		// the same parameters that is the same direction, and the per-position normaliser of the old kernels hid the rest.
-		// Found when the forward scale factors became part of the backward recursion.)
-		if (lb) {
-			if (ov) (void)hipStreamWaitEvent(sk, p.evx[1], 0);
-			launch_bwd_acc(p, sk, 3, 0, p.n_mem_b);
-		}
-		(void)hipEventRecord(p.evx[9], sk);
-	}
 	if (one && ov) (void)hipStreamWaitEvent(sa, p.evx[1], 0); // the backward chain follows the same launch
 	if (!one && p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
 	if (p.fused) {
@@ -669,10 +657,24 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		// every bulk tile's start vector (beside the forward sweep, or in its grid); then one wave per group of four
 		// tiles walks them backwards and feeds the matrix cores.  bt never reaches HBM.
 		if (!mg) launch_bwd_struct(p, sa, 4, fb0, p.n_items_b - fb0 - p.n_B_b);
+		// fused == 2 (item lists): the tiles of backward runs are a side pass on the transfer-matrix stream; it reads X of tiles
+		// that may belong to the BULK forward sweep (a tile can be glued backward only), so it follows that sweep as well as
+		// the run tiles.  (Until round 2 it followed the run tiles only and could read a bulk tile's X of the PREVIOUS E-step;
+		// with the same parameters that is the same direction, and the per-position normaliser of the old kernels hid the
+		// rest.  Found when the forward scale factors became part of the backward recursion.)  Tried in round 3 and removed:
+		// the single tiles that are members of FORWARD runs in that side pass too, so that the main pass would wait for the
+		// bulk sweeps only -- 13.7 against 10.8 ms: a full-length item that starts at the end of the runs' path, in a phase
+		// whose vector units are saturated, ends long after the main pass (the fused back half has a second launch to hide
+		// them in; this one has not).
+		if (p.fused == 2 && lw) {
+			if (lb) { if (ov) (void)hipStreamWaitEvent(sk, p.evx[1], 0); launch_bwd_acc(p, sk, 3, 0, p.n_mem_b); }
+			(void)hipEventRecord(p.evx[9], sk);
+		}
 		(void)hipStreamWaitEvent(sa, p.evx[1], 0); // X of the bulk tiles; merged: and the start vectors of the same grid
 		// boundary vectors and X of the run tiles (fused == 2, missing until round 2: a tile of a forward run is an ordinary
-		// single tile of the bulk pass below, which could read its X before it was written; found with PSMC_HIP_POISON=vary)
-		const bool late = p.fused == 1 && p.runs_in_b && p.n_list_b > 0; // every run tile is in the second list: the first launch does not wait for the runs' path
+		// single tile of the bulk pass below, which could read its X before it was written; found with PSMC_HIP_POISON=vary).
+		// fused == 1 with every run tile in the second list (runs_in_b): only that launch waits for the runs' path.
+		const bool late = p.fused == 1 && p.runs_in_b && p.n_list_b > 0;
 		if (lw && ov && sw != sa && !late) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
 		if (p.fused == 2) launch_bwd_acc(p, sa, 0, fb0, p.n_items_b - fb0);

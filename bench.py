@@ -634,8 +634,8 @@ def main():
             traffic8 = None
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_n128.json")))
-                if abs(pj["bins"] - bins) <= 64:
-                    traffic8 = pj["kernels"]
+                if abs(pj["bins"] - bins) <= 64 and "k_bwd_count8_struct" in pj["kernels"]:
+                    traffic8 = pj["kernels"]["k_bwd_count8_struct"]["hbm_bytes_per_launch"]
             except Exception:
                 pass
             out["n128"] = {"value": bins / (d8 * 1e-3), "unit": "bins/s", "ms_per_step": d8, "ms_min": d8min, "first_call_ms": f8, "kernels_ms": kern8, "factored_stats": fac8,

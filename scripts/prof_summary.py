@@ -57,12 +57,12 @@ if os.path.exists(os.path.join(pm, NAME + "_FETCH_SIZE_counter_collection.csv"))
                bins=bins,
                calibration=dict(kernel="k_stream_copy8: reads 2^30 B and writes 2^30 B per launch, 8 B/lane", raw_FETCH_SIZE=cal['FETCH_SIZE'], raw_WRITE_SIZE=cal['WRITE_SIZE'],
                                 correction="bytes_read = 2 * FETCH_SIZE * 1024 (gfx950 tallies 128-B requests at 64 B: 524296 KB raw for 2^30 B); bytes_written = WRITE_SIZE * 1024 (exact)"),
-               note="k_bwd_count4f_struct / k_expect_mfma are launched twice per E-step (full pass + redo of repaired tiles) and k_fwd_struct<speculate> also runs checkpoint-only for the factored extra: the largest launch is reported for them",
+               note="the back-half kernels are launched several times per E-step (two lists, side passes over run tiles, redo of repaired tiles) and k_fwd_struct<speculate> also runs checkpoint-only for the factored statistics: the LARGEST launch is reported for them",
                kernels={})
     for k, d in sorted(res.items()):
         if not k.startswith('k_'): continue
         rd = d.get('FETCH_SIZE', {}); wr = d.get('WRITE_SIZE', {})
-        full = k in ('k_expect_mfma', 'k_bwd_count4f_struct', 'k_bwd_count8_struct', 'k_fwd_struct<speculate>')  # several variants per E-step: the full pass
+        full = k in ('k_expect_mfma', 'k_bwd_count4f_struct', 'k_bwd_count8_struct', 'k_fwd_struct<speculate>', 'k_bwd_acc_struct', 'k_bwd_acc_ckpt', 'k_sweep_struct')  # several variants per E-step (side passes, redo): the full pass
         r_b = rd.get('max_bytes' if full else 'bytes_per_launch', 0.0); w_b = wr.get('max_bytes' if full else 'bytes_per_launch', 0.0)
         out['kernels'][k] = dict(launches=rd.get('launches', wr.get('launches')), read_bytes_per_launch=r_b, write_bytes_per_launch=w_b,
                                  hbm_bytes_per_launch=r_b + w_b, bytes_per_bin=(r_b + w_b) / bins)

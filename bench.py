@@ -553,7 +553,7 @@ def main():
                                      "bins_total": total_s, "bins_this_rank": sh.bins,
                                      "note": "config 3: one %d-bin genome, segments LPT-sharded over %d GPUs, 1 all-reduce per step; "
                                              "MAX over ranks like the headline" % (total_s, world)}
-    if world > 1 and args.group_extra > 0 and mode == hip.MODE_FAST and not single_gpu_test:
+    if world > 1 and args.group_extra > 0 and mode == hip.MODE_FAST:
         # the C library's own sharding over the same N devices, driven by rank 0 alone while the other ranks wait: what the
         # psmc binary runs with PSMC_HIP_DEVICES=0..N-1 (the driver's scaling run otherwise only sees the Python path)
         sh.close()
@@ -566,7 +566,8 @@ def main():
                         gsegs = [x for r in range(world) for x in sim.simulate_genome(a, e, a0, lens, seed=43 + r)]
                     else:
                         gsegs = sim.simulate_genome(a, e, a0, lens, seed=43)
-                    r_ = group_engine_run(hip, gsegs, list(range(world)), moving, args.steps, args.warmup, mode)
+                    gdev = [0] * world if single_gpu_test else list(range(world))   # BENCH_SINGLE_GPU_TEST: the shards share device 0 (host sum instead of RCCL)
+                    r_ = group_engine_run(hip, gsegs, gdev, moving, args.steps, args.warmup, mode)
                     r_["bins_total"] = int(sum(len(x) for x in gsegs)); r_["value"] = r_["bins_total"] / (r_["ms_per_step"] * 1e-3)
                     ge[sc_name] = r_
                 except Exception as ex_:

@@ -723,12 +723,12 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		return 0;
 	};
 	if (lw && ov) { if (sw != sm) (void)hipStreamWaitEvent(sm, p.evx[7], 0); (void)hipStreamWaitEvent(sa, p.evx[9], 0); } // run tiles done
-	auto launch_ll = [&]() { // the log-likelihood needs the forward tables only
-		if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
-		else hipLaunchKernelGGL(k_ll<64>, g, b, 0, sm, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
+	auto launch_ll = [&](hipStream_t st) { // the log-likelihood needs the forward tables only
+		if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, st, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
+		else hipLaunchKernelGGL(k_ll<64>, g, b, 0, st, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
 		PSMC_DBG("k_ll", p.n_chunks, 0, 0);
 	};
-	auto launch_reduce = [&]() {
+	auto launch_reduce = [&](hipStream_t sm) { // (the parameter shadows the main stream on purpose: the optimistic tail reduces on another one)
 		const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_list_a + 3) / 4 + (p.n_list_b + 3) / 4 : nS; // fused: one C partial per group of four tiles
 		if (p.fused == 2) {
 			launch_reduce_factored(p, sm);
@@ -751,15 +751,19 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	// after the host has read both flagged-tile counts -- two host round trips (~0.1 ms) leave the critical path.  If a
 	// verify does flag tiles, the repair rounds run as before and the tail is simply enqueued again: it overwrites
 	// d_LLpart, the stage buffer and d_stats from the repaired tables.  (With the fused / factored back half only: the
-	// unfused one takes its counts in a separate pass that has its own dependencies.)
+	// unfused one takes its counts in a separate pass that has its own dependencies.)  The tail runs on the counts' stream
+	// of the unfused plan, which is idle here: on the main stream it would sit between the forward verify and a forward
+	// REPAIR round, and the repair would wait for the whole back half instead of running beside it.
 	const bool optimistic = p.fused != 0 && ov;
 	if (optimistic) {
-		launch_ll();
-		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); // back half + backward verify done
-		if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
-		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
-		if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
-		launch_reduce();
+		(void)hipStreamWaitEvent(sx, p.evx[4], 0); // forward verify (and compaction) done: the forward tables are final unless it flagged tiles
+		launch_ll(sx);
+		(void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sx, p.evx[2], 0); // back half + backward verify done
+		if (p.ev[1]) (void)hipEventRecord(p.ev[1], sx);
+		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sx);
+		if (p.ev[3]) (void)hipEventRecord(p.ev[3], sx);
+		launch_reduce(sx);
+		(void)hipEventRecord(p.evx[10], sx);
 	}
 	bool ll_stale = !optimistic;
 	while (!(ch[0].done && ch[1].done)) {
@@ -794,11 +798,12 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (!progressed) __builtin_ia32_pause();
 	}
 	const bool repaired = rep->fwd_rounds + rep->bwd_rounds > 0;
+	if (optimistic) (void)hipStreamWaitEvent(sm, p.evx[10], 0); // the caller synchronises the main stream; a second tail must not overtake the first
 	if (optimistic && !repaired) return (int)hipGetLastError(); // the tail is already in flight
 	if (hipStreamSynchronize(sm) != hipSuccess) return -1;
 	if (p.ev[1]) (void)hipEventRecord(p.ev[1], sm);
 	// ---- counts from the final tables
-	if (ll_stale) launch_ll();
+	if (ll_stale) launch_ll(sm);
 	if (p.fused) {
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
@@ -851,7 +856,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		}
 	}
 	if (p.ev[3]) (void)hipEventRecord(p.ev[3], sm);
-	launch_reduce();
+	launch_reduce(sm);
 	return (int)hipGetLastError();
 }
 

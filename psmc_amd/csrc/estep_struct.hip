@@ -677,15 +677,25 @@ __device__ __forceinline__ void struct_step1n(const StructPar1 (&c)[PER], double
 	}
 }
 
+// Round 3: the chain is the sequential part of the runs' path, and a product used to cost 4-8 us (7 ms per launch at 128
+// states, where it ran beside the bulk sweeps): one wave fetched a matrix 16 rows at a time and waited a full memory
+// latency per batch.  Now a work-group of NW = S / RW waves shares a product -- wave w takes the RW = 32 / PER rows
+// RW w .. RW w + RW - 1 (the source states it reads with v_readlane) -- and every wave has the NEXT matrix's rows in flight
+// while it multiplies the current ones (two register buffers of RW x PER doubles); the partial sums meet in LDS (one
+// barrier per product, double-buffered), every wave adds them in wave order and carries the whole vector, so that the
+// normalisation, the backward sweep's last steps and the next product need no further exchange.  ~0.3 us per product.
 template <int PER>
-__global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ runs, int n_f, const double *__restrict__ Kcol,
+__global__ __launch_bounds__(64 * (PER == 1 ? 2 : 8)) void k_kchain_struct(const KcRun *__restrict__ runs, int n_f, const double *__restrict__ Kcol,
                                                         const double *__restrict__ Kexp, const double *__restrict__ sp,
                                                         const double *__restrict__ e, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, double *__restrict__ entry,
                                                         double *__restrict__ bentry, int sub)
 {
-	constexpr int S = 64 * PER;
-	const int lane = threadIdx.x;
+	constexpr int S = 64 * PER, RW = 32 / PER, NW = S / RW;
+	__shared__ double part[2][NW][S];
+	const int lane = threadIdx.x & 63;
+	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	__builtin_amdgcn_s_setprio(3); // the sequential part of the longest dependency chain of phase 1
 	const bool fwd = (int)blockIdx.x < n_f;
 	const KcRun r = runs[blockIdx.x];
 	double *vec = fwd ? entry : bentry;
@@ -701,42 +711,65 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 		s1[q].mS = sp[3 * S + k]; s1[q].wS = sp[S + k]; s1[q].mP = sp[2 * S + k]; s1[q].wP = sp[k]; s1[q].dd = sp[4 * S + k];
 		e0[q] = e[k]; e1[q] = e[S + k];
 	}
-	for (int q = 0; q + 1 < r.count; ++q) {
-		double y[PER];
-		for (int ss = 0; ss < sub; ++ss) { // the tile's map = the product of its `sub` range maps, applied in traversal order
-		const int64_t kb = ((int64_t)(r.kc0 + q) * sub + ss) * S;
-		double ex[PER], xs[PER], em = -1e300;
+	const int n_mats = (r.count - 1) * sub; // matrix j = tile j / sub of the run, range j % sub: consecutive in Kcol
+	const int64_t kb0 = (int64_t)r.kc0 * sub * S;
+	const int row0 = RW * w, src_h = row0 >> 6, src_l = row0 & 63; // this wave's rows = source states row0 .. row0 + RW - 1: register src_h, lanes src_l ..
+	double ma[RW][PER], mb[RW][PER], ea[PER], eb[PER];
+	auto load = [&](int j, double (&m)[RW][PER], double (&ex)[PER]) {
+		const int64_t kb = kb0 + (int64_t)j * S;
 #pragma unroll
-		for (int h = 0; h < PER; ++h) { ex[h] = Kexp[kb + lane + 64 * h]; em = fmax(em, x[h] > 0.0 ? ex[h] : -1e300); }
+		for (int i = 0; i < RW; ++i)
+#pragma unroll
+			for (int h = 0; h < PER; ++h) m[i][h] = Kcol[(kb + row0 + i) * S + lane + 64 * h];
+#pragma unroll
+		for (int h = 0; h < PER; ++h) ex[h] = Kexp[kb + lane + 64 * h];
+	};
+	auto product = [&](int j, const double (&m)[RW][PER], const double (&ex)[PER]) {
+		double xs[PER], y[PER], em = -1e300;
+#pragma unroll
+		for (int h = 0; h < PER; ++h) em = fmax(em, x[h] > 0.0 ? ex[h] : -1e300);
 		const double emax = wave_max_f64(em);
 #pragma unroll
 		for (int h = 0; h < PER; ++h) { xs[h] = x[h] > 0.0 ? __builtin_amdgcn_ldexp(x[h], (int)(ex[h] - emax)) : 0.0; y[h] = 0.0; }
+		double src = xs[0];
+		if constexpr (PER == 2) src = src_h ? xs[1] : xs[0]; // wave-uniform choice
 #pragma unroll
-		for (int hs = 0; hs < PER; ++hs)
-			for (int k = 0; k < 64; ++k) {
-				const double v = readlane_f64(xs[hs], k);
-				const double *row = Kcol + (kb + 64 * hs + k) * S + lane;
+		for (int i = 0; i < RW; ++i) {
+			const double v = readlane_f64(src, src_l + i);
 #pragma unroll
-				for (int h = 0; h < PER; ++h) y[h] = __builtin_fma(v, row[64 * h], y[h]);
-			}
-		{
-			double tot = y[0];
-			if constexpr (PER == 2) tot += y[1];
-			const double inv = rcp_newton(first_lane_f64(wave_sum_nat(tot)));
-#pragma unroll
-			for (int h = 0; h < PER; ++h) { y[h] *= inv; x[h] = y[h]; }
+			for (int h = 0; h < PER; ++h) y[h] = __builtin_fma(v, m[i][h], y[h]);
 		}
+		double (*pp)[S] = part[j & 1];
+#pragma unroll
+		for (int h = 0; h < PER; ++h) pp[w][lane + 64 * h] = y[h];
+		__syncthreads();
+#pragma unroll
+		for (int h = 0; h < PER; ++h) {
+			double tsum = pp[0][lane + 64 * h];
+#pragma unroll
+			for (int v = 1; v < NW; ++v) tsum += pp[v][lane + 64 * h];
+			y[h] = tsum;
 		}
-		if (!fwd) { // the tile's last steps p* .. lo with the sweep's own scaling: bt_lo as the sweep leaves it
+		double tot = y[0];
+		if constexpr (PER == 2) tot += y[1];
+		const double inv = rcp_newton(first_lane_f64(wave_sum_nat(tot)));
+#pragma unroll
+		for (int h = 0; h < PER; ++h) x[h] = y[h] * inv;
+	};
+	auto tile_done = [&]() { // after the last range map of a tile: x = the vector at the tile's far boundary
+		double y[PER];
+#pragma unroll
+		for (int h = 0; h < PER; ++h) y[h] = x[h];
+		if (!fwd) { // the tile's last steps p* .. lo with the sweep's own scaling: bt_lo as the sweep leaves it (every wave, redundantly)
 			const Chunk c = chunks[t];
 			const int top = min(c.hi, c.L - 1), ps = min((c.lo + 3) & ~3, top);
 			const uint8_t *o = obs + c.off;
-			for (int pp = ps; pp >= c.lo; --pp) {
-				const int sym = (int)o[pp - 1] & 3;
+			for (int pq = ps; pq >= c.lo; --pq) {
+				const int sym = (int)o[pq - 1] & 3;
 				double ev[PER];
 #pragma unroll
 				for (int h = 0; h < PER; ++h) ev[h] = walk_ev(sym, e0[h], e1[h]);
-				if ((pp & 3) == 0) {
+				if ((pq & 3) == 0) {
 					double tot = y[0];
 					if constexpr (PER == 2) tot += y[1];
 					const double inv = rcp_newton(first_lane_f64(wave_sum_nat(tot)));
@@ -750,7 +783,17 @@ __global__ __launch_bounds__(64) void k_kchain_struct(const KcRun *__restrict__ 
 		}
 		t += fwd ? 1 : -1;
 #pragma unroll
-		for (int h = 0; h < PER; ++h) { vec[(int64_t)t * S + lane + 64 * h] = y[h]; x[h] = y[h]; }
+		for (int h = 0; h < PER; ++h) { if (w == 0) vec[(int64_t)t * S + lane + 64 * h] = y[h]; x[h] = y[h]; }
+	};
+	if (n_mats > 0) load(0, ma, ea);
+	for (int j = 0; j < n_mats; j += 2) { // two products per trip: the buffers swap roles without moving registers
+		if (j + 1 < n_mats) load(j + 1, mb, eb);
+		product(j, ma, ea);
+		if (j % sub == sub - 1) tile_done();
+		if (j + 1 >= n_mats) break;
+		if (j + 2 < n_mats) load(j + 2, ma, ea);
+		product(j + 1, mb, eb);
+		if ((j + 1) % sub == sub - 1) tile_done();
 	}
 }
 
@@ -875,10 +918,10 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
 	if (p.ns == 128)
-		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
+		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(512), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, 1);
 	else
-		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(64), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
+		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(128), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kc_sub);
 	PSMC_DBG("launch_kchain", p.n_kc, p.n_chain_f, p.n_chain_b);
 }

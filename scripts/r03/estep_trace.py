@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-E-step trace of the adaptive warm-ups: ms, repair rounds / tiles, mean warm-ups, glued tiles (30 M-bin genome or a share)."""
+"""Per-E-step trace over 30 moving-parameter E-steps: ms, repair rounds / tiles, the plan (mean warm-ups, glued tiles); 30 M-bin genome (share 1)
+or rank 0's share of N GPUs.  (Written for the adaptive warm-ups of round 3, removed since: profiles/r03_adaptive_warmup_trace.txt.)"""
 import json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np

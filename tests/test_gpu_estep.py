@@ -853,3 +853,29 @@ def test_group_factored_few_states(hip, oracle, n):
     assert relmax(f["sums"], np.stack([lo.sum(1), up.sum(1), np.diag(o["A"]).copy(), lo.sum(0), up.sum(0)])) < FAST_TOL_STATS
     assert relmax(f["E"], o["E"]) < FAST_TOL_STATS and abs(f["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
     g.close()
+
+
+def test_options_from_the_environment(hip, golden, oracle, monkeypatch):
+    """PSMC_HIP_OPTIONS="key=value,key=value" reaches every context of the process (A/B of a whole program under another plan
+    without touching its code); a key the library does not know makes psmc_hip_create fail instead of passing for a result."""
+    p = golden.params("n64_curve")
+    o = oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid)
+    monkeypatch.setenv("PSMC_HIP_OPTIONS", "merge1=0,two_phase=2,chunk=512")
+    es = hip.HipEStep(64, mode=hip.MODE_FAST)
+    es.load_segments(golden.segs_mid)
+    check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+    d = es.fast_diag()
+    assert d["tile_len"] == 512 and not d["merged_phase1"] and d["fused_launches"] == 2, d
+    es.close()
+    monkeypatch.setenv("PSMC_HIP_OPTIONS", "merge1=1")
+    es = hip.HipEStep(64, mode=hip.MODE_FAST)
+    es.load_segments(golden.segs_mid)
+    check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+    assert es.fast_diag()["merged_phase1"]
+    es.close()
+    monkeypatch.setenv("PSMC_HIP_OPTIONS", "lanes8=1")   # removed in round 3
+    with pytest.raises(hip.HipError):
+        hip.HipEStep(64, mode=hip.MODE_FAST)
+    monkeypatch.setenv("PSMC_HIP_OPTIONS", "chunk")
+    with pytest.raises(hip.HipError):
+        hip.HipEStep(64, mode=hip.MODE_FAST)

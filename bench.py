@@ -554,27 +554,40 @@ def main():
                                      "note": "config 3: one %d-bin genome, segments LPT-sharded over %d GPUs, 1 all-reduce per step; "
                                              "MAX over ranks like the headline" % (total_s, world)}
     if world > 1 and args.group_extra > 0 and mode == hip.MODE_FAST:
-        # the C library's own sharding over the same N devices, driven by rank 0 alone while the other ranks wait: what the
-        # psmc binary runs with PSMC_HIP_DEVICES=0..N-1 (the driver's scaling run otherwise only sees the Python path)
+        # the C library's own sharding over the same N devices (what the psmc binary runs with PSMC_HIP_DEVICES=0..N-1; the
+        # driver's scaling run otherwise only sees the Python path).  Rank 0 starts `bench.py --engine group` as a CHILD
+        # process under a timeout: this path has never met more than one device, and a hang or a crash in it must cost this
+        # extra, not the bench line.  The other ranks free their devices and wait on a key of the rendezvous store (host side) --
+        # an RCCL barrier would leave a spinning kernel on the very devices the child measures.
+        import datetime
         sh.close()
-        torch.cuda.synchronize(); dist.barrier()
+        sync()
+        store = dist.distributed_c10d._get_default_store()
         if rank == 0:
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+                   and not k.startswith("TORCHELASTIC")}
             ge = {}
-            for sc_name in ("weak", "strong"):
+            for sc_name in ("weak", "strong"):   # (everything that can fail is inside the try: the other ranks wait for the key below)
+                cmd = [sys.executable, os.path.abspath(__file__), "--engine", "group", "--gpus", str(world), "--scaling", sc_name, "--steps", str(args.steps),
+                       "--warmup", str(args.warmup), "--cpu-sample", "0", "--bins", str(args.bins), "--segments", str(args.segments), "--traj", args.traj]
+                if single_gpu_test:   # BENCH_SINGLE_GPU_TEST: the shards share device 0 (host sum instead of RCCL)
+                    cmd += ["--group-devices", ",".join(["0"] * world)]
                 try:
-                    if sc_name == "weak":
-                        gsegs = [x for r in range(world) for x in sim.simulate_genome(a, e, a0, lens, seed=43 + r)]
-                    else:
-                        gsegs = sim.simulate_genome(a, e, a0, lens, seed=43)
-                    gdev = [0] * world if single_gpu_test else list(range(world))   # BENCH_SINGLE_GPU_TEST: the shards share device 0 (host sum instead of RCCL)
-                    r_ = group_engine_run(hip, gsegs, gdev, moving, args.steps, args.warmup, mode)
-                    r_["bins_total"] = int(sum(len(x) for x in gsegs)); r_["value"] = r_["bins_total"] / (r_["ms_per_step"] * 1e-3)
-                    ge[sc_name] = r_
+                    r_ = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+                    if r_.returncode != 0:
+                        raise RuntimeError("rc %d: %s" % (r_.returncode, r_.stderr.strip()[-300:]))
+                    j_ = json.loads(r_.stdout.strip().splitlines()[-1])
+                    ge[sc_name] = {"value": j_["value"], "ms_per_step": j_["ms_per_step"], "first_call_ms": j_["first_call_ms"], "bins_total": j_["config"]["bins_total"],
+                                   "devices": j_["config"]["devices"], "reduce": j_["config"]["sharding"], "selfcheck": j_["config"]["selfcheck"]}
                 except Exception as ex_:
-                    ge[sc_name] = {"error": str(ex_)}
-            ge["note"] = "one process (rank 0), psmc_hip_group_* over devices 0..%d: RCCL all-reduce inside group.hip; compare weak with the headline, strong with strong_scaling" % (world - 1)
+                    ge[sc_name] = {"error": str(ex_)[-400:]}
+            ge["note"] = ("a child process of rank 0, `bench.py --engine group --gpus %d`: psmc_hip_group_* over devices 0..%d, RCCL all-reduce inside group.hip; "
+                          "compare weak with the headline, strong with strong_scaling" % (world, world - 1))
             out["group_engine"] = ge
-        dist.barrier()
+            store.set("psmc_bench_group_extra_done", "1")
+        else:
+            store.wait(["psmc_bench_group_extra_done"], datetime.timedelta(minutes=20))
     if rank == 0 and world == 1 and args.exact_extra > 0 and mode == hip.MODE_FAST:
         try:
             lens_l = np.array([len(s) for s in segs], dtype=np.int32)

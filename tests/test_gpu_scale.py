@@ -177,3 +177,29 @@ def test_shard_sized_inputs_one_round_plan(hip, golden, genome, workload):
     if fb is not fa:
         fb.close()
     fa.close(); ex.close()
+
+
+def test_bench_two_ranks_on_one_device():
+    """The driver's N > 1 command line (torch.distributed.run, one rank per GPU) on a box with one GPU: BENCH_SINGLE_GPU_TEST=1 puts
+    both ranks on device 0 (gloo instead of RCCL).  Checks the contract line, the strong-scaling extra and the child process that
+    runs the C library's own multi-device engine (psmc_hip_group_*) beside it."""
+    import json
+    import sys
+    env = dict(os.environ, BENCH_SINGLE_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--bins", "3000000", "--segments", "9"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]   # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3 and j["warmup"] == 2 and j["unit"] == "bins/s"
+    from psmc_amd import sim
+    genome_bins = int(sim.human_like_lengths(3_000_000, n_seg=9).sum())
+    assert abs(j["value"] - 2 * genome_bins / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]   # whole-job aggregate: both ranks' genomes
+    assert j["strong_scaling"]["bins_total"] == genome_bins and j["strong_scaling"]["value"] > 0
+    for sc, bins in (("weak", 2 * genome_bins), ("strong", genome_bins)):
+        g = j["group_engine"][sc]
+        assert "error" not in g, g
+        assert g["bins_total"] == bins and g["devices"] == [0, 0] and g["value"] > 0
+        assert g["selfcheck"]["shards"] == 2 and g["selfcheck"]["path"] == "host_sum", g   # two shards on one device: no communicator

@@ -78,8 +78,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           their waves on distinct SIMDs, and the dependent chain walks -> chains -> run tiles -> back
  *                           half on one stream; 0: side by side on streams of their own.  auto: 1 with one round
  *  --- glued runs ---------------------------------------------------------------------------------------------------
- *  "kc_min"        4        runs of at least this many tiles get their boundary vectors from a chain of tile transfer
- *                           matrices instead of a walk; 0 = never
+ *  "kc_min"        auto     runs of at least this many tiles get their boundary vectors from a chain of tile transfer
+ *                           matrices instead of a walk; 0 = never.  auto (-1): 4 with 64 states, 8 with 65..128
  *  "kc_div"        16       at most n_tiles / kc_div tiles per direction get a transfer matrix
  *  "kc_sub"        auto     64 states: a tile's steps are cut into this many ranges with a matrix (and a pair of
  *                           waves) each; auto: ranges of about (tile + warmup) / 8 steps, at most 4

@@ -39,7 +39,8 @@ struct psmc_hip_ctx {
 	bool warm_shift_set = false, kc_sub_set = false;
 	int warm_shift_used = 1, kc_sub_used = 4;
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
-	int kc_min = 4;            // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never)
+	int kc_min = -1;           // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never; -1: 4 with
+	                           // 64 states, 8 with 65..128 -- measured, build_items)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
 	double *d_Kcol = nullptr; size_t kcol_cap = 0;
 	hipStream_t stream5 = nullptr;
@@ -298,7 +299,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->kc_sub_set = true; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "two_phase") { if (v != -1 && v != 0 && v != 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
-	else if (k == "kc_min") { if (v < 0) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
+	else if (k == "kc_min") { if (v < -1) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "fuse128") { c->fuse128 = v != 0 ? 1 : 0; c->plan_dirty = true; }
@@ -519,7 +520,9 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0)
 static bool fused_counts(const psmc_hip_ctx *c) { return c->fuse && c->expect_impl == 1 && (c->ns == 64 || (c->ns == 128 && c->fuse128)); }
 
 // the column-per-lane transfer-matrix kernel (k_kcol2_struct): 64 states.  With 65..128 states it takes 2.3x fewer vector
-// instructions too, but its chain path ends later and the E-step got slower (30.6 vs 28.3 ms, round 2): not built.
+// instructions too, but its chain path ends later and the E-step is slower -- round 2: 30.6 vs 28.3 ms factored; round 3, with
+// the run tiles in the second launch of the counts and the faster chain kernel: 45.7 vs 44.1 ms full counts, 29.2 vs 27.3
+// factored, whatever kc_sub (profiles/r03_kc_min_sweep.txt) -- so that instantiation is not built.
 static bool kcol2_on(const psmc_hip_ctx *c) { return c->ns == 64; }
 
 static void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const double *par_base = nullptr)
@@ -909,7 +912,8 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	//   d_items + 12nc: wl_f (2nc) | wl_b (2nc) | kc tiles (4nc: KcTile) | runs (4nc + : KcRun)
 	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b;
 	c->n_wl_f = c->n_wl_b = 0;
-	const bool chains = c->kc_min >= 2; // 64 states: one state per lane in the chain kernel; 128: two
+	const int kc_min = c->kc_min >= 0 ? c->kc_min : (c->ns == 128 ? 8 : 4); // auto: measured per model size (profiles/r03_kc_min_sweep.txt)
+	const bool chains = kc_min >= 2; // 64 states: one state per lane in the chain kernel; 128: two
 	const int head_count = c->ns == 64 ? 0 : 1; // k_walk1_struct knows count 0 (stop at the head's start vector); the four-runs-per-wave walk of 65..128 states walks through the head tile
 	auto add_runs = [&](const std::vector<std::pair<long long, std::pair<int, int>>> &k, int n_long, bool bwd) {
 		int &nw = bwd ? c->n_wl_b : c->n_wl_f;
@@ -920,7 +924,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 		int budget = std::max(64, nc / c->kc_div);
 		for (int i = 0; i < n_long; ++i) {
 			int first = k[i].second.first, count = k[i].second.second;
-			const bool chain = chains && count >= c->kc_min && count - 1 <= budget;
+			const bool chain = chains && count >= kc_min && count - 1 <= budget;
 			if (chain) budget -= count - 1;
 			if (chain && !bwd && c->chunks[first].lo == 1) {
 				// position 1 is an initial condition, not a step: there is no X_0 for a transfer matrix to start from.

@@ -919,7 +919,7 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
 	if (p.ns == 128)
 		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(512), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
-		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, 1);
+		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kc_sub);
 	else
 		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(128), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kc_sub);

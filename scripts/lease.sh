@@ -4,7 +4,7 @@
 #   suite [pytest args]           the GPU test suite (PSMC_HIP_POISON=vary in the environment: every device allocation poisoned)
 #   bench [bench.py args]         the driver's bench command (default: --steps 20 --warmup 5) + a digest of the line
 #   sweep CFG [CFG ...]           scripts/shard_sweep.py, one --cfg per argument ("" = defaults); env SHARES (8,4,2,1), CHR (500000),
-#                                 REPEAT (1: A B A B ... when > 1), FACTORED (0), WARMUP (10), STEPS (12)
+#                                 REPEAT (1: A B A B ... when > 1), FACTORED (0), STATES (64; 128 = config 5), WARMUP (10), STEPS (12)
 #   timeline SHARES CHR           rocprofv3 --kernel-trace of a few E-steps, kernel timeline of the last one (every kernel)
 #   prof                          rocprofv3 kernel stats + PMC FETCH_SIZE / WRITE_SIZE passes (calibrated on a known copy) of the bench
 #                                 command and of config 5 alone, SQ matrix-pipe counters of the 128-state back halves;
@@ -79,7 +79,7 @@ case "$task" in
   bench) do_bench "$@" ;;
   sweep)
     CF=(); for c in "$@"; do CF+=(--cfg "$c"); done
-    timeout 1200 python scripts/shard_sweep.py "${CF[@]}" --shares "${SHARES-8,4,2,1}" --chr "${CHR-500000}" --repeat "${REPEAT-1}" --factored "${FACTORED-0}" --warmup "${WARMUP-10}" --steps "${STEPS-12}" --out gpurun_out/sweep.json > gpurun_out/sweep.log 2> gpurun_out/sweep.err
+    timeout 1200 python scripts/shard_sweep.py "${CF[@]}" --shares "${SHARES-8,4,2,1}" --chr "${CHR-500000}" --repeat "${REPEAT-1}" --factored "${FACTORED-0}" --n-states "${STATES-64}" --warmup "${WARMUP-10}" --steps "${STEPS-12}" --out gpurun_out/sweep.json > gpurun_out/sweep.log 2> gpurun_out/sweep.err
     echo "sweep rc=$?"; tail -3 gpurun_out/sweep.err | cut -c1-300; show_sweep gpurun_out/sweep.json ;;
   timeline)
     cd /tmp; rm -rf $R/gpurun_out/prof/tl*

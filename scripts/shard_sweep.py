@@ -40,9 +40,10 @@ def main():
 
     a, e, a0 = bench.load_params()
     traj, _ = bench.load_trajectory(os.path.join(ROOT, "tests", "golden", "traj_n64.json"))
-    if args.n_states == 128:
-        g = np.load(os.path.join(ROOT, "tests", "golden", "estep_n128.npz"))
-        traj = [(g["n128_curve.a"], g["n128_curve.e"], g["n128_curve.a0"])]
+    if args.n_states == 128:   # config 5: parameters of consecutive EM rounds of `psmc -N25 -p 64*2` on the benchmark genome
+        from psmc_amd import hostlib
+        t8 = json.load(open(os.path.join(ROOT, "tests", "golden", "traj_n128.json")))
+        traj = [hostlib.hmm_params(t8["pattern"], r["params"]) for r in t8["rounds"] if r["round"] >= 1][:25]
     lens = sim.human_like_lengths(30_000_000, n_seg=90)
     full = sim.simulate_genome(a, e, a0, lens, seed=43)
     work = []

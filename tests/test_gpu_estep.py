@@ -377,7 +377,8 @@ def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=512, warmup=256), dict(chunk=1000, warmup=100, overlap=0, learn=0),
                                   dict(chunk=264, warmup=300, **GENOME), dict(chunk=768, warmup=64, two_phase=2),
-                                  dict(fuse128=0), dict(fuse128=0, chunk=512, warmup=256), dict(fuse128=0, chunk=1000, warmup=100, overlap=0, learn=0)])
+                                  dict(fuse128=0), dict(fuse128=0, chunk=512, warmup=256), dict(fuse128=0, chunk=1000, warmup=100, overlap=0, learn=0),
+                                  dict(chunk=400, warmup=64, kc_min=2), dict(chunk=264, warmup=300, kc_min=4, **GENOME)])
 def test_fast_n128(hip, golden, oracle, opts):
     """-p "64*2" in fast mode: 8 states per lane in the structured sweeps; the counts fused with the backward sweep, four
     waves per group of four tiles (default), or from the bt table in four 64x64 quadrants (fuse128=0)."""

@@ -77,6 +77,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "merge1"        auto     1: bulk forward sweep and backward warm-up pass in ONE grid, so that the dispatcher puts
  *                           their waves on distinct SIMDs, and the dependent chain walks -> chains -> run tiles -> back
  *                           half on one stream; 0: side by side on streams of their own.  auto: 1 with one round
+ *  "merge_order"   auto     block order of that grid: 1 = the forward blocks, then the backward blocks (the dispatcher deals blocks out
+ *                           XCD first, so alternating directions put each direction on four of the eight XCDs); 0 = alternating.
+ *                           auto: 1 while a tile is shorter than its warm-up
  *  --- glued runs ---------------------------------------------------------------------------------------------------
  *  "kc_min"        auto     runs of at least this many tiles get their boundary vectors from a chain of tile transfer
  *                           matrices instead of a walk; 0 = never.  auto (-1): 4 with 64 states, 8 with 65..128

@@ -26,6 +26,23 @@
 
 namespace psmc {
 
+#ifdef PSMC_TRACE_SWEEP
+// Debug build only (make EXTRA=-DPSMC_TRACE_SWEEP; scripts/sweep_trace.py): wall-clock stamps (100 MHz) of every wave of the bulk
+// forward sweep (f), the backward warm-up pass (b) and the walks (w) -- [0] start, [1] first stored block (end of the warm-up),
+// [2] end, [3] HW_ID | XCC_ID << 32 | 16-step blocks of the longest row << 40 -- read by psmc_hip_debug_trace.
+__device__ unsigned long long g_trace_f[4 * 16384], g_trace_b[4 * 16384], g_trace_w[4 * 16384];
+__device__ __forceinline__ void trace_put(unsigned long long *t, int block, int slot, unsigned long long v) {
+	if ((threadIdx.x & 63) == 0 && block < 16384) t[4 * block + slot] = v;
+}
+__device__ __forceinline__ unsigned long long trace_hw() {
+	const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+	return (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32);
+}
+#define PSMC_TRACE(t, block, slot, v) trace_put(t, block, slot, v)
+#else
+#define PSMC_TRACE(t, block, slot, v) ((void)0)
+#endif
+
 // symbol i (0..15) of a 16-byte block, clamped to 0..3 (row 3 of the LDS emission table is 1.0 like row 2)
 template <int J> __device__ __forceinline__ int sym_of(unsigned w) { return (int)((w >> (8 * J)) & 3u); }
 // word g (0..3) of the block's 16 symbols
@@ -85,6 +102,8 @@ constexpr int SWEEP_WALK = 1;       // leave only the boundary vectors (entry / 
 constexpr int SWEEP_TOP_ONLY = 4;   // backward: stop once the top tile's start vector (bentry) is stored: the warm-up alone
 constexpr int SWEEP_NO_TOUCH = 8;   // REPAIR kernels: do not flag the tile for the redo pass of the counts
 constexpr int SWEEP_FROM_ENTRY = 2; // REPAIR kernels: start from the boundary vector a walk left instead of the neighbour's table row
+constexpr int SWEEP_MERGED = 64;    // backward blocks of the list-order merged phase-1 grid
+constexpr int SWEEP_ALTERNATE = 32; // k_sweep_struct: even blocks forward, odd blocks backward (default: list order)
 constexpr int SWEEP_CKPT = 16;     // forward: store X only at the positions p % 8 == 0 (and the item's last one): the
                                    // factored counts recompute the rest from these checkpoints (estep_factored.hip)
 
@@ -165,6 +184,11 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	const int slot = block * R + (lane >> 4);
 	const bool valid = slot < n_items;
 	const SweepItem it = items[valid ? slot : 0];
+#ifdef PSMC_TRACE_SWEEP
+	const bool tr = !REPAIR && !walk && !from_entry;
+	bool tr_first = true;
+	if (tr) PSMC_TRACE(g_trace_f, block, 0, wall_clock64());
+#endif
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	else __builtin_amdgcn_s_setprio(1); // ahead of the backward warm-up and the rest of phase 1: once its warm-up is done this sweep
 	                                    // is paced by its stores and leaves the vector units to them
@@ -212,6 +236,9 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
 		nb_max = max(nb_max, rnb[r]);
 	}
+#ifdef PSMC_TRACE_SWEEP
+	if (tr) PSMC_TRACE(g_trace_f, block, 3, trace_hw() | ((unsigned long long)nb_max << 40));
+#endif
 	for (int bi = 0; bi < nb_max; ++bi) {
 		int bb[R];
 #pragma unroll
@@ -225,11 +252,17 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 			}
 			const bool full = base + 1 >= p_first && base + 16 <= p_last && !(cur.next_lo >= base + 1 && cur.next_lo <= base + 16);
 			const int mode = !full ? 0 : (base + 1 >= lo_store ? 1 : 2);
+#ifdef PSMC_TRACE_SWEEP
+			if (tr && tr_first && __all(mode == 1)) { tr_first = false; PSMC_TRACE(g_trace_f, block, 1, wall_clock64()); }
+#endif
 			if (__all(mode == 1)) fwd_block<1, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 			else if (__all(mode == 2)) fwd_block<2, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 			else fwd_block<0, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 		}
 	}
+#ifdef PSMC_TRACE_SWEEP
+	if (tr) PSMC_TRACE(g_trace_f, block, 2, wall_clock64());
+#endif
 }
 
 template <bool REPAIR, int NPL, bool CK = false>
@@ -315,7 +348,14 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	__syncthreads();
 	const int slot = block * R + (lane >> 4);
 	const SweepItem it = items[slot < n_items ? slot : 0];
+#ifdef PSMC_TRACE_SWEEP
+	const bool trb = !REPAIR && (flags & SWEEP_TOP_ONLY);
+	const unsigned long long trb_c0 = __builtin_readcyclecounter();
+	if (trb) PSMC_TRACE(g_trace_b, block, 0, wall_clock64());
+#endif
 	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
+	else if ((flags & SWEEP_TOP_ONLY) && (flags & SWEEP_MERGED)) __builtin_amdgcn_s_setprio(1); // list-order merged grid: second wave on the SIMD of a forward
+	                                                                                              // block (priority 1) with three quarters of its steps: ends with it
 	const int t_top = it.first + it.count - 1;
 	const Chunk c = chunks[t_top];
 	const int L = c.L;
@@ -356,6 +396,9 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
 		nb_max = max(nb_max, rnb[r]);
 	}
+#ifdef PSMC_TRACE_SWEEP
+	if (trb) PSMC_TRACE(g_trace_b, block, 3, trace_hw() | ((unsigned long long)nb_max << 40));
+#endif
 	for (int bi = 0; bi < nb_max; ++bi) {
 		int bb[R];
 #pragma unroll
@@ -370,6 +413,9 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 			else bwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 		}
 	}
+#ifdef PSMC_TRACE_SWEEP
+	if (trb) { PSMC_TRACE(g_trace_b, block, 2, wall_clock64()); PSMC_TRACE(g_trace_b, block, 1, __builtin_readcyclecounter() - trb_c0); } // [1]: shader-clock cycles
+#endif
 }
 
 template <bool REPAIR, int NPL>
@@ -416,6 +462,10 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
                                                        double *__restrict__ bexit)
 {
 	const int lane = threadIdx.x, block = (int)blockIdx.x;
+#ifdef PSMC_TRACE_SWEEP
+	PSMC_TRACE(g_trace_w, block, 0, wall_clock64()); PSMC_TRACE(g_trace_w, block, 3, trace_hw());
+	struct TraceEnd { int b; __device__ ~TraceEnd() { if (threadIdx.x == 0 && b < 16384) g_trace_w[4 * b + 2] = wall_clock64(); } } trace_end{block};
+#endif
 	__builtin_amdgcn_s_setprio(3);
 	const WaveScanMasks wm = wave_scan_masks(lane);
 	const double e0 = e[lane], e1 = e[64 + lane];
@@ -797,8 +847,7 @@ __global__ __launch_bounds__(64 * (PER == 1 ? 2 : 8)) void k_kchain_struct(const
 	}
 }
 
-// The bulk of both sweeps in ONE grid: even blocks take forward items, odd blocks backward items (as long as both
-// lists last).  Two uses.  (1) The unfused back half (flags 0 / 0): both table writers share the chip from the first
+// The bulk of both sweeps in ONE grid (block order: see the kernel).  Two uses.  (1) The unfused back half (flags 0 / 0): both table writers share the chip from the first
 // to the last wave.  (2) Phase 1 of the fused / factored E-step of a SHARD-SIZED input ("merge1", api.hip plan_fast):
 // the forward sweep (flags_f: SWEEP_CKPT or 0) and the warm-up-only backward pass (flags_b = SWEEP_TOP_ONLY).  Such an
 // E-step has fewer waves than the device has SIMDs (1024), and the dispatcher places the waves of ONE grid on distinct
@@ -816,9 +865,16 @@ __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ 
                                                        double *__restrict__ sb, double *__restrict__ bentry,
                                                        double *__restrict__ bexit)
 {
+	// Block order.  The dispatcher deals the work-groups of a grid out breadth first -- XCD = index % 8, then shader engine,
+	// compute unit, SIMD -- so a short period in the direction pattern aliases with that hierarchy: with even = forward, odd =
+	// backward (SWEEP_ALTERNATE: what the unfused back half runs, where both directions do the same work) every XCD holds ONE
+	// direction.  For phase 1 of a shard-sized E-step, where the forward blocks (warm-up + tile + stores) outlast the
+	// warm-up-only backward ones, that half of the device ended 0.3 ms after the other (scripts/sweep_trace.py); in list
+	// order -- all forward blocks, then all backward blocks -- the second wave on a SIMD is of the other direction.
 	const int nbf = (n_f + 3) / 4, nbb = (n_b + 3) / 4, both = 2 * min(nbf, nbb), b = blockIdx.x;
 	bool fwd; int blk;
-	if (b < both) { fwd = (b & 1) == 0; blk = b >> 1; }
+	if (!(flags_b & SWEEP_ALTERNATE)) { fwd = b < nbf; blk = fwd ? b : b - nbf; }
+	else if (b < both) { fwd = (b & 1) == 0; blk = b >> 1; }
 	else { fwd = nbf > nbb; blk = b - both + min(nbf, nbb); }
 	if (fwd) fwd_struct_body<false, NPL, CK>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, flags_f, f, invd, entry, nullptr);
 	else bwd_struct_body<false, NPL>(blk, sp, e, obs, chunks, items_b, n_b, W, T, flags_b, bt, sb, bentry, bexit, nullptr);
@@ -899,7 +955,7 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 {
 	const int nblk = (nf + 3) / 4 + (nb + 3) / 4;
 	if (nblk <= 0) return;
-	const int flags_f = p.ckpt ? SWEEP_CKPT : 0, flags_b = top_only ? SWEEP_TOP_ONLY : 0;
+	const int flags_f = p.ckpt ? SWEEP_CKPT : 0, flags_b = (top_only ? SWEEP_TOP_ONLY : 0) | (top_only && p.merge_order ? SWEEP_MERGED : SWEEP_ALTERNATE);
 #define PSMC_LS(NPL, CK) hipLaunchKernelGGL((k_sweep_struct<NPL, CK>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
 		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit)
@@ -943,3 +999,14 @@ void launch_walks(const EstepLaunch &p, hipStream_t st)
 }
 
 } // namespace psmc
+
+#ifdef PSMC_TRACE_SWEEP
+// debug build only: which = 0 forward bulk sweep, 1 backward warm-up pass, 2 walks; out = 4 * n stamps
+extern "C" int psmc_hip_debug_trace(int which, unsigned long long *out, int n)
+{
+	if (n > 16384) n = 16384;
+	return (int)(which == 0 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(psmc::g_trace_f), sizeof(unsigned long long) * 4 * n)
+	             : which == 1 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(psmc::g_trace_b), sizeof(unsigned long long) * 4 * n)
+	                          : hipMemcpyFromSymbol(out, HIP_SYMBOL(psmc::g_trace_w), sizeof(unsigned long long) * 4 * n));
+}
+#endif

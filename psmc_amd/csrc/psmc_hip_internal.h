@@ -63,6 +63,7 @@ struct EstepLaunch {
 	int fused;           // structured only: 1 = backward sweep and counts in one kernel, bt never stored (estep_fused.hip);
 	                     // 2 = factored statistics, no N x N counts at all (estep_factored.hip)
 	int ckpt;            // fused == 2: the forward sweep stores X at p % 8 == 0 only, the counts recompute the rest
+	int merge_order;     // merged phase-1 grid: 1 = all forward blocks, then all backward blocks; 0 = alternating
 	int merge1;          // fused != 0: bulk forward sweep and backward warm-up pass in ONE grid (k_sweep_struct) -- the dispatcher spreads
 	                     // the waves of one grid over distinct SIMDs, not those of concurrent grids (shard-sized inputs: api.hip plan_fast)
 	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)

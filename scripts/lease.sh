@@ -7,8 +7,9 @@
 #                                 REPEAT (1: A B A B ... when > 1), FACTORED (0), STATES (64; 128 = config 5), WARMUP (10), STEPS (12)
 #   timeline SHARES CHR           rocprofv3 --kernel-trace of a few E-steps, kernel timeline of the last one (every kernel)
 #   prof                          rocprofv3 kernel stats + PMC FETCH_SIZE / WRITE_SIZE passes (calibrated on a known copy) of the bench
-#                                 command and of config 5 alone, SQ matrix-pipe counters of the 128-state back halves;
-#                                 then locally: python scripts/prof_summary.py <tag> 30000001 (and PROF_NAME=n128 ...) -> profiles/
+#                                 command and of config 5 alone, SQ instruction counters of both (scripts/sq_summary.py);
+#                                 then locally: python scripts/prof_summary.py <tag> 30000001 (and PROF_NAME=n128 ...), python scripts/sq_summary.py <tag> n64|n128 -> profiles/
+#   wtrace [SHARE] ["opts"]       per-wave time stamps of phase 1: rebuilds the library with -DPSMC_TRACE_SWEEP, runs scripts/sweep_trace.py, rebuilds it plain
 #   probes                        psmc_hip_pipe_probe2 table + psmc_hip_place_probe grid (scripts/r03/probes.py)
 #   trace [SHARE] ["opts"]        per-E-step trace over 30 moving-parameter E-steps: ms, repair rounds, plan (scripts/r03/estep_trace.py)
 #   northstar                     scripts/northstar.py: psmc -N25 + 100 bootstraps at -N25, exact and fast (~9 min)
@@ -68,10 +69,15 @@ import sys; sys.path.insert(0, '$R')
 from psmc_amd import hip
 print(hip.stream_probe(1 << 27))" > $R/gpurun_out/pmc/calib_$C.out 2> $R/gpurun_out/pmc/calib_$C.err; echo "calib $C rc=$?"
   done
-  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc -o n128_SQ -- python $R/scripts/r03/n128_run.py 2 > $R/gpurun_out/pmc/n128_SQ.json 2> $R/gpurun_out/pmc/n128_SQ.err; echo "sq n128 rc=$?"
+  SQC="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU"
+  echo "rocprofv3 --kernel-trace --pmc $SQC -- python scripts/r03/n128_run.py 2  (scripts/lease.sh prof)" > $R/gpurun_out/pmc/n128_SQ.cmd
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQC --output-format csv -d $R/gpurun_out/pmc -o n128_SQ -- python $R/scripts/r03/n128_run.py 2 > $R/gpurun_out/pmc/n128_SQ.json 2> $R/gpurun_out/pmc/n128_SQ.err; echo "sq n128 rc=$?"
+  echo "rocprofv3 --kernel-trace --pmc $SQC -- python bench.py --steps 2 --warmup 1 $BARGS  (scripts/lease.sh prof)" > $R/gpurun_out/pmc/n64_SQ.cmd
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQC --output-format csv -d $R/gpurun_out/pmc -o n64_SQ -- python $R/bench.py --steps 2 --warmup 1 $BARGS > $R/gpurun_out/pmc/n64_SQ.json 2> $R/gpurun_out/pmc/n64_SQ.err; echo "sq n64 rc=$?"
   cd $R
   python scripts/prof_summary.py lease 30000001 | tail -30
   PROF_NAME=n128 PROF_STATES=128 PROF_CMD="python scripts/r03/n128_run.py" python scripts/prof_summary.py lease 30000001 | tail -20
+  python scripts/sq_summary.py lease n64 | head -12; python scripts/sq_summary.py lease n128 | head -10
   find gpurun_out/pmc gpurun_out/prof -name "*.csv" -size +3M -delete
 }
 case "$task" in
@@ -86,6 +92,9 @@ case "$task" in
     timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof -o tl -- python $R/scripts/shard_sweep.py --shares "${1-8}" --chr "${2-0}" --steps 4 --warmup 8 > $R/gpurun_out/tl.log 2>&1; echo "rocprof rc=$?"
     cd $R; python scripts/prof_timeline.py $(ls gpurun_out/prof/tl*.db | tail -1) k_reduce2 all | tee gpurun_out/timeline.txt | cut -c1-120 ;;
   prof) do_prof ;;
+  wtrace)
+    make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc EXTRA=-DPSMC_TRACE_SWEEP 2>&1 | grep -E "error" ; timeout 300 python scripts/sweep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/wave_trace.txt | cut -c1-230
+    make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc 2>&1 | grep -E "error" ;;
   probes) timeout 300 python scripts/r03/probes.py 2>&1 | grep -v amdgpu.ids ;;
   trace) timeout 600 python scripts/r03/estep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids ;;
   northstar) timeout 2400 python scripts/northstar.py gpurun_out/northstar.json gpurun_out/traj_n128.json > gpurun_out/ns.log 2> gpurun_out/ns.err; echo "northstar rc=$?"; tail -5 gpurun_out/ns.err | cut -c1-300; tail -30 gpurun_out/ns.log | cut -c1-300 ;;

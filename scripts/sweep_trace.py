@@ -5,7 +5,7 @@ Every wave of the bulk forward sweep and of the backward warm-up pass stamps its
 its warm-up) and its end with the 100 MHz wall clock, plus the SIMD it ran on.  Prints percentiles of those stamps relative to
 the earliest start, and the same split by "first / second wave on its SIMD".
 
-    python scripts/sweep_trace.py [share_N] ["opt=v opt=v"]     # share_N: rank 0's share of the genome at N GPUs (1 = whole genome)
+    python scripts/sweep_trace.py [share_N] ["opt=v opt=v"]     # share_N: rank 0's share of the genome at N GPUs (1 = whole genome, 0 = one 500 k-bin chromosome)
 """
 import ctypes as C
 import os
@@ -30,7 +30,10 @@ def main():
     traj, _ = bench.load_trajectory(os.path.join(ROOT, "tests", "golden", "traj_n64.json"))
     lens = sim.human_like_lengths(30_000_000, n_seg=90)
     full = sim.simulate_genome(a, e, a0, lens, seed=43)
-    segs = [full[i] for i in partition_segments(lens, share)[0]]
+    if share == 0:   # config 2: one 500 k-bin chromosome
+        segs = [sim.simulate_segment(a, e, a0, 500000, np.random.default_rng(7))]
+    else:
+        segs = [full[i] for i in partition_segments(lens, share)[0]]
     sh = bench.Shard(hip, torch, segs, 64, 0, hip.MODE_FAST, opts)
     es = sh.es
     stream = torch.cuda.current_stream()

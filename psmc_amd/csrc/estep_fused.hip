@@ -102,6 +102,9 @@ __device__ __forceinline__ void count4f_mfma(const double (&FA)[NPLF], const dou
 #pragma unroll
 		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[j2], acc[j][j2], 0, 0, 0);
 }
+#ifdef PSMC_TRACE_SWEEP
+__device__ unsigned long long g_trace_c[4 * 8192];
+#endif
 __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                                 const double *__restrict__ invd, const uint8_t *__restrict__ obs,
                                                                 const Chunk *__restrict__ chunks, const int *__restrict__ tiles,
@@ -117,6 +120,11 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
 	__syncthreads();
 	const int group = group0 + blockIdx.x;
+#ifdef PSMC_TRACE_SWEEP
+	// debug build (scripts/sweep_trace.py): wall-clock start / end and shader-clock cycles of every wave of the counts
+	struct TraceC { int g; unsigned long long w0, c0; __device__ ~TraceC() { if (threadIdx.x == 0 && g < 8192) { g_trace_c[4 * g] = w0; g_trace_c[4 * g + 1] = __builtin_readcyclecounter() - c0; g_trace_c[4 * g + 2] = wall_clock64(); } } }
+		trace_c{group, (unsigned long long)wall_clock64(), (unsigned long long)__builtin_readcyclecounter()};
+#endif
 	const int entry = tiles[4 * blockIdx.x + row];
 	const bool valid = entry >= 0, from_above = valid && mode == 0 && (entry & (1 << 30)) != 0;
 	const int tile = valid ? (entry & ~(1 << 30)) : 0;
@@ -430,3 +438,11 @@ void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo,
 }
 
 } // namespace psmc
+
+#ifdef PSMC_TRACE_SWEEP
+extern "C" int psmc_hip_debug_trace_counts(unsigned long long *out, int n) // debug build only: 4 * n stamps of k_bwd_count4f_struct (by group)
+{
+	if (n > 8192) n = 8192;
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psmc::g_trace_c), sizeof(unsigned long long) * 4 * n);
+}
+#endif

@@ -107,6 +107,17 @@ def main():
                 print("   %-44s %4d waves: steps p50 %6d max %6d | end us p50 %7.0f  p90 %7.0f  p99 %7.0f  max %7.0f | us per step p50 %.3f" % (
                     lab, sel.sum(), np.percentile(steps[sel], 50), steps[sel].max(), np.percentile(en[sel], 50), np.percentile(en[sel], 90), np.percentile(en[sel], 99), en[sel].max(),
                     np.percentile((en[sel] - st[sel]) / np.maximum(steps[sel], 1), 50)))
+    # the fused back half: shader clock under the matrix instructions
+    buf = np.zeros(4 * 8192, dtype=np.uint64)
+    if lib.psmc_hip_debug_trace_counts(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 8192) == 0:
+        t = buf.reshape(8192, 4); t = t[t[:, 0] > 0]
+        t = t[t[:, 0] >= t[:, 0].max() - np.uint64(2_000_000)]
+        if len(t):
+            dur = (t[:, 2].astype(np.int64) - t[:, 0].astype(np.int64)) / 100.0
+            mhz = t[:, 1].astype(np.float64) / np.maximum(dur, 1e-3)
+            q = lambda x: "min %7.0f  p10 %7.0f  p50 %7.0f  p90 %7.0f  max %7.0f" % (x.min(), np.percentile(x, 10), np.percentile(x, 50), np.percentile(x, 90), x.max())
+            print("fused backward + counts (k_bwd_count4f_struct): %d waves; wave duration us: %s" % (len(t), q(dur)))
+            print("   shader clock over the wave's life, MHz: " + q(mhz))
     sh.close()
 
 

@@ -943,7 +943,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
 				if (!bwd) for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
 				else for (int t = first + count - 1; t > first; --t) { kc.push_back(t); kc.push_back(1); }
-			} else { w[2 * nw] = first; w[2 * nw + 1] = count; ++nw; }
+			} else { w[2 * nw] = first; w[2 * nw + 1] = (head_count == 0 && !bwd) ? -(count - 1) : count; ++nw; } // k_walk1_struct forward: stop where the last tile starts
 		}
 	};
 	add_runs(kf, c->n_long_f, false);

@@ -193,7 +193,9 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	else __builtin_amdgcn_s_setprio(1); // ahead of the backward warm-up and the rest of phase 1: once its warm-up is done this sweep
 	                                    // is paced by its stores and leaves the vector units to them
 	const Chunk c = chunks[it.first];
-	const int p_last = chunks[it.first + it.count - 1].hi;
+	// a walk (65..128 states: k_walk_struct) stops where its last tile starts: the step at that position stores the tile's start
+	// vector, and nobody reads what a walk computes inside the last tile of its run (round 3; see k_walk1_struct)
+	const int p_last = (walk && !REPAIR) ? chunks[it.first + it.count - 1].lo : chunks[it.first + it.count - 1].hi;
 	const uint8_t *o = obs + c.off;
 	double *fo = f + c.off * S + k0, *io = invd + c.off;
 	StructParN<NPL> sc;
@@ -361,7 +363,9 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	const int L = c.L;
 	BwdCursor cur;
 	cur.lo = c.lo; cur.top = min(c.hi, L - 1); cur.tile = t_top;
-	const int p_low = (flags & SWEEP_TOP_ONLY) ? cur.top : chunks[it.first].lo;
+	// TOP_ONLY: the warm-up alone; a walk stops where the lowest tile's start vector (bentry) is stored
+	const int p_low = (flags & SWEEP_TOP_ONLY) ? cur.top
+	                  : ((!REPAIR && (flags & SWEEP_WALK)) ? min(chunks[it.first].hi, chunks[it.first].L - 1) : chunks[it.first].lo);
 	const bool valid = slot < n_items && cur.top >= cur.lo; // a tile holding only position L owns no transition
 	const bool walk = (flags & (SWEEP_WALK | SWEEP_TOP_ONLY)) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0;
 	cur.store = !walk;
@@ -472,9 +476,11 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 	if (block < n_f) { // ---------------- forward
 		const SweepItem it = items_f[block];
 		const Chunk c = chunks[it.first];
-		// count = -k <= 0: walk through k tiles and stop where tile first + k, the head of a transfer-matrix chain, starts --
-		// only its start vector is wanted (k = 0: the warm-up alone; k = 1: a segment's first tile, which has no X_0 for
-		// a matrix to start from); the head tile itself is the first matrix of the chain
+		// count = -k <= 0: walk through k tiles and stop where tile first + k starts -- only its start vector is wanted.  k = 0:
+		// the head of a transfer-matrix chain (the warm-up alone; the head tile itself is the first matrix of the chain); k = 1
+		// there: a segment's first tile, which has no X_0 for a matrix to start from; and since round 3 every SHORT run of
+		// r tiles is the item (first, -(r - 1)): nobody reads what a walk computes inside the LAST tile of its run (the run
+		// tiles are recomputed from the boundary vectors), and those T steps were the end of the longest walks
 		const bool warm_only = it.count <= 0;
 		const int thru = warm_only ? -it.count : it.count;
 		const int p_last = thru == 0 ? c.lo - 1 : chunks[it.first + thru - 1].hi;
@@ -508,7 +514,8 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 		int tile = it.first + max(it.count, 1) - 1;
 		const Chunk c = chunks[tile];
 		int lo = c.lo, top = min(c.hi, c.L - 1);
-		const int L = c.L, p_low = warm_only ? top + 1 : chunks[it.first].lo;
+		// a run of r tiles: stop where the lowest tile's start vector (bentry) exists -- its own T steps are for the recomputation
+		const int L = c.L, p_low = warm_only ? top + 1 : chunks[it.first + 1].lo;
 		if (top < lo) return;
 		const uint8_t *o = obs + c.off;
 		StructPar1 s1; s1.mS = sp[192 + lane]; s1.wS = sp[64 + lane]; s1.mP = sp[128 + lane]; s1.wP = sp[lane]; s1.dd = sp[256 + lane];
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
 			}
 			w = wn;
 		}
-		if (warm_only) bentry[(int64_t)tile * 64 + lane] = x;
+		if (warm_only || it.count > 1) bentry[(int64_t)tile * 64 + lane] = x;
 	}
 }
 

@@ -82,7 +82,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           auto: 1 while a tile is shorter than its warm-up
  *  --- glued runs ---------------------------------------------------------------------------------------------------
  *  "kc_min"        auto     runs of at least this many tiles get their boundary vectors from a chain of tile transfer
- *                           matrices instead of a walk; 0 = never.  auto (-1): 4 with 64 states, 8 with 65..128
+ *                           matrices instead of a walk; 0 = never.  auto (-1): 4 with 64 states (5 in the two-round plan), 8 with
+ *                           65..128 (12)
  *  "kc_div"        16       at most n_tiles / kc_div tiles per direction get a transfer matrix
  *  "kc_sub"        auto     64 states: a tile's steps are cut into this many ranges with a matrix (and a pair of
  *                           waves) each; auto: ranges of about (tile + warmup) / 8 steps, at most 4

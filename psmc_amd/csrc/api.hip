@@ -41,8 +41,8 @@ struct psmc_hip_ctx {
 	bool warm_shift_set = false, kc_sub_set = false;
 	int warm_shift_used = 1, kc_sub_used = 4;
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
-	int kc_min = -1;           // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never; -1: 4 with
-	                           // 64 states, 8 with 65..128 -- measured, build_items)
+	int kc_min = -1;           // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never; -1: 4 / 5 with
+	                           // 64 states (one round of tiles / two), 8 / 12 with 65..128 -- measured, build_items)
 	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
 	double *d_Kcol = nullptr; size_t kcol_cap = 0;
 	hipStream_t stream5 = nullptr;
@@ -915,7 +915,8 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	//   d_items + 12nc: wl_f (2nc) | wl_b (2nc) | kc tiles (4nc: KcTile) | runs (4nc + : KcRun)
 	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b;
 	c->n_wl_f = c->n_wl_b = 0;
-	const int kc_min = c->kc_min >= 0 ? c->kc_min : (c->ns == 128 ? 8 : 4); // auto: measured per model size (profiles/r03_kc_min_sweep.txt)
+	// auto: measured per model size and plan (profiles/r03_kc_min_sweep.txt): one more tile is walked where there are two rounds of tiles
+	const int kc_min = c->kc_min >= 0 ? c->kc_min : (c->ns == 128 ? (nc > 4096 ? 12 : 8) : (nc > 4096 ? 5 : 4));
 	const bool chains = kc_min >= 2; // 64 states: one state per lane in the chain kernel; 128: two
 	const int head_count = c->ns == 64 ? 0 : 1; // k_walk1_struct knows count 0 (stop at the head's start vector); the four-runs-per-wave walk of 65..128 states walks through the head tile
 	auto add_runs = [&](const std::vector<std::pair<long long, std::pair<int, int>>> &k, int n_long, bool bwd) {

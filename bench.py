@@ -535,7 +535,7 @@ def main():
                 out["shard_sweep"] = {"error": str(ex_)}
         if world == 1 and args.group_extra > 0:
             try:  # the product's own multi-GPU engine on this one device: must reproduce the headline (within 2 %)
-                ge = group_engine_run(hip, segs, [local], moving, args.steps, args.warmup, mode)
+                ge = group_engine_run(hip, segs, [local], moving, args.steps, max(args.warmup, 10), mode)   # a fresh context: past its learning steps (the headline's context has run more E-steps by now)
                 ge["value"] = total_bins / (ge["ms_per_step"] * 1e-3); ge["vs_headline"] = ms_per_step / ge["ms_per_step"]
                 out["group_engine"] = ge
             except Exception as ex_:

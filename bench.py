@@ -528,18 +528,6 @@ def main():
                                                  "per bin (no counts GEMM, no bt table); blocking call incl. read-back; moving parameters"}
             except Exception as ex_:
                 out["factored_stats"] = {"error": str(ex_)}
-        if world == 1 and mode == hip.MODE_FAST and args.shard_extra > 0 and not args.fixed_params:
-            try:
-                out["shard_sweep"] = shard_sweep_extra(hip, torch, sim, partition_segments, segs, lens, a, e, a0, moving, local, args.opt, stream, ms_per_step)
-            except Exception as ex_:
-                out["shard_sweep"] = {"error": str(ex_)}
-        if world == 1 and args.group_extra > 0:
-            try:  # the product's own multi-GPU engine on this one device: must reproduce the headline (within 2 %)
-                ge = group_engine_run(hip, segs, [local], moving, args.steps, max(args.warmup, 10), mode)   # a fresh context: past its learning steps (the headline's context has run more E-steps by now)
-                ge["value"] = total_bins / (ge["ms_per_step"] * 1e-3); ge["vs_headline"] = ms_per_step / ge["ms_per_step"]
-                out["group_engine"] = ge
-            except Exception as ex_:
-                out["group_engine"] = {"error": str(ex_)}
     # ---- config 3 proper beside a weak-scaling headline: ONE genome sharded over the ranks
     if world > 1 and args.scaling == "weak" and mode == hip.MODE_FAST:
         sh.close()
@@ -667,6 +655,28 @@ def main():
             s8.close()
         except Exception as ex_:
             out["n128"] = {"error": str(ex_)}
+    if rank == 0 and world == 1 and mode == hip.MODE_FAST and args.shard_extra > 0 and not args.fixed_params:
+        try:  # (after the extras that need the headline's context: see the note on hardware queues below)
+            try:
+                sh.close()
+            except Exception:
+                pass
+            out["shard_sweep"] = shard_sweep_extra(hip, torch, sim, partition_segments, segs, lens, a, e, a0, moving, local, args.opt, stream, ms_per_step)
+        except Exception as ex_:
+            out["shard_sweep"] = {"error": str(ex_)}
+    if rank == 0 and world == 1 and args.group_extra > 0 and mode == hip.MODE_FAST:
+        try:  # the product's own multi-GPU engine on this one device: must reproduce the headline (within 2 %).
+            # Every other context of the process is closed first: a context holds five streams, and beyond GPU_MAX_HW_QUEUES = 8
+            # streams of one process share hardware queues -- the E-step's own streams would then wait for each other
+            try:
+                sh.close()
+            except Exception:
+                pass
+            ge = group_engine_run(hip, segs, [local], moving, args.steps, max(args.warmup, 10), mode)   # a fresh context: past its learning steps
+            ge["value"] = total_bins / (ge["ms_per_step"] * 1e-3); ge["vs_headline"] = ms_per_step / ge["ms_per_step"]
+            out["group_engine"] = ge
+        except Exception as ex_:
+            out["group_engine"] = {"error": str(ex_)}
     if rank == 0 and world == 1 and args.boot_extra > 0 and mode == hip.MODE_FAST:
         try:  # config 4 through the product binary (every context of this process is closed: the exact batch sizes its groups by the free memory)
             try:

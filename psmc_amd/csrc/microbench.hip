@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void k_place_probe(double *__restrict__ out, i
 		c.mS[i] = 0.01 + 1e-4 * (lane + i) + seed * 1e-9; c.wS[i] = 0.012 - 1e-5 * lane; c.mP[i] = 0.009 + 1e-5 * i;
 		c.wP[i] = 0.011; c.dd[i] = 0.3; xv[i] = 1.0 + 0.01 * (lane & 15) + 0.001 * i;
 	}
+	// seed < 0 (PSMC_HIP_PROBE_PRIO=1): the first half of the grid -- the first wave the dispatcher puts on every SIMD -- runs at wave
+	// priority 0, the second half at 3: does s_setprio decide who issues, or the age of the wave?
+	if (seed < 0.0) { if (2 * blockIdx.x < gridDim.x) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); } // the YOUNGER wave of every SIMD at the higher priority
 	const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
 	const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20); // HW_REG_XCC_ID
 	const unsigned long long t0 = __builtin_readcyclecounter();
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256) void k_place_probe(double *__restrict__ out, i
 }
 int run_place_probe(hipStream_t stream, double *d_out, int n_waves, int wpb, int steps)
 {
-	hipLaunchKernelGGL(k_place_probe, dim3((n_waves + wpb - 1) / wpb), dim3(64 * wpb), 0, stream, d_out, steps, 0.37);
+	hipLaunchKernelGGL(k_place_probe, dim3((n_waves + wpb - 1) / wpb), dim3(64 * wpb), 0, stream, d_out, steps, getenv("PSMC_HIP_PROBE_PRIO") ? -0.37 : 0.37);
 	return (int)hipGetLastError();
 }
 

@@ -38,12 +38,15 @@ struct psmc_hip_ctx {
 	int merge1_used = 0;
 	int merge_order = -1;      // "merge_order": block order of that grid: 1 = forward blocks, then backward blocks; 0 = alternating (every XCD gets one
 	                           // direction); -1 = by the plan: 1 while a tile is shorter than its warm-up (measured: 3.75 M bins 3.00 vs 3.25 ms, 7.5 M equal, 15 M 7.9 vs 7.6)
+	int coarse = -1;           // "coarse": a bulk sweep item spans up to this many consecutive tiles of a segment: ONE speculative warm-up per item and
+	                           // direction, the backward pass walks the item and leaves every tile's start vector (build_items); -1 = by the plan
+	int coarse_used = 1, items_coarse = -1;
 	bool warm_shift_set = false, kc_sub_set = false;
 	int warm_shift_used = 1, kc_sub_used = 4;
 	int kc_div = 16;           // "kc_div": at most n_tiles / kc_div tiles per direction get a transfer matrix (16 tile sweeps of work each)
 	int kc_min = -1;           // "kc_min": runs of at least this many tiles get the transfer-matrix chain instead of a walk (0: never; -1: 4 / 5 with
 	                           // 64 states (one round of tiles / two), 8 / 12 with 65..128 -- measured, build_items)
-	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0;
+	int n_wl_f = 0, n_wl_b = 0, n_kc = 0, n_chain_f = 0, n_chain_b = 0, n_singles_b = 0;
 	double *d_Kcol = nullptr; size_t kcol_cap = 0;
 	hipStream_t stream5 = nullptr;
 	int ckpt = 1;              // "ckpt": factored statistics recompute X from checkpoints every 8 positions instead of reading the table
@@ -297,6 +300,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
 	else if (k == "runs_late") { c->runs_late = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
+	else if (k == "coarse") { if (v < -1 || v > 16) return PSMC_HIP_EINVAL; c->coarse = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "merge_order") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge_order = (int)v; }
 	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->kc_sub_set = true; c->plan_dirty = true; c->items_dirty = true; }
@@ -763,6 +767,11 @@ static int plan_fast(psmc_hip_ctx *c)
 	c->two_phase_used = c->two_phase >= 0 ? c->two_phase : (one_round ? 0 : 2);
 	c->merge1_used = c->merge1 >= 0 ? c->merge1 : (one_round ? 1 : 0);
 	c->warm_shift_used = c->warm_shift_set ? c->warm_shift : (one_round ? 0 : 1);
+	// Coarse items (round 4).  The fused back half wants ~4096 tiles (four on every SIMD), but phase 1 does not: with one
+	// speculation per TILE a 3.75 M-bin share pays 4096 x 2 x 3072 warm-up bins for 3.75 M owned ones, at two waves per SIMD.
+	// With one speculation per ITEM of two tiles the bulk grid is 512 + 512 waves -- one per SIMD, the unloaded step latency --
+	// and the backward pass walks W + T steps per item, leaving the start vector of both tiles.
+	c->coarse_used = c->coarse >= 0 ? std::max(c->coarse, 1) : (one_round && nc > 2048 ? 2 : 1);
 	// transfer matrices: a tile's steps are cut into ranges of about 1000 steps (one wave pair each), so that the column
 	// kernel is no longer than a bulk sweep; short tiles need fewer ranges -- and every range is one more 64 x 64 product
 	// in the sequential chain that follows
@@ -781,7 +790,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_items, (size_t)24 * nc + 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_items, (size_t)26 * nc + 64))) return rc;
 		if ((rc = dev_alloc(c, &c->d_ftiles, (size_t)2 * (nc + 4)))) return rc;
 		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
 		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
@@ -799,36 +808,50 @@ static int plan_fast(psmc_hip_ctx *c)
 
 // Sweep items of the structured kernels: maximal runs of glued tiles (one segment, at most group_cap
 // bins), ordered by step count so that the four rows of a wave finish together (longest first).
-static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
+static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 {
 	const int nc = (int)c->chunks.size(), W = c->warmup;
+	// Coarse items (round 4): the tiles between two learned runs are cut at fixed boundaries (tile index inside the segment
+	// % coarse == 0) into BULK items of up to `coarse` tiles.  An item speculates once per direction; the forward sweep runs
+	// through its tiles (X stored, every tile's entry vector left on the way), the backward pass of the fused / factored
+	// plans walks it from the top tile's warm-up down to the lowest tile's top and leaves every tile's start vector.  Only
+	// item heads can fail a verify; a head that does is glued to its neighbour like any tile (learn_groups) and the run it
+	// forms is walked / chained as before.  Backward: not in the two-phase plan, whose odd tiles do not speculate at all.
+	const int cf = std::max(1, coarse), cb = two_phase_bwd ? 1 : cf;
 	// Two-phase plan (fused back half, two launches): a single tile with an odd index inside its segment does not
 	// speculate backward.  It is in the second list and starts from the exit vector its neighbour above left in the
 	// first launch -- half of the backward warm-up work disappears.  Verify / repair / learning are unchanged: such a
 	// tile trivially agrees with its neighbour unless a later repair changes that neighbour.  (A forward counterpart --
 	// odd tiles from the X_{lo-1} of their neighbour in a second forward launch -- was built in round 2, measured equal
 	// and removed in round 3: the dependency costs what the saved warm-ups gain.)
-	std::vector<int> odd(nc, 0);
-	for (int b = 1; b < nc; ++b) if (c->chunks[b].off == c->chunks[b - 1].off) odd[b] = !odd[b - 1];
+	std::vector<int> odd(nc, 0), idx(nc, 0); // idx: the tile's index inside its segment
+	for (int b = 1; b < nc; ++b) if (c->chunks[b].off == c->chunks[b - 1].off) { odd[b] = !odd[b - 1]; idx[b] = idx[b - 1] + 1; }
 	// key: glued runs first (launched apart from the bulk), then phase A longest first, then phase B
 	std::vector<std::pair<long long, std::pair<int, int>>> kf, kb; // (key, (first, count))
-	auto key = [](int steps, int count, bool phase_b) { return (count > 1 ? -(1ll << 40) : (phase_b ? (1ll << 40) : 0ll)) - steps; };
-	std::vector<char> from_above(nc, 0), in_run(nc, 0); // in_run: member of a glued run of either direction
-	std::vector<std::pair<int, int>> gf, gb; // forward / backward groups (first, count)
+	auto key = [](int steps, bool run, bool phase_b) { return (run ? -(1ll << 40) : (phase_b ? (1ll << 40) : 0ll)) - steps; };
+	std::vector<char> from_above(nc, 0), in_run(nc, 0), in_run_f(nc, 0), in_run_b(nc, 0); // in_run: member of a glued run of either direction
+	std::vector<std::pair<int, int>> gf, gb; // forward / backward groups (first, count): learned runs and bulk items
+	auto same_seg = [&](int x, int y) { return c->chunks[x].off == c->chunks[y].off; };
 	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
 		int e = b + 1;
-		while (e < nc && c->glue_f[e] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
+		while (e < nc && c->glue_f[e] && same_seg(e, b) && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
+		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = in_run_f[t] = 1;
+		else // a bulk item: the unglued tiles that follow, up to the next coarse boundary or the head of a run
+			while (e < nc && e - b < cf && same_seg(e, b) && idx[e] % cf != 0 && !c->glue_f[e] && !(e + 1 < nc && c->glue_f[e + 1] && same_seg(e + 1, e))) ++e;
 		gf.push_back({b, e - b});
-		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = 1;
 		b = e;
 	}
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
 		int e = b + 1;
-		while (e < nc && c->glue_b[e - 1] && c->chunks[e].off == c->chunks[b].off && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap &&
+		while (e < nc && c->glue_b[e - 1] && same_seg(e, b) && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap &&
 		       c->chunks[e].lo < c->chunks[e].L) // a last tile holding only position L owns no transition: never a group's top
 			++e;
+		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = in_run_b[t] = 1;
+		else
+			while (e < nc && e - b < cb && same_seg(e, b) && idx[e] % cb != 0 && !c->glue_b[e - 1] && !(e + 1 < nc && c->glue_b[e] && same_seg(e + 1, e)) &&
+			       c->chunks[e].lo < c->chunks[e].L)
+				++e;
 		gb.push_back({b, e - b});
-		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = 1;
 		b = e;
 	}
 	// Run tiles in the SECOND launch (round 3).  The first launch of the fused back half then waits for the bulk sweeps only
@@ -848,7 +871,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 		bool pb = two_phase_bwd && e - b == 1 && odd[b] && b + 1 < nc && c->chunks[b + 1].off == lo.off && c->chunks[b + 1].lo < c->chunks[b + 1].L;
 		if (pb && c->runs_in_b && (in_run[b] || in_run[b + 1] || above_budget <= 0)) pb = false;
 		if (pb) { from_above[b] = 1; --above_budget; }
-		kb.push_back({key(std::min(top.hi + chunk_warm_b(top, W) + 1, top.L) - lo.lo, e - b, pb), {b, e - b}});
+		kb.push_back({key(std::min(top.hi + chunk_warm_b(top, W) + 1, top.L) - lo.lo, in_run_b[b] != 0, pb), {b, e - b}});
 	}
 	// tile lists of the fused back half: A = every tile whose X and start vector exist after phase A, B = the rest.
 	// B must hold the from-above tiles; A must hold the tile above every from-above tile; the run tiles go to B (above);
@@ -873,7 +896,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	for (const auto &gr : gf) {
 		const int b = gr.first, e = b + gr.second;
 		const Chunk &h = c->chunks[b], &l = c->chunks[e - 1];
-		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, e - b, false), {b, e - b}});
+		kf.push_back({key(l.hi - std::max(1, h.lo - chunk_warm_f(h, W)) + 1, in_run_f[b] != 0, false), {b, e - b}});
 	}
 	std::sort(kf.begin(), kf.end()); std::sort(kb.begin(), kb.end());
 	// layout of d_items (ints): items_f | items_b | ritems_f | ritems_b | members_f | members_b, 2*nc each
@@ -881,20 +904,20 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 	c->n_mem_f = c->n_mem_b = 0;
 	for (size_t i = 0; i < kf.size(); ++i) {
 		h[2 * i] = kf[i].second.first; h[2 * i + 1] = kf[i].second.second;
-		if (kf[i].second.second > 1)
+		if (in_run_f[kf[i].second.first])
 			for (int t = 0; t < kf[i].second.second; ++t) { mem[2 * (size_t)c->n_mem_f] = kf[i].second.first + t; mem[2 * (size_t)c->n_mem_f + 1] = 1; ++c->n_mem_f; }
 	}
 	for (size_t i = 0; i < kb.size(); ++i) {
 		h[(size_t)2 * nc + 2 * i] = kb[i].second.first; h[(size_t)2 * nc + 2 * i + 1] = kb[i].second.second;
-		if (kb[i].second.second > 1)
+		if (in_run_b[kb[i].second.first])
 			for (int t = 0; t < kb[i].second.second; ++t) {
 				mem[(size_t)2 * nc + 2 * (size_t)c->n_mem_b] = kb[i].second.first + t; mem[(size_t)2 * nc + 2 * (size_t)c->n_mem_b + 1] = 1; ++c->n_mem_b;
 			}
 	}
 	c->n_items_f = (int)kf.size(); c->n_items_b = (int)kb.size();
 	c->n_long_f = c->n_long_b = 0; // glued runs sort first (more steps than any single tile)
-	while (c->n_long_f < c->n_items_f && kf[c->n_long_f].second.second > 1) ++c->n_long_f;
-	while (c->n_long_b < c->n_items_b && kb[c->n_long_b].second.second > 1) ++c->n_long_b;
+	while (c->n_long_f < c->n_items_f && in_run_f[kf[c->n_long_f].second.first]) ++c->n_long_f;
+	while (c->n_long_b < c->n_items_b && in_run_b[kb[c->n_long_b].second.first]) ++c->n_long_b;
 	c->n_B_b = 0; // from-above singles sort last
 	for (int b = 0; b < nc; ++b) c->n_B_b += from_above[b];
 	{
@@ -904,8 +927,16 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd)
 		la.insert(la.end(), lb.begin(), lb.end());
 		if (!la.empty()) HIPCHK(c, hipMemcpy(c->d_ftiles, la.data(), sizeof(int) * la.size(), hipMemcpyHostToDevice));
 	}
-	c->items_two_phase = two_phase_bwd ? 2 : 0;
+	c->items_two_phase = two_phase_bwd ? 2 : 0; c->items_coarse = coarse;
 	HIPCHK(c, hipMemcpy(c->d_items, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+	{ // every tile outside the backward runs as a one-tile item, bulk items in launch order: what the factored back half's main pass
+	  // takes when its bulk items span several tiles (its kernels work on single tiles)
+		std::vector<int> sg;
+		for (size_t i = (size_t)c->n_long_b; i < kb.size(); ++i)
+			for (int t = kb[i].second.second - 1; t >= 0; --t) { sg.push_back(kb[i].second.first + t); sg.push_back(1); }
+		c->n_singles_b = (int)sg.size() / 2;
+		if (!sg.empty()) HIPCHK(c, hipMemcpy(c->d_items + (size_t)24 * nc, sg.data(), sizeof(int) * sg.size(), hipMemcpyHostToDevice));
+	}
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
 	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": a walk delivers the start vector
 	// of its head tile (the usual speculative warm-up, nothing more: walk item with count <= 0, see k_walk1_struct; round 1
@@ -1035,7 +1066,10 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 		HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * c->chunks.size(), hipMemcpyHostToDevice));
 		c->chunks_dirty = false;
 	}
-	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0)) && (rc = build_items(c, two_phase_bwd))) return rc;
+	// coarse bulk items: the fused and the factored back half only (their backward pass of phase 1 leaves start vectors, no table)
+	const int coarse = (c->use_struct && p.fused != 0) ? c->coarse_used : 1;
+	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0) || c->items_coarse != coarse) && (rc = build_items(c, two_phase_bwd, coarse))) return rc;
+	p.coarse = coarse; p.d_singles_b = c->d_items + 24 * (size_t)p.n_chunks; p.n_singles_b = c->n_singles_b;
 	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;

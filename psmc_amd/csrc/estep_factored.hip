@@ -442,7 +442,8 @@ __global__ __launch_bounds__(SA) void k_reduce_factored2(const double *__restric
 void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, int n)
 {
 	if (n <= 0) return;
-	const SweepItemA *items = (const SweepItemA *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
+	// which == 6: the main pass when the bulk items span several tiles (coarse): every tile outside the backward runs, one by one
+	const SweepItemA *items = (const SweepItemA *)(which == 1 ? p.d_ritems_b : (which == 3 ? p.d_members_b : (which == 6 ? p.d_singles_b : p.d_items_b))) + first;
 	const int mode = which == 1 ? 1 : (which == 2 ? 2 : 0);
 	if (p.ckpt)
 		hipLaunchKernelGGL(k_bwd_acc_ckpt, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,

@@ -677,7 +677,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		const bool late = p.fused == 1 && p.runs_in_b && p.n_list_b > 0;
 		if (lw && ov && sw != sa && !late) (void)hipStreamWaitEvent(sa, p.evx[7], 0);
 		if (p.ev[8]) (void)hipEventRecord(p.ev[8], sa);
-		if (p.fused == 2) launch_bwd_acc(p, sa, 0, fb0, p.n_items_b - fb0);
+		if (p.fused == 2) { if (p.coarse > 1) launch_bwd_acc(p, sa, 6, 0, p.n_singles_b); else launch_bwd_acc(p, sa, 0, fb0, p.n_items_b - fb0); }
 		else {
 			launch_bwd_count(p, sa, 0, false);
 			if (p.n_list_b > 0) { // its tiles start from the exit vectors list A left

@@ -104,6 +104,7 @@ constexpr int SWEEP_NO_TOUCH = 8;   // REPAIR kernels: do not flag the tile for 
 constexpr int SWEEP_FROM_ENTRY = 2; // REPAIR kernels: start from the boundary vector a walk left instead of the neighbour's table row
 constexpr int SWEEP_MERGED = 64;    // backward blocks of the list-order merged phase-1 grid
 constexpr int SWEEP_ALTERNATE = 32; // k_sweep_struct: even blocks forward, odd blocks backward (default: list order)
+constexpr int SWEEP_COARSE = 128;   // bulk items may span several tiles (api.hip build_items, "coarse"): they are not the few latency-critical runs
 constexpr int SWEEP_CKPT = 16;     // forward: store X only at the positions p % 8 == 0 (and the item's last one): the
                                    // factored counts recompute the rest from these checkpoints (estep_factored.hip)
 
@@ -189,7 +190,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	bool tr_first = true;
 	if (tr) PSMC_TRACE(g_trace_f, block, 0, wall_clock64());
 #endif
-	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
+	if (REPAIR || (__any(it.count > 1) && !(flags & SWEEP_COARSE))) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
 	else __builtin_amdgcn_s_setprio(1); // ahead of the backward warm-up and the rest of phase 1: once its warm-up is done this sweep
 	                                    // is paced by its stores and leaves the vector units to them
 	const Chunk c = chunks[it.first];
@@ -355,8 +356,8 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	const unsigned long long trb_c0 = __builtin_readcyclecounter();
 	if (trb) PSMC_TRACE(g_trace_b, block, 0, wall_clock64());
 #endif
-	if (REPAIR || __any(it.count > 1)) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
-	else if ((flags & SWEEP_TOP_ONLY) && (flags & SWEEP_MERGED)) __builtin_amdgcn_s_setprio(1); // list-order merged grid: second wave on the SIMD of a forward
+	if (REPAIR || (__any(it.count > 1) && !(flags & SWEEP_COARSE))) __builtin_amdgcn_s_setprio(3); // few, latency-critical waves
+	else if ((flags & (SWEEP_TOP_ONLY | SWEEP_COARSE)) && (flags & SWEEP_MERGED)) __builtin_amdgcn_s_setprio(1); // list-order merged grid: second wave on the SIMD of a forward
 	                                                                                              // block (priority 1) with three quarters of its steps: ends with it
 	const int t_top = it.first + it.count - 1;
 	const Chunk c = chunks[t_top];
@@ -925,7 +926,7 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
 	const int flags = (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0) // run tiles are done before the counts start
-	                  | (p.ckpt ? SWEEP_CKPT : 0);
+	                  | (p.ckpt ? SWEEP_CKPT : 0) | (which == 0 && p.coarse > 1 ? SWEEP_COARSE : 0);
 #define PSMC_LF(REP, NPL, CK) hipLaunchKernelGGL((k_fwd_struct<REP, NPL, CK>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
 	const bool rep = which != 0;
@@ -940,7 +941,8 @@ void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	if (n_items <= 0) return;
 	const dim3 g((n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 || which == 5 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
-	const int flags = which == 5 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? SWEEP_TOP_ONLY : 0));
+	// which == 4 with coarse items: the pass walks every item from the top tile's warm-up down to the lowest tile's top and leaves each tile's start vector
+	const int flags = which == 5 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? (p.coarse > 1 ? (SWEEP_WALK | SWEEP_COARSE) : SWEEP_TOP_ONLY) : 0));
 #define PSMC_LB(REP, NPL) hipLaunchKernelGGL((k_bwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, \
 		n_items, p.warmup, p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b)
 	const bool rep = !(which == 0 || which == 4);
@@ -962,7 +964,9 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 {
 	const int nblk = (nf + 3) / 4 + (nb + 3) / 4;
 	if (nblk <= 0) return;
-	const int flags_f = p.ckpt ? SWEEP_CKPT : 0, flags_b = (top_only ? SWEEP_TOP_ONLY : 0) | (top_only && p.merge_order ? SWEEP_MERGED : SWEEP_ALTERNATE);
+	const int co = top_only && p.coarse > 1 ? SWEEP_COARSE : 0; // coarse items: the fused / factored plans only (api.hip enqueue_fast)
+	const int flags_f = (p.ckpt ? SWEEP_CKPT : 0) | co,
+	          flags_b = (top_only ? (co ? SWEEP_WALK | co : SWEEP_TOP_ONLY) : 0) | (top_only && p.merge_order ? SWEEP_MERGED : SWEEP_ALTERNATE);
 #define PSMC_LS(NPL, CK) hipLaunchKernelGGL((k_sweep_struct<NPL, CK>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
 		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit)

@@ -71,6 +71,9 @@ struct EstepLaunch {
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
+	int coarse;                       // > 1: a bulk item spans up to this many tiles (one speculation per item; the backward pass of the fused /
+	                                  // factored plans WALKS its item and leaves every tile's start vector): api.hip build_items
+	const int *d_singles_b; int n_singles_b; // coarse > 1, factored back half: every tile outside the backward runs as a one-tile item
 	int n_B_b;                        // trailing backward items of the two-phase plan: they start from the exit vector of the tile above (second list of the fused back half)
 	const int *d_ftiles; int n_list_a, n_list_b; // fused back half: tile lists A | B (each padded to a multiple of 4 with -1)
 	int runs_in_b;                    // ... and every tile of a glued run is in list B: only the second launch waits for the runs' path

@@ -5,7 +5,7 @@
 #   bench [bench.py args]         the driver's bench command (default: --steps 20 --warmup 5) + a digest of the line
 #   sweep CFG [CFG ...]           scripts/shard_sweep.py, one --cfg per argument ("" = defaults); env SHARES (8,4,2,1), CHR (500000),
 #                                 REPEAT (1: A B A B ... when > 1), FACTORED (0), STATES (64; 128 = config 5), WARMUP (10), STEPS (12)
-#   timeline SHARES CHR           rocprofv3 --kernel-trace of a few E-steps, kernel timeline of the last one (every kernel)
+#   timeline SHARES CHR           rocprofv3 --kernel-trace of a few E-steps, kernel timeline of the last one (every kernel); env CFG (options), FACTORED, TAG (output suffix)
 #   prof                          rocprofv3 kernel stats + PMC FETCH_SIZE / WRITE_SIZE passes (calibrated on a known copy) of the bench
 #                                 command and of config 5 alone, SQ instruction counters of both (scripts/sq_summary.py);
 #                                 then locally: python scripts/prof_summary.py <tag> 30000001 (and PROF_NAME=n128 ...), python scripts/sq_summary.py <tag> n64|n128 -> profiles/
@@ -89,8 +89,8 @@ case "$task" in
     echo "sweep rc=$?"; tail -3 gpurun_out/sweep.err | cut -c1-300; show_sweep gpurun_out/sweep.json ;;
   timeline)
     cd /tmp; rm -rf $R/gpurun_out/prof/tl*
-    timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof -o tl -- python $R/scripts/shard_sweep.py --shares "${1-8}" --chr "${2-0}" --steps 4 --warmup 8 > $R/gpurun_out/tl.log 2>&1; echo "rocprof rc=$?"
-    cd $R; python scripts/prof_timeline.py $(ls gpurun_out/prof/tl*.db | tail -1) k_reduce2 all | tee gpurun_out/timeline.txt | cut -c1-120 ;;
+    timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof -o tl -- python $R/scripts/shard_sweep.py --shares "${1-8}" --chr "${2-0}" --cfg "${CFG-}" --factored "${FACTORED-0}" --steps 4 --warmup "${WARMUP-8}" > $R/gpurun_out/tl.log 2>&1; echo "rocprof rc=$?"
+    cd $R; python scripts/prof_timeline.py $(ls -t gpurun_out/prof/tl*.db | head -1) ${LASTK-k_reduce2} all | tee "gpurun_out/timeline${TAG-}.txt" | cut -c1-120 ;;
   prof) do_prof ;;
   wtrace)
     make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc EXTRA=-DPSMC_TRACE_SWEEP 2>&1 | grep -E "error" ; timeout 300 python scripts/sweep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/wave_trace.txt | cut -c1-230

@@ -357,7 +357,9 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
                                   dict(two_phase=2), dict(chunk=256, warmup=512, two_phase=2), dict(GENOME), dict(chunk=256, warmup=512, **GENOME), dict(chunk=768, warmup=256, overlap=0, **GENOME), dict(chunk=768, warmup=64, merge1=0),
                                   dict(merge1=1, two_phase=2), dict(chunk=256, warmup=512, merge1=1, warm_shift=1), dict(chunk=1000, warmup=100, kc_sub=2),
                                   dict(chunk=1000, warmup=100, **GENOME), dict(chunk=256, warmup=512, runs_late=0, **GENOME),
-                                  dict(chunk=768, warmup=64, runs_late=0, **GENOME)])
+                                  dict(chunk=768, warmup=64, runs_late=0, **GENOME),
+                                  dict(chunk=256, warmup=512, coarse=2), dict(chunk=256, warmup=64, coarse=3), dict(chunk=1000, warmup=100, coarse=2, merge1=0), dict(chunk=768, warmup=64, coarse=4, learn=0),
+                                  dict(chunk=256, warmup=512, coarse=2, **GENOME), dict(chunk=1000, warmup=100, coarse=2, overlap=0)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is
@@ -378,7 +380,8 @@ def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=512, warmup=256), dict(chunk=1000, warmup=100, overlap=0, learn=0),
                                   dict(chunk=264, warmup=300, **GENOME), dict(chunk=768, warmup=64, two_phase=2),
                                   dict(fuse128=0), dict(fuse128=0, chunk=512, warmup=256), dict(fuse128=0, chunk=1000, warmup=100, overlap=0, learn=0),
-                                  dict(chunk=400, warmup=64, kc_min=2), dict(chunk=264, warmup=300, kc_min=4, **GENOME)])
+                                  dict(chunk=400, warmup=64, kc_min=2), dict(chunk=264, warmup=300, kc_min=4, **GENOME),
+                                  dict(chunk=512, warmup=256, coarse=2), dict(chunk=400, warmup=64, coarse=3, kc_min=2)])
 def test_fast_n128(hip, golden, oracle, opts):
     """-p "64*2" in fast mode: 8 states per lane in the structured sweeps; the counts fused with the backward sweep, four
     waves per group of four tiles (default), or from the bt table in four 64x64 quadrants (fuse128=0)."""
@@ -415,7 +418,8 @@ def test_fast_n128(hip, golden, oracle, opts):
 @pytest.mark.parametrize("opts", [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, merge1=0),
                                   dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=5000, warmup=16, overlap=0),
                                   dict(chunk=100, warmup=30, two_phase=2), dict(chunk=37, warmup=5, group_cap=3000, **GENOME), dict(chunk=64, warmup=0, warm_shift=1),
-                                  dict(chunk=64, warmup=0, two_phase=2)])
+                                  dict(chunk=64, warmup=0, two_phase=2), dict(chunk=100, warmup=30, coarse=2), dict(chunk=37, warmup=5, group_cap=3000, coarse=3),
+                                  dict(chunk=64, warmup=0, coarse=2), dict(chunk=100, warmup=30, coarse=2, **GENOME)])
 def test_fast_odd_tilings(hip, golden, oracle, opts):
     """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
     everything is repaired / learned into runs and stays inside the tolerance."""
@@ -436,7 +440,8 @@ def tri_sums(A):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
-                                  dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, **GENOME), dict(GENOME), dict(chunk=1001, warmup=100, merge1=0), dict(chunk=264, warmup=300, warm_shift=1)])
+                                  dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, **GENOME), dict(GENOME), dict(chunk=1001, warmup=100, merge1=0), dict(chunk=264, warmup=300, warm_shift=1),
+                                  dict(chunk=256, warmup=512, coarse=2), dict(chunk=1001, warmup=100, coarse=3), dict(chunk=264, warmup=64, coarse=2, merge1=0), dict(chunk=256, warmup=512, coarse=2, ckpt=0, **GENOME)])
 def test_fast_factored_statistics(hip, golden, oracle, opts):
     """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
     (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset.
@@ -722,7 +727,8 @@ def test_fast_stress_tiny_tiles_recycled_memory(hip, golden, oracle):
     o = oracle.estep(p["a"], p["e"], p["a0"], segs)
     want = tri_sums(o["A"])
     opts_list = [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, merge1=0), dict(chunk=64, warmup=0),
-                 dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=37, warmup=5, group_cap=3000, two_phase=2)]
+                 dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=37, warmup=5, group_cap=3000, two_phase=2),
+                 dict(chunk=100, warmup=30, coarse=2), dict(chunk=64, warmup=0, coarse=3), dict(chunk=37, warmup=5, group_cap=3000, coarse=2, **GENOME)]
     rng = random.Random(7)
     bad = []
     for rep in range(12):

@@ -96,7 +96,14 @@ def cpu_baseline(a, e, a0, segs, sample_bins):
     t0 = time.perf_counter()
     eng.estep(a, e, a0, sample)
     dt = time.perf_counter() - t0
-    return {"value": tot / dt, "unit": "bins/s", "cores": 1, "kind": kind,
+    model = "unknown"
+    try:   # the host CPU model and its core count beside the single-thread number
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": tot / dt, "unit": "bins/s", "cores": 1, "kind": kind, "host_cpu": model, "host_cores": os.cpu_count(),
             "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
 
 

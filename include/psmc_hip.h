@@ -80,6 +80,14 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "merge_order"   auto     block order of that grid: 1 = the forward blocks, then the backward blocks (the dispatcher deals blocks out
  *                           XCD first, so alternating directions put each direction on four of the eight XCDs); 0 = alternating.
  *                           auto: 1 while a tile is shorter than its warm-up
+ *  "coarse"        auto     a bulk sweep item spans up to this many consecutive tiles of a segment: ONE speculative warm-up per item
+ *                           and direction (the forward sweep runs through its tiles, the backward pass of phase 1 walks the item and
+ *                           leaves every tile's start vector), so the back half keeps its ~4096 tiles while phase 1 pays half the
+ *                           warm-ups.  Fused / factored back half only.  auto: 2 in the one-round plan when there are more than 2048
+ *                           tiles shorter than their warm-up (1 M .. 12 M bins), else 1
+ *  "gate"          auto     1: one-wave gate kernels order the DISPATCH of phase 1's grids across streams -- walks, then the bulk
+ *                           grid, then the transfer matrices -- so that every walk gets a SIMD slot of its own (they give up after
+ *                           ~200 us); 0: whatever order the queues come up in.  auto: with coarse items
  *  --- glued runs ---------------------------------------------------------------------------------------------------
  *  "kc_min"        auto     runs of at least this many tiles get their boundary vectors from a chain of tile transfer
  *                           matrices instead of a walk; 0 = never.  auto (-1): 4 with 64 states (5 in the two-round plan), 8 with
@@ -226,7 +234,8 @@ int psmc_hip_post_counts(psmc_hip_ctx *ctx, int seg, const int32_t *cnt1, int32_
  * Options: every psmc_hip_set_option key (applied to all shards) and "rccl" (-1 auto: RCCL when the devices are
  * distinct and more than one shard holds segments, else the host adds the shards' vectors in shard order -- also when
  * librccl cannot be opened or refuses the communicator; 0 never; 1 always, e.g. a one-device group as a smoke test of
- * the RCCL path: a missing RCCL is then an error). */
+ * the RCCL path: a missing RCCL is then an error; 2 (tests) always, and the devices may repeat -- for a stand-in library
+ * named by the environment variable PSMC_HIP_RCCL_LIB (tests/stub_rccl), which is loaded instead of librccl when set). */
 typedef struct psmc_hip_group psmc_hip_group;
 int  psmc_hip_group_create(psmc_hip_group **g, int n_states, int n_dev, const int *devices, int mode);
 void psmc_hip_group_destroy(psmc_hip_group *g);

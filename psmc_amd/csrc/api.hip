@@ -38,6 +38,9 @@ struct psmc_hip_ctx {
 	int merge1_used = 0;
 	int merge_order = -1;      // "merge_order": block order of that grid: 1 = forward blocks, then backward blocks; 0 = alternating (every XCD gets one
 	                           // direction); -1 = by the plan: 1 while a tile is shorter than its warm-up (measured: 3.75 M bins 3.00 vs 3.25 ms, 7.5 M equal, 15 M 7.9 vs 7.6)
+	int gate = -1;             // "gate": order the dispatch of phase 1's grids walks -> bulk -> transfer matrices (estep_struct.hip k_gate); -1 = with coarse
+	                           // items (measured: without them the bulk grid is the critical path and walks that land late, stacked on few SIMDs, slow fewer of its waves)
+	int *d_gate = nullptr;
 	int coarse = -1;           // "coarse": a bulk sweep item spans up to this many consecutive tiles of a segment: ONE speculative warm-up per item and
 	                           // direction, the backward pass walks the item and leaves every tile's start vector (build_items); -1 = by the plan
 	int coarse_used = 1, items_coarse = -1;
@@ -255,7 +258,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (c->parent) { // a batch child owns its plan only: streams, events, staging, observations and tables are the parent's
 		// (d_seg*: a child that took the exact fallback of psmc_hip_estep -- 65..128 states, a matrix without the PSMC form)
 		void *mine[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-		                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_items, c->d_ftiles, c->d_Kcol,
+		                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_gate, c->d_touch, c->d_items, c->d_ftiles, c->d_Kcol,
 		                c->d_segA, c->d_segE, c->d_segA0, c->d_chk};
 		for (void *p : mine) if (p) (void)hipFree(p);
 		if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -271,7 +274,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (!c->obs_borrowed && c->d_obs) (void)hipFree(c->d_obs);
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
-	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol,
+	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_gate, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol,
 	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
@@ -300,6 +303,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
 	else if (k == "runs_late") { c->runs_late = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
+	else if (k == "gate") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->gate = (int)v; }
 	else if (k == "coarse") { if (v < -1 || v > 16) return PSMC_HIP_EINVAL; c->coarse = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "merge_order") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge_order = (int)v; }
 	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
@@ -577,6 +581,13 @@ static void collect_timing(psmc_hip_ctx *c)
 			c->last_ms[3] = a + b;
 		} else el(c->ev[8], c->ev[9], c->last_ms[3]);  // the full expect pass (kernel alone)
 		el(c->ev[3], c->ev[4], c->last_ms[4]);
+		if (getenv("PSMC_HIP_DEBUG_TIMES")) { // where the step's time goes, from the marks the launchers leave anyway
+			double cs = 0, ce = 0, wk = 0, rt = 0;
+			auto el2 = [&](hipEvent_t a, hipEvent_t b, double &out) { if (hipEventElapsedTime(&t, a, b) == hipSuccess) out = t; else (void)hipGetLastError(); };
+			el2(c->ev[0], c->ev[8], cs); el2(c->ev[0], c->ev[9], ce); el2(c->ev[0], c->evx[6], wk); el2(c->ev[0], c->evx[7], rt);
+			double kc = 0, bg = 0; el2(c->ev[0], c->evx[8], kc); el2(c->ev[0], c->evx[1], bg);
+			fprintf(stderr, "[psmc_hip] times: total %.3f | bulk grid end %.3f | matrices end %.3f walks+chain end %.3f run tiles end %.3f | counts %.3f .. %.3f\n", c->last_ms[0], bg, kc, wk, rt, cs, ce);
+		}
 		el(c->ev[0], c->ev[5], c->last_ms[5]);  // speculative forward sweep kernel
 		el(c->ev[7], c->ev[6], c->last_ms[6]);  // speculative backward sweep kernel
 	} else {
@@ -700,13 +711,14 @@ static int estep_exact(psmc_hip_ctx *c, const double *a, const double *e, const 
 // the plan depends on whether the matrix has the PSMC form, which only stage_params() finds out.
 static int ensure_fast_buffers(psmc_hip_ctx *c)
 {
-	if (c->d_stage && c->d_stats && c->d_warm && c->d_cnt && c->h_cnt) return 0;
+	if (c->d_stage && c->d_stats && c->d_warm && c->d_cnt && c->h_cnt && c->d_gate) return 0;
 	int rc;
 	const size_t sl = (size_t)c->ns * c->ns + 3 * (size_t)c->ns + 1;
 	if ((rc = dev_alloc(c, &c->d_stage, (size_t)RED_ROWS * sl))) return rc;
 	if ((rc = dev_alloc(c, &c->d_stats, sl))) return rc;
 	if ((rc = dev_alloc(c, &c->d_warm, (size_t)2))) return rc;
 	if ((rc = dev_alloc(c, &c->d_cnt, (size_t)4))) return rc;
+	if ((rc = dev_alloc(c, &c->d_gate, (size_t)4))) return rc;
 	if (!c->h_cnt && (hipHostMalloc((void **)&c->h_cnt, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
 	                  hipHostGetDevicePointer((void **)&c->m_cnt, c->h_cnt, 0) != hipSuccess)) {
 		c->h_cnt = nullptr;
@@ -771,7 +783,9 @@ static int plan_fast(psmc_hip_ctx *c)
 	// speculation per TILE a 3.75 M-bin share pays 4096 x 2 x 3072 warm-up bins for 3.75 M owned ones, at two waves per SIMD.
 	// With one speculation per ITEM of two tiles the bulk grid is 512 + 512 waves -- one per SIMD, the unloaded step latency --
 	// and the backward pass walks W + T steps per item, leaving the start vector of both tiles.
-	c->coarse_used = c->coarse >= 0 ? std::max(c->coarse, 1) : (one_round && nc > 2048 ? 2 : 1);
+	// Measured (profiles/r04_coarse_sweep.txt): 3.75 M bins 2.98 -> 2.69 ms, 7.5 M 4.86 -> 4.45; no gain once a tile is as long as its
+	// warm-up (15 M: 7.0 vs 7.3) or when the fine tiles already fit one wave per SIMD (500 k), none with two rounds of tiles (genome).
+	c->coarse_used = c->coarse >= 0 ? std::max(c->coarse, 1) : (one_round && nc > 2048 && T < c->warmup ? 2 : 1);
 	// transfer matrices: a tile's steps are cut into ranges of about 1000 steps (one wave pair each), so that the column
 	// kernel is no longer than a bulk sweep; short tiles need fewer ranges -- and every range is one more 64 x 64 product
 	// in the sequential chain that follows
@@ -1069,6 +1083,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	// coarse bulk items: the fused and the factored back half only (their backward pass of phase 1 leaves start vectors, no table)
 	const int coarse = (c->use_struct && p.fused != 0) ? c->coarse_used : 1;
 	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0) || c->items_coarse != coarse) && (rc = build_items(c, two_phase_bwd, coarse))) return rc;
+	p.d_gate = (c->gate >= 0 ? c->gate != 0 : coarse > 1) ? c->d_gate : nullptr;
 	p.coarse = coarse; p.d_singles_b = c->d_items + 24 * (size_t)p.n_chunks; p.n_singles_b = c->n_singles_b;
 	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
 	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;

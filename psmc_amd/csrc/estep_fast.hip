@@ -596,6 +596,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	rep->converged = 1;
 	(void)hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), sm);
 	(void)hipMemsetAsync(p.d_touch_f, 0, 2 * sizeof(int) * (size_t)p.n_chunks, sm); // touch_f | touch_b
+	if (p.d_gate) (void)hipMemsetAsync(p.d_gate, 0, 2 * sizeof(int), sm); // started-counters of the walks and of the bulk grid
 	if (p.ev[0]) (void)hipEventRecord(p.ev[0], sm);
 	(void)hipEventRecord(p.evx[0], sm);
 	if (ov) (void)hipStreamWaitEvent(sa, p.evx[0], 0); // parameters uploaded, flags cleared
@@ -618,6 +619,9 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (ov && sw != sa) (void)hipStreamWaitEvent(sw, p.evx[0], 0);
 		launch_walks(p, sw); // short runs, and the start vector of every chain run
 	}
+	// dispatch order walks -> bulk -> transfer matrices (estep_struct.hip k_gate): the bulk grid's stream waits until every walk has its slot
+	const bool gated = lw && ov && p.d_gate != nullptr && sw != sm;
+	if (gated) launch_gate(sm, p.d_gate, walk_blocks(p));
 	if (mg) {
 		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0 - p.n_B_b, true);
 		(void)hipEventRecord(p.evx[1], sm);
@@ -625,6 +629,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (lw) {
 		if (p.n_kc > 0) { // long runs: transfer matrices of their tiles (a stream of their own), then the chain
 			if (ov) (void)hipStreamWaitEvent(sk, p.evx[0], 0);
+			// ... and the matrices wait until the bulk grid has been dispatched (merged: both directions; else the forward sweep)
+			if (gated && sk != sm) launch_gate(sk, p.d_gate + 1, std::min(2048, mg ? (p.n_items_f - ff0 + 3) / 4 + (p.n_items_b - fb0 - p.n_B_b + 3) / 4 : (p.structured ? (p.n_items_f - ff0 + 3) / 4 : 0)));
 			launch_kchain(p, sk, sw, p.evx[8]);
 		}
 		(void)hipEventRecord(p.evx[6], sw);

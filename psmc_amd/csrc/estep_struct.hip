@@ -92,6 +92,27 @@ template <int S> __device__ __forceinline__ void fill_lds_e(double *lds_e, const
 	for (int i = lane; i < S; i += 64) { lds_e[i] = e[i]; lds_e[S + i] = e[S + i]; lds_e[2 * S + i] = 1.0; lds_e[3 * S + i] = 1.0; }
 }
 
+// ---- Dispatch order across streams (round 4).
+// Phase 1 runs three kinds of waves side by side, on streams of their own: a few hundred WALKS (one latency-critical wave each,
+// priority 3), the BULK grid, and the transfer-matrix blocks (two waves x 176 registers each, several per SIMD).  The dispatcher
+// places the waves of one grid on distinct SIMDs but serves the queues in whatever order their first packets become ready; when the
+// matrices and the bulk were dispatched before the walks, the walks found no free slot: they started up to 0.6 ms late and up to
+// five on one SIMD, and a 7.5 M-bin share took 5.4 instead of 4.3 ms in two E-steps out of three (scripts/sweep_trace.py with
+// TRACE_STEPS; profiles/r04_walk_placement_trace.txt).  Kernels of different streams cannot be ordered by START with events (an event
+// waits for completion), so every wave group announces its start in a counter and a one-wave gate kernel ahead of the next kind
+// waits for it: walks -> bulk -> matrices.  The gate gives up after ~200 us (streams that share a hardware queue would otherwise wait
+// for a kernel queued behind them).
+__device__ __forceinline__ void announce_start(int *ctr) { if (ctr && threadIdx.x == 0) atomicAdd(ctr, 1); }
+__global__ __launch_bounds__(64) void k_gate(const int *__restrict__ ctr, int want)
+{
+	const unsigned long long t0 = wall_clock64();
+	while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < 20000ull) __builtin_amdgcn_s_sleep(8);
+}
+void launch_gate(hipStream_t st, const int *ctr, int want)
+{
+	if (want > 0) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, ctr, want);
+}
+
 // A sweep ITEM is a run of `count` consecutive tiles of one segment that one row walks through in
 // sequence (count == 1 unless the host glued tiles: see api.hip learn_groups -- where the chain forgets
 // slowly a speculative start is wrong and the repair rounds would walk the region tile by tile anyway;
@@ -274,8 +295,9 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
                                                      int n_items, int W, int T, int flags, double *__restrict__ f,
                                                      double *__restrict__ invd, double *__restrict__ entry,
-                                                     int *__restrict__ touch_f)
+                                                     int *__restrict__ touch_f, int *__restrict__ started)
 {
+	announce_start(started);
 	fwd_struct_body<REPAIR, NPL, CK>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
 }
 
@@ -352,7 +374,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	const int slot = block * R + (lane >> 4);
 	const SweepItem it = items[slot < n_items ? slot : 0];
 #ifdef PSMC_TRACE_SWEEP
-	const bool trb = !REPAIR && (flags & SWEEP_TOP_ONLY);
+	const bool trb = !REPAIR && (flags & (SWEEP_TOP_ONLY | SWEEP_COARSE));
 	const unsigned long long trb_c0 = __builtin_readcyclecounter();
 	if (trb) PSMC_TRACE(g_trace_b, block, 0, wall_clock64());
 #endif
@@ -443,8 +465,9 @@ __global__ __launch_bounds__(64) void k_walk_struct(const double *__restrict__ s
                                                       const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
                                                       int n_f, const SweepItem *__restrict__ items_b, int n_b, int W, int T,
                                                       double *__restrict__ entry, double *__restrict__ bentry,
-                                                      double *__restrict__ bexit)
+                                                      double *__restrict__ bexit, int *__restrict__ started)
 {
+	announce_start(started);
 	const int nbf = (n_f + 3) / 4;
 	if ((int)blockIdx.x < nbf)
 		fwd_struct_body<false, NPL>(blockIdx.x, sp, e, a0, obs, chunks, items_f, n_f, W, T, SWEEP_WALK, nullptr, nullptr, entry, nullptr);
@@ -464,9 +487,10 @@ __global__ __launch_bounds__(64) void k_walk1_struct(const double *__restrict__ 
                                                        const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
                                                        int n_f, const SweepItem *__restrict__ items_b, int n_b, int W, int T,
                                                        double *__restrict__ entry, double *__restrict__ bentry,
-                                                       double *__restrict__ bexit)
+                                                       double *__restrict__ bexit, int *__restrict__ started)
 {
 	const int lane = threadIdx.x, block = (int)blockIdx.x;
+	announce_start(started);
 #ifdef PSMC_TRACE_SWEEP
 	PSMC_TRACE(g_trace_w, block, 0, wall_clock64()); PSMC_TRACE(g_trace_w, block, 3, trace_hw());
 	struct TraceEnd { int b; __device__ ~TraceEnd() { if (threadIdx.x == 0 && b < 16384) g_trace_w[4 * b + 2] = wall_clock64(); } } trace_end{block};
@@ -871,8 +895,9 @@ __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ 
                                                        int flags_f, int flags_b, double *__restrict__ f, double *__restrict__ invd,
                                                        double *__restrict__ entry, double *__restrict__ bt,
                                                        double *__restrict__ sb, double *__restrict__ bentry,
-                                                       double *__restrict__ bexit)
+                                                       double *__restrict__ bexit, int *__restrict__ started)
 {
+	announce_start(started);
 	// Block order.  The dispatcher deals the work-groups of a grid out breadth first -- XCD = index % 8, then shader engine,
 	// compute unit, SIMD -- so a short period in the direction pattern aliases with that hierarchy: with even = forward, odd =
 	// backward (SWEEP_ALTERNATE: what the unfused back half runs, where both directions do the same work) every XCD holds ONE
@@ -928,7 +953,7 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	const int flags = (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0) // run tiles are done before the counts start
 	                  | (p.ckpt ? SWEEP_CKPT : 0) | (which == 0 && p.coarse > 1 ? SWEEP_COARSE : 0);
 #define PSMC_LF(REP, NPL, CK) hipLaunchKernelGGL((k_fwd_struct<REP, NPL, CK>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
-		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f)
+		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f, which == 0 && p.d_gate ? p.d_gate + 1 : nullptr)
 	const bool rep = which != 0;
 	if (p.ns == 128) { if (rep) PSMC_LF(true, 8, false); else PSMC_LF(false, 8, false); }
 	else if (p.ckpt) { if (rep) PSMC_LF(true, 4, true); else PSMC_LF(false, 4, true); } // checkpoint stores are a compile-time variant: no per-step branches in the full-table kernels
@@ -969,7 +994,7 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 	          flags_b = (top_only ? (co ? SWEEP_WALK | co : SWEEP_TOP_ONLY) : 0) | (top_only && p.merge_order ? SWEEP_MERGED : SWEEP_ALTERNATE);
 #define PSMC_LS(NPL, CK) hipLaunchKernelGGL((k_sweep_struct<NPL, CK>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
-		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit)
+		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_gate ? p.d_gate + 1 : nullptr)
 	if (p.ns == 128) PSMC_LS(8, false); else if (p.ckpt) PSMC_LS(4, true); else PSMC_LS(4, false);
 	PSMC_DBG("launch_sweeps", nf, nb, top_only);
 #undef PSMC_LS
@@ -992,6 +1017,7 @@ void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_cha
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kc_sub);
 	PSMC_DBG("launch_kchain", p.n_kc, p.n_chain_f, p.n_chain_b);
 }
+int walk_blocks(const EstepLaunch &p) { return p.ns == 64 ? p.n_wl_f + p.n_wl_b : (p.n_wl_f + 3) / 4 + (p.n_wl_b + 3) / 4; }
 // walks over the glued runs: boundary vectors only.  64 states: one wave per run, one state per lane; 65..128: four runs per wave
 void launch_walks(const EstepLaunch &p, hipStream_t st)
 {
@@ -999,13 +1025,13 @@ void launch_walks(const EstepLaunch &p, hipStream_t st)
 	if (p.ns == 64) {
 		hipLaunchKernelGGL(k_walk1_struct, dim3(p.n_wl_f + p.n_wl_b), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
 		                   (const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup,
-		                   p.tile_len, p.d_entry, p.d_bentry, p.d_bexit);
+		                   p.tile_len, p.d_entry, p.d_bentry, p.d_bexit, p.d_gate);
 		PSMC_DBG("launch_walks", p.n_wl_f, p.n_wl_b, 0);
 		return;
 	}
 	hipLaunchKernelGGL(k_walk_struct<8>, dim3((p.n_wl_f + 3) / 4 + (p.n_wl_b + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks,
 	                   (const SweepItem *)p.d_wl_f, p.n_wl_f, (const SweepItem *)p.d_wl_b, p.n_wl_b, p.warmup, p.tile_len,
-	                   p.d_entry, p.d_bentry, p.d_bexit);
+	                   p.d_entry, p.d_bentry, p.d_bexit, p.d_gate);
 	PSMC_DBG("launch_walks (four per wave)", p.n_wl_f, p.n_wl_b, 0);
 }
 

@@ -38,9 +38,15 @@ struct Rccl {
 	bool open(std::string &err)
 	{
 		if (lib) return true;
-		const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-		for (const char *nm : names) if ((lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-		if (!lib) { err = std::string("cannot open librccl: ") + dlerror(); return false; }
+		// PSMC_HIP_RCCL_LIB: the library to load instead (a site's own RCCL build; tests/stub_rccl: a single-process stand-in that
+		// lets the multi-shard branch below run on a one-GPU box -- see the "rccl" = 2 option)
+		if (const char *own = getenv("PSMC_HIP_RCCL_LIB")) {
+			if (!(lib = dlopen(own, RTLD_NOW | RTLD_LOCAL))) { err = std::string("cannot open PSMC_HIP_RCCL_LIB: ") + dlerror(); return false; }
+		} else {
+			const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+			for (const char *nm : names) if ((lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+			if (!lib) { err = std::string("cannot open librccl: ") + dlerror(); return false; }
+		}
 		CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
 		CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
 		AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
@@ -65,7 +71,8 @@ struct psmc_hip_group {
 	size_t stats_len = 0;
 	std::vector<hipStream_t> st;
 	std::string err;
-	int want_rccl = -1;                          // "rccl": -1 auto (distinct devices, more than one shard), 0 never, 1 always
+	int want_rccl = -1;                          // "rccl": -1 auto (distinct devices, more than one shard), 0 never, 1 always, 2 (tests): always, and
+	                                             // a device may repeat -- real RCCL refuses that communicator, the stand-in of tests/stub_rccl does not
 	bool distinct = true;
 	Rccl rccl;
 	std::vector<ncclComm_t> comm;
@@ -121,7 +128,7 @@ extern "C" const char *psmc_hip_group_last_error(const psmc_hip_group *g) { retu
 extern "C" int psmc_hip_group_set_option(psmc_hip_group *g, const char *key, double value)
 {
 	if (!g || !key) return PSMC_HIP_EINVAL;
-	if (!strcmp(key, "rccl")) { g->want_rccl = value < 0 ? -1 : (value != 0 ? 1 : 0); return PSMC_HIP_OK; }
+	if (!strcmp(key, "rccl")) { g->want_rccl = value < 0 ? -1 : (value == 2 ? 2 : (value != 0 ? 1 : 0)); return PSMC_HIP_OK; }
 	for (int i = 0; i < g->n_sh; ++i) {
 		const int rc = psmc_hip_set_option(g->sh[i], key, value);
 		if (rc) return gfail(g, rc, std::string("set_option: ") + key);
@@ -194,15 +201,15 @@ static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &ou
 	out.assign(len, 0.0);
 	int n_live = 0, first = -1;
 	for (int s = 0; s < g->n_sh; ++s) if (live[s]) { ++n_live; if (first < 0) first = s; }
-	bool use_rccl = g->want_rccl == 1 || (g->want_rccl < 0 && g->distinct && n_live > 1 && n_live == g->n_sh); // auto: every device takes part
-	if (use_rccl && !g->distinct) return gfail(g, PSMC_HIP_EINVAL, "rccl = 1 needs distinct devices");
+	bool use_rccl = g->want_rccl >= 1 || (g->want_rccl < 0 && g->distinct && n_live > 1 && n_live == g->n_sh); // auto: every device takes part
+	if (use_rccl && !g->distinct && g->want_rccl != 2) return gfail(g, PSMC_HIP_EINVAL, "rccl = 1 needs distinct devices");
 	if (use_rccl && n_live != g->n_sh) return gfail(g, PSMC_HIP_ESTATE, "RCCL all-reduce: a shard holds no segment (fewer segments than devices)");
 	if (use_rccl && g->comm.empty()) {
 		// auto mode falls back to the host sum when there is no usable RCCL on this node (same result, one more copy per
 		// shard); "rccl" = 1 keeps the hard error
 		std::string why;
 		if (!g->rccl.open(why)) {
-			if (g->want_rccl == 1) return gfail(g, PSMC_HIP_EDEVICE, why);
+			if (g->want_rccl >= 1) return gfail(g, PSMC_HIP_EDEVICE, why);
 			g->rccl_note = why; g->want_rccl = 0; use_rccl = false;
 		} else {
 			g->comm.assign(g->n_sh, nullptr);
@@ -210,7 +217,7 @@ static int reduce_vectors(psmc_hip_group *g, size_t len, std::vector<double> &ou
 			if (r != ncclSuccess) {
 				g->comm.clear();
 				why = std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(r);
-				if (g->want_rccl == 1) return gfail(g, PSMC_HIP_EDEVICE, why);
+				if (g->want_rccl >= 1) return gfail(g, PSMC_HIP_EDEVICE, why);
 				g->rccl_note = why; g->want_rccl = 0; use_rccl = false;
 			}
 		}
@@ -298,7 +305,7 @@ extern "C" int psmc_hip_group_estep(psmc_hip_group *g, const double *a, const do
 	if (g->mode == PSMC_HIP_MODE_FAST) {
 		int rc = for_shards(g, [&](int s) { return psmc_hip_estep_device(g->sh[s], a, e, a0, g->d_stats[s], g->st[s]); });
 		std::vector<double> v;
-		if (rc == PSMC_HIP_ENOTSUP) {
+		if (rc == PSMC_HIP_ENOTSUP && n > 64) { // (only the wide models have that fallback)
 			// 65..128 states and a matrix without the PSMC form (e.g. after psmc_cap_matrix): the device-resident entry point
 			// has no kernels for it, psmc_hip_estep falls back to the exact ones -- do the same per shard and add the host
 			// vectors in shard order, so that a command that works on one GPU works on a device list
@@ -313,6 +320,7 @@ extern "C" int psmc_hip_group_estep(psmc_hip_group *g, const double *a, const do
 				if (n_live++ == 0) v = hv[s]; else for (size_t i = 0; i < len; ++i) v[i] += hv[s][i];
 			}
 			g->last_reduce = n_live > 1 ? 2 : 0;
+			g->err.clear(); // the ENOTSUP of the first attempt is not this call's result
 		} else {
 			if (rc) return rc;
 			if ((rc = reduce_vectors(g, (size_t)n * n + 2 * n + 1, v, live_shards(g)))) return rc;

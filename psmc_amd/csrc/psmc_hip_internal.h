@@ -71,6 +71,8 @@ struct EstepLaunch {
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
+	int *d_gate;                      // [0] walk blocks started, [1] bulk blocks started: the gates that order the DISPATCH of phase 1's grids (estep_struct.hip
+	                                  // k_gate); null: no gates
 	int coarse;                       // > 1: a bulk item spans up to this many tiles (one speculation per item; the backward pass of the fused /
 	                                  // factored plans WALKS its item and leaves every tile's start vector): api.hip build_items
 	const int *d_singles_b; int n_singles_b; // coarse > 1, factored back half: every tile outside the backward runs as a one-tile item
@@ -129,6 +131,8 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
 void launch_walks(const EstepLaunch &p, hipStream_t st);
+void launch_gate(hipStream_t st, const int *ctr, int want);
+int walk_blocks(const EstepLaunch &p);
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols);
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb, bool top_only);
 void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo, bool all_from_bentry = false);

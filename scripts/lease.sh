@@ -89,11 +89,12 @@ case "$task" in
     echo "sweep rc=$?"; tail -3 gpurun_out/sweep.err | cut -c1-300; show_sweep gpurun_out/sweep.json ;;
   timeline)
     cd /tmp; rm -rf $R/gpurun_out/prof/tl*
-    timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof -o tl -- python $R/scripts/shard_sweep.py --shares "${1-8}" --chr "${2-0}" --cfg "${CFG-}" --factored "${FACTORED-0}" --steps 4 --warmup "${WARMUP-8}" > $R/gpurun_out/tl.log 2>&1; echo "rocprof rc=$?"
-    cd $R; python scripts/prof_timeline.py $(ls -t gpurun_out/prof/tl*.db | head -1) ${LASTK-k_reduce2} all | tee "gpurun_out/timeline${TAG-}.txt" | cut -c1-120 ;;
+    timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof -o tl -- python $R/scripts/shard_sweep.py --shares "${1-8}" --chr "${2-0}" --cfg "${CFG-}" --factored "${FACTORED-0}" --steps "${STEPS-4}" --warmup "${WARMUP-8}" > $R/gpurun_out/tl.log 2>&1; echo "rocprof rc=$?"
+    cd $R; python scripts/prof_timeline.py $(ls -t gpurun_out/prof/tl*.db | head -1) ${LASTK-k_reduce2} all | tee "gpurun_out/timeline${TAG-}.txt" | cut -c1-120
+    python scripts/r04/timeline_steps.py $(ls -t gpurun_out/prof/tl*.db | head -1) ${LASTK-k_reduce2} 2 | tee "gpurun_out/timeline_steps${TAG-}.txt" ;;
   prof) do_prof ;;
   wtrace)
-    make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc EXTRA=-DPSMC_TRACE_SWEEP 2>&1 | grep -E "error" ; timeout 300 python scripts/sweep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/wave_trace.txt | cut -c1-230
+    make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc EXTRA=-DPSMC_TRACE_SWEEP 2>&1 | grep -E "error" ; TRACE_STEPS="${TRACE_STEPS-0}" timeout 300 python scripts/sweep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/wave_trace.txt | cut -c1-230
     make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc 2>&1 | grep -E "error" ;;
   probes) timeout 300 python scripts/r03/probes.py 2>&1 | grep -v amdgpu.ids ;;
   trace) timeout 600 python scripts/r03/estep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids ;;

@@ -43,6 +43,20 @@ def main():
     torch.cuda.synchronize()
     d = es.fast_diag()
     lib = hip.load_library()
+    # round 4: one line per step over a few more steps -- total, and how the walks were placed (two walks on one SIMD run at half speed)
+    for i in range(int(os.environ.get("TRACE_STEPS", "0"))):
+        es.estep_device(*traj[(10 + i) % len(traj)], sh.stats.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        buf = np.zeros(4 * 16384, dtype=np.uint64)
+        assert lib.psmc_hip_debug_trace(2, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), 16384) == 0
+        t = buf.reshape(16384, 4); t = t[t[:, 0] > 0]; t = t[t[:, 0] >= t[:, 0].max() - np.uint64(2_000_000)]
+        hw = t[:, 3]; h = hw.astype(np.int64) & 0xFFFFFFFF; xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
+        simd_id = ((((xcc * 8 + ((h >> 13) & 7)) * 2 + ((h >> 12) & 1)) * 16 + ((h >> 8) & 0xF)) * 4 + ((h >> 4) & 3))
+        dur = (t[:, 2].astype(np.int64) - t[:, 0].astype(np.int64)) / 100.0
+        cnt = np.bincount(np.unique(simd_id, return_counts=True)[1])
+        k = es.timing()
+        print("step %2d total %.3f ms | walks %d on %d SIMDs, SIMDs holding 1/2/3+ walks: %s | walk us p50 %.0f p90 %.0f max %.0f | start spread %.0f us" % (
+            i, k["total"], len(t), len(set(simd_id.tolist())), cnt[1:].tolist(), np.percentile(dur, 50), np.percentile(dur, 90), dur.max(), (t[:, 0].max() - t[:, 0].min()) / 100.0), flush=True)
     nw = (d["items_fwd"] + 3) // 4
     print("tiles %d x %d, fwd items %d, bwd items %d, kernels %s" % (d["n_chunks"], d["tile_len"], d["items_fwd"], d["items_bwd"], {k: round(v, 2) for k, v in es.timing().items()}))
     walk_simds, walk_cus = {}, set()

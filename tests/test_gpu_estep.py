@@ -772,12 +772,27 @@ def test_group_exact_is_bit_identical_to_one_context(hip, golden, devices):
     g.close(); one.close()
 
 
-@pytest.mark.parametrize("devices,rccl", [([0, 0], -1), ([0], 1), ([0, 0, 0, 0], 0)])
-def test_group_fast_reduction(hip, golden, oracle, devices, rccl):
+def stub_rccl(monkeypatch):
+    """Point group.hip at tests/stub_rccl (a single-process stand-in for librccl that accepts a repeated device and keeps the
+    stream-order guarantees of a grouped all-reduce): with the group option rccl=2 the multi-shard communicator branch of
+    reduce_vectors runs on this one-GPU box."""
+    d = os.path.join(ROOT, "tests", "stub_rccl")
+    so = os.path.join(d, "librccl_stub.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(d, "stub_rccl.hip")):
+        subprocess.run(["make", "-s", "-C", d], check=True)
+    monkeypatch.setenv("PSMC_HIP_RCCL_LIB", so)
+
+
+@pytest.mark.parametrize("devices,rccl", [([0, 0], -1), ([0], 1), ([0, 0, 0, 0], 0), ([0, 0], 2), ([0, 0, 0, 0], 2)])
+def test_group_fast_reduction(hip, golden, oracle, devices, rccl, monkeypatch):
     """Fast mode: every shard's reduction kernel leaves [A | E | LL] in HBM; shards on distinct devices are summed by
     ONE RCCL all-reduce (here: a one-device communicator, rccl=1, exercises that path -- library open, communicator,
     grouped call on the E-step's stream), shards sharing a GPU by the host in shard order.  Full counts and factored
-    statistics against the oracle."""
+    statistics against the oracle.  rccl=2: 2 and 4 shards on this one device through the grouped,
+    in-place, per-stream all-reduce branch, with tests/stub_rccl standing in for librccl -- the ordering of the exchange
+    against each shard's E-step stream is what can go wrong there."""
+    if rccl == 2:
+        stub_rccl(monkeypatch)
     p = golden.params("n64_curve")
     segs = golden.segs_mid
     o = oracle.estep(p["a"], p["e"], p["a0"], segs)
@@ -785,7 +800,7 @@ def test_group_fast_reduction(hip, golden, oracle, devices, rccl):
     g.load_segments(segs)
     for it in range(2):
         check_fast(g.estep(p["a"], p["e"], p["a0"]), o)
-    assert g.info()["last_reduce"] == (1 if rccl == 1 else (2 if len(devices) > 1 else 0))
+    assert g.info()["last_reduce"] == (1 if rccl >= 1 else (2 if len(devices) > 1 else 0))
     f = g.estep_factored(p["a"], p["e"], p["a0"])
     lo, up = np.tril(o["A"], -1), np.triu(o["A"], 1)
     assert relmax(f["sums"], np.stack([lo.sum(1), up.sum(1), np.diag(o["A"]).copy(), lo.sum(0), up.sum(0)])) < FAST_TOL_STATS
@@ -810,12 +825,15 @@ def test_group_with_more_shards_than_segments(hip, golden, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("devices,rccl,path", [([0], -1, "single"), ([0, 0], -1, "host_sum"), ([0], 1, "rccl"), ([0, 0, 0], 0, "host_sum")])
-def test_group_selfcheck(hip, devices, rccl, path):
+@pytest.mark.parametrize("devices,rccl,path", [([0], -1, "single"), ([0, 0], -1, "host_sum"), ([0], 1, "rccl"), ([0, 0, 0], 0, "host_sum"), ([0, 0, 0], 2, "rccl")])
+def test_group_selfcheck(hip, devices, rccl, path, monkeypatch):
     """First contact with a device list before any segment is loaded: shard s puts s + 1 into its vector with an
     asynchronous copy on its E-step stream, the exchange follows on the same stream and must return n(n+1)/2 -- through
     the RCCL communicator (rccl=1: a one-device communicator on this box) or the host sum.  What bench.py --engine
-    group calls before it times anything."""
+    group calls before it times anything.  rccl=2: three shards through the communicator branch (tests/stub_rccl): after the
+    all-reduce EVERY shard's device vector must hold the sum."""
+    if rccl == 2:
+        stub_rccl(monkeypatch)
     g = hip.HipGroup(64, devices, mode=hip.MODE_FAST, rccl=rccl)
     r = g.selfcheck()
     assert r["shards"] == len(devices) and r["path"] == path, r

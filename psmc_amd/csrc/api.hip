@@ -233,11 +233,18 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 			if (end == std::string::npos) end = all.size();
 			const std::string kv = all.substr(at, end - at);
 			const size_t eq = kv.find('=');
-			if (!kv.empty() && (eq == std::string::npos || psmc_hip_set_option(c, kv.substr(0, eq).c_str(), atof(kv.c_str() + eq + 1)) != PSMC_HIP_OK)) {
+			at = end + 1;
+			if (kv.empty()) continue;
+			// the value must be a whole number token ("chunk=abc" or "kc_min=" must not pass for 0), and the message names the pair
+			char *endp = nullptr;
+			const double val = eq == std::string::npos ? 0.0 : strtod(kv.c_str() + eq + 1, &endp);
+			const bool parsed = eq != std::string::npos && eq + 1 < kv.size() && endp && *endp == '\0';
+			if (parsed && kv.compare(0, eq, "rccl") == 0) continue; // a group-level key (psmc_hip_group_set_option): not this context's business
+			if (!parsed || psmc_hip_set_option(c, kv.substr(0, eq).c_str(), val) != PSMC_HIP_OK) {
+				fprintf(stderr, "[psmc_hip] PSMC_HIP_OPTIONS: bad entry \"%s\" (unknown key, value out of range, or not a number)\n", kv.c_str());
 				psmc_hip_destroy(c);
 				return PSMC_HIP_EINVAL;
 			}
-			at = end + 1;
 		}
 	}
 	*out = c;
@@ -754,7 +761,6 @@ static int plan_fast(psmc_hip_ctx *c)
 		int64_t want = st ? c->struct_tiles : c->target_waves;
 		if (st && !c->struct_tiles_set && bins < 2 * ROUND1 * (int64_t)std::max(c->warmup, 1)) {
 			want = std::max<int64_t>(ROUND1 - (int64_t)c->work.size(), ROUND1 / 2); // every segment ends in a ragged tile: stay inside the round
-			one_round = true;
 		}
 		T = (int)((bins + want - 1) / want);
 		T = std::max(256, (T + 63) & ~63);
@@ -775,7 +781,7 @@ static int plan_fast(psmc_hip_ctx *c)
 	const int nc = (int)c->chunks.size();
 	c->chunk_used = T;
 	c->planned_struct = st;
-	one_round = st && nc <= ROUND1; // also when the caller chose the tile length
+	one_round = st && nc <= ROUND1; // the criterion: the tiles fit one round of the fused back half (also when the caller chose the tile length)
 	c->two_phase_used = c->two_phase >= 0 ? c->two_phase : (one_round ? 0 : 2);
 	c->merge1_used = c->merge1 >= 0 ? c->merge1 : (one_round ? 1 : 0);
 	c->warm_shift_used = c->warm_shift_set ? c->warm_shift : (one_round ? 0 : 1);
@@ -1203,6 +1209,8 @@ extern "C" int psmc_hip_fast_info(psmc_hip_ctx *c, int out[8])
 extern "C" int psmc_hip_fast_plan(psmc_hip_ctx *c, double out[8])
 {
 	if (!c || !out) return PSMC_HIP_EINVAL;
+	// the plan is made by the first fast E-step after load / select / an option that changes it (it depends on the matrix's form)
+	if (c->plan_dirty || c->chunks.empty()) return fail(c, PSMC_HIP_ESTATE, "fast_plan: no current plan (run a fast E-step first)");
 	const int nc = (int)c->chunks.size();
 	double sf = 0, sb = 0, mf = 0, mb = 0; int nf = 0, nb = 0, gf = 0, gb = 0;
 	for (int b = 0; b < nc; ++b) {

@@ -760,7 +760,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	// unfused one takes its counts in a separate pass that has its own dependencies.)  The tail runs on the counts' stream
 	// of the unfused plan, which is idle here: on the main stream it would sit between the forward verify and a forward
 	// REPAIR round, and the repair would wait for the whole back half instead of running beside it.
-	const bool optimistic = p.fused != 0 && ov;
+	static const bool recheck = getenv("PSMC_HIP_DEBUG_RECHECK") != nullptr; // the diagnostic below runs after the E-step: keep the ordinary tail
+	const bool optimistic = p.fused != 0 && ov && !recheck;
 	if (optimistic) {
 		(void)hipStreamWaitEvent(sx, p.evx[4], 0); // forward verify (and compaction) done: the forward tables are final unless it flagged tiles
 		launch_ll(sx);
@@ -828,7 +829,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		launch_expect(p, sm, 0);
 		if (p.ev[9]) (void)hipEventRecord(p.ev[9], sm);
 	}
-	if (p.fused == 1 && getenv("PSMC_HIP_DEBUG_RECHECK")) {
+	if (p.fused == 1 && recheck) {
 		// diagnostic: recompute EVERY group from the final tables, every tile from its own start vector, and name the groups
 		// whose partial differs from what the protocol (first pass + redo of the touched groups) left
 		const int ga = (p.n_list_a + 3) / 4, gb = (p.n_list_b + 3) / 4, ng = ga + gb;

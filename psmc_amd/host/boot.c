@@ -39,6 +39,7 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		if (q[1] == 'd' && !pat_d) { pat_d = q; ++q; continue; }
 		pat_ok = 0; /* a second %d, or any other conversion */
 	}
+	if (pat_ok && strlen(out_pattern) + 16 >= 4096) pat_ok = 0; /* the expansion below writes into char fn[4096]: a longer pattern would be cut, and every replicate would open the same file */
 	if (n_rep < 1 || !pat_ok || !pat_d) { fprintf(stderr, "psmc_boot: need a replicate count and an output pattern with exactly one %%d (and no other conversion)\n"); return 1; }
 	if (o->decode || o->cnt_file || o->print_prob || o->simulate) { fprintf(stderr, "psmc_boot: decoding / simulation options make no sense on bootstrap replicates\n"); return 1; }
 	if (psmc_setup_begin(o, &su)) return 1;

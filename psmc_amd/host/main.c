@@ -98,6 +98,12 @@ int main(int argc, char *argv[])
 		if (fp) fclose(fp);
 	} else if (psmc_pattern_parse(o.pattern_text ? o.pattern_text : "4+5*3+4", &pat) == 0) { n_states = pat.n_states; psmc_pattern_free(&pat); }
 	if (n_states < 1) { fprintf(stderr, "psmc: malformed pattern\n"); return 1; }
+	if (n_states > 128) { /* the reference has no such limit (khmm.c:10-23 allocates for any n); this build's kernels keep one or two states per lane */
+		fprintf(stderr, "psmc: the pattern gives %d hidden states; this MI355X build supports at most 128 (e.g. -p \"64*2\"). "
+		        "Use a coarser pattern, or the reference binary for this run.\n", n_states);
+		psmc_options_free(&o);
+		return 2;
+	}
 	const char *mode_s = getenv("PSMC_HIP_MODE"), *dev_s = getenv("PSMC_HIP_DEVICE");
 	int mode = (mode_s && strcmp(mode_s, "fast") == 0) ? PSMC_HIP_MODE_FAST : PSMC_HIP_MODE_EXACT;
 	if ((o.decode || o.print_prob || o.cnt_file) && mode == PSMC_HIP_MODE_FAST) {

@@ -44,6 +44,20 @@ def oracle_psmc():
     return exe
 
 
+def test_psmc_binary_refuses_more_than_128_states():
+    """the reference takes any pattern (khmm.c:10-23, cli.c:66-99); this build's kernels stop at 128 hidden
+    states.  `psmc -p "100*2"` (200 states) must say so -- naming the limit -- and exit 2 before it touches a device (so this
+    runs on CPU), never crash or write a partial .psmc.  README.md and INTEGRATION.md section A state the same limit."""
+    subprocess.run(["make", "-s", "-C", HOST, "psmc"], check=True)
+    files = sorted(glob.glob(os.path.join(CLI, "*.psmcfa")))
+    assert files
+    r = subprocess.run([os.path.join(HOST, "psmc"), "-N1", "-p", "100*2", files[0]], capture_output=True, text=True)
+    assert r.returncode == 2 and r.stdout == "", (r.returncode, r.stdout[:200])
+    assert "200 hidden states" in r.stderr and "at most 128" in r.stderr, r.stderr
+    for txt in ("README.md", "INTEGRATION.md"):
+        assert "128 hidden states" in open(os.path.join(ROOT, txt)).read(), txt
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_host_logic_byte_identical(oracle_psmc, name):
     """with bit-identical sufficient statistics the whole .psmc file is

@@ -150,6 +150,12 @@ int psmc_hip_estep(psmc_hip_ctx *ctx, const double *a, const double *e, const do
  *   fast mode: one replicate fills the device, so they run back to back, each on its own learned tile plan (kept in
  *     a per-replicate child context that shares this context's observations and tables); sums = factored statistics.
  * Segment tables are in batch layout afterwards: decode / get_tables need a single E-step first. */
+/* Exact mode: allocate the batch's tables now -- min(max_bins, what "batch_bins" allows or 0.9 of the free device memory;
+ * max_bins <= 0: no upper bound), max_bins = the table bins all replicates together can need, e.g. n_rep x the padded
+ * length of the loaded segments -- instead of inside the first psmc_hip_estep_batch.  The driver clears what it hands out:
+ * ~250 GB take 4-6 s, which a caller can spend while it is still loading (psmc_boot does; the first EM iteration then costs
+ * what the others do).  Fast mode: no-op. */
+int psmc_hip_reserve_batch_tables(psmc_hip_ctx *ctx, int64_t max_bins);
 int psmc_hip_estep_batch(psmc_hip_ctx *ctx, int n_rep, const double *a, const double *e, const double *a0,
                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL);
 /* Diagnostic: out = {launch groups of the last exact batch (fast: replicates run), replicate contexts alive}. */

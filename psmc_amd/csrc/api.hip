@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "psmc_hip.h"
@@ -1281,6 +1282,34 @@ static int batch_selections(psmc_hip_ctx *c, int n_rep, const int32_t *sel_off, 
 	return 0;
 }
 
+// Table bins an exact batch may use: "batch_bins", or 0.9 of the device memory that is free or already in this context's tables.
+// (Round 3 took 0.9 of the free memory PLUS all of what the context held: the second call saw a larger capacity than the first,
+// re-planned its groups and re-allocated 250 GB of tables -- 8 s; profiles/r04_boot_breakdown.txt.)
+static int batch_capacity(psmc_hip_ctx *c, int64_t *cap)
+{
+	*cap = c->batch_bins;
+	if (*cap > 0) return 0;
+	size_t fr = 0, tot = 0;
+	HIPCHK(c, hipMemGetInfo(&fr, &tot));
+	const double S = (double)c->ns, per_bin = S * 8.0 * 2.0 + 8.0;
+	const double held = (double)c->tab_bins * (S * 8.0 * (c->have_b ? 2.0 : 1.0) + 8.0 + (c->d_sb ? 8.0 : 0.0));
+	*cap = (int64_t)(((double)fr + held) * 0.9 / per_bin) - 256;
+	if (*cap < 1) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: no device memory left for tables");
+	return 0;
+}
+
+extern "C" int psmc_hip_reserve_batch_tables(psmc_hip_ctx *c, int64_t max_bins)
+{
+	if (!c) return PSMC_HIP_EINVAL;
+	if (c->mode != PSMC_HIP_MODE_EXACT) return PSMC_HIP_OK; // fast mode keeps one replicate's tables: nothing to reserve
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "reserve_batch_tables: no segments loaded");
+	int64_t cap = 0;
+	int rc = batch_capacity(c, &cap);
+	if (rc) return rc;
+	return ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap);
+}
+
 // Exact mode: the sweeps of ALL replicates of a group in one launch each (forward, backward, expect), replicate-major;
 // every (replicate, unique segment) entry has its own table slot and reads its replicate's parameter block.  Groups =
 // as many consecutive replicates as fit the table memory.  Statistics are added per replicate in selection order on
@@ -1293,15 +1322,9 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	std::vector<RepSel> reps;
 	int rc;
 	if ((rc = batch_selections(c, n_rep, sel_off, sel_idx, reps))) return rc;
-	// how many table bins fit: what is free now plus what the context already holds
-	int64_t cap = c->batch_bins;
-	if (cap <= 0) {
-		size_t fr = 0, tot = 0;
-		HIPCHK(c, hipMemGetInfo(&fr, &tot));
-		const double per_bin = (double)S * 8.0 * 2.0 + 8.0;
-		const double held = (double)c->tab_bins * ((double)S * 8.0 * (c->have_b ? 2.0 : 1.0) + 8.0);
-		cap = (int64_t)(((double)fr * 0.9 + held) / per_bin) - 256;
-	}
+	// how many table bins fit (batch_capacity: the same answer in every call, whatever the context holds already)
+	int64_t cap = 0;
+	if ((rc = batch_capacity(c, &cap))) return rc;
 	size_t n_entries_all = 0;
 	for (const RepSel &R : reps) n_entries_all += R.work.size();
 	const int align = c->ns == 128 ? (n_entries_all <= 256 ? 1 : (n_entries_all <= 512 ? 2 : 4)) : 4; // sweeps per block sharing one parameter set in LDS
@@ -1317,7 +1340,12 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 			worst = std::max(worst, bins); worst_entries = std::max(worst_entries, ent); worst_reps = std::max(worst_reps, r1 - r0);
 			r0 = r1;
 		}
-		if ((rc = ensure_tables(c, true, worst))) return rc;
+		// tables: for the largest group when the caller fixed "batch_bins"; else for everything that fits (or all replicates at once), ONCE -- a hipMalloc of
+		// 250 GB takes 4-6 s on this driver (it clears the memory: scripts/r04/malloc_probe.py), so the size must not depend on
+		// this call's groups, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
+		int64_t all_bins = 0; // what ONE group of all replicates would need: never allocate beyond it
+		for (const RepSel &R : reps) all_bins += R.bins;
+		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins))))) return rc;
 		if ((rc = ensure_seg_outputs(c, (int)worst_entries))) return rc;
 		if (c->bw_cap < worst_entries) {
 			if ((rc = dev_alloc(c, &c->d_bw_seg, worst_entries))) return rc;
@@ -1327,7 +1355,10 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		}
 		if (c->bpar_cap < (size_t)worst_reps) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)worst_reps * PL))) return rc; c->bpar_cap = (size_t)worst_reps; }
 	}
+	static const bool dbg_t = getenv("PSMC_HIP_DEBUG_TIMES") != nullptr;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	for (int r0 = 0; r0 < n_rep;) {
+		const double t_a = now();
 		int r1 = r0; int64_t bins = 0;
 		while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ++r1; }
 		const int ng = r1 - r0;
@@ -1351,12 +1382,16 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		fill_common(c, p, c->stream, c->d_bpar);
 		p.d_work = c->d_bw_seg; p.n_work = nw; p.d_work_par = c->d_bw_par; p.d_work_tab = c->d_bw_tab; p.par_stride = (int64_t)PL; p.work_align = align;
 		p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
+		const double t_b = now();
 		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch)", hipGetLastError());
+		if (dbg_t) (void)hipStreamSynchronize(c->stream);
+		const double t_c = now();
 		c->h_segA.resize((size_t)nw * S * S); c->h_segE.resize((size_t)nw * 3 * S); c->h_s.resize((size_t)run);
 		HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(c->h_s.data(), c->d_s, sizeof(double) * (size_t)run, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
+		const double t_d = now();
 		collect_timing(c);
 		// hmm_add_expect in selection order per replicate (khmm.c:346-359), he_sum starting from zeros; LL += hmm_lk (em.c:48)
 		std::vector<double> sA((size_t)n * n), sE((size_t)2 * n);
@@ -1389,6 +1424,8 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 					}
 			}
 		}
+		if (dbg_t) fprintf(stderr, "[psmc_hip] batch group %d: %d replicates, %d entries, %.1f M table bins | prepare %.3f s, kernels %.3f (fwd %.0f bwd %.0f expect %.0f ms), read-back %.3f, host sums %.3f\n",
+		                   c->last_batch_groups, ng, nw, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3], t_d - t_c, now() - t_d);
 		++c->last_batch_groups;
 		r0 = r1;
 	}
@@ -1409,7 +1446,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles;
 		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
 		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
-		k->fuse128 = c->fuse128;
+		k->fuse128 = c->fuse128; k->coarse = c->coarse; k->gate = c->gate;
 		k->merge1 = c->merge1; k->merge_order = c->merge_order; k->runs_late = c->runs_late; k->warm_shift_set = c->warm_shift_set; k->kc_sub_set = c->kc_sub_set;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];

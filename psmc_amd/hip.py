@@ -26,7 +26,7 @@ EXPORTS = [
     "psmc_hip_device_count", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
-    "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
+    "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_reserve_batch_tables", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
     "psmc_hip_pipe_probe2", "psmc_hip_place_probe", "psmc_hip_group_selfcheck", "psmc_hip_fast_plan",
     "psmc_hip_group_create", "psmc_hip_group_destroy", "psmc_hip_group_last_error", "psmc_hip_group_set_option",

@@ -16,11 +16,21 @@
 #include "psmc_hip.h"
 
 #define MAX_DEV 64
-typedef struct { int n_dev, n_states; psmc_hip_ctx *ctx[MAX_DEV]; } hip_bb;
+typedef struct { int n_dev, n_states, n_rep; psmc_hip_ctx *ctx[MAX_DEV]; } hip_bb;
 
 static int bb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L)
 {
-	return psmc_hip_load_segments(((hip_bb *)self)->ctx[dev], n_seg, sym, L);
+	psmc_hip_ctx *c = ((hip_bb *)self)->ctx[dev];
+	int rc = psmc_hip_load_segments(c, n_seg, sym, L);
+	/* exact mode: take the batch's table memory now (the driver clears what it hands out: seconds for 250 GB) -- part of loading,
+	 * not of the first EM iteration */
+	if (rc == 0) {
+		const hip_bb *h = (const hip_bb *)self;
+		int64_t all = 0; /* this device's share of the replicates x every trunk (padded to 64 bins): an upper bound of what one group can hold */
+		for (int i = 0; i < n_seg; ++i) all += ((int64_t)L[i] + 63) & ~(int64_t)63;
+		rc = psmc_hip_reserve_batch_tables(c, all * ((h->n_rep + h->n_dev - 1) / h->n_dev));
+	}
+	return rc;
 }
 static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
                           const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
@@ -100,6 +110,7 @@ int main(int argc, char *argv[])
 		}
 		h.n_dev = d + 1;
 	}
+	h.n_rep = n_rep;
 	const char *fs = getenv("PSMC_FACTORED");
 	psmc_batch_backend bb = {&h, h.n_dev, bb_load, bb_estep_batch, bb_error, bb_destroy, mode == PSMC_HIP_MODE_FAST && !(fs && atoi(fs) == 0)};
 	const int status = psmc_boot_run(&o, n_rep, seed0, pattern, &bb);

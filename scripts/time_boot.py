@@ -55,6 +55,8 @@ def main():
         res["runs"]["psmc_boot_" + mode] = dict(rc=r.returncode, wall_s=round(wall, 2), per_iteration_ms=[dict(esteps=x, msteps=y) for x, y in its],
                                                stderr_tail=r.stderr[-400:] if r.returncode else "")
         sys.stderr.write("[time_boot] %s: %.1f s, iterations %s\n" % (mode, wall, its))
+        for ln in r.stderr.splitlines():   # PSMC_HIP_DEBUG_TIMES=1: the library's per-group breakdown of the exact batch
+            if "batch group" in ln: sys.stderr.write(ln[:260] + "\n")
         t0 = time.time()
         one = subprocess.run([os.path.join(HOST, "psmc"), "-b"] + args, capture_output=True, text=True, env=dict(env, PSMC_SEED="1000"))
         w1 = time.time() - t0

@@ -55,7 +55,9 @@ struct psmc_hip_ctx {
 	hipStream_t stream5 = nullptr;
 	int ckpt = 1;              // "ckpt": factored statistics recompute X from checkpoints every 8 positions instead of reading the table
 	int fuse = 1;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip): structured matrices, up to 64 states
-	int fuse128 = 1;           // "fuse128": the same with 65..128 states (k_bwd_count8_struct: four waves per group of four tiles)
+	int fuse128 = 2;           // "fuse128": the same with 65..128 states: 2 = k_bwd_count8x_struct (sixteen tiles per work-group, one sweep per tile, operands
+	                           // exchanged through LDS), 1 = k_bwd_count8_struct (four waves redo the sweep of four tiles), 0 = unfused
+	int count_group = 4;       // tiles per work-group of the fused back half, what the tile lists are padded to (build_items)
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
 	int warm_shift = 1;        // "warm_shift": before that, once, give such a tile a warm-up of warmup << warm_shift bins (0: glue at once)
 	bool chunks_dirty = false; // a tile's warm-up changed: d_chunks is stale
@@ -321,7 +323,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "kc_min") { if (v < -1) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
-	else if (k == "fuse128") { c->fuse128 = v != 0 ? 1 : 0; c->plan_dirty = true; }
+	else if (k == "fuse128") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->fuse128 = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
@@ -812,7 +814,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_items, (size_t)26 * nc + 64))) return rc;
-		if ((rc = dev_alloc(c, &c->d_ftiles, (size_t)2 * (nc + 4)))) return rc;
+		if ((rc = dev_alloc(c, &c->d_ftiles, (size_t)2 * (nc + 16)))) return rc;
 		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
 		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
 		    hipHostGetDevicePointer((void **)&c->m_ritems, c->h_ritems, 0) != hipSuccess)
@@ -943,8 +945,9 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 	for (int b = 0; b < nc; ++b) c->n_B_b += from_above[b];
 	{
 		c->n_list_a = (int)la.size(); c->n_list_b = (int)lb.size();
-		while (la.size() % 4) la.push_back(-1);
-		while (lb.size() % 4) lb.push_back(-1);
+		c->count_group = c->ns == 128 && c->fuse128 == 2 ? 16 : 4;
+		while (la.size() % c->count_group) la.push_back(-1);
+		while (lb.size() % c->count_group) lb.push_back(-1);
 		la.insert(la.end(), lb.begin(), lb.end());
 		if (!la.empty()) HIPCHK(c, hipMemcpy(c->d_ftiles, la.data(), sizeof(int) * la.size(), hipMemcpyHostToDevice));
 	}
@@ -1092,7 +1095,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0) || c->items_coarse != coarse) && (rc = build_items(c, two_phase_bwd, coarse))) return rc;
 	p.d_gate = (c->gate >= 0 ? c->gate != 0 : coarse > 1) ? c->d_gate : nullptr;
 	p.coarse = coarse; p.d_singles_b = c->d_items + 24 * (size_t)p.n_chunks; p.n_singles_b = c->n_singles_b;
-	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles;
+	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles; p.count_group = c->count_group;
 	c->timing_two_launches = p.fused == 1 && p.n_list_b > 0;
 	p.d_items_f = c->d_items; p.d_items_b = c->d_items + 2 * p.n_chunks;
 	p.d_ritems_f = c->d_items + 4 * p.n_chunks; p.d_ritems_b = c->d_items + 6 * p.n_chunks;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const doubl
 {
 	constexpr int SA = 16 * NPLA;
 	double ev[NPLA];
-	loadN<NPLA>(lds_e + sym * SA + k0, ev);
+	ev_load<NPLA>(lds_e + sym * SA, k0, ev);
 	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
 	double f = 1.0;
 	if (NORM) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 	__shared__ double lds_e[4 * SA], lds_m[8]; // e rows: hom, het, 1, 1;  emission-count masks per symbol
 	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLA * m;
 #pragma unroll
-	for (int i = lane; i < SA; i += 64) { lds_e[i] = e[i]; lds_e[SA + i] = e[SA + i]; lds_e[2 * SA + i] = 1.0; lds_e[3 * SA + i] = 1.0; }
+	for (int i = lane; i < SA; i += 64) { const int q = ev_slot<NPLA>(i); lds_e[q] = e[i]; lds_e[SA + q] = e[SA + i]; lds_e[2 * SA + q] = 1.0; lds_e[3 * SA + q] = 1.0; } // ev_load layout
 	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
 	__syncthreads();
 	const int slot = blockIdx.x * 4 + row;
@@ -266,7 +266,7 @@ template <bool NORM>
 __device__ __forceinline__ void fwd_recompute_step(const StructParN<NPLA> &sc, const double *lds_e, int k0, int sym, double inv, double (&x)[NPLA])
 {	// forward roles of the five vectors: mS = P (bwd wP), wS = qa (bwd mP), mP = R (bwd wS), wP = c (bwd mS)
 	double ev[NPLA], su[NPLA], pv[NPLA];
-	loadN<NPLA>(lds_e + sym * SA + k0, ev);
+	ev_load<NPLA>(lds_e + sym * SA, k0, ev);
 	if (NORM) {
 #pragma unroll
 		for (int i = 0; i < NPLA; ++i) ev[i] *= inv;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64, 2) void k_bwd_acc_ckpt(const double *__restrict
 	__shared__ double lds_e[4 * SA], lds_m[8];
 	__shared__ double lds_x[4 * 8 * SA]; // the block's X, private to the lane that wrote it: [row][j][half][2 m + i]
 	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLA * m;
-	lds_e[lane] = e[lane]; lds_e[SA + lane] = e[SA + lane]; lds_e[2 * SA + lane] = 1.0; lds_e[3 * SA + lane] = 1.0;
+	{ const int q = ev_slot<4>(lane); lds_e[q] = e[lane]; lds_e[SA + q] = e[SA + lane]; lds_e[2 * SA + q] = 1.0; lds_e[3 * SA + q] = 1.0; } // ev_load layout
 	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
 	__syncthreads();
 	double *xs = lds_x + row * (8 * SA) + 2 * m;

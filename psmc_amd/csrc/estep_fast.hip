@@ -735,7 +735,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		PSMC_DBG("k_ll", p.n_chunks, 0, 0);
 	};
 	auto launch_reduce = [&](hipStream_t sm) { // (the parameter shadows the main stream on purpose: the optimistic tail reduces on another one)
-		const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_list_a + 3) / 4 + (p.n_list_b + 3) / 4 : nS; // fused: one C partial per group of four tiles
+		const int nS = p.n_chunks * p.n_sub, nC = p.fused == 1 ? (p.n_list_a + p.count_group - 1) / p.count_group + (p.n_list_b + p.count_group - 1) / p.count_group : nS; // fused: one C partial per group of four tiles
 		if (p.fused == 2) {
 			launch_reduce_factored(p, sm);
 		} else if (p.ns == 128) {

@@ -68,7 +68,7 @@ __device__ __forceinline__ void count4f_step(const StructParN<NPLF> &sc, const d
                                              double (&FA)[NPLF], double (&FB)[NPLF], double (&S)[2][NPLF])
 {
 	double ev[NPLF], y[NPLF];
-	loadN<NPLF>(lds_e + sym * SF + k0, ev);
+	ev_load<NPLF>(lds_e + sym * SF, k0, ev);
 	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
 	double rho_next = rho;
 	if (NORM) { // bt keeps its OWN scaling (sb_p = 1/sum(bt_{p+1})): the vectors handed from tile to tile must not depend on a forward table
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 {
 	__shared__ double lds_e[4 * SF], lds_m[8]; // e rows: hom, het, 1, 1;  count masks per symbol
 	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLF * m;
-	lds_e[lane] = e[lane]; lds_e[SF + lane] = e[SF + lane]; lds_e[2 * SF + lane] = 1.0; lds_e[3 * SF + lane] = 1.0;
+	{ const int q = ev_slot<NPLF>(lane); lds_e[q] = e[lane]; lds_e[SF + q] = e[SF + lane]; lds_e[2 * SF + q] = 1.0; lds_e[3 * SF + q] = 1.0; } // ev_load layout
 	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
 	__syncthreads();
 	const int group = group0 + blockIdx.x;
@@ -259,7 +259,7 @@ __device__ __forceinline__ void count8_step(const StructParN<NPL8> &sc, const do
                                             d4f_t (&acc)[2][NPL8], double (&S)[2][2])
 {
 	double ev[NPL8], y[NPL8], FA[2], FB[NPL8];
-	loadN<NPL8>(lds_e + sym * S8 + k0, ev);
+	ev_load<NPL8>(lds_e + sym * S8, k0, ev);
 	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
 	double rho_next = rho;
 	if (NORM) { // bt keeps its own scaling, the weight follows both scale factors (see count4f_step)
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_count8_struct(const double *__re
 	__shared__ double lds_e[4 * S8], lds_m[8];
 	const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, row = lane >> 4, m = lane & 15, k0 = NPL8 * m;
 	const bool wave0 = q == 0;
-	if (tid < S8) { lds_e[tid] = e[tid]; lds_e[S8 + tid] = e[S8 + tid]; lds_e[2 * S8 + tid] = 1.0; lds_e[3 * S8 + tid] = 1.0; }
+	if (tid < S8) { const int q8 = ev_slot<NPL8>(tid); lds_e[q8] = e[tid]; lds_e[S8 + q8] = e[S8 + tid]; lds_e[2 * S8 + q8] = 1.0; lds_e[3 * S8 + q8] = 1.0; } // ev_load layout
 	if (tid < 8) lds_m[tid] = (tid == 0 || tid == 3) ? 1.0 : 0.0;
 	__syncthreads();
 	const int group = group0 + blockIdx.x;
@@ -418,17 +418,260 @@ __global__ __launch_bounds__(256, 1) void k_bwd_count8_struct(const double *__re
 	}
 }
 
+// ---- 128 states, ONE sweep per tile (round 4): k_bwd_count8x_struct, "fuse128" = 2.
+// k_bwd_count8_struct above lets each of a group's four waves redo the whole eight-states-per-lane sweep of the SAME four tiles to
+// own a quarter of C: three of the four sweeps are redundant (9.4 vector instructions per matrix instruction, 0.45 of the FP64 peak
+// on the algorithmic flops).  Here a work-group holds SIXTEEN tiles, four per wave.  Every wave sweeps only its own four tiles and
+// publishes, per position, both operands of the matrix instructions -- rho.X (8 per lane) and bt (8 per lane) -- to LDS; after one
+// barrier every wave runs the K dimension over all sixteen tiles for ITS quarter of C (rows j = 2w, 2w+1 of every block):
+// 4 producer waves x 16 matrix instructions = 64 per step and wave instead of 16, on one sweep instead of four.  The waves sit on
+// four different SIMDs, so the pipe rule of DESIGN.md section 3 (nothing overlaps a matrix instruction on the SAME SIMD) does not
+// stand in the way.  LDS: [parity][producer wave][pair p][lane] as 16-byte cells -- a lane writes its 8 + 8 values with eight
+// conflict-free ds_write_b128 and reads a producer's operands with five ds_read_b128 (its A pair, all four B pairs); two parities,
+// one barrier per position.  X is read from HBM once, by the tile's owner (whole rows, one position ahead).
+constexpr int G8X = 16; // tiles per work-group
+// the structured step with its five constant vectors (mS | wS | mP | wP | dd, S8 each) read from LDS just in time: 80 registers the
+// kernel cannot spare next to 128 accumulators, two X rows, sixteen emission sums and the operands in flight
+// LDS layout of a 128-vector for the eight-states-per-lane kernels: [pair p = 0..3][lane m = 0..15] cells of 16 bytes holding states
+// 8m + 2p, 8m + 2p + 1 -- the sixteen lanes of a row read consecutive cells (a ds_read_b128 of the natural layout, 64 bytes apart per
+// lane, is a four-way bank conflict); the four rows read the same cells (a broadcast)
+__device__ __forceinline__ void load8p(const d2v_t *v, int m, double (&out)[NPL8]) {
+#pragma unroll
+	for (int p = 0; p < 4; ++p) { const d2v_t t = v[16 * p + m]; out[2 * p] = t.x; out[2 * p + 1] = t.y; }
+}
+__device__ __forceinline__ void fill8p(d2v_t *v, int k, double val) { reinterpret_cast<double *>(v + 16 * ((k & 7) >> 1) + (k >> 3))[k & 1] = val; } // state k = 8m + 2p + h
+__device__ __forceinline__ void struct_step8_lds(const d2v_t *lds_sc, int m, double (&x)[NPL8])
+{
+	double cS[NPL8], cP[NPL8], su[NPL8], pv[NPL8];
+	load8p(lds_sc, m, cS); load8p(lds_sc + 2 * 64, m, cP);
+	su[NPL8 - 1] = x[NPL8 - 1] * cS[NPL8 - 1];
+#pragma unroll
+	for (int i = NPL8 - 2; i >= 0; --i) su[i] = __builtin_fma(x[i], cS[i], su[i + 1]);
+	pv[0] = x[0] * cP[0];
+#pragma unroll
+	for (int i = 1; i < NPL8; ++i) pv[i] = __builtin_fma(x[i], cP[i], pv[i - 1]);
+	const double ES = row_excl_suffix(su[0]), EP = row_excl_prefix(pv[NPL8 - 1]);
+	double wS[NPL8], wP[NPL8], dd[NPL8];
+	load8p(lds_sc + 64, m, wS); load8p(lds_sc + 3 * 64, m, wP); load8p(lds_sc + 4 * 64, m, dd);
+#pragma unroll
+	for (int i = 0; i < NPL8; ++i) { // the same expression tree as struct_step (struct_prims.h): the two kernels round alike
+		const double t = __builtin_fma(wS[i], su[i], __builtin_fma(wP[i], pv[i], dd[i] * x[i]));
+		x[i] = __builtin_fma(wS[i], ES, __builtin_fma(wP[i], EP, t));
+	}
+}
+template <bool NORM, bool MASKED>
+__device__ __forceinline__ void count8x_step(const d2v_t *lds_sc, const d2v_t *lds_e, const double *lds_m, int m, int sym,
+                                             const double (&X)[NPL8], double (&x)[NPL8], bool active, double inv, double &rho,
+                                             double (&FA)[NPL8], double (&FB)[NPL8], double (&S)[2][NPL8])
+{
+	double ev[NPL8], y[NPL8];
+	load8p(lds_e + sym * 64, m, ev);
+	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
+	double rho_next = rho;
+	if (NORM) { // bt keeps its own scaling, the weight follows both scale factors (see count4f_step)
+		double t = 0.0;
+#pragma unroll
+		for (int i = 0; i < NPL8; ++i) t += x[i];
+		const double tot = row_sum16(t);
+		const double sb = rcp_newton(tot);
+#pragma unroll
+		for (int i = 0; i < NPL8; ++i) ev[i] *= sb;
+		rho_next = rho * (inv * tot);
+		if (MASKED) rho_next = active ? rho_next : rho;
+	}
+#pragma unroll
+	for (int i = 0; i < NPL8; ++i) y[i] = x[i];
+	struct_step8_lds(lds_sc, m, y);
+#pragma unroll
+	for (int i = 0; i < NPL8; ++i) {
+		FA[i] = rho * X[i];
+		if (MASKED) FA[i] = active ? FA[i] : 0.0; // an idle row may hold anything
+		const double gk = FA[i] * y[i];           // E[o_p][k] += rho X_p[k] y_p[k]
+		S[0][i] = __builtin_fma(gk, mk.x, S[0][i]);
+		S[1][i] = __builtin_fma(gk, mk.y, S[1][i]);
+		FB[i] = MASKED ? (active ? x[i] : 0.0) : x[i];
+		const double nb = y[i] * ev[i];
+		x[i] = MASKED ? (active ? nb : x[i]) : nb;
+	}
+	rho = rho_next;
+}
+
+__global__ __launch_bounds__(256, 1) void k_bwd_count8x_struct(const double *__restrict__ sp, const double *__restrict__ e,
+                                                                 const double *__restrict__ invd, const uint8_t *__restrict__ obs,
+                                                                 const Chunk *__restrict__ chunks, const int *__restrict__ tiles,
+                                                                 int group0, int mode, const double *__restrict__ f,
+                                                                 double *__restrict__ bentry, double *__restrict__ bexit,
+                                                                 double *__restrict__ Cpart,
+                                                                 double *__restrict__ Epart, const int *__restrict__ touch_f,
+                                                                 const int *__restrict__ touch_b)
+{
+	__shared__ d2v_t lds_e[4 * 64];   // emission rows hom | het | 1 | 1 in the load8p layout
+	__shared__ double lds_m[8];
+	__shared__ d2v_t xa[2][4][4][64], xb[2][4][4][64]; // operands A = rho.X, B = bt: [parity][producer wave][state pair][lane], 32 KB each
+	__shared__ int lds_ng[4];
+	__shared__ d2v_t lds_sc[5 * 64]; // backward roles: mS = c | wS = R | mP = qa | wP = P | dd (sp = P | R | qa | c | dd), load8p layout
+	const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4, m = lane & 15, k0 = NPL8 * m;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	if (tid < S8) {
+		fill8p(lds_e, tid, e[tid]); fill8p(lds_e + 64, tid, e[S8 + tid]); fill8p(lds_e + 2 * 64, tid, 1.0); fill8p(lds_e + 3 * 64, tid, 1.0);
+		fill8p(lds_sc, tid, sp[3 * S8 + tid]); fill8p(lds_sc + 64, tid, sp[S8 + tid]); fill8p(lds_sc + 2 * 64, tid, sp[2 * S8 + tid]);
+		fill8p(lds_sc + 3 * 64, tid, sp[tid]); fill8p(lds_sc + 4 * 64, tid, sp[4 * S8 + tid]);
+	}
+	if (tid < 8) lds_m[tid] = (tid == 0 || tid == 3) ? 1.0 : 0.0;
+	__syncthreads();
+	const int group = group0 + blockIdx.x;
+	const int entry = tiles[G8X * blockIdx.x + 4 * w + row];
+	const bool valid = entry >= 0, from_above = valid && mode == 0 && (entry & (1 << 30)) != 0;
+	const int tile = valid ? (entry & ~(1 << 30)) : 0;
+	// redo pass: the whole group is recomputed when a repair touched any of its sixteen tiles (block-uniform)
+	if (mode == 2 && !__syncthreads_or(valid && (touch_f[tile] | touch_b[tile]) != 0)) return;
+	const Chunk c = chunks[tile];
+	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
+	const bool work = valid && top >= lo;
+	const double *fo = f + c.off * S8 + k0;
+	const double *io = invd + c.off;
+	double x[NPL8];
+	loadN<NPL8>((from_above ? bexit + (int64_t)(tile + 1) * S8 : bentry + (int64_t)tile * S8) + k0, x);
+	if (from_above) storeN<NPL8>(bentry + (int64_t)tile * S8 + k0, x); // what verify compares and a redo starts from (this wave owns the tile)
+	const int p_min = lo, p_max = max(top, lo);
+	double rho;
+	{
+		double y[NPL8], Xt[NPL8];
+		loadN<NPL8>(fo + (int64_t)(p_max - 1) * S8, Xt);
+#pragma unroll
+		for (int i = 0; i < NPL8; ++i) y[i] = x[i];
+		struct_step8_lds(lds_sc, m, y);
+		double t = 0.0;
+#pragma unroll
+		for (int i = 0; i < NPL8; ++i) t = __builtin_fma(Xt[i], y[i], t);
+		rho = work ? (double)c.mult * rcp_newton(row_sum16(t)) : 0.0;
+	}
+	d4f_t acc[2][NPL8];
+	double S[2][NPL8];
+#pragma unroll
+	for (int j2 = 0; j2 < NPL8; ++j2) {
+		acc[0][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0}; acc[1][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0};
+		S[0][j2] = S[1][j2] = 0.0;
+	}
+	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
+	const int ng = g_hi - g_lo + 1;
+	const int64_t off0 = readlane_i64f(c.off, 0), off1 = readlane_i64f(c.off, 16), off2 = readlane_i64f(c.off, 32), off3 = readlane_i64f(c.off, 48);
+	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
+	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
+	if (lane == 0) lds_ng[w] = max(max(n0, n1), max(n2, n3));
+	__syncthreads();
+	const int ng_max = max(max(lds_ng[0], lds_ng[1]), max(lds_ng[2], lds_ng[3])); // every wave takes the same number of steps: one barrier each
+	auto row_pos = [&](int g, int j) { return min(max(4 * g + j + 1, p_min), p_max); };
+	auto load_inv = [&](int g) { return io[min(max(4 * g + 4, p_min), p_max) - 1]; };
+	double Xa[NPL8], Xb[NPL8]; // X rows, one position ahead, in two alternating buffers
+	loadN<NPL8>(fo + (int64_t)(row_pos(max(g_hi, 0), 3) - 1) * S8, Xa);
+	double inv_cur = load_inv(max(g_hi, 0));
+	auto all_full = [&](int gi_) {
+		const int g = max(g_hi - gi_, g_lo);
+		return __all(gi_ < ng && 4 * g + 1 >= lo && 4 * g + 4 <= top) != 0;
+	};
+	int gi = 0, par = 0;
+	auto exchange = [&](const double (&FA)[NPL8], const double (&FB)[NPL8]) {
+#pragma unroll
+		for (int p = 0; p < 4; ++p) {
+			d2v_t u, v; u.x = FA[2 * p]; u.y = FA[2 * p + 1]; v.x = FB[2 * p]; v.y = FB[2 * p + 1];
+			xa[par][w][p][lane] = u; xb[par][w][p][lane] = v;
+		}
+		__syncthreads();
+		// K over the four tiles of producer wave g, the next producer's operands in flight while this one's sixteen matrix
+		// instructions issue (1024 cycles: the LDS latency disappears behind them; left to itself hipcc fetched each operand right
+		// before its use, 26 s_waitcnt per step).  The sched_barriers keep that order.
+		d2v_t oa[2], ob[2][4];
+		oa[0] = xa[par][0][w][lane];
+#pragma unroll
+		for (int p = 0; p < 4; ++p) ob[0][p] = xb[par][0][p][lane];
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			if (g < 3) {
+				oa[(g + 1) & 1] = xa[par][g + 1][w][lane];
+#pragma unroll
+				for (int p = 0; p < 4; ++p) ob[(g + 1) & 1][p] = xb[par][g + 1][p][lane];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			const d2v_t a = oa[g & 1];
+			const double B[NPL8] = {ob[g & 1][0].x, ob[g & 1][0].y, ob[g & 1][1].x, ob[g & 1][1].y, ob[g & 1][2].x, ob[g & 1][2].y, ob[g & 1][3].x, ob[g & 1][3].y};
+#pragma unroll
+			for (int j2 = 0; j2 < NPL8; ++j2) {
+				acc[0][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, B[j2], acc[0][j2], 0, 0, 0);
+				acc[1][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, B[j2], acc[1][j2], 0, 0, 0);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		par ^= 1;
+	};
+	auto do_group = [&](auto masked_tag) {
+		constexpr bool MASKED = decltype(masked_tag)::value;
+		const unsigned w0 = *reinterpret_cast<const unsigned *>(obs + off0 + 4 * (int64_t)max(gh0 - min(gi, max(n0 - 1, 0)), 0));
+		const unsigned w1 = *reinterpret_cast<const unsigned *>(obs + off1 + 4 * (int64_t)max(gh1 - min(gi, max(n1 - 1, 0)), 0));
+		const unsigned w2 = *reinterpret_cast<const unsigned *>(obs + off2 + 4 * (int64_t)max(gh2 - min(gi, max(n2 - 1, 0)), 0));
+		const unsigned w3 = *reinterpret_cast<const unsigned *>(obs + off3 + 4 * (int64_t)max(gh3 - min(gi, max(n3 - 1, 0)), 0));
+		const unsigned ww = row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
+		const int g = max(g_hi - gi, g_lo);
+		const bool in_tile = gi < ng;
+		const int s3 = (int)((ww >> 24) & 3u), s2 = (int)((ww >> 16) & 3u), s1 = (int)((ww >> 8) & 3u), s0 = (int)(ww & 3u);
+		const int pb = 4 * g + 1;
+		const double inv = inv_cur;
+		double FA[NPL8], FB[NPL8];
+		// position J of the group: its X row is in XC; the next position's row (J - 1, or J = 3 of the group below) is fetched into XN
+#define PSMC_C8X(NORM, J, SYM, XC, XN, GN, JN)                                                                                   \
+		loadN<NPL8>(fo + (int64_t)(row_pos(GN, JN) - 1) * S8, XN);                                                          \
+		count8x_step<NORM, MASKED>(lds_sc, lds_e, lds_m, m, SYM, XC, x, in_tile && pb + J <= top && pb + J >= lo, inv, rho, FA, FB, S); \
+		if (J == 3) inv_cur = load_inv(g - 1);                                                                               \
+		exchange(FA, FB);
+		PSMC_C8X(true, 3, s3, Xa, Xb, g, 2) PSMC_C8X(false, 2, s2, Xb, Xa, g, 1) PSMC_C8X(false, 1, s1, Xa, Xb, g, 0) PSMC_C8X(false, 0, s0, Xb, Xa, g - 1, 3)
+#undef PSMC_C8X
+		if (in_tile && g == g_lo) storeN<NPL8>(bexit + (int64_t)tile * S8 + k0, x);
+	};
+	// three single-path loops, as in the kernels above (with both paths in one body hipcc shuffles the accumulators between VGPRs and
+	// AGPRs every iteration).  The choice is per wave; a wave passes four barriers per group whichever loop it is in, and ng_max
+	// groups in all
+	for (; gi < ng_max && !all_full(gi); ++gi) do_group(std::true_type{});
+	for (; gi < ng_max && all_full(gi); ++gi) do_group(std::false_type{});
+	for (; gi < ng_max; ++gi) do_group(std::true_type{});
+	// the matrix-core results are not interlocked against plain reads: let the last instructions drain
+	asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
+	             : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]),
+	               "+a"(acc[0][7]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[1][4]), "+a"(acc[1][5]),
+	               "+a"(acc[1][6]), "+a"(acc[1][7]));
+	// C[8 M + j][8 N + j2], j = 2 w + jj, M = row + 4 r, N = m: eight adjacent columns per lane
+	double *out = Cpart + (int64_t)group * (S8 * S8);
+#pragma unroll
+	for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			double v[NPL8];
+#pragma unroll
+			for (int j2 = 0; j2 < NPL8; ++j2) v[j2] = acc[jj][j2][r];
+			storeN<NPL8>(out + (int64_t)(8 * (row + 4 * r) + 2 * w + jj) * S8 + k0, v);
+		}
+	if (valid) {
+		double *os = Epart + (int64_t)tile * (3 * S8) + k0;
+		const double zero[NPL8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+		storeN<NPL8>(os, S[0]); storeN<NPL8>(os + S8, S[1]); storeN<NPL8>(os + 2 * S8, zero); // missing symbols are not counted (khmm.c:355)
+	}
+}
+
 // list 0 / 1: tile list A / B of the plan (api.hip build_items);  redo: only the groups a repair touched
 void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo, bool all_from_bentry)
 {
-	const int ga = (p.n_list_a + 3) / 4, gb = (p.n_list_b + 3) / 4;
+	const int G = p.count_group; // tiles per work-group / per C partial: 4, or 16 (k_bwd_count8x_struct)
+	const int ga = (p.n_list_a + G - 1) / G, gb = (p.n_list_b + G - 1) / G;
 	const int n_groups = list == 0 ? ga : gb;
 	if (n_groups <= 0) return;
-	const int *tl = p.d_ftiles + (list == 0 ? 0 : 4 * ga);
+	const int *tl = p.d_ftiles + (list == 0 ? 0 : G * ga);
 	const int g0 = list == 0 ? 0 : ga, md = all_from_bentry ? 3 : (redo ? 2 : 0); // 3 (diagnostic): every group, every tile from its bentry
 	if (p.ns == 128) {
-		hipLaunchKernelGGL(k_bwd_count8_struct, dim3(n_groups), dim3(256), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
-		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+		if (G == G8X)
+			hipLaunchKernelGGL(k_bwd_count8x_struct, dim3(n_groups), dim3(256), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
+			                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+		else
+			hipLaunchKernelGGL(k_bwd_count8_struct, dim3(n_groups), dim3(256), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
+			                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
 		PSMC_DBG("launch_bwd_count (128 states)", list, redo, n_groups);
 		return;
 	}

@@ -89,7 +89,7 @@ template <int NPL> __device__ __forceinline__ double tile_sum(const double (&x)[
 // e[0] | e[1] | 1 | 1 (rows of S) for the per-symbol emission fetch
 template <int S> __device__ __forceinline__ void fill_lds_e(double *lds_e, const double *__restrict__ e, int lane) {
 #pragma unroll
-	for (int i = lane; i < S; i += 64) { lds_e[i] = e[i]; lds_e[S + i] = e[S + i]; lds_e[2 * S + i] = 1.0; lds_e[3 * S + i] = 1.0; }
+	for (int i = lane; i < S; i += 64) { const int q = ev_slot<S / 16>(i); lds_e[q] = e[i]; lds_e[S + q] = e[S + i]; lds_e[2 * S + q] = 1.0; lds_e[3 * S + q] = 1.0; } // ev_load layout (struct_prims.h)
 }
 
 // ---- Dispatch order across streams (round 4).
@@ -152,7 +152,7 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double 
 		cur.tile += 1; cur.next_lo += T;
 	}
 	double ev[NPL];
-	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
+	ev_load<NPL>(lds_e + sym_of<J>(w) * S, k0, ev);
 	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}) rounded down to a power of two, off the critical path
 		const double inv = pow2_rcp(tile_sum<NPL>(x));
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 		loadN<NPL>(a0 + k0, x);
 		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
 			double ev[NPL];
-			loadN<NPL>(lds_e + ((int)o[0] & 3) * S + k0, ev);
+			ev_load<NPL>(lds_e + ((int)o[0] & 3) * S, k0, ev);
 #pragma unroll
 			for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 			if (valid && c.lo == 1 && !walk) storeN<NPL>(fo, x);
@@ -318,7 +318,7 @@ __device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double 
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p <= p_first && p >= p_low)) return;
 	double ev[NPL];
-	loadN<NPL>(lds_e + sym_of<J>(w) * S + k0, ev);
+	ev_load<NPL>(lds_e + sym_of<J>(w) * S, k0, ev);
 	if (J == 3) { // sb_p = 1/sum(bt_{p+1}), off the critical path
 		const double s = rcp_newton(tile_sum<NPL>(x));
 #pragma unroll
@@ -405,7 +405,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 		p_first = cur.top;
 	} else {
 		const int q = min(c.hi + chunk_warm_b(c, W) + 1, L); // B_q := 1
-		loadN<NPL>(lds_e + ((int)o[q - 1] & 3) * S + k0, x);
+		ev_load<NPL>(lds_e + ((int)o[q - 1] & 3) * S, k0, x);
 		p_first = q - 1;
 	}
 	// highest block.  A tile that holds only position L (not valid: it owns no transition) has p_first = L - 1, which is 0 for a
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 		const int p = fwd ? lo + q : top - q;
 		const int sym = (int)o[p - 1] & 3; // wave-uniform: a scalar byte load
 		double ev[NPL];
-		loadN<NPL>(lds_e + sym * S + k0, ev);
+		ev_load<NPL>(lds_e + sym * S, k0, ev);
 		if ((p & 3) == 0) { // rescale the column by a power of two and remember the exponent
 			const double s = row_sum16(lane_sum<NPL>(x));
 			const int ex = s > 0.0 ? __builtin_amdgcn_frexp_exp(s) : 0;

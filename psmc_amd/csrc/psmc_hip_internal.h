@@ -78,6 +78,7 @@ struct EstepLaunch {
 	const int *d_singles_b; int n_singles_b; // coarse > 1, factored back half: every tile outside the backward runs as a one-tile item
 	int n_B_b;                        // trailing backward items of the two-phase plan: they start from the exit vector of the tile above (second list of the fused back half)
 	const int *d_ftiles; int n_list_a, n_list_b; // fused back half: tile lists A | B (each padded to a multiple of 4 with -1)
+	int count_group;                  // ... tiles per work-group of the fused back half (one C partial each): 4; 16 = k_bwd_count8x_struct (128 states, "fuse128" = 2)
 	int runs_in_b;                    // ... and every tile of a glued run is in list B: only the second launch waits for the runs' path
 	hipStream_t stream4, stream5;
 	// walks: heads of the chain runs (count 1) followed by the short runs; transfer-matrix chains of the long runs

@@ -141,6 +141,24 @@ template <int NPL> __device__ __forceinline__ void storeN(double *p, const doubl
 #pragma unroll
 	for (int i = 0; i < NPL / 2; ++i) { d2v_t a; a.x = v[2 * i]; a.y = v[2 * i + 1]; reinterpret_cast<d2v_t *>(p)[i] = a; }
 }
+// Per-lane vectors in LDS (emission rows, constants): lane m of a 16-lane row wants its NPL adjacent states k = NPL m + i.  Stored in
+// the natural order that is a ds_read_b128 with 8 NPL bytes between lanes -- a two-way (NPL = 4) or four-way (NPL = 8) bank conflict
+// on every read (round 4: the 128-state counts kernel lost 15 % to it).  So a row of 16 NPL doubles is kept as cells of 16 bytes,
+// cell 16 p + m = states NPL m + 2p, NPL m + 2p + 1: the sixteen lanes of a row read consecutive cells, the four rows the same ones.
+#ifdef PSMC_EV_NATURAL // A/B build: the natural order of rounds 1-3
+template <int NPL> __device__ __forceinline__ int ev_slot(int k) { return k; }
+template <int NPL> __device__ __forceinline__ void ev_load(const double *row, int k0, double (&v)[NPL]) {
+#pragma unroll
+	for (int i = 0; i < NPL / 2; ++i) { const d2v_t a = reinterpret_cast<const d2v_t *>(row + k0)[i]; v[2 * i] = a.x; v[2 * i + 1] = a.y; }
+}
+#else
+template <int NPL> __device__ __forceinline__ int ev_slot(int k) { return 2 * (16 * ((k % NPL) >> 1) + k / NPL) + (k & 1); } // index of state k in its row
+template <int NPL> __device__ __forceinline__ void ev_load(const double *row, int k0, double (&v)[NPL]) {
+	const d2v_t *c = reinterpret_cast<const d2v_t *>(row) + k0 / NPL;
+#pragma unroll
+	for (int p = 0; p < NPL / 2; ++p) { const d2v_t t = c[16 * p]; v[2 * p] = t.x; v[2 * p + 1] = t.y; }
+}
+#endif
 __device__ __forceinline__ void load4(const double *p, double (&v)[4]) { loadN<4>(p, v); }
 __device__ __forceinline__ void store4(double *p, const double (&v)[4]) { storeN<4>(p, v); }
 

@@ -107,6 +107,33 @@ def cpu_baseline(a, e, a0, segs, sample_bins):
             "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
 
 
+def factored_roofline(bins, kern, dt_step):
+    """the path `psmc` runs in fast mode has no matrix instruction and little memory traffic (130 B per bin with
+    checkpoints); its kernels are bound by vector-instruction ISSUE.  One SIMD issues at most one f64 vector instruction per 4
+    cycles, so the roof is SIMDs x sustained clock / 4 wave-instructions per second; `achieved` = the vector instructions the back
+    half's kernel issues per launch (SQ_INSTS_VALU of a separate rocprofv3 --pmc pass, scaled by the counters' coverage of the
+    device: profiles/sq_factored.json) over its launch duration measured live.  HBM beside it."""
+    simds, clock = 1024, 2.1e9    # 256 CUs x 4; the shader clock these kernels sustain (scripts/sweep_trace.py: 1.8-2.2 GHz under load)
+    peak = simds * clock / 4.0
+    r = {"bound": "valu_issue", "kernel": "k_bwd_acc_ckpt", "kernel_ms": kern.get("expect"), "peak": peak, "unit": "wave-instructions/s",
+         "hbm": {"alg_bytes_per_bin": 2 * (8 * N_STATES + 9) / 8.0, "achieved_GBs": bins * 2 * (8 * N_STATES + 9) / 8.0 / dt_step / 1e9,
+                 "frac": bins * 2 * (8 * N_STATES + 9) / 8.0 / dt_step / 1e9 / HBM_PEAK_GBS},
+         "achieved": None, "frac": None, "valu_per_bin": None}
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "sq_factored.json")))
+        k = pj["kernels"]["k_bwd_acc_ckpt"]
+        if abs(pj["bins"] - bins) <= 64 and kern.get("expect", 0) > 0:
+            r["valu_per_bin"] = k["valu_per_launch"] / pj["bins"]
+            r["achieved"] = k["valu_per_launch"] / (kern["expect"] * 1e-3)
+            r["frac"] = r["achieved"] / peak
+            r["forward_sweep"] = {"kernel": "k_fwd_struct<ckpt>", "kernel_ms": kern.get("fwd_sweep"),
+                                  "valu_per_bin": pj["kernels"]["k_fwd_struct<false,4,true>"]["valu_per_launch"] / pj["bins"]}
+            r["note"] = pj.get("note", "")
+    except Exception:
+        pass
+    return r
+
+
 def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, diag, value, ms_per_step, traj_src, n_moving, stats_numel):
     """The JSON line of the contract from what was measured (pure function: tests/test_bench_line.py feeds it fake
     measurements for every plan the library can report)."""
@@ -530,7 +557,9 @@ def main():
                 for i in range(nf):
                     es.estep_factored(*moving[i % len(moving)])
                 dtf = (time.perf_counter() - t1) / nf
-                out["factored_stats"] = {"value": bins / dtf, "unit": "bins/s", "ms_per_step": dtf * 1e3, "kernels_ms": es.timing(),
+                kf = es.timing()
+                out["factored_stats"] = {"value": bins / dtf, "unit": "bins/s", "ms_per_step": dtf * 1e3, "kernels_ms": kf,
+                                         "roofline": factored_roofline(bins, kf, dtf),
                                          "note": "psmc_hip_estep_factored: triangular sums of A, E, LL from the backward sweep in O(N) "
                                                  "per bin (no counts GEMM, no bt table); blocking call incl. read-back; moving parameters"}
             except Exception as ex_:
@@ -636,15 +665,17 @@ def main():
                         "note": "blocking call incl. read-back; median of %d after %d warm-up calls" % (NT8, NW8)}
             except Exception as ex_:
                 fac8 = {"error": str(ex_)}
-            # roofline of the back half (k_bwd_count8_struct: backward sweep + 128 x 128 counts, four waves per group of four tiles):
-            # 2 n^2 flop per bin on v_mfma_f64_16x16x4 beside four redundant O(n) sweeps
-            flop8 = 2 * 128 * 128 + 4 * 24 * 128
+            # roofline of the back half on the ALGORITHMIC flops: 2 n^2 (counts, v_mfma_f64_16x16x4) + 24 n (one O(n) backward sweep) per bin.
+            # k_bwd_count8x_struct (round 4: sixteen tiles per work-group, one sweep per tile, operands exchanged through LDS) executes
+            # exactly that; round 3's k_bwd_count8_struct ("fuse128=1") redoes the sweep in each of its four waves: executed_flop_per_bin
+            flop8 = 2 * 128 * 128 + 24 * 128
+            kname8 = "k_bwd_count8x_struct" if "fuse128=1" not in args.opt else "k_bwd_count8_struct"
             tf8 = bins * flop8 / (kern8["expect"] * 1e-3) / 1e12 if kern8.get("expect", 0) > 0 else 0.0
             traffic8 = None
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_n128.json")))
-                if abs(pj["bins"] - bins) <= 64 and "k_bwd_count8_struct" in pj["kernels"]:
-                    traffic8 = pj["kernels"]["k_bwd_count8_struct"]["hbm_bytes_per_launch"]
+                if abs(pj["bins"] - bins) <= 64 and kname8 in pj["kernels"]:
+                    traffic8 = pj["kernels"][kname8]["hbm_bytes_per_launch"]
             except Exception:
                 pass
             out["n128"] = {"value": bins / (d8 * 1e-3), "unit": "bins/s", "ms_per_step": d8, "ms_min": d8min, "first_call_ms": f8, "kernels_ms": kern8, "factored_stats": fac8,
@@ -652,12 +683,13 @@ def main():
                                      % (bins, len(segs), par8, NT8, NW8),
                            "tiles": diag8.get("n_chunks"), "tile_bins": diag8.get("tile_len"), "repair_rounds": [diag8.get("fwd_rounds"), diag8.get("bwd_rounds")],
                            "alg_bytes_per_bin": 16 * 128 + 18, "alg_flop_per_bin_counts": 2 * 128 * 128,
-                           "roofline": {"bound": "mfma", "kernel": "k_bwd_count8_struct", "launches_per_step": diag8.get("fused_launches", 1), "kernel_ms": kern8.get("expect"),
+                           "roofline": {"bound": "mfma", "kernel": kname8, "launches_per_step": diag8.get("fused_launches", 1), "kernel_ms": kern8.get("expect"),
                                         "achieved": tf8, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf8 / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop8,
                                         "mfma_only_frac": bins * 2 * 128 * 128 / (kern8["expect"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS if kern8.get("expect", 0) > 0 else None,
                                         "hbm": {"alg_bytes_per_bin": 8 * 128 + 9, "achieved_GBs": bins * (8 * 128 + 9) / (kern8["expect"] * 1e-3) / 1e9 if kern8.get("expect", 0) > 0 else None},
                                         "traffic": traffic8,
-                                        "note": "executed flops: 2 n^2 counts + four waves per group each redoing the 24 n sweep; mfma_only_frac counts the 2 n^2 alone; "
+                                        "executed_flop_per_bin": flop8 if kname8 == "k_bwd_count8x_struct" else 2 * 128 * 128 + 4 * 24 * 128,
+                                        "note": "frac is on the algorithmic flops 2 n^2 + 24 n (VERDICT r3 item 2); mfma_only_frac counts the 2 n^2 alone; "
                                                 "traffic = PMC bytes per launch from profiles/pmc_traffic_n128.json (a separate rocprofv3 --pmc pass of this command), null if absent"}}
             s8.close()
         except Exception as ex_:

@@ -8,8 +8,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 #include "psmc_hip.h"
 #include "psmc_hip_internal.h"
@@ -126,6 +128,8 @@ struct psmc_hip_ctx {
 	bool timing_valid = false;
 	// batch (psmc_hip_estep_batch)
 	int64_t batch_bins = 0;            // "batch_bins": table bins per launch group of the exact batch (0 = from free memory)
+	int exact_refwd = -1;              // "exact_refwd": exact batch, 64 states: 1 = no f table, the expect pass recomputes the forward sweep (twice the replicates
+	                                   // per group at +0.4 us per bin of the longest segment); 0 = tables for f and b; -1 = 1
 	int32_t *d_bw_seg = nullptr, *d_bw_par = nullptr; int64_t *d_bw_tab = nullptr; size_t bw_cap = 0; // work list of a group
 	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_par][PAR_LEN] parameter blocks of a group
 	int last_batch_groups = 0;
@@ -326,6 +330,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "fuse128") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->fuse128 = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
+	else if (k == "exact_refwd") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; }
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
@@ -511,7 +516,7 @@ static int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const
 	return 0;
 }
 
-static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0)
+static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0, bool need_f = true)
 {
 	if (c->parent) { // a batch child works in its parent's tables (same segments, one E-step at a time)
 		int rc = ensure_tables(c->parent, need_b);
@@ -520,17 +525,19 @@ static int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins = 0)
 		return rc;
 	}
 	const int64_t bins = std::max(c->total, want_bins) + 128;
-	if (c->tab_bins < bins) {
-		int rc;
-		if ((rc = dev_alloc(c, &c->d_f, (size_t)bins * c->ns))) return rc;
-		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) return rc;
-		if (c->mode == PSMC_HIP_MODE_FAST && (rc = dev_alloc(c, &c->d_sb, (size_t)bins))) return rc;
+	int rc;
+	if (c->tab_bins < bins) { // grow: everything goes, and comes back as needed
+		if (c->d_f) { (void)hipFree(c->d_f); c->d_f = nullptr; }
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
 		c->have_b = false;
+		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) { c->tab_bins = 0; return rc; }
+		if (c->mode == PSMC_HIP_MODE_FAST && (rc = dev_alloc(c, &c->d_sb, (size_t)bins))) { c->tab_bins = 0; return rc; }
 		c->tab_bins = bins;
 	}
+	// the exact batch with the recomputed forward sweep keeps no f table: give its memory to the replicates
+	if (!need_f && c->d_f) { (void)hipFree(c->d_f); c->d_f = nullptr; }
+	if (need_f && !c->d_f && (rc = dev_alloc(c, &c->d_f, (size_t)c->tab_bins * c->ns))) return rc;
 	if (need_b && !c->have_b) {
-		int rc;
 		if ((rc = dev_alloc(c, &c->d_b, (size_t)c->tab_bins * c->ns))) return rc;
 		c->have_b = true;
 	}
@@ -1288,14 +1295,15 @@ static int batch_selections(psmc_hip_ctx *c, int n_rep, const int32_t *sel_off, 
 // Table bins an exact batch may use: "batch_bins", or 0.9 of the device memory that is free or already in this context's tables.
 // (Round 3 took 0.9 of the free memory PLUS all of what the context held: the second call saw a larger capacity than the first,
 // re-planned its groups and re-allocated 250 GB of tables -- 8 s; profiles/r04_boot_breakdown.txt.)
+static bool batch_refwd(const psmc_hip_ctx *c) { return c->ns == 64 && c->exact_refwd != 0; } // k_expect_exact_rf: 64 states
 static int batch_capacity(psmc_hip_ctx *c, int64_t *cap)
 {
 	*cap = c->batch_bins;
 	if (*cap > 0) return 0;
 	size_t fr = 0, tot = 0;
 	HIPCHK(c, hipMemGetInfo(&fr, &tot));
-	const double S = (double)c->ns, per_bin = S * 8.0 * 2.0 + 8.0;
-	const double held = (double)c->tab_bins * (S * 8.0 * (c->have_b ? 2.0 : 1.0) + 8.0 + (c->d_sb ? 8.0 : 0.0));
+	const double S = (double)c->ns, per_bin = S * 8.0 * (batch_refwd(c) ? 1.0 : 2.0) + 8.0;
+	const double held = (double)c->tab_bins * (S * 8.0 * ((c->have_b ? 1.0 : 0.0) + (c->d_f ? 1.0 : 0.0)) + 8.0 + (c->d_sb ? 8.0 : 0.0));
 	*cap = (int64_t)(((double)fr + held) * 0.9 / per_bin) - 256;
 	if (*cap < 1) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: no device memory left for tables");
 	return 0;
@@ -1310,7 +1318,7 @@ extern "C" int psmc_hip_reserve_batch_tables(psmc_hip_ctx *c, int64_t max_bins)
 	int64_t cap = 0;
 	int rc = batch_capacity(c, &cap);
 	if (rc) return rc;
-	return ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap);
+	return ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !batch_refwd(c));
 }
 
 // Exact mode: the sweeps of ALL replicates of a group in one launch each (forward, backward, expect), replicate-major;
@@ -1348,7 +1356,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		// this call's groups, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
 		int64_t all_bins = 0; // what ONE group of all replicates would need: never allocate beyond it
 		for (const RepSel &R : reps) all_bins += R.bins;
-		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins))))) return rc;
+		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins)), !batch_refwd(c)))) return rc;
 		if ((rc = ensure_seg_outputs(c, (int)worst_entries))) return rc;
 		if (c->bw_cap < worst_entries) {
 			if ((rc = dev_alloc(c, &c->d_bw_seg, worst_entries))) return rc;
@@ -1384,6 +1392,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		EstepLaunch p;
 		fill_common(c, p, c->stream, c->d_bpar);
 		p.d_work = c->d_bw_seg; p.n_work = nw; p.d_work_par = c->d_bw_par; p.d_work_tab = c->d_bw_tab; p.par_stride = (int64_t)PL; p.work_align = align;
+		p.exact_refwd = batch_refwd(c) ? 1 : 0;
 		p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
 		const double t_b = now();
 		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch)", hipGetLastError());
@@ -1398,11 +1407,27 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		collect_timing(c);
 		// hmm_add_expect in selection order per replicate (khmm.c:346-359), he_sum starting from zeros; LL += hmm_lk (em.c:48)
 		std::vector<double> sA((size_t)n * n), sE((size_t)2 * n);
+		// hmm_lk of every (replicate, segment) entry: a running product over all of its bins with the platform log() -- 0.7 ns per bin,
+		// 0.36 s per group of 28 replicates on one core; the entries are independent, so host threads share them (each value is
+		// computed by one thread exactly as before: bit-identical)
+		std::vector<double> lk_all(wseg.size(), 0.0);
+		{
+			const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+			std::atomic<size_t> next(0);
+			auto work = [&]() {
+				for (size_t i = next.fetch_add(1); i < wseg.size(); i = next.fetch_add(1))
+					if (wseg[i] >= 0) lk_all[i] = host_lk(&c->h_s[(size_t)wtab[i]], c->L[wseg[i]]);
+			};
+			std::vector<std::thread> th;
+			for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+			work();
+			for (std::thread &t : th) t.join();
+		}
 		for (int r = r0; r < r1; ++r) {
 			const RepSel &R = reps[r];
 			const int f0 = first[r - r0];
 			lk.resize(R.work.size());
-			for (size_t j = 0; j < R.work.size(); ++j) lk[j] = host_lk(&c->h_s[(size_t)wtab[f0 + j]], c->L[R.work[j]]);
+			for (size_t j = 0; j < R.work.size(); ++j) lk[j] = lk_all[(size_t)f0 + j];
 			std::fill(sA.begin(), sA.end(), 0.0); std::fill(sE.begin(), sE.end(), 0.0);
 			double ll = 0.0;
 			for (size_t i = 0; i < R.sel2work.size(); ++i) {

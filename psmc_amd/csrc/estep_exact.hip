@@ -24,7 +24,8 @@ __device__ __forceinline__ double pick_e(int sym, double e0, double e1) {
 
 // ---------------------------------------------------------------- forward
 // khmm.c:145-190.  One wave per selected segment.
-template <int REP>
+// STORE_F = false: only the scale factors s[] are written (the batch's table-free forward pass: k_expect_exact_rf below recomputes f)
+template <int REP, bool STORE_F = true>
 __global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, const double *__restrict__ e,
                                                     const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                     const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, 
 		double sum;
 		{ double r[4]; rep_rows<REP>(g, r); sum = seq_sum_rep(r); }
 		x = g / sum;
-		fo[lane] = x;
+		if (STORE_F) fo[lane] = x;
 		if (lane == 0) so[0] = sum;
 	}
 	for (int base = 0; base < L; base += 64) { // positions base+1 .. base+64
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64) void k_fwd_exact(const double *__restrict__ a, 
 			const double g = pick_e(sym, e0, e1) * tmp;
 			{ double q[4]; rep_rows<REP>(g, q); sum = seq_sum_rep(q); }
 			x = g / sum;
-			fo[(int64_t)(base + i) * 64 + lane] = x;
+			if (STORE_F) fo[(int64_t)(base + i) * 64 + lane] = x;
 			if (lane == 0) so[base + i] = sum;
 		}
 		symv = symn;
@@ -262,6 +263,118 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 		oe[col] = E0; oe[S + col] = E1; oe[2 * S + col] = E2;
 		const int sym1 = o[0]; // khmm.c:321-322: A0[l] += a0[l]*e[o_1][l]*b[1][l], A0 starts at 0
 		segA0[(int64_t)blockIdx.x * S + col] = 0.0 + a0[col] * e[sym1 * S + col] * bo[col];
+	}
+}
+
+// ---------------------------------------------------------------- expect with the forward sweep recomputed (exact batch, 64 states)
+// VERDICT r3 item 3(a).  A batch group is as many replicates as fit the tables, and f + b + s cost 1032 bytes per bin: 12-14
+// replicates of a 30 M-bin genome in 250 GB, i.e. ~550 waves in the latency-bound sweeps on a device with 1024 SIMDs.  hmm_expect
+// adds A[k][l] += f[u][k] ae b[u+1][l] for u ASCENDING (khmm.c:310-319), the order in which the forward sweep produces f -- so
+// the third pass can recompute f instead of reading it back: the recursion is deterministic, the same instructions in the same
+// order give the same bits, and the f table (half of the memory) is never written.  One work-group per (replicate, segment):
+//   wave 0  the forward recursion of k_fwd_exact, verbatim, its vector going into a two-half LDS ring of 16 positions each;
+//   wave 1  rows k = 0..31 of A (lane = column l) + E and A0;   wave 2  rows k = 32..63 of A.
+// The consumers work on the half the producer filled in the previous phase: one barrier per 16 positions.  They are far below
+// the producer's 0.8 us per position (3 instructions per cell and position against ~400 per position), so the pass runs at the
+// forward sweep's latency: group time (fwd s[] only) + bwd + this = 0.83 + 0.53 + 0.83 us per bin of the longest segment instead
+// of 0.83 + 0.53 + 0.45, for twice the replicates per group.  q = e[o][l] a[k][l] is formed here with one rounding, as
+// hmm_pre_backward (khmm.c:194-206) and the host's aeT do.
+template <int REP>
+__global__ __launch_bounds__(192, 2) void k_expect_exact_rf(const double *__restrict__ a, const double *__restrict__ e,
+                                                          const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                          const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
+                                                          const ExWork wl, const double *__restrict__ b, const double *__restrict__ s,
+                                                          double *__restrict__ segA, double *__restrict__ segE, double *__restrict__ segA0)
+{
+	constexpr int RB = 16; // positions per ring half
+	__shared__ double ring[2][RB][64];
+	const int lane = threadIdx.x & 63;
+	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int seg = wl.seg[blockIdx.x];
+	if (seg < 0) return; // padding entry of a batch (block-uniform)
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[blockIdx.x] : off;
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x] * wl.par_stride : 0; a += po; e += po; a0 += po; }
+	const int L = seg_len[seg];
+	const int n = L - 1;                 // u = 1 .. L-1: index i = u - 1 = 0 .. n-1 uses f[i], b[i+1], obs[i+1] (A) and f[i], b[i], s[i], obs[i] (E)
+	const int P = (n + RB - 1) / RB;     // phases: every wave passes exactly P barriers
+	const uint8_t *o = obs + off;
+	const double e0 = e[lane], e1 = e[64 + lane];
+	if (w == 0) { // ---------------- producer: k_fwd_exact, position by position (khmm.c:171-185)
+		double col[64];
+#pragma unroll
+		for (int l = 0; l < 64; ++l) col[l] = a[l * 64 + lane];
+		int symv = o[lane];
+		double x = 0.0;
+		for (int base = 0; base < n; base += 64) { // positions base+1 .. base+64 = indices base .. base+63
+			const int nb = min(64, n - base);
+			const int symn = (base + 64 < L) ? (int)o[base + 64 + lane] : 2;
+			for (int i = 0; i < nb; ++i) {
+				const int sym = __builtin_amdgcn_readlane(symv, i);
+				double g, sum;
+				if (base + i == 0) g = a0[lane] * pick_e(sym, e0, e1);
+				else { double r[4]; rep_rows<REP>(x, r); const double tmp = xdot64(r, col); g = pick_e(sym, e0, e1) * tmp; }
+				{ double q[4]; rep_rows<REP>(g, q); sum = seq_sum_rep(q); }
+				x = g / sum;
+				const int idx = base + i;
+				ring[(idx / RB) & 1][idx % RB][lane] = x;
+				if (idx % RB == RB - 1 || idx == n - 1) __syncthreads(); // the half is complete: hand it to the consumers
+			}
+			symv = symn;
+		}
+		return;
+	}
+	// ---------------- consumers
+	const int cw = w - 1, k0 = 32 * cw, colc = lane; // rows k0 .. k0+31 of A, lane = column l
+	const double *bo = b + toff * 64, *so = s + toff;
+	double arow[32], acc[32];
+#pragma unroll
+	for (int j = 0; j < 32; ++j) { arow[j] = a[(k0 + j) * 64 + colc]; acc[j] = PSMC_TINY; } // khmm.c:305-306
+	double E0 = PSMC_TINY, E1 = PSMC_TINY, E2 = PSMC_TINY; // khmm.c:307-308 (wave 1 only)
+	double bprev = n > 0 ? bo[colc] : 0.0;                  // b[i] of the block's first position (E uses b[i], A uses b[i+1])
+	double bn[RB]; int sv = 2, sve = 2; double ssv = 0.0;
+	auto load_blk = [&](int i0, double (&bn_)[RB], int &sv_, int &sve_, double &ss_) {
+#pragma unroll
+		for (int t = 0; t < RB; ++t) bn_[t] = bo[(int64_t)min(i0 + t + 1, L - 1) * 64 + colc];
+		const int ii = min(i0 + min(lane, RB - 1), L - 1);
+		sv_ = o[min(ii + 1, L - 1)];   // symbol of position u + 1 (A)
+		sve_ = o[ii];                  // symbol of position u (E)
+		ss_ = so[ii];
+	};
+	for (int ph = 0; ph < P; ++ph) {
+		const int i0 = ph * RB, nb = min(RB, n - i0);
+		// (no double buffer for the b rows: two work-groups per compute unit need the wave below 256 registers, and the consumers have
+		// ~14 us per phase for ~5 us of work -- the load latency is paid in their slack, not on the producer's path)
+		load_blk(i0, bn, sv, sve, ssv);
+		__syncthreads(); // the producer has filled half ph & 1
+		const double (*hf)[64] = ring[ph & 1];
+#pragma unroll
+		for (int t = 0; t < RB; ++t) {
+			if (t < nb) {
+				const int sym = __builtin_amdgcn_readlane(sv, t);
+				const double es = pick_e(sym, e0, e1);      // e[o_{u+1}][l]
+				const double bl = bn[t];
+#pragma unroll
+				for (int j = 0; j < 32; ++j) {
+					const double q = es * arow[j];            // ae[o][k][l]: one rounding (khmm.c:194-206)
+					acc[j] += hf[t][k0 + j] * q * bl;         // khmm.c:316
+				}
+				if (cw == 0) { // khmm.c:317: Ec[k] += f[u][k] * b[u][k] * s[u]
+					const int syme = __builtin_amdgcn_readlane(sve, t);
+					const double v = hf[t][colc] * bprev * readlane_f64(ssv, t);
+					if (syme == 0) E0 += v; else if (syme == 1) E1 += v; else E2 += v;
+				}
+				bprev = bl;
+			}
+		}
+	}
+	double *out = segA + (int64_t)blockIdx.x * 4096;
+#pragma unroll
+	for (int j = 0; j < 32; ++j) out[(k0 + j) * 64 + colc] = acc[j];
+	if (cw == 0) {
+		double *oe = segE + (int64_t)blockIdx.x * 192;
+		oe[colc] = E0; oe[64 + colc] = E1; oe[128 + colc] = E2;
+		const int sym1 = o[0]; // khmm.c:321-322
+		segA0[(int64_t)blockIdx.x * 64 + colc] = 0.0 + a0[colc] * e[sym1 * 64 + colc] * bo[colc];
 	}
 }
 
@@ -662,7 +775,14 @@ int launch_exact(const EstepLaunch &p)
 	if (p.ns == 128) return rep == 0 ? launch_exact128_t<0>(p) : launch_exact128_t<1>(p);
 	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.n_work, p.par_stride};
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
-	if (rep == 0)
+	if (p.exact_refwd) { // scale factors only
+		if (rep == 0)
+			hipLaunchKernelGGL((k_fwd_exact<0, false>), dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
+			                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
+		else
+			hipLaunchKernelGGL((k_fwd_exact<1, false>), dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
+			                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
+	} else if (rep == 0)
 		hipLaunchKernelGGL(k_fwd_exact<0>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	else
@@ -677,6 +797,14 @@ int launch_exact(const EstepLaunch &p)
 		hipLaunchKernelGGL(k_bwd_exact<1>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
+	if (p.exact_refwd) { // no f table: the third pass recomputes the forward sweep (k_expect_exact_rf)
+		if (rep == 0)
+			hipLaunchKernelGGL(k_expect_exact_rf<0>, dim3(p.n_work), dim3(192), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,
+			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+		else
+			hipLaunchKernelGGL(k_expect_exact_rf<1>, dim3(p.n_work), dim3(192), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,
+			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+	} else
 	hipLaunchKernelGGL(k_expect_exact<64>, dim3(p.n_work, 17), dim3(64), 0, p.stream, p.d_a, p.d_aeT, p.d_e, p.d_a0,
 	                   p.d_obs, p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
 	if (p.ev[3]) hipEventRecord(p.ev[3], p.stream);

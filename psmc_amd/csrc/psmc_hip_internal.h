@@ -48,6 +48,7 @@ struct EstepLaunch {
 	hipEvent_t evx[14];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
 	int overlap;
 	int rep_impl, expect_impl, n_states;
+	int exact_refwd;             // exact batch, 64 states: no f table -- the expect pass recomputes the forward sweep (estep_exact.hip k_expect_exact_rf)
 	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)
 	// parameters (padded to NS)
 	const double *d_a;   // a[l*64+k] row-major P(l->k)... i.e. a[row*64+col]

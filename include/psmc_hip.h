@@ -85,6 +85,10 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           leaves every tile's start vector), so the back half keeps its ~4096 tiles while phase 1 pays half the
  *                           warm-ups.  Fused / factored back half only.  auto: 2 in the one-round plan when there are more than 2048
  *                           tiles shorter than their warm-up (1 M .. 12 M bins), else 1
+ *  "lanes8"        auto     64 states, fused / factored back half: 1 = the bulk sweeps of phase 1 run EIGHT tiles per wave (8 lanes x 8 states per
+ *                           tile: a scan level less, ~13 instead of 17 vector instructions per tile-step, half as many waves); 0 = four.
+ *                           auto: with the factored statistics (their forward sweep stores checkpoints only); the full-count E-step,
+ *                           whose forward sweep is paced by its table stores, is slower with it
  *  "gate"          auto     1: one-wave gate kernels order the DISPATCH of phase 1's grids across streams -- walks, then the bulk
  *                           grid, then the transfer matrices -- so that every walk gets a SIMD slot of its own (they give up after
  *                           ~200 us); 0: whatever order the queues come up in.  auto: with coarse items
@@ -99,7 +103,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  --- back half ----------------------------------------------------------------------------------------------------
  *  "fuse"          1        structured sweeps, up to 64 states: the backward sweep feeds the counts' matrix
  *                           instructions directly, bt never stored; 0: bt table + separate counts kernel
- *  "fuse128"       1        the same with 65..128 states (four waves per group of four tiles)
+ *  "fuse128"       2        the same with 65..128 states: 2 = sixteen tiles per work-group, one sweep per tile, operands of the matrix
+ *                           instructions exchanged through LDS; 1 = round 3's kernel (four waves redo the sweep of four tiles); 0 = unfused
  *  "ckpt"          1        psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest
  *  "structured"    1        1 = O(N) sweeps when a[][] has the PSMC form (checked per call), 0 = always the dense sweeps
  *  "overlap"       1        forward chain, backward chain, counts and walks on streams of their own; 0: one stream
@@ -110,6 +115,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  --- exact mode ---------------------------------------------------------------------------------------------------
  *  "rep_impl"      1        row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical)
  *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch group; 0 = what fits the free device memory
+ *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1 (auto) = no f table -- the expect pass recomputes the forward sweep in its own
+ *                           work-group (bit-identical), so a launch group holds twice the replicates; 0 = f and b tables, three kernels
  *
  * Removed in round 3 after losing their A/B (DESIGN.md section 3 keeps the measurements): "count_impl", "kc_warm",
  * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "lanes8", "exact_lds", and the value 1 of "two_phase". */

@@ -41,6 +41,9 @@ struct psmc_hip_ctx {
 	int merge1_used = 0;
 	int merge_order = -1;      // "merge_order": block order of that grid: 1 = forward blocks, then backward blocks; 0 = alternating (every XCD gets one
 	                           // direction); -1 = by the plan: 1 while a tile is shorter than its warm-up (measured: 3.75 M bins 3.00 vs 3.25 ms, 7.5 M equal, 15 M 7.9 vs 7.6)
+	int lanes8 = -1;           // "lanes8": 64 states, fused / factored plans: the bulk sweeps of phase 1 run eight tiles per wave (8 lanes x 8 states: a quarter
+	                           // fewer vector instructions per tile-step, half the waves).  -1 = with the factored statistics only -- measured (round 4, genome):
+	                           // factored 10.26 -> 9.91 ms; full counts 12.09 -> 12.73 (its forward sweep is paced by 15.6 GB of stores and half as many waves hide less)
 	int gate = -1;             // "gate": order the dispatch of phase 1's grids walks -> bulk -> transfer matrices (estep_struct.hip k_gate); -1 = with coarse
 	                           // items (measured: without them the bulk grid is the critical path and walks that land late, stacked on few SIMDs, slow fewer of its waves)
 	int *d_gate = nullptr;
@@ -317,6 +320,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
 	else if (k == "runs_late") { c->runs_late = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
+	else if (k == "lanes8") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->lanes8 = (int)v; }
 	else if (k == "gate") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->gate = (int)v; }
 	else if (k == "coarse") { if (v < -1 || v > 16) return PSMC_HIP_EINVAL; c->coarse = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "merge_order") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge_order = (int)v; }
@@ -1100,6 +1104,7 @@ static int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const
 	// coarse bulk items: the fused and the factored back half only (their backward pass of phase 1 leaves start vectors, no table)
 	const int coarse = (c->use_struct && p.fused != 0) ? c->coarse_used : 1;
 	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0) || c->items_coarse != coarse) && (rc = build_items(c, two_phase_bwd, coarse))) return rc;
+	p.lanes8 = (c->lanes8 >= 0 ? c->lanes8 != 0 && p.fused != 0 : p.fused == 2) && c->ns == 64 ? 1 : 0;
 	p.d_gate = (c->gate >= 0 ? c->gate != 0 : coarse > 1) ? c->d_gate : nullptr;
 	p.coarse = coarse; p.d_singles_b = c->d_items + 24 * (size_t)p.n_chunks; p.n_singles_b = c->n_singles_b;
 	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles; p.count_group = c->count_group;
@@ -1474,7 +1479,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles;
 		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
 		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
-		k->fuse128 = c->fuse128; k->coarse = c->coarse; k->gate = c->gate;
+		k->fuse128 = c->fuse128; k->coarse = c->coarse; k->gate = c->gate; k->lanes8 = c->lanes8; k->exact_refwd = c->exact_refwd;
 		k->merge1 = c->merge1; k->merge_order = c->merge_order; k->runs_late = c->runs_late; k->warm_shift_set = c->warm_shift_set; k->kc_sub_set = c->kc_sub_set;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];

@@ -621,6 +621,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	}
 	// dispatch order walks -> bulk -> transfer matrices (estep_struct.hip k_gate): the bulk grid's stream waits until every walk has its slot
 	const bool gated = lw && ov && p.d_gate != nullptr && sw != sm;
+	const int rw = p.lanes8 && p.ns == 64 && p.fused ? 8 : 4; // tiles per wave of the bulk grid
 	if (gated) launch_gate(sm, p.d_gate, walk_blocks(p));
 	if (mg) {
 		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0 - p.n_B_b, true);
@@ -630,7 +631,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.n_kc > 0) { // long runs: transfer matrices of their tiles (a stream of their own), then the chain
 			if (ov) (void)hipStreamWaitEvent(sk, p.evx[0], 0);
 			// ... and the matrices wait until the bulk grid has been dispatched (merged: both directions; else the forward sweep)
-			if (gated && sk != sm) launch_gate(sk, p.d_gate + 1, std::min(2048, mg ? (p.n_items_f - ff0 + 3) / 4 + (p.n_items_b - fb0 - p.n_B_b + 3) / 4 : (p.structured ? (p.n_items_f - ff0 + 3) / 4 : 0)));
+			if (gated && sk != sm) launch_gate(sk, p.d_gate + 1, std::min(2048, mg ? (p.n_items_f - ff0 + rw - 1) / rw + (p.n_items_b - fb0 - p.n_B_b + rw - 1) / rw : (p.structured ? (p.n_items_f - ff0 + rw - 1) / rw : 0)));
 			launch_kchain(p, sk, sw, p.evx[8]);
 		}
 		(void)hipEventRecord(p.evx[6], sw);

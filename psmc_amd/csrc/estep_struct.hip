@@ -71,8 +71,24 @@ __device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, co
 	v.w = row == 0 ? s0.w : (row == 1 ? s1.w : (row == 2 ? s2.w : s3.w));
 	return v;
 }
-template <int NPL> __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructParN<NPL> &c) {
-	constexpr int S = 16 * NPL; // sp = P | R | qa | c | dd, S each
+// Tile geometry of a sweep wave: LPT lanes per tile (16: four tiles per wave, a tile is a DPP row; 8: eight tiles per wave, 8 lanes x 8
+// states -- 64 states only; see struct_prims.h), NPL adjacent states per lane.
+template <int NPL, int LPT> __device__ __forceinline__ void tile_step(const StructParN<NPL> &c, double (&x)[NPL], const Half8Masks &hm) {
+	if constexpr (LPT == 8) struct_step_h8(c, x, hm); else struct_step<NPL>(c, x);
+}
+// eight rows (8 lanes per tile)
+__device__ __forceinline__ uint4 row_symbols(const uint8_t *__restrict__ obs, const int64_t (&roff)[8], const int (&bb)[8], int row)
+{
+	uint4 v = *reinterpret_cast<const uint4 *>(obs + roff[0] + ((int64_t)bb[0] << 4));
+#pragma unroll
+	for (int r = 1; r < 8; ++r) {
+		const uint4 s = *reinterpret_cast<const uint4 *>(obs + roff[r] + ((int64_t)bb[r] << 4));
+		v.x = row == r ? s.x : v.x; v.y = row == r ? s.y : v.y; v.z = row == r ? s.z : v.z; v.w = row == r ? s.w : v.w;
+	}
+	return v;
+}
+template <int NPL, int LPT = 16> __device__ __forceinline__ void load_struct_par(const double *__restrict__ sp, int k0, bool fwd, StructParN<NPL> &c) {
+	constexpr int S = LPT * NPL; // sp = P | R | qa | c | dd, S each
 	loadN<NPL>(sp + (fwd ? 0 : 3 * S) + k0, c.mS);  // forward: P,  backward: c
 	loadN<NPL>(sp + (fwd ? 2 * S : S) + k0, c.wS);  // forward: qa, backward: R
 	loadN<NPL>(sp + (fwd ? S : 2 * S) + k0, c.mP);  // forward: R,  backward: qa
@@ -85,11 +101,14 @@ template <int NPL> __device__ __forceinline__ double lane_sum(const double (&x)[
 	return t;
 }
 // sum over the states of the lane's tile, identical in all of its lanes
-template <int NPL> __device__ __forceinline__ double tile_sum(const double (&x)[NPL]) { return row_sum16(lane_sum<NPL>(x)); }
+template <int NPL, int LPT = 16> __device__ __forceinline__ double tile_sum(const double (&x)[NPL]) {
+	if constexpr (LPT == 8) return half8_sum(lane_sum<NPL>(x)); else return row_sum16(lane_sum<NPL>(x));
+}
 // e[0] | e[1] | 1 | 1 (rows of S) for the per-symbol emission fetch
-template <int S> __device__ __forceinline__ void fill_lds_e(double *lds_e, const double *__restrict__ e, int lane) {
+template <int NPL, int LPT = 16> __device__ __forceinline__ void fill_lds_e(double *lds_e, const double *__restrict__ e, int lane) {
+	constexpr int S = NPL * LPT;
 #pragma unroll
-	for (int i = lane; i < S; i += 64) { const int q = ev_slot<S / 16>(i); lds_e[q] = e[i]; lds_e[S + q] = e[S + i]; lds_e[2 * S + q] = 1.0; lds_e[3 * S + q] = 1.0; } // ev_load layout (struct_prims.h)
+	for (int i = lane; i < S; i += 64) { const int q = ev_slot<NPL, LPT>(i); lds_e[q] = e[i]; lds_e[S + q] = e[S + i]; lds_e[2 * S + q] = 1.0; lds_e[3 * S + q] = 1.0; } // ev_load layout (struct_prims.h)
 }
 
 // ---- Dispatch order across streams (round 4).
@@ -135,8 +154,8 @@ struct FwdCursor { int next_lo, tile; };
 
 // MODE 0: per-step range / store / boundary predicates;  MODE 1: all 16 positions are computed and
 // stored and no tile starts inside the block;  MODE 2: warm-up, nothing stored.
-template <int MODE, int J, int NPL, bool CK>
-__device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
+template <int MODE, int J, int NPL, bool CK, int LPT>
+__device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                          double *fo, double *io, double *entry, int g, double &inv_keep)
 {
@@ -146,28 +165,28 @@ __device__ __forceinline__ void fwd_step(const StructParN<NPL> &c, const double 
 	// lo0 = first position whose X is stored (INT_MAX for a walk, which only leaves the boundary vectors)
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p >= p_first && p <= p_last)) return;
-	constexpr int S = 16 * NPL;
+	constexpr int S = LPT * NPL;
 	if (MODE == 0 && p == cur.next_lo) { // the X_{lo-1} this tile builds on
 		storeN<NPL>(entry + (int64_t)cur.tile * S + k0, x);
 		cur.tile += 1; cur.next_lo += T;
 	}
 	double ev[NPL];
-	ev_load<NPL>(lds_e + sym_of<J>(w) * S, k0, ev);
+	ev_load<NPL, LPT>(lds_e + sym_of<J>(w) * S, k0, ev);
 	if (J == 3) { // p % NORM_EVERY == 0 (groups are 4-aligned): d_p = sum(X_{p-1}) rounded down to a power of two, off the critical path
-		const double inv = pow2_rcp(tile_sum<NPL>(x));
+		const double inv = pow2_rcp(tile_sum<NPL, LPT>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= inv;
 		if (MODE == 1) inv_keep = m == g ? inv : inv_keep; // one 32-byte store per tile and block instead of four 8-byte ones
 		else if (MODE == 0 && p >= lo0 && m == 0) io[idx] = inv;
 	}
-	struct_step<NPL>(c, x);
+	tile_step<NPL, LPT>(c, x, hm);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 	if (MODE == 1) { if (!CK || (J == 3 && (g & 1))) storeN<NPL>(fo + (int64_t)idx * S, x); }
 	else if (MODE == 0 && p >= lo0 && (!CK || (p & 7) == 0 || p == p_last)) storeN<NPL>(fo + (int64_t)idx * S, x);
 }
-template <int MODE, int NPL, bool CK>
-__device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int NPL, bool CK, int LPT>
+__device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_last, int lo0, int T, FwdCursor &cur, double (&x)[NPL],
                                           double *fo, double *io, double *entry)
 {
@@ -178,10 +197,10 @@ __device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double
 	for (int g = 0; g < 4; ++g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g;
-		fwd_step<MODE, 0, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
-		fwd_step<MODE, 1, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
-		fwd_step<MODE, 2, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
-		fwd_step<MODE, 3, NPL, CK>(c, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 0, NPL, CK, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 1, NPL, CK, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 2, NPL, CK, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
+		fwd_step<MODE, 3, NPL, CK, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_last, lo0, T, cur, x, fo, io, entry, g, inv_keep);
 	}
 	if (MODE == 1 && m < 4) io[base + 4 * m + 3] = inv_keep; // 1/d_p of the block's four normalising positions
 }
@@ -189,7 +208,7 @@ __device__ __forceinline__ void fwd_block(const StructParN<NPL> &c, const double
 // items[4*blockIdx.x + row] = work of this row.  REPAIR: the list holds the flagged tiles (count 1); a
 // row starts from the neighbour's stored X_{lo-1} and recomputes its whole tile (the verify kernel
 // then decides whether the next tile has to follow).  No vector-memory load inside the sweep.
-template <bool REPAIR, int NPL, bool CK = false>
+template <bool REPAIR, int NPL, bool CK = false, int LPT = 16>
 __device__ __forceinline__ void fwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                 const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -198,12 +217,13 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
                                                 int *__restrict__ touch_f)
 {
 	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0; // SWEEP_CKPT: the CK instantiation
-	constexpr int S = 16 * NPL, R = 4; // R tiles per wave
+	constexpr int S = LPT * NPL, R = 64 / LPT; // R tiles per wave
 	__shared__ double lds_e[4 * S]; // e[0], e[1], 1, 1
-	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
-	fill_lds_e<S>(lds_e, e, lane);
+	const int lane = threadIdx.x, m = lane & (LPT - 1), k0 = NPL * m;
+	const Half8Masks hm = half8_masks(lane);
+	fill_lds_e<NPL, LPT>(lds_e, e, lane);
 	__syncthreads();
-	const int slot = block * R + (lane >> 4);
+	const int slot = block * R + lane / LPT;
 	const bool valid = slot < n_items;
 	const SweepItem it = items[valid ? slot : 0];
 #ifdef PSMC_TRACE_SWEEP
@@ -221,7 +241,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	const uint8_t *o = obs + c.off;
 	double *fo = f + c.off * S + k0, *io = invd + c.off;
 	StructParN<NPL> sc;
-	load_struct_par<NPL>(sp, k0, true, sc);
+	load_struct_par<NPL, LPT>(sp, k0, true, sc);
 	double x[NPL];
 	int p_first;
 	if (REPAIR && valid && m == 0 && !(flags & SWEEP_NO_TOUCH)) touch_f[it.first] = 1; // X / inv_d of this tile change
@@ -234,7 +254,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 		loadN<NPL>(a0 + k0, x);
 		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
 			double ev[NPL];
-			ev_load<NPL>(lds_e + ((int)o[0] & 3) * S, k0, ev);
+			ev_load<NPL, LPT>(lds_e + ((int)o[0] & 3) * S, k0, ev);
 #pragma unroll
 			for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 			if (valid && c.lo == 1 && !walk) storeN<NPL>(fo, x);
@@ -255,9 +275,9 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	int nb_max = 0;
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		roff[r] = readlane_i64(c.off, 16 * r);
-		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
-		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
+		roff[r] = readlane_i64(c.off, LPT * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, LPT * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, LPT * r);
 		nb_max = max(nb_max, rnb[r]);
 	}
 #ifdef PSMC_TRACE_SWEEP
@@ -267,7 +287,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 		int bb[R];
 #pragma unroll
 		for (int r = 0; r < R; ++r) bb[r] = rbf[r] + min(bi, max(rnb[r] - 1, 0));
-		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
+		const uint4 sv = row_symbols(obs, roff, bb, lane / LPT);
 		if (bi < nblk) {
 			const int base = (b_first + bi) << 4;
 			if (cur.next_lo == base + 1 && base + 1 >= p_first && base + 1 <= p_last) { // a tile starts exactly at this block
@@ -279,9 +299,9 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 #ifdef PSMC_TRACE_SWEEP
 			if (tr && tr_first && __all(mode == 1)) { tr_first = false; PSMC_TRACE(g_trace_f, block, 1, wall_clock64()); }
 #endif
-			if (__all(mode == 1)) fwd_block<1, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else if (__all(mode == 2)) fwd_block<2, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
-			else fwd_block<0, NPL, CK>(sc, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			if (__all(mode == 1)) fwd_block<1, NPL, CK, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else if (__all(mode == 2)) fwd_block<2, NPL, CK, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			else fwd_block<0, NPL, CK, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 		}
 	}
 #ifdef PSMC_TRACE_SWEEP
@@ -289,7 +309,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 #endif
 }
 
-template <bool REPAIR, int NPL, bool CK = false>
+template <bool REPAIR, int NPL, bool CK = false, int LPT = 16>
 __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
                                                      int *__restrict__ touch_f, int *__restrict__ started)
 {
 	announce_start(started);
-	fwd_struct_body<REPAIR, NPL, CK>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
+	fwd_struct_body<REPAIR, NPL, CK, LPT>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
 }
 
 // ------------------------------------------------------------------ backward
@@ -309,18 +329,18 @@ struct BwdCursor { int lo, top, tile; bool store; }; // store: false for a walk,
 
 // MODE 1: every position of the block is strictly inside (lo, top) of the current tile;
 // MODE 2: warm-up above the top tile's top;  MODE 0: general.
-template <int MODE, int J, int NPL>
-__device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double *lds_e, int k0, int m, unsigned w, int base,
+template <int MODE, int J, int NPL, int LPT>
+__device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, unsigned w, int base,
                                          int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                          double *sbo, double *bentry, double *bexit)
 {
-	constexpr int S = 16 * NPL;
+	constexpr int S = LPT * NPL;
 	const int p = base + J + 1, idx = base + J;
 	if (MODE == 0 && !(p <= p_first && p >= p_low)) return;
 	double ev[NPL];
-	ev_load<NPL>(lds_e + sym_of<J>(w) * S, k0, ev);
+	ev_load<NPL, LPT>(lds_e + sym_of<J>(w) * S, k0, ev);
 	if (J == 3) { // sb_p = 1/sum(bt_{p+1}), off the critical path
-		const double s = rcp_newton(tile_sum<NPL>(x));
+		const double s = rcp_newton(tile_sum<NPL, LPT>(x));
 #pragma unroll
 		for (int i = 0; i < NPL; ++i) ev[i] *= s;
 		if ((MODE == 1 || (MODE == 0 && p <= cur.top && cur.store)) && m == 0) sbo[idx] = s;
@@ -329,7 +349,7 @@ __device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double 
 		if (cur.store) storeN<NPL>(bto + (int64_t)cur.top * S, x); // bt[top+1]
 		storeN<NPL>(bentry + (int64_t)cur.tile * S + k0, x);
 	}
-	struct_step<NPL>(c, x);
+	tile_step<NPL, LPT>(c, x, hm);
 #pragma unroll
 	for (int i = 0; i < NPL; ++i) x[i] *= ev[i];
 	if (MODE == 1) storeN<NPL>(bto + (int64_t)idx * S, x);
@@ -341,8 +361,8 @@ __device__ __forceinline__ void bwd_step(const StructParN<NPL> &c, const double 
 		}
 	}
 }
-template <int MODE, int NPL>
-__device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const double *lds_e, int k0, int m, const uint4 sv, int base,
+template <int MODE, int NPL, int LPT>
+__device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const Half8Masks &hm, const double *lds_e, int k0, int m, const uint4 sv, int base,
                                           int p_first, int p_low, int T, BwdCursor &cur, double (&x)[NPL], double *bto,
                                           double *sbo, double *bentry, double *bexit)
 {
@@ -350,15 +370,15 @@ __device__ __forceinline__ void bwd_block(const StructParN<NPL> &c, const double
 	for (int g = 3; g >= 0; --g) {
 		const unsigned w = sym_word(sv, g);
 		const int pb = base + 4 * g;
-		bwd_step<MODE, 3, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 2, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 1, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-		bwd_step<MODE, 0, NPL>(c, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 3, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 2, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 1, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+		bwd_step<MODE, 0, NPL, LPT>(c, hm, lds_e, k0, m, w, pb, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 	}
 }
 
 // items: tiles first .. first+count-1, walked from the highest down.
-template <bool REPAIR, int NPL>
+template <bool REPAIR, int NPL, int LPT = 16>
 __device__ __forceinline__ void bwd_struct_body(int block, const double *__restrict__ sp, const double *__restrict__ e,
                                                 const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                 const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -366,12 +386,13 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
                                                 double *__restrict__ bentry, double *__restrict__ bexit,
                                                 int *__restrict__ touch_b)
 {
-	constexpr int S = 16 * NPL, R = 4;
+	constexpr int S = LPT * NPL, R = 64 / LPT;
 	__shared__ double lds_e[4 * S];
-	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
-	fill_lds_e<S>(lds_e, e, lane);
+	const int lane = threadIdx.x, m = lane & (LPT - 1), k0 = NPL * m;
+	const Half8Masks hm = half8_masks(lane);
+	fill_lds_e<NPL, LPT>(lds_e, e, lane);
 	__syncthreads();
-	const int slot = block * R + (lane >> 4);
+	const int slot = block * R + lane / LPT;
 	const SweepItem it = items[slot < n_items ? slot : 0];
 #ifdef PSMC_TRACE_SWEEP
 	const bool trb = !REPAIR && (flags & (SWEEP_TOP_ONLY | SWEEP_COARSE));
@@ -395,7 +416,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	const uint8_t *o = obs + c.off;
 	double *bto = bt + c.off * S + k0, *sbo = sb + c.off;
 	StructParN<NPL> sc;
-	load_struct_par<NPL>(sp, k0, false, sc);
+	load_struct_par<NPL, LPT>(sp, k0, false, sc);
 	double x[NPL]; // bt_{p+1} = e[o_{p+1}] * B_{p+1} (own scaling)
 	int p_first;
 	if (REPAIR) { // continue from the value the tile above computed at our top boundary
@@ -405,7 +426,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 		p_first = cur.top;
 	} else {
 		const int q = min(c.hi + chunk_warm_b(c, W) + 1, L); // B_q := 1
-		ev_load<NPL>(lds_e + ((int)o[q - 1] & 3) * S, k0, x);
+		ev_load<NPL, LPT>(lds_e + ((int)o[q - 1] & 3) * S, k0, x);
 		p_first = q - 1;
 	}
 	// highest block.  A tile that holds only position L (not valid: it owns no transition) has p_first = L - 1, which is 0 for a
@@ -418,9 +439,9 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	int nb_max = 0;
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
-		roff[r] = readlane_i64(c.off, 16 * r);
-		rbf[r] = __builtin_amdgcn_readlane(b_first, 16 * r);
-		rnb[r] = __builtin_amdgcn_readlane(nblk, 16 * r);
+		roff[r] = readlane_i64(c.off, LPT * r);
+		rbf[r] = __builtin_amdgcn_readlane(b_first, LPT * r);
+		rnb[r] = __builtin_amdgcn_readlane(nblk, LPT * r);
 		nb_max = max(nb_max, rnb[r]);
 	}
 #ifdef PSMC_TRACE_SWEEP
@@ -430,14 +451,14 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 		int bb[R];
 #pragma unroll
 		for (int r = 0; r < R; ++r) bb[r] = rbf[r] - min(bi, max(rnb[r] - 1, 0));
-		const uint4 sv = row_symbols(obs, roff, bb, lane >> 4);
+		const uint4 sv = row_symbols(obs, roff, bb, lane / LPT);
 		if (bi < nblk) {
 			const int base = (b_first - bi) << 4;
 			int mode = (base + 1 > cur.lo && base + 16 < cur.top) ? 1 : ((base + 1 > cur.top && base + 16 <= p_first) ? 2 : 0);
 			if (walk && mode == 1) mode = 2;
-			if (__all(mode == 1)) bwd_block<1, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else if (__all(mode == 2)) bwd_block<2, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
-			else bwd_block<0, NPL>(sc, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			if (__all(mode == 1)) bwd_block<1, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else if (__all(mode == 2)) bwd_block<2, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
+			else bwd_block<0, NPL, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_low, T, cur, x, bto, sbo, bentry, bexit);
 		}
 	}
 #ifdef PSMC_TRACE_SWEEP
@@ -445,7 +466,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 #endif
 }
 
-template <bool REPAIR, int NPL>
+template <bool REPAIR, int NPL, int LPT = 16>
 __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                      const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
                                                      const SweepItem *__restrict__ items, int n_items, int W, int T,
@@ -453,7 +474,7 @@ __global__ __launch_bounds__(64) void k_bwd_struct(const double *__restrict__ sp
                                                      double *__restrict__ bentry, double *__restrict__ bexit,
                                                      int *__restrict__ touch_b)
 {
-	bwd_struct_body<REPAIR, NPL>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
+	bwd_struct_body<REPAIR, NPL, LPT>(blockIdx.x, sp, e, obs, chunks, items, n_items, W, T, flags, bt, sb, bentry, bexit, touch_b);
 }
 
 // Both directions' walks over the glued runs in ONE launch (blocks [0, nbf) forward, the rest backward):
@@ -591,7 +612,7 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 	constexpr int S = 16 * NPL, BPT = S / 4; // S unit vectors per tile, four per wave: BPT blocks per tile
 	__shared__ double lds_e[4 * S];
 	const int lane = threadIdx.x, m = lane & 15, k0 = NPL * m;
-	fill_lds_e<S>(lds_e, e, lane);
+	fill_lds_e<NPL, 16>(lds_e, e, lane);
 	__syncthreads();
 	const int j = blockIdx.x / BPT, col = 4 * (blockIdx.x % BPT) + (lane >> 4);
 	// the transfer matrices head the longest dependency chain of the first phase (columns -> chain -> run tiles ->
@@ -887,7 +908,7 @@ __global__ __launch_bounds__(64 * (PER == 1 ? 2 : 8)) void k_kchain_struct(const
 // with two waves and 268 idle (psmc_hip_place_probe, profiles/r03_place_probe.json), and every step of a
 // latency-bound sweep then costs 508 cycles instead of 287.  Per launch: 2 x (8n+9) algorithmic bytes per bin in use
 // (1), (8n+9) in use (2).
-template <int NPL, bool CK>
+template <int NPL, bool CK, int LPT = 16>
 __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                        const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                        const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items_f,
@@ -904,13 +925,14 @@ __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ 
 	// direction.  For phase 1 of a shard-sized E-step, where the forward blocks (warm-up + tile + stores) outlast the
 	// warm-up-only backward ones, that half of the device ended 0.3 ms after the other (scripts/sweep_trace.py); in list
 	// order -- all forward blocks, then all backward blocks -- the second wave on a SIMD is of the other direction.
-	const int nbf = (n_f + 3) / 4, nbb = (n_b + 3) / 4, both = 2 * min(nbf, nbb), b = blockIdx.x;
+	constexpr int R = 64 / LPT; // tiles per wave
+	const int nbf = (n_f + R - 1) / R, nbb = (n_b + R - 1) / R, both = 2 * min(nbf, nbb), b = blockIdx.x;
 	bool fwd; int blk;
 	if (!(flags_b & SWEEP_ALTERNATE)) { fwd = b < nbf; blk = fwd ? b : b - nbf; }
 	else if (b < both) { fwd = (b & 1) == 0; blk = b >> 1; }
 	else { fwd = nbf > nbb; blk = b - both + min(nbf, nbb); }
-	if (fwd) fwd_struct_body<false, NPL, CK>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, flags_f, f, invd, entry, nullptr);
-	else bwd_struct_body<false, NPL>(blk, sp, e, obs, chunks, items_b, n_b, W, T, flags_b, bt, sb, bentry, bexit, nullptr);
+	if (fwd) fwd_struct_body<false, NPL, CK, LPT>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, flags_f, f, invd, entry, nullptr);
+	else bwd_struct_body<false, NPL, LPT>(blk, sp, e, obs, chunks, items_b, n_b, W, T, flags_b, bt, sb, bentry, bexit, nullptr);
 }
 
 // ------------------------------------------------------------------ dirty-tile lists
@@ -948,14 +970,22 @@ __global__ __launch_bounds__(64) void k_compact(const int *__restrict__ dirty, i
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
-	const dim3 g((n_items + 3) / 4), b(64);
+	// the throughput-bound bulk launch of a 64-state model: eight tiles per wave ("lanes8": 8 lanes x 8 states, ~13 instead of 17 vector
+	// instructions per tile-step; the latency-bound launches -- repairs, run tiles -- keep four, whose step is a third shorter)
+	const bool l8 = p.lanes8 && p.ns == 64 && which == 0;
+	const dim3 g(l8 ? (n_items + 7) / 8 : (n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
 	const int flags = (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0) // run tiles are done before the counts start
 	                  | (p.ckpt ? SWEEP_CKPT : 0) | (which == 0 && p.coarse > 1 ? SWEEP_COARSE : 0);
 #define PSMC_LF(REP, NPL, CK) hipLaunchKernelGGL((k_fwd_struct<REP, NPL, CK>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f, which == 0 && p.d_gate ? p.d_gate + 1 : nullptr)
 	const bool rep = which != 0;
-	if (p.ns == 128) { if (rep) PSMC_LF(true, 8, false); else PSMC_LF(false, 8, false); }
+	if (l8) {
+#define PSMC_LF8(CK) hipLaunchKernelGGL((k_fwd_struct<false, 8, CK, 8>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f, p.d_gate ? p.d_gate + 1 : nullptr)
+		if (p.ckpt) PSMC_LF8(true); else PSMC_LF8(false);
+#undef PSMC_LF8
+	} else if (p.ns == 128) { if (rep) PSMC_LF(true, 8, false); else PSMC_LF(false, 8, false); }
 	else if (p.ckpt) { if (rep) PSMC_LF(true, 4, true); else PSMC_LF(false, 4, true); } // checkpoint stores are a compile-time variant: no per-step branches in the full-table kernels
 	else { if (rep) PSMC_LF(true, 4, false); else PSMC_LF(false, 4, false); }
 	PSMC_DBG("launch_fwd_struct", which, first, n_items);
@@ -964,14 +994,18 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items)
 {
 	if (n_items <= 0) return;
-	const dim3 g((n_items + 3) / 4), b(64);
+	const bool l8 = p.lanes8 && p.ns == 64 && which == 4; // the warm-up pass of the fused / factored back half
+	const dim3 g(l8 ? (n_items + 7) / 8 : (n_items + 3) / 4), b(64);
 	const SweepItem *items = (const SweepItem *)(which == 1 || which == 5 ? p.d_ritems_b : (which == 3 ? p.d_members_b : p.d_items_b)) + first;
 	// which == 4 with coarse items: the pass walks every item from the top tile's warm-up down to the lowest tile's top and leaves each tile's start vector
 	const int flags = which == 5 ? SWEEP_WALK : (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : (which == 4 ? (p.coarse > 1 ? (SWEEP_WALK | SWEEP_COARSE) : SWEEP_TOP_ONLY) : 0));
 #define PSMC_LB(REP, NPL) hipLaunchKernelGGL((k_bwd_struct<REP, NPL>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, \
 		n_items, p.warmup, p.tile_len, flags, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b)
 	const bool rep = !(which == 0 || which == 4);
-	if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
+	if (l8)
+		hipLaunchKernelGGL((k_bwd_struct<false, 8, 8>), g, b, 0, st, p.d_sp, p.d_e, p.d_obs, p.d_chunks, items, n_items, p.warmup, p.tile_len, flags,
+		                   p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_touch_b);
+	else if (p.ns == 128) { if (rep) PSMC_LB(true, 8); else PSMC_LB(false, 8); }
 	else { if (rep) PSMC_LB(true, 4); else PSMC_LB(false, 4); }
 	PSMC_DBG("launch_bwd_struct", which, first, n_items);
 #undef PSMC_LB
@@ -987,7 +1021,8 @@ void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd)
 // blocks do the warm-up-only pass of the fused / factored back half (phase 1 of a shard-sized E-step)
 void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb, int nb, bool top_only)
 {
-	const int nblk = (nf + 3) / 4 + (nb + 3) / 4;
+	const bool l8 = p.lanes8 && p.ns == 64 && top_only; // phase 1 of the fused / factored plans (see launch_fwd_struct)
+	const int nblk = l8 ? (nf + 7) / 8 + (nb + 7) / 8 : (nf + 3) / 4 + (nb + 3) / 4;
 	if (nblk <= 0) return;
 	const int co = top_only && p.coarse > 1 ? SWEEP_COARSE : 0; // coarse items: the fused / factored plans only (api.hip enqueue_fast)
 	const int flags_f = (p.ckpt ? SWEEP_CKPT : 0) | co,
@@ -995,7 +1030,12 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 #define PSMC_LS(NPL, CK) hipLaunchKernelGGL((k_sweep_struct<NPL, CK>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
 		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_gate ? p.d_gate + 1 : nullptr)
-	if (p.ns == 128) PSMC_LS(8, false); else if (p.ckpt) PSMC_LS(4, true); else PSMC_LS(4, false);
+#define PSMC_LS8(CK) hipLaunchKernelGGL((k_sweep_struct<8, CK, 8>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
+		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
+		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_gate ? p.d_gate + 1 : nullptr)
+	if (l8) { if (p.ckpt) PSMC_LS8(true); else PSMC_LS8(false); }
+	else if (p.ns == 128) PSMC_LS(8, false); else if (p.ckpt) PSMC_LS(4, true); else PSMC_LS(4, false);
+#undef PSMC_LS8
 	PSMC_DBG("launch_sweeps", nf, nb, top_only);
 #undef PSMC_LS
 }

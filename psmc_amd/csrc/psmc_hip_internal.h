@@ -72,6 +72,7 @@ struct EstepLaunch {
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
+	int lanes8;                       // 64 states: the bulk sweeps of phase 1 run eight tiles per wave (estep_struct.hip launch_fwd_struct)
 	int *d_gate;                      // [0] walk blocks started, [1] bulk blocks started: the gates that order the DISPATCH of phase 1's grids (estep_struct.hip
 	                                  // k_gate); null: no gates
 	int coarse;                       // > 1: a bulk item spans up to this many tiles (one speculation per item; the backward pass of the fused /

@@ -129,9 +129,57 @@ __device__ __forceinline__ void struct_step(const StructParN<NPL> &c, double (&x
 	}
 }
 
-// (An eight-tiles-per-wave form of this step -- 8 lanes x 8 states, masked three-level scans, 51 instead of 68 cycles per
-// tile-step in isolation -- was built in round 2 and removed in round 3: in the E-step it measured inside the noise, 12.9 vs
-// 13.0 ms full counts, 10.7 vs 10.8 factored, profiles/r03_e_sweep.txt.)
+// ---- 8-lane groups (two per DPP row, eight tiles per wave): 64 states as 8 lanes x 8 states.  The cross-lane part of a scan
+// shrinks from four levels to three and is shared by twice as many states per lane: ~13 vector instructions per tile-step instead
+// of 17.  row_shr / row_shl by 1 and 2 would cross the group boundary inside a row: those levels are masked (an FMA instead of an
+// add); the shift by 4 uses the DPP bank mask instead.  (Round 2 built this, round 3 removed it -- inside the noise while phase 1
+// ended with the runs' path -- round 4 brought it back for the bulk sweeps, "lanes8": DESIGN.md.)
+template <int CTRL, int BANKMASK> __device__ __forceinline__ double dpp_zb(double v) {
+	long long s = __builtin_bit_cast(long long, v);
+	long long r = __builtin_amdgcn_update_dpp(0LL, s, CTRL, 0xf, BANKMASK, false);
+	return __builtin_bit_cast(double, r);
+}
+struct Half8Masks { double p1, p2, s1, s2; };
+__device__ __forceinline__ Half8Masks half8_masks(int lane) {
+	const int m = lane & 7;
+	Half8Masks k; k.p1 = m >= 1 ? 1.0 : 0.0; k.p2 = m >= 2 ? 1.0 : 0.0; k.s1 = m <= 6 ? 1.0 : 0.0; k.s2 = m <= 5 ? 1.0 : 0.0;
+	return k;
+}
+__device__ __forceinline__ double half8_excl_prefix(double t, const Half8Masks &k) {
+	t = __builtin_fma(k.p1, dpp_z<0x111>(t), t);
+	t = __builtin_fma(k.p2, dpp_z<0x112>(t), t);
+	t = t + dpp_zb<0x114, 0xA>(t); // lanes 4..7 and 12..15 of the row only
+	return k.p1 * dpp_z<0x111>(t);
+}
+__device__ __forceinline__ double half8_excl_suffix(double t, const Half8Masks &k) {
+	t = __builtin_fma(k.s1, dpp_z<0x101>(t), t);
+	t = __builtin_fma(k.s2, dpp_z<0x102>(t), t);
+	t = t + dpp_zb<0x104, 0x5>(t); // lanes 0..3 and 8..11 of the row only
+	return k.s1 * dpp_z<0x101>(t);
+}
+// sum over the 8 lanes of a group, bit-identical in all of them (every level adds the same two numbers)
+__device__ __forceinline__ double half8_sum(double t) {
+	t = t + dpp_mov<0xB1>(t);  // quad_perm:[1,0,3,2]
+	t = t + dpp_mov<0x4E>(t);  // quad_perm:[2,3,0,1]
+	t = t + dpp_mov<0x141>(t); // row_half_mirror
+	return t;
+}
+__device__ __forceinline__ void struct_step_h8(const StructParN<8> &c, double (&x)[8], const Half8Masks &k)
+{
+	double su[8], pv[8];
+	su[7] = x[7] * c.mS[7];
+#pragma unroll
+	for (int i = 6; i >= 0; --i) su[i] = __builtin_fma(x[i], c.mS[i], su[i + 1]);
+	pv[0] = x[0] * c.mP[0];
+#pragma unroll
+	for (int i = 1; i < 8; ++i) pv[i] = __builtin_fma(x[i], c.mP[i], pv[i - 1]);
+	const double ES = half8_excl_suffix(su[0], k), EP = half8_excl_prefix(pv[7], k);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const double t = __builtin_fma(c.wS[i], su[i], __builtin_fma(c.wP[i], pv[i], c.dd[i] * x[i]));
+		x[i] = __builtin_fma(c.wS[i], ES, __builtin_fma(c.wP[i], EP, t));
+	}
+}
 
 template <int NPL> __device__ __forceinline__ void loadN(const double *p, double (&v)[NPL]) {
 #pragma unroll
@@ -146,17 +194,18 @@ template <int NPL> __device__ __forceinline__ void storeN(double *p, const doubl
 // on every read (round 4: the 128-state counts kernel lost 15 % to it).  So a row of 16 NPL doubles is kept as cells of 16 bytes,
 // cell 16 p + m = states NPL m + 2p, NPL m + 2p + 1: the sixteen lanes of a row read consecutive cells, the four rows the same ones.
 #ifdef PSMC_EV_NATURAL // A/B build: the natural order of rounds 1-3
-template <int NPL> __device__ __forceinline__ int ev_slot(int k) { return k; }
-template <int NPL> __device__ __forceinline__ void ev_load(const double *row, int k0, double (&v)[NPL]) {
+template <int NPL, int LPT = 16> __device__ __forceinline__ int ev_slot(int k) { return k; }
+template <int NPL, int LPT = 16> __device__ __forceinline__ void ev_load(const double *row, int k0, double (&v)[NPL]) {
 #pragma unroll
 	for (int i = 0; i < NPL / 2; ++i) { const d2v_t a = reinterpret_cast<const d2v_t *>(row + k0)[i]; v[2 * i] = a.x; v[2 * i + 1] = a.y; }
 }
 #else
-template <int NPL> __device__ __forceinline__ int ev_slot(int k) { return 2 * (16 * ((k % NPL) >> 1) + k / NPL) + (k & 1); } // index of state k in its row
-template <int NPL> __device__ __forceinline__ void ev_load(const double *row, int k0, double (&v)[NPL]) {
+// (LPT lanes per tile: 16, or 8 in the eight-tiles-per-wave sweeps -- then a row of LPT NPL doubles is LPT cells per state pair)
+template <int NPL, int LPT = 16> __device__ __forceinline__ int ev_slot(int k) { return 2 * (LPT * ((k % NPL) >> 1) + k / NPL) + (k & 1); } // index of state k in its row
+template <int NPL, int LPT = 16> __device__ __forceinline__ void ev_load(const double *row, int k0, double (&v)[NPL]) {
 	const d2v_t *c = reinterpret_cast<const d2v_t *>(row) + k0 / NPL;
 #pragma unroll
-	for (int p = 0; p < NPL / 2; ++p) { const d2v_t t = c[16 * p]; v[2 * p] = t.x; v[2 * p + 1] = t.y; }
+	for (int p = 0; p < NPL / 2; ++p) { const d2v_t t = c[LPT * p]; v[2 * p] = t.x; v[2 * p + 1] = t.y; }
 }
 #endif
 __device__ __forceinline__ void load4(const double *p, double (&v)[4]) { loadN<4>(p, v); }

@@ -359,7 +359,9 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
                                   dict(chunk=1000, warmup=100, **GENOME), dict(chunk=256, warmup=512, runs_late=0, **GENOME),
                                   dict(chunk=768, warmup=64, runs_late=0, **GENOME),
                                   dict(chunk=256, warmup=512, coarse=2), dict(chunk=256, warmup=64, coarse=3), dict(chunk=1000, warmup=100, coarse=2, merge1=0), dict(chunk=768, warmup=64, coarse=4, learn=0),
-                                  dict(chunk=256, warmup=512, coarse=2, **GENOME), dict(chunk=1000, warmup=100, coarse=2, overlap=0)])
+                                  dict(chunk=256, warmup=512, coarse=2, **GENOME), dict(chunk=1000, warmup=100, coarse=2, overlap=0),
+                                  dict(lanes8=1), dict(chunk=256, warmup=512, lanes8=1), dict(chunk=1000, warmup=100, lanes8=1, **GENOME), dict(chunk=256, warmup=64, lanes8=1, coarse=2),
+                                  dict(chunk=768, warmup=64, lanes8=1, merge1=0)])
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_fast_fused_backward_counts(hip, golden, oracle, opts, fuse):
     """fuse=1 (default): the wave that walks four tiles backwards feeds bt straight into the f64 matrix cores (bt is
@@ -419,7 +421,8 @@ def test_fast_n128(hip, golden, oracle, opts):
                                   dict(chunk=64, warmup=0, fuse=0), dict(chunk=64, warmup=0), dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=5000, warmup=16, overlap=0),
                                   dict(chunk=100, warmup=30, two_phase=2), dict(chunk=37, warmup=5, group_cap=3000, **GENOME), dict(chunk=64, warmup=0, warm_shift=1),
                                   dict(chunk=64, warmup=0, two_phase=2), dict(chunk=100, warmup=30, coarse=2), dict(chunk=37, warmup=5, group_cap=3000, coarse=3),
-                                  dict(chunk=64, warmup=0, coarse=2), dict(chunk=100, warmup=30, coarse=2, **GENOME)])
+                                  dict(chunk=64, warmup=0, coarse=2), dict(chunk=100, warmup=30, coarse=2, **GENOME),
+                                  dict(chunk=100, warmup=30, lanes8=1), dict(chunk=37, warmup=5, group_cap=3000, lanes8=1, **GENOME), dict(chunk=64, warmup=0, lanes8=1, coarse=3)])
 def test_fast_odd_tilings(hip, golden, oracle, opts):
     """Tile lengths that are not multiples of the 16-bin blocks, tiles shorter than a block, no warm-up at all:
     everything is repaired / learned into runs and stays inside the tolerance."""
@@ -441,7 +444,8 @@ def tri_sums(A):
 
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
                                   dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, **GENOME), dict(GENOME), dict(chunk=1001, warmup=100, merge1=0), dict(chunk=264, warmup=300, warm_shift=1),
-                                  dict(chunk=256, warmup=512, coarse=2), dict(chunk=1001, warmup=100, coarse=3), dict(chunk=264, warmup=64, coarse=2, merge1=0), dict(chunk=256, warmup=512, coarse=2, ckpt=0, **GENOME)])
+                                  dict(chunk=256, warmup=512, coarse=2), dict(chunk=1001, warmup=100, coarse=3), dict(chunk=264, warmup=64, coarse=2, merge1=0), dict(chunk=256, warmup=512, coarse=2, ckpt=0, **GENOME),
+                                  dict(lanes8=1), dict(chunk=264, warmup=300, lanes8=1), dict(chunk=256, warmup=512, lanes8=1, coarse=2), dict(chunk=1001, warmup=100, lanes8=1, **GENOME)])
 def test_fast_factored_statistics(hip, golden, oracle, opts):
     """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
     (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset.
@@ -732,7 +736,8 @@ def test_fast_stress_tiny_tiles_recycled_memory(hip, golden, oracle):
     want = tri_sums(o["A"])
     opts_list = [dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, merge1=0), dict(chunk=64, warmup=0),
                  dict(chunk=64, warmup=0, **GENOME), dict(chunk=100, warmup=30, **GENOME), dict(chunk=37, warmup=5, group_cap=3000, two_phase=2),
-                 dict(chunk=100, warmup=30, coarse=2), dict(chunk=64, warmup=0, coarse=3), dict(chunk=37, warmup=5, group_cap=3000, coarse=2, **GENOME)]
+                 dict(chunk=100, warmup=30, coarse=2), dict(chunk=64, warmup=0, coarse=3), dict(chunk=37, warmup=5, group_cap=3000, coarse=2, **GENOME),
+                 dict(chunk=100, warmup=30, lanes8=1), dict(chunk=64, warmup=0, lanes8=1, **GENOME)]
     rng = random.Random(7)
     bad = []
     for rep in range(12):

@@ -608,7 +608,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	const bool lw = p.structured && (p.n_long_f > 0 || p.n_long_b > 0) && (ov || p.fused);
 	const bool lf = lw && p.n_long_f > 0, lb = lw && p.n_long_b > 0;
 	const int ff0 = lf ? p.n_long_f : 0, fb0 = lb ? p.n_long_b : 0;
-	// Shard-sized inputs ("merge1", api.hip plan_fast): the bulk forward sweep and the backward warm-up pass are ONE grid
+	// Shard-sized inputs ("merge1", api_fast.hip plan_fast): the bulk forward sweep and the backward warm-up pass are ONE grid
 	// (k_sweep_struct), so that the dispatcher puts their waves on distinct SIMDs.  The backward chain's stream is then
 	// idle during phase 1 and carries the whole dependent chain walks -> transfer-matrix chain -> run tiles -> back half ->
 	// verify: every hand-over between streams costs 50-70 us (rocprofv3 timelines, profiles/r03_shard_timeline_*.txt),

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void k_bwd_count8x_struct(const double *__r
 	}
 }
 
-// list 0 / 1: tile list A / B of the plan (api.hip build_items);  redo: only the groups a repair touched
+// list 0 / 1: tile list A / B of the plan (api_fast.hip build_items);  redo: only the groups a repair touched
 void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo, bool all_from_bentry)
 {
 	const int G = p.count_group; // tiles per work-group / per C partial: 4, or 16 (k_bwd_count8x_struct)

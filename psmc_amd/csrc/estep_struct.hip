@@ -133,7 +133,7 @@ void launch_gate(hipStream_t st, const int *ctr, int want)
 }
 
 // A sweep ITEM is a run of `count` consecutive tiles of one segment that one row walks through in
-// sequence (count == 1 unless the host glued tiles: see api.hip learn_groups -- where the chain forgets
+// sequence (count == 1 unless the host glued tiles: see api_fast.hip learn_groups -- where the chain forgets
 // slowly a speculative start is wrong and the repair rounds would walk the region tile by tile anyway;
 // gluing lets one row do that walk while the rest of the sweep is still running).  All tiles of an item
 // but the last are T positions long.
@@ -144,7 +144,7 @@ constexpr int SWEEP_NO_TOUCH = 8;   // REPAIR kernels: do not flag the tile for 
 constexpr int SWEEP_FROM_ENTRY = 2; // REPAIR kernels: start from the boundary vector a walk left instead of the neighbour's table row
 constexpr int SWEEP_MERGED = 64;    // backward blocks of the list-order merged phase-1 grid
 constexpr int SWEEP_ALTERNATE = 32; // k_sweep_struct: even blocks forward, odd blocks backward (default: list order)
-constexpr int SWEEP_COARSE = 128;   // bulk items may span several tiles (api.hip build_items, "coarse"): they are not the few latency-critical runs
+constexpr int SWEEP_COARSE = 128;   // bulk items may span several tiles (api_fast.hip build_items, "coarse"): they are not the few latency-critical runs
 constexpr int SWEEP_CKPT = 16;     // forward: store X only at the positions p % 8 == 0 (and the item's last one): the
                                    // factored counts recompute the rest from these checkpoints (estep_factored.hip)
 
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(64 * (PER == 1 ? 2 : 8)) void k_kchain_struct(const
 }
 
 // The bulk of both sweeps in ONE grid (block order: see the kernel).  Two uses.  (1) The unfused back half (flags 0 / 0): both table writers share the chip from the first
-// to the last wave.  (2) Phase 1 of the fused / factored E-step of a SHARD-SIZED input ("merge1", api.hip plan_fast):
+// to the last wave.  (2) Phase 1 of the fused / factored E-step of a SHARD-SIZED input ("merge1", api_fast.hip plan_fast):
 // the forward sweep (flags_f: SWEEP_CKPT or 0) and the warm-up-only backward pass (flags_b = SWEEP_TOP_ONLY).  Such an
 // E-step has fewer waves than the device has SIMDs (1024), and the dispatcher places the waves of ONE grid on distinct
 // SIMDs but knows nothing about the grids of other streams: two launches of 512 waves side by side leave 268 SIMDs
@@ -1024,7 +1024,7 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 	const bool l8 = p.lanes8 && p.ns == 64 && top_only; // phase 1 of the fused / factored plans (see launch_fwd_struct)
 	const int nblk = l8 ? (nf + 7) / 8 + (nb + 7) / 8 : (nf + 3) / 4 + (nb + 3) / 4;
 	if (nblk <= 0) return;
-	const int co = top_only && p.coarse > 1 ? SWEEP_COARSE : 0; // coarse items: the fused / factored plans only (api.hip enqueue_fast)
+	const int co = top_only && p.coarse > 1 ? SWEEP_COARSE : 0; // coarse items: the fused / factored plans only (api_fast.hip enqueue_fast)
 	const int flags_f = (p.ckpt ? SWEEP_CKPT : 0) | co,
 	          flags_b = (top_only ? (co ? SWEEP_WALK | co : SWEEP_TOP_ONLY) : 0) | (top_only && p.merge_order ? SWEEP_MERGED : SWEEP_ALTERNATE);
 #define PSMC_LS(NPL, CK) hipLaunchKernelGGL((k_sweep_struct<NPL, CK>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \

@@ -1,4 +1,4 @@
-// psmc_hip_internal.h -- shared between api.hip and the kernel translation units.
+// psmc_hip_internal.h -- shared between the api*.hip files (the C-ABI) and the kernel translation units.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +20,7 @@ struct Chunk {
 	int32_t hi;   // last position owned by the tile
 	int32_t mult; // how many times the segment occurs in the selection (bootstrap)
 	int32_t flags; // CHUNK_*
-	int32_t wf, wb; // structured sweeps: the tile's own speculative warm-up in bins, forward / backward (api.hip learn_groups:
+	int32_t wf, wb; // structured sweeps: the tile's own speculative warm-up in bins, forward / backward (api_fast.hip learn_groups:
 	                // starts at the "warmup" option and grows after a failure)
 };
 __host__ __device__ inline int chunk_warm_f(const Chunk &c, int) { return c.wf; }
@@ -66,7 +66,7 @@ struct EstepLaunch {
 	int ckpt;            // fused == 2: the forward sweep stores X at p % 8 == 0 only, the counts recompute the rest
 	int merge_order;     // merged phase-1 grid: 1 = all forward blocks, then all backward blocks; 0 = alternating
 	int merge1;          // fused != 0: bulk forward sweep and backward warm-up pass in ONE grid (k_sweep_struct) -- the dispatcher spreads
-	                     // the waves of one grid over distinct SIMDs, not those of concurrent grids (shard-sized inputs: api.hip plan_fast)
+	                     // the waves of one grid over distinct SIMDs, not those of concurrent grids (shard-sized inputs: api_fast.hip plan_fast)
 	const int *d_items_f, *d_items_b; // [n_items_*][2] sweep items (first tile, count) in launch order (estep_struct.hip)
 	int n_items_f, n_items_b, tile_len;
 	int n_long_f, n_long_b;           // leading items that are glued runs: walked beside the bulk (stream4 / stream3)
@@ -76,7 +76,7 @@ struct EstepLaunch {
 	int *d_gate;                      // [0] walk blocks started, [1] bulk blocks started: the gates that order the DISPATCH of phase 1's grids (estep_struct.hip
 	                                  // k_gate); null: no gates
 	int coarse;                       // > 1: a bulk item spans up to this many tiles (one speculation per item; the backward pass of the fused /
-	                                  // factored plans WALKS its item and leaves every tile's start vector): api.hip build_items
+	                                  // factored plans WALKS its item and leaves every tile's start vector): api_fast.hip build_items
 	const int *d_singles_b; int n_singles_b; // coarse > 1, factored back half: every tile outside the backward runs as a one-tile item
 	int n_B_b;                        // trailing backward items of the two-phase plan: they start from the exit vector of the tile above (second list of the fused back half)
 	const int *d_ftiles; int n_list_a, n_list_b; // fused back half: tile lists A | B (each padded to a multiple of 4 with -1)

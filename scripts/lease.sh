@@ -78,6 +78,7 @@ print(hip.stream_probe(1 << 27))" > $R/gpurun_out/pmc/calib_$C.out 2> $R/gpurun_
   python scripts/prof_summary.py lease 30000001 | tail -30
   PROF_NAME=n128 PROF_STATES=128 PROF_CMD="python scripts/r03/n128_run.py" python scripts/prof_summary.py lease 30000001 | tail -20
   python scripts/sq_summary.py lease n64 | head -12; python scripts/sq_summary.py lease n128 | head -10
+  mkdir -p gpurun_out/summaries; cp profiles/lease_* profiles/pmc_traffic*.json gpurun_out/summaries/ 2>/dev/null   # only gpurun_out/ travels back
   find gpurun_out/pmc gpurun_out/prof -name "*.csv" -size +3M -delete
 }
 case "$task" in

@@ -62,7 +62,7 @@ if os.path.exists(os.path.join(pm, NAME + "_FETCH_SIZE_counter_collection.csv"))
     for k, d in sorted(res.items()):
         if not k.startswith('k_'): continue
         rd = d.get('FETCH_SIZE', {}); wr = d.get('WRITE_SIZE', {})
-        full = k in ('k_expect_mfma', 'k_bwd_count4f_struct', 'k_bwd_count8_struct', 'k_fwd_struct<speculate>', 'k_bwd_acc_struct', 'k_bwd_acc_ckpt', 'k_sweep_struct')  # several variants per E-step (side passes, redo): the full pass
+        full = k in ('k_expect_mfma', 'k_bwd_count4f_struct', 'k_bwd_count8_struct', 'k_bwd_count8x_struct', 'k_fwd_struct<speculate>', 'k_bwd_acc_struct', 'k_bwd_acc_ckpt', 'k_sweep_struct')  # several variants per E-step (side passes, redo): the full pass
         r_b = rd.get('max_bytes' if full else 'bytes_per_launch', 0.0); w_b = wr.get('max_bytes' if full else 'bytes_per_launch', 0.0)
         out['kernels'][k] = dict(launches=rd.get('launches', wr.get('launches')), read_bytes_per_launch=r_b, write_bytes_per_launch=w_b,
                                  hbm_bytes_per_launch=r_b + w_b, bytes_per_bin=(r_b + w_b) / bins)

@@ -907,9 +907,17 @@ def test_options_from_the_environment(hip, golden, oracle, monkeypatch):
     check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
     assert es.fast_diag()["merged_phase1"]
     es.close()
-    monkeypatch.setenv("PSMC_HIP_OPTIONS", "lanes8=1")   # removed in round 3
-    with pytest.raises(hip.HipError):
-        hip.HipEStep(64, mode=hip.MODE_FAST)
-    monkeypatch.setenv("PSMC_HIP_OPTIONS", "chunk")
-    with pytest.raises(hip.HipError):
-        hip.HipEStep(64, mode=hip.MODE_FAST)
+    for bad in ("walk_heads=1",      # removed in round 3
+                "chunk",             # no value
+                "chunk=abc",         # not a number must not pass for 0 ...
+                "kc_min=",           # ... nor an empty value
+                "chunk=512x"):       # ... nor trailing junk
+        monkeypatch.setenv("PSMC_HIP_OPTIONS", bad)
+        with pytest.raises(hip.HipError):
+            hip.HipEStep(64, mode=hip.MODE_FAST)
+    monkeypatch.setenv("PSMC_HIP_OPTIONS", "rccl=0,chunk=512")   # a group-level key is not a context's business: skipped, not an error
+    es = hip.HipEStep(64, mode=hip.MODE_FAST)
+    es.load_segments(golden.segs_mid)
+    check_fast(es.estep(p["a"], p["e"], p["a0"]), o)
+    assert es.fast_diag()["tile_len"] == 512
+    es.close()

@@ -115,8 +115,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  --- exact mode ---------------------------------------------------------------------------------------------------
  *  "rep_impl"      1        row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical)
  *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch group; 0 = what fits the free device memory
- *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1 (auto) = no f table -- the expect pass recomputes the forward sweep in its own
- *                           work-group (bit-identical), so a launch group holds twice the replicates; 0 = f and b tables, three kernels
+ *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1 = no f table -- the expect pass recomputes the forward sweep in its own
+ *                           work-group (bit-identical), so a launch group holds twice the replicates; 0 = f and b tables, three kernels.
+ *                           auto: 1 only when the tables of all replicates would not fit one launch group
  *
  * Removed in round 3 after losing their A/B (DESIGN.md section 3 keeps the measurements): "count_impl", "kc_warm",
  * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "lanes8", "exact_lds", and the value 1 of "two_phase". */

@@ -31,17 +31,32 @@ static int batch_selections(psmc_hip_ctx *c, int n_rep, const int32_t *sel_off, 
 // Table bins an exact batch may use: "batch_bins", or 0.9 of the device memory that is free or already in this context's tables.
 // (Round 3 took 0.9 of the free memory PLUS all of what the context held: the second call saw a larger capacity than the first,
 // re-planned its groups and re-allocated 250 GB of tables -- 8 s; profiles/r04_boot_breakdown.txt.)
-static bool batch_refwd(const psmc_hip_ctx *c) { return c->ns == 64 && c->exact_refwd != 0; } // k_expect_exact_rf: 64 states
-static int batch_capacity(psmc_hip_ctx *c, int64_t *cap)
+static int batch_capacity(psmc_hip_ctx *c, int64_t *cap, bool refwd)
 {
 	*cap = c->batch_bins;
 	if (*cap > 0) return 0;
 	size_t fr = 0, tot = 0;
 	HIPCHK(c, hipMemGetInfo(&fr, &tot));
-	const double S = (double)c->ns, per_bin = S * 8.0 * (batch_refwd(c) ? 1.0 : 2.0) + 8.0;
+	const double S = (double)c->ns, per_bin = S * 8.0 * (refwd ? 1.0 : 2.0) + 8.0;
 	const double held = (double)c->tab_bins * (S * 8.0 * ((c->have_b ? 1.0 : 0.0) + (c->d_f ? 1.0 : 0.0)) + 8.0 + (c->d_sb ? 8.0 : 0.0));
 	*cap = (int64_t)(((double)fr + held) * 0.9 / per_bin) - 256;
 	if (*cap < 1) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: no device memory left for tables");
+	return 0;
+}
+
+// Does this batch run without the f table (k_expect_exact_rf: 64 states)?  "exact_refwd" 1 / 0: yes / no.  Auto: only when the f and b
+// tables of all its replicates (need_bins; <= 0: unknown) would NOT fit one launch group -- the recompute pass runs at the forward
+// sweep's latency (0.83 instead of 0.45 us per bin of the longest segment), which pays when it halves the number of groups (100
+// replicates of a genome: 11.9 against 13.2 s per EM iteration) and costs when one group would have done (16 replicates: 2.4 against 1.9 s).
+static int batch_refwd(psmc_hip_ctx *c, int64_t need_bins, bool *refwd)
+{
+	*refwd = false;
+	if (c->ns != 64 || c->exact_refwd == 0) return 0;
+	if (c->exact_refwd == 1) { *refwd = true; return 0; }
+	int64_t cap_tab = 0;
+	int rc = batch_capacity(c, &cap_tab, false);
+	if (rc) return rc;
+	*refwd = need_bins <= 0 || need_bins > cap_tab;
 	return 0;
 }
 
@@ -52,9 +67,10 @@ extern "C" int psmc_hip_reserve_batch_tables(psmc_hip_ctx *c, int64_t max_bins)
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "reserve_batch_tables: no segments loaded");
 	int64_t cap = 0;
-	int rc = batch_capacity(c, &cap);
-	if (rc) return rc;
-	return ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !batch_refwd(c));
+	bool refwd = false;
+	int rc = batch_refwd(c, max_bins, &refwd);
+	if (rc || (rc = batch_capacity(c, &cap, refwd))) return rc;
+	return ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !refwd);
 }
 
 // Exact mode: the sweeps of ALL replicates of a group in one launch each (forward, backward, expect), replicate-major;
@@ -70,8 +86,10 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	int rc;
 	if ((rc = batch_selections(c, n_rep, sel_off, sel_idx, reps))) return rc;
 	// how many table bins fit (batch_capacity: the same answer in every call, whatever the context holds already)
-	int64_t cap = 0;
-	if ((rc = batch_capacity(c, &cap))) return rc;
+	int64_t cap = 0, all_bins = 0; // all_bins: what ONE group of all replicates would need
+	for (const RepSel &R : reps) all_bins += R.bins;
+	bool refwd = false;
+	if ((rc = batch_refwd(c, all_bins, &refwd)) || (rc = batch_capacity(c, &cap, refwd))) return rc;
 	size_t n_entries_all = 0;
 	for (const RepSel &R : reps) n_entries_all += R.work.size();
 	const int align = c->ns == 128 ? (n_entries_all <= 256 ? 1 : (n_entries_all <= 512 ? 2 : 4)) : 4; // sweeps per block sharing one parameter set in LDS
@@ -90,9 +108,8 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		// tables: for the largest group when the caller fixed "batch_bins"; else for everything that fits (or all replicates at once), ONCE -- a hipMalloc of
 		// 250 GB takes 4-6 s on this driver (it clears the memory: scripts/r04/malloc_probe.py), so the size must not depend on
 		// this call's groups, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
-		int64_t all_bins = 0; // what ONE group of all replicates would need: never allocate beyond it
-		for (const RepSel &R : reps) all_bins += R.bins;
-		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins)), !batch_refwd(c)))) return rc;
+		// (never beyond what one group of all replicates would need)
+		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins)), !refwd))) return rc;
 		if ((rc = ensure_seg_outputs(c, (int)worst_entries))) return rc;
 		if (c->bw_cap < worst_entries) {
 			if ((rc = dev_alloc(c, &c->d_bw_seg, worst_entries))) return rc;
@@ -128,7 +145,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		EstepLaunch p;
 		fill_common(c, p, c->stream, c->d_bpar);
 		p.d_work = c->d_bw_seg; p.n_work = nw; p.d_work_par = c->d_bw_par; p.d_work_tab = c->d_bw_tab; p.par_stride = (int64_t)PL; p.work_align = align;
-		p.exact_refwd = batch_refwd(c) ? 1 : 0;
+		p.exact_refwd = refwd ? 1 : 0;
 		p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
 		const double t_b = now();
 		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch)", hipGetLastError());

@@ -135,7 +135,8 @@ struct psmc_hip_ctx {
 	// batch (psmc_hip_estep_batch)
 	int64_t batch_bins = 0;            // "batch_bins": table bins per launch group of the exact batch (0 = from free memory)
 	int exact_refwd = -1;              // "exact_refwd": exact batch, 64 states: 1 = no f table, the expect pass recomputes the forward sweep (twice the replicates
-	                                   // per group at +0.4 us per bin of the longest segment); 0 = tables for f and b; -1 = 1
+	                                   // per group at +0.4 us per bin of the longest segment); 0 = tables for f and b; -1 = only when the tables of all
+	                                   // replicates do not fit one launch group (api_batch.hip batch_refwd)
 	int32_t *d_bw_seg = nullptr, *d_bw_par = nullptr; int64_t *d_bw_tab = nullptr; size_t bw_cap = 0; // work list of a group
 	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_par][PAR_LEN] parameter blocks of a group
 	int last_batch_groups = 0;

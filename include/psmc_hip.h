@@ -87,8 +87,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           tiles shorter than their warm-up (1 M .. 12 M bins), else 1
  *  "lanes8"        auto     64 states, fused / factored back half: 1 = the bulk sweeps of phase 1 run EIGHT tiles per wave (8 lanes x 8 states per
  *                           tile: a scan level less, ~13 instead of 17 vector instructions per tile-step, half as many waves); 0 = four.
- *                           auto: with the factored statistics (their forward sweep stores checkpoints only); the full-count E-step,
- *                           whose forward sweep is paced by its table stores, is slower with it
+ *                           auto: with the factored statistics of a genome-sized input (their forward sweep stores checkpoints only, three
+ *                           waves per SIMD: issue-bound); slower for the full-count E-step (forward sweep paced by its table stores) and for
+ *                           shard-sized inputs (one wave per SIMD: the 8 x 8 step is a third longer)
  *  "gate"          auto     1: one-wave gate kernels order the DISPATCH of phase 1's grids across streams -- walks, then the bulk
  *                           grid, then the transfer matrices -- so that every walk gets a SIMD slot of its own (they give up after
  *                           ~200 us); 0: whatever order the queues come up in.  auto: with coarse items

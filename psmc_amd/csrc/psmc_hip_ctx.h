@@ -45,7 +45,7 @@ struct psmc_hip_ctx {
 	int merge_order = -1;      // "merge_order": block order of that grid: 1 = forward blocks, then backward blocks; 0 = alternating (every XCD gets one
 	                           // direction); -1 = by the plan: 1 while a tile is shorter than its warm-up (measured: 3.75 M bins 3.00 vs 3.25 ms, 7.5 M equal, 15 M 7.9 vs 7.6)
 	int lanes8 = -1;           // "lanes8": 64 states, fused / factored plans: the bulk sweeps of phase 1 run eight tiles per wave (8 lanes x 8 states: a quarter
-	                           // fewer vector instructions per tile-step, half the waves).  -1 = with the factored statistics only -- measured (round 4, genome):
+	                           // fewer vector instructions per tile-step, half the waves).  -1 = with the factored statistics of a genome-sized input only (more than one round of tiles) -- measured (round 4, genome):
 	                           // factored 10.26 -> 9.91 ms; full counts 12.09 -> 12.73 (its forward sweep is paced by 15.6 GB of stores and half as many waves hide less)
 	int gate = -1;             // "gate": order the dispatch of phase 1's grids walks -> bulk -> transfer matrices (estep_struct.hip k_gate); -1 = with coarse
 	                           // items (measured: without them the bulk grid is the critical path and walks that land late, stacked on few SIMDs, slow fewer of its waves)

@@ -93,6 +93,11 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "gate"          auto     1: one-wave gate kernels order the DISPATCH of phase 1's grids across streams -- walks, then the bulk
  *                           grid, then the transfer matrices -- so that every walk gets a SIMD slot of its own (they give up after
  *                           ~200 us); 0: whatever order the queues come up in.  auto: with coarse items
+ *  "share_learn"   1        psmc_hip_estep_batch, fast mode: the replicates tile every segment with ONE tile length (the largest
+ *                           replicate's) and a replicate that plans starts from the glue flags and warm-ups its predecessors learned
+ *                           at the same (segment, tile) -- the slow regions belong to the data, so replicate 2..R skip most of the repair
+ *                           rounds of their first E-step; results then depend on the batch's call history (two contexts with the same
+ *                           history agree bit for bit).  0: every replicate plans and learns for itself
  *  --- glued runs ---------------------------------------------------------------------------------------------------
  *  "kc_min"        auto     runs of at least this many tiles get their boundary vectors from a chain of tile transfer
  *                           matrices instead of a walk; 0 = never.  auto (-1): 4 with 64 states (5 in the two-round plan), 8 with

@@ -93,6 +93,7 @@ static void destroy_kids(psmc_hip_ctx *c)
 {
 	for (psmc_hip_ctx *k : c->kids) psmc_hip_destroy(k);
 	c->kids.clear();
+	c->share_T = 0; // the shared learning goes with the plans it was made for
 }
 
 extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
@@ -162,6 +163,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "fuse128") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->fuse128 = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
+	else if (k == "share_learn") { c->share_learn = v != 0 ? 1 : 0; }
 	else if (k == "exact_refwd") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; }
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;

@@ -222,7 +222,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		psmc_hip_ctx *k = new (std::nothrow) psmc_hip_ctx();
 		if (!k) return nullptr;
 		k->n = c->n; k->ns = c->ns; k->device = c->device; k->mode = c->mode; k->parent = c;
-		k->chunk = c->chunk; k->warmup = c->warmup; k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
+		k->chunk = c->chunk > 0 ? c->chunk : c->share_T; k->warmup = c->warmup; // (share_T = 0 without "share_learn": its own tiling) k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles;
 		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
@@ -245,6 +245,29 @@ static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double 
                       const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
 {
 	const int n = c->n;
+	if (c->share_T == 0 && c->share_learn) {
+		// One tile length for every replicate (the largest one's: the others then have fewer tiles than a round holds), so that a tile
+		// is (segment, index) in all of them and what one replicate learns about the slow regions serves the next (psmc_hip_ctx.h)
+		int T = c->chunk;
+		if (T <= 0) {
+			std::vector<RepSel> reps;
+			int rc0 = batch_selections(c, n_rep, sel_off, sel_idx, reps);
+			if (rc0) return rc0;
+			int64_t most = 0; size_t nw = 1;
+			for (const RepSel &R : reps) {
+				int64_t bins = 0;
+				for (int32_t sg : R.work) bins += c->L[sg];
+				if (bins > most) { most = bins; nw = R.work.size(); }
+			}
+			T = auto_tile_len(c, most, nw, true);
+		}
+		c->share_T = T;
+		c->sh_glue_f.assign(c->n_seg, {}); c->sh_glue_b.assign(c->n_seg, {}); c->sh_wf.assign(c->n_seg, {}); c->sh_wb.assign(c->n_seg, {});
+		for (int sg = 0; sg < c->n_seg; ++sg) {
+			const size_t nt = ((size_t)c->L[sg] + T - 1) / T;
+			c->sh_glue_f[sg].assign(nt, 0); c->sh_glue_b[sg].assign(nt, 0); c->sh_wf[sg].assign(nt, c->warmup); c->sh_wb[sg].assign(nt, c->warmup);
+		}
+	}
 	for (int r = 0; r < n_rep; ++r) {
 		psmc_hip_ctx *k = batch_child(c, r);
 		if (!k) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: cannot create the replicate context");

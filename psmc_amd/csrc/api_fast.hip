@@ -25,6 +25,17 @@ int ensure_fast_buffers(psmc_hip_ctx *c)
 	return 0;
 }
 
+// the tile length the planner picks for `bins` bins in n_work segments (see plan_fast)
+int auto_tile_len(const psmc_hip_ctx *c, int64_t bins, size_t n_work, bool st)
+{
+	const int64_t ROUND1 = 4096;
+	int64_t want = st ? c->struct_tiles : c->target_waves; // about target_waves (dense: 1 tile per wave) or struct_tiles (4 per wave) tiles, never below 256 bins
+	if (st && !c->struct_tiles_set && bins < 2 * ROUND1 * (int64_t)std::max(c->warmup, 1))
+		want = std::max<int64_t>(ROUND1 - (int64_t)n_work, ROUND1 / 2); // every segment ends in a ragged tile: stay inside the round
+	const int T = (int)((bins + want - 1) / want);
+	return std::max(256, (T + 63) & ~63);
+}
+
 static int plan_fast(psmc_hip_ctx *c)
 {
 	int64_t bins = 0;
@@ -48,18 +59,12 @@ static int plan_fast(psmc_hip_ctx *c)
 	// walks, not by the bulk warm-ups alone.)
 	const int64_t ROUND1 = 4096;
 	bool one_round = false;
-	if (T <= 0) { // auto: about target_waves (dense: 1 tile per wave) or struct_tiles (4 per wave) tiles, never below 256 bins
-		int64_t want = st ? c->struct_tiles : c->target_waves;
-		if (st && !c->struct_tiles_set && bins < 2 * ROUND1 * (int64_t)std::max(c->warmup, 1)) {
-			want = std::max<int64_t>(ROUND1 - (int64_t)c->work.size(), ROUND1 / 2); // every segment ends in a ragged tile: stay inside the round
-		}
-		T = (int)((bins + want - 1) / want);
-		T = std::max(256, (T + 63) & ~63);
-	}
-	c->chunks.clear();
+	if (T <= 0) T = auto_tile_len(c, bins, c->work.size(), st);
+	c->chunks.clear(); c->chunk_seg.clear(); c->chunk_idx.clear();
 	for (size_t w = 0; w < c->work.size(); ++w) {
 		const int32_t s = c->work[w];
 		for (int32_t lo = 1; lo <= c->L[s]; lo += T) {
+			c->chunk_seg.push_back(s); c->chunk_idx.push_back((lo - 1) / T);
 			Chunk ch;
 			ch.off = c->off[s]; ch.L = c->L[s]; ch.lo = lo; ch.hi = std::min(c->L[s], lo + T - 1); ch.mult = c->mult[w];
 			ch.flags = 0; ch.wf = ch.wb = c->warmup;
@@ -90,7 +95,16 @@ static int plan_fast(psmc_hip_ctx *c)
 	c->kc_sub_used = c->kc_sub_set ? c->kc_sub : std::max(1, std::min(4, (int)((8 * (int64_t)T + T + c->warmup - 1) / std::max(T + c->warmup, 1))));
 	// the counts kernel splits a tile over n_sub waves: keep about the same number of partial blocks
 	c->n_sub_used = st ? (fused_counts(c) ? 1 : std::max(1, std::min(c->n_sub, (9216 + nc - 1) / std::max(nc, 1)))) : c->n_sub;
-	c->glue_f.assign(nc, 0); c->glue_b.assign(nc, 0); // a new tiling forgets what was learned
+	c->glue_f.assign(nc, 0); c->glue_b.assign(nc, 0); // a new tiling forgets what was learned ...
+	if (c->parent && c->parent->share_T == T && st) { // ... but a batch replicate starts from what its predecessors learned at the same tiles
+		const psmc_hip_ctx *P = c->parent;
+		for (int b = 0; b < nc; ++b) {
+			const int sg = c->chunk_seg[b], ix = c->chunk_idx[b];
+			if (sg >= (int)P->sh_glue_f.size() || ix >= (int)P->sh_glue_f[sg].size()) continue;
+			c->glue_f[b] = P->sh_glue_f[sg][ix]; c->glue_b[b] = P->sh_glue_b[sg][ix];
+			c->chunks[b].wf = std::max(c->chunks[b].wf, P->sh_wf[sg][ix]); c->chunks[b].wb = std::max(c->chunks[b].wb, P->sh_wb[sg][ix]);
+		}
+	}
 	c->items_dirty = true;
 	int rc;
 	if (nc > c->chunk_cap) {
@@ -347,6 +361,18 @@ static void learn_groups(psmc_hip_ctx *c)
 			else c->glue_b[b] = 1;
 			c->items_dirty = true;
 		}
+	if (c->parent && c->parent->share_T == c->chunk_used && (!c->flagged_f.empty() || !c->flagged_b.empty())) { // share it with the replicates that plan later
+		psmc_hip_ctx *P = c->parent;
+		auto put = [&](int b) {
+			if (b < 0 || b >= nc) return;
+			const int sg = c->chunk_seg[b], ix = c->chunk_idx[b];
+			if (sg >= (int)P->sh_glue_f.size() || ix >= (int)P->sh_glue_f[sg].size()) return;
+			P->sh_glue_f[sg][ix] |= c->glue_f[b]; P->sh_glue_b[sg][ix] |= c->glue_b[b];
+			P->sh_wf[sg][ix] = std::max(P->sh_wf[sg][ix], c->chunks[b].wf); P->sh_wb[sg][ix] = std::max(P->sh_wb[sg][ix], c->chunks[b].wb);
+		};
+		for (int b : c->flagged_f) put(b);
+		for (int b : c->flagged_b) put(b);
+	}
 }
 
 int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *d_out,

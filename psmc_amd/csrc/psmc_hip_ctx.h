@@ -145,6 +145,15 @@ struct psmc_hip_ctx {
 	// staging, observations and TABLES (they run one after the other)
 	psmc_hip_ctx *parent = nullptr;
 	std::vector<psmc_hip_ctx *> kids;
+	// ... and what the replicates of one parent have LEARNED is shared through the parent (round 4): they tile every segment with the
+	// same tile length share_T, so a tile is (segment, index) in all of them, and a replicate that plans starts from the glue flags and
+	// warm-ups its predecessors needed (the slow regions belong to the data: the first E-step of replicate 2..R no longer repeats the
+	// repair rounds of replicate 1).  Filled by learn_groups of the children, read by their plan_fast (api_fast.hip).
+	int share_learn = 1;       // "share_learn": 0 = every replicate of a fast batch learns for itself (and tiles its own selection)
+	int share_T = 0;
+	std::vector<std::vector<uint8_t>> sh_glue_f, sh_glue_b;   // [segment][tile index]
+	std::vector<std::vector<int32_t>> sh_wf, sh_wb;
+	std::vector<int32_t> chunk_seg, chunk_idx;                // of every tile of the current plan
 };
 
 inline int fail(psmc_hip_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -193,6 +202,7 @@ double host_lk(const double *s, int L);                                         
 int  ensure_seg_outputs(psmc_hip_ctx *c, int nw);                                                           // api.hip
 int  estep_exact(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *A, double *E, double *A0, double *LL, double *chk); // api.hip
 int  ensure_fast_buffers(psmc_hip_ctx *c);                                                                  // api_fast.hip
+int  auto_tile_len(const psmc_hip_ctx *c, int64_t bins, size_t n_work, bool structured);                    // api_fast.hip
 int  enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *d_out, hipStream_t st); // api_fast.hip
 int  read_warm(psmc_hip_ctx *c, hipStream_t st);                                                            // api_fast.hip
 int  estep_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *A, double *E, double *A0, double *LL, double *chk); // api_fast.hip

@@ -690,16 +690,33 @@ def test_exact_batch_n128(hip, golden, oracle):
         es.close()
 
 
-def test_fast_batch_keeps_a_plan_per_replicate(hip, golden, oracle):
-    """Fast mode: the replicates run back to back on per-replicate child contexts (own tiling of their selection, own
-    learned runs) sharing one set of tables.  Within tolerance of the oracle, and bit-identical to fresh contexts fed
-    the same call history; the repair rounds disappear from the second EM iteration on."""
+@pytest.mark.parametrize("share", [0, 1])
+def test_fast_batch_keeps_a_plan_per_replicate(hip, golden, oracle, share):
+    """Fast mode: the replicates run back to back on per-replicate child contexts (own learned runs) sharing one set of
+    tables.  Within tolerance of the oracle; the repair rounds disappear from the second EM iteration on.  share_learn=0: every
+    replicate tiles and learns for itself -- bit-identical to fresh contexts fed the same call history.  share_learn=1
+    (default, round 4): one tile length for all replicates, and a replicate that plans starts from what its predecessors
+    learned at the same (segment, tile): fewer repair rounds in the first iteration, results inside the same tolerance and
+    bit-identical between two batch contexts with the same history."""
     segs = golden.segs_mid
     params = _traj_params(4)
     sels = [[5, 4, 5, 3, 5], [0, 1, 2], [2, 2, 1, 0, 4], list(range(6))]
     opts = dict(chunk=768, warmup=256, group_cap=200000)
-    es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, share_learn=share, **opts)
     es.load_segments(segs)
+    if share:
+        es2 = hip.HipEStep(64, mode=hip.MODE_FAST, share_learn=1, **opts)
+        es2.load_segments(segs)
+        for it in range(3):
+            got = es.estep_batch(params, sels, want="both")
+            got2 = es2.estep_batch(params, sels, want="both")
+            assert bits_equal(got["A"], got2["A"]) and bits_equal(got["sums"], got2["sums"]) and bits_equal(got["LL"], got2["LL"])
+            for r, sel in enumerate(sels):
+                a, e, a0 = params[r]
+                o = oracle.estep(a, e, a0, [segs[i] for i in sel])
+                check_fast(dict(A=got["A"][r], E=got["E"][r], LL=got["LL"][r]), o)
+        es.close(); es2.close()
+        return
     fresh = []
     for sel in sels:
         f = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)

@@ -39,7 +39,10 @@ static int batch_capacity(psmc_hip_ctx *c, int64_t *cap, bool refwd)
 	HIPCHK(c, hipMemGetInfo(&fr, &tot));
 	const double S = (double)c->ns, per_bin = S * 8.0 * (refwd ? 1.0 : 2.0) + 8.0;
 	const double held = (double)c->tab_bins * (S * 8.0 * ((c->have_b ? 1.0 : 0.0) + (c->d_f ? 1.0 : 0.0)) + 8.0 + (c->d_sb ? 8.0 : 0.0));
-	*cap = (int64_t)(((double)fr + held) * 0.9 / per_bin) - 256;
+	// (the call-wide scale-factor table of a batch without the f table stays allocated between calls: count it as free, or the second
+	// call would see a smaller capacity than the first and cut other groups)
+	*cap = (int64_t)(((double)fr + held + (double)c->s_all_cap * 8.0) * 0.9 / per_bin) - 256;
+	if (refwd) *cap -= *cap / 64; // ... and leave room for it: 8 of every 520 bytes
 	if (*cap < 1) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: no device memory left for tables");
 	return 0;
 }
@@ -94,58 +97,85 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	for (const RepSel &R : reps) n_entries_all += R.work.size();
 	const int align = c->ns == 128 ? (n_entries_all <= 256 ? 1 : (n_entries_all <= 512 ? 2 : 4)) : 4; // sweeps per block sharing one parameter set in LDS
 	c->last_batch_groups = 0;
-	std::vector<int32_t> wseg, wpar; std::vector<int64_t> wtab; std::vector<int> first;
-	std::vector<double> hp, lk;
-	{ // the groups are known before the first launch: size the tables once for the largest of them (no re-allocation in the loop)
-		int64_t worst = 0; size_t worst_entries = 0; int worst_reps = 0;
+	// The work list of the whole call, replicate-major, every replicate padded to `align` entries: entry -> segment, replicate (= its
+	// parameter block), offset of its tables inside ITS launch group, offset of its scale factors in the call-wide s table.  Groups =
+	// as many consecutive replicates as fit the table memory: slices [g_first[g], g_first[g+1]) of that list.
+	std::vector<int32_t> wseg, wpar; std::vector<int64_t> wtab, wtab_s; std::vector<int> first(n_rep + 1, 0), g_rep;
+	std::vector<double> lk;
+	int64_t worst = 0; size_t worst_entries = 0;
+	{
+		int64_t s_run = 0;
 		for (int r0 = 0; r0 < n_rep;) {
 			if (reps[r0].bins > cap) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: the tables of one replicate do not fit the device memory (batch_bins)");
-			int r1 = r0; int64_t bins = 0; size_t ent = 0;
-			while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ent += (reps[r1].work.size() + align - 1) / align * align; ++r1; }
-			worst = std::max(worst, bins); worst_entries = std::max(worst_entries, ent); worst_reps = std::max(worst_reps, r1 - r0);
+			int r1 = r0; int64_t bins = 0;
+			while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ++r1; }
+			g_rep.push_back(r0);
+			int64_t run = 0; const size_t e0 = wseg.size();
+			for (int r = r0; r < r1; ++r) {
+				first[r] = (int)wseg.size();
+				for (int32_t sg : reps[r].work) { wseg.push_back(sg); wpar.push_back(r); wtab.push_back(run); wtab_s.push_back(s_run + run); run += ((int64_t)c->L[sg] + 63) & ~(int64_t)63; }
+				while (wseg.size() % align) { wseg.push_back(-1); wpar.push_back(r); wtab.push_back(0); wtab_s.push_back(0); }
+			}
+			s_run += run;
+			worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
 			r0 = r1;
 		}
-		// tables: for the largest group when the caller fixed "batch_bins"; else for everything that fits (or all replicates at once), ONCE -- a hipMalloc of
-		// 250 GB takes 4-6 s on this driver (it clears the memory: scripts/r04/malloc_probe.py), so the size must not depend on
-		// this call's groups, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
-		// (never beyond what one group of all replicates would need)
+		g_rep.push_back(n_rep); first[n_rep] = (int)wseg.size();
+	}
+	const int n_groups = (int)g_rep.size() - 1, n_all = (int)wseg.size();
+	// Without the f table the forward pass writes scale factors only (8 bytes per bin), so with several groups it runs ONCE over the
+	// replicates of ALL of them -- thousands of waves, issue-bound, instead of one latency-bound launch of ~1000 waves per group
+	// (100 replicates of a genome: 1.8 s against 4 x 0.9 s per EM iteration) -- into a call-wide s table (15 GB for 1.9 G bins).
+	const bool fwd_all = refwd && n_groups > 1;
+	{
+		// tables: for the largest group when the caller fixed "batch_bins"; else for everything that fits (or all replicates at once), ONCE -- a
+		// hipMalloc of 250 GB takes 4-6 s on this driver (it clears the memory: scripts/r04/malloc_probe.py), so the size must not depend
+		// on this call's groups, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
 		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins)), !refwd))) return rc;
 		if ((rc = ensure_seg_outputs(c, (int)worst_entries))) return rc;
-		if (c->bw_cap < worst_entries) {
-			if ((rc = dev_alloc(c, &c->d_bw_seg, worst_entries))) return rc;
-			if ((rc = dev_alloc(c, &c->d_bw_par, worst_entries))) return rc;
-			if ((rc = dev_alloc(c, &c->d_bw_tab, worst_entries))) return rc;
-			c->bw_cap = worst_entries;
+		if (c->bw_cap < (size_t)n_all) {
+			if ((rc = dev_alloc(c, &c->d_bw_seg, (size_t)n_all))) return rc;
+			if ((rc = dev_alloc(c, &c->d_bw_par, (size_t)n_all))) return rc;
+			if ((rc = dev_alloc(c, &c->d_bw_tab, (size_t)2 * n_all))) return rc; // tables | scale factors
+			c->bw_cap = (size_t)n_all;
 		}
-		if (c->bpar_cap < (size_t)worst_reps) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)worst_reps * PL))) return rc; c->bpar_cap = (size_t)worst_reps; }
+		if (c->bpar_cap < (size_t)n_rep) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)n_rep * PL))) return rc; c->bpar_cap = (size_t)n_rep; }
+		if (fwd_all && c->s_all_cap < (size_t)all_bins + 128) { if ((rc = dev_alloc(c, &c->d_s_all, (size_t)all_bins + 128))) return rc; c->s_all_cap = (size_t)all_bins + 128; }
 	}
 	static const bool dbg_t = getenv("PSMC_HIP_DEBUG_TIMES") != nullptr;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	for (int r0 = 0; r0 < n_rep;) {
-		const double t_a = now();
-		int r1 = r0; int64_t bins = 0;
-		while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ++r1; }
-		const int ng = r1 - r0;
-		wseg.clear(); wpar.clear(); wtab.clear(); first.assign(ng, 0);
-		int64_t run = 0;
-		for (int r = r0; r < r1; ++r) {
-			first[r - r0] = (int)wseg.size();
-			for (int32_t sg : reps[r].work) { wseg.push_back(sg); wpar.push_back(r - r0); wtab.push_back(run); run += ((int64_t)c->L[sg] + 63) & ~(int64_t)63; }
-			while (wseg.size() % align) { wseg.push_back(-1); wpar.push_back(r - r0); wtab.push_back(0); }
-		}
-		const int nw = (int)wseg.size();
-		hp.resize((size_t)ng * PL);
-		for (int r = r0; r < r1; ++r) (void)fill_params(c, a + (size_t)r * n * n, e + (size_t)r * 2 * n, a0 + (size_t)r * n, hp.data() + (size_t)(r - r0) * PL);
+	{
+		std::vector<double> hp((size_t)n_rep * PL);
+		for (int r = 0; r < n_rep; ++r) (void)fill_params(c, a + (size_t)r * n * n, e + (size_t)r * 2 * n, a0 + (size_t)r * n, hp.data() + (size_t)r * PL);
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		HIPCHK(c, hipMemcpy(c->d_bw_seg, wseg.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice));
-		HIPCHK(c, hipMemcpy(c->d_bw_par, wpar.data(), sizeof(int32_t) * nw, hipMemcpyHostToDevice));
-		HIPCHK(c, hipMemcpy(c->d_bw_tab, wtab.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_bw_seg, wseg.data(), sizeof(int32_t) * n_all, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_bw_par, wpar.data(), sizeof(int32_t) * n_all, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_bw_tab, wtab.data(), sizeof(int64_t) * n_all, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_bw_tab + n_all, wtab_s.data(), sizeof(int64_t) * n_all, hipMemcpyHostToDevice));
 		HIPCHK(c, hipMemcpy(c->d_bpar, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
-		c->tables_batch = true;
+	}
+	c->tables_batch = true;
+	double fwd_all_s = 0.0;
+	if (fwd_all) {
+		const double t0 = now();
 		EstepLaunch p;
 		fill_common(c, p, c->stream, c->d_bpar);
-		p.d_work = c->d_bw_seg; p.n_work = nw; p.d_work_par = c->d_bw_par; p.d_work_tab = c->d_bw_tab; p.par_stride = (int64_t)PL; p.work_align = align;
+		p.d_work = c->d_bw_seg; p.n_work = n_all; p.d_work_par = c->d_bw_par; p.d_work_tab = c->d_bw_tab + n_all; p.par_stride = (int64_t)PL; p.work_align = align;
+		p.exact_refwd = 1; p.exact_only = 1; p.d_s = c->d_s_all;
+		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch, forward pass of all replicates)", hipGetLastError());
+		if (dbg_t) { (void)hipStreamSynchronize(c->stream); fwd_all_s = now() - t0; }
+	}
+	for (int g = 0; g < n_groups; ++g) {
+		const double t_a = now();
+		const int r0 = g_rep[g], r1 = g_rep[g + 1], ng = r1 - r0, e0 = first[r0], nw = first[r1] - e0;
+		const int64_t s_base = fwd_all ? wtab_s[e0] : 0;
+		int64_t run = 0;
+		for (int i = e0; i < e0 + nw; ++i) if (wseg[i] >= 0) run = std::max(run, wtab[i] + (((int64_t)c->L[wseg[i]] + 63) & ~(int64_t)63));
+		EstepLaunch p;
+		fill_common(c, p, c->stream, c->d_bpar);
+		p.d_work = c->d_bw_seg + e0; p.n_work = nw; p.d_work_par = c->d_bw_par + e0; p.d_work_tab = c->d_bw_tab + e0; p.par_stride = (int64_t)PL; p.work_align = align;
 		p.exact_refwd = refwd ? 1 : 0;
+		if (fwd_all) { p.exact_only = 2; p.d_work_tab_s = c->d_bw_tab + n_all + e0; p.d_s = c->d_s_all; }
 		p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
 		const double t_b = now();
 		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch)", hipGetLastError());
@@ -154,7 +184,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		c->h_segA.resize((size_t)nw * S * S); c->h_segE.resize((size_t)nw * 3 * S); c->h_s.resize((size_t)run);
 		HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipMemcpyAsync(c->h_s.data(), c->d_s, sizeof(double) * (size_t)run, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->h_s.data(), (fwd_all ? c->d_s_all : c->d_s) + s_base, sizeof(double) * (size_t)run, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		const double t_d = now();
 		collect_timing(c);
@@ -163,13 +193,13 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		// hmm_lk of every (replicate, segment) entry: a running product over all of its bins with the platform log() -- 0.7 ns per bin,
 		// 0.36 s per group of 28 replicates on one core; the entries are independent, so host threads share them (each value is
 		// computed by one thread exactly as before: bit-identical)
-		std::vector<double> lk_all(wseg.size(), 0.0);
+		std::vector<double> lk_all((size_t)nw, 0.0);
 		{
 			const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 			std::atomic<size_t> next(0);
 			auto work = [&]() {
-				for (size_t i = next.fetch_add(1); i < wseg.size(); i = next.fetch_add(1))
-					if (wseg[i] >= 0) lk_all[i] = host_lk(&c->h_s[(size_t)wtab[i]], c->L[wseg[i]]);
+				for (size_t i = next.fetch_add(1); i < (size_t)nw; i = next.fetch_add(1))
+					if (wseg[e0 + i] >= 0) lk_all[i] = host_lk(&c->h_s[(size_t)wtab[e0 + i]], c->L[wseg[e0 + i]]);
 			};
 			std::vector<std::thread> th;
 			for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
@@ -178,7 +208,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		}
 		for (int r = r0; r < r1; ++r) {
 			const RepSel &R = reps[r];
-			const int f0 = first[r - r0];
+			const int f0 = first[r] - e0; // the replicate's first entry inside the group's launch
 			lk.resize(R.work.size());
 			for (size_t j = 0; j < R.work.size(); ++j) lk[j] = lk_all[(size_t)f0 + j];
 			std::fill(sA.begin(), sA.end(), 0.0); std::fill(sE.begin(), sE.end(), 0.0);
@@ -205,10 +235,10 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 					}
 			}
 		}
-		if (dbg_t) fprintf(stderr, "[psmc_hip] batch group %d: %d replicates, %d entries, %.1f M table bins | prepare %.3f s, kernels %.3f (fwd %.0f bwd %.0f expect %.0f ms), read-back %.3f, host sums %.3f\n",
-		                   c->last_batch_groups, ng, nw, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3], t_d - t_c, now() - t_d);
+		if (dbg_t) fprintf(stderr, "[psmc_hip] batch group %d: %d replicates, %d entries, %.1f M table bins | prepare %.3f s, kernels %.3f (fwd %.0f bwd %.0f expect %.0f ms%s), read-back %.3f, host sums %.3f\n",
+		                   c->last_batch_groups, ng, nw, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3],
+		                   fwd_all ? (g == 0 ? (std::string("; forward pass of all replicates ") + std::to_string(fwd_all_s) + " s").c_str() : "; fwd: see group 0") : "", t_d - t_c, now() - t_d);
 		++c->last_batch_groups;
-		r0 = r1;
 	}
 	return PSMC_HIP_OK;
 }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 #pragma unroll
 	for (int l = 0; l < 64; ++l) row0[l] = aeT[l * 64 + lane];
 	const uint8_t *o = obs + off;
-	const double *so = s + toff;
+	const double *so = s + (wl.tab_s ? wl.tab_s[w] : toff);
 	double *bo = b + toff * 64;
 
 	// b[L][k] = 1/s[L] (khmm.c:226)
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(192, 2) void k_expect_exact_rf(const double *__rest
 	}
 	// ---------------- consumers
 	const int cw = w - 1, k0 = 32 * cw, colc = lane; // rows k0 .. k0+31 of A, lane = column l
-	const double *bo = b + toff * 64, *so = s + toff;
+	const double *bo = b + toff * 64, *so = s + (wl.tab_s ? wl.tab_s[blockIdx.x] : toff);
 	double arow[32], acc[32];
 #pragma unroll
 	for (int j = 0; j < 32; ++j) { arow[j] = a[(k0 + j) * 64 + colc]; acc[j] = PSMC_TINY; } // khmm.c:305-306
@@ -716,7 +716,7 @@ template <int REP> static int launch_exact128_t(const EstepLaunch &p)
 	// (a batch list is padded per parameter set to p.work_align entries: that many waves per block at most)
 	const int wpb = p.work_align > 0 ? p.work_align : (p.n_work <= 256 ? 1 : (p.n_work <= 512 ? 2 : 4));
 	const int nb = (p.n_work + wpb - 1) / wpb;
-	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.n_work, p.par_stride};
+	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, nullptr, p.n_work, p.par_stride};
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
 	hipLaunchKernelGGL(k_fwd_exact128<REP>, dim3(nb), dim3(64 * wpb), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
 	                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
@@ -773,9 +773,10 @@ int launch_exact(const EstepLaunch &p)
 	if (p.n_work <= 0) return 0;
 	(void)hipGetLastError(); // the value returned below must be about THESE launches (polled events, elapsed-time queries leave errors behind)
 	if (p.ns == 128) return rep == 0 ? launch_exact128_t<0>(p) : launch_exact128_t<1>(p);
-	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.n_work, p.par_stride};
+	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.d_work_tab_s, p.n_work, p.par_stride};
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
-	if (p.exact_refwd) { // scale factors only
+	if (p.exact_only == 2) { /* the scale factors exist: the batch ran the forward pass of all its replicates at once */ }
+	else if (p.exact_refwd) { // scale factors only
 		if (rep == 0)
 			hipLaunchKernelGGL((k_fwd_exact<0, false>), dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
 			                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
@@ -789,6 +790,7 @@ int launch_exact(const EstepLaunch &p)
 		hipLaunchKernelGGL(k_fwd_exact<1>, dim3(p.n_work), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs,
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_f, p.d_s);
 	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
+	if (p.exact_only == 1) { if (p.ev[4]) hipEventRecord(p.ev[4], p.stream); return (int)hipGetLastError(); }
 	const int nb = (p.n_work + 3) / 4;
 	if (rep == 0)
 		hipLaunchKernelGGL(k_bwd_exact<0>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,

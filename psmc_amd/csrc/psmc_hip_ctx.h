@@ -138,7 +138,8 @@ struct psmc_hip_ctx {
 	                                   // per group at +0.4 us per bin of the longest segment); 0 = tables for f and b; -1 = only when the tables of all
 	                                   // replicates do not fit one launch group (api_batch.hip batch_refwd)
 	int32_t *d_bw_seg = nullptr, *d_bw_par = nullptr; int64_t *d_bw_tab = nullptr; size_t bw_cap = 0; // work list of a group
-	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_par][PAR_LEN] parameter blocks of a group
+	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_rep][PAR_LEN] parameter blocks of a batch call
+	double *d_s_all = nullptr; size_t s_all_cap = 0; // exact batch without the f table, several groups: the scale factors of ALL replicates (one forward pass)
 	int last_batch_groups = 0;
 	bool tables_batch = false;         // the tables hold the slots of a batch group, not the segments at their own offsets
 	// fast batch: one plan-holding child per replicate; children share the parent's streams, events, parameter

@@ -36,6 +36,8 @@ struct ExWork {
 	const int32_t *seg;  // [n] segment id; < 0: padding entry (keeps the entries of one parameter set block-aligned)
 	const int32_t *par;  // [n] parameter-set index, or nullptr: all 0
 	const int64_t *tab;  // [n] offset of the entry's f/b/s tables in bins, or nullptr: seg_off[seg]
+	const int64_t *tab_s; // [n] offset of the entry's scale factors when they live elsewhere (the exact batch's forward pass over ALL replicates
+	                      // at once, api_batch.hip), or nullptr: the same as its f/b tables
 	int n;
 	int64_t par_stride;  // doubles between consecutive parameter sets
 };
@@ -48,6 +50,8 @@ struct EstepLaunch {
 	hipEvent_t evx[14];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
 	int overlap;
 	int rep_impl, expect_impl, n_states;
+	const int64_t *d_work_tab_s; // ExWork::tab_s
+	int exact_only;              // exact batch: 1 = only the forward pass (scale factors), 2 = everything but the forward pass, 0 = all three
 	int exact_refwd;             // exact batch, 64 states: no f table -- the expect pass recomputes the forward sweep (estep_exact.hip k_expect_exact_rf)
 	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)
 	// parameters (padded to NS)

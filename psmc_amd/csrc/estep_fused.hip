@@ -86,7 +86,9 @@ __device__ __forceinline__ void count4f_step(const StructParN<NPLF> &sc, const d
 	for (int i = 0; i < NPLF; ++i) {
 		FA[i] = rho * X[i];
 		if (MASKED) FA[i] = active ? FA[i] : 0.0; // an idle row may hold anything
-		const double gk = FA[i] * y[i];
+		// (an idle row -- a tile that owns no transition, a padding entry -- may hold anything, NaN included: its start vector was never
+		// written.  0 x NaN is NaN, so the product is SELECTED away, not multiplied away; found with PSMC_HIP_POISON=1 in round 4.)
+		const double gk = MASKED ? (active ? FA[i] * y[i] : 0.0) : FA[i] * y[i];
 		S[0][i] = __builtin_fma(gk, mk.x, S[0][i]);
 		S[1][i] = __builtin_fma(gk, mk.y, S[1][i]);
 		FB[i] = MASKED ? (active ? x[i] : 0.0) : x[i];
@@ -281,7 +283,7 @@ __device__ __forceinline__ void count8_step(const StructParN<NPL8> &sc, const do
 		FA[j] = rho * Xq[j];
 		if (MASKED) FA[j] = active ? FA[j] : 0.0;
 		const double yq = q == 0 ? y[j] : (q == 1 ? y[2 + j] : (q == 2 ? y[4 + j] : y[6 + j])); // wave-uniform select
-		const double gk = FA[j] * yq;
+		const double gk = MASKED ? (active ? FA[j] * yq : 0.0) : FA[j] * yq; // selected, not multiplied away (count4f_step)
 		S[0][j] = __builtin_fma(gk, mk.x, S[0][j]);
 		S[1][j] = __builtin_fma(gk, mk.y, S[1][j]);
 	}
@@ -486,7 +488,7 @@ __device__ __forceinline__ void count8x_step(const d2v_t *lds_sc, const d2v_t *l
 	for (int i = 0; i < NPL8; ++i) {
 		FA[i] = rho * X[i];
 		if (MASKED) FA[i] = active ? FA[i] : 0.0; // an idle row may hold anything
-		const double gk = FA[i] * y[i];           // E[o_p][k] += rho X_p[k] y_p[k]
+		const double gk = MASKED ? (active ? FA[i] * y[i] : 0.0) : FA[i] * y[i]; // E[o_p][k] += rho X_p[k] y_p[k]; selected, not multiplied away (count4f_step)
 		S[0][i] = __builtin_fma(gk, mk.x, S[0][i]);
 		S[1][i] = __builtin_fma(gk, mk.y, S[1][i]);
 		FB[i] = MASKED ? (active ? x[i] : 0.0) : x[i];

@@ -4,6 +4,7 @@ the same seeded inputs.  Exact mode: bit for bit.  Fast mode: stated tolerances
 (statistics 1e-10 of the largest cell, LL 1e-12 relative)."""
 import os
 import subprocess
+import sys
 import numpy as np
 import pytest
 from conftest import bits_equal
@@ -904,6 +905,45 @@ def test_group_factored_few_states(hip, oracle, n):
     assert relmax(f["sums"], np.stack([lo.sum(1), up.sum(1), np.diag(o["A"]).copy(), lo.sum(0), up.sum(0)])) < FAST_TOL_STATS
     assert relmax(f["E"], o["E"]) < FAST_TOL_STATS and abs(f["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
     g.close()
+
+
+def test_fast_results_do_not_depend_on_unwritten_memory():
+    """PSMC_HIP_POISON=1 fills every device allocation with NaN before use (the variable is read once per process, hence the
+    child process).  Round 4 found with it that the fused back half multiplied the emission term of an idle row -- a tile
+    that holds only position L, a padding entry: its start vector is never written -- by a zero weight instead of selecting
+    it away: 0 x NaN reached E.  The tilings that showed it (tiles of 100 bins on segments whose last tile holds one
+    position) and the 128-state path, full counts and factored statistics, against the oracle."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import orc
+from psmc_amd import hip
+g = np.load(os.path.join(%r, "tests", "golden", "hmm_params.npz"))
+sm = np.load(os.path.join(%r, "tests", "golden", "segments_small.npz")); md = np.load(os.path.join(%r, "tests", "golden", "segments_mid.npz"))
+segs = [sm[k] for k in sorted(sm)] + [md[k] for k in sorted(md)][3:]
+def rel(x, y): return float(np.abs(np.asarray(x) - np.asarray(y)).max() / np.abs(np.asarray(y)).max())
+a, e, a0 = g["n64_curve.a"], g["n64_curve.e"], g["n64_curve.a0"]
+o = orc.Oracle().estep(a, e, a0, segs)
+for opts in (dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000), dict(chunk=100, warmup=30, coarse=2), dict(chunk=256, warmup=64, lanes8=1)):
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts); es.load_segments(segs)
+    for it in range(2):
+        r = es.estep(a, e, a0); f = es.estep_factored(a, e, a0)
+        assert np.isfinite(r["A"]).all() and np.isfinite(r["E"]).all() and np.isfinite(f["sums"]).all() and np.isfinite(f["E"]).all(), (opts, it)
+        assert rel(r["A"], o["A"]) < 1e-10 and rel(r["E"], o["E"]) < 1e-10 and rel(f["E"], o["E"]) < 1e-10 and abs(r["LL"] - o["LL"]) <= 1e-12 * abs(o["LL"]), (opts, it)
+    es.close()
+g8 = np.load(os.path.join(%r, "tests", "golden", "estep_n128.npz"))
+a, e, a0 = g8["n128_curve.a"], g8["n128_curve.e"], g8["n128_curve.a0"]
+o = orc.Oracle().estep(a, e, a0, segs)
+for opts in (dict(), dict(fuse128=1), dict(chunk=400, warmup=64)):
+    es = hip.HipEStep(128, mode=hip.MODE_FAST, **opts); es.load_segments(segs)
+    for it in range(2):
+        r = es.estep(a, e, a0)
+        assert np.isfinite(r["A"]).all() and np.isfinite(r["E"]).all() and rel(r["A"], o["A"]) < 1e-10 and rel(r["E"], o["E"]) < 1e-10, (opts, it)
+    es.close()
+print("poison ok")
+''' % ((ROOT,) * 6)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_POISON="1"), timeout=600)
+    assert r.returncode == 0 and "poison ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_options_from_the_environment(hip, golden, oracle, monkeypatch):

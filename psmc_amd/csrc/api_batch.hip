@@ -252,7 +252,8 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		psmc_hip_ctx *k = new (std::nothrow) psmc_hip_ctx();
 		if (!k) return nullptr;
 		k->n = c->n; k->ns = c->ns; k->device = c->device; k->mode = c->mode; k->parent = c;
-		k->chunk = c->chunk > 0 ? c->chunk : c->share_T; k->warmup = c->warmup; // (share_T = 0 without "share_learn": its own tiling) k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
+		k->chunk = c->chunk > 0 ? c->chunk : c->share_T; // (share_T = 0 without "share_learn": its own tiling)
+		k->warmup = c->warmup; k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles;
 		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 	for (int i = threadIdx.x; i < 2 * 4096; i += 256) lds_ae[i] = aeT[4096 + i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform: segment, length and the loop run on the scalar unit
 	if (w >= wl.n) return;
 	const int seg = wl.seg[w];
 	if (seg < 0) return; // padding entry of a batch
@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 			const double su = readlane_f64(sv, i);
 			double r[4];
 			rep_rows<REP>(x, r);
+			dpp_guard(r);
 			double tmp;
 			if (sym == 0) {
-				tmp = xdot64(r, row0);
+				tmp = xdot64_guarded(r, row0);
 			} else {
 				const double *t = lds_ae + (sym - 1) * 4096 + lane;
 				double acc = 0.0;
@@ -147,6 +148,63 @@ __global__ __launch_bounds__(256) void k_bwd_exact(const double *__restrict__ ae
 }
 
 // ---------------------------------------------------------------- expect
+// One position of hmm_expect for four rows k0..k0+3 of A in the lane's column: acc[j] += f[u][k0+j] * q[sym][j] * b[u+1][l]
+// (khmm.c:316, products left to right, then the sum).  `ft` holds sixteen f values -- four positions x four rows -- in the lanes
+// m = 4 (position) + j of EVERY 16-lane row, so each operand is one v_mov_b64_dpp instead of two v_readlane.  The whole position,
+// the three-way choice of the emission row included, is ONE asm block: a wave alone on its SIMD pays four cycles for every
+// instruction of any kind (wave_prims.h xdot16), and hipcc's lowering of the choice costs more than the sixteen instructions
+// it selects (flag registers for a uniform branch, a copy of the four sums per position).  Homozygous path: 19 instructions.
+#define PSMC_EXBODY(Q0, Q1, Q2, Q3, N0, N1, N2, N3)                                                       \
+	"v_mov_b64_dpp %4, %9 row_newbcast:" #N0 " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+	"v_mov_b64_dpp %5, %9 row_newbcast:" #N1 " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+	"v_mov_b64_dpp %6, %9 row_newbcast:" #N2 " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+	"v_mov_b64_dpp %7, %9 row_newbcast:" #N3 " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                \
+	"v_mul_f64 %4, %4, " Q0 "\n\tv_mul_f64 %5, %5, " Q1 "\n\tv_mul_f64 %6, %6, " Q2 "\n\tv_mul_f64 %7, %7, " Q3 "\n\t" \
+	"v_mul_f64 %4, %4, %10\n\tv_mul_f64 %5, %5, %10\n\tv_mul_f64 %6, %6, %10\n\tv_mul_f64 %7, %7, %10\n\t"        \
+	"v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %5\n\tv_add_f64 %2, %2, %6\n\tv_add_f64 %3, %3, %7\n\t"
+#define PSMC_EXPOS(N0, N1, N2, N3)                                                                          \
+	asm("v_readlane_b32 %8, %11, %12\n\t"                                                                   \
+	    "s_cmp_eq_u32 %8, 0\n\ts_cbranch_scc1 .Lex0_%=\n\t"                                                  \
+	    "s_cmp_eq_u32 %8, 1\n\ts_cbranch_scc1 .Lex1_%=\n\t"                                                  \
+	    PSMC_EXBODY("%21", "%22", "%23", "%24", N0, N1, N2, N3) "s_branch .Lexe_%=\n"                           \
+	    ".Lex1_%=:\n\t" PSMC_EXBODY("%17", "%18", "%19", "%20", N0, N1, N2, N3) "s_branch .Lexe_%=\n"          \
+	    ".Lex0_%=:\n\t" PSMC_EXBODY("%13", "%14", "%15", "%16", N0, N1, N2, N3)                                 \
+	    ".Lexe_%=:"                                                                                             \
+	    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(st) \
+	    : "v"(ft), "v"(bl), "v"(sv), "n"(T), "v"(q[0][0]), "v"(q[0][1]), "v"(q[0][2]), "v"(q[0][3]),    \
+	      "v"(q[1][0]), "v"(q[1][1]), "v"(q[1][2]), "v"(q[1][3]), "v"(q[2][0]), "v"(q[2][1]), "v"(q[2][2]), "v"(q[2][3]) \
+	    : "scc")
+template <int T>
+__device__ __forceinline__ void expect_pos4(double (&acc)[4], double ft, const double (&q)[3][4], double bl, int sv)
+{
+	double t0, t1, t2, t3; int st;
+	if constexpr ((T & 3) == 0) { PSMC_EXPOS(0, 1, 2, 3); }
+	else if constexpr ((T & 3) == 1) { PSMC_EXPOS(4, 5, 6, 7); }
+	else if constexpr ((T & 3) == 2) { PSMC_EXPOS(8, 9, 10, 11); }
+	else { PSMC_EXPOS(12, 13, 14, 15); }
+}
+
+// One position of the emission counts, lane = state: Ec[o_u][k] += f[u][k] * b[u][k] * s[u] (khmm.c:317); `ssv` holds sixteen
+// scale factors in the lanes 0..15 of every row, `sv` the sixteen symbols.  Same reasoning as expect_pos4: 8 instructions.
+template <int T>
+__device__ __forceinline__ void expect_posE(double &E0, double &E1, double &E2, double fu, double bu, double ssv, int sv)
+{
+	double t, u; int st;
+	asm("v_readlane_b32 %5, %9, %10\n\t"
+	    "v_mov_b64_dpp %3, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	    "v_mul_f64 %4, %6, %7\n\t"
+	    "v_mul_f64 %4, %4, %3\n\t"
+	    "s_cmp_eq_u32 %5, 0\n\ts_cbranch_scc1 .Lee0_%=\n\t"
+	    "s_cmp_eq_u32 %5, 1\n\ts_cbranch_scc1 .Lee1_%=\n\t"
+	    "v_add_f64 %2, %2, %4\n\ts_branch .Leee_%=\n"
+	    ".Lee1_%=:\n\tv_add_f64 %1, %1, %4\n\ts_branch .Leee_%=\n"
+	    ".Lee0_%=:\n\tv_add_f64 %0, %0, %4\n"
+	    ".Leee_%=:"
+	    : "+v"(E0), "+v"(E1), "+v"(E2), "=&v"(t), "=&v"(u), "=&s"(st)
+	    : "v"(fu), "v"(bu), "v"(ssv), "v"(sv), "n"(T)
+	    : "scc");
+}
+
 // khmm.c:297-324.  S = padded number of states (64 or 128), H = S/64 column halves.
 // grid = (n_work, (S/4)*H + H): the first (S/4)*H blocks accumulate rows 4g..4g+3 of
 // A for one segment (lane = column lane+64*half) in position order; the last H
@@ -198,8 +256,60 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 #pragma unroll
 			for (int t = 0; t < BLK; ++t) bn_[t] = bo[(int64_t)min(i0 + t + 1, L - 1) * S + col];
 		};
-		if (n > 0) load_blk(0, ft, bn, sv);
-		for (int i0 = 0; i0 < n; i0 += BLK) {
+		int i0 = 0;
+		if constexpr (S == 64) {
+			// full blocks of 32 positions, two register buffers filled alternately one block ahead (~1.3 us of work per block against
+			// the latency of the loads); no clamps, no per-position address arithmetic.  What is left goes through the generic loop below.
+			constexpr int B2 = 32;
+			if (n >= B2) {
+				const int fm = lane & 15;
+				const double *fq = fo + (int64_t)(fm >> 2) * 64 + k0 + (fm & 3); // chunk c of the block at i: fq[(i + 4c) * 64]
+				const double *bq = bo + 64 + col;                                 // b[i+1][l] = bq[i * 64]
+				double fA[8], bA[B2], fB[8], bB[B2]; int sA = 2, sB = 2;
+				typedef const double __attribute__((address_space(1))) *gptr_t;
+				auto load = [&](int i, double (&f_)[8], double (&b_)[B2], int &s_) {
+					const int64_t d = (int64_t)i * 64;
+#pragma unroll
+					for (int g = 0; g < 4; ++g) { // one address per eight rows, the rest in the instruction's offset field
+						const double *bg_ = bq + d + 8 * g * 64, *fg_ = fq + d + 8 * g * 64;
+						asm volatile("" : "+v"(bg_), "+v"(fg_));
+						const gptr_t bg = (gptr_t)bg_, fg = (gptr_t)fg_;
+#pragma unroll
+						for (int t = 0; t < 8; ++t) b_[8 * g + t] = bg[t * 64];
+						f_[2 * g] = fg[0]; f_[2 * g + 1] = fg[4 * 64];
+					}
+					{
+						typedef const uint8_t __attribute__((address_space(1))) *gbptr_t;
+						const uint8_t *yp_ = o + i + 1 + (lane & 31);
+						asm volatile("" : "+v"(yp_)); // (pinned like the rest: see the E part below)
+						s_ = *(gbptr_t)yp_;
+					}
+					asm volatile("" ::: "memory");  // all of a block's loads ahead of the other block's positions: they may not sink
+					__builtin_amdgcn_sched_barrier(0); // below something that might write memory, and the scheduler may not move them either
+				};
+#define PSMC_EXP1(T, F, B, SV) expect_pos4<T>(acc, F[(T) >> 2], q, B[T], SV);
+#define PSMC_EXP8(T, F, B, SV) PSMC_EXP1(T, F, B, SV) PSMC_EXP1(T + 1, F, B, SV) PSMC_EXP1(T + 2, F, B, SV) PSMC_EXP1(T + 3, F, B, SV) \
+	PSMC_EXP1(T + 4, F, B, SV) PSMC_EXP1(T + 5, F, B, SV) PSMC_EXP1(T + 6, F, B, SV) PSMC_EXP1(T + 7, F, B, SV)
+#define PSMC_EXP32(F, B, SV) PSMC_EXP8(0, F, B, SV) PSMC_EXP8(8, F, B, SV) PSMC_EXP8(16, F, B, SV) PSMC_EXP8(24, F, B, SV)
+				load(0, fA, bA, sA);
+				for (;;) { // the block in hand is full; the next one is fetched unconditionally (the last fetch repeats the block in
+				           // hand): a conditional fetch makes hipcc wait for every outstanding load before the first position
+					load(i0 + 2 * B2 <= n ? i0 + B2 : i0, fB, bB, sB);
+					PSMC_EXP32(fA, bA, sA)
+					i0 += B2;
+					if (i0 + B2 > n) break;
+					load(i0 + 2 * B2 <= n ? i0 + B2 : i0, fA, bA, sA);
+					PSMC_EXP32(fB, bB, sB)
+					i0 += B2;
+					if (i0 + B2 > n) break;
+				}
+#undef PSMC_EXP32
+#undef PSMC_EXP8
+#undef PSMC_EXP1
+			}
+		}
+		if (n > i0) load_blk(i0, ft, bn, sv);
+		for (; i0 < n; i0 += BLK) {
 			double ft2 = 0.0, bn2[BLK]; int sv2 = 2;
 			if (i0 + BLK < n) load_blk(i0 + BLK, ft2, bn2, sv2);
 			const int nb = min(BLK, n - i0);
@@ -241,8 +351,54 @@ __global__ __launch_bounds__(64) void k_expect_exact(const double *__restrict__ 
 				fu_[t] = fo[r]; bu_[t] = bo[r];
 			}
 		};
-		if (n > 0) load_blk(0, fu, bu, sv, symv);
-		for (int i0 = 0; i0 < n; i0 += BLK) {
+		int i0 = 0;
+		if constexpr (S == 64) { // full blocks of 16 positions, as in the A part above
+			if (n >= BLK) {
+				typedef const double __attribute__((address_space(1))) *gptr_t;
+				double fA[BLK], bA[BLK], fB[BLK], bB[BLK], ssA = 0.0, ssB = 0.0; int yA = 2, yB = 2;
+				auto load = [&](int i, double (&f_)[BLK], double (&b_)[BLK], double &ss_, int &y_) {
+					const int64_t d = (int64_t)i * 64 + col;
+#pragma unroll
+					for (int g = 0; g < 2; ++g) {
+						const double *fg_ = fo + d + 8 * g * 64, *bg_ = bo + d + 8 * g * 64;
+						asm volatile("" : "+v"(fg_), "+v"(bg_));
+						const gptr_t fg = (gptr_t)fg_, bg = (gptr_t)bg_;
+#pragma unroll
+						for (int t = 0; t < 8; ++t) { f_[8 * g + t] = fg[t * 64]; b_[8 * g + t] = bg[t * 64]; }
+					}
+					{ // (through pinned pointers as well: loads from a const __restrict__ argument are invariant to hipcc, which sinks them
+					  //  past the memory clobber into the block that uses them -- behind the other block's sixteen positions)
+						typedef const uint8_t __attribute__((address_space(1))) *gbptr_t;
+						const double *sp_ = so + i + (lane & 15); const uint8_t *yp_ = o + i + (lane & 15);
+						asm volatile("" : "+v"(sp_), "+v"(yp_));
+						ss_ = *(gptr_t)sp_; y_ = *(gbptr_t)yp_;
+					}
+					asm volatile("" ::: "memory");
+					__builtin_amdgcn_sched_barrier(0);
+				};
+#define PSMC_EE1(T, F, B, SS, Y) expect_posE<T>(E0, E1, E2, F[T], B[T], SS, Y);
+#define PSMC_EE16(F, B, SS, Y)                                                                                              \
+	PSMC_EE1(0, F, B, SS, Y) PSMC_EE1(1, F, B, SS, Y) PSMC_EE1(2, F, B, SS, Y) PSMC_EE1(3, F, B, SS, Y) PSMC_EE1(4, F, B, SS, Y)    \
+	PSMC_EE1(5, F, B, SS, Y) PSMC_EE1(6, F, B, SS, Y) PSMC_EE1(7, F, B, SS, Y) PSMC_EE1(8, F, B, SS, Y) PSMC_EE1(9, F, B, SS, Y)    \
+	PSMC_EE1(10, F, B, SS, Y) PSMC_EE1(11, F, B, SS, Y) PSMC_EE1(12, F, B, SS, Y) PSMC_EE1(13, F, B, SS, Y)                       \
+	PSMC_EE1(14, F, B, SS, Y) PSMC_EE1(15, F, B, SS, Y)
+				load(0, fA, bA, ssA, yA);
+				for (;;) {
+					load(i0 + 2 * BLK <= n ? i0 + BLK : i0, fB, bB, ssB, yB);
+					PSMC_EE16(fA, bA, ssA, yA)
+					i0 += BLK;
+					if (i0 + BLK > n) break;
+					load(i0 + 2 * BLK <= n ? i0 + BLK : i0, fA, bA, ssA, yA);
+					PSMC_EE16(fB, bB, ssB, yB)
+					i0 += BLK;
+					if (i0 + BLK > n) break;
+				}
+#undef PSMC_EE16
+#undef PSMC_EE1
+			}
+		}
+		if (n > i0) load_blk(i0, fu, bu, sv, symv);
+		for (; i0 < n; i0 += BLK) {
 			double fu2[BLK], bu2[BLK], sv2 = 0.0; int symv2 = 2;
 			if (i0 + BLK < n) load_blk(i0 + BLK, fu2, bu2, sv2, symv2);
 			const int nb = min(BLK, n - i0);
@@ -326,9 +482,12 @@ __global__ __launch_bounds__(192, 2) void k_expect_exact_rf(const double *__rest
 	// ---------------- consumers
 	const int cw = w - 1, k0 = 32 * cw, colc = lane; // rows k0 .. k0+31 of A, lane = column l
 	const double *bo = b + toff * 64, *so = s + (wl.tab_s ? wl.tab_s[blockIdx.x] : toff);
-	double arow[32], acc[32];
+	// q0 = ae[0][k][l] = e[0][l] * a[k][l] with its one rounding (khmm.c:194-206), kept for the homozygous symbol -- nearly every
+	// position; the other two symbols form the product per position (e[2][l] = 1.0: the product IS a[k][l])
+	// (rows of `a` re-read from the cache there: 32 more registers would spill)
+	double q0[32], acc[32];
 #pragma unroll
-	for (int j = 0; j < 32; ++j) { arow[j] = a[(k0 + j) * 64 + colc]; acc[j] = PSMC_TINY; } // khmm.c:305-306
+	for (int j = 0; j < 32; ++j) { q0[j] = e0 * a[(k0 + j) * 64 + colc]; acc[j] = PSMC_TINY; } // khmm.c:305-306
 	double E0 = PSMC_TINY, E1 = PSMC_TINY, E2 = PSMC_TINY; // khmm.c:307-308 (wave 1 only)
 	double bprev = n > 0 ? bo[colc] : 0.0;                  // b[i] of the block's first position (E uses b[i], A uses b[i+1])
 	double bn[RB]; int sv = 2, sve = 2; double ssv = 0.0;
@@ -351,12 +510,21 @@ __global__ __launch_bounds__(192, 2) void k_expect_exact_rf(const double *__rest
 		for (int t = 0; t < RB; ++t) {
 			if (t < nb) {
 				const int sym = __builtin_amdgcn_readlane(sv, t);
-				const double es = pick_e(sym, e0, e1);      // e[o_{u+1}][l]
 				const double bl = bn[t];
+				if (sym == 0) {
 #pragma unroll
-				for (int j = 0; j < 32; ++j) {
-					const double q = es * arow[j];            // ae[o][k][l]: one rounding (khmm.c:194-206)
-					acc[j] += hf[t][k0 + j] * q * bl;         // khmm.c:316
+					for (int j = 0; j < 32; ++j) acc[j] += hf[t][k0 + j] * q0[j] * bl; // khmm.c:316
+				} else {
+					const double es = sym == 1 ? e1 : 1.0;    // e[o_{u+1}][l]
+					typedef const double __attribute__((address_space(1))) *gptr_t;
+					const double *ar_ = a + k0 * 64 + colc;
+					asm volatile("" : "+v"(ar_));             // loop invariant, but NOT to be hoisted into registers
+					const gptr_t ar = (gptr_t)ar_;
+#pragma unroll
+					for (int j = 0; j < 32; ++j) {
+						const double q = es * ar[j * 64];     // ae[o][k][l]: one rounding (khmm.c:194-206)
+						acc[j] += hf[t][k0 + j] * q * bl;
+					}
 				}
 				if (cw == 0) { // khmm.c:317: Ec[k] += f[u][k] * b[u][k] * s[u]
 					const int syme = __builtin_amdgcn_readlane(sve, t);
@@ -515,14 +683,19 @@ constexpr int S2 = 128;
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // strict left-to-right sum over states 0..127; ev/od: replicated forms of the even / odd states
-#define PSMC_SEQ2(N, B) s = s + bcast16<N>(ev[B]); s = s + bcast16<N>(od[B]);
-#define PSMC_SEQ2x16(B)                                                                         \
-	PSMC_SEQ2(0, B) PSMC_SEQ2(1, B) PSMC_SEQ2(2, B) PSMC_SEQ2(3, B) PSMC_SEQ2(4, B) PSMC_SEQ2(5, B)     \
-	PSMC_SEQ2(6, B) PSMC_SEQ2(7, B) PSMC_SEQ2(8, B) PSMC_SEQ2(9, B) PSMC_SEQ2(10, B) PSMC_SEQ2(11, B)   \
-	PSMC_SEQ2(12, B) PSMC_SEQ2(13, B) PSMC_SEQ2(14, B) PSMC_SEQ2(15, B)
-__device__ __forceinline__ double seq_sum_rep2(const double (&ev)[4], const double (&od)[4]) {
-	double s = 0.0;
-	PSMC_SEQ2x16(0) PSMC_SEQ2x16(1) PSMC_SEQ2x16(2) PSMC_SEQ2x16(3)
+#define PSMC_FB2(N) "v_fmac_f64_dpp %0, %1, %3 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"   \
+                    "v_fmac_f64_dpp %0, %2, %3 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void add_bcast16x2(double &s, double ev, double od, double one) { // states 32B .. 32B+31 in order
+	asm(PSMC_FB2(0) PSMC_FB2(1) PSMC_FB2(2) PSMC_FB2(3) PSMC_FB2(4) PSMC_FB2(5) PSMC_FB2(6) PSMC_FB2(7)
+	    PSMC_FB2(8) PSMC_FB2(9) PSMC_FB2(10) PSMC_FB2(11) PSMC_FB2(12) PSMC_FB2(13) PSMC_FB2(14) PSMC_FB2(15)
+	    : "+v"(s) : "v"(ev), "v"(od), "v"(one));
+}
+__device__ __forceinline__ double seq_sum_rep2(const double (&ev_)[4], const double (&od_)[4]) {
+	double ev[4] = {ev_[0], ev_[1], ev_[2], ev_[3]}, od[4] = {od_[0], od_[1], od_[2], od_[3]};
+	dpp_guard(ev); dpp_guard(od);
+	double s = 0.0, one = 1.0; // one instruction per term: s + x as fma(x, 1.0, s) (add_bcast, wave_prims.h)
+	add_bcast16x2(s, ev[0], od[0], one); add_bcast16x2(s, ev[1], od[1], one);
+	add_bcast16x2(s, ev[2], od[2], one); add_bcast16x2(s, ev[3], od[3], one);
 	return s;
 }
 
@@ -608,7 +781,7 @@ __global__ __launch_bounds__(256) void k_fwd_exact128(const double *__restrict__
 	for (int i = threadIdx.x; i < S2 * S2; i += blockDim.x) lds_m[i] = a[i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int w = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (w >= wl.n) return;
 	const int seg = wl.seg[w];
 	if (seg < 0) return; // padding entry of a batch
@@ -662,7 +835,7 @@ __global__ __launch_bounds__(256) void k_bwd_exact128(const double *__restrict__
 	for (int i = threadIdx.x; i < 3 * S2; i += blockDim.x) lds_m[S2 * S2 + i] = e[i];
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int w = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (w >= wl.n) return;
 	const int seg = wl.seg[w];
 	if (seg < 0) return; // padding entry of a batch

@@ -99,34 +99,64 @@ __device__ __forceinline__ double wave_sum_rep(const double (&r)[4]) {
 // Strict left-to-right sum x[0]+x[1]+...+x[63] starting from 0.0 (exact mode:
 // reproduces `for (k...) sum += v[k]` of the reference bit for bit); every
 // lane gets the total.
-#define PSMC_SEQ16(j)                                                              \
-	s = s + bcast16<0>(r[j]);  s = s + bcast16<1>(r[j]);  s = s + bcast16<2>(r[j]);  \
-	s = s + bcast16<3>(r[j]);  s = s + bcast16<4>(r[j]);  s = s + bcast16<5>(r[j]);  \
-	s = s + bcast16<6>(r[j]);  s = s + bcast16<7>(r[j]);  s = s + bcast16<8>(r[j]);  \
-	s = s + bcast16<9>(r[j]);  s = s + bcast16<10>(r[j]); s = s + bcast16<11>(r[j]); \
-	s = s + bcast16<12>(r[j]); s = s + bcast16<13>(r[j]); s = s + bcast16<14>(r[j]); \
-	s = s + bcast16<15>(r[j]);
+// One instruction per term: v_fmac_f64_dpp with the multiplier 1.0.  fma(x, 1.0, s) rounds the exact value x*1.0 + s = x + s
+// once -- it IS the IEEE sum s + x, bit for bit, for every input (the one place an fma appears in the exact kernels; the
+// products of the recursions keep their own rounding).  v_add_f64 has no DPP form on gfx950, so the alternative is a
+// v_mov_b64_dpp per term: 64 more vector instructions per position of a sweep that is bound by their issue.
+template <int N> __device__ __forceinline__ void add_bcast(double &s, double r, double one) {
+	asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+	    : "+v"(s) : "v"(r), "v"(one), "n"(N));
+}
+// the sixteen lanes of one row group in order, as ONE asm block (the compiler pads a wait state around every block)
+#define PSMC_FB(N) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void add_bcast16(double &s, double r, double one) {
+	asm(PSMC_FB(0) PSMC_FB(1) PSMC_FB(2) PSMC_FB(3) PSMC_FB(4) PSMC_FB(5) PSMC_FB(6) PSMC_FB(7)
+	    PSMC_FB(8) PSMC_FB(9) PSMC_FB(10) PSMC_FB(11) PSMC_FB(12) PSMC_FB(13) PSMC_FB(14) PSMC_FB(15)
+	    : "+v"(s) : "v"(r), "v"(one));
+}
+#define PSMC_SEQ16(R) add_bcast16(s, R, one);
 __device__ __forceinline__ double seq_sum_rep(const double (&r)[4]) {
-	double s = 0.0;
-	PSMC_SEQ16(0) PSMC_SEQ16(1) PSMC_SEQ16(2) PSMC_SEQ16(3)
+	double q[4] = {r[0], r[1], r[2], r[3]};
+	dpp_guard(q); // the asm below is invisible to the compiler's hazard padding (VALU write -> DPP read)
+	double s = 0.0, one = 1.0;
+	PSMC_SEQ16(q[0]) PSMC_SEQ16(q[1]) PSMC_SEQ16(q[2]) PSMC_SEQ16(q[3])
 	return s;
 }
 
 // exact-order dot product: ((x0*m0 + x1*m1) + x2*m2) + ... , products rounded
-// separately (file is compiled with -ffp-contract=off), first term 0.0 + p0.
-#define PSMC_XDOT16(R, M, O)                                                                  \
-	acc = acc + bcast16<0>(R) * M[(O) + 0];   acc = acc + bcast16<1>(R) * M[(O) + 1];   \
-	acc = acc + bcast16<2>(R) * M[(O) + 2];   acc = acc + bcast16<3>(R) * M[(O) + 3];   \
-	acc = acc + bcast16<4>(R) * M[(O) + 4];   acc = acc + bcast16<5>(R) * M[(O) + 5];   \
-	acc = acc + bcast16<6>(R) * M[(O) + 6];   acc = acc + bcast16<7>(R) * M[(O) + 7];   \
-	acc = acc + bcast16<8>(R) * M[(O) + 8];   acc = acc + bcast16<9>(R) * M[(O) + 9];   \
-	acc = acc + bcast16<10>(R) * M[(O) + 10]; acc = acc + bcast16<11>(R) * M[(O) + 11]; \
-	acc = acc + bcast16<12>(R) * M[(O) + 12]; acc = acc + bcast16<13>(R) * M[(O) + 13]; \
-	acc = acc + bcast16<14>(R) * M[(O) + 14]; acc = acc + bcast16<15>(R) * M[(O) + 15];
-__device__ __forceinline__ double xdot64(const double (&r)[4], const double (&m)[64]) {
+// separately (v_mul_f64 then v_add_f64, never an fma), first term 0.0 + p0.
+// Sixteen terms of one row group as ONE asm block: a wave alone on its SIMD issues one instruction of ANY kind every four
+// cycles, so the exact sweeps pay for every s_nop as for a multiply.  Left to itself hipcc funnels the sixteen broadcasts
+// through one temporary and pads a wait state before each (a DPP move reads its destination as `old`: VALU write -> DPP
+// read); here two temporaries alternate, so the register a v_mov_b64_dpp overwrites was written four instructions earlier.
+// Callers pass R through dpp_guard() after its last VALU write.
+#define PSMC_XD(N, T, M) "v_mov_b64_dpp " T ", %3 row_newbcast:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                         "v_mul_f64 " T ", " T ", " M "\n\t"                                                        \
+                         "v_add_f64 %0, %0, " T "\n\t"
+__device__ __forceinline__ void xdot16(double &acc, double R, double m0, double m1, double m2, double m3, double m4, double m5,
+                                       double m6, double m7, double m8, double m9, double m10, double m11, double m12,
+                                       double m13, double m14, double m15) {
+	double t0, t1;
+	asm(PSMC_XD(0, "%1", "%4") PSMC_XD(1, "%2", "%5") PSMC_XD(2, "%1", "%6") PSMC_XD(3, "%2", "%7")
+	    PSMC_XD(4, "%1", "%8") PSMC_XD(5, "%2", "%9") PSMC_XD(6, "%1", "%10") PSMC_XD(7, "%2", "%11")
+	    PSMC_XD(8, "%1", "%12") PSMC_XD(9, "%2", "%13") PSMC_XD(10, "%1", "%14") PSMC_XD(11, "%2", "%15")
+	    PSMC_XD(12, "%1", "%16") PSMC_XD(13, "%2", "%17") PSMC_XD(14, "%1", "%18") PSMC_XD(15, "%2", "%19")
+	    : "+v"(acc), "=&v"(t0), "=&v"(t1)
+	    : "v"(R), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7), "v"(m8), "v"(m9), "v"(m10), "v"(m11),
+	      "v"(m12), "v"(m13), "v"(m14), "v"(m15));
+}
+#define PSMC_XDOT16(R, M, O)                                                                                                   \
+	xdot16(acc, R, M[(O) + 0], M[(O) + 1], M[(O) + 2], M[(O) + 3], M[(O) + 4], M[(O) + 5], M[(O) + 6], M[(O) + 7], M[(O) + 8], \
+	       M[(O) + 9], M[(O) + 10], M[(O) + 11], M[(O) + 12], M[(O) + 13], M[(O) + 14], M[(O) + 15]);
+__device__ __forceinline__ double xdot64_guarded(const double (&q)[4], const double (&m)[64]) { // q has passed dpp_guard()
 	double acc = 0.0;
-	PSMC_XDOT16(r[0], m, 0) PSMC_XDOT16(r[1], m, 16) PSMC_XDOT16(r[2], m, 32) PSMC_XDOT16(r[3], m, 48)
+	PSMC_XDOT16(q[0], m, 0) PSMC_XDOT16(q[1], m, 16) PSMC_XDOT16(q[2], m, 32) PSMC_XDOT16(q[3], m, 48)
 	return acc;
+}
+__device__ __forceinline__ double xdot64(const double (&r)[4], const double (&m)[64]) {
+	double q[4] = {r[0], r[1], r[2], r[3]};
+	dpp_guard(q);
+	return xdot64_guarded(q, m);
 }
 
 // fast dot product: 4 independent FMA chains (one per row group) interleaved so

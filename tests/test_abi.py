@@ -50,8 +50,11 @@ def test_argument_validation(lib):
 
 
 def test_exact_kernels_have_no_fma():
-    """hipcc contracts a*b+c by default; the exact mode must never contain an FMA
-    outside the IEEE division expansion."""
+    """hipcc contracts a*b+c by default; the exact mode must never contain an FMA outside the IEEE division expansion
+     -- with ONE deliberate exception that is checked here operand by operand: the ordered sums
+    s = s + x_k are issued as v_fmac_f64_dpp s, x, ONE (wave_prims.h add_bcast), and fma(x, 1.0, s) is the IEEE sum bit
+    for bit.  Every such instruction must multiply by a register that the kernel loads with the constant 1.0 and never
+    writes otherwise."""
     out = "/tmp/psmc_exact_audit.s"
     src = os.path.join(ROOT, "psmc_amd", "csrc", "estep_exact.hip")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
@@ -59,11 +62,31 @@ def test_exact_kernels_have_no_fma():
                    check=True, stderr=subprocess.DEVNULL)
     txt = open(out).read()
     n_div = len(re.findall(r"v_div_fmas_f64", txt))
-    n_fma = len(re.findall(r"\bv_fma_f64|\bv_fmac_f64", txt))
+    n_fma = len(re.findall(r"\bv_fma_f64|\bv_fmac_f64(?!_dpp)", txt))
     assert n_div > 0
     # each IEEE f64 division expands to v_div_scale x2, v_rcp, 5-6 v_fma, v_div_fmas, v_div_fixup
     assert n_fma <= 7 * n_div, (n_fma, n_div)
     assert "v_mfma" not in txt and "v_pk_fma" not in txt
+    n_sum = 0
+    wr = re.compile(r"(?:v_|ds_|global_load|buffer_load|flat_load|scratch_load)\w*\s+(v\d+|v\[\d+:\d+\])")
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else {int(tok[1:])}
+    for fn in re.split(r"^\.Lfunc_end\d+:", txt, flags=re.M):
+        lines = [l.strip() for l in fn.split("\n")]
+        uses = [(i, re.match(r"v_fmac_f64_dpp (v\[\d+:\d+\]), (v\[\d+:\d+\]), (v\[\d+:\d+\])", l)) for i, l in enumerate(lines)]
+        uses = [(i, m.group(3)) for i, m in uses if m]
+        n_sum += len(uses)
+        for reg in set(r for _, r in uses):
+            first, last = min(i for i, r in uses if r == reg), max(i for i, r in uses if r == reg)
+            loads = [i for i, l in enumerate(lines) if l == "v_mov_b64_e32 %s, 1.0" % reg]
+            assert loads and min(loads) < first, (reg, "not loaded with 1.0 before its first use")
+            # from that load to the last sum that multiplies by it (text order covers the loops in between) nothing else writes the pair
+            for l in lines[min(loads) + 1:last]:
+                m = wr.match(l)
+                if m and not l.startswith("v_fmac_f64_dpp") and (regs(m.group(1)) & regs(reg)):
+                    assert l == "v_mov_b64_e32 %s, 1.0" % reg, (reg, l)
+    assert n_sum > 0 and n_sum % 16 == 0
 
 
 def test_every_option_is_documented():

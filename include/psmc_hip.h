@@ -119,11 +119,13 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "n_sub"         6        waves per tile in the separate counts kernel
  *  "expect_impl"   1        separate counts kernel: 1 v_mfma_f64_16x16x4, 0 vector instructions (cross-check)
  *  --- exact mode ---------------------------------------------------------------------------------------------------
- *  "rep_impl"      1        row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical)
+ *  "rep_impl"      auto     row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical); -1 = auto:
+ *                           0 when a launch has more than one wave per SIMD (bootstrap batch), else 1
  *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch group; 0 = what fits the free device memory
- *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1 = no f table -- the expect pass recomputes the forward sweep in its own
- *                           work-group (bit-identical), so a launch group holds twice the replicates; 0 = f and b tables, three kernels.
- *                           auto: 1 only when the tables of all replicates would not fit one launch group
+ *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1, 2 = no f table -- the expect pass recomputes the forward sweep in its own
+ *                           work-group (bit-identical), so a launch group holds twice the replicates; 2 = two entries per work-group
+ *                           (two producer waves, two consumer waves: four entries per compute unit), 1 = one; 0 = f and b tables,
+ *                           three kernels.  auto: 2, and only when the tables of all replicates would not fit one launch group
  *
  * Removed in round 3 after losing their A/B (DESIGN.md section 3 keeps the measurements): "count_impl", "kc_warm",
  * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "lanes8", "exact_lds", and the value 1 of "two_phase". */

@@ -164,11 +164,11 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
 	else if (k == "share_learn") { c->share_learn = v != 0 ? 1 : 0; }
-	else if (k == "exact_refwd") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; }
+	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; }
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
-	else if (k == "rep_impl") c->rep_impl = v != 0 ? 1 : 0;
+	else if (k == "rep_impl") c->rep_impl = v < 0 ? -1 : (v != 0 ? 1 : 0);
 	else if (k == "expect_impl") c->expect_impl = v != 0 ? 1 : 0;
 	else if (k == "n_sub") { if (v < 1 || v > 64) return PSMC_HIP_EINVAL; c->n_sub = (int)v; c->plan_dirty = true; }
 	else if (k == "target_waves") { if (v < 1) return PSMC_HIP_EINVAL; c->target_waves = (int)v; c->plan_dirty = true; }

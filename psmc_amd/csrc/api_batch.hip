@@ -55,7 +55,7 @@ static int batch_refwd(psmc_hip_ctx *c, int64_t need_bins, bool *refwd)
 {
 	*refwd = false;
 	if (c->ns != 64 || c->exact_refwd == 0) return 0;
-	if (c->exact_refwd == 1) { *refwd = true; return 0; }
+	if (c->exact_refwd >= 1) { *refwd = true; return 0; }
 	int64_t cap_tab = 0;
 	int rc = batch_capacity(c, &cap_tab, false);
 	if (rc) return rc;
@@ -174,7 +174,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		EstepLaunch p;
 		fill_common(c, p, c->stream, c->d_bpar);
 		p.d_work = c->d_bw_seg + e0; p.n_work = nw; p.d_work_par = c->d_bw_par + e0; p.d_work_tab = c->d_bw_tab + e0; p.par_stride = (int64_t)PL; p.work_align = align;
-		p.exact_refwd = refwd ? 1 : 0;
+		p.exact_refwd = refwd ? (c->exact_refwd == 1 ? 1 : 2) : 0; // 2: two entries per work-group (k_expect_exact_rf2), the default
 		if (fwd_all) { p.exact_only = 2; p.d_work_tab_s = c->d_bw_tab + n_all + e0; p.d_s = c->d_s_all; }
 		p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
 		const double t_b = now();

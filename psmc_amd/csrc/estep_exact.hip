@@ -546,6 +546,163 @@ __global__ __launch_bounds__(192, 2) void k_expect_exact_rf(const double *__rest
 	}
 }
 
+// Two entries per work-group (round 4, after the instruction trimming above).  With one entry per group of three waves a compute
+// unit holds two entries -- eight wave slots at 256 registers -- and the pass runs at 512 entries x one producer step per ~1 us
+// with the vector pipes half idle: a consumer wave needs ~110 vector instructions per position, the producer ~280.  Here a group
+// is TWO producers (entries 2b, 2b+1 of the list: same replicate, same parameters -- the batch pads every replicate to four
+// entries) and two consumers that serve both, entry after entry out of a ring per entry: wave 2 rows 0..31 of A, wave 3 rows
+// 32..63.  The emission counts and A0 moved to the producers (lane = state there, and the wave has f[u][k] and s[u] in hand).
+// Four entries per compute unit, every SIMD a producer and a consumer: the pass becomes bound by the vector pipe.
+// Same instructions in the same order per entry as k_expect_exact_rf: bit-identical.
+template <int REP>
+__global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__restrict__ a, const double *__restrict__ e,
+                                                           const double *__restrict__ a0, const uint8_t *__restrict__ obs,
+                                                           const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
+                                                           const ExWork wl, const double *__restrict__ b, const double *__restrict__ s,
+                                                           double *__restrict__ segA, double *__restrict__ segE, double *__restrict__ segA0)
+{
+	constexpr int RB = 16, CB = 4; // positions per ring half; b rows a consumer fetches at a time
+	__shared__ double ring[2][2][RB][64]; // [entry][half][position][state]
+	const int lane = threadIdx.x & 63;
+	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int ent = 2 * (int)blockIdx.x;
+	{ const int64_t po = wl.par ? wl.par[ent] * wl.par_stride : 0; a += po; e += po; a0 += po; }
+	// segment of the two entries (-1: padding / past the list) and their positions u = 1 .. L-1 (index i = u-1 = 0 .. n-1)
+	const int sg0 = wl.seg[ent], sg1 = ent + 1 < wl.n ? wl.seg[ent + 1] : -1;
+	const int n0 = sg0 >= 0 ? seg_len[sg0] - 1 : -1, n1 = sg1 >= 0 ? seg_len[sg1] - 1 : -1;
+	const int P = (max(max(n0, n1), 0) + RB - 1) / RB; // phases: every wave passes exactly P barriers
+	const double e0 = e[lane], e1 = e[64 + lane];
+	if (w < 2) { // ---------------- producer of entry w: k_fwd_exact, position by position (khmm.c:171-185), + E and A0 of the entry
+		const int sg = w == 0 ? sg0 : sg1, n = w == 0 ? n0 : n1, L = n + 1;
+		const int64_t off = sg >= 0 ? seg_off[sg] : 0, toff = sg >= 0 && wl.tab ? wl.tab[ent + w] : off;
+		const uint8_t *o = obs + off;
+		const double *bo = b + toff * 64 + lane, *so = s + (sg >= 0 && wl.tab_s ? wl.tab_s[ent + w] : toff);
+		double col[64];
+#pragma unroll
+		for (int l = 0; l < 64; ++l) col[l] = a[l * 64 + lane];
+		double x = 0.0, E0 = PSMC_TINY, E1 = PSMC_TINY, E2 = PSMC_TINY; // khmm.c:307-308
+		int symn = n > 0 ? (int)o[lane & 15] : 2; // symbols of the positions of phase 0 (obs is padded by >= 64 bytes)
+		for (int ph = 0; ph < P; ++ph) {
+			const int i0 = ph * RB, nb = min(RB, n - i0);
+			const int symv = symn;
+			double bq[RB], ssv = 0.0; // b[u][k] and s[u] of this phase's positions: fetched now, used after the last of them
+			if (nb > 0) {
+#pragma unroll
+				for (int t = 0; t < RB; ++t) bq[t] = bo[(int64_t)min(i0 + t, L - 1) * 64];
+				ssv = so[min(i0 + (lane & 15), L - 1)];
+				if (i0 + RB < n) symn = (int)o[i0 + RB + (lane & 15)];
+			}
+			for (int t = 0; t < nb; ++t) {
+				const int sym = __builtin_amdgcn_readlane(symv, t);
+				double g, sum;
+				if (i0 + t == 0) g = a0[lane] * pick_e(sym, e0, e1);
+				else { double r[4]; rep_rows<REP>(x, r); const double tmp = xdot64(r, col); g = pick_e(sym, e0, e1) * tmp; }
+				{ double q[4]; rep_rows<REP>(g, q); sum = seq_sum_rep(q); }
+				x = g / sum;
+				ring[w][ph & 1][t][lane] = x;
+			}
+			if (nb > 0) { // khmm.c:317: Ec[o_u][k] += f[u][k] * b[u][k] * s[u], u ascending
+#define PSMC_PE(T) if (T < nb) expect_posE<T>(E0, E1, E2, ring[w][ph & 1][T][lane], bq[T], ssv, symv);
+				PSMC_PE(0) PSMC_PE(1) PSMC_PE(2) PSMC_PE(3) PSMC_PE(4) PSMC_PE(5) PSMC_PE(6) PSMC_PE(7)
+				PSMC_PE(8) PSMC_PE(9) PSMC_PE(10) PSMC_PE(11) PSMC_PE(12) PSMC_PE(13) PSMC_PE(14) PSMC_PE(15)
+#undef PSMC_PE
+			}
+			__syncthreads(); // the halves of this phase are complete: hand them to the consumers
+		}
+		if (sg >= 0) {
+			double *oe = segE + (int64_t)(ent + w) * 192;
+			oe[lane] = E0; oe[64 + lane] = E1; oe[128 + lane] = E2;
+			const int sym1 = o[0]; // khmm.c:321-322
+			segA0[(int64_t)(ent + w) * 64 + lane] = 0.0 + a0[lane] * e[sym1 * 64 + lane] * bo[0];
+		}
+		return;
+	}
+	// ---------------- consumers: rows k0 .. k0+31 of A of BOTH entries, lane = column l
+	// 64 sums + 32 products e*a of the homozygous symbol fill the register file, and a choice between two instruction sequences that
+	// both update the sums makes hipcc copy all of them at every position.  So four rows of a position are ONE asm block: the LDS
+	// reads of the forward vector, the choice of the emission row (the other two symbols read e*a -- the host's aeT, the same
+	// single-rounding product -- from memory) and the twelve instructions of khmm.c:316 (products left to right, then the sum).
+	const int cw = w - 2, k0 = 32 * cw, colc = lane;
+	double q0[32], acc[2][32];
+#pragma unroll
+	for (int j = 0; j < 32; ++j) { q0[j] = e0 * a[(k0 + j) * 64 + colc]; acc[0][j] = PSMC_TINY; acc[1][j] = PSMC_TINY; } // khmm.c:194-206, 305-306
+	const double *ap1 = a + 2 * 4096 + colc * 64 + k0, *ap2 = ap1 + 4096; // aeT[1], aeT[2]: [l * 64 + k] (api.hip fill_params)
+	asm volatile("" : "+v"(ap1), "+v"(ap2));
+	// operands: 0-3 sums, 4-7 f (then the products), 8-11 e*a of a rare symbol, 12-15 e*a of symbol 0, 16 b[u+1][l], 17 LDS byte address
+	// of f[u][first row] (wave-uniform: broadcast reads), 18 / 19 this lane's rows of aeT[1] / aeT[2], 20 symbol, 21 byte offset of the rows
+#define PSMC_C4(A, O, BL, AD, SYM)                                                                                                    \
+	{ double u0, u1, u2, u3, g0, g1, g2, g3;                                                                                           \
+	  asm("s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+	      "ds_read_b64 %4, %17\n\tds_read_b64 %5, %17 offset:8\n\tds_read_b64 %6, %17 offset:16\n\tds_read_b64 %7, %17 offset:24\n\t"       \
+	      "s_cmp_eq_u32 %20, 0\n\ts_cbranch_scc0 .Lc4s_%=\n\t"                                                                            \
+	      "s_waitcnt lgkmcnt(3)\n\tv_mul_f64 %4, %4, %12\n\ts_waitcnt lgkmcnt(2)\n\tv_mul_f64 %5, %5, %13\n\t"                               \
+	      "s_waitcnt lgkmcnt(1)\n\tv_mul_f64 %6, %6, %14\n\ts_waitcnt lgkmcnt(0)\n\tv_mul_f64 %7, %7, %15\n"                                \
+	      ".Lc4j_%=:\n\t"                                                                                                                \
+	      "v_mul_f64 %4, %4, %16\n\tv_mul_f64 %5, %5, %16\n\tv_mul_f64 %6, %6, %16\n\tv_mul_f64 %7, %7, %16\n\t"                            \
+	      "v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %5\n\tv_add_f64 %2, %2, %6\n\tv_add_f64 %3, %3, %7\n\t"                                \
+	      "s_branch .Lc4e_%=\n"                                                                                                          \
+	      ".Lc4s_%=:\n\t"                                                                                                                \
+	      "s_cmp_eq_u32 %20, 1\n\ts_cbranch_scc0 .Lc4t_%=\n\t"                                                                            \
+	      "global_load_dwordx2 %8, %18, off offset:%21\n\tglobal_load_dwordx2 %9, %18, off offset:%21+8\n\t"                               \
+	      "global_load_dwordx2 %10, %18, off offset:%21+16\n\tglobal_load_dwordx2 %11, %18, off offset:%21+24\n\t"                         \
+	      "s_branch .Lc4w_%=\n"                                                                                                          \
+	      ".Lc4t_%=:\n\t"                                                                                                                \
+	      "global_load_dwordx2 %8, %19, off offset:%21\n\tglobal_load_dwordx2 %9, %19, off offset:%21+8\n\t"                               \
+	      "global_load_dwordx2 %10, %19, off offset:%21+16\n\tglobal_load_dwordx2 %11, %19, off offset:%21+24\n"                           \
+	      ".Lc4w_%=:\n\t"                                                                                                                \
+	      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                                             \
+	      "v_mul_f64 %4, %4, %8\n\tv_mul_f64 %5, %5, %9\n\tv_mul_f64 %6, %6, %10\n\tv_mul_f64 %7, %7, %11\n\t"                              \
+	      "s_branch .Lc4j_%=\n"                                                                                                          \
+	      ".Lc4e_%=:"                                                                                                                      \
+	      : "+v"(A[O]), "+v"(A[O + 1]), "+v"(A[O + 2]), "+v"(A[O + 3]), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3),                        \
+	        "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)                                                                                     \
+	      : "v"(q0[O]), "v"(q0[O + 1]), "v"(q0[O + 2]), "v"(q0[O + 3]), "v"(BL), "v"(AD), "v"(ap1), "v"(ap2), "s"(SYM), "n"(8 * (O))       \
+	      : "scc"); }
+	typedef const double __attribute__((address_space(3))) *lptr_t;
+	for (int ph = 0; ph < P; ++ph) {
+		__syncthreads(); // the producers have filled half ph & 1
+		const int i0 = ph * RB;
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const int n = q == 0 ? n0 : n1, nb = min(RB, n - i0);
+			if (nb > 0) { // (wave-uniform)
+				const int sg = q == 0 ? sg0 : sg1, L = n + 1;
+				const int64_t off = seg_off[sg], toff = wl.tab ? wl.tab[ent + q] : off;
+				const double *bo = b + toff * 64 + colc;
+				const int sv = obs[off + min(i0 + min(lane, RB - 1) + 1, L - 1)]; // symbols of positions u + 1
+				const unsigned hbase = (unsigned)(uintptr_t)(lptr_t)&ring[q][ph & 1][0][k0];
+#pragma unroll
+				for (int c = 0; c < RB / CB; ++c) {
+					double bn[CB];
+#pragma unroll
+					for (int t = 0; t < CB; ++t) bn[t] = bo[(int64_t)min(i0 + CB * c + t + 1, L - 1) * 64];
+#pragma unroll
+					for (int tt = 0; tt < CB; ++tt) {
+						const int t = CB * c + tt;
+						if (t < nb) {
+							const int sym = __builtin_amdgcn_readlane(sv, t);
+							const double bl = bn[tt];
+							const unsigned ad = hbase + (unsigned)t * 512u;
+							PSMC_C4(acc[q], 0, bl, ad, sym) PSMC_C4(acc[q], 4, bl, ad + 32u, sym) PSMC_C4(acc[q], 8, bl, ad + 64u, sym)
+							PSMC_C4(acc[q], 12, bl, ad + 96u, sym) PSMC_C4(acc[q], 16, bl, ad + 128u, sym) PSMC_C4(acc[q], 20, bl, ad + 160u, sym)
+							PSMC_C4(acc[q], 24, bl, ad + 192u, sym) PSMC_C4(acc[q], 28, bl, ad + 224u, sym)
+						}
+					}
+				}
+			}
+		}
+	}
+#undef PSMC_C4
+#pragma unroll
+	for (int q = 0; q < 2; ++q) {
+		if ((q == 0 ? sg0 : sg1) >= 0) {
+			double *out = segA + (int64_t)(ent + q) * 4096;
+#pragma unroll
+			for (int j = 0; j < 32; ++j) out[(k0 + j) * 64 + colc] = acc[q][j];
+		}
+	}
+}
+
 // ---------------------------------------------------------------- posterior decoding
 // hmm_post_decode (khmm.c:264-281) on the tables of one segment: path[u] = argmax_k
 // f[u][k]*b[u][k]*s[u] with the FIRST maximum winning (the reference compares with `<`),
@@ -942,7 +1099,9 @@ int launch_post_counts(hipStream_t st, const double *f, const double *b, const d
 // ---------------------------------------------------------------- launchers
 int launch_exact(const EstepLaunch &p)
 {
-	const int rep = p.rep_impl;
+	// auto: a wave alone on its SIMD pays for every instruction and waits out the LDS round trip of ds_bpermute -- the register
+	// swaps win; from two waves per SIMD on the vector pipe is the bound and the eight ds_bpermute cost it nothing
+	const int rep = p.rep_impl < 0 ? (p.n_work > 1024 ? 0 : 1) : p.rep_impl;
 	if (p.n_work <= 0) return 0;
 	(void)hipGetLastError(); // the value returned below must be about THESE launches (polled events, elapsed-time queries leave errors behind)
 	if (p.ns == 128) return rep == 0 ? launch_exact128_t<0>(p) : launch_exact128_t<1>(p);
@@ -972,7 +1131,14 @@ int launch_exact(const EstepLaunch &p)
 		hipLaunchKernelGGL(k_bwd_exact<1>, dim3(nb), dim3(256), 0, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs,
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
-	if (p.exact_refwd) { // no f table: the third pass recomputes the forward sweep (k_expect_exact_rf)
+	if (p.exact_refwd == 2 && p.work_align >= 2 && p.n_work % 2 == 0) { // two entries per work-group (k_expect_exact_rf2)
+		if (rep == 0)
+			hipLaunchKernelGGL(k_expect_exact_rf2<0>, dim3(p.n_work / 2), dim3(256), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,
+			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+		else
+			hipLaunchKernelGGL(k_expect_exact_rf2<1>, dim3(p.n_work / 2), dim3(256), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,
+			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+	} else if (p.exact_refwd) { // no f table: the third pass recomputes the forward sweep (k_expect_exact_rf)
 		if (rep == 0)
 			hipLaunchKernelGGL(k_expect_exact_rf<0>, dim3(p.n_work), dim3(192), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,
 			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);

@@ -27,7 +27,7 @@ struct psmc_hip_ctx {
 	int n = 0, ns = 64, device = 0, mode = PSMC_HIP_MODE_EXACT; // ns: states padded to 64 or 128
 	std::string err;
 	// options
-	int chunk = 0, warmup = 3072, max_rounds = 4096, rep_impl = 1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
+	int chunk = 0, warmup = 3072, max_rounds = 4096, rep_impl = -1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
 	double warm_tol = 1e-12;
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
 	bool struct_tiles_set = false; // the caller chose struct_tiles: no adaptation to small inputs

@@ -130,18 +130,25 @@ __device__ __forceinline__ double seq_sum_rep(const double (&r)[4]) {
 // through one temporary and pads a wait state before each (a DPP move reads its destination as `old`: VALU write -> DPP
 // read); here two temporaries alternate, so the register a v_mov_b64_dpp overwrites was written four instructions earlier.
 // Callers pass R through dpp_guard() after its last VALU write.
-#define PSMC_XD(N, T, M) "v_mov_b64_dpp " T ", %3 row_newbcast:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-                         "v_mul_f64 " T ", " T ", " M "\n\t"                                                        \
-                         "v_add_f64 %0, %0, " T "\n\t"
+// The three instructions of a term are spread over three steps -- step n broadcasts x_n, multiplies term n-1 and adds term n-2 --
+// so that no instruction reads what the one before it wrote; three temporaries rotate (term n uses temporary n % 3: the
+// register a v_mov_b64_dpp overwrites was last written seven instructions earlier).
+#define PSMC_XMOV(N, T) "v_mov_b64_dpp " T ", %4 row_newbcast:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define PSMC_XMUL(T, M) "v_mul_f64 " T ", " T ", " M "\n\t"
+#define PSMC_XADD(T) "v_add_f64 %0, %0, " T "\n\t"
+#define PSMC_XSTEP(N, TN, TM, MM, TA) PSMC_XMOV(N, TN) PSMC_XMUL(TM, MM) PSMC_XADD(TA)
 __device__ __forceinline__ void xdot16(double &acc, double R, double m0, double m1, double m2, double m3, double m4, double m5,
                                        double m6, double m7, double m8, double m9, double m10, double m11, double m12,
                                        double m13, double m14, double m15) {
-	double t0, t1;
-	asm(PSMC_XD(0, "%1", "%4") PSMC_XD(1, "%2", "%5") PSMC_XD(2, "%1", "%6") PSMC_XD(3, "%2", "%7")
-	    PSMC_XD(4, "%1", "%8") PSMC_XD(5, "%2", "%9") PSMC_XD(6, "%1", "%10") PSMC_XD(7, "%2", "%11")
-	    PSMC_XD(8, "%1", "%12") PSMC_XD(9, "%2", "%13") PSMC_XD(10, "%1", "%14") PSMC_XD(11, "%2", "%15")
-	    PSMC_XD(12, "%1", "%16") PSMC_XD(13, "%2", "%17") PSMC_XD(14, "%1", "%18") PSMC_XD(15, "%2", "%19")
-	    : "+v"(acc), "=&v"(t0), "=&v"(t1)
+	double t0, t1, t2;
+	asm(PSMC_XMOV(0, "%1") PSMC_XMOV(1, "%2") PSMC_XMUL("%1", "%5")
+	    PSMC_XSTEP(2, "%3", "%2", "%6", "%1") PSMC_XSTEP(3, "%1", "%3", "%7", "%2") PSMC_XSTEP(4, "%2", "%1", "%8", "%3")
+	    PSMC_XSTEP(5, "%3", "%2", "%9", "%1") PSMC_XSTEP(6, "%1", "%3", "%10", "%2") PSMC_XSTEP(7, "%2", "%1", "%11", "%3")
+	    PSMC_XSTEP(8, "%3", "%2", "%12", "%1") PSMC_XSTEP(9, "%1", "%3", "%13", "%2") PSMC_XSTEP(10, "%2", "%1", "%14", "%3")
+	    PSMC_XSTEP(11, "%3", "%2", "%15", "%1") PSMC_XSTEP(12, "%1", "%3", "%16", "%2") PSMC_XSTEP(13, "%2", "%1", "%17", "%3")
+	    PSMC_XSTEP(14, "%3", "%2", "%18", "%1") PSMC_XSTEP(15, "%1", "%3", "%19", "%2")
+	    PSMC_XMUL("%1", "%20") PSMC_XADD("%3") PSMC_XADD("%1")
+	    : "+v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2)
 	    : "v"(R), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7), "v"(m8), "v"(m9), "v"(m10), "v"(m11),
 	      "v"(m12), "v"(m13), "v"(m14), "v"(m15));
 }

@@ -45,7 +45,7 @@ def main():
                 fh.write(t[n60:].tobytes() + b"\n")
     res = dict(workload="%d trunks (%d bins, longest %d), %d replicates, -N%d -t15 -r5 -p 4+25*2+4+6" % (len(trunks), sum(len(t) for t in trunks), max(len(t) for t in trunks), n_rep, iters), runs={})
     args = ["-N%d" % iters, "-t15", "-r5", "-p", "4+25*2+4+6", path]
-    for mode in (("fast",) if os.environ.get("BOOT_FAST_ONLY") else ("exact", "fast")):
+    for mode in (("fast",) if os.environ.get("BOOT_FAST_ONLY") else ("exact",) if os.environ.get("BOOT_EXACT_ONLY") else ("exact", "fast")):
         env = dict(os.environ, PSMC_HIP_MODE=mode, PSMC_TIMING="1")
         t0 = time.time()
         r = subprocess.run([os.path.join(HOST, "psmc_boot"), "-R", str(n_rep), "-S", "1000", "-O", os.path.join(tmp, "boot_%s-%%d.psmc" % mode), "--"] + args,

@@ -634,14 +634,15 @@ def _traj_params(n_sets):
     return [hostlib.hmm_params(tj["pattern"], r["params"]) for r in tj["rounds"][1:1 + n_sets]]
 
 
-@pytest.mark.parametrize("refwd", [1, 0])
+@pytest.mark.parametrize("refwd", [2, 1, 0])
 @pytest.mark.parametrize("batch_bins", [0, 80000])
 def test_exact_batch_is_bit_identical_to_separate_calls(hip, golden, batch_bins, refwd):
     """psmc_hip_estep_batch, exact mode: 8 replicates (own parameters, own bootstrap multiset with repeats) in one grid
     per kernel == 8 x (psmc_hip_select + psmc_hip_estep), bit for bit; with a table budget that forces several launch
     groups as well.  exact_refwd=1 (default): no f table in the batch -- the expect pass recomputes the
     forward sweep (k_expect_exact_rf: producer wave + two consumer waves per entry) and must give the very same bits as the
-    three-pass kernels the separate calls run; segments of 1, 2, 15, 16, 17 bins included (ring halves of 16 positions)."""
+    three-pass kernels the separate calls run; segments of 1, 2, 15, 16, 17 bins included (ring halves of 16 positions).
+    exact_refwd=2: two entries per work-group (k_expect_exact_rf2) -- pairs of unequal length, a padding entry as partner."""
     segs = golden.segs_small + golden.segs_mid[2:]
     segs = segs + [segs[0][:k].copy() for k in (1, 2, 15, 16, 17, 33)]   # edge lengths of the recompute kernel's ring
     rng = np.random.default_rng(4)

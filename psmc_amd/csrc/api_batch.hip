@@ -97,6 +97,19 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	for (const RepSel &R : reps) n_entries_all += R.work.size();
 	const int align = c->ns == 128 ? (n_entries_all <= 256 ? 1 : (n_entries_all <= 512 ? 2 : 4)) : 4; // sweeps per block sharing one parameter set in LDS
 	c->last_batch_groups = 0;
+	// Entries per group.  An entry is one sequential sweep over its segment, and the replicates of a bootstrap are made of equal trunks
+	// (utils/splitfa.c), so a launch runs in ROUNDS: the backward sweep has one wave slot per SIMD before waves share one, the recompute
+	// pass (k_expect_exact_rf2) four entries per compute unit -- both 4 x CUs entries.  What memory allows beyond a whole number of
+	// rounds runs as a nearly empty extra round (1088 entries on 1024 slots: two rounds, measured 1.85 s against 0.95 s for 1024), so
+	// a group is cut at the last full round it can hold.
+	size_t ent_cap = SIZE_MAX;
+	if (refwd && c->ns == 64 && n_entries_all > 0 && all_bins > cap) {
+		int cus = 0;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+		const size_t slots = (size_t)cus * (c->exact_refwd == 1 ? 2 : 4);
+		const size_t fit = (size_t)((double)cap / ((double)all_bins / (double)n_entries_all)); // entries the table memory holds
+		if (fit >= slots) ent_cap = fit / slots * slots;
+	}
 	// The work list of the whole call, replicate-major, every replicate padded to `align` entries: entry -> segment, replicate (= its
 	// parameter block), offset of its tables inside ITS launch group, offset of its scale factors in the call-wide s table.  Groups =
 	// as many consecutive replicates as fit the table memory: slices [g_first[g], g_first[g+1]) of that list.
@@ -107,8 +120,9 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		int64_t s_run = 0;
 		for (int r0 = 0; r0 < n_rep;) {
 			if (reps[r0].bins > cap) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: the tables of one replicate do not fit the device memory (batch_bins)");
-			int r1 = r0; int64_t bins = 0;
-			while (r1 < n_rep && bins + reps[r1].bins <= cap) { bins += reps[r1].bins; ++r1; }
+			int r1 = r0; int64_t bins = 0; size_t ents = 0;
+			auto padded = [&](int r) { return (reps[r].work.size() + align - 1) / align * align; };
+			while (r1 < n_rep && bins + reps[r1].bins <= cap && (r1 == r0 || ents + padded(r1) <= ent_cap)) { bins += reps[r1].bins; ents += padded(r1); ++r1; }
 			g_rep.push_back(r0);
 			int64_t run = 0; const size_t e0 = wseg.size();
 			for (int r = r0; r < r1; ++r) {

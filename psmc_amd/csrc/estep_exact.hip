@@ -628,36 +628,77 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 	for (int j = 0; j < 32; ++j) { q0[j] = e0 * a[(k0 + j) * 64 + colc]; acc[0][j] = PSMC_TINY; acc[1][j] = PSMC_TINY; } // khmm.c:194-206, 305-306
 	const double *ap1 = a + 2 * 4096 + colc * 64 + k0, *ap2 = ap1 + 4096; // aeT[1], aeT[2]: [l * 64 + k] (api.hip fill_params)
 	asm volatile("" : "+v"(ap1), "+v"(ap2));
-	// operands: 0-3 sums, 4-7 f (then the products), 8-11 e*a of a rare symbol, 12-15 e*a of symbol 0, 16 b[u+1][l], 17 LDS byte address
-	// of f[u][first row] (wave-uniform: broadcast reads), 18 / 19 this lane's rows of aeT[1] / aeT[2], 20 symbol, 21 byte offset of the rows
-#define PSMC_C4(A, O, BL, AD, SYM)                                                                                                    \
-	{ double u0, u1, u2, u3, g0, g1, g2, g3;                                                                                           \
-	  asm("s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-	      "ds_read_b64 %4, %17\n\tds_read_b64 %5, %17 offset:8\n\tds_read_b64 %6, %17 offset:16\n\tds_read_b64 %7, %17 offset:24\n\t"       \
-	      "s_cmp_eq_u32 %20, 0\n\ts_cbranch_scc0 .Lc4s_%=\n\t"                                                                            \
-	      "s_waitcnt lgkmcnt(3)\n\tv_mul_f64 %4, %4, %12\n\ts_waitcnt lgkmcnt(2)\n\tv_mul_f64 %5, %5, %13\n\t"                               \
-	      "s_waitcnt lgkmcnt(1)\n\tv_mul_f64 %6, %6, %14\n\ts_waitcnt lgkmcnt(0)\n\tv_mul_f64 %7, %7, %15\n"                                \
+	// One position = eight asm blocks of four rows.  Operands: 0-3 sums | 4-7 f of this block's rows (then the products) | 8-11 f of the
+	// NEXT block's rows | 12-15 e*a of a rare symbol | 16-19 e*a of symbol 0 | 20 b[u+1][l] | 21 LDS byte address of f[u][k0] (wave-uniform:
+	// broadcast reads) | 22 / 23 this lane's rows of aeT[1] / aeT[2] | 24 symbol | 25 byte offset of the block's rows.  The LDS reads of
+	// block k+1 are issued before block k computes (a read costs ~100 cycles, and eight exposed ones per position made the consumers the
+	// slowest waves of the group): registers 8-11 leave a block with their loads IN FLIGHT and enter the next one as its 4-7 -- only
+	// asm statements stand between (tests/test_abi.py checks the compiled code for that), and each waits (lgkmcnt counts down in issue
+	// order for LDS; foreign scalar loads in the count only make the wait longer) before it touches them.
+#define PSMC_C4_TAIL                                                                                                                  \
+	      "s_cmp_eq_u32 %24, 0\n\ts_cbranch_scc0 .Lc4s_%=\n\t"                                                                            \
+	      "v_mul_f64 %4, %4, %16\n\tv_mul_f64 %5, %5, %17\n\tv_mul_f64 %6, %6, %18\n\tv_mul_f64 %7, %7, %19\n"                                \
 	      ".Lc4j_%=:\n\t"                                                                                                                \
-	      "v_mul_f64 %4, %4, %16\n\tv_mul_f64 %5, %5, %16\n\tv_mul_f64 %6, %6, %16\n\tv_mul_f64 %7, %7, %16\n\t"                            \
+	      "v_mul_f64 %4, %4, %20\n\tv_mul_f64 %5, %5, %20\n\tv_mul_f64 %6, %6, %20\n\tv_mul_f64 %7, %7, %20\n\t"                            \
 	      "v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %5\n\tv_add_f64 %2, %2, %6\n\tv_add_f64 %3, %3, %7\n\t"                                \
 	      "s_branch .Lc4e_%=\n"                                                                                                          \
 	      ".Lc4s_%=:\n\t"                                                                                                                \
-	      "s_cmp_eq_u32 %20, 1\n\ts_cbranch_scc0 .Lc4t_%=\n\t"                                                                            \
-	      "global_load_dwordx2 %8, %18, off offset:%21\n\tglobal_load_dwordx2 %9, %18, off offset:%21+8\n\t"                               \
-	      "global_load_dwordx2 %10, %18, off offset:%21+16\n\tglobal_load_dwordx2 %11, %18, off offset:%21+24\n\t"                         \
+	      "s_cmp_eq_u32 %24, 1\n\ts_cbranch_scc0 .Lc4t_%=\n\t"                                                                            \
+	      "global_load_dwordx2 %12, %22, off offset:%25\n\tglobal_load_dwordx2 %13, %22, off offset:%25+8\n\t"                             \
+	      "global_load_dwordx2 %14, %22, off offset:%25+16\n\tglobal_load_dwordx2 %15, %22, off offset:%25+24\n\t"                         \
 	      "s_branch .Lc4w_%=\n"                                                                                                          \
 	      ".Lc4t_%=:\n\t"                                                                                                                \
-	      "global_load_dwordx2 %8, %19, off offset:%21\n\tglobal_load_dwordx2 %9, %19, off offset:%21+8\n\t"                               \
-	      "global_load_dwordx2 %10, %19, off offset:%21+16\n\tglobal_load_dwordx2 %11, %19, off offset:%21+24\n"                           \
+	      "global_load_dwordx2 %12, %23, off offset:%25\n\tglobal_load_dwordx2 %13, %23, off offset:%25+8\n\t"                             \
+	      "global_load_dwordx2 %14, %23, off offset:%25+16\n\tglobal_load_dwordx2 %15, %23, off offset:%25+24\n"                           \
 	      ".Lc4w_%=:\n\t"                                                                                                                \
 	      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                                             \
-	      "v_mul_f64 %4, %4, %8\n\tv_mul_f64 %5, %5, %9\n\tv_mul_f64 %6, %6, %10\n\tv_mul_f64 %7, %7, %11\n\t"                              \
+	      "v_mul_f64 %4, %4, %12\n\tv_mul_f64 %5, %5, %13\n\tv_mul_f64 %6, %6, %14\n\tv_mul_f64 %7, %7, %15\n\t"                            \
 	      "s_branch .Lc4j_%=\n"                                                                                                          \
 	      ".Lc4e_%=:"                                                                                                                      \
-	      : "+v"(A[O]), "+v"(A[O + 1]), "+v"(A[O + 2]), "+v"(A[O + 3]), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3),                        \
+
+#define PSMC_C4_IN(A, O, BL, AD, SYM)                                                                                                 \
 	        "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)                                                                                     \
 	      : "v"(q0[O]), "v"(q0[O + 1]), "v"(q0[O + 2]), "v"(q0[O + 3]), "v"(BL), "v"(AD), "v"(ap1), "v"(ap2), "s"(SYM), "n"(8 * (O))       \
-	      : "scc"); }
+	      : "scc")
+	// first block of a position: reads its own rows and the next block's
+#define PSMC_C4F(A, BL, AD, SYM, C0, C1, C2, C3, N0, N1, N2, N3)                                                                     \
+	{ double g0, g1, g2, g3;                                                                                                           \
+	  asm("s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+	      "ds_read_b64 %4, %21\n\tds_read_b64 %5, %21 offset:8\n\tds_read_b64 %6, %21 offset:16\n\tds_read_b64 %7, %21 offset:24\n\t"       \
+	      "ds_read_b64 %8, %21 offset:32\n\tds_read_b64 %9, %21 offset:40\n\tds_read_b64 %10, %21 offset:48\n\tds_read_b64 %11, %21 offset:56\n\t" \
+	      "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
+	      PSMC_C4_TAIL                                                                                                                  \
+	      : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "=&v"(C0), "=&v"(C1), "=&v"(C2), "=&v"(C3),                                    \
+	        "=&v"(N0), "=&v"(N1), "=&v"(N2), "=&v"(N3),                                                                                    \
+	        PSMC_C4_IN(A, 0, BL, AD, SYM); }
+	// blocks 1..6: rows O..O+3 arrive in C0..C3; reads the rows of block O/4 + 1 (LDS offset NO = 8 * (O + 4)) into N0..N3
+#define PSMC_C4M(A, O, NO, BL, AD, SYM, C0, C1, C2, C3, N0, N1, N2, N3)                                                              \
+	{ double g0, g1, g2, g3;                                                                                                           \
+	  asm("ds_read_b64 %8, %21 offset:" #NO "\n\tds_read_b64 %9, %21 offset:" #NO "+8\n\t"                                                 \
+	      "ds_read_b64 %10, %21 offset:" #NO "+16\n\tds_read_b64 %11, %21 offset:" #NO "+24\n\t"                                           \
+	      "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
+	      PSMC_C4_TAIL                                                                                                                  \
+	      : "+v"(A[O]), "+v"(A[O + 1]), "+v"(A[O + 2]), "+v"(A[O + 3]), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(C3),                            \
+	        "=&v"(N0), "=&v"(N1), "=&v"(N2), "=&v"(N3),                                                                                    \
+	        PSMC_C4_IN(A, O, BL, AD, SYM); }
+	// last block: nothing to read ahead (operands 8-11 are placeholders)
+#define PSMC_C4L(A, O, BL, AD, SYM, C0, C1, C2, C3)                                                                                  \
+	{ double g0, g1, g2, g3, z0, z1, z2, z3;                                                                                           \
+	  asm("s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+	      PSMC_C4_TAIL                                                                                                                  \
+	      : "+v"(A[O]), "+v"(A[O + 1]), "+v"(A[O + 2]), "+v"(A[O + 3]), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(C3),                            \
+	        "=&v"(z0), "=&v"(z1), "=&v"(z2), "=&v"(z3),                                                                                    \
+	        PSMC_C4_IN(A, O, BL, AD, SYM); }
+#define PSMC_CPOS(A, BL, AD, SYM)                                                                                                     \
+	{ double fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3;                                                                                   \
+	  PSMC_C4F(A, BL, AD, SYM, fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3)                                                                 \
+	  PSMC_C4M(A, 4, 64, BL, AD, SYM, fb0, fb1, fb2, fb3, fa0, fa1, fa2, fa3)                                                          \
+	  PSMC_C4M(A, 8, 96, BL, AD, SYM, fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3)                                                          \
+	  PSMC_C4M(A, 12, 128, BL, AD, SYM, fb0, fb1, fb2, fb3, fa0, fa1, fa2, fa3)                                                        \
+	  PSMC_C4M(A, 16, 160, BL, AD, SYM, fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3)                                                        \
+	  PSMC_C4M(A, 20, 192, BL, AD, SYM, fb0, fb1, fb2, fb3, fa0, fa1, fa2, fa3)                                                        \
+	  PSMC_C4M(A, 24, 224, BL, AD, SYM, fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3)                                                        \
+	  PSMC_C4L(A, 28, BL, AD, SYM, fb0, fb1, fb2, fb3) }
 	typedef const double __attribute__((address_space(3))) *lptr_t;
 	for (int ph = 0; ph < P; ++ph) {
 		__syncthreads(); // the producers have filled half ph & 1
@@ -683,16 +724,19 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 							const int sym = __builtin_amdgcn_readlane(sv, t);
 							const double bl = bn[tt];
 							const unsigned ad = hbase + (unsigned)t * 512u;
-							PSMC_C4(acc[q], 0, bl, ad, sym) PSMC_C4(acc[q], 4, bl, ad + 32u, sym) PSMC_C4(acc[q], 8, bl, ad + 64u, sym)
-							PSMC_C4(acc[q], 12, bl, ad + 96u, sym) PSMC_C4(acc[q], 16, bl, ad + 128u, sym) PSMC_C4(acc[q], 20, bl, ad + 160u, sym)
-							PSMC_C4(acc[q], 24, bl, ad + 192u, sym) PSMC_C4(acc[q], 28, bl, ad + 224u, sym)
+							PSMC_CPOS(acc[q], bl, ad, sym)
 						}
 					}
 				}
 			}
 		}
 	}
-#undef PSMC_C4
+#undef PSMC_CPOS
+#undef PSMC_C4L
+#undef PSMC_C4M
+#undef PSMC_C4F
+#undef PSMC_C4_IN
+#undef PSMC_C4_TAIL
 #pragma unroll
 	for (int q = 0; q < 2; ++q) {
 		if ((q == 0 ? sg0 : sg1) >= 0) {

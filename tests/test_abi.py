@@ -49,18 +49,29 @@ def test_argument_validation(lib):
     assert lib.psmc_hip_create(None, 64, 0, 0) == -1
 
 
+_EXACT_ASM = []
+
+
+def _exact_asm():
+    """gfx950 assembly of the exact kernels (compiled once per test session: ~30 s)"""
+    if not _EXACT_ASM:
+        out = "/tmp/psmc_exact_audit_%d.s" % os.getpid()
+        src = os.path.join(ROOT, "psmc_amd", "csrc", "estep_exact.hip")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, src],
+                       check=True, stderr=subprocess.DEVNULL)
+        _EXACT_ASM.append(open(out).read())
+        os.unlink(out)
+    return _EXACT_ASM[0]
+
+
 def test_exact_kernels_have_no_fma():
     """hipcc contracts a*b+c by default; the exact mode must never contain an FMA outside the IEEE division expansion
      -- with ONE deliberate exception that is checked here operand by operand: the ordered sums
     s = s + x_k are issued as v_fmac_f64_dpp s, x, ONE (wave_prims.h add_bcast), and fma(x, 1.0, s) is the IEEE sum bit
     for bit.  Every such instruction must multiply by a register that the kernel loads with the constant 1.0 and never
     writes otherwise."""
-    out = "/tmp/psmc_exact_audit.s"
-    src = os.path.join(ROOT, "psmc_amd", "csrc", "estep_exact.hip")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                    "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, src],
-                   check=True, stderr=subprocess.DEVNULL)
-    txt = open(out).read()
+    txt = _exact_asm()
     n_div = len(re.findall(r"v_div_fmas_f64", txt))
     n_fma = len(re.findall(r"\bv_fma_f64|\bv_fmac_f64(?!_dpp)", txt))
     assert n_div > 0
@@ -87,6 +98,33 @@ def test_exact_kernels_have_no_fma():
                 if m and not l.startswith("v_fmac_f64_dpp") and (regs(m.group(1)) & regs(reg)):
                     assert l == "v_mov_b64_e32 %s, 1.0" % reg, (reg, l)
     assert n_sum > 0 and n_sum % 16 == 0
+
+
+def test_recompute_consumers_keep_in_flight_registers_untouched():
+    """k_expect_exact_rf2's consumers hand registers with LDS loads IN FLIGHT from one asm block to the next (estep_exact.hip,
+    PSMC_CPOS).  That is sound only while nothing but asm stands between the blocks of a position: checked on the compiled code."""
+    L = _exact_asm().split("\n")
+    blocks, i = [], 0
+    while i < len(L):
+        if "ASMSTART" in L[i]:
+            j = i
+            while "ASMEND" not in L[j]: j += 1
+            if any(".Lc4j_" in x for x in L[i:j]): blocks.append((i, j))
+            i = j
+        i += 1
+    assert len(blocks) >= 2 * 256      # 2 entries x 16 positions x 8 blocks, for each of the two rep_impl instances
+    n_handover = 0
+    for (i0, j0), (i1, j1) in zip(blocks, blocks[1:]):
+        body1 = [x.strip() for x in L[i1 + 1:j1] if x.strip()]
+        if body1[0].startswith("s_waitcnt lgkmcnt(0)") and body1[1].startswith("ds_read"): continue   # first block of a position: nothing in flight
+        if body1[0].startswith("s_waitcnt lgkmcnt(0)"):
+            pass                                                                                       # last block: waits for everything first
+        infl = [re.match(r"\s*ds_read_b64 (v\[\d+:\d+\])", x).group(1) for x in L[i0 + 1:j0] if x.strip().startswith("ds_read_b64")][-4:]
+        between = [x.strip() for x in L[j0 + 1:i1] if x.strip() and not x.strip().startswith(";")]
+        assert all(x.startswith("s_nop") for x in between), between
+        assert len(infl) == 4
+        n_handover += 1
+    assert n_handover >= 2 * 2 * 16 * 7
 
 
 def test_every_option_is_documented():

@@ -121,7 +121,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
 	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_gate, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol,
-	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar, c->d_s_all};
+	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar, c->d_s_all, c->d_cu_mask};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);

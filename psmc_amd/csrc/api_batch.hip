@@ -154,6 +154,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 			c->bw_cap = (size_t)n_all;
 		}
 		if (c->bpar_cap < (size_t)n_rep) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)n_rep * PL))) return rc; c->bpar_cap = (size_t)n_rep; }
+		if (refwd && !c->d_cu_mask && (rc = dev_alloc(c, &c->d_cu_mask, (size_t)4096))) return rc;
 		if (fwd_all && c->s_all_cap < (size_t)all_bins + 128) { if ((rc = dev_alloc(c, &c->d_s_all, (size_t)all_bins + 128))) return rc; c->s_all_cap = (size_t)all_bins + 128; }
 	}
 	static const bool dbg_t = getenv("PSMC_HIP_DEBUG_TIMES") != nullptr;
@@ -189,6 +190,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		fill_common(c, p, c->stream, c->d_bpar);
 		p.d_work = c->d_bw_seg + e0; p.n_work = nw; p.d_work_par = c->d_bw_par + e0; p.d_work_tab = c->d_bw_tab + e0; p.par_stride = (int64_t)PL; p.work_align = align;
 		p.exact_refwd = refwd ? (c->exact_refwd == 1 ? 1 : 2) : 0; // 2: two entries per work-group (k_expect_exact_rf2), the default
+		p.d_cu_mask = c->d_cu_mask;
 		if (fwd_all) { p.exact_only = 2; p.d_work_tab_s = c->d_bw_tab + n_all + e0; p.d_s = c->d_s_all; }
 		p.d_segA = c->d_segA; p.d_segE = c->d_segE; p.d_segA0 = c->d_segA0; p.d_chk = c->d_chk;
 		const double t_b = now();

@@ -559,12 +559,41 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
                                                            const double *__restrict__ a0, const uint8_t *__restrict__ obs,
                                                            const int64_t *__restrict__ seg_off, const int32_t *__restrict__ seg_len,
                                                            const ExWork wl, const double *__restrict__ b, const double *__restrict__ s,
-                                                           double *__restrict__ segA, double *__restrict__ segE, double *__restrict__ segA0)
+                                                           double *__restrict__ segA, double *__restrict__ segE, double *__restrict__ segA0,
+                                                           int *__restrict__ cu_mask)
 {
 	constexpr int RB = 16, CB = 4; // positions per ring half; b rows a consumer fetches at a time
 	__shared__ double ring[2][2][RB][64]; // [entry][half][position][state]
+	__shared__ int roles[8];
 	const int lane = threadIdx.x & 63;
-	const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	// Which wave does what.  The four waves of a group sit on the four SIMDs of a compute unit, and so do those of the second resident
+	// group: with fixed roles wave i of both lands on SIMD i -- two producers (2 x ~280 vector instructions per position) on two of
+	// the SIMDs, two consumers on the others (measured: 1.6 us per position where the mixed placement needs ~1).  So a wave takes
+	// its role from the SIMD it runs on and a bit t the group claims in a word of its compute unit (the first resident group gets
+	// t = 0, the second t = 1): producer iff (SIMD + t) is even, entry / row half = SIMD >> 1.  Every SIMD then holds one producer
+	// and one consumer.  Without the word, or when the waves do not sit on four different SIMDs: roles by wave number.
+	int w = wv, held = 0, key = 0;
+	if (cu_mask) {
+		unsigned hid, xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hid));  // [5:4] SIMD, [11:8] CU, [12] SH, [15:13] SE
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); // [3:0] XCC
+		const int simd = (int)((hid >> 4) & 3u);
+		if (lane == 0) roles[wv] = simd;
+		if (threadIdx.x == 0) {
+			key = (int)(((xcc & 15u) << 8) | ((hid >> 8) & 0xffu));
+			int t;
+			if (!(atomicOr(&cu_mask[key], 1) & 1)) { t = 0; held = 1; }
+			else if (!(atomicOr(&cu_mask[key], 2) & 2)) { t = 1; held = 2; }
+			else t = (int)(blockIdx.x & 1); // (more groups on the unit than the two this kernel's registers allow: not expected)
+			roles[4] = t;
+		}
+		__syncthreads();
+		const int seen = (1 << roles[0]) | (1 << roles[1]) | (1 << roles[2]) | (1 << roles[3]);
+		if (seen == 15) w = ((simd + roles[4]) & 1) == 0 ? (simd >> 1) : 2 + (simd >> 1);
+	}
+	w = __builtin_amdgcn_readfirstlane(w);
+	auto release = [&]() { if (held) atomicAnd(&cu_mask[key], ~held); }; // (thread 0 only holds one)
 	const int ent = 2 * (int)blockIdx.x;
 	{ const int64_t po = wl.par ? wl.par[ent] * wl.par_stride : 0; a += po; e += po; a0 += po; }
 	// segment of the two entries (-1: padding / past the list) and their positions u = 1 .. L-1 (index i = u-1 = 0 .. n-1)
@@ -615,6 +644,7 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 			const int sym1 = o[0]; // khmm.c:321-322
 			segA0[(int64_t)(ent + w) * 64 + lane] = 0.0 + a0[lane] * e[sym1 * 64 + lane] * bo[0];
 		}
+		release();
 		return;
 	}
 	// ---------------- consumers: rows k0 .. k0+31 of A of BOTH entries, lane = column l
@@ -745,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 			for (int j = 0; j < 32; ++j) out[(k0 + j) * 64 + colc] = acc[q][j];
 		}
 	}
+	release();
 }
 
 // ---------------------------------------------------------------- posterior decoding
@@ -1176,12 +1207,13 @@ int launch_exact(const EstepLaunch &p)
 		                   p.d_seg_off, p.d_seg_len, wl, p.d_s, p.d_b, p.d_chk);
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
 	if (p.exact_refwd == 2 && p.work_align >= 2 && p.n_work % 2 == 0) { // two entries per work-group (k_expect_exact_rf2)
+		if (p.d_cu_mask) (void)hipMemsetAsync(p.d_cu_mask, 0, 4096 * sizeof(int), p.stream);
 		if (rep == 0)
 			hipLaunchKernelGGL(k_expect_exact_rf2<0>, dim3(p.n_work / 2), dim3(256), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,
-			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0, p.d_cu_mask);
 		else
 			hipLaunchKernelGGL(k_expect_exact_rf2<1>, dim3(p.n_work / 2), dim3(256), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,
-			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);
+			                   p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0, p.d_cu_mask);
 	} else if (p.exact_refwd) { // no f table: the third pass recomputes the forward sweep (k_expect_exact_rf)
 		if (rep == 0)
 			hipLaunchKernelGGL(k_expect_exact_rf<0>, dim3(p.n_work), dim3(192), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl,

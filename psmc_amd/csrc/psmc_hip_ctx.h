@@ -139,6 +139,7 @@ struct psmc_hip_ctx {
 	                                   // replicates do not fit one launch group (api_batch.hip batch_refwd)
 	int32_t *d_bw_seg = nullptr, *d_bw_par = nullptr; int64_t *d_bw_tab = nullptr; size_t bw_cap = 0; // work list of a group
 	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_rep][PAR_LEN] parameter blocks of a batch call
+	int *d_cu_mask = nullptr;          // k_expect_exact_rf2: one word per compute unit (which role order its resident work-groups took), 4096 words
 	double *d_s_all = nullptr; size_t s_all_cap = 0; // exact batch without the f table, several groups: the scale factors of ALL replicates (one forward pass)
 	int last_batch_groups = 0;
 	bool tables_batch = false;         // the tables hold the slots of a batch group, not the segments at their own offsets

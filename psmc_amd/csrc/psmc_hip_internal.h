@@ -51,6 +51,7 @@ struct EstepLaunch {
 	int overlap;
 	int rep_impl, expect_impl, n_states;
 	const int64_t *d_work_tab_s; // ExWork::tab_s
+	int *d_cu_mask = nullptr;    // k_expect_exact_rf2: 4096 zeroed words, or null (static wave roles)
 	int exact_only;              // exact batch: 1 = only the forward pass (scale factors), 2 = everything but the forward pass, 0 = all three
 	int exact_refwd;             // exact batch, 64 states: no f table -- the expect pass recomputes the forward sweep (estep_exact.hip k_expect_exact_rf)
 	int ns;                      // padded number of states: 64, or 128 (exact mode only; then d_aeT is a transposed)

@@ -2,7 +2,9 @@
 //
 // Reproduces khmm.c's hmm_forward / hmm_backward / hmm_expect (lh3/psmc
 // khmm.c:145-190, 210-241, 297-324) BIT FOR BIT: strict IEEE-754 double, no FMA
-// contraction (file built with -ffp-contract=off and uses no fma), every sum in
+// contraction (file built with -ffp-contract=off; the one fused instruction in it,
+// v_fmac_f64_dpp s, x, 1.0 of the ordered sums, rounds x + s once: the IEEE sum --
+// wave_prims.h add_bcast, audited by tests/test_abi.py), every sum in
 // the reference's index order, true division.  That forbids tree reductions,
 // atomics and any split of a segment along the sequence, so the parallelism is
 // one wavefront per segment (lane = hidden state k) for the two sweeps, and

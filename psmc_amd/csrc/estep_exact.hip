@@ -4,7 +4,7 @@
 // khmm.c:145-190, 210-241, 297-324) BIT FOR BIT: strict IEEE-754 double, no FMA
 // contraction (file built with -ffp-contract=off; the one fused instruction in it,
 // v_fmac_f64_dpp s, x, 1.0 of the ordered sums, rounds x + s once: the IEEE sum --
-// wave_prims.h add_bcast, audited by tests/test_abi.py), every sum in
+// wave_prims.h add_bcast16, audited by tests/test_abi.py), every sum in
 // the reference's index order, true division.  That forbids tree reductions,
 // atomics and any split of a segment along the sequence, so the parallelism is
 // one wavefront per segment (lane = hidden state k) for the two sweeps, and
@@ -927,7 +927,7 @@ __device__ __forceinline__ void add_bcast16x2(double &s, double ev, double od, d
 __device__ __forceinline__ double seq_sum_rep2(const double (&ev_)[4], const double (&od_)[4]) {
 	double ev[4] = {ev_[0], ev_[1], ev_[2], ev_[3]}, od[4] = {od_[0], od_[1], od_[2], od_[3]};
 	dpp_guard(ev); dpp_guard(od);
-	double s = 0.0, one = 1.0; // one instruction per term: s + x as fma(x, 1.0, s) (add_bcast, wave_prims.h)
+	double s = 0.0, one = 1.0; // one instruction per term: s + x as fma(x, 1.0, s) (add_bcast16, wave_prims.h)
 	add_bcast16x2(s, ev[0], od[0], one); add_bcast16x2(s, ev[1], od[1], one);
 	add_bcast16x2(s, ev[2], od[2], one); add_bcast16x2(s, ev[3], od[3], one);
 	return s;

@@ -103,10 +103,6 @@ __device__ __forceinline__ double wave_sum_rep(const double (&r)[4]) {
 // once -- it IS the IEEE sum s + x, bit for bit, for every input (the one place an fma appears in the exact kernels; the
 // products of the recursions keep their own rounding).  v_add_f64 has no DPP form on gfx950, so the alternative is a
 // v_mov_b64_dpp per term: 64 more vector instructions per position of a sweep that is bound by their issue.
-template <int N> __device__ __forceinline__ void add_bcast(double &s, double r, double one) {
-	asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-	    : "+v"(s) : "v"(r), "v"(one), "n"(N));
-}
 // the sixteen lanes of one row group in order, as ONE asm block (the compiler pads a wait state around every block)
 #define PSMC_FB(N) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
 __device__ __forceinline__ void add_bcast16(double &s, double r, double one) {

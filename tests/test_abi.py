@@ -68,7 +68,7 @@ def _exact_asm():
 def test_exact_kernels_have_no_fma():
     """hipcc contracts a*b+c by default; the exact mode must never contain an FMA outside the IEEE division expansion
      -- with ONE deliberate exception that is checked here operand by operand: the ordered sums
-    s = s + x_k are issued as v_fmac_f64_dpp s, x, ONE (wave_prims.h add_bcast), and fma(x, 1.0, s) is the IEEE sum bit
+    s = s + x_k are issued as v_fmac_f64_dpp s, x, ONE (wave_prims.h add_bcast16), and fma(x, 1.0, s) is the IEEE sum bit
     for bit.  Every such instruction must multiply by a register that the kernel loads with the constant 1.0 and never
     writes otherwise."""
     txt = _exact_asm()

@@ -11,8 +11,11 @@
  * reference code it replaces.  Plain C types only; every function returns 0 or
  * a negative PSMC_HIP_E* code, never aborts, never prints.
  *
- * Conventions: n = number of hidden states (psmc's n+1; <= 128; fast mode beyond 64 states runs the structured
- * sweeps for matrices of the PSMC form and psmc_hip_estep falls back to the exact kernels for any other matrix);
+ * Conventions: n = number of hidden states (psmc's n+1; <= PSMC_HIP_MAX_STATES = 1024.  Up to 64: every kernel; 65..128:
+ * fast mode runs the structured sweeps for matrices of the PSMC form and psmc_hip_estep falls back to the exact kernels for
+ * any other matrix; 129..1024 (`psmc -p "100*2"`): the wide exact kernels of estep_wide.hip whatever the mode -- psmc_hip_estep,
+ * _estep_segments, _estep_batch, the table readers and the decoding entry points; the device-resident and factored fast entry
+ * points return PSMC_HIP_ENOTSUP there);
  * row-major FP64; a[k*n+l]=P(k->l) (khmm.h:34); e[b*n+k], b=0 hom / 1 het
  * (khmm.h:34; the missing-data row e[2][*]=1 of khmm.c:21 is implied);
  * a0[k] (khmm.h:36); observations are bytes 0/1/2 exactly as psmc_read_seq
@@ -28,11 +31,13 @@ extern "C" {
 #define PSMC_HIP_MODE_EXACT 0 /* bit-identical to khmm.c (ordered sums, no FMA) */
 #define PSMC_HIP_MODE_FAST  1 /* tiled speculative sweeps, FMA/MFMA, tree reductions; stats within 1e-10 */
 
+#define PSMC_HIP_MAX_STATES 1024 /* exact mode; the fast kernels cover up to 128 states (beyond: a fast-mode context runs the exact ones) */
+
 #define PSMC_HIP_OK        0
 #define PSMC_HIP_EINVAL   -1 /* bad argument (NULL, n out of range, empty segment ...) */
 #define PSMC_HIP_ENOMEM   -2 /* host or device allocation failed */
 #define PSMC_HIP_EDEVICE  -3 /* HIP runtime error; see psmc_hip_last_error() */
-#define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (n > 128; the device-resident / factored fast entry points with n > 64 and a matrix without the PSMC form) */
+#define PSMC_HIP_ENOTSUP  -4 /* not supported in this build (n > 1024; the device-resident / factored fast entry points with n > 128, or with n > 64 and a matrix without the PSMC form) */
 #define PSMC_HIP_ESTATE   -5 /* call order violated (no segments loaded ...) */
 #define PSMC_HIP_ECONVERGE -6 /* fast mode: tile boundaries did not converge within max_rounds */
 
@@ -40,6 +45,8 @@ typedef struct psmc_hip_ctx psmc_hip_ctx;
 
 /* Number of visible HIP devices (0 when none / no driver). */
 int psmc_hip_device_count(void);
+/* Compute units of a device (256 on an MI355X; 0 on error). */
+int psmc_hip_device_cus(int device);
 
 /* Replaces hmm_new_par/hmm_new_exp bookkeeping (khmm.c:10-23, 60-69). */
 int psmc_hip_create(psmc_hip_ctx **ctx, int n_states, int device, int mode);
@@ -50,7 +57,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 /* Options.  None is needed: the defaults are what bench.py and the psmc binary run, and the plan adapts to the input
  * (see "auto").  PSMC_HIP_OPTIONS="key=value,key=value" in the environment sets them for every context of a process.
  * Unknown keys and out-of-range values return PSMC_HIP_EINVAL.  Setting any option drops the per-replicate plans a
- * fast-mode batch has learned.  Exact mode reads only "rep_impl" and "batch_bins".
+ * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort" and "exact_refwd".
  *
  *  key             default  meaning
  *  --- plan of the fast mode (tiles, speculation) ---------------------------------------------------------------
@@ -121,15 +128,29 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  --- exact mode ---------------------------------------------------------------------------------------------------
  *  "rep_impl"      auto     row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical); -1 = auto:
  *                           0 when a launch has more than one wave per SIMD (bootstrap batch), else 1
- *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch group; 0 = what fits the free device memory
+ *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch; 0 = what fits the free device memory
+ *  "batch_sort"    1        psmc_hip_estep_batch: the entries -- (replicate, segment) sweeps -- of ALL replicates are dealt to the launches
+ *                           longest first, so that the long trunks share one launch and the others end with their own, shorter, longest
+ *                           entry; 0 = replicate-major order (every launch then lasts as long as the longest trunk).  Bit-identical.
  *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1, 2 = no f table -- the expect pass recomputes the forward sweep in its own
  *                           work-group (bit-identical), so a launch group holds twice the replicates; 2 = two entries per work-group
  *                           (two producer waves, two consumer waves: four entries per compute unit), 1 = one; 0 = f and b tables,
  *                           three kernels.  auto: 2, and only when the tables of all replicates would not fit one launch group
  *
- * Removed in round 3 after losing their A/B (DESIGN.md section 3 keeps the measurements): "count_impl", "kc_warm",
- * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "lanes8", "exact_lds", and the value 1 of "two_phase". */
+ * With 65..128 states "lanes8", "gate", "kc_sub", "kcol_prio" and "ckpt" are accepted and ignored (their kernels are 64-state ones);
+ * beyond 128 states only "batch_bins" and "batch_sort" are read.
+ * Removed in round 3 after losing their A/B (HISTORY.md keeps the measurements): "count_impl", "kc_warm",
+ * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "exact_lds", and the value 1 of "two_phase" ("lanes8" came back in
+ * round 4 with new semantics, see above). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
+
+/* Restrict the kernels of this context to `count` compute units starting at `first` in the bit order of HIP's compute-unit
+ * masks (hipExtStreamCreateWithCUMask; on an MI355X consecutive bits go round the eight XCDs, so a range of 24 is three
+ * units of every XCD); count = 0: the whole device again.  Two contexts with disjoint ranges share a device without ever
+ * sharing a SIMD: psmc_boot runs the main run (README:49-53 of the reference) beside the bootstrap batch like this -- the
+ * main run's 90 sequential sweeps keep a SIMD each, and the batch sizes its launches for the units it was left
+ * (psmc_amd/host/boot.c).  Re-creates the context's streams: call it between E-steps, before the first for preference. */
+int psmc_hip_set_cu_range(psmc_hip_ctx *ctx, int first, int count);
 
 /* Replaces the per-segment hmm_new_data copies of em.c:38-44 / khmm.c:37-45:
  * uploads all segments once; the caller keeps ownership of seq. */
@@ -153,6 +174,11 @@ int psmc_hip_select(psmc_hip_ctx *ctx, int n_sel, const int32_t *seg_idx);
  * and from psmc_hip_group_estep alike.  Exact mode returns the reference's values. */
 int psmc_hip_estep(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, double *A, double *E,
                    double *A0, double *LL, double *chk);
+
+/* Allocate now the tables a single E-step over the loaded segments needs (exact: f, b, s; fast: X and the scale factors),
+ * instead of inside the first psmc_hip_estep: a caller that shares the device with an exact batch (psmc_boot --main) takes
+ * its share BEFORE the batch sizes its own from what is free. */
+int psmc_hip_reserve_tables(psmc_hip_ctx *ctx);
 
 /* Config 4 (bootstrap): n_rep E-steps over ONE loaded segment set in a single call -- replicate r has its own
  * parameters a[r] (n*n), e[r] (2*n), a0[r] (n) and its own multiset sel_idx[sel_off[r] .. sel_off[r+1]) of loaded
@@ -287,74 +313,6 @@ int  psmc_hip_group_route(psmc_hip_group *g, int seg, psmc_hip_ctx **ctx, int *l
  * `stream` like psmc_hip_estep_device */
 int  psmc_hip_estep_factored_device(psmc_hip_ctx *ctx, const double *a, const double *e, const double *a0, void *d_stats,
                                     void *stream);
-
-/* Built-in check of the cross-lane primitives on the device (row replication
- * variants, DPP broadcasts, f64 MFMA layout).  Returns 0 when all agree;
- * a positive bitmask of failed primitives otherwise. */
-int psmc_hip_selftest(int device);
-
-/* Diagnostic: shader cycles per operation of the FP64 building blocks (dependent
- * and independent v_fmac_f64_dpp chains, row replication, f64 MFMA ...), one
- * wave; see psmc_amd/csrc/microbench.hip for the meaning of out[0..13]. */
-int psmc_hip_microbench(int device, double *out, int n);
-
-/* Diagnostic: do the f64 matrix instructions of one wave overlap with the f64 vector instructions of another wave
- * on the same SIMD?  One work-group on one CU, waves go to its four SIMDs round robin; a "matrix wave" issues 64
- * v_mfma_f64_16x16x4 per round, a "vector wave" 1024 v_fma_f64 (8 chains) -- ~4100 cycles of issue either way.
- * out[8*c + w] = shader cycles per round of wave w in configuration c (0 where the configuration has no wave w):
- *   c=0: 4 matrix waves (one per SIMD)      c=1: 4 vector waves         c=2: 8 matrix waves (two per SIMD)
- *   c=3: 8 vector waves                     c=4: waves 0-3 matrix, 4-7 vector (one of each per SIMD)
- *   c=5: even waves matrix, odd waves vector (SIMDs 0 and 2 hold two matrix waves, 1 and 3 two vector waves).
- * Separate pipes would give c=4 the times of c=0 / c=1; one shared pipe gives it their sum.  n >= 48. */
-#define PSMC_HIP_PIPE_PROBE_CONFIGS 6
-int psmc_hip_pipe_probe(int device, double *out, int n);
-
-/* Diagnostic, second edition of the pipe probe: which instructions of one wave overlap with another wave's
- * v_mfma_f64 on the same SIMD?  One work-group of up to 8 waves on one CU (wave w -> SIMD w % 4); kinds8[w] says what
- * wave w issues per round (~4 k cycles of issue when alone): 0 idle, 1 v_mfma_f64_16x16x4 x 64, 2 v_fma_f64 x 1024,
- * 3 v_mov_b32_dpp x 1024, 4 DPP scan levels (2 v_mov_b32_dpp + v_add_f64, as the sweeps' row scans) ~ 1024 in all,
- * 5 ds_read_b128 x 512, 6 s_load_dwordx4 x 256 + v_readlane_b32 x 512, 7 v_add_u32 x 1024, 8 v_fma_f32 x 1024,
- * 9 v_add_f64 x 1024.  out8[w] = shader cycles per round of wave w (0 for idle waves). */
-int psmc_hip_pipe_probe2(int device, const int *kinds8, int rounds, double *out8);
-
-/* Diagnostic: where do the waves of a launch smaller than the device land?  n_kernels (1..4) launches of n_waves waves
- * of the structured sweep step (no memory traffic), in work-groups of waves_per_block (1..4) waves, side by side on
- * streams of their own.  out[3*(k*n_waves_padded + w) + 0..2] = shader cycles per step of wave w of launch k, its
- * HW_ID register (SIMD bits 5:4, CU 11:8, SH 12, SE 15:13) and its XCC_ID; n_waves_padded = n_waves rounded up to a
- * multiple of waves_per_block.  *ms_out = the slowest launch.  A shard-sized E-step has fewer waves than the device
- * has SIMDs: if they are stacked on the same SIMDs, every step costs a multiple of its latency. */
-int psmc_hip_place_probe(int device, int n_waves, int waves_per_block, int n_kernels, int steps, double *out, double *ms_out);
-
-/* Diagnostic: an 8-byte-per-lane streaming copy (reads and writes 8*n_doubles bytes, 5
- * launches) to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the access
- * width the kernels use; *ms_out = average duration of one launch. */
-int psmc_hip_stream_probe(int device, long long n_doubles, double *ms_out);
-
-/* Diagnostic: what plain streaming kernels reach on this device with 16-byte accesses over two
- * buffers of `bytes` each: gbps_out[0] fill, [1] read, [2] copy (read + write), [3] the store
- * pattern of the structured sweeps (four 512-byte-per-step streams per wave).  GB/s. */
-int psmc_hip_hbm_probe(int device, long long bytes, double *gbps_out);
-
-/* Diagnostic: the structured sweep step (no memory traffic) on n_waves wavefronts at once, `steps`
- * steps each: out[0] kernel ms, [1] mean / [2] max shader cycles per step of a wave, [3] mean shader
- * clock in MHz the waves saw -- how far FP64 issue and clocks hold up when the whole device is busy.
- */
-int psmc_hip_load_probe(int device, int n_waves, int steps, double *out);
-
-/* Diagnostic: psmc_hip_load_probe with the table stores of a forward sweep: each wave appends 512 bytes per tile and
- * step during the last `store_steps` of its `steps` steps.  mode 1: two 16-byte stores per lane and step (what
- * k_fwd_struct does), 2: the same bytes written as 2 KB per tile every 4th step.  out[0..3] as psmc_hip_load_probe,
- * out[4] = GB/s of the stores over the whole kernel. */
-int psmc_hip_load_probe_st(int device, int n_waves, int steps, int store_steps, int mode, double *out);
-
-/* Wall time in ms of the last E-step measured with HIP events on the streams the
- * kernels ran on.  Exact mode: [0] total, [1] forward, [2] backward, [3] expect,
- * [4] host-copy tail.  Fast mode: [0] total, [1] both sweep chains (speculate +
- * repair rounds; forward and backward run concurrently), [2] LL + redo of the
- * counts after the chains, [3] the full expect kernel alone (fused back half: its one or two
- * launches, summed), [4] reductions, [5] the
- * speculative forward sweep kernel alone, [6] the speculative backward sweep alone. */
-int psmc_hip_last_timing(psmc_hip_ctx *ctx, double ms[7]);
 
 #ifdef __cplusplus
 }

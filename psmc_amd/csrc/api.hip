@@ -12,6 +12,57 @@ __attribute__((constructor)) static void psmc_hip_more_queues() { setenv("GPU_MA
 
 static void destroy_kids(psmc_hip_ctx *c);
 
+// The five streams of a context, on the whole device or -- psmc_hip_set_cu_range -- masked to a range of its compute units.
+static int make_streams(psmc_hip_ctx *c)
+{
+	hipStream_t *st[5] = {&c->stream, &c->stream2, &c->stream3, &c->stream4, &c->stream5};
+	for (hipStream_t *s : st) if (*s) { (void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr; }
+	if (c->cu_count <= 0) {
+		for (hipStream_t *s : st) if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) return PSMC_HIP_EDEVICE;
+		return 0;
+	}
+	int cus = 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) return PSMC_HIP_EDEVICE;
+	if (c->cu_first < 0 || c->cu_first + c->cu_count > cus) return PSMC_HIP_EINVAL;
+	std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+	for (int i = c->cu_first; i < c->cu_first + c->cu_count; ++i) mask[(size_t)i >> 5] |= 1u << (i & 31);
+	for (hipStream_t *s : st) if (hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()) != hipSuccess) return PSMC_HIP_EDEVICE;
+	return 0;
+}
+
+extern "C" int psmc_hip_device_cus(int device)
+{
+	int cus = 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return cus;
+}
+
+extern "C" int psmc_hip_set_cu_range(psmc_hip_ctx *c, int first, int count)
+{
+	if (!c || first < 0 || count < 0) return fail(c, PSMC_HIP_EINVAL, "set_cu_range: bad argument");
+	if (c->parent) return fail(c, PSMC_HIP_EINVAL, "set_cu_range: not on a replicate context");
+	HIPCHK(c, hipSetDevice(c->device));
+	destroy_kids(c); // replicate contexts share the parent's streams
+	const int of = c->cu_first, oc = c->cu_count;
+	c->cu_first = count > 0 ? first : 0; c->cu_count = count;
+	int rc = make_streams(c);
+	if (rc) { // leave a usable context behind
+		c->cu_first = of; c->cu_count = oc;
+		if (make_streams(c) != 0) { c->cu_first = c->cu_count = 0; (void)make_streams(c); }
+		return fail(c, rc, "set_cu_range: cannot create the masked streams (range outside the device?)", hipGetLastError());
+	}
+	return PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_reserve_tables(psmc_hip_ctx *c)
+{
+	if (!c) return PSMC_HIP_EINVAL;
+	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "reserve_tables: no segments loaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	const bool exact = c->mode == PSMC_HIP_MODE_EXACT || c->ns > 128;
+	return ensure_tables(c, exact, 0, true);
+}
+
 extern "C" int psmc_hip_device_count(void)
 {
 	int n = 0;
@@ -40,24 +91,22 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 	*out = nullptr;
 	if (n_states < 1) return PSMC_HIP_EINVAL;
 	if (mode != PSMC_HIP_MODE_EXACT && mode != PSMC_HIP_MODE_FAST) return PSMC_HIP_EINVAL;
-	if (n_states > 128) return PSMC_HIP_ENOTSUP; // fast mode beyond 64 states: structured matrices only (checked per E-step)
+	if (n_states > PSMC_HIP_MAX_STATES) return PSMC_HIP_ENOTSUP; // one thread per state in a work-group of the wide exact kernels (estep_wide.hip)
 	int nd = psmc_hip_device_count();
 	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
 	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
 	psmc_hip_ctx *c = new (std::nothrow) psmc_hip_ctx();
 	if (!c) return PSMC_HIP_ENOMEM;
-	c->n = n_states; c->ns = n_states > 64 ? 128 : 64; c->device = device; c->mode = mode;
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	if (hipStreamCreateWithFlags(&c->stream5, hipStreamNonBlocking) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
+	// states padded to 64 or 128 (one or two per lane); beyond that to the next multiple of 64: the wide EXACT kernels, whatever the mode
+	c->n = n_states; c->ns = n_states > 128 ? (n_states + 63) / 64 * 64 : (n_states > 64 ? 128 : 64); c->device = device; c->mode = mode;
+	c->par_len = c->ns > 128 ? 2 * (size_t)c->ns * c->ns + 4 * (size_t)c->ns : psmc_hip_ctx::PAR_LEN;
+	if (make_streams(c) != 0) { psmc_hip_destroy(c); return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 14; ++i)
 		if (hipEventCreate(&c->evx[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
 	for (int i = 0; i < 10; ++i)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return PSMC_HIP_EDEVICE; }
-	if (hipHostMalloc((void **)&c->h_par, psmc_hip_ctx::PAR_LEN * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-	    hipMalloc((void **)&c->d_par, psmc_hip_ctx::PAR_LEN * sizeof(double)) != hipSuccess) {
+	if (hipHostMalloc((void **)&c->h_par, c->par_len * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+	    hipMalloc((void **)&c->d_par, c->par_len * sizeof(double)) != hipSuccess) {
 		psmc_hip_destroy(c);
 		return PSMC_HIP_ENOMEM;
 	}
@@ -164,7 +213,8 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
 	else if (k == "share_learn") { c->share_learn = v != 0 ? 1 : 0; }
-	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; }
+	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; c->reserved_refwd = -1; }
+	else if (k == "batch_sort") { c->batch_sort = v != 0 ? 1 : 0; }
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
@@ -179,6 +229,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 int set_segments_common(psmc_hip_ctx *c, int n_seg, const int32_t *L)
 {
 	destroy_kids(c); // batch children hold plans over the previous segments
+	c->reserved_refwd = -1;
 	c->n_seg = n_seg;
 	c->L.assign(L, L + n_seg);
 	int rc;
@@ -307,6 +358,18 @@ static void fill_kcc(int S, const double *sp, const double *e3 /* 3 rows of S */
 bool fill_params(const psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *dst)
 {
 	const int n = c->n;
+	if (c->ns > 128) { // wide exact kernels: a | aT | e(3) | a0, stride S (estep_wide.hip)
+		const size_t S = (size_t)c->ns;
+		double *pa = dst, *pt = pa + S * S, *pe = pt + S * S, *pa0 = pe + 3 * S;
+		memset(pa, 0, c->par_len * sizeof(double));
+		for (int k = 0; k < n; ++k) {
+			for (int l = 0; l < n; ++l) { pa[k * S + l] = a[(size_t)k * n + l]; pt[l * S + k] = a[(size_t)k * n + l]; }
+			pe[k] = e[k]; pe[S + k] = e[n + k];
+			pa0[k] = a0[k];
+		}
+		for (size_t k = 0; k < S; ++k) pe[2 * S + k] = 1.0; // khmm.c:21
+		return false;
+	}
 	if (c->ns == 128) { // a | aT | e(3) | a0, stride 128; the e*a products are formed on the device
 		double *pa = dst, *pt = pa + 16384, *pe = pt + 16384, *pa0 = pe + 384;
 		memset(pa, 0, psmc_hip_ctx::PAR_LEN * sizeof(double));
@@ -346,19 +409,12 @@ int stage_params(psmc_hip_ctx *c, const double *a, const double *e, const double
 {
 	HIPCHK(c, hipStreamSynchronize(st)); // previous async copy out of the pinned staging buffer
 	c->use_struct = fill_params(c, a, e, a0, c->h_par);
-	HIPCHK(c, hipMemcpyAsync(c->d_par, c->h_par, psmc_hip_ctx::PAR_LEN * sizeof(double), hipMemcpyHostToDevice, st));
+	HIPCHK(c, hipMemcpyAsync(c->d_par, c->h_par, c->par_len * sizeof(double), hipMemcpyHostToDevice, st));
 	return 0;
 }
 
-int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins, bool need_f)
+static int ensure_tables_once(psmc_hip_ctx *c, bool need_b, int64_t bins, bool need_f)
 {
-	if (c->parent) { // a batch child works in its parent's tables (same segments, one E-step at a time)
-		int rc = ensure_tables(c->parent, need_b);
-		c->d_f = c->parent->d_f; c->d_b = c->parent->d_b; c->d_s = c->parent->d_s; c->d_sb = c->parent->d_sb;
-		c->tab_bins = c->parent->tab_bins; c->have_b = c->parent->have_b;
-		return rc;
-	}
-	const int64_t bins = std::max(c->total, want_bins) + 128;
 	int rc;
 	if (c->tab_bins < bins) { // grow: everything goes, and comes back as needed
 		if (c->d_f) { (void)hipFree(c->d_f); c->d_f = nullptr; }
@@ -376,6 +432,31 @@ int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins, bool need_f)
 		c->have_b = true;
 	}
 	return 0;
+}
+
+int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins, bool need_f)
+{
+	if (c->parent) { // a batch child works in its parent's tables (same segments, one E-step at a time)
+		int rc = ensure_tables(c->parent, need_b);
+		c->d_f = c->parent->d_f; c->d_b = c->parent->d_b; c->d_s = c->parent->d_s; c->d_sb = c->parent->d_sb;
+		c->tab_bins = c->parent->tab_bins; c->have_b = c->parent->have_b;
+		return rc;
+	}
+	const int64_t bins = std::max(c->total, want_bins) + 128;
+	int rc = ensure_tables_once(c, need_b, bins, need_f);
+	if (rc == PSMC_HIP_ENOMEM && c->tab_bins > bins) {
+		// The tables were sized for another layout -- an exact batch without the f table holds twice the bins of one with it -- and the
+		// table this call adds does not fit beside them at that size (a single E-step, decode or get_tables after such a
+		// batch).  Start over at what THIS call needs.
+		if (c->d_f) { (void)hipFree(c->d_f); c->d_f = nullptr; }
+		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
+		if (c->d_s) { (void)hipFree(c->d_s); c->d_s = nullptr; }
+		if (c->d_sb) { (void)hipFree(c->d_sb); c->d_sb = nullptr; }
+		c->have_b = false; c->tab_bins = 0; c->reserved_refwd = -1;
+		(void)hipGetLastError();
+		rc = ensure_tables_once(c, need_b, bins, need_f);
+	}
+	return rc;
 }
 
 // fused backward sweep + counts: structured matrices; 64 states, or 128 with "fuse128"
@@ -405,6 +486,10 @@ void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const double *
 	if (c->ns == 128) {
 		p.d_aeT = pb + 16384; p.d_e = pb + 32768; p.d_a0 = pb + 32768 + 384;
 		p.d_re = pb + psmc_hip_ctx::RE128_OFF; p.d_sp = pb + psmc_hip_ctx::SP128_OFF; p.d_kcc = pb + psmc_hip_ctx::KCC128_OFF;
+	} else if (c->ns > 128) { // a | aT | e(3) | a0 (fill_params); exact kernels only
+		const size_t S = (size_t)c->ns;
+		p.d_aeT = pb + S * S; p.d_e = pb + 2 * S * S; p.d_a0 = pb + 2 * S * S + 3 * S;
+		p.d_re = p.d_sp = p.d_kcc = nullptr; p.structured = 0; p.fused = 0; p.ckpt = 0;
 	}
 	p.d_obs = c->d_obs; p.d_seg_off = c->d_seg_off; p.d_seg_len = c->d_seg_len;
 	p.d_work = c->d_work; p.n_work = (int)c->work.size();
@@ -505,7 +590,7 @@ extern "C" int psmc_hip_estep_segments(psmc_hip_ctx *c, const double *a, const d
                                        double *segA, double *segE, double *segA0, double *segLL, double *chk)
 {
 	if (!c || !a || !e || !a0) return fail(c, PSMC_HIP_EINVAL, "estep_segments: bad argument");
-	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "estep_segments: exact mode only");
+	if (c->mode != PSMC_HIP_MODE_EXACT && c->ns <= 128) return fail(c, PSMC_HIP_ENOTSUP, "estep_segments: exact mode only");
 	int rc = run_exact(c, a, e, a0);
 	if (rc) return rc;
 	const int n = c->n, ns = (int)c->sel.size();
@@ -560,7 +645,8 @@ extern "C" int psmc_hip_estep(psmc_hip_ctx *c, const double *a, const double *e,
                               double *A0, double *LL, double *chk)
 {
 	if (!c || !a || !e || !a0) return fail(c, PSMC_HIP_EINVAL, "estep: bad argument");
-	if (c->mode == PSMC_HIP_MODE_EXACT) return estep_exact(c, a, e, a0, A, E, A0, LL, chk);
+	// beyond 128 states there is no fast path: a fast-mode context runs the wide exact kernels (inside every fast tolerance)
+	if (c->mode == PSMC_HIP_MODE_EXACT || c->ns > 128) return estep_exact(c, a, e, a0, A, E, A0, LL, chk);
 	HIPCHK(c, hipSetDevice(c->device));
 	int rc = ensure_fast_buffers(c); // d_stats must exist before the first enqueue (the plan follows stage_params)
 	if (rc) return rc;
@@ -596,14 +682,15 @@ extern "C" int psmc_hip_get_tables(psmc_hip_ctx *c, int seg, double *f, double *
 extern "C" int psmc_hip_decode(psmc_hip_ctx *c, int seg, int32_t *path, double *maxp)
 {
 	if (!c || seg < 0 || seg >= c->n_seg || !path) return fail(c, PSMC_HIP_EINVAL, "decode: bad argument");
-	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "decode: exact mode only");
+	if (c->mode != PSMC_HIP_MODE_EXACT && c->ns <= 128) return fail(c, PSMC_HIP_ENOTSUP, "decode: exact mode only");
 	if (!c->d_f || !c->have_b || c->tables_batch) return fail(c, PSMC_HIP_ESTATE, "decode: no single E-step yet");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->L[seg];
 	int32_t *dp = nullptr; double *dm = nullptr;
 	if (hipMalloc((void **)&dp, sizeof(int32_t) * (size_t)L) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipMalloc");
 	if (hipMalloc((void **)&dm, sizeof(double) * (size_t)L) != hipSuccess) { (void)hipFree(dp); return fail(c, PSMC_HIP_ENOMEM, "hipMalloc"); }
-	int rc = launch_post_decode(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], L, c->n, c->ns, dp, dm);
+	int rc = c->ns > 128 ? launch_post_decode_wide(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], L, c->n, c->ns, dp, dm)
+	                     : launch_post_decode(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], L, c->n, c->ns, dp, dm);
 	hipError_t e1 = hipMemcpyAsync(path, dp, sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, c->stream);
 	hipError_t e2 = maxp ? hipMemcpyAsync(maxp, dm, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
 	hipError_t e3 = hipStreamSynchronize(c->stream);
@@ -615,15 +702,16 @@ extern "C" int psmc_hip_decode(psmc_hip_ctx *c, int seg, int32_t *path, double *
 extern "C" int psmc_hip_posterior(psmc_hip_ctx *c, int seg, double *post, double *recomb)
 {
 	if (!c || seg < 0 || seg >= c->n_seg || (!post && !recomb)) return fail(c, PSMC_HIP_EINVAL, "posterior: bad argument");
-	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "posterior: exact mode only");
+	if (c->mode != PSMC_HIP_MODE_EXACT && c->ns <= 128) return fail(c, PSMC_HIP_ENOTSUP, "posterior: exact mode only");
 	if (!c->d_f || !c->have_b || c->tables_batch) return fail(c, PSMC_HIP_ESTATE, "posterior: no single E-step yet");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->L[seg], n = c->n;
 	double *dp = nullptr, *dr = nullptr;
 	if (post && hipMalloc((void **)&dp, sizeof(double) * (size_t)L * n) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipMalloc");
 	if (recomb && hipMalloc((void **)&dr, sizeof(double) * (size_t)L) != hipSuccess) { if (dp) (void)hipFree(dp); return fail(c, PSMC_HIP_ENOMEM, "hipMalloc"); }
-	const double *d_e = c->ns == 128 ? c->d_par + 32768 : c->d_par + 4 * 4096;
-	int rc = launch_post_full(c->stream, c->d_par, d_e, c->d_obs, c->d_f, c->d_b, c->d_s, c->off[seg], L, n, c->ns, dp, dr);
+	const double *d_e = c->ns > 128 ? c->d_par + 2 * (size_t)c->ns * c->ns : (c->ns == 128 ? c->d_par + 32768 : c->d_par + 4 * 4096);
+	int rc = c->ns > 128 ? launch_post_full_wide(c->stream, c->d_par, d_e, c->d_obs, c->d_f, c->d_b, c->d_s, c->off[seg], L, n, c->ns, dp, dr)
+	                     : launch_post_full(c->stream, c->d_par, d_e, c->d_obs, c->d_f, c->d_b, c->d_s, c->off[seg], L, n, c->ns, dp, dr);
 	hipError_t e1 = post ? hipMemcpyAsync(post, dp, sizeof(double) * (size_t)L * n, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
 	hipError_t e2 = recomb ? hipMemcpyAsync(recomb, dr, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
 	hipError_t e3 = hipStreamSynchronize(c->stream);
@@ -636,7 +724,7 @@ extern "C" int psmc_hip_posterior(psmc_hip_ctx *c, int seg, double *post, double
 extern "C" int psmc_hip_post_counts(psmc_hip_ctx *c, int seg, const int32_t *cnt1, int32_t l, int32_t n_cnt, double *cnt)
 {
 	if (!c || seg < 0 || seg >= c->n_seg || !cnt || l < 0 || n_cnt < 1 || (l > 0 && !cnt1)) return fail(c, PSMC_HIP_EINVAL, "post_counts: bad argument");
-	if (c->mode != PSMC_HIP_MODE_EXACT) return fail(c, PSMC_HIP_ENOTSUP, "post_counts: exact mode only");
+	if (c->mode != PSMC_HIP_MODE_EXACT && c->ns <= 128) return fail(c, PSMC_HIP_ENOTSUP, "post_counts: exact mode only");
 	if (!c->d_f || !c->have_b || c->tables_batch) return fail(c, PSMC_HIP_ESTATE, "post_counts: no single E-step yet");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int L = c->L[seg], n = c->n, min_l = L < l ? L : l;
@@ -646,23 +734,11 @@ extern "C" int psmc_hip_post_counts(psmc_hip_ctx *c, int seg, const int32_t *cnt
 	if (hipMalloc((void **)&dc, sizeof(double) * (size_t)n * n_cnt) != hipSuccess) { (void)hipFree(d1); return fail(c, PSMC_HIP_ENOMEM, "hipMalloc"); }
 	hipError_t e0 = hipMemcpyAsync(d1, cnt1, sizeof(int32_t) * (size_t)min_l * n_cnt, hipMemcpyHostToDevice, c->stream);
 	hipError_t e1 = hipMemcpyAsync(dc, cnt, sizeof(double) * (size_t)n * n_cnt, hipMemcpyHostToDevice, c->stream);
-	int rc = launch_post_counts(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], min_l, d1, n_cnt, n, c->ns, dc);
+	int rc = c->ns > 128 ? launch_post_counts_wide(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], min_l, d1, n_cnt, n, c->ns, dc)
+	                     : launch_post_counts(c->stream, c->d_f, c->d_b, c->d_s, c->off[seg], min_l, d1, n_cnt, n, c->ns, dc);
 	hipError_t e2 = hipMemcpyAsync(cnt, dc, sizeof(double) * (size_t)n * n_cnt, hipMemcpyDeviceToHost, c->stream);
 	hipError_t e3 = hipStreamSynchronize(c->stream);
 	(void)hipFree(d1); (void)hipFree(dc);
 	if (rc || e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(c, PSMC_HIP_EDEVICE, "post_counts");
-	return PSMC_HIP_OK;
-}
-
-extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[7])
-{
-	if (!c || !ms) return PSMC_HIP_EINVAL;
-	if (!c->timing_valid) {
-		HIPCHK(c, hipSetDevice(c->device));
-		if (hipEventSynchronize(c->ev[4]) != hipSuccess) return fail(c, PSMC_HIP_ESTATE, "last_timing: nothing recorded");
-		collect_timing(c);
-		if (!c->timing_valid) return fail(c, PSMC_HIP_ESTATE, "last_timing: events incomplete");
-	}
-	for (int i = 0; i < 7; ++i) ms[i] = c->last_ms[i];
 	return PSMC_HIP_OK;
 }

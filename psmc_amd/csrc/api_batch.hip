@@ -28,10 +28,14 @@ static int batch_selections(psmc_hip_ctx *c, int n_rep, const int32_t *sel_off, 
 	return 0;
 }
 
-// Table bins an exact batch may use: "batch_bins", or 0.9 of the device memory that is free or already in this context's tables.
-// (Round 3 took 0.9 of the free memory PLUS all of what the context held: the second call saw a larger capacity than the first,
-// re-planned its groups and re-allocated 250 GB of tables -- 8 s; profiles/r04_boot_breakdown.txt.)
-static int batch_capacity(psmc_hip_ctx *c, int64_t *cap, bool refwd)
+// Table bins ONE launch of an exact batch may use: "batch_bins", or what 0.9 of the device memory that is free or already in this
+// context's tables holds.  (Round 3 took 0.9 of the free memory PLUS all of what the context held: the second call saw a larger
+// capacity than the first, re-planned its groups and re-allocated 250 GB of tables -- 8 s; profiles/r04_boot_breakdown.txt.)
+// all_bins (> 0: known) = the table bins of every entry of the call: a batch without the f table whose entries do not fit one
+// launch keeps the scale factors of ALL of them in a call-wide table (one forward pass, see below) -- 8 bytes per bin of the whole
+// call, taken out of the budget BEFORE the per-launch capacity is computed (it was a fixed 1/64 of the capacity, right
+// for four launches and too little beyond seven).
+static int batch_capacity(psmc_hip_ctx *c, int64_t *cap, bool refwd, int64_t all_bins)
 {
 	*cap = c->batch_bins;
 	if (*cap > 0) return 0;
@@ -39,25 +43,34 @@ static int batch_capacity(psmc_hip_ctx *c, int64_t *cap, bool refwd)
 	HIPCHK(c, hipMemGetInfo(&fr, &tot));
 	const double S = (double)c->ns, per_bin = S * 8.0 * (refwd ? 1.0 : 2.0) + 8.0;
 	const double held = (double)c->tab_bins * (S * 8.0 * ((c->have_b ? 1.0 : 0.0) + (c->d_f ? 1.0 : 0.0)) + 8.0 + (c->d_sb ? 8.0 : 0.0));
-	// (the call-wide scale-factor table of a batch without the f table stays allocated between calls: count it as free, or the second
-	// call would see a smaller capacity than the first and cut other groups)
-	*cap = (int64_t)(((double)fr + held + (double)c->s_all_cap * 8.0) * 0.9 / per_bin) - 256;
-	if (refwd) *cap -= *cap / 64; // ... and leave room for it: 8 of every 520 bytes
+	// (the call-wide scale-factor table stays allocated between calls: count it as free, or the second call would see a smaller
+	// capacity than the first and cut other launches)
+	double budget = ((double)fr + held + (double)c->s_all_cap * 8.0) * 0.9;
+	*cap = (int64_t)(budget / per_bin) - 256;
+	if (refwd && (all_bins <= 0 || all_bins > *cap)) { // several launches: room for the call-wide scale factors
+		const double s_all = all_bins > 0 ? (double)all_bins * 8.0 : budget / 65.0; // unknown size: what four launches need
+		budget -= s_all;
+		*cap = (int64_t)(budget / per_bin) - 256;
+	}
 	if (*cap < 1) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: no device memory left for tables");
 	return 0;
 }
 
 // Does this batch run without the f table (k_expect_exact_rf: 64 states)?  "exact_refwd" 1 / 0: yes / no.  Auto: only when the f and b
-// tables of all its replicates (need_bins; <= 0: unknown) would NOT fit one launch group -- the recompute pass runs at the forward
-// sweep's latency (0.83 instead of 0.45 us per bin of the longest segment), which pays when it halves the number of groups (100
-// replicates of a genome: 11.9 against 13.2 s per EM iteration) and costs when one group would have done (16 replicates: 2.4 against 1.9 s).
+// tables of all its entries (need_bins; <= 0: unknown) would NOT fit one launch -- the recompute pass runs at the forward sweep's
+// latency (0.83 instead of 0.45 us per bin of the longest segment), which pays when it halves the number of launches (100
+// replicates of a genome: 11.9 against 13.2 s per EM iteration) and costs when one would have done (16 replicates: 2.4 against 1.9 s).
+// The decision is made ONCE per table reservation: psmc_hip_reserve_batch_tables decides from the caller's upper
+// bound and sizes the tables for it; a batch that follows keeps that decision instead of deciding again from its own (smaller)
+// count of unique bins -- two different answers meant an f table allocated at the b-only capacity: out of memory.
 static int batch_refwd(psmc_hip_ctx *c, int64_t need_bins, bool *refwd)
 {
 	*refwd = false;
 	if (c->ns != 64 || c->exact_refwd == 0) return 0;
 	if (c->exact_refwd >= 1) { *refwd = true; return 0; }
+	if (c->reserved_refwd >= 0) { *refwd = c->reserved_refwd != 0; return 0; }
 	int64_t cap_tab = 0;
-	int rc = batch_capacity(c, &cap_tab, false);
+	int rc = batch_capacity(c, &cap_tab, false, need_bins);
 	if (rc) return rc;
 	*refwd = need_bins <= 0 || need_bins > cap_tab;
 	return 0;
@@ -66,85 +79,111 @@ static int batch_refwd(psmc_hip_ctx *c, int64_t need_bins, bool *refwd)
 extern "C" int psmc_hip_reserve_batch_tables(psmc_hip_ctx *c, int64_t max_bins)
 {
 	if (!c) return PSMC_HIP_EINVAL;
-	if (c->mode != PSMC_HIP_MODE_EXACT) return PSMC_HIP_OK; // fast mode keeps one replicate's tables: nothing to reserve
+	if (c->mode != PSMC_HIP_MODE_EXACT && c->ns <= 128) return PSMC_HIP_OK; // fast mode keeps one replicate's tables: nothing to reserve
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "reserve_batch_tables: no segments loaded");
 	int64_t cap = 0;
 	bool refwd = false;
+	c->reserved_refwd = -1;
 	int rc = batch_refwd(c, max_bins, &refwd);
-	if (rc || (rc = batch_capacity(c, &cap, refwd))) return rc;
-	return ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !refwd);
+	if (rc || (rc = batch_capacity(c, &cap, refwd, max_bins))) return rc;
+	rc = ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !refwd);
+	if (rc == 0 && c->exact_refwd < 0) c->reserved_refwd = refwd ? 1 : 0; // (a fixed "exact_refwd" needs no memory)
+	return rc;
 }
 
-// Exact mode: the sweeps of ALL replicates of a group in one launch each (forward, backward, expect), replicate-major;
-// every (replicate, unique segment) entry has its own table slot and reads its replicate's parameter block.  Groups =
-// as many consecutive replicates as fit the table memory.  Statistics are added per replicate in selection order on
-// the host, exactly like psmc_hip_estep: bit-identical to n_rep separate calls.
+// Exact mode.  An ENTRY is one (replicate, unique segment) pair: one sequential sweep over that segment with that replicate's
+// parameters, into a table slot of its own.  Round 4 cut the call into groups of consecutive replicates; every group then held
+// a copy of the longest trunk and every launch lasted as long as that trunk (the sweeps are sequential: one wave per entry), with
+// 30 % of the slot time idle beside the shorter ones.  Round 5 schedules ENTRIES: the entries of a replicate are sorted by
+// length and cut into blocks of `align` (the sweeps of a work-group share one parameter set in LDS / registers), the blocks of
+// all replicates are sorted by length, longest first, and dealt to launches that hold what the table memory and the wave slots
+// (four entries per compute unit of this context's share of the device) allow.  The long trunks then share ONE launch and the
+// others end when their -- shorter -- longest entry does (utils/splitfa.c: most trunks are exactly 500 k bins, the tails up to
+// 750 k).  "batch_sort" = 0 keeps the replicate-major order (A/B).  Per-entry statistics stay on the host until the last launch;
+// they are added per replicate in selection order exactly like psmc_hip_estep does: bit-identical to n_rep separate calls.
+namespace {
+struct Block { int rep; int first, n; int64_t bins; int32_t maxL; }; // entries ord[rep][first .. first + n) of a replicate
+}
 static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0, const int32_t *sel_off,
                        const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
 {
 	const int n = c->n;
-	const size_t S = (size_t)c->ns, PL = psmc_hip_ctx::PAR_LEN;
+	const size_t S = (size_t)c->ns, PL = c->par_len;
 	std::vector<RepSel> reps;
 	int rc;
 	if ((rc = batch_selections(c, n_rep, sel_off, sel_idx, reps))) return rc;
-	// how many table bins fit (batch_capacity: the same answer in every call, whatever the context holds already)
-	int64_t cap = 0, all_bins = 0; // all_bins: what ONE group of all replicates would need
+	int64_t cap = 0, all_bins = 0; // all_bins: what ONE launch of all entries would need
 	for (const RepSel &R : reps) all_bins += R.bins;
 	bool refwd = false;
-	if ((rc = batch_refwd(c, all_bins, &refwd)) || (rc = batch_capacity(c, &cap, refwd))) return rc;
+	if ((rc = batch_refwd(c, all_bins, &refwd)) || (rc = batch_capacity(c, &cap, refwd, all_bins))) return rc;
 	size_t n_entries_all = 0;
 	for (const RepSel &R : reps) n_entries_all += R.work.size();
-	const int align = c->ns == 128 ? (n_entries_all <= 256 ? 1 : (n_entries_all <= 512 ? 2 : 4)) : 4; // sweeps per block sharing one parameter set in LDS
+	// sweeps per work-group sharing one parameter set: four with 64 states (k_bwd_exact, k_expect_exact_rf2), up to four with
+	// 65..128 (the matrix in LDS: fewer while the device has idle compute units), one beyond (estep_wide.hip)
+	const int align = c->ns > 128 ? 1 : (c->ns == 128 ? (n_entries_all <= 256 ? 1 : (n_entries_all <= 512 ? 2 : 4)) : 4);
 	c->last_batch_groups = 0;
-	// Entries per group.  An entry is one sequential sweep over its segment, and the replicates of a bootstrap are made of equal trunks
-	// (utils/splitfa.c), so a launch runs in ROUNDS: the backward sweep has one wave slot per SIMD before waves share one, the recompute
-	// pass (k_expect_exact_rf2) four entries per compute unit -- both 4 x CUs entries.  What memory allows beyond a whole number of
-	// rounds runs as a nearly empty extra round (1088 entries on 1024 slots: two rounds, measured 1.85 s against 0.95 s for 1024), so
-	// a group is cut at the last full round it can hold.
+	auto padded_len = [&](int32_t sg) { return ((int64_t)c->L[sg] + 63) & ~(int64_t)63; };
+	// Entries per launch: the backward sweep has one wave slot per SIMD before waves share one, the recompute pass
+	// (k_expect_exact_rf2) four entries per compute unit -- both 4 x CUs entries; a fifth entry on a unit waits for a whole
+	// round (1088 entries on 1024 slots: measured 1.85 s against 0.95 s for 1024).  Only a call that needs several launches is cut.
 	size_t ent_cap = SIZE_MAX;
-	if (refwd && c->ns == 64 && n_entries_all > 0 && all_bins > cap) {
-		int cus = 0;
-		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
-		const size_t slots = (size_t)cus * (c->exact_refwd == 1 ? 2 : 4);
-		const size_t fit = (size_t)((double)cap / ((double)all_bins / (double)n_entries_all)); // entries the table memory holds
-		if (fit >= slots) ent_cap = fit / slots * slots;
+	if (refwd && all_bins > cap) {
+		int cus = c->cu_count;
+		if (cus <= 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0)) { (void)hipGetLastError(); cus = 256; }
+		ent_cap = (size_t)cus * (c->exact_refwd == 1 ? 2 : 4);
 	}
-	// The work list of the whole call, replicate-major, every replicate padded to `align` entries: entry -> segment, replicate (= its
-	// parameter block), offset of its tables inside ITS launch group, offset of its scale factors in the call-wide s table.  Groups =
-	// as many consecutive replicates as fit the table memory: slices [g_first[g], g_first[g+1]) of that list.
-	std::vector<int32_t> wseg, wpar; std::vector<int64_t> wtab, wtab_s; std::vector<int> first(n_rep + 1, 0), g_rep;
-	std::vector<double> lk;
+	// blocks of every replicate
+	std::vector<std::vector<int32_t>> ord(n_rep); // work indices of a replicate, longest first ("batch_sort") or as selected
+	std::vector<Block> blocks;
+	for (int r = 0; r < n_rep; ++r) {
+		const RepSel &R = reps[r];
+		ord[r].resize(R.work.size());
+		for (size_t i = 0; i < R.work.size(); ++i) ord[r][i] = (int32_t)i;
+		if (c->batch_sort) std::stable_sort(ord[r].begin(), ord[r].end(), [&](int32_t x, int32_t y) { return c->L[R.work[x]] > c->L[R.work[y]]; });
+		for (int f0 = 0; f0 < (int)ord[r].size(); f0 += align) {
+			Block b = {r, f0, std::min(align, (int)ord[r].size() - f0), 0, 0};
+			for (int i = 0; i < b.n; ++i) { const int32_t sg = R.work[ord[r][f0 + i]]; b.bins += padded_len(sg); b.maxL = std::max(b.maxL, c->L[sg]); }
+			if (b.bins > cap) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: the tables of one block of entries do not fit the device memory (batch_bins)");
+			blocks.push_back(b);
+		}
+	}
+	if (c->batch_sort) std::stable_sort(blocks.begin(), blocks.end(), [](const Block &x, const Block &y) { return x.maxL > y.maxL; });
+	// The work list of the whole call in launch order, every block padded to `align` entries: entry -> segment, replicate (= its
+	// parameter block), offset of its tables inside ITS launch, offset of its scale factors in the call-wide s table.
+	std::vector<int32_t> wseg, wpar; std::vector<int64_t> wtab, wtab_s; std::vector<int> l_first; // l_first: first entry of every launch
+	std::vector<std::vector<int>> ent_of(n_rep); // [replicate][work index] -> entry
+	for (int r = 0; r < n_rep; ++r) ent_of[r].assign(reps[r].work.size(), -1);
 	int64_t worst = 0; size_t worst_entries = 0;
 	{
-		int64_t s_run = 0;
-		for (int r0 = 0; r0 < n_rep;) {
-			if (reps[r0].bins > cap) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: the tables of one replicate do not fit the device memory (batch_bins)");
-			int r1 = r0; int64_t bins = 0; size_t ents = 0;
-			auto padded = [&](int r) { return (reps[r].work.size() + align - 1) / align * align; };
-			while (r1 < n_rep && bins + reps[r1].bins <= cap && (r1 == r0 || ents + padded(r1) <= ent_cap)) { bins += reps[r1].bins; ents += padded(r1); ++r1; }
-			g_rep.push_back(r0);
-			int64_t run = 0; const size_t e0 = wseg.size();
-			for (int r = r0; r < r1; ++r) {
-				first[r] = (int)wseg.size();
-				for (int32_t sg : reps[r].work) { wseg.push_back(sg); wpar.push_back(r); wtab.push_back(run); wtab_s.push_back(s_run + run); run += ((int64_t)c->L[sg] + 63) & ~(int64_t)63; }
-				while (wseg.size() % align) { wseg.push_back(-1); wpar.push_back(r); wtab.push_back(0); wtab_s.push_back(0); }
+		int64_t s_run = 0, run = 0; size_t e0 = 0;
+		l_first.push_back(0);
+		for (const Block &b : blocks) {
+			if (wseg.size() > e0 && (run + b.bins > cap || (wseg.size() - e0) + (size_t)align > ent_cap)) { // next launch
+				worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
+				s_run += run; run = 0; e0 = wseg.size(); l_first.push_back((int)e0);
 			}
-			s_run += run;
-			worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
-			r0 = r1;
+			for (int i = 0; i < align; ++i) {
+				if (i < b.n) {
+					const int32_t wi = ord[b.rep][b.first + i], sg = reps[b.rep].work[wi];
+					ent_of[b.rep][wi] = (int)wseg.size();
+					wseg.push_back(sg); wpar.push_back(b.rep); wtab.push_back(run); wtab_s.push_back(s_run + run); run += padded_len(sg);
+				} else { wseg.push_back(-1); wpar.push_back(b.rep); wtab.push_back(0); wtab_s.push_back(0); }
+			}
 		}
-		g_rep.push_back(n_rep); first[n_rep] = (int)wseg.size();
+		worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
+		l_first.push_back((int)wseg.size());
 	}
-	const int n_groups = (int)g_rep.size() - 1, n_all = (int)wseg.size();
-	// Without the f table the forward pass writes scale factors only (8 bytes per bin), so with several groups it runs ONCE over the
-	// replicates of ALL of them -- thousands of waves, issue-bound, instead of one latency-bound launch of ~1000 waves per group
-	// (100 replicates of a genome: 1.8 s against 4 x 0.9 s per EM iteration) -- into a call-wide s table (15 GB for 1.9 G bins).
-	const bool fwd_all = refwd && n_groups > 1;
+	const int n_launches = (int)l_first.size() - 1, n_all = (int)wseg.size();
+	// Without the f table the forward pass writes scale factors only (8 bytes per bin), so with several launches it runs ONCE over the
+	// entries of ALL of them -- thousands of waves, issue-bound, instead of one latency-bound launch of ~1000 waves each (100
+	// replicates of a genome: 1.25 s against 4 x 0.9 s per EM iteration) -- into a call-wide s table (15 GB for 1.9 G bins).  Its
+	// waves start in list order: longest first.
+	const bool fwd_all = refwd && n_launches > 1;
 	{
-		// tables: for the largest group when the caller fixed "batch_bins"; else for everything that fits (or all replicates at once), ONCE -- a
-		// hipMalloc of 250 GB takes 4-6 s on this driver (it clears the memory: scripts/r04/malloc_probe.py), so the size must not depend
-		// on this call's groups, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
+		// tables: for the largest launch when the caller fixed "batch_bins"; else for everything that fits (or all entries at once), ONCE -- a
+		// hipMalloc of 250 GB takes 4-6 s on this driver (it clears the memory: profiles/r04_boot_breakdown.txt), so the size must not depend
+		// on this call's launches, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
 		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins)), !refwd))) return rc;
 		if ((rc = ensure_seg_outputs(c, (int)worst_entries))) return rc;
 		if (c->bw_cap < (size_t)n_all) {
@@ -158,7 +197,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		if (fwd_all && c->s_all_cap < (size_t)all_bins + 128) { if ((rc = dev_alloc(c, &c->d_s_all, (size_t)all_bins + 128))) return rc; c->s_all_cap = (size_t)all_bins + 128; }
 	}
 	static const bool dbg_t = getenv("PSMC_HIP_DEBUG_TIMES") != nullptr;
-	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	auto now = []() { return dbg_now(); };
 	{
 		std::vector<double> hp((size_t)n_rep * PL);
 		for (int r = 0; r < n_rep; ++r) (void)fill_params(c, a + (size_t)r * n * n, e + (size_t)r * 2 * n, a0 + (size_t)r * n, hp.data() + (size_t)r * PL);
@@ -177,15 +216,18 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		fill_common(c, p, c->stream, c->d_bpar);
 		p.d_work = c->d_bw_seg; p.n_work = n_all; p.d_work_par = c->d_bw_par; p.d_work_tab = c->d_bw_tab + n_all; p.par_stride = (int64_t)PL; p.work_align = align;
 		p.exact_refwd = 1; p.exact_only = 1; p.d_s = c->d_s_all;
-		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch, forward pass of all replicates)", hipGetLastError());
+		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch, forward pass of all entries)", hipGetLastError());
 		if (dbg_t) { (void)hipStreamSynchronize(c->stream); fwd_all_s = now() - t0; }
 	}
-	for (int g = 0; g < n_groups; ++g) {
+	// per-entry results of the whole call on the host (34 KB each): a replicate's entries may sit in different launches
+	c->h_segA.resize((size_t)n_all * S * S); c->h_segE.resize((size_t)n_all * 3 * S);
+	std::vector<double> lk_all((size_t)n_all, 0.0);
+	for (int g = 0; g < n_launches; ++g) {
 		const double t_a = now();
-		const int r0 = g_rep[g], r1 = g_rep[g + 1], ng = r1 - r0, e0 = first[r0], nw = first[r1] - e0;
+		const int e0 = l_first[g], nw = l_first[g + 1] - e0;
 		const int64_t s_base = fwd_all ? wtab_s[e0] : 0;
-		int64_t run = 0;
-		for (int i = e0; i < e0 + nw; ++i) if (wseg[i] >= 0) run = std::max(run, wtab[i] + (((int64_t)c->L[wseg[i]] + 63) & ~(int64_t)63));
+		int64_t run = 0; int32_t longest = 0;
+		for (int i = e0; i < e0 + nw; ++i) if (wseg[i] >= 0) { run = std::max(run, wtab[i] + padded_len(wseg[i])); longest = std::max(longest, c->L[wseg[i]]); }
 		EstepLaunch p;
 		fill_common(c, p, c->stream, c->d_bpar);
 		p.d_work = c->d_bw_seg + e0; p.n_work = nw; p.d_work_par = c->d_bw_par + e0; p.d_work_tab = c->d_bw_tab + e0; p.par_stride = (int64_t)PL; p.work_align = align;
@@ -197,65 +239,63 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch)", hipGetLastError());
 		if (dbg_t) (void)hipStreamSynchronize(c->stream);
 		const double t_c = now();
-		c->h_segA.resize((size_t)nw * S * S); c->h_segE.resize((size_t)nw * 3 * S); c->h_s.resize((size_t)run);
-		HIPCHK(c, hipMemcpyAsync(c->h_segA.data(), c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipMemcpyAsync(c->h_segE.data(), c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
+		c->h_s.resize((size_t)run);
+		HIPCHK(c, hipMemcpyAsync(c->h_segA.data() + (size_t)e0 * S * S, c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->h_segE.data() + (size_t)e0 * 3 * S, c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(c->h_s.data(), (fwd_all ? c->d_s_all : c->d_s) + s_base, sizeof(double) * (size_t)run, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		const double t_d = now();
 		collect_timing(c);
-		// hmm_add_expect in selection order per replicate (khmm.c:346-359), he_sum starting from zeros; LL += hmm_lk (em.c:48)
-		std::vector<double> sA((size_t)n * n), sE((size_t)2 * n);
-		// hmm_lk of every (replicate, segment) entry: a running product over all of its bins with the platform log() -- 0.7 ns per bin,
-		// 0.36 s per group of 28 replicates on one core; the entries are independent, so host threads share them (each value is
-		// computed by one thread exactly as before: bit-identical)
-		std::vector<double> lk_all((size_t)nw, 0.0);
+		// hmm_lk of every entry of the launch (khmm.c:245-260): a running product over all of its bins with the platform log() -- 0.7 ns
+		// per bin, 0.36 s per 28 replicates on one core; the entries are independent, so host threads share them (each value is computed
+		// by one thread exactly as before: bit-identical)
 		{
 			const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 			std::atomic<size_t> next(0);
 			auto work = [&]() {
 				for (size_t i = next.fetch_add(1); i < (size_t)nw; i = next.fetch_add(1))
-					if (wseg[e0 + i] >= 0) lk_all[i] = host_lk(&c->h_s[(size_t)wtab[e0 + i]], c->L[wseg[e0 + i]]);
+					if (wseg[e0 + i] >= 0) lk_all[(size_t)e0 + i] = host_lk(&c->h_s[(size_t)wtab[e0 + i]], c->L[wseg[e0 + i]]);
 			};
 			std::vector<std::thread> th;
 			for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
 			work();
 			for (std::thread &t : th) t.join();
 		}
-		for (int r = r0; r < r1; ++r) {
-			const RepSel &R = reps[r];
-			const int f0 = first[r] - e0; // the replicate's first entry inside the group's launch
-			lk.resize(R.work.size());
-			for (size_t j = 0; j < R.work.size(); ++j) lk[j] = lk_all[(size_t)f0 + j];
-			std::fill(sA.begin(), sA.end(), 0.0); std::fill(sE.begin(), sE.end(), 0.0);
-			double ll = 0.0;
-			for (size_t i = 0; i < R.sel2work.size(); ++i) {
-				const int w = f0 + R.sel2work[i];
-				const double *hA = &c->h_segA[(size_t)w * S * S], *hE = &c->h_segE[(size_t)w * 3 * S];
-				ll += lk[R.sel2work[i]];
-				for (int k = 0; k < n; ++k)
-					for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * S + l];
-				for (int b = 0; b < 2; ++b)
-					for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * S + l];
-			}
-			if (A) memcpy(A + (size_t)r * n * n, sA.data(), sizeof(double) * n * n);
-			if (E) memcpy(E + (size_t)r * 2 * n, sE.data(), sizeof(double) * 2 * n);
-			if (LL) LL[r] = ll;
-			if (sums) { // SL | SU | DG | CL | CU of the summed matrix, for callers with the O(N) objective
-				double *q = sums + (size_t)r * 5 * n;
-				memset(q, 0, sizeof(double) * 5 * n);
-				for (int k = 0; k < n; ++k)
-					for (int l = 0; l < n; ++l) {
-						const double v = sA[(size_t)k * n + l];
-						if (l < k) { q[k] += v; q[3 * n + l] += v; } else if (l > k) { q[n + k] += v; q[4 * n + l] += v; } else q[2 * n + k] = v;
-					}
-			}
-		}
-		if (dbg_t) fprintf(stderr, "[psmc_hip] batch group %d: %d replicates, %d entries, %.1f M table bins | prepare %.3f s, kernels %.3f (fwd %.0f bwd %.0f expect %.0f ms%s), read-back %.3f, host sums %.3f\n",
-		                   c->last_batch_groups, ng, nw, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3],
-		                   fwd_all ? (g == 0 ? (std::string("; forward pass of all replicates ") + std::to_string(fwd_all_s) + " s").c_str() : "; fwd: see group 0") : "", t_d - t_c, now() - t_d);
+		if (dbg_t) fprintf(stderr, "[psmc_hip] batch launch %d: %d entries (longest %d bins), %.1f M table bins | prepare %.3f s, kernels %.3f (fwd %.0f bwd %.0f expect %.0f ms%s), read-back %.3f, hmm_lk %.3f\n",
+		                   g, nw, (int)longest, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3],
+		                   fwd_all ? (g == 0 ? (std::string("; forward pass of all entries ") + std::to_string(fwd_all_s) + " s").c_str() : "; fwd: see launch 0") : "", t_d - t_c, now() - t_d);
 		++c->last_batch_groups;
 	}
+	// hmm_add_expect in selection order per replicate (khmm.c:346-359), he_sum starting from zeros; LL += hmm_lk (em.c:48)
+	const double t_s = now();
+	std::vector<double> sA((size_t)n * n), sE((size_t)2 * n);
+	for (int r = 0; r < n_rep; ++r) {
+		const RepSel &R = reps[r];
+		std::fill(sA.begin(), sA.end(), 0.0); std::fill(sE.begin(), sE.end(), 0.0);
+		double ll = 0.0;
+		for (size_t i = 0; i < R.sel2work.size(); ++i) {
+			const int w = ent_of[r][R.sel2work[i]];
+			const double *hA = &c->h_segA[(size_t)w * S * S], *hE = &c->h_segE[(size_t)w * 3 * S];
+			ll += lk_all[(size_t)w];
+			for (int k = 0; k < n; ++k)
+				for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * S + l];
+			for (int b = 0; b < 2; ++b)
+				for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * S + l];
+		}
+		if (A) memcpy(A + (size_t)r * n * n, sA.data(), sizeof(double) * n * n);
+		if (E) memcpy(E + (size_t)r * 2 * n, sE.data(), sizeof(double) * 2 * n);
+		if (LL) LL[r] = ll;
+		if (sums) { // SL | SU | DG | CL | CU of the summed matrix, for callers with the O(N) objective
+			double *q = sums + (size_t)r * 5 * n;
+			memset(q, 0, sizeof(double) * 5 * n);
+			for (int k = 0; k < n; ++k)
+				for (int l = 0; l < n; ++l) {
+					const double v = sA[(size_t)k * n + l];
+					if (l < k) { q[k] += v; q[3 * n + l] += v; } else if (l > k) { q[n + k] += v; q[4 * n + l] += v; } else q[2 * n + k] = v;
+				}
+		}
+	}
+	if (dbg_t) fprintf(stderr, "[psmc_hip] batch: %d replicates, %d entries in %d launches, host sums %.3f s\n", n_rep, n_all, n_launches, now() - t_s);
 	return PSMC_HIP_OK;
 }
 
@@ -315,20 +355,37 @@ static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double 
 			c->sh_glue_f[sg].assign(nt, 0); c->sh_glue_b[sg].assign(nt, 0); c->sh_wf[sg].assign(nt, c->warmup); c->sh_wb[sg].assign(nt, c->warmup);
 		}
 	}
+	static const bool dbg_t = getenv("PSMC_HIP_DEBUG_TIMES") != nullptr;
+	const double t_call = dbg_now();
+	double t_est = 0.0;
 	for (int r = 0; r < n_rep; ++r) {
+		const double t_k = dbg_now();
 		psmc_hip_ctx *k = batch_child(c, r);
+		c->dbg_acc[0] += dbg_now() - t_k;
 		if (!k) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: cannot create the replicate context");
 		const int n_sel = sel_off[r + 1] - sel_off[r];
 		if (n_sel < 1) return fail(c, PSMC_HIP_EINVAL, "estep_batch: empty selection");
 		const int32_t *idx = sel_idx + sel_off[r];
 		int rc = 0;
-		if ((int)k->sel.size() != n_sel || memcmp(k->sel.data(), idx, sizeof(int32_t) * n_sel) != 0) rc = psmc_hip_select(k, n_sel, idx);
+		{
+			const double t_s = dbg_now();
+			if ((int)k->sel.size() != n_sel || memcmp(k->sel.data(), idx, sizeof(int32_t) * n_sel) != 0) rc = psmc_hip_select(k, n_sel, idx);
+			c->dbg_acc[1] += dbg_now() - t_s;
+		}
+		const double t_e = dbg_now();
 		const double *ar = a + (size_t)r * n * n, *er = e + (size_t)r * 2 * n, *a0r = a0 + (size_t)r * n;
 		if (rc == 0) {
 			if (A) rc = psmc_hip_estep(k, ar, er, a0r, A + (size_t)r * n * n, E ? E + (size_t)r * 2 * n : nullptr, nullptr, LL ? LL + r : nullptr, nullptr);
 			if (rc == 0 && sums) rc = psmc_hip_estep_factored(k, ar, er, a0r, sums + (size_t)r * 5 * n, E ? E + (size_t)r * 2 * n : nullptr, LL ? LL + r : nullptr);
 		}
+		t_est += dbg_now() - t_e;
 		if (rc) { c->err = "replicate " + std::to_string(r) + ": " + k->err; return rc; }
+	}
+	if (dbg_t) {
+		const double *q = c->dbg_acc;
+		fprintf(stderr, "[psmc_hip] fast batch on device %d: %d replicates %.3f s | contexts %.3f, select %.3f, E-steps %.3f (plan %.3f, items %.3f, launches %.3f, rest %.3f); "
+		                "%.0f repair rounds, %.0f repaired tiles\n", c->device, n_rep, dbg_now() - t_call, q[0], q[1], t_est, q[2], q[3], q[4], t_est - q[2] - q[3] - q[4], q[6], q[7]);
+		for (double &v : c->dbg_acc) v = 0.0;
 	}
 	c->tables_batch = true;
 	c->last_batch_groups = n_rep;
@@ -342,7 +399,7 @@ extern "C" int psmc_hip_estep_batch(psmc_hip_ctx *c, int n_rep, const double *a,
 	if (c->parent) return fail(c, PSMC_HIP_EINVAL, "estep_batch: not on a replicate context");
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep_batch: no segments loaded");
 	HIPCHK(c, hipSetDevice(c->device));
-	if (c->mode == PSMC_HIP_MODE_EXACT) return batch_exact(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
+	if (c->mode == PSMC_HIP_MODE_EXACT || c->ns > 128) return batch_exact(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL); // (beyond 128 states: the wide exact kernels whatever the mode)
 	return batch_fast(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
 }
 

@@ -390,7 +390,11 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 		return fail(c, PSMC_HIP_ENOTSUP, "fast mode beyond 64 states needs a transition matrix of the PSMC form (structured sweeps)");
 	if (c->want_factored && !c->use_struct)
 		return fail(c, PSMC_HIP_ENOTSUP, "factored statistics need a transition matrix of the PSMC form");
-	if ((c->plan_dirty || c->planned_struct != c->use_struct) && (rc = plan_fast(c))) return rc;
+	{
+		const double t0 = dbg_now();
+		if ((c->plan_dirty || c->planned_struct != c->use_struct) && (rc = plan_fast(c))) return rc;
+		dbg_root(c)->dbg_acc[2] += dbg_now() - t0;
+	}
 	EstepLaunch p;
 	fill_common(c, p, st);
 	p.d_chunks = c->d_chunks; p.n_chunks = (int)c->chunks.size(); p.warmup = c->warmup; p.n_sub = c->n_sub_used;
@@ -406,7 +410,11 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	}
 	// coarse bulk items: the fused and the factored back half only (their backward pass of phase 1 leaves start vectors, no table)
 	const int coarse = (c->use_struct && p.fused != 0) ? c->coarse_used : 1;
-	if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0) || c->items_coarse != coarse) && (rc = build_items(c, two_phase_bwd, coarse))) return rc;
+	{
+		const double t0 = dbg_now();
+		if (c->use_struct && (c->items_dirty || c->items_two_phase != (two_phase_bwd ? 2 : 0) || c->items_coarse != coarse) && (rc = build_items(c, two_phase_bwd, coarse))) return rc;
+		dbg_root(c)->dbg_acc[3] += dbg_now() - t0;
+	}
 	// auto: the factored statistics of a genome-sized input (issue-bound at three waves per SIMD); a shard-sized one runs one wave per SIMD,
 	// where the longer step of the 8 x 8 form costs more than its fewer instructions save (3.75 M bins: 3.23 vs 2.96 ms)
 	p.lanes8 = (c->lanes8 >= 0 ? c->lanes8 != 0 && p.fused != 0 : p.fused == 2 && p.n_chunks > 4096) && c->ns == 64 ? 1 : 0;
@@ -434,7 +442,13 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
-	if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
+	{
+		const double t0 = dbg_now();
+		if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
+		psmc_hip_ctx *R = dbg_root(c);
+		R->dbg_acc[4] += dbg_now() - t0;
+		R->dbg_acc[6] += c->report.fwd_rounds + c->report.bwd_rounds; R->dbg_acc[7] += c->report.fwd_tiles + c->report.bwd_tiles;
+	}
 	if (!c->report.converged) return fail(c, PSMC_HIP_ECONVERGE, "fast mode: tile boundaries did not converge within max_rounds");
 	if (c->use_struct && c->learn) learn_groups(c);
 	return 0;

@@ -1,6 +1,8 @@
-// api_probes.hip -- diagnostics behind the C-ABI: device self-test, instruction microbenchmarks, the pipe / placement / HBM probes
-// that DESIGN.md cites.  Not part of an E-step.
+// api_probes.hip -- libpsmc_hip_diag.so (include/psmc_hip_diag.h): device self-test, instruction microbenchmarks, the pipe /
+// placement / compute-unit-mask / HBM probes that DESIGN.md cites, and the HIP-event timing of a context's last E-step.
+// Not part of an E-step and not part of the drop-in library: it links against libpsmc_hip.so.
 #include "psmc_hip_ctx.h"
+#include "psmc_hip_diag.h"
 
 extern "C" int psmc_hip_selftest(int device)
 {
@@ -219,4 +221,61 @@ extern "C" int psmc_hip_load_probe_st(int device, int n_waves, int steps, int st
 	} else rc = PSMC_HIP_EDEVICE;
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d); (void)hipFree(tbl);
 	return rc;
+}
+
+// Two streams with complementary compute-unit masks (or none), the placement probe on both at once.
+extern "C" int psmc_hip_cumask_probe(int device, int n_cus_a, int n_waves_a, int n_waves_b, int steps, double *out, double *ms_out)
+{
+	int nd = psmc_hip_device_count();
+	if (n_cus_a < 0 || n_waves_a < 1 || n_waves_b < 1 || n_waves_a > (1 << 16) || n_waves_b > (1 << 16) || steps < 4 || !out) return PSMC_HIP_EINVAL;
+	if (nd <= 0 || device < 0 || device >= nd) return PSMC_HIP_EDEVICE;
+	if (hipSetDevice(device) != hipSuccess) return PSMC_HIP_EDEVICE;
+	int cus = 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return PSMC_HIP_EDEVICE;
+	if (n_cus_a >= cus) return PSMC_HIP_EINVAL;
+	double *d = nullptr;
+	if (hipMalloc((void **)&d, sizeof(double) * 3 * (size_t)(n_waves_a + n_waves_b)) != hipSuccess) return PSMC_HIP_ENOMEM;
+	hipStream_t st[2] = {nullptr, nullptr};
+	int rc = 0;
+	if (n_cus_a > 0) {
+		const int words = (cus + 31) / 32;
+		std::vector<uint32_t> ma(words, 0u), mb(words, 0u);
+		for (int i = 0; i < cus; ++i) (i < n_cus_a ? ma : mb)[i >> 5] |= 1u << (i & 31);
+		if (hipExtStreamCreateWithCUMask(&st[0], (uint32_t)words, ma.data()) != hipSuccess) rc = 1;
+		if (rc == 0 && hipExtStreamCreateWithCUMask(&st[1], (uint32_t)words, mb.data()) != hipSuccess) rc = 1;
+	} else {
+		if (hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking) != hipSuccess) rc = 1;
+		if (rc == 0 && hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking) != hipSuccess) rc = 1;
+	}
+	hipEvent_t e0, e1[2];
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1[0]); (void)hipEventCreate(&e1[1]);
+	for (int pass = 0; pass < 2 && rc == 0; ++pass) { // pass 0 warms clocks and the instruction cache
+		(void)hipDeviceSynchronize();
+		(void)hipEventRecord(e0, st[0]);
+		(void)hipStreamWaitEvent(st[1], e0, 0);
+		rc = run_place_probe(st[0], d, n_waves_a, 1, steps & ~3); (void)hipEventRecord(e1[0], st[0]);
+		if (rc == 0) { rc = run_place_probe(st[1], d + 3 * (size_t)n_waves_a, n_waves_b, 1, steps & ~3); (void)hipEventRecord(e1[1], st[1]); }
+	}
+	if (rc == 0 && hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, d, sizeof(double) * 3 * (size_t)(n_waves_a + n_waves_b), hipMemcpyDeviceToHost) == hipSuccess) {
+		float a = 0, b = 0;
+		(void)hipEventElapsedTime(&a, e0, e1[0]); (void)hipEventElapsedTime(&b, e0, e1[1]);
+		if (ms_out) *ms_out = std::max(a, b);
+	} else rc = 1;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1[0]); (void)hipEventDestroy(e1[1]);
+	for (int k = 0; k < 2; ++k) if (st[k]) (void)hipStreamDestroy(st[k]);
+	(void)hipFree(d);
+	return rc ? PSMC_HIP_EDEVICE : PSMC_HIP_OK;
+}
+
+extern "C" int psmc_hip_last_timing(psmc_hip_ctx *c, double ms[7])
+{
+	if (!c || !ms) return PSMC_HIP_EINVAL;
+	if (!c->timing_valid) {
+		HIPCHK(c, hipSetDevice(c->device));
+		if (hipEventSynchronize(c->ev[4]) != hipSuccess) return fail(c, PSMC_HIP_ESTATE, "last_timing: nothing recorded");
+		collect_timing(c);
+		if (!c->timing_valid) return fail(c, PSMC_HIP_ESTATE, "last_timing: events incomplete");
+	}
+	for (int i = 0; i < 7; ++i) ms[i] = c->last_ms[i];
+	return PSMC_HIP_OK;
 }

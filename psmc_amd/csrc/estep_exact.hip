@@ -1181,6 +1181,7 @@ int launch_exact(const EstepLaunch &p)
 	const int rep = p.rep_impl < 0 ? (p.n_work > 1024 ? 0 : 1) : p.rep_impl;
 	if (p.n_work <= 0) return 0;
 	(void)hipGetLastError(); // the value returned below must be about THESE launches (polled events, elapsed-time queries leave errors behind)
+	if (p.ns > 128) return launch_exact_wide(p);
 	if (p.ns == 128) return rep == 0 ? launch_exact128_t<0>(p) : launch_exact128_t<1>(p);
 	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.d_work_tab_s, p.n_work, p.par_stride};
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);

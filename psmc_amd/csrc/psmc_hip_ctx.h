@@ -96,6 +96,7 @@ struct psmc_hip_ctx {
 	bool plan_dirty = true;
 	// parameters
 	double *h_par = nullptr, *d_par = nullptr; // a | aeT(3) | e(3) | a0 | re(3)
+	size_t par_len = 0;        // doubles in one parameter block: PAR_LEN up to 128 states, 2 S^2 + 4 S beyond (a | aT | e(3) | a0, estep_wide.hip)
 	static constexpr size_t PAR_LEN = 2 * 16384 + 3 * 128 + 128 + 3 * 128 + 5 * 128 + 2 * 11 * 128; // ns=64: ... | re(3) | sp(5) (17152) | kcc; ns=128: a | aT | e(3) | a0 | re(3) | sp(5) | kcc
 	static constexpr size_t RE128_OFF = 2 * 16384 + 3 * 128 + 128, SP128_OFF = RE128_OFF + 3 * 128, KCC128_OFF = SP128_OFF + 5 * 128;
 	static constexpr size_t SP_OFF = 4 * 4096 + 192 + 64 + 192; // structured vectors P | R | qa | c | dd
@@ -141,6 +142,9 @@ struct psmc_hip_ctx {
 	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_rep][PAR_LEN] parameter blocks of a batch call
 	int *d_cu_mask = nullptr;          // k_expect_exact_rf2: one word per compute unit (which role order its resident work-groups took), 4096 words
 	double *d_s_all = nullptr; size_t s_all_cap = 0; // exact batch without the f table, several groups: the scale factors of ALL replicates (one forward pass)
+	int batch_sort = 1;                // "batch_sort": the exact batch deals ENTRIES to its launches longest first (api_batch.hip); 0 = replicate-major order
+	int reserved_refwd = -1;           // what psmc_hip_reserve_batch_tables decided about the f table (-1: nothing reserved): the batches that follow keep it
+	int cu_first = 0, cu_count = 0;    // psmc_hip_set_cu_range: the streams of this context are masked to these compute units (0: the whole device)
 	int last_batch_groups = 0;
 	bool tables_batch = false;         // the tables hold the slots of a batch group, not the segments at their own offsets
 	// fast batch: one plan-holding child per replicate; children share the parent's streams, events, parameter
@@ -156,7 +160,13 @@ struct psmc_hip_ctx {
 	std::vector<std::vector<uint8_t>> sh_glue_f, sh_glue_b;   // [segment][tile index]
 	std::vector<std::vector<int32_t>> sh_wf, sh_wb;
 	std::vector<int32_t> chunk_seg, chunk_idx;                // of every tile of the current plan
+	// PSMC_HIP_DEBUG_TIMES: host seconds spent in the pieces of the fast E-steps of this context and its batch children since the last
+	// report -- [0] replicate context creation, [1] select, [2] plan_fast (tiling + per-plan allocations), [3] build_items,
+	// [4] launch_fast (kernels + verify / repair rounds, synchronous), [5] result read-back; and [6] repair rounds, [7] repaired tiles
+	double dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+inline double dbg_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline psmc_hip_ctx *dbg_root(psmc_hip_ctx *c) { return c->parent ? c->parent : c; }
 
 inline int fail(psmc_hip_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
 {

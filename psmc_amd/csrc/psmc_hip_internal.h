@@ -134,6 +134,12 @@ inline bool dbg_sync_on() { static const bool on = getenv("PSMC_HIP_DEBUG_SYNC")
 constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
+int launch_exact_wide(const EstepLaunch &p); // estep_wide.hip: 129 .. 1024 states
+int launch_post_decode_wide(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n, int S, int32_t *path, double *maxp);
+int launch_post_full_wide(hipStream_t st, const double *a, const double *e, const uint8_t *obs, const double *f, const double *b, const double *s,
+                          int64_t off, int L, int n, int S, double *post, double *recomb);
+int launch_post_counts_wide(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int min_l, const int32_t *cnt1,
+                            int n_cnt, int n, int S, double *cnt);
 int launch_fast(const EstepLaunch &p, FastReport *rep);
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);

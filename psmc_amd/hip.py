@@ -15,6 +15,7 @@ MODE_FAST = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_DIAG = None
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
@@ -23,15 +24,22 @@ _i64p = C.POINTER(C.c_int64)
 
 # every symbol include/psmc_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "psmc_hip_device_count", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
+    "psmc_hip_device_count", "psmc_hip_device_cus", "psmc_hip_set_cu_range", "psmc_hip_reserve_tables", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
     "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_reserve_batch_tables", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
-    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts", "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe", "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe",
-    "psmc_hip_pipe_probe2", "psmc_hip_place_probe", "psmc_hip_group_selfcheck", "psmc_hip_fast_plan",
+    "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts",
+    "psmc_hip_group_selfcheck", "psmc_hip_fast_plan",
     "psmc_hip_group_create", "psmc_hip_group_destroy", "psmc_hip_group_last_error", "psmc_hip_group_set_option",
     "psmc_hip_group_load_segments", "psmc_hip_group_estep", "psmc_hip_group_estep_factored", "psmc_hip_group_info",
     "psmc_hip_group_route", "psmc_hip_estep_factored_device",
+]
+
+# every symbol include/psmc_hip_diag.h declares: libpsmc_hip_diag.so, the lab bench -- not part of the drop-in library
+DIAG_EXPORTS = [
+    "psmc_hip_selftest", "psmc_hip_last_timing", "psmc_hip_microbench", "psmc_hip_stream_probe", "psmc_hip_hbm_probe",
+    "psmc_hip_load_probe", "psmc_hip_load_probe_st", "psmc_hip_pipe_probe", "psmc_hip_pipe_probe2", "psmc_hip_place_probe",
+    "psmc_hip_cumask_probe",
 ]
 
 
@@ -88,6 +96,9 @@ def load_library():
     lib.psmc_hip_load_segments.argtypes = [C.c_void_p, C.c_int, C.POINTER(_u8p), _i32p]
     lib.psmc_hip_load_segments_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p]
     lib.psmc_hip_select.argtypes = [C.c_void_p, C.c_int, _i32p]
+    lib.psmc_hip_set_cu_range.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.psmc_hip_reserve_tables.argtypes = [C.c_void_p]
+    lib.psmc_hip_device_cus.argtypes = [C.c_int]
     lib.psmc_hip_estep.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.psmc_hip_estep_segments.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.psmc_hip_estep_device.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_void_p]
@@ -96,10 +107,25 @@ def load_library():
     lib.psmc_hip_fast_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.psmc_hip_get_tables.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     lib.psmc_hip_decode.argtypes = [C.c_void_p, C.c_int, _i32p, _dp]
-    lib.psmc_hip_selftest.argtypes = [C.c_int]
-    lib.psmc_hip_last_timing.argtypes = [C.c_void_p, _dp]
     _LIB = lib
     return lib
+
+
+def load_diag():
+    """dlopen psmc_amd/libpsmc_hip_diag.so (self-test, probes, event timing; include/psmc_hip_diag.h).  It links against
+    libpsmc_hip.so, which is loaded first so that both resolve the same copy."""
+    global _DIAG
+    if _DIAG is not None:
+        return _DIAG
+    load_library()
+    p = os.path.join(os.path.dirname(lib_path()), "libpsmc_hip_diag.so")
+    if not os.path.exists(p):
+        raise HipError("%s not built: run `make -C psmc_amd/csrc`" % p)
+    d = C.CDLL(p)
+    d.psmc_hip_selftest.argtypes = [C.c_int]
+    d.psmc_hip_last_timing.argtypes = [C.c_void_p, _dp]
+    _DIAG = d
+    return d
 
 
 def _p(x):
@@ -149,6 +175,17 @@ class HipEStep:
 
     def set_option(self, key, value):
         self._chk(self.lib.psmc_hip_set_option(self.h, key.encode(), float(value)), "set_option(%s)" % key)
+
+    def set_cu_range(self, first, count):
+        """Mask the context's streams to `count` compute units from `first` (0: whole device); psmc_hip_set_cu_range."""
+        self._chk(self.lib.psmc_hip_set_cu_range(self.h, int(first), int(count)), "set_cu_range")
+
+    def reserve_tables(self):
+        self._chk(self.lib.psmc_hip_reserve_tables(self.h), "reserve_tables")
+
+    def reserve_batch_tables(self, max_bins):
+        self.lib.psmc_hip_reserve_batch_tables.argtypes = [C.c_void_p, C.c_int64]
+        self._chk(self.lib.psmc_hip_reserve_batch_tables(self.h, int(max_bins)), "reserve_batch_tables")
 
     def load_segments(self, segs):
         segs = [np.ascontiguousarray(s, dtype=np.uint8) for s in segs]
@@ -302,7 +339,7 @@ class HipEStep:
 
     def timing(self):
         ms = np.zeros(7)
-        self._chk(self.lib.psmc_hip_last_timing(self.h, _p(ms)), "last_timing")
+        self._chk(load_diag().psmc_hip_last_timing(self.h, _p(ms)), "last_timing")
         if self.mode == MODE_FAST:  # forward and backward chains run concurrently: see include/psmc_hip.h
             return dict(total=ms[0], chains=ms[1], tail=ms[2], expect=ms[3], reduce=ms[4], fwd_sweep=ms[5],
                         bwd_sweep=ms[6], forward=ms[1], backward=ms[2])
@@ -310,7 +347,7 @@ class HipEStep:
 
 
 def selftest(device=0):
-    lib = load_library()
+    lib = load_diag()
     return lib.psmc_hip_selftest(int(device))
 
 
@@ -326,45 +363,45 @@ MICROBENCH_NAMES = ["fmac_dpp dependent", "v_fma_f64 dependent", "v_add_f64 depe
 
 
 def microbench(device=0):
-    lib = load_library()
+    lib = load_diag()
     out = np.zeros(len(MICROBENCH_NAMES))
     lib.psmc_hip_microbench.argtypes = [C.c_int, _dp, C.c_int]
     rc = lib.psmc_hip_microbench(int(device), _p(out), len(MICROBENCH_NAMES))
     if rc != 0:
-        raise HipError("microbench: %s" % lib.psmc_hip_strerror(rc).decode())
+        raise HipError("microbench: %s" % load_library().psmc_hip_strerror(rc).decode())
     return dict(zip(MICROBENCH_NAMES, out.tolist()))
 
 
 def hbm_probe(nbytes=8 << 30, device=0):
     """Achievable HBM rates of plain streaming kernels (GB/s): fill, read, copy, sweep-like stores."""
-    lib = load_library()
+    lib = load_diag()
     lib.psmc_hip_hbm_probe.argtypes = [C.c_int, C.c_longlong, _dp]
     out = np.zeros(4)
     rc = lib.psmc_hip_hbm_probe(int(device), int(nbytes), _p(out))
     if rc != 0:
-        raise HipError("hbm_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+        raise HipError("hbm_probe: %s" % load_library().psmc_hip_strerror(rc).decode())
     return dict(zip(["fill", "read", "copy", "sweep_store"], out.tolist()))
 
 
 def load_probe(n_waves, steps=20000, device=0):
     """The structured step on n_waves waves at once: kernel ms, mean / max cycles per step, mean shader MHz."""
-    lib = load_library()
+    lib = load_diag()
     lib.psmc_hip_load_probe.argtypes = [C.c_int, C.c_int, C.c_int, _dp]
     out = np.zeros(4)
     rc = lib.psmc_hip_load_probe(int(device), int(n_waves), int(steps), _p(out))
     if rc != 0:
-        raise HipError("load_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+        raise HipError("load_probe: %s" % load_library().psmc_hip_strerror(rc).decode())
     return dict(zip(["ms", "cycles_per_step", "max_cycles_per_step", "mhz"], out.tolist()))
 
 
 def stream_probe(n_doubles=1 << 27, device=0):
     """Known-size 8 B/lane copy (for PMC calibration); returns (ms per launch, GB/s read+write)."""
-    lib = load_library()
+    lib = load_diag()
     lib.psmc_hip_stream_probe.argtypes = [C.c_int, C.c_longlong, _dp]
     ms = C.c_double(0)
     rc = lib.psmc_hip_stream_probe(int(device), int(n_doubles), C.byref(ms))
     if rc != 0:
-        raise HipError("stream_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+        raise HipError("stream_probe: %s" % load_library().psmc_hip_strerror(rc).decode())
     return ms.value, 16.0 * n_doubles / (ms.value * 1e-3) / 1e9
 
 
@@ -374,12 +411,12 @@ PIPE_PROBE_CONFIGS = ["4 matrix waves (1/SIMD)", "4 vector waves (1/SIMD)", "8 m
 
 def pipe_probe(device=0):
     """Cross-wave overlap of f64 matrix and f64 vector instructions on one SIMD: {configuration: cycles per round of each wave}."""
-    lib = load_library()
+    lib = load_diag()
     lib.psmc_hip_pipe_probe.argtypes = [C.c_int, _dp, C.c_int]
     out = np.zeros(8 * len(PIPE_PROBE_CONFIGS))
     rc = lib.psmc_hip_pipe_probe(int(device), _p(out), len(out))
     if rc != 0:
-        raise HipError("pipe_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+        raise HipError("pipe_probe: %s" % load_library().psmc_hip_strerror(rc).decode())
     return {name: [round(v, 1) for v in out[8 * i:8 * i + 8] if v > 0] for i, name in enumerate(PIPE_PROBE_CONFIGS)}
 
 
@@ -389,25 +426,25 @@ PIPE_KINDS = {"idle": 0, "mfma_f64": 1, "fma_f64": 2, "mov_dpp": 3, "scan_levels
 
 def pipe_probe2(kinds, rounds=64, device=0):
     """Cycles per round of up to 8 waves of one work-group (wave w -> SIMD w % 4), kinds[w] from PIPE_KINDS."""
-    lib = load_library()
+    lib = load_diag()
     k = (C.c_int * 8)(*([PIPE_KINDS[x] if isinstance(x, str) else int(x) for x in kinds] + [0] * (8 - len(kinds))))
     out = np.zeros(8)
     lib.psmc_hip_pipe_probe2.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, _dp]
     rc = lib.psmc_hip_pipe_probe2(int(device), k, int(rounds), _p(out))
     if rc != 0:
-        raise HipError("pipe_probe2: %s" % lib.psmc_hip_strerror(rc).decode())
+        raise HipError("pipe_probe2: %s" % load_library().psmc_hip_strerror(rc).decode())
     return [float(v) for v in out[:len(kinds)]]
 
 
 def place_probe(n_waves, waves_per_block=1, n_kernels=1, steps=3328, device=0):
     """Where the waves of small launches land: dict(ms, cycles_per_step mean/max, simds_used, max_waves_per_simd, hist)."""
-    lib = load_library()
+    lib = load_diag()
     npad = (n_waves + waves_per_block - 1) // waves_per_block * waves_per_block
     out = np.zeros(3 * npad * n_kernels); ms = C.c_double(0)
     lib.psmc_hip_place_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_double)]
     rc = lib.psmc_hip_place_probe(int(device), int(n_waves), int(waves_per_block), int(n_kernels), int(steps), _p(out), C.byref(ms))
     if rc != 0:
-        raise HipError("place_probe: %s" % lib.psmc_hip_strerror(rc).decode())
+        raise HipError("place_probe: %s" % load_library().psmc_hip_strerror(rc).decode())
     o = out.reshape(-1, 3)
     o = o[o[:, 0] > 0]
     hw = o[:, 1].astype(np.int64); xcc = o[:, 2].astype(np.int64) & 0xf
@@ -417,6 +454,30 @@ def place_probe(n_waves, waves_per_block=1, n_kernels=1, steps=3328, device=0):
     cus = len(np.unique(key // 4))
     return dict(ms=ms.value, cycles_mean=float(o[:, 0].mean()), cycles_max=float(o[:, 0].max()), waves=len(o), simds_used=len(cnt), cus_used=cus,
                 max_waves_per_simd=int(cnt.max()), hist={int(k): int((cnt == k).sum()) for k in np.unique(cnt)})
+
+
+def cumask_probe(n_cus_a, n_waves_a, n_waves_b, steps=3328, device=0):
+    """Two concurrent launches on streams with complementary compute-unit masks (stream A: the first n_cus_a units of the
+    mask's bit order; 0 = no masks): where their waves land.  dict(ms, a=..., b=..., shared_cus) with per-launch cus_used,
+    simds_used, max_waves_per_simd, cycles_mean, and the number of compute units both touched."""
+    lib = load_diag()
+    out = np.zeros(3 * (n_waves_a + n_waves_b)); ms = C.c_double(0)
+    lib.psmc_hip_cumask_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_double)]
+    rc = lib.psmc_hip_cumask_probe(int(device), int(n_cus_a), int(n_waves_a), int(n_waves_b), int(steps), _p(out), C.byref(ms))
+    if rc != 0:
+        raise HipError("cumask_probe: %s" % load_library().psmc_hip_strerror(rc).decode())
+    o = out.reshape(-1, 3)
+
+    def summary(q):
+        hw = q[:, 1].astype(np.int64); xcc = q[:, 2].astype(np.int64) & 0xf
+        simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+        cukey = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+        _, cnt = np.unique(cukey * 4 + simd, return_counts=True)
+        per_xcc = {int(x): int(len(np.unique(cukey[xcc == x]))) for x in np.unique(xcc)}
+        return dict(waves=len(q), cus_used=len(np.unique(cukey)), simds_used=len(cnt), max_waves_per_simd=int(cnt.max()),
+                    cycles_mean=float(q[:, 0].mean()), cycles_max=float(q[:, 0].max()), cus_per_xcc=per_xcc), set(cukey.tolist())
+    a, ka = summary(o[:n_waves_a]); b, kb = summary(o[n_waves_a:])
+    return dict(ms=ms.value, a=a, b=b, shared_cus=len(ka & kb))
 
 
 class HipGroup:

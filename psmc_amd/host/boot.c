@@ -10,6 +10,7 @@
  * dealt round robin, one host thread driving each device.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -25,7 +26,18 @@ typedef struct {
 	double *A, *E, *sums, LL;
 } replicate;
 
-int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_pattern, psmc_batch_backend *bb)
+/* the main run's EM rounds (psmc_run_finish) on a thread of their own */
+typedef struct { psmc_run_state *st; int status; double ms; } main_job;
+static void *main_thread(void *arg)
+{
+	main_job *j = (main_job *)arg;
+	const double t0 = now_ms();
+	j->status = psmc_run_finish(j->st);
+	j->ms = now_ms() - t0;
+	return 0;
+}
+
+int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_pattern, psmc_batch_backend *bb, psmc_run_state *main_run)
 {
 	psmc_setup su;
 	psmc_input in;
@@ -90,6 +102,15 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 	}
 	const int timing = getenv("PSMC_TIMING") != 0;
 	int failed = 0;
+	/* The main run starts now: every draw from drand48 -- its own (psmc_run_begin) and the replicates' (above) -- is done, and from here
+	 * on the two only share the device: the main run's sweeps on the compute units its context was given, the batch on the others. */
+	main_job mj = {main_run, 0, 0.0};
+	pthread_t main_tid;
+	int main_started = 0;
+	if (main_run) {
+		if (pthread_create(&main_tid, 0, main_thread, &mj) == 0) main_started = 1;
+		else { fprintf(stderr, "psmc_boot: cannot start the main run's thread\n"); failed = 1; }
+	}
 	for (int it = 0; it != o->n_iters && !failed; ++it) { /* main.c:16-20, all replicates in lock step */
 		const double t0 = now_ms();
 		/* E-steps: one batch per device */
@@ -138,6 +159,12 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 			fprintf(stderr, "[psmc_boot] iteration %d: %d E-steps %.1f ms on %d device(s), M-steps %.1f ms\n", it + 1, n_rep, t1 - t0, bb->n_dev, now_ms() - t1);
 	}
 	status = failed ? 1 : 0;
+	if (main_started) {
+		pthread_join(main_tid, 0);
+		main_run = 0; /* psmc_run_finish freed it */
+		if (mj.status) { fprintf(stderr, "psmc_boot: the main run failed\n"); status = 1; }
+		if (timing) fprintf(stderr, "[psmc_boot] main run: %d EM iterations beside the replicates in %.1f ms\n", o->n_iters, mj.ms);
+	}
 done_rep:
 	for (int r = 0; r < n_rep; ++r) {
 		if (rep[r].out) fclose(rep[r].out);

@@ -1,19 +1,29 @@
 /* boot_main.c -- the `psmc_boot` executable: all bootstrap replicates of lh3/psmc's README:57-62 in one process on
  * the MI355X(s) of the node.
  *
- *   psmc_boot -R <replicates> [-S <first seed>] -O <out pattern with %d> -- <psmc options> split.psmcfa
+ *   psmc_boot -R <replicates> [-S <first seed>] -O <out pattern with %d> [--main <out.psmc> --main-input <in.psmcfa>]
+ *             -- <psmc options> split.psmcfa
  *
  * e.g.  psmc_boot -R 100 -S 1 -O round-%d.psmc -- -N25 -t15 -r5 -p "4+25*2+4+6" split.psmcfa
  * writes what  for r in 0..99: PSMC_SEED=$((1+r)) psmc -N25 -t15 -r5 -b -p ... -o round-$r.psmc split.psmcfa  would
  * (-b is implied).  PSMC_HIP_MODE=exact|fast and PSMC_FAST_MSTEP as for psmc; PSMC_HIP_DEVICES=0,1,.. (a device may be
  * listed twice = two contexts on it; default: all visible devices, twice each in fast mode); OMP_NUM_THREADS bounds
  * the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr.
+ *
+ * --main / --main-input: the whole workflow of the reference's README:49-62 as ONE job -- the un-resampled main run
+ * (`psmc <psmc options> -o out.psmc in.psmcfa`, on the unsplit input) runs on a thread of its own BESIDE the replicates, on the
+ * first device.  Exact mode: its context is masked to PSMC_BOOT_MAIN_CUS compute units (default 24: its ~90 sequential sweeps
+ * keep a SIMD each) and the batch to the others, so that the two never share a SIMD and the batch sizes its launches for its
+ * share (psmc_hip_set_cu_range); the main run's 3 s E-steps -- the critical path of one wave over the longest chromosome -- then
+ * hide behind the batch's 6 s ones instead of preceding them.  The main output is byte-identical to `psmc`'s, the replicates to
+ * a run without --main (tests/test_host_cli.py).
  * There is no CPU E-step in this binary. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "psmc_host.h"
 #include "psmc_hip.h"
+#include "hipbe.h"
 
 #define MAX_DEV 64
 typedef struct { int n_dev, n_states, n_rep; psmc_hip_ctx *ctx[MAX_DEV]; } hip_bb;
@@ -42,34 +52,46 @@ static void bb_destroy(void *self) { hip_bb *h = (hip_bb *)self; for (int d = 0;
 
 static void usage(void)
 {
-	fprintf(stderr, "Usage: psmc_boot -R <replicates> [-S <first seed>] -O <output pattern with %%d> -- <psmc options> input.psmcfa\n"
-	                "       (replicate r = `PSMC_SEED=<seed+r> psmc -b <psmc options> -o <pattern %% r>`; PSMC_HIP_MODE, PSMC_HIP_DEVICES)\n");
+	fprintf(stderr, "Usage: psmc_boot -R <replicates> [-S <first seed>] -O <output pattern with %%d> [--main <out.psmc> --main-input <unsplit.psmcfa>]\n"
+	                "                 -- <psmc options> input.psmcfa\n"
+	                "       (replicate r = `PSMC_SEED=<seed+r> psmc -b <psmc options> -o <pattern %% r>`; --main: `psmc <psmc options> -o <out.psmc>\n"
+	                "        <unsplit.psmcfa>` beside them in the same job; PSMC_HIP_MODE, PSMC_HIP_DEVICES, PSMC_BOOT_MAIN_CUS)\n");
 }
 
 int main(int argc, char *argv[])
 {
 	int n_rep = 0, i = 1;
 	long seed0 = 1;
-	const char *pattern = 0;
+	const char *pattern = 0, *main_out = 0, *main_in = 0;
+	setenv("GPU_MAX_HW_QUEUES", "16", 1); /* before the first HIP call: the main run's stream and the batch's must not share a hardware queue */
 	for (; i < argc; ++i) {
 		if (!strcmp(argv[i], "--")) { ++i; break; }
 		if (!strcmp(argv[i], "-R") && i + 1 < argc) n_rep = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-S") && i + 1 < argc) seed0 = atol(argv[++i]);
 		else if (!strcmp(argv[i], "-O") && i + 1 < argc) pattern = argv[++i];
+		else if (!strcmp(argv[i], "--main") && i + 1 < argc) main_out = argv[++i];
+		else if (!strcmp(argv[i], "--main-input") && i + 1 < argc) main_in = argv[++i];
 		else { usage(); return 1; }
 	}
-	if (n_rep < 1 || !pattern || i >= argc) { usage(); return 1; }
-	psmc_options o;
-	psmc_options_default(&o);
-	{ /* psmc's own option parser on the rest of the command line */
+	if (n_rep < 1 || !pattern || i >= argc || (main_out != 0) != (main_in != 0)) { usage(); return 1; }
+	psmc_options o, om;
+	psmc_options_default(&o); psmc_options_default(&om);
+	{ /* psmc's own option parser on the rest of the command line (twice with --main: the main run's copy) */
 		char **av = (char **)malloc(sizeof(char *) * (size_t)(argc - i + 2));
 		av[0] = argv[0];
 		for (int k = i; k < argc; ++k) av[k - i + 1] = argv[k];
-		const int rc = psmc_options_parse(&o, argc - i + 1, av);
+		int rc = psmc_options_parse(&o, argc - i + 1, av);
+		if (rc == 0 && main_out) rc = psmc_options_parse(&om, argc - i + 1, av);
 		free(av);
-		if (rc) { psmc_options_free(&o); return 1; }
+		if (rc) { psmc_options_free(&o); psmc_options_free(&om); return 1; }
 	}
 	o.bootstrap = 1;
+	if (main_out) { /* `psmc <psmc options> -o main_out main_in`: no -b */
+		om.bootstrap = 0;
+		free(om.in_file); om.in_file = strdup(main_in);
+		free(om.out_file); om.out_file = strdup(main_out);
+		if (om.decode || om.cnt_file || om.print_prob || om.simulate) { fprintf(stderr, "psmc_boot: decoding / simulation options make no sense on bootstrap replicates\n"); return 1; }
+	}
 	psmc_pattern pat;
 	int n_states = 0;
 	if (o.param_file) {
@@ -81,6 +103,7 @@ int main(int argc, char *argv[])
 	const char *mode_s = getenv("PSMC_HIP_MODE"), *devs = getenv("PSMC_HIP_DEVICES"), *fm = getenv("PSMC_FAST_MSTEP");
 	const int mode = (mode_s && strcmp(mode_s, "fast") == 0) ? PSMC_HIP_MODE_FAST : PSMC_HIP_MODE_EXACT;
 	o.fast_mstep = fm ? atoi(fm) != 0 : (mode == PSMC_HIP_MODE_FAST);
+	om.fast_mstep = o.fast_mstep;
 	hip_bb h;
 	memset(&h, 0, sizeof h);
 	h.n_states = n_states;
@@ -113,8 +136,38 @@ int main(int argc, char *argv[])
 	h.n_rep = n_rep;
 	const char *fs = getenv("PSMC_FACTORED");
 	psmc_batch_backend bb = {&h, h.n_dev, bb_load, bb_estep_batch, bb_error, bb_destroy, mode == PSMC_HIP_MODE_FAST && !(fs && atoi(fs) == 0)};
-	const int status = psmc_boot_run(&o, n_rep, seed0, pattern, &bb);
+	/* the main run: a context of its own on the first device, begun (header, input, RD 0, tables) before the batch sizes its tables */
+	psmc_estep_backend be_main;
+	psmc_run_state *main_run = 0;
+	memset(&be_main, 0, sizeof be_main);
+	if (main_out) {
+		const int use_factored = om.fast_mstep && mode == PSMC_HIP_MODE_FAST && n_states <= 128 && !(fs && atoi(fs) == 0);
+		int rc = psmc_hipbe_create(&be_main, n_states, mode, use_factored, 0, list[0]);
+		if (rc == 0 && mode == PSMC_HIP_MODE_EXACT) { /* split the first device: [0, m) main run, [m, all) the batch contexts on it */
+			const char *ms = getenv("PSMC_BOOT_MAIN_CUS");
+			const int cus = psmc_hip_device_cus(list[0]), m = ms ? atoi(ms) : 24;
+			if (m > 0 && m < cus) {
+				rc = psmc_hip_set_cu_range(psmc_hipbe_ctx(&be_main), 0, m);
+				for (int d = 0; d < h.n_dev && rc == 0; ++d)
+					if (list[d] == list[0]) rc = psmc_hip_set_cu_range(h.ctx[d], m, cus - m);
+			}
+		}
+		if (rc) {
+			fprintf(stderr, "psmc_boot: cannot set up the main run on device %d (%s)\n", list[0], psmc_hip_strerror(rc));
+			if (be_main.destroy) be_main.destroy(be_main.self);
+			bb.destroy(bb.self); psmc_options_free(&o); psmc_options_free(&om);
+			return 2;
+		}
+		main_run = psmc_run_begin(&om, &be_main);
+		if (main_run && (rc = psmc_hip_reserve_tables(psmc_hipbe_ctx(&be_main)))) {
+			fprintf(stderr, "psmc_boot: no device memory for the main run's tables (%s)\n", psmc_hip_strerror(rc));
+			main_run = 0;
+		}
+		if (!main_run) { be_main.destroy(be_main.self); bb.destroy(bb.self); psmc_options_free(&o); psmc_options_free(&om); return 1; }
+	}
+	const int status = psmc_boot_run(&o, n_rep, seed0, pattern, &bb, main_run);
+	if (be_main.destroy) be_main.destroy(be_main.self);
 	bb.destroy(bb.self);
-	psmc_options_free(&o);
+	psmc_options_free(&o); psmc_options_free(&om);
 	return status;
 }

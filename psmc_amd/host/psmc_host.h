@@ -130,6 +130,11 @@ void psmc_options_free(psmc_options *o);
 /* Whole program given an E-step backend: header, RD 0, n_iters EM rounds,
  * optional decoding / simulation.  Returns the process exit status. */
 int psmc_run(psmc_options *o, psmc_estep_backend *be);
+/* ... in two halves: everything up to RD 0 -- all draws from the process-wide drand48 stream happen here -- and the EM rounds,
+ * decoding and output (frees the state).  psmc_run_begin returns NULL after printing what went wrong. */
+typedef struct psmc_run_state psmc_run_state;
+psmc_run_state *psmc_run_begin(psmc_options *o, psmc_estep_backend *be);
+int psmc_run_finish(psmc_run_state *st);
 
 /* one EM round (psmc_em, em.c:27-78); prints the IT line to out */
 int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, FILE *out);
@@ -160,7 +165,9 @@ typedef struct psmc_batch_backend {
 	void (*destroy)(void *self);
 	int  can_factor; /* estep_batch can produce the triangular sums directly */
 } psmc_batch_backend;
-int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_pattern, psmc_batch_backend *bb);
+/* main_run (may be NULL): a psmc_run_begin()'ed run -- the un-resampled main run of README:49-53 on its own input -- whose EM
+ * rounds psmc_boot_run drives on a thread of its own beside the replicates (psmc_boot --main) */
+int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_pattern, psmc_batch_backend *bb, psmc_run_state *main_run);
 void psmc_print_round(const psmc_model *m, int64_t sum_called, FILE *out); /* psmc_print_data, aux.c:49-82 */
 
 /* synthetic data for benchmarks: hmm_simulate-like draw (khmm.c:386-423) with our own RNG */

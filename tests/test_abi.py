@@ -16,18 +16,33 @@ def lib():
     return hip.load_library()
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "psmc_hip.h")).read()
+def declared_symbols(header="psmc_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(psmc_hip_[a-z_0-9]+)\s*\(", txt)))
 
 
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return set(re.findall(r"\bT (psmc_hip_[a-z_0-9]+)$", out, flags=re.M))
+
+
 def test_exports_match_header(lib):
+    """The product library exports the E-step ABI and NOTHING of the lab bench; the diagnostics live in
+    libpsmc_hip_diag.so with a header of their own."""
     from psmc_amd import hip
     names = declared_symbols()
     assert names == sorted(hip.EXPORTS)
     for nm in names:
         assert hasattr(lib, nm), nm
+    assert _exported(hip.lib_path()) == set(names)
+    dnames = declared_symbols("psmc_hip_diag.h")
+    assert dnames == sorted(hip.DIAG_EXPORTS)
+    assert not set(dnames) & set(names)
+    diag = hip.load_diag()
+    for nm in dnames:
+        assert hasattr(diag, nm), nm
+    assert _exported(os.path.join(os.path.dirname(hip.lib_path()), "libpsmc_hip_diag.so")) == set(dnames)
 
 
 def test_no_silent_cpu_fallback(lib):
@@ -44,7 +59,7 @@ def test_no_silent_cpu_fallback(lib):
 def test_argument_validation(lib):
     h = C.c_void_p()
     assert lib.psmc_hip_create(C.byref(h), 0, 0, 0) == -1       # EINVAL
-    assert lib.psmc_hip_create(C.byref(h), 129, 0, 0) == -4     # ENOTSUP: > 128 states not in this build
+    assert lib.psmc_hip_create(C.byref(h), 1025, 0, 0) == -4    # ENOTSUP: beyond PSMC_HIP_MAX_STATES (one thread per state in a work-group)
     assert lib.psmc_hip_create(C.byref(h), 64, 0, 7) == -1
     assert lib.psmc_hip_create(None, 64, 0, 0) == -1
 
@@ -65,6 +80,21 @@ def _exact_asm():
     return _EXACT_ASM[0]
 
 
+_WIDE_ASM = []
+
+
+def _wide_asm():
+    if not _WIDE_ASM:
+        out = "/tmp/psmc_wide_audit_%d.s" % os.getpid()
+        src = os.path.join(ROOT, "psmc_amd", "csrc", "estep_wide.hip")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, src],
+                       check=True, stderr=subprocess.DEVNULL)
+        _WIDE_ASM.append(open(out).read())
+        os.unlink(out)
+    return _WIDE_ASM[0]
+
+
 def test_exact_kernels_have_no_fma():
     """hipcc contracts a*b+c by default; the exact mode must never contain an FMA outside the IEEE division expansion
      -- with ONE deliberate exception that is checked here operand by operand: the ordered sums
@@ -78,6 +108,12 @@ def test_exact_kernels_have_no_fma():
     # each IEEE f64 division expands to v_div_scale x2, v_rcp, 5-6 v_fma, v_div_fmas, v_div_fixup
     assert n_fma <= 7 * n_div, (n_fma, n_div)
     assert "v_mfma" not in txt and "v_pk_fma" not in txt
+    # the wide kernels (129 .. 1024 states, estep_wide.hip) have no deliberate exception at all
+    wide = _wide_asm()
+    n_div_w = len(re.findall(r"v_div_fmas_f64", wide))
+    assert n_div_w > 0
+    assert len(re.findall(r"\bv_fma_f64|\bv_fmac_f64", wide)) <= 7 * n_div_w
+    assert "v_mfma" not in wide and "v_pk_fma" not in wide
     n_sum = 0
     wr = re.compile(r"(?:v_|ds_|global_load|buffer_load|flat_load|scratch_load)\w*\s+(v\d+|v\[\d+:\d+\])")
     def regs(tok):

@@ -248,7 +248,7 @@ def test_errors(hip):
     with pytest.raises(hip.HipError):
         es.select([1])
     with pytest.raises(hip.HipError):
-        hip.HipEStep(129)                        # exact mode: at most 128 states (two per lane)
+        hip.HipEStep(1025)                       # at most PSMC_HIP_MAX_STATES = 1024 (one thread per state in a work-group)
     es.close()
     es = hip.HipEStep(65, mode=hip.MODE_FAST)    # beyond 64 states the tiled fast sweeps are the structured ones only
     a, e, a0 = random_hmm(np.random.default_rng(1), 65)
@@ -673,6 +673,97 @@ def test_exact_batch_is_bit_identical_to_separate_calls(hip, golden, batch_bins,
     f2, b2, s2 = ex2.tables(5)
     assert bits_equal(r["A"], r2["A"]) and bits_equal(f, f2) and bits_equal(b, b2)
     es.close(); ex2.close()
+
+
+@pytest.mark.parametrize("sort", [1, 0])
+def test_exact_batch_entry_schedule(hip, golden, sort):
+    """Round 5: the batch deals ENTRIES -- (replicate, segment) sweeps -- to its launches longest first ("batch_sort"), so a
+    replicate's entries sit in different launches and its statistics are put together on the host after the last one.  Twelve
+    replicates over segments of very unequal length, a table budget that forces 4+ launches: bit-identical to separate calls,
+    with and without the sort, with the f table and without."""
+    segs = golden.segs_small + golden.segs_mid[2:]
+    rng = np.random.default_rng(14)
+    params = _traj_params(6) * 2
+    sels = [rng.integers(0, len(segs), size=rng.integers(1, len(segs))).tolist() for _ in range(12)]
+    ref = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    ref.load_segments(segs)
+    want = []
+    for (a, e, a0), sel in zip(params, sels):
+        ref.select(sel)
+        want.append(ref.estep(a, e, a0))
+    ref.close()
+    for refwd in (2, 0):
+        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=60000, exact_refwd=refwd, batch_sort=sort)
+        es.load_segments(segs)
+        got = es.estep_batch(params, sels)
+        assert es.batch_info()["groups"] >= 4
+        for r, w in enumerate(want):
+            assert bits_equal(got["A"][r], w["A"]) and bits_equal(got["E"][r], w["E"]) and got["LL"][r] == w["LL"], (refwd, r)
+        es.close()
+
+
+def test_exact_batch_reserve_then_smaller_batch_then_single_estep(hip, golden):
+    """psmc_hip_reserve_batch_tables decides about the f table from the caller's upper bound, the batch that
+    follows used to decide again from its own count of unique bins -- two answers, an f table allocated at the b-only capacity.
+    The decision is now made once; and a single E-step (decode, get_tables) after a batch without the f table re-sizes the
+    tables instead of adding an f table at the batch's bin count.  Sequence: reserve (bound above the f + b capacity) -> batch
+    whose unique bins fit it -> single E-step -> tables -> batch again; every result bit-identical to a plain context."""
+    segs = golden.segs_small + golden.segs_mid[2:]
+    params = _traj_params(4)
+    sels = [[0, 3, 8, 8], [10, 9], [11, 12, 1], list(range(len(segs)))]
+    ref = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    ref.load_segments(segs)
+    want = []
+    for (a, e, a0), sel in zip(params, sels):
+        ref.select(sel)
+        want.append(ref.estep(a, e, a0))
+    ref.select(list(range(len(segs))))
+    r1 = ref.estep(*params[0]); f1, b1, s1 = ref.tables(10)
+    total = int(sum((len(s) + 63) // 64 * 64 for s in segs))
+    es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=2 * total)
+    es.load_segments(segs)
+    es.reserve_batch_tables(5 * total)          # above "batch_bins": the batch will run without the f table, in several launches
+    for _ in range(2):
+        got = es.estep_batch(params, sels)
+        for r, w in enumerate(want):
+            assert bits_equal(got["A"][r], w["A"]) and bits_equal(got["E"][r], w["E"]) and got["LL"][r] == w["LL"], r
+        es.select(list(range(len(segs))))
+        r2 = es.estep(*params[0]); f2, b2, s2 = es.tables(10)
+        assert bits_equal(r2["A"], r1["A"]) and bits_equal(f2, f1) and bits_equal(b2, b1) and bits_equal(s2, s1)
+    es.close(); ref.close()
+
+
+def test_exact_context_on_a_range_of_compute_units(hip, golden):
+    """psmc_hip_set_cu_range: two exact contexts on disjoint compute-unit ranges of one device (what psmc_boot --main sets up),
+    run one after the other and at the same time from two threads: the same bits as an unmasked context."""
+    import threading
+    p = golden.params("n64_curve")
+    segs = golden.segs_small + golden.segs_mid[2:]
+    plain = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    plain.load_segments(segs)
+    w = plain.estep(p["a"], p["e"], p["a0"])
+    cus = hip.load_library().psmc_hip_device_cus(0)
+    assert cus >= 64
+    a_ = hip.HipEStep(64, mode=hip.MODE_EXACT); a_.set_cu_range(0, 24); a_.load_segments(segs); a_.reserve_tables()
+    b_ = hip.HipEStep(64, mode=hip.MODE_EXACT); b_.set_cu_range(24, cus - 24); b_.load_segments(segs)
+    out = {}
+    def run(tag, es):
+        for _ in range(3):
+            out[tag] = es.estep(p["a"], p["e"], p["a0"])
+    th = [threading.Thread(target=run, args=("a", a_)), threading.Thread(target=run, args=("b", b_))]
+    for t in th: t.start()
+    for t in th: t.join()
+    for tag in ("a", "b"):
+        assert bits_equal(out[tag]["A"], w["A"]) and bits_equal(out[tag]["E"], w["E"]) and out[tag]["LL"] == w["LL"], tag
+    with pytest.raises(hip.HipError):
+        a_.set_cu_range(cus - 4, 8)            # outside the device
+    r = a_.estep(p["a"], p["e"], p["a0"])      # ... and the context still works
+    assert bits_equal(r["A"], w["A"])
+    a_.set_cu_range(0, 0)                      # whole device again
+    assert bits_equal(a_.estep(p["a"], p["e"], p["a0"])["A"], w["A"])
+    pr = hip.cumask_probe(24, 96, 512, 400)
+    assert pr["shared_cus"] == 0 and pr["a"]["cus_used"] <= 24
+    plain.close(); a_.close(); b_.close()
 
 
 def test_exact_batch_n128(hip, golden, oracle):

@@ -44,18 +44,19 @@ def oracle_psmc():
     return exe
 
 
-def test_psmc_binary_refuses_more_than_128_states():
-    """the reference takes any pattern (khmm.c:10-23, cli.c:66-99); this build's kernels stop at 128 hidden
-    states.  `psmc -p "100*2"` (200 states) must say so -- naming the limit -- and exit 2 before it touches a device (so this
-    runs on CPU), never crash or write a partial .psmc.  README.md and INTEGRATION.md section A state the same limit."""
+def test_psmc_binary_refuses_more_than_1024_states():
+    """The reference takes any pattern (khmm.c:10-23, cli.c:66-99).  Round 5 lifted this build's ceiling from 128 to 1024 hidden
+    states (the wide exact kernels keep one thread per state in a work-group, psmc_amd/csrc/estep_wide.hip): `-p "100*2"` now runs
+    (goldens small_n200_N2 / small_n149_d below); `psmc -p "200*6"` (1200 states) must still say so -- naming the limit -- and exit 2
+    before it touches a device (so this runs on CPU), never crash or write a partial .psmc.  README.md and INTEGRATION.md state it."""
     subprocess.run(["make", "-s", "-C", HOST, "psmc"], check=True)
     files = sorted(glob.glob(os.path.join(CLI, "*.psmcfa")))
     assert files
-    r = subprocess.run([os.path.join(HOST, "psmc"), "-N1", "-p", "100*2", files[0]], capture_output=True, text=True)
+    r = subprocess.run([os.path.join(HOST, "psmc"), "-N1", "-p", "200*6", files[0]], capture_output=True, text=True)
     assert r.returncode == 2 and r.stdout == "", (r.returncode, r.stdout[:200])
-    assert "200 hidden states" in r.stderr and "at most 128" in r.stderr, r.stderr
+    assert "1200 hidden states" in r.stderr and "at most 1024" in r.stderr, r.stderr
     for txt in ("README.md", "INTEGRATION.md"):
-        assert "128 hidden states" in open(os.path.join(ROOT, txt)).read(), txt
+        assert "1024 hidden states" in open(os.path.join(ROOT, txt)).read(), txt
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -115,8 +116,8 @@ def test_boot_driver_equals_single_bootstrap_runs(oracle_psmc, tmp_path, fast_ms
     for byte what `PSMC_SEED=<seed+r> psmc -b` writes -- same psmc_resamp draw (aux.c:8-47), same -I initial
     parameters, same rounds -- for 5 replicates dealt over the devices, M-steps on threads."""
     exe = os.path.join(BUILD, "psmc_oracle_boot")
-    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-o", exe, os.path.join(ROOT, "tests", "host_oracle_boot_main.c"),
-                    "-I" + HOST, "-I" + os.path.join(ROOT, "oracle"), "-L" + HOST, "-lpsmc_host",
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "host_oracle_boot_main.c"),
+                    "-I" + HOST, "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "tests"), "-L" + HOST, "-lpsmc_host",
                     "-L" + os.path.join(ROOT, "oracle"), "-lpsmc_oracle",
                     "-Wl,-rpath," + HOST, "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lz", "-lm"], check=True)
     args = ["-N2", "-I", "0.3", os.path.join(CLI, "mid.psmcfa.gz")]
@@ -131,6 +132,30 @@ def test_boot_driver_equals_single_bootstrap_runs(oracle_psmc, tmp_path, fast_ms
         assert got == one.stdout, k
         seen.add(got)
     assert len(seen) == 5   # the replicates really differ
+
+
+def test_boot_main_run_beside_replicates(oracle_psmc, tmp_path):
+    """psmc_boot --main: the un-resampled main run of README:49-53 on its OWN input, on a thread beside the
+    replicates.  boot.c / run.c with the oracle backends: the main output is byte for byte what `psmc` writes for that input, the
+    replicates are byte for byte what they are without --main -- every drand48 draw (seeding, -I, -b) happens before the thread starts."""
+    exe = os.path.join(BUILD, "psmc_oracle_boot")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "host_oracle_boot_main.c"),
+                    "-I" + HOST, "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "tests"), "-L" + HOST, "-lpsmc_host",
+                    "-L" + os.path.join(ROOT, "oracle"), "-lpsmc_oracle",
+                    "-Wl,-rpath," + HOST, "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lz", "-lm"], check=True)
+    opts = ["-N2", "-I", "0.3", "-p", "4+5*3+4"]
+    split, whole = os.path.join(CLI, "mid.psmcfa.gz"), os.path.join(CLI, "small.psmcfa")
+    env = dict(os.environ, PSMC_SEED="99")
+    r0 = subprocess.run([exe, "3", "17", str(tmp_path / "plain-%d.psmc")] + opts + [split], capture_output=True, text=True, env=env)
+    assert r0.returncode == 0, r0.stderr
+    r1 = subprocess.run([exe, "3", "17", str(tmp_path / "with-%d.psmc"), "--main", str(tmp_path / "main.psmc"), whole] + opts + [split],
+                        capture_output=True, text=True, env=env)
+    assert r1.returncode == 0, r1.stderr
+    one = subprocess.run([oracle_psmc] + opts + [whole], capture_output=True, text=True, env=env)
+    assert one.returncode == 0 and open(tmp_path / "main.psmc").read() == one.stdout
+    assert "RD\t2" in one.stdout
+    for k in range(3):
+        assert open(tmp_path / ("with-%d.psmc" % k)).read() == open(tmp_path / ("plain-%d.psmc" % k)).read(), k
 
 
 @pytest.fixture(scope="module")

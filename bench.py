@@ -103,8 +103,61 @@ def cpu_baseline(a, e, a0, segs, sample_bins):
                 model = ln.split(":", 1)[1].strip(); break
     except OSError:
         pass
-    return {"value": tot / dt, "unit": "bins/s", "cores": 1, "kind": kind, "host_cpu": model, "host_cores": os.cpu_count(),
-            "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
+    out = {"value": tot / dt, "unit": "bins/s", "cores": 1, "kind": kind, "host_cpu": model, "host_cores": os.cpu_count(),
+           "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
+    try:
+        out["multi"] = cpu_baseline_multi(a, e, a0, segs, kind, tot / dt)
+    except Exception as ex_:
+        out["multi"] = {"error": str(ex_)[-300:]}
+    return out
+
+
+def usable_cores():
+    """what the box really gives this process: the scheduler affinity, capped by the cgroup's CPU quota (the driver's container: 16)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline_multi(a, e, a0, segs, kind, one_core_rate):
+    """SURVEY section 8(d) "optionally a P-process CPU run": segments are independent (em.c:36-55), so the reference's honest
+    ceiling on this host is P processes, one 500 k-bin trunk each, P = the cores this container may use -- and, whatever P,
+    one E-step cannot finish before the longest segment has been swept by one core (VERDICT r4 missing 5)."""
+    import subprocess as sp
+    import tempfile
+    P = usable_cores()
+    trunks = []
+    for s in segs:
+        for j in range(0, len(s) - 499_999, 500_000):
+            if len(trunks) < P:
+                trunks.append(s[j:j + 500_000])
+    P = len(trunks)
+    d = tempfile.mkdtemp(prefix="psmc_cpu_multi_")
+    np.savez(os.path.join(d, "in.npz"), a=a, e=e, a0=a0, **{"t%d" % i: t for i, t in enumerate(trunks)})
+    code = ("import sys, time, numpy as np; sys.path.insert(0, %r); import orc; g = np.load(%r); "
+            "eng = orc.Reference() if %r == 'reference' else orc.Oracle(); t0 = time.perf_counter(); "
+            "eng.estep(g['a'], g['e'], g['a0'], [g['t' + sys.argv[1]]]); print(time.perf_counter() - t0)"
+            % (os.path.join(ROOT, "tests"), os.path.join(d, "in.npz"), kind))
+    t0 = time.perf_counter()
+    procs = [sp.Popen([sys.executable, "-c", code, str(i)], stdout=sp.PIPE, stderr=sp.DEVNULL, text=True) for i in range(P)]
+    times = [float(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    wall = time.perf_counter() - t0
+    bins = sum(len(t) for t in trunks)
+    longest = max(len(s) for s in segs)
+    total = sum(len(s) for s in segs)
+    rate = bins / max(times)
+    return {"value": rate, "unit": "bins/s", "cores": P, "kind": kind,
+            "sample": "%d processes x one 500 k-bin trunk at once: slowest %.2f s (wall incl. start-up %.2f s)" % (P, max(times), wall),
+            "per_core_under_load": bins / sum(times),
+            "estep_floor_s": {"longest_segment_bins": int(longest), "one_core": longest / one_core_rate,
+                              "throughput_at_%d_cores" % P: total / rate,
+                              "note": "one E-step of this workload on this host's CPU cannot take less than max(these two): segments are the "
+                                      "only parallelism the reference's algorithm has (em.c:36-55)"}}
 
 
 def factored_roofline(bins, kern, dt_step):

@@ -57,7 +57,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 /* Options.  None is needed: the defaults are what bench.py and the psmc binary run, and the plan adapts to the input
  * (see "auto").  PSMC_HIP_OPTIONS="key=value,key=value" in the environment sets them for every context of a process.
  * Unknown keys and out-of-range values return PSMC_HIP_EINVAL.  Setting any option drops the per-replicate plans a
- * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort" and "exact_refwd".
+ * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_slots" and "exact_refwd".
  *
  *  key             default  meaning
  *  --- plan of the fast mode (tiles, speculation) ---------------------------------------------------------------
@@ -132,6 +132,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "batch_sort"    1        psmc_hip_estep_batch: the entries -- (replicate, segment) sweeps -- of ALL replicates are dealt to the launches
  *                           longest first, so that the long trunks share one launch and the others end with their own, shorter, longest
  *                           entry; 0 = replicate-major order (every launch then lasts as long as the longest trunk).  Bit-identical.
+ *  "batch_slots"   0        psmc_hip_estep_batch without the f table, several launches: entries per launch; 0 = four per compute unit of the
+ *                           context's share of the device (the recompute pass holds that many at a time; one more waits for a whole round).
+ *                           psmc_boot --main without compute-unit masks leaves the main run's sweeps some slots this way
  *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1, 2 = no f table -- the expect pass recomputes the forward sweep in its own
  *                           work-group (bit-identical), so a launch group holds twice the replicates; 2 = two entries per work-group
  *                           (two producer waves, two consumer waves: four entries per compute unit), 1 = one; 0 = f and b tables,

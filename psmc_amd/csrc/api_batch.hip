@@ -132,6 +132,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		int cus = c->cu_count;
 		if (cus <= 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0)) { (void)hipGetLastError(); cus = 256; }
 		ent_cap = (size_t)cus * (c->exact_refwd == 1 ? 2 : 4);
+		if (c->batch_slots > 0) ent_cap = (size_t)std::max(c->batch_slots, 4) / 4 * 4;
 	}
 	// blocks of every replicate
 	std::vector<std::vector<int32_t>> ord(n_rep); // work indices of a replicate, longest first ("batch_sort") or as selected
@@ -319,7 +320,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
 		for (int i = 0; i < 10; ++i) k->ev[i] = c->ev[i];
-		k->h_par = c->h_par; k->d_par = c->d_par;
+		k->h_par = c->h_par; k->d_par = c->d_par; k->par_len = c->par_len;
 		// same segments, same offsets, the parent's copy of the observations
 		k->d_obs = c->d_obs; k->obs_borrowed = true; k->off = c->off; k->total = c->total;
 		if (set_segments_common(k, c->n_seg, c->L.data()) != 0) { c->err = k->err; psmc_hip_destroy(k); return nullptr; } // never keep a half-built child

@@ -143,6 +143,7 @@ struct psmc_hip_ctx {
 	int *d_cu_mask = nullptr;          // k_expect_exact_rf2: one word per compute unit (which role order its resident work-groups took), 4096 words
 	double *d_s_all = nullptr; size_t s_all_cap = 0; // exact batch without the f table, several groups: the scale factors of ALL replicates (one forward pass)
 	int batch_sort = 1;                // "batch_sort": the exact batch deals ENTRIES to its launches longest first (api_batch.hip); 0 = replicate-major order
+	int batch_slots = 0;               // "batch_slots": entries per launch of an exact batch that needs several (0: four per compute unit of the context's share)
 	int reserved_refwd = -1;           // what psmc_hip_reserve_batch_tables decided about the f table (-1: nothing reserved): the batches that follow keep it
 	int cu_first = 0, cu_count = 0;    // psmc_hip_set_cu_range: the streams of this context are masked to these compute units (0: the whole device)
 	int last_batch_groups = 0;

@@ -477,6 +477,8 @@ def cumask_probe(n_cus_a, n_waves_a, n_waves_b, steps=3328, device=0):
         return dict(waves=len(q), cus_used=len(np.unique(cukey)), simds_used=len(cnt), max_waves_per_simd=int(cnt.max()),
                     cycles_mean=float(q[:, 0].mean()), cycles_max=float(q[:, 0].max()), cus_per_xcc=per_xcc), set(cukey.tolist())
     a, ka = summary(o[:n_waves_a]); b, kb = summary(o[n_waves_a:])
+    # the compute units stream A touched, as (xcc, se, sh, cu): which units the first n_cus_a bits of the mask name
+    a["cus"] = sorted((k >> 8, (k >> 5) & 7, (k >> 4) & 1, k & 15) for k in ka)
     return dict(ms=ms.value, a=a, b=b, shared_cus=len(ka & kb))
 
 

@@ -150,6 +150,12 @@ int main(int argc, char *argv[])
 				rc = psmc_hip_set_cu_range(psmc_hipbe_ctx(&be_main), 0, m);
 				for (int d = 0; d < h.n_dev && rc == 0; ++d)
 					if (list[d] == list[0]) rc = psmc_hip_set_cu_range(h.ctx[d], m, cus - m);
+			} else if (m <= 0) { /* no masks: the main run's long sweeps (one per chromosome) each keep a recompute work-group out of its
+			                      * compute unit, so the batch leaves them PSMC_BOOT_MAIN_SLOTS entry slots per launch (default 64) */
+				const char *ss = getenv("PSMC_BOOT_MAIN_SLOTS");
+				const int keep = ss ? atoi(ss) : 64;
+				for (int d = 0; d < h.n_dev && rc == 0; ++d)
+					if (list[d] == list[0] && 4 * cus - keep >= 4) rc = psmc_hip_set_option(h.ctx[d], "batch_slots", 4 * cus - keep);
 			}
 		}
 		if (rc) {

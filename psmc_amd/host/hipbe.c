@@ -5,7 +5,14 @@
 #include <string.h>
 #include "hipbe.h"
 
-typedef struct { psmc_hip_ctx *ctx; psmc_hip_group *grp; int n_seg, n_states; double *chk; char msg[256]; } hip_be;
+typedef struct {
+	psmc_hip_ctx *ctx; psmc_hip_group *grp; int n_seg, n_states; double *chk; char msg[256];
+	/* what a fast-mode run needs to repeat ONE E-step in exact mode when its tile boundaries do not converge (PSMC_HIP_ECONVERGE):
+	 * how it was created, the segments (borrowed from the caller's psmc_input, alive for the whole run), and the exact twin once made */
+	int mode, device; char *devs;
+	const uint8_t **sym; int32_t *L;
+	psmc_hip_ctx *x_ctx; psmc_hip_group *x_grp; int n_fallbacks;
+} hip_be;
 
 /* the per-segment readers go to the context that holds the segment's tables */
 static int route(hip_be *h, int seg, psmc_hip_ctx **c, int *local)
@@ -19,13 +26,56 @@ static int hb_load(void *self, int n_seg, const uint8_t *const *sym, const int32
 	hip_be *h = (hip_be *)self;
 	h->n_seg = n_seg;
 	h->chk = (double *)realloc(h->chk, sizeof(double) * (size_t)n_seg);
+	h->sym = (const uint8_t **)realloc((void *)h->sym, sizeof(void *) * (size_t)n_seg);
+	h->L = (int32_t *)realloc(h->L, sizeof(int32_t) * (size_t)n_seg);
+	for (int i = 0; i < n_seg; ++i) { h->sym[i] = sym[i]; h->L[i] = L[i]; }
+	if (h->x_ctx) { psmc_hip_destroy(h->x_ctx); h->x_ctx = 0; }
+	if (h->x_grp) { psmc_hip_group_destroy(h->x_grp); h->x_grp = 0; }
 	return h->grp ? psmc_hip_group_load_segments(h->grp, n_seg, sym, L) : psmc_hip_load_segments(h->ctx, n_seg, sym, L);
 }
+/* PSMC_HIP_ECONVERGE from a fast E-step (the verify / repair rounds of the speculative tiles ran out: an input whose chain forgets
+ * more slowly than anything the plan allows for) used to end the run.  The statistics are a well-defined quantity all the same:
+ * this ONE E-step is repeated by the exact kernels -- a twin context / group in exact mode over the same segments, made on first
+ * need -- with a note on stderr; the run goes on in fast mode.  (khmm.c:145-324 has no such failure mode.) */
+static int exact_once(hip_be *h, const double *a, const double *e, const double *a0, double *A, double *E, double *LL)
+{
+	int rc = 0;
+	fprintf(stderr, "psmc: fast E-step did not converge (%s); repeating this E-step with the exact kernels\n",
+	        h->grp ? psmc_hip_group_last_error(h->grp) : psmc_hip_last_error(h->ctx));
+	if (!h->x_ctx && !h->x_grp) {
+		if (h->grp) {
+			int list[64], n_list = 0;
+			char *dup = strdup(h->devs ? h->devs : "0");
+			for (char *t = strtok(dup, ","); t && n_list < 64; t = strtok(0, ",")) list[n_list++] = atoi(t);
+			free(dup);
+			rc = psmc_hip_group_create(&h->x_grp, h->n_states, n_list, list, PSMC_HIP_MODE_EXACT);
+			if (rc == 0) rc = psmc_hip_group_load_segments(h->x_grp, h->n_seg, h->sym, h->L);
+		} else {
+			rc = psmc_hip_create(&h->x_ctx, h->n_states, h->device, PSMC_HIP_MODE_EXACT);
+			if (rc == 0) rc = psmc_hip_load_segments(h->x_ctx, h->n_seg, h->sym, h->L);
+		}
+		if (rc) { fprintf(stderr, "psmc: cannot set up the exact E-step (%s)\n", psmc_hip_strerror(rc)); return rc; }
+	}
+	++h->n_fallbacks;
+	return h->x_grp ? psmc_hip_group_estep(h->x_grp, a, e, a0, A, E, 0, LL, h->chk) : psmc_hip_estep(h->x_ctx, a, e, a0, A, E, 0, LL, h->chk);
+}
+
+static void tri_sums(int n, const double *A, double *sums)
+{
+	memset(sums, 0, sizeof(double) * 5 * (size_t)n);
+	for (int k = 0; k < n; ++k)
+		for (int l = 0; l < n; ++l) {
+			const double v = A[(size_t)k * n + l];
+			if (l < k) { sums[k] += v; sums[3 * n + l] += v; } else if (l > k) { sums[n + k] += v; sums[4 * n + l] += v; } else sums[2 * n + k] = v;
+		}
+}
+
 static int hb_estep(void *self, const double *a, const double *e, const double *a0, double *A, double *E, double *LL,
                     double *chk)
 {
 	hip_be *h = (hip_be *)self;
 	int rc = h->grp ? psmc_hip_group_estep(h->grp, a, e, a0, A, E, 0, LL, h->chk) : psmc_hip_estep(h->ctx, a, e, a0, A, E, 0, LL, h->chk);
+	if (rc == PSMC_HIP_ECONVERGE && h->mode == PSMC_HIP_MODE_FAST) rc = exact_once(h, a, e, a0, A, E, LL);
 	if (rc) return rc;
 	for (int i = 0; i < h->n_seg; ++i) { /* the diagnostic of khmm.c:239-240 */
 		if (h->chk[i] > 1.0 + 1e-6 || h->chk[i] < 1.0 - 1e-6) fprintf(stderr, "++ Underflow may have happened (%lg).\n", h->chk[i]);
@@ -37,19 +87,14 @@ static int hb_estep_factored(void *self, const double *a, const double *e, const
 {
 	hip_be *h = (hip_be *)self;
 	int rc = h->grp ? psmc_hip_group_estep_factored(h->grp, a, e, a0, sums, E, LL) : psmc_hip_estep_factored(h->ctx, a, e, a0, sums, E, LL);
-	if (rc != PSMC_HIP_ENOTSUP) return rc;
-	/* a matrix without the two rank-1 triangles (e.g. -C): full counts, triangular sums on the host */
+	if (rc != PSMC_HIP_ENOTSUP && rc != PSMC_HIP_ECONVERGE) return rc;
+	/* a matrix without the two rank-1 triangles (e.g. -C): full counts, triangular sums on the host; tile boundaries that
+	 * did not converge: the exact kernels once (exact_once), sums of their A */
 	const int n = h->n_states;
 	double *A = (double *)calloc((size_t)n * n, sizeof(double));
-	rc = h->grp ? psmc_hip_group_estep(h->grp, a, e, a0, A, E, 0, LL, h->chk) : psmc_hip_estep(h->ctx, a, e, a0, A, E, 0, LL, h->chk);
-	if (rc == 0) {
-		memset(sums, 0, sizeof(double) * 5 * (size_t)n);
-		for (int k = 0; k < n; ++k)
-			for (int l = 0; l < n; ++l) {
-				const double v = A[(size_t)k * n + l];
-				if (l < k) { sums[k] += v; sums[3 * n + l] += v; } else if (l > k) { sums[n + k] += v; sums[4 * n + l] += v; } else sums[2 * n + k] = v;
-			}
-	}
+	if (rc == PSMC_HIP_ECONVERGE) rc = exact_once(h, a, e, a0, A, E, LL);
+	else rc = hb_estep(self, a, e, a0, A, E, LL, 0);
+	if (rc == 0) tri_sums(n, A, sums);
 	free(A);
 	return rc;
 }
@@ -74,7 +119,14 @@ static int hb_post_counts(void *self, int seg, const int32_t *cnt1, int32_t l1, 
 	return rc ? rc : psmc_hip_post_counts(c, l, cnt1, l1, n_cnt, cnt);
 }
 static const char *hb_error(void *self) { hip_be *h = (hip_be *)self; return h->grp ? psmc_hip_group_last_error(h->grp) : psmc_hip_last_error(h->ctx); }
-static void hb_destroy(void *self) { hip_be *h = (hip_be *)self; if (h->grp) psmc_hip_group_destroy(h->grp); else psmc_hip_destroy(h->ctx); free(h->chk); free(h); }
+static void hb_destroy(void *self)
+{
+	hip_be *h = (hip_be *)self;
+	if (h->x_ctx) psmc_hip_destroy(h->x_ctx);
+	if (h->x_grp) psmc_hip_group_destroy(h->x_grp);
+	if (h->grp) psmc_hip_group_destroy(h->grp); else psmc_hip_destroy(h->ctx);
+	free(h->chk); free((void *)h->sym); free(h->L); free(h->devs); free(h);
+}
 
 
 int psmc_hipbe_create(psmc_estep_backend *be, int n_states, int mode, int use_factored, const char *devs, int device)
@@ -83,7 +135,9 @@ int psmc_hipbe_create(psmc_estep_backend *be, int n_states, int mode, int use_fa
 	int rc;
 	memset(be, 0, sizeof *be);
 	if (!h) return PSMC_HIP_ENOMEM;
-	h->n_states = n_states;
+	h->n_states = n_states; h->mode = mode;
+	h->device = devs && *devs && !strchr(devs, ',') ? atoi(devs) : device;
+	h->devs = devs ? strdup(devs) : 0;
 	if (devs && strchr(devs, ',')) { /* several devices: shard every E-step */
 		int list[64], n_list = 0;
 		char *dup = strdup(devs);
@@ -93,7 +147,7 @@ int psmc_hipbe_create(psmc_estep_backend *be, int n_states, int mode, int use_fa
 		const char *rc_s = getenv("PSMC_HIP_RCCL");
 		if (rc == 0 && rc_s) rc = psmc_hip_group_set_option(h->grp, "rccl", atof(rc_s));
 	} else rc = psmc_hip_create(&h->ctx, n_states, devs && *devs ? atoi(devs) : device, mode);
-	if (rc) { if (h->grp) psmc_hip_group_destroy(h->grp); free(h); return rc; }
+	if (rc) { if (h->grp) psmc_hip_group_destroy(h->grp); free(h->devs); free(h); return rc; }
 	be->self = h; be->load = hb_load; be->estep = hb_estep; be->tables = hb_tables; be->decode = hb_decode;
 	be->estep_factored = use_factored ? hb_estep_factored : 0; be->error = hb_error; be->destroy = hb_destroy;
 	be->posterior = hb_posterior; be->post_counts = hb_post_counts;

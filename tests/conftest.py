@@ -88,6 +88,18 @@ def reference():
     return orc.Reference()
 
 
+FAST_METRICS = []   # psmc_amd.parity.fast_error_metrics of every fast-vs-reference comparison of the session (check_fast)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not FAST_METRICS:
+        return
+    keys = sorted({k for m in FAST_METRICS for k in m})
+    worst = {k: max(m[k] for m in FAST_METRICS if k in m) for k in keys}
+    terminalreporter.write_line("fast mode vs exact / oracle, worst of %d comparisons: %s" % (
+        len(FAST_METRICS), "  ".join("%s %.2e" % (k, worst[k]) for k in keys)))
+
+
 def bits_equal(x, y):
     x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
     return x.shape == y.shape and np.array_equal(x.view(np.uint64), y.view(np.uint64))

@@ -393,6 +393,33 @@ def test_psmc_boot_binary_equals_single_runs_on_gpu(tmp_path, pattern):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("main_cus", ["24", "0"])
+def test_psmc_boot_main_run_on_gpu(tmp_path, main_cus):
+    """psmc_boot --main: the README:49-62 workflow as one job.  The main run (`psmc <options> -o main.psmc
+    whole.psmcfa`) runs beside the replicates on the same device -- its context masked to a range of compute units and the batch
+    to the others (PSMC_BOOT_MAIN_CUS=24), or unmasked with entry slots kept free (=0) -- and writes the bytes `psmc` writes;
+    the replicates write the bytes they write without --main (entry schedule, launch count and compute-unit share do not
+    reach the results)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "psmc_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    opts = ["-N3", "-t15", "-r5", "-I", "0.2", "-p", "4+25*2+4+6"]
+    split, whole = os.path.join(CLI, "mid.psmcfa.gz"), os.path.join(CLI, "small.psmcfa")
+    env = dict(os.environ, PSMC_SEED="7", PSMC_BOOT_MAIN_CUS=main_cus, PSMC_HIP_OPTIONS="batch_bins=150000")   # several launches at fixture size
+    boot = os.path.join(HOST, "psmc_boot")
+    r0 = subprocess.run([boot, "-R", "9", "-S", "40", "-O", str(tmp_path / "p-%d.psmc"), "--"] + opts + [split], capture_output=True, text=True, env=env)
+    assert r0.returncode == 0, r0.stderr
+    r1 = subprocess.run([boot, "-R", "9", "-S", "40", "-O", str(tmp_path / "m-%d.psmc"), "--main", str(tmp_path / "main.psmc"), "--main-input", whole, "--"] + opts + [split],
+                        capture_output=True, text=True, env=env)
+    assert r1.returncode == 0, r1.stderr
+    one = subprocess.run([os.path.join(HOST, "psmc")] + opts + [whole], capture_output=True, text=True, env=env)
+    assert one.returncode == 0 and open(tmp_path / "main.psmc").read() == one.stdout and "RD\t3" in one.stdout
+    for k in range(9):
+        assert open(tmp_path / ("m-%d.psmc" % k)).read() == open(tmp_path / ("p-%d.psmc" % k)).read(), k
+    single = subprocess.run([os.path.join(HOST, "psmc"), "-b"] + opts + [split], capture_output=True, text=True, env=dict(env, PSMC_SEED="44", PSMC_HIP_OPTIONS=""))
+    assert single.returncode == 0 and open(tmp_path / "m-4.psmc").read() == single.stdout
+
+
+@pytest.mark.gpu
 def test_psmc_boot_binary_fast_mode_close(tmp_path):
     """PSMC_HIP_MODE=fast: per-replicate tile plans + factored statistics + O(N) objective; LK of every round within
     1e-6 of the exact-mode replicate (two rounds: the chaotic search has not had time to separate the runs)."""

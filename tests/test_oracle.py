@@ -57,6 +57,41 @@ def test_estep_mid_bitexact(golden, oracle, key):
     assert bits_equal(r["seg_LL"], g[key + ".seg_LL"]) and bits_equal(r["seg_chk"], g[key + ".seg_chk"])
 
 
+@pytest.mark.parametrize("key", ["n200", "n149"])
+def test_estep_wide_bitexact(golden, oracle, key):
+    """Beyond 128 states (`-p "100*2"`: 200; `-p "4+47*3+4"`: 149): the reference's statistics and thinned tables
+    (tests/golden/make_golden_wide.py) -- the pin for the wide exact kernels of round 5."""
+    import os
+    from conftest import GOLD
+    g = dict(np.load(os.path.join(GOLD, "estep_wide.npz")))
+    a, e, a0 = g[key + ".a"], g[key + ".e"], g[key + ".a0"]
+    r = oracle.estep(a, e, a0, golden.segs_small[:8], per_seg=True)
+    assert bits_equal(r["A"], g[key + ".A"]) and bits_equal(r["E"], g[key + ".E"]) and bits_equal(r["A0"], g[key + ".A0"])
+    assert r["LL"] == float(g[key + ".LL"]) and bits_equal(r["seg_chk"], g[key + ".seg_chk"]) and bits_equal(r["seg_E"], g[key + ".seg_E"])
+    f, b, s, lk, chk = oracle.fwd_bwd(a, e, a0, golden.segs_small[5])
+    assert bits_equal(f[1::7], g[key + ".f65"]) and bits_equal(b[1::7], g[key + ".b65"]) and bits_equal(s[1:], g[key + ".s65"])
+
+
+def test_estep_stress_bitexact(oracle):
+    """The real-data-shaped fixture (N runs of 2e4 / 2e5 bins, a run of homozygosity, a het-dense stretch, a segment that is
+    one long N run; tests/golden/make_golden_stress.py): the reference's statistics at the parameters of EM round 1."""
+    import gzip, os
+    from conftest import GOLD
+    lut = np.full(256, 2, np.uint8); lut[ord("T")] = 0; lut[ord("K")] = 1
+    segs, cur = [], []
+    for line in gzip.open(os.path.join(GOLD, "stress", "stress.psmcfa.gz"), "rb"):
+        if line.startswith(b">"):
+            if cur: segs.append(np.concatenate(cur))
+            cur = []
+        else:
+            cur.append(lut[np.frombuffer(line.rstrip(b"\n"), dtype=np.uint8)])
+    segs.append(np.concatenate(cur))
+    g = dict(np.load(os.path.join(GOLD, "stress", "stress_estep.npz")))
+    r = oracle.estep(g["rd1.a"], g["rd1.e"], g["rd1.a0"], segs, per_seg=True)
+    assert bits_equal(r["A"], g["rd1.A"]) and bits_equal(r["E"], g["rd1.E"]) and r["LL"] == float(g["rd1.LL"])
+    assert bits_equal(r["seg_LL"], g["rd1.seg_LL"]) and bits_equal(r["seg_chk"], g["rd1.seg_chk"])
+
+
 def test_invariants(golden, oracle):
     """sum A = sum E = L-1 per segment (+ the HMM_TINY seeds); posterior sums to 1."""
     p = golden.params("n64_curve")

@@ -345,44 +345,38 @@ def group_engine_run(hip, segs, devices, moving, steps, warmup, mode):
         g.close()
 
 
-def boot_extra(sim, a, e, a0, n_rep=16, iters=3):
-    """Config 4 through the product binary: psmc_boot -R 16 -- -N3 over splitfa-like trunks of the benchmark genome
-    (utils/splitfa.c:20-35: 500 k-bin trunks), exact and fast mode, per-iteration times from PSMC_TIMING (the first
-    iterations of the exact mode pay for the first touch of its table memory: the last one is the steady state)."""
+def boot_extra(n_rep=16, iters=3):
+    """Config 4 through the product binary: psmc_boot -R 16 -- -N3 over the splitfa trunks of the benchmark genome
+    (utils/splitfa.c:20-35: 500 k-bin trunks; scripts/northstar_data.py), fast and exact mode, per-iteration times from
+    PSMC_TIMING; and the same exact job with the main run beside it (psmc_boot --main: README:49-62 as one job).
+    The fast run comes FIRST: the device memory a process leaves behind is cleared by the driver when the next process
+    allocates it -- after an exact batch (250 GB of tables) that costs the next process ~4 s inside its first large
+    hipMalloc, which round 4's record showed as a 5.7 s first iteration of the fast run (profiles/r05_boot_first_iteration.txt)."""
     import re, subprocess, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import northstar_data as nd
     host = os.path.join(ROOT, "psmc_amd", "host")
-    lens = sim.human_like_lengths(30_000_000, n_seg=22)
-    segs = sim.simulate_genome(a, e, a0, lens, seed=43)
-    trunks = []
-    for s in segs:
-        L, pos = len(s), 0
-        while L - pos >= 750_000:
-            trunks.append(s[pos:pos + 500_000]); pos += 500_000
-        trunks.append(s[pos:])
     tmp = tempfile.mkdtemp(prefix="psmc_bench_")
-    path = os.path.join(tmp, "split.psmcfa")
-    conv = np.frombuffer(b"TKN", dtype=np.uint8)
-    with open(path, "wb") as fh:
-        for i, s in enumerate(trunks):
-            fh.write((">t%d\n" % i).encode())
-            t = conv[s]
-            n60 = len(t) // 60 * 60
-            fh.write(np.concatenate([t[:n60].reshape(-1, 60), np.full((n60 // 60, 1), 10, np.uint8)], axis=1).tobytes())
-            if n60 < len(t):
-                fh.write(t[n60:].tobytes() + b"\n")
-    res = {"workload": "%d trunks, %d bins, longest %d; %d replicates, -N%d -t15 -r5 -p %s" % (len(trunks), sum(len(t) for t in trunks), max(len(t) for t in trunks), n_rep, iters, PATTERN),
+    fd = nd.files(tmp)
+    res = {"workload": "%d trunks, %d bins, longest %d; %d replicates, -N%d -t15 -r5 -p %s" % (fd["n_trunks"], fd["trunk_bins"], fd["longest_trunk"], n_rep, iters, PATTERN),
            "note": "psmc_boot binary (psmc_hip_estep_batch under it): all replicates in lock step, E-steps batched on the device, M-steps on host threads; "
-                   "per_iteration_ms covers ALL replicates"}
+                   "per_iteration_ms covers ALL replicates; exact_with_main: the same plus the main run of the 90-segment genome on a thread of its own (--main)"}
     try:
-        for m in ("exact", "fast"):
-            env = dict(os.environ, PSMC_HIP_MODE=m, PSMC_TIMING="1")
+        for m in ("fast", "exact", "exact_with_main"):
+            env = dict(os.environ, PSMC_HIP_MODE=m.split("_")[0], PSMC_TIMING="1")
+            cmd = [os.path.join(host, "psmc_boot"), "-R", str(n_rep), "-S", "1000", "-O", os.path.join(tmp, "b_%s-%%d.psmc" % m)]
+            if m == "exact_with_main":
+                cmd += ["--main", os.path.join(tmp, "b_main.psmc"), "--main-input", fd["genome"]]
+            cmd += ["--", "-N%d" % iters, "-t15", "-r5", "-p", PATTERN, fd["split"]]
             t0 = time.perf_counter()
-            r = subprocess.run([os.path.join(host, "psmc_boot"), "-R", str(n_rep), "-S", "1000", "-O", os.path.join(tmp, "b_%s-%%d.psmc" % m), "--",
-                                "-N%d" % iters, "-t15", "-r5", "-p", PATTERN, path], capture_output=True, text=True, env=env, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
             wall = time.perf_counter() - t0
             its = [(float(x.group(1)), float(x.group(2))) for x in re.finditer(r"E-steps ([0-9.]+) ms on \d+ device\(s\), M-steps ([0-9.]+) ms", r.stderr)]
             res[m] = {"rc": r.returncode, "wall_s": round(wall, 2), "per_iteration_ms": [{"esteps": x, "msteps": y} for x, y in its],
                       "esteps_ms_per_replicate_last": (its[-1][0] / n_rep) if its else None}
+            mes = [float(x.group(1)) for x in re.finditer(r"\[psmc\] E-step ([0-9.]+) ms", r.stderr)]
+            if mes:
+                res[m]["main_run_estep_ms"] = mes
             if r.returncode != 0:
                 res[m]["stderr_tail"] = r.stderr[-300:]
     finally:
@@ -670,14 +664,26 @@ def main():
             lens_l = np.array([len(s) for s in segs], dtype=np.int32)
             off = np.concatenate([[0], np.cumsum((lens_l.astype(np.int64) + 63) // 64 * 64)])
             d_obs = sh.d_obs
+            pm = moving[1 % len(moving)]
+            r_fast = sh.es.estep(*pm)            # what the timed path computes, at the parameters the exact E-step below is run with
+            f_fast = sh.es.estep_factored(*pm)
             sh.es.close()
             ex = hip.HipEStep(N_STATES, device=local, mode=hip.MODE_EXACT)
             ex.load_segments_device(d_obs.data_ptr(), off[:-1], lens_l, keepalive=d_obs)
             ex.estep(a, e, a0)
-            t1 = time.perf_counter(); ex.estep(*moving[1 % len(moving)]); dte = time.perf_counter() - t1
+            t1 = time.perf_counter(); r_ex = ex.estep(*pm); dte = time.perf_counter() - t1
+            from psmc_amd.parity import fast_error_metrics
+            fm = fast_error_metrics(r_fast, r_ex, pm[0], pm[1])
+            lo_, up_ = np.tril(r_ex["A"], -1), np.triu(r_ex["A"], 1)
+            ts_ = np.stack([lo_.sum(1), up_.sum(1), np.diag(r_ex["A"]).copy(), lo_.sum(0), up_.sum(0)])
+            fm["factored_sums_max"] = float(np.abs(f_fast["sums"] - ts_).max() / np.abs(ts_).max())
+            fm["factored_sums_cell"] = float((np.abs(f_fast["sums"] - ts_) / ts_)[ts_ >= 1e-6 * ts_.max()].max())
             out["exact_mode"] = {"value": bins / dte, "unit": "bins/s", "ms_per_step": dte * 1e3,
                                  "kernels_ms": ex.timing(),
-                                 "note": "bit-identical to khmm.c; one wave per segment, critical path = longest segment (%d bins)" % int(lens_l.max())}
+                                 "note": "bit-identical to khmm.c; one wave per segment, critical path = longest segment (%d bins)" % int(lens_l.max()),
+                                 "fast_vs_exact": dict(fm, note="the timed (fast) E-step against this exact one at the same parameters, full size: A_max / E_max = "
+                                                                "max|x - ref| / max|ref| (the gate, 1e-10); A_cell / E_cell = largest relative error of a cell >= 1e-6 x the "
+                                                                "largest; QA / QE = relative error of sum A log a and sum E log e, what hmm_Q reads (psmc_amd/parity.py)")}
             ex.close()
         except Exception as ex_:  # the headline number must survive an extra's failure
             out["exact_mode"] = {"error": str(ex_)}
@@ -776,7 +782,7 @@ def main():
             except Exception:
                 pass
             torch.cuda.empty_cache()
-            out["boot"] = boot_extra(sim, a, e, a0)
+            out["boot"] = boot_extra()
         except Exception as ex_:
             out["boot"] = {"error": str(ex_)}
     if rank == 0:

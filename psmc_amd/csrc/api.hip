@@ -170,7 +170,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
 	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_gate, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol,
-	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar, c->d_s_all, c->d_cu_mask};
+	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar, c->d_s_all, c->d_cu_mask, c->d_lkp};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -213,7 +213,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
 	else if (k == "share_learn") { c->share_learn = v != 0 ? 1 : 0; }
-	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; c->reserved_refwd = -1; }
+	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; c->reserved_refwd = -1; c->reserved_cap = 0; }
 	else if (k == "batch_sort") { c->batch_sort = v != 0 ? 1 : 0; }
 	else if (k == "batch_slots") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_slots = (int)v; }
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
@@ -230,7 +230,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 int set_segments_common(psmc_hip_ctx *c, int n_seg, const int32_t *L)
 {
 	destroy_kids(c); // batch children hold plans over the previous segments
-	c->reserved_refwd = -1;
+	c->reserved_refwd = -1; c->reserved_cap = 0;
 	c->n_seg = n_seg;
 	c->L.assign(L, L + n_seg);
 	int rc;
@@ -453,7 +453,7 @@ int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins, bool need_f)
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
 		if (c->d_s) { (void)hipFree(c->d_s); c->d_s = nullptr; }
 		if (c->d_sb) { (void)hipFree(c->d_sb); c->d_sb = nullptr; }
-		c->have_b = false; c->tab_bins = 0; c->reserved_refwd = -1;
+		c->have_b = false; c->tab_bins = 0; c->reserved_refwd = -1; c->reserved_cap = 0;
 		(void)hipGetLastError();
 		rc = ensure_tables_once(c, need_b, bins, need_f);
 	}

@@ -84,11 +84,15 @@ extern "C" int psmc_hip_reserve_batch_tables(psmc_hip_ctx *c, int64_t max_bins)
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "reserve_batch_tables: no segments loaded");
 	int64_t cap = 0;
 	bool refwd = false;
-	c->reserved_refwd = -1;
+	c->reserved_refwd = -1; c->reserved_cap = 0;
 	int rc = batch_refwd(c, max_bins, &refwd);
 	if (rc || (rc = batch_capacity(c, &cap, refwd, max_bins))) return rc;
 	rc = ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !refwd);
-	if (rc == 0 && c->exact_refwd < 0) c->reserved_refwd = refwd ? 1 : 0; // (a fixed "exact_refwd" needs no memory)
+	if (rc == 0) {
+		if (c->exact_refwd < 0) c->reserved_refwd = refwd ? 1 : 0; // (a fixed "exact_refwd" needs no memory)
+		c->reserved_cap = cap; // the batches that follow plan their launches for THIS capacity: a second estimate from a different bound
+		                       // (the call-wide scale-factor table is sized by the bound) would re-allocate 250 GB in the first EM iteration
+	}
 	return rc;
 }
 
@@ -117,6 +121,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	for (const RepSel &R : reps) all_bins += R.bins;
 	bool refwd = false;
 	if ((rc = batch_refwd(c, all_bins, &refwd)) || (rc = batch_capacity(c, &cap, refwd, all_bins))) return rc;
+	if (c->reserved_cap > 0 && c->batch_bins <= 0) cap = std::min(cap, c->reserved_cap);
 	size_t n_entries_all = 0;
 	for (const RepSel &R : reps) n_entries_all += R.work.size();
 	// sweeps per work-group sharing one parameter set: four with 64 states (k_bwd_exact, k_expect_exact_rf2), up to four with
@@ -226,7 +231,6 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	for (int g = 0; g < n_launches; ++g) {
 		const double t_a = now();
 		const int e0 = l_first[g], nw = l_first[g + 1] - e0;
-		const int64_t s_base = fwd_all ? wtab_s[e0] : 0;
 		int64_t run = 0; int32_t longest = 0;
 		for (int i = e0; i < e0 + nw; ++i) if (wseg[i] >= 0) { run = std::max(run, wtab[i] + padded_len(wseg[i])); longest = std::max(longest, c->L[wseg[i]]); }
 		EstepLaunch p;
@@ -240,27 +244,32 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		if (launch_exact(p) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_exact (batch)", hipGetLastError());
 		if (dbg_t) (void)hipStreamSynchronize(c->stream);
 		const double t_c = now();
-		c->h_s.resize((size_t)run);
+		// hmm_lk of the launch's entries (khmm.c:245-260): the running products on the device (k_lk_products: the same multiplications
+		// in the same order), the platform's log() of the few numbers that are logged here -- instead of reading 8 bytes per bin back
+		const int LC = psmc_hip_ctx::LKP_CAP;
+		if (c->lkp_cap < (size_t)nw) { if ((rc = dev_alloc(c, &c->d_lkp, (size_t)nw * LC))) return rc; c->lkp_cap = (size_t)nw; }
+		if (launch_lk_products(c->stream, p, fwd_all ? c->d_s_all : c->d_s, LC, c->d_lkp) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_lk_products", hipGetLastError());
+		c->h_lkp.resize((size_t)nw * LC);
 		HIPCHK(c, hipMemcpyAsync(c->h_segA.data() + (size_t)e0 * S * S, c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(c->h_segE.data() + (size_t)e0 * 3 * S, c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipMemcpyAsync(c->h_s.data(), (fwd_all ? c->d_s_all : c->d_s) + s_base, sizeof(double) * (size_t)run, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->h_lkp.data(), c->d_lkp, sizeof(double) * (size_t)nw * LC, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		const double t_d = now();
 		collect_timing(c);
-		// hmm_lk of every entry of the launch (khmm.c:245-260): a running product over all of its bins with the platform log() -- 0.7 ns
-		// per bin, 0.36 s per 28 replicates on one core; the entries are independent, so host threads share them (each value is computed
-		// by one thread exactly as before: bit-identical)
-		{
-			const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-			std::atomic<size_t> next(0);
-			auto work = [&]() {
-				for (size_t i = next.fetch_add(1); i < (size_t)nw; i = next.fetch_add(1))
-					if (wseg[e0 + i] >= 0) lk_all[(size_t)e0 + i] = host_lk(&c->h_s[(size_t)wtab[e0 + i]], c->L[wseg[e0 + i]]);
-			};
-			std::vector<std::thread> th;
-			for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-			work();
-			for (std::thread &t : th) t.join();
+		for (int i = 0; i < nw; ++i) {
+			if (wseg[e0 + i] < 0) continue;
+			const double *q = &c->h_lkp[(size_t)i * LC];
+			const int cnt = (int)q[0];
+			if (cnt >= 1 && cnt < LC) {
+				double sum = 0.0;
+				for (int j = 1; j <= cnt; ++j) sum += log(q[j]);
+				lk_all[(size_t)e0 + i] = sum;
+			} else { // more resets than the buffer holds (scale factors far from 1): this entry's scale factors, the host's product
+				const int32_t sg = wseg[e0 + i];
+				c->h_s.resize((size_t)c->L[sg]);
+				HIPCHK(c, hipMemcpy(c->h_s.data(), (fwd_all ? c->d_s_all + wtab_s[e0 + i] : c->d_s + wtab[e0 + i]), sizeof(double) * (size_t)c->L[sg], hipMemcpyDeviceToHost));
+				lk_all[(size_t)e0 + i] = host_lk(c->h_s.data(), c->L[sg]);
+			}
 		}
 		if (dbg_t) fprintf(stderr, "[psmc_hip] batch launch %d: %d entries (longest %d bins), %.1f M table bins | prepare %.3f s, kernels %.3f (fwd %.0f bwd %.0f expect %.0f ms%s), read-back %.3f, hmm_lk %.3f\n",
 		                   g, nw, (int)longest, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3],

@@ -1173,6 +1173,49 @@ int launch_post_counts(hipStream_t st, const double *f, const double *b, const d
 	return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- hmm_lk without the table read-back
+// hmm_lk (khmm.c:245-260) is a running product of the scale factors, `prod *= s[u]`, that is logged and reset whenever it leaves
+// [1e-25, 1e25), plus one last log.  The logarithm must be the host's (the reference calls the platform libm), but the products are
+// plain IEEE multiplications in position order: the device forms them -- the same multiplications in the same order, hence the same
+// bits -- and hands over only the numbers that are logged, a few dozen per entry instead of 8 bytes per bin (the exact batch read 4 GB
+// of scale factors per launch over PCIe for this: 0.08 s of every 1.2 s).  One wave per entry: 64 scale factors per load, the chain
+// itself wave-uniform.  out[entry * cap]: [0] = the count n as a double, [1 .. n] the products in order (the last one is the final
+// `sum += log(prod)`); n > cap - 1: overflow, the host reads that entry's scale factors instead.
+__global__ __launch_bounds__(64) void k_lk_products(const int32_t *__restrict__ seg_len, const ExWork wl, const int64_t *__restrict__ seg_off,
+                                                    const double *__restrict__ s, int cap, double *__restrict__ out)
+{
+	const int lane = threadIdx.x;
+	const int seg = wl.seg[blockIdx.x];
+	double *o = out + (int64_t)blockIdx.x * cap;
+	if (seg < 0) { if (lane == 0) o[0] = 0.0; return; }
+	const int L = seg_len[seg];
+	const double *so = s + (wl.tab_s ? wl.tab_s[blockIdx.x] : (wl.tab ? wl.tab[blockIdx.x] : seg_off[seg]));
+	double prod = 1.0;
+	int n = 0;
+	for (int base = 0; base < L; base += 64) {
+		const int nb = min(64, L - base);
+		const double sv = so[base + min(lane, nb - 1)];
+		for (int i = 0; i < nb; ++i) {
+			prod = prod * readlane_f64(sv, i);
+			if (prod < PSMC_TINY || prod >= 1.0 / PSMC_TINY) { // khmm.c:252-255 (wave-uniform)
+				++n;
+				if (lane == 0 && n < cap) o[n] = prod;
+				prod = 1.0;
+			}
+		}
+	}
+	++n; // khmm.c:257: the last log, whatever the product
+	if (lane == 0) { if (n < cap) o[n] = prod; o[0] = (double)n; }
+}
+
+int launch_lk_products(hipStream_t st, const EstepLaunch &p, const double *d_s, int cap, double *d_out)
+{
+	if (p.n_work <= 0) return 0;
+	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.d_work_tab_s, p.n_work, p.par_stride};
+	hipLaunchKernelGGL(k_lk_products, dim3(p.n_work), dim3(64), 0, st, p.d_seg_len, wl, p.d_seg_off, d_s, cap, d_out);
+	return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers
 int launch_exact(const EstepLaunch &p)
 {

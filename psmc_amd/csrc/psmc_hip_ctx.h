@@ -141,9 +141,12 @@ struct psmc_hip_ctx {
 	int32_t *d_bw_seg = nullptr, *d_bw_par = nullptr; int64_t *d_bw_tab = nullptr; size_t bw_cap = 0; // work list of a group
 	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_rep][PAR_LEN] parameter blocks of a batch call
 	int *d_cu_mask = nullptr;          // k_expect_exact_rf2: one word per compute unit (which role order its resident work-groups took), 4096 words
+	double *d_lkp = nullptr; size_t lkp_cap = 0; std::vector<double> h_lkp; // hmm_lk's logged products of a launch's entries (k_lk_products), LKP_CAP doubles each
+	static constexpr int LKP_CAP = 1024;
 	double *d_s_all = nullptr; size_t s_all_cap = 0; // exact batch without the f table, several groups: the scale factors of ALL replicates (one forward pass)
 	int batch_sort = 1;                // "batch_sort": the exact batch deals ENTRIES to its launches longest first (api_batch.hip); 0 = replicate-major order
 	int batch_slots = 0;               // "batch_slots": entries per launch of an exact batch that needs several (0: four per compute unit of the context's share)
+	int64_t reserved_cap = 0;          // ... and the per-launch capacity it sized the tables for
 	int reserved_refwd = -1;           // what psmc_hip_reserve_batch_tables decided about the f table (-1: nothing reserved): the batches that follow keep it
 	int cu_first = 0, cu_count = 0;    // psmc_hip_set_cu_range: the streams of this context are masked to these compute units (0: the whole device)
 	int last_batch_groups = 0;

@@ -134,6 +134,7 @@ inline bool dbg_sync_on() { static const bool on = getenv("PSMC_HIP_DEBUG_SYNC")
 constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
+int launch_lk_products(hipStream_t st, const EstepLaunch &p, const double *d_s, int cap, double *d_out); // estep_exact.hip: hmm_lk's products on the device
 int launch_exact_wide(const EstepLaunch &p); // estep_wide.hip: 129 .. 1024 states
 int launch_post_decode_wide(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n, int S, int32_t *path, double *maxp);
 int launch_post_full_wide(hipStream_t st, const double *a, const double *e, const uint8_t *obs, const double *f, const double *b, const double *s,

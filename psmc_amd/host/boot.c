@@ -100,6 +100,22 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		R->sums = factored ? (double *)calloc((size_t)5 * N, sizeof(double)) : 0;
 		R->E = (double *)calloc((size_t)2 * N, sizeof(double));
 	}
+	if (bb->reserve) { /* the replicates are drawn: every device learns what its batch will need, and takes it before the first E-step */
+		for (int d = 0; d < bb->n_dev; ++d) {
+			int64_t bins = 0;
+			unsigned char *seen = (unsigned char *)malloc((size_t)(in.n_seg > 0 ? in.n_seg : 1));
+			for (int r = d; r < n_rep; r += bb->n_dev) {
+				memset(seen, 0, (size_t)in.n_seg);
+				for (int i = 0; i < rep[r].n_idx; ++i) {
+					const int32_t sg = rep[r].idx[i];
+					if (!seen[sg]) { seen[sg] = 1; bins += ((int64_t)in.seg[sg].L + 63) & ~(int64_t)63; }
+				}
+			}
+			free(seen);
+			const int rc = bb->reserve(bb->self, d, bins);
+			if (rc) { fprintf(stderr, "psmc_boot: cannot reserve the tables on device %d: %s\n", d, bb->error(bb->self, d)); goto done_rep; }
+		}
+	}
 	const int timing = getenv("PSMC_TIMING") != 0;
 	int failed = 0;
 	/* The main run starts now: every draw from drand48 -- its own (psmc_run_begin) and the replicates' (above) -- is done, and from here

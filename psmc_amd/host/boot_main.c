@@ -12,11 +12,15 @@
  *
  * --main / --main-input: the whole workflow of the reference's README:49-62 as ONE job -- the un-resampled main run
  * (`psmc <psmc options> -o out.psmc in.psmcfa`, on the unsplit input) runs on a thread of its own BESIDE the replicates, on the
- * first device.  Exact mode: its context is masked to PSMC_BOOT_MAIN_CUS compute units (default 24: its ~90 sequential sweeps
- * keep a SIMD each) and the batch to the others, so that the two never share a SIMD and the batch sizes its launches for its
- * share (psmc_hip_set_cu_range); the main run's 3 s E-steps -- the critical path of one wave over the longest chromosome -- then
- * hide behind the batch's 6 s ones instead of preceding them.  The main output is byte-identical to `psmc`'s, the replicates to
- * a run without --main (tests/test_host_cli.py).
+ * first device; its 3 s E-steps -- the critical path of one wave over the longest chromosome -- hide behind the batch's 7 s ones
+ * instead of preceding them.  Exact mode, default (PSMC_BOOT_MAIN_CUS=0): no compute-unit masks; the batch keeps
+ * PSMC_BOOT_MAIN_SLOTS (64) entry slots per launch free, because each of the main run's long sweeps keeps one recompute
+ * work-group out of its compute unit (measured, 100 replicates of a 30 M-bin genome: batch 6.75 -> 7.17 s per iteration, main
+ * run 3.1 -> 3.25 s per E-step).  PSMC_BOOT_MAIN_CUS=<multiple of 32>: the main run's context is masked to that many compute
+ * units and the batch to the others (psmc_hip_set_cu_range; the mask's bits go round the XCDs, then round the four shader
+ * engines of an XCD, so only multiples of 32 leave every engine the same number of units -- 24 left the engines 7 / 7 / 7 / 8
+ * and the batch's launches took 1.6 x as long; with 32: 7.42 s).  The main output is byte-identical to `psmc`'s, the
+ * replicates to a run without --main (tests/test_host_cli.py).
  * There is no CPU E-step in this binary. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,17 +34,13 @@ typedef struct { int n_dev, n_states, n_rep; psmc_hip_ctx *ctx[MAX_DEV]; } hip_b
 
 static int bb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L)
 {
-	psmc_hip_ctx *c = ((hip_bb *)self)->ctx[dev];
-	int rc = psmc_hip_load_segments(c, n_seg, sym, L);
-	/* exact mode: take the batch's table memory now (the driver clears what it hands out: seconds for 250 GB) -- part of loading,
-	 * not of the first EM iteration */
-	if (rc == 0) {
-		const hip_bb *h = (const hip_bb *)self;
-		int64_t all = 0; /* this device's share of the replicates x every trunk (padded to 64 bins): an upper bound of what one group can hold */
-		for (int i = 0; i < n_seg; ++i) all += ((int64_t)L[i] + 63) & ~(int64_t)63;
-		rc = psmc_hip_reserve_batch_tables(c, all * ((h->n_rep + h->n_dev - 1) / h->n_dev));
-	}
-	return rc;
+	return psmc_hip_load_segments(((hip_bb *)self)->ctx[dev], n_seg, sym, L);
+}
+/* exact mode: take the batch's table memory before the first EM iteration, sized for the replicates as drawn (the driver clears what
+ * it hands out: seconds for 250 GB) -- part of the set-up, not of an iteration */
+static int bb_reserve(void *self, int dev, int64_t table_bins)
+{
+	return psmc_hip_reserve_batch_tables(((hip_bb *)self)->ctx[dev], table_bins);
 }
 static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
                           const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
@@ -135,7 +135,7 @@ int main(int argc, char *argv[])
 	}
 	h.n_rep = n_rep;
 	const char *fs = getenv("PSMC_FACTORED");
-	psmc_batch_backend bb = {&h, h.n_dev, bb_load, bb_estep_batch, bb_error, bb_destroy, mode == PSMC_HIP_MODE_FAST && !(fs && atoi(fs) == 0)};
+	psmc_batch_backend bb = {&h, h.n_dev, bb_load, bb_estep_batch, bb_error, bb_destroy, mode == PSMC_HIP_MODE_FAST && !(fs && atoi(fs) == 0), bb_reserve};
 	/* the main run: a context of its own on the first device, begun (header, input, RD 0, tables) before the batch sizes its tables */
 	psmc_estep_backend be_main;
 	psmc_run_state *main_run = 0;
@@ -145,7 +145,7 @@ int main(int argc, char *argv[])
 		int rc = psmc_hipbe_create(&be_main, n_states, mode, use_factored, 0, list[0]);
 		if (rc == 0 && mode == PSMC_HIP_MODE_EXACT) { /* split the first device: [0, m) main run, [m, all) the batch contexts on it */
 			const char *ms = getenv("PSMC_BOOT_MAIN_CUS");
-			const int cus = psmc_hip_device_cus(list[0]), m = ms ? atoi(ms) : 24;
+			const int cus = psmc_hip_device_cus(list[0]), m = ms ? atoi(ms) : 0;
 			if (m > 0 && m < cus) {
 				rc = psmc_hip_set_cu_range(psmc_hipbe_ctx(&be_main), 0, m);
 				for (int d = 0; d < h.n_dev && rc == 0; ++d)

@@ -164,6 +164,10 @@ typedef struct psmc_batch_backend {
 	const char *(*error)(void *self, int dev);
 	void (*destroy)(void *self);
 	int  can_factor; /* estep_batch can produce the triangular sums directly */
+	/* optional (may be NULL): called once per device after the replicates are drawn and before the first E-step, with the table
+	 * bins the device's replicates need together (the padded lengths of every replicate's UNIQUE trunks): the backend can take
+	 * its table memory now, sized for exactly this job (psmc_hip_reserve_batch_tables) */
+	int  (*reserve)(void *self, int dev, int64_t table_bins);
 } psmc_batch_backend;
 /* main_run (may be NULL): a psmc_run_begin()'ed run -- the un-resampled main run of README:49-53 on its own input -- whose EM
  * rounds psmc_boot_run drives on a thread of its own beside the replicates (psmc_boot --main) */

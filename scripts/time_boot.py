@@ -14,6 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
 HOST = os.path.join(ROOT, "psmc_amd", "host")
 
 
@@ -21,29 +22,11 @@ def main():
     out_json = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r02_boot_timing.json")
     n_rep = int(os.environ.get("BOOT_REPLICATES", "100"))
     iters = int(os.environ.get("BOOT_ITERS", "3"))
-    from psmc_amd import sim
-    g = np.load(os.path.join(ROOT, "tests", "golden", "hmm_params.npz"))
-    a, e, a0 = g["n64_curve.a"], g["n64_curve.e"], g["n64_curve.a0"]
-    lens = sim.human_like_lengths(30_000_000, n_seg=22)
-    segs = sim.simulate_genome(a, e, a0, lens, seed=43)
-    trunks = []
-    for s in segs:            # splitfa: 500k-bin trunks, merge a tail < 1.5 trunks into the last one
-        L, pos = len(s), 0
-        while L - pos >= 750_000:
-            trunks.append(s[pos:pos + 500_000]); pos += 500_000
-        trunks.append(s[pos:])
+    import northstar_data as nd
     tmp = os.environ.get("TMPDIR", "/tmp")
-    path = os.path.join(tmp, "split.psmcfa")
-    conv = np.frombuffer(b"TKN", dtype=np.uint8)
-    with open(path, "wb") as fh:
-        for i, s in enumerate(trunks):
-            fh.write((">t%d\n" % i).encode())
-            t = conv[s]
-            n60 = len(t) // 60 * 60
-            fh.write(np.concatenate([t[:n60].reshape(-1, 60), np.full((n60 // 60, 1), 10, np.uint8)], axis=1).tobytes())
-            if n60 < len(t):
-                fh.write(t[n60:].tobytes() + b"\n")
-    res = dict(workload="%d trunks (%d bins, longest %d), %d replicates, -N%d -t15 -r5 -p 4+25*2+4+6" % (len(trunks), sum(len(t) for t in trunks), max(len(t) for t in trunks), n_rep, iters), runs={})
+    fd = nd.files(tmp, want=("split",))
+    path = fd["split"]
+    res = dict(workload="%d trunks (%d bins, longest %d), %d replicates, -N%d -t15 -r5 -p 4+25*2+4+6" % (fd["n_trunks"], fd["trunk_bins"], fd["longest_trunk"], n_rep, iters), runs={})
     args = ["-N%d" % iters, "-t15", "-r5", "-p", "4+25*2+4+6", path]
     for mode in (("fast",) if os.environ.get("BOOT_FAST_ONLY") else ("exact",) if os.environ.get("BOOT_EXACT_ONLY") else ("exact", "fast")):
         env = dict(os.environ, PSMC_HIP_MODE=mode, PSMC_TIMING="1")
@@ -56,7 +39,7 @@ def main():
                                                stderr_tail=r.stderr[-400:] if r.returncode else "")
         sys.stderr.write("[time_boot] %s: %.1f s, iterations %s\n" % (mode, wall, its))
         for ln in r.stderr.splitlines():   # PSMC_HIP_DEBUG_TIMES=1: the library's per-group breakdown of the exact batch
-            if "batch group" in ln: sys.stderr.write(ln[:260] + "\n")
+            if "batch launch" in ln or "fast batch" in ln or "batch:" in ln: sys.stderr.write(ln[:260] + "\n")
         t0 = time.time()
         one = subprocess.run([os.path.join(HOST, "psmc"), "-b"] + args, capture_output=True, text=True, env=dict(env, PSMC_SEED="1000"))
         w1 = time.time() - t0

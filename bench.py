@@ -175,7 +175,14 @@ def factored_roofline(bins, kern, dt_step):
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "sq_factored.json")))
         k = pj["kernels"]["k_bwd_acc_ckpt"]
-        if abs(pj["bins"] - bins) <= 64 and kern.get("expect", 0) > 0:
+        # the instruction counts are a STATIC record: valid only for the kernel sources they were taken from
+        import hashlib
+        sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, s), "rb").read() for s in pj.get("kernel_sources", []))).hexdigest()[:16]
+        r["counts_valid"] = bool(pj.get("kernel_src_sha16")) and sha == pj.get("kernel_src_sha16")
+        r["clock_assumed_GHz"] = clock / 1e9
+        if not r["counts_valid"]:
+            r["note"] = "profiles/sq_factored.json was taken from other kernel sources (sha %s, now %s): no issue roofline until it is re-taken (scripts/lease.sh prof)" % (pj.get("kernel_src_sha16"), sha)
+        elif abs(pj["bins"] - bins) <= 64 and kern.get("expect", 0) > 0:
             r["valu_per_bin"] = k["valu_per_launch"] / pj["bins"]
             r["achieved"] = k["valu_per_launch"] / (kern["expect"] * 1e-3)
             r["frac"] = r["achieved"] / peak

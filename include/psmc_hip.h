@@ -97,6 +97,8 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           auto: with the factored statistics of a genome-sized input (their forward sweep stores checkpoints only, three
  *                           waves per SIMD: issue-bound); slower for the full-count E-step (forward sweep paced by its table stores) and for
  *                           shard-sized inputs (one wave per SIMD: the 8 x 8 step is a third longer)
+ *  "lanes8b"       0        1: the factored back half without checkpoints ("ckpt" = 0) runs eight tiles per wave too (8 lanes x 8 states,
+ *                           one wave per SIMD).  A measured experiment of round 5, kept for A/B: slower than four tiles
  *  "gate"          auto     1: one-wave gate kernels order the DISPATCH of phase 1's grids across streams -- walks, then the bulk
  *                           grid, then the transfer matrices -- so that every walk gets a SIMD slot of its own (they give up after
  *                           ~200 us); 0: whatever order the queues come up in.  auto: with coarse items

@@ -1,12 +1,12 @@
 #!/bin/bash
-# SQ counters + isolated durations for one option set of scripts/sweep_factored.py (ARGS), counters in CNT
+# SQ counters + isolated durations for one option set of profiles/experiments/sweep_factored.py (ARGS), counters in CNT
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/sq2; rm -f $R/gpurun_out/sq2/*
 cd /tmp
 CNT=${CNT:-"SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"}
-timeout 600 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/sq2 -o run -- python $R/scripts/sweep_factored.py ${ARGS:---full fuse=1} > $R/gpurun_out/sq2/run.log 2> $R/gpurun_out/sq2/run.err
+timeout 600 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/sq2 -o run -- python $R/profiles/experiments/sweep_factored.py ${ARGS:---full fuse=1} > $R/gpurun_out/sq2/run.log 2> $R/gpurun_out/sq2/run.err
 echo "exit $?"; tail -3 $R/gpurun_out/sq2/run.err | cut -c1-300
 cd $R
 python - <<'PY'

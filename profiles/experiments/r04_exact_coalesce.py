@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Driver of scripts/r04/exact_coalesce.c: 25 EM rounds x 120 tile starts, CPU only.
+"""Driver of profiles/experiments/r04_exact_coalesce.c: 25 EM rounds x 120 tile starts, CPU only.
 
-    python scripts/r04/exact_coalesce.py [out.txt]
+    python profiles/experiments/r04_exact_coalesce.py [out.txt]
 """
 import json, os, struct, subprocess, sys
 import numpy as np

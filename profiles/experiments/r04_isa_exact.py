@@ -5,7 +5,7 @@ A wave alone on its SIMD -- the exact sweeps of a single E-step: one wave per se
 per four cycles, so the loop's instruction count x 4 cycles x positions is the floor of the sweep (DESIGN.md section 8,
 "Exact mode, instruction by instruction").  Prints, per kernel, its largest natural loops: label, instructions, mix.
 
-    python scripts/r04/isa_exact.py > profiles/r04b_exact_isa_counts.txt
+    python profiles/experiments/r04_isa_exact.py > profiles/r04b_exact_isa_counts.txt
 """
 import os, re, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,7 @@ def main():
                     "-S", "--cuda-device-only", "-o", asm_path, os.path.join(CSRC, "estep_exact.hip")], check=True, stderr=subprocess.DEVNULL)
     asm = open(asm_path).read()
     os.unlink(asm_path)
-    print("# python scripts/r04/isa_exact.py -- innermost natural loops of the exact kernels (label, instructions, mix); straight-line count:")
+    print("# python profiles/experiments/r04_isa_exact.py -- innermost natural loops of the exact kernels (label, instructions, mix); straight-line count:")
     print("# side paths inside a loop (the rare symbols) are included once.  k_fwd_exact<REP, STORE_F>: REP 1 = v_permlane swaps (single E-step),")
     print("# 0 = ds_bpermute (batch).  The position loops of k_expect_exact / k_expect_exact_rf2 are unrolled asm blocks: see DESIGN.md for their counts.")
     for m in re.finditer(r"^(_ZN4psmc\w+):", asm, re.M):

@@ -7,7 +7,7 @@ to the tolerance: the start vector still matters.  The run machinery then pays a
 every possible start vector and a run tile needs q sweeps instead of 64 columns.  This prints, over all tile boundaries of a
 simulated chromosome, the distribution of the numerical rank of K_W at 1e-13 / 1e-12.
 
-    python scripts/r04/lowrank_experiment.py [bins=500000] [tile=1856] [W=3072] [round=10]
+    python profiles/experiments/r04_lowrank_experiment.py [bins=500000] [tile=1856] [W=3072] [round=10]
 """
 import json, os, sys
 import numpy as np

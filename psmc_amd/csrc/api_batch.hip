@@ -208,11 +208,14 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		std::vector<double> hp((size_t)n_rep * PL);
 		for (int r = 0; r < n_rep; ++r) (void)fill_params(c, a + (size_t)r * n * n, e + (size_t)r * 2 * n, a0 + (size_t)r * n, hp.data() + (size_t)r * PL);
 		HIPCHK(c, hipStreamSynchronize(c->stream));
-		HIPCHK(c, hipMemcpy(c->d_bw_seg, wseg.data(), sizeof(int32_t) * n_all, hipMemcpyHostToDevice));
-		HIPCHK(c, hipMemcpy(c->d_bw_par, wpar.data(), sizeof(int32_t) * n_all, hipMemcpyHostToDevice));
-		HIPCHK(c, hipMemcpy(c->d_bw_tab, wtab.data(), sizeof(int64_t) * n_all, hipMemcpyHostToDevice));
-		HIPCHK(c, hipMemcpy(c->d_bw_tab + n_all, wtab_s.data(), sizeof(int64_t) * n_all, hipMemcpyHostToDevice));
-		HIPCHK(c, hipMemcpy(c->d_bpar, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+		// (asynchronous copies on the context's own stream: a blocking hipMemcpy waits for every kernel on the DEVICE -- with psmc_boot
+		// --main that is the main run's 1.6 s forward sweep; measured: 11.5 instead of 7.2 s per iteration while the main run was alive)
+		HIPCHK(c, hipMemcpyAsync(c->d_bw_seg, wseg.data(), sizeof(int32_t) * n_all, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->d_bw_par, wpar.data(), sizeof(int32_t) * n_all, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->d_bw_tab, wtab.data(), sizeof(int64_t) * n_all, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->d_bw_tab + n_all, wtab_s.data(), sizeof(int64_t) * n_all, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->d_bpar, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream)); // (the host vectors go out of scope)
 	}
 	c->tables_batch = true;
 	double fwd_all_s = 0.0;
@@ -246,31 +249,39 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		const double t_c = now();
 		// hmm_lk of the launch's entries (khmm.c:245-260): the running products on the device (k_lk_products: the same multiplications
 		// in the same order), the platform's log() of the few numbers that are logged here -- instead of reading 8 bytes per bin back
-		const int LC = psmc_hip_ctx::LKP_CAP;
-		if (c->lkp_cap < (size_t)nw) { if ((rc = dev_alloc(c, &c->d_lkp, (size_t)nw * LC))) return rc; c->lkp_cap = (size_t)nw; }
-		if (launch_lk_products(c->stream, p, fwd_all ? c->d_s_all : c->d_s, LC, c->d_lkp) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_lk_products", hipGetLastError());
-		c->h_lkp.resize((size_t)nw * LC);
+		std::vector<int64_t> lkoff((size_t)nw);
+		int64_t lk_tot = 0;
+		for (int i = 0; i < nw; ++i) { lkoff[i] = lk_tot; lk_tot += wseg[e0 + i] >= 0 ? c->L[wseg[e0 + i]] / LKP_DIV + LKP_MIN : 1; }
+		if (c->lkp_cap < (size_t)lk_tot) { if ((rc = dev_alloc(c, &c->d_lkp, (size_t)lk_tot))) return rc; c->lkp_cap = (size_t)lk_tot; }
+		if (c->lkoff_cap < (size_t)nw) { if ((rc = dev_alloc(c, &c->d_lkoff, (size_t)nw))) return rc; c->lkoff_cap = (size_t)nw; }
+		HIPCHK(c, hipMemcpyAsync(c->d_lkoff, lkoff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, c->stream));
+		if (launch_lk_products(c->stream, p, fwd_all ? c->d_s_all : c->d_s, c->d_lkoff, c->d_lkp) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_lk_products", hipGetLastError());
+		c->h_lkp.resize((size_t)lk_tot);
 		HIPCHK(c, hipMemcpyAsync(c->h_segA.data() + (size_t)e0 * S * S, c->d_segA, sizeof(double) * nw * S * S, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(c->h_segE.data() + (size_t)e0 * 3 * S, c->d_segE, sizeof(double) * nw * 3 * S, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipMemcpyAsync(c->h_lkp.data(), c->d_lkp, sizeof(double) * (size_t)nw * LC, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipMemcpyAsync(c->h_lkp.data(), c->d_lkp, sizeof(double) * (size_t)lk_tot, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream)); // (lkoff stays alive until here)
 		const double t_d = now();
 		collect_timing(c);
+		int n_over = 0;
 		for (int i = 0; i < nw; ++i) {
 			if (wseg[e0 + i] < 0) continue;
-			const double *q = &c->h_lkp[(size_t)i * LC];
-			const int cnt = (int)q[0];
-			if (cnt >= 1 && cnt < LC) {
+			const int32_t sg = wseg[e0 + i];
+			const double *q = &c->h_lkp[(size_t)lkoff[i]];
+			const int cnt = (int)q[0], cap_i = c->L[sg] / LKP_DIV + LKP_MIN;
+			if (cnt >= 1 && cnt < cap_i) {
 				double sum = 0.0;
 				for (int j = 1; j <= cnt; ++j) sum += log(q[j]);
 				lk_all[(size_t)e0 + i] = sum;
-			} else { // more resets than the buffer holds (scale factors far from 1): this entry's scale factors, the host's product
-				const int32_t sg = wseg[e0 + i];
+			} else { // more logged products than the buffer holds (scale factors around 0.03 throughout): this entry's scale factors, the host's product
+				++n_over;
 				c->h_s.resize((size_t)c->L[sg]);
-				HIPCHK(c, hipMemcpy(c->h_s.data(), (fwd_all ? c->d_s_all + wtab_s[e0 + i] : c->d_s + wtab[e0 + i]), sizeof(double) * (size_t)c->L[sg], hipMemcpyDeviceToHost));
+				HIPCHK(c, hipMemcpyAsync(c->h_s.data(), (fwd_all ? c->d_s_all + wtab_s[e0 + i] : c->d_s + wtab[e0 + i]), sizeof(double) * (size_t)c->L[sg], hipMemcpyDeviceToHost, c->stream));
+				HIPCHK(c, hipStreamSynchronize(c->stream));
 				lk_all[(size_t)e0 + i] = host_lk(c->h_s.data(), c->L[sg]);
 			}
 		}
+		if (dbg_t && n_over) fprintf(stderr, "[psmc_hip] batch launch %d: %d entries logged more products than their buffer holds (host hmm_lk)\n", g, n_over);
 		if (dbg_t) fprintf(stderr, "[psmc_hip] batch launch %d: %d entries (longest %d bins), %.1f M table bins | prepare %.3f s, kernels %.3f (fwd %.0f bwd %.0f expect %.0f ms%s), read-back %.3f, hmm_lk %.3f\n",
 		                   g, nw, (int)longest, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3],
 		                   fwd_all ? (g == 0 ? (std::string("; forward pass of all entries ") + std::to_string(fwd_all_s) + " s").c_str() : "; fwd: see launch 0") : "", t_d - t_c, now() - t_d);
@@ -324,7 +335,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles;
 		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
 		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
-		k->fuse128 = c->fuse128; k->coarse = c->coarse; k->gate = c->gate; k->lanes8 = c->lanes8; k->exact_refwd = c->exact_refwd;
+		k->fuse128 = c->fuse128; k->coarse = c->coarse; k->gate = c->gate; k->lanes8 = c->lanes8; k->lanes8b = c->lanes8b; k->exact_refwd = c->exact_refwd;
 		k->merge1 = c->merge1; k->merge_order = c->merge_order; k->runs_late = c->runs_late; k->warm_shift_set = c->warm_shift_set; k->kc_sub_set = c->kc_sub_set;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];

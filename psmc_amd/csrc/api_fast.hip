@@ -418,6 +418,7 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	// auto: the factored statistics of a genome-sized input (issue-bound at three waves per SIMD); a shard-sized one runs one wave per SIMD,
 	// where the longer step of the 8 x 8 form costs more than its fewer instructions save (3.75 M bins: 3.23 vs 2.96 ms)
 	p.lanes8 = (c->lanes8 >= 0 ? c->lanes8 != 0 && p.fused != 0 : p.fused == 2 && p.n_chunks > 4096) && c->ns == 64 ? 1 : 0;
+	p.lanes8b = c->lanes8b && c->ns == 64 && p.fused == 2 && !p.ckpt ? 1 : 0;
 	p.d_gate = (c->gate >= 0 ? c->gate != 0 : coarse > 1) ? c->d_gate : nullptr;
 	p.coarse = coarse; p.d_singles_b = c->d_items + 24 * (size_t)p.n_chunks; p.n_singles_b = c->n_singles_b;
 	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles; p.count_group = c->count_group;

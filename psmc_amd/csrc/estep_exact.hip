@@ -666,7 +666,9 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 	// block k+1 are issued before block k computes (a read costs ~100 cycles, and eight exposed ones per position made the consumers the
 	// slowest waves of the group): registers 8-11 leave a block with their loads IN FLIGHT and enter the next one as its 4-7 -- only
 	// asm statements stand between (tests/test_abi.py checks the compiled code for that), and each waits (lgkmcnt counts down in issue
-	// order for LDS; foreign scalar loads in the count only make the wait longer) before it touches them.
+	// order for LDS; foreign scalar loads in the count only make the wait longer) before it touches them.  The blocks read LDS the
+	// compiler knows nothing about: they are `asm volatile` with a "memory" clobber, so that none of them can be moved across the
+	// barrier that orders the producers' writes against these reads, duplicated, or dropped.
 #define PSMC_C4_TAIL                                                                                                                  \
 	      "s_cmp_eq_u32 %24, 0\n\ts_cbranch_scc0 .Lc4s_%=\n\t"                                                                            \
 	      "v_mul_f64 %4, %4, %16\n\tv_mul_f64 %5, %5, %17\n\tv_mul_f64 %6, %6, %18\n\tv_mul_f64 %7, %7, %19\n"                                \
@@ -691,11 +693,11 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 #define PSMC_C4_IN(A, O, BL, AD, SYM)                                                                                                 \
 	        "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)                                                                                     \
 	      : "v"(q0[O]), "v"(q0[O + 1]), "v"(q0[O + 2]), "v"(q0[O + 3]), "v"(BL), "v"(AD), "v"(ap1), "v"(ap2), "s"(SYM), "n"(8 * (O))       \
-	      : "scc")
+	      : "scc", "memory")
 	// first block of a position: reads its own rows and the next block's
 #define PSMC_C4F(A, BL, AD, SYM, C0, C1, C2, C3, N0, N1, N2, N3)                                                                     \
 	{ double g0, g1, g2, g3;                                                                                                           \
-	  asm("s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+	  asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
 	      "ds_read_b64 %4, %21\n\tds_read_b64 %5, %21 offset:8\n\tds_read_b64 %6, %21 offset:16\n\tds_read_b64 %7, %21 offset:24\n\t"       \
 	      "ds_read_b64 %8, %21 offset:32\n\tds_read_b64 %9, %21 offset:40\n\tds_read_b64 %10, %21 offset:48\n\tds_read_b64 %11, %21 offset:56\n\t" \
 	      "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 	// blocks 1..6: rows O..O+3 arrive in C0..C3; reads the rows of block O/4 + 1 (LDS offset NO = 8 * (O + 4)) into N0..N3
 #define PSMC_C4M(A, O, NO, BL, AD, SYM, C0, C1, C2, C3, N0, N1, N2, N3)                                                              \
 	{ double g0, g1, g2, g3;                                                                                                           \
-	  asm("ds_read_b64 %8, %21 offset:" #NO "\n\tds_read_b64 %9, %21 offset:" #NO "+8\n\t"                                                 \
+	  asm volatile("ds_read_b64 %8, %21 offset:" #NO "\n\tds_read_b64 %9, %21 offset:" #NO "+8\n\t"                                                 \
 	      "ds_read_b64 %10, %21 offset:" #NO "+16\n\tds_read_b64 %11, %21 offset:" #NO "+24\n\t"                                           \
 	      "s_waitcnt lgkmcnt(4)\n\t"                                                                                                    \
 	      PSMC_C4_TAIL                                                                                                                  \
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void k_expect_exact_rf2(const double *__res
 	// last block: nothing to read ahead (operands 8-11 are placeholders)
 #define PSMC_C4L(A, O, BL, AD, SYM, C0, C1, C2, C3)                                                                                  \
 	{ double g0, g1, g2, g3, z0, z1, z2, z3;                                                                                           \
-	  asm("s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+	  asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
 	      PSMC_C4_TAIL                                                                                                                  \
 	      : "+v"(A[O]), "+v"(A[O + 1]), "+v"(A[O + 2]), "+v"(A[O + 3]), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(C3),                            \
 	        "=&v"(z0), "=&v"(z1), "=&v"(z2), "=&v"(z3),                                                                                    \
@@ -1179,16 +1181,18 @@ int launch_post_counts(hipStream_t st, const double *f, const double *b, const d
 // plain IEEE multiplications in position order: the device forms them -- the same multiplications in the same order, hence the same
 // bits -- and hands over only the numbers that are logged, a few dozen per entry instead of 8 bytes per bin (the exact batch read 4 GB
 // of scale factors per launch over PCIe for this: 0.08 s of every 1.2 s).  One wave per entry: 64 scale factors per load, the chain
-// itself wave-uniform.  out[entry * cap]: [0] = the count n as a double, [1 .. n] the products in order (the last one is the final
-// `sum += log(prod)`); n > cap - 1: overflow, the host reads that entry's scale factors instead.
+// itself wave-uniform.  Entry i writes to out + lk_off[i], cap = L / LKP_DIV + LKP_MIN doubles (a reset every LKP_DIV bins on average would
+// need scale factors around 0.03: ten times below a run of heterozygous bins): [0] = the count n as a double, [1 .. n] the products
+// in order (the last one is the final `sum += log(prod)`); n > cap - 1: overflow, the host reads that entry's scale factors instead.
 __global__ __launch_bounds__(64) void k_lk_products(const int32_t *__restrict__ seg_len, const ExWork wl, const int64_t *__restrict__ seg_off,
-                                                    const double *__restrict__ s, int cap, double *__restrict__ out)
+                                                    const double *__restrict__ s, const int64_t *__restrict__ lk_off, double *__restrict__ out)
 {
 	const int lane = threadIdx.x;
 	const int seg = wl.seg[blockIdx.x];
-	double *o = out + (int64_t)blockIdx.x * cap;
+	double *o = out + lk_off[blockIdx.x];
 	if (seg < 0) { if (lane == 0) o[0] = 0.0; return; }
 	const int L = seg_len[seg];
+	const int cap = L / LKP_DIV + LKP_MIN;
 	const double *so = s + (wl.tab_s ? wl.tab_s[blockIdx.x] : (wl.tab ? wl.tab[blockIdx.x] : seg_off[seg]));
 	double prod = 1.0;
 	int n = 0;
@@ -1208,11 +1212,11 @@ __global__ __launch_bounds__(64) void k_lk_products(const int32_t *__restrict__ 
 	if (lane == 0) { if (n < cap) o[n] = prod; o[0] = (double)n; }
 }
 
-int launch_lk_products(hipStream_t st, const EstepLaunch &p, const double *d_s, int cap, double *d_out)
+int launch_lk_products(hipStream_t st, const EstepLaunch &p, const double *d_s, const int64_t *d_lk_off, double *d_out)
 {
 	if (p.n_work <= 0) return 0;
 	const ExWork wl = {p.d_work, p.d_work_par, p.d_work_tab, p.d_work_tab_s, p.n_work, p.par_stride};
-	hipLaunchKernelGGL(k_lk_products, dim3(p.n_work), dim3(64), 0, st, p.d_seg_len, wl, p.d_seg_off, d_s, cap, d_out);
+	hipLaunchKernelGGL(k_lk_products, dim3(p.n_work), dim3(64), 0, st, p.d_seg_len, wl, p.d_seg_off, d_s, d_lk_off, d_out);
 	return (int)hipGetLastError();
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ int64_t readlane_i64f(int64_t v, int lane) {
 // to the boundary repairs, is computed from a forward table, and a forward REPAIR may be rewriting that table while it is
 // read (by design: the repair flags the tile, which is recomputed at the end).  The 16 lanes of a row could see different
 // scale factors, the exit vector came out bent instead of merely rescaled, and the repair of the tile below adopted it:
-// 1 E-step in 1 500 off by up to 3e-2 in a stress of tiny tiles (scripts/dbg_flaky_tiling.py), caught first as a flaky
+// 1 E-step in 1 500 off by up to 3e-2 in a stress of tiny tiles (profiles/experiments/dbg_flaky_tiling.py), caught first as a flaky
 // test_fast_odd_tilings.  The vectors that travel between tiles must depend on the observations and the parameters only.
 // Tried on top of this and removed: issuing the matrix instructions of step p between the vector instructions of step
 // p-1 (sched_group_barrier pattern, operands held for a step) -- slower, 6.49 vs 6.22 ms: the dependent chains of the scans

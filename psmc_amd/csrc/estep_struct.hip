@@ -432,7 +432,7 @@ __device__ __forceinline__ void bwd_struct_body(int block, const double *__restr
 	// highest block.  A tile that holds only position L (not valid: it owns no transition) has p_first = L - 1, which is 0 for a
 	// one-bin segment: block -1 would be read 16 bytes BELOW the segment's observations -- for the first segment below the
 	// allocation (harmless in value, the row is idle, but a page fault whenever nothing is mapped there; found with
-	// scripts/dbg_flaky_tiling.py, which recycles device memory between contexts)
+	// profiles/experiments/dbg_flaky_tiling.py, which recycles device memory between contexts)
 	const int b_first = max((p_first - 1) >> 4, 0);
 	const int nblk = valid ? b_first - ((p_low - 1) >> 4) + 1 : 0;
 	int64_t roff[R]; int rbf[R], rnb[R];

@@ -47,6 +47,7 @@ struct psmc_hip_ctx {
 	int lanes8 = -1;           // "lanes8": 64 states, fused / factored plans: the bulk sweeps of phase 1 run eight tiles per wave (8 lanes x 8 states: a quarter
 	                           // fewer vector instructions per tile-step, half the waves).  -1 = with the factored statistics of a genome-sized input only (more than one round of tiles) -- measured (round 4, genome):
 	                           // factored 10.26 -> 9.91 ms; full counts 12.09 -> 12.73 (its forward sweep is paced by 15.6 GB of stores and half as many waves hide less)
+	int lanes8b = 0;           // "lanes8b": the factored back half WITHOUT checkpoints ("ckpt" = 0) runs eight tiles per wave (round 5 experiment: slower, off)
 	int gate = -1;             // "gate": order the dispatch of phase 1's grids walks -> bulk -> transfer matrices (estep_struct.hip k_gate); -1 = with coarse
 	                           // items (measured: without them the bulk grid is the critical path and walks that land late, stacked on few SIMDs, slow fewer of its waves)
 	int *d_gate = nullptr;
@@ -141,8 +142,8 @@ struct psmc_hip_ctx {
 	int32_t *d_bw_seg = nullptr, *d_bw_par = nullptr; int64_t *d_bw_tab = nullptr; size_t bw_cap = 0; // work list of a group
 	double *d_bpar = nullptr; size_t bpar_cap = 0; // [n_rep][PAR_LEN] parameter blocks of a batch call
 	int *d_cu_mask = nullptr;          // k_expect_exact_rf2: one word per compute unit (which role order its resident work-groups took), 4096 words
-	double *d_lkp = nullptr; size_t lkp_cap = 0; std::vector<double> h_lkp; // hmm_lk's logged products of a launch's entries (k_lk_products), LKP_CAP doubles each
-	static constexpr int LKP_CAP = 1024;
+	double *d_lkp = nullptr; size_t lkp_cap = 0; std::vector<double> h_lkp; // hmm_lk's logged products of a launch's entries (k_lk_products)
+	int64_t *d_lkoff = nullptr; size_t lkoff_cap = 0;                     // ... and where each entry's begin
 	double *d_s_all = nullptr; size_t s_all_cap = 0; // exact batch without the f table, several groups: the scale factors of ALL replicates (one forward pass)
 	int batch_sort = 1;                // "batch_sort": the exact batch deals ENTRIES to its launches longest first (api_batch.hip); 0 = replicate-major order
 	int batch_slots = 0;               // "batch_slots": entries per launch of an exact batch that needs several (0: four per compute unit of the context's share)

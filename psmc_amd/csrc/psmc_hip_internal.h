@@ -78,6 +78,7 @@ struct EstepLaunch {
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
 	int lanes8;                       // 64 states: the bulk sweeps of phase 1 run eight tiles per wave (estep_struct.hip launch_fwd_struct)
+	int lanes8b;                      // 64 states, factored back half without checkpoints: eight tiles per wave as well (estep_factored.hip k_bwd_acc_struct_h8; experiment)
 	int *d_gate;                      // [0] walk blocks started, [1] bulk blocks started: the gates that order the DISPATCH of phase 1's grids (estep_struct.hip
 	                                  // k_gate); null: no gates
 	int coarse;                       // > 1: a bulk item spans up to this many tiles (one speculation per item; the backward pass of the fused /
@@ -134,7 +135,8 @@ inline bool dbg_sync_on() { static const bool on = getenv("PSMC_HIP_DEBUG_SYNC")
 constexpr int RED_ROWS = 64;
 
 int launch_exact(const EstepLaunch &p);
-int launch_lk_products(hipStream_t st, const EstepLaunch &p, const double *d_s, int cap, double *d_out); // estep_exact.hip: hmm_lk's products on the device
+constexpr int LKP_DIV = 16, LKP_MIN = 64; // k_lk_products: an entry of L bins may log L / LKP_DIV + LKP_MIN products before the host takes over
+int launch_lk_products(hipStream_t st, const EstepLaunch &p, const double *d_s, const int64_t *d_lk_off, double *d_out); // estep_exact.hip: hmm_lk's products on the device
 int launch_exact_wide(const EstepLaunch &p); // estep_wide.hip: 129 .. 1024 states
 int launch_post_decode_wide(hipStream_t st, const double *f, const double *b, const double *s, int64_t off, int L, int n, int S, int32_t *path, double *maxp);
 int launch_post_full_wide(hipStream_t st, const double *a, const double *e, const uint8_t *obs, const double *f, const double *b, const double *s,

@@ -4,7 +4,7 @@ or rank 0's share of N GPUs.  (Written for the adaptive warm-ups of round 3, rem
 import json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, bench
 from psmc_amd import hip, sim

@@ -7,10 +7,10 @@ instructions of each kernel is its main loop (k_bwd_acc_ckpt: one block of 8 pos
 4 positions of 4 tiles), whose instruction counts divided by the tile-positions per trip are instructions per bin.
 Writes profiles/sq_factored.json (`valu_per_launch` = per bin x bins; + the SQ-counter ratios when a counter pass is given).
 
-    python scripts/r04/isa_count.py [bins=30000001]
+    python scripts/isa_count.py [bins=30000001]
 """
 import collections, json, os, re, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "psmc_amd", "csrc")
 
 def classify(x, c):
@@ -49,7 +49,7 @@ def loops_of(asm, mangled_part):
 
 def main():
     bins = int(sys.argv[1]) if len(sys.argv) > 1 else 30000001
-    res = {"bins": bins, "kernels": {}, "note": "static instruction counts of the main loop (scripts/r04/isa_count.py): vector instructions per bin x bins; "
+    res = {"bins": bins, "kernels": {}, "note": "static instruction counts of the main loop (scripts/isa_count.py): vector instructions per bin x bins; "
            "a SIMD issues at most one f64 vector instruction per 4 cycles"}
     for src, kernels in (("estep_factored.hip", [("k_bwd_acc_ckpt", "14k_bwd_acc_ckpt", 8 * 4)]),
                          ("estep_struct.hip", [("k_fwd_struct<false,4,true>", "12k_fwd_structILb0ELi4ELb1E", 4 * 4)])):

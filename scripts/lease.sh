@@ -10,9 +10,10 @@
 #                                 command and of config 5 alone, SQ instruction counters of both (scripts/sq_summary.py);
 #                                 then locally: python scripts/prof_summary.py <tag> 30000001 (and PROF_NAME=n128 ...), python scripts/sq_summary.py <tag> n64|n128 -> profiles/
 #   wtrace [SHARE] ["opts"]       per-wave time stamps of phase 1: rebuilds the library with -DPSMC_TRACE_SWEEP, runs scripts/sweep_trace.py, rebuilds it plain
-#   probes                        psmc_hip_pipe_probe2 table + psmc_hip_place_probe grid (scripts/r03/probes.py)
-#   trace [SHARE] ["opts"]        per-E-step trace over 30 moving-parameter E-steps: ms, repair rounds, plan (scripts/r03/estep_trace.py)
-#   northstar                     scripts/northstar.py: psmc -N25 + 100 bootstraps at -N25, exact and fast (~9 min)
+#   probes                        psmc_hip_pipe_probe2 table + psmc_hip_place_probe grid (scripts/probes.py)
+#   trace [SHARE] ["opts"]        per-E-step trace over 30 moving-parameter E-steps: ms, repair rounds, plan (scripts/estep_trace.py)
+#   northstar                     scripts/northstar.py: psmc_boot --main (main run + 100 bootstraps at -N25 as ONE job), exact and fast; NS_SEPARATE=1 (default
+#                                 here): also `psmc` alone in both modes, and the joint job's main output byte for byte against it (~7 min)
 #   final                         suite + bench + prof
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -60,23 +61,23 @@ do_prof() {
   cd /tmp
   BARGS="--cpu-sample 0 --exact-extra 0 --n128-extra 0 --boot-extra 0 --shard-extra 0 --group-extra 0"
   timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 1 $BARGS > $R/gpurun_out/prof/bench.json 2> $R/gpurun_out/prof/bench.err; echo "stats bench rc=$?"
-  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o n128 -- python $R/scripts/r03/n128_run.py 6 > $R/gpurun_out/prof/n128.json 2> $R/gpurun_out/prof/n128.err; echo "stats n128 rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o n128 -- python $R/scripts/n128_run.py 6 > $R/gpurun_out/prof/n128.json 2> $R/gpurun_out/prof/n128.err; echo "stats n128 rc=$?"
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc -o bench_$C -- python $R/bench.py --steps 2 --warmup 1 $BARGS > $R/gpurun_out/pmc/bench_$C.json 2> $R/gpurun_out/pmc/bench_$C.err; echo "pmc bench $C rc=$?"
-    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc -o n128_$C -- python $R/scripts/r03/n128_run.py 2 > $R/gpurun_out/pmc/n128_$C.json 2> $R/gpurun_out/pmc/n128_$C.err; echo "pmc n128 $C rc=$?"
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc -o n128_$C -- python $R/scripts/n128_run.py 2 > $R/gpurun_out/pmc/n128_$C.json 2> $R/gpurun_out/pmc/n128_$C.err; echo "pmc n128 $C rc=$?"
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc -o calib_$C -- python -c "
 import sys; sys.path.insert(0, '$R')
 from psmc_amd import hip
 print(hip.stream_probe(1 << 27))" > $R/gpurun_out/pmc/calib_$C.out 2> $R/gpurun_out/pmc/calib_$C.err; echo "calib $C rc=$?"
   done
   SQC="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU"
-  echo "rocprofv3 --kernel-trace --pmc $SQC -- python scripts/r03/n128_run.py 2  (scripts/lease.sh prof)" > $R/gpurun_out/pmc/n128_SQ.cmd
-  timeout 600 rocprofv3 --kernel-trace --pmc $SQC --output-format csv -d $R/gpurun_out/pmc -o n128_SQ -- python $R/scripts/r03/n128_run.py 2 > $R/gpurun_out/pmc/n128_SQ.json 2> $R/gpurun_out/pmc/n128_SQ.err; echo "sq n128 rc=$?"
+  echo "rocprofv3 --kernel-trace --pmc $SQC -- python scripts/n128_run.py 2  (scripts/lease.sh prof)" > $R/gpurun_out/pmc/n128_SQ.cmd
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQC --output-format csv -d $R/gpurun_out/pmc -o n128_SQ -- python $R/scripts/n128_run.py 2 > $R/gpurun_out/pmc/n128_SQ.json 2> $R/gpurun_out/pmc/n128_SQ.err; echo "sq n128 rc=$?"
   echo "rocprofv3 --kernel-trace --pmc $SQC -- python bench.py --steps 2 --warmup 1 $BARGS  (scripts/lease.sh prof)" > $R/gpurun_out/pmc/n64_SQ.cmd
   timeout 600 rocprofv3 --kernel-trace --pmc $SQC --output-format csv -d $R/gpurun_out/pmc -o n64_SQ -- python $R/bench.py --steps 2 --warmup 1 $BARGS > $R/gpurun_out/pmc/n64_SQ.json 2> $R/gpurun_out/pmc/n64_SQ.err; echo "sq n64 rc=$?"
   cd $R
   python scripts/prof_summary.py lease 30000001 | tail -30
-  PROF_NAME=n128 PROF_STATES=128 PROF_CMD="python scripts/r03/n128_run.py" python scripts/prof_summary.py lease 30000001 | tail -20
+  PROF_NAME=n128 PROF_STATES=128 PROF_CMD="python scripts/n128_run.py" python scripts/prof_summary.py lease 30000001 | tail -20
   python scripts/sq_summary.py lease n64 | head -12; python scripts/sq_summary.py lease n128 | head -10
   mkdir -p gpurun_out/summaries; cp profiles/lease_* profiles/pmc_traffic*.json gpurun_out/summaries/ 2>/dev/null   # only gpurun_out/ travels back
   find gpurun_out/pmc gpurun_out/prof -name "*.csv" -size +3M -delete
@@ -92,14 +93,14 @@ case "$task" in
     cd /tmp; rm -rf $R/gpurun_out/prof/tl*
     timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof -o tl -- python $R/scripts/shard_sweep.py --shares "${1-8}" --chr "${2-0}" --cfg "${CFG-}" --factored "${FACTORED-0}" --steps "${STEPS-4}" --warmup "${WARMUP-8}" > $R/gpurun_out/tl.log 2>&1; echo "rocprof rc=$?"
     cd $R; python scripts/prof_timeline.py $(ls -t gpurun_out/prof/tl*.db | head -1) ${LASTK-k_reduce2} all | tee "gpurun_out/timeline${TAG-}.txt" | cut -c1-120
-    python scripts/r04/timeline_steps.py $(ls -t gpurun_out/prof/tl*.db | head -1) ${LASTK-k_reduce2} 2 | tee "gpurun_out/timeline_steps${TAG-}.txt" ;;
+    python scripts/timeline_steps.py $(ls -t gpurun_out/prof/tl*.db | head -1) ${LASTK-k_reduce2} 2 | tee "gpurun_out/timeline_steps${TAG-}.txt" ;;
   prof) do_prof ;;
   wtrace)
     make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc EXTRA=-DPSMC_TRACE_SWEEP 2>&1 | grep -E "error" ; TRACE_STEPS="${TRACE_STEPS-0}" timeout 300 python scripts/sweep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/wave_trace.txt | cut -c1-230
     make -s -C psmc_amd/csrc clean; make -s -C psmc_amd/csrc 2>&1 | grep -E "error" ;;
-  probes) timeout 300 python scripts/r03/probes.py 2>&1 | grep -v amdgpu.ids ;;
-  trace) timeout 600 python scripts/r03/estep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids ;;
-  northstar) timeout 2400 python scripts/northstar.py gpurun_out/northstar.json gpurun_out/traj_n128.json > gpurun_out/ns.log 2> gpurun_out/ns.err; echo "northstar rc=$?"; tail -5 gpurun_out/ns.err | cut -c1-300; tail -30 gpurun_out/ns.log | cut -c1-300 ;;
+  probes) timeout 300 python scripts/probes.py 2>&1 | grep -v amdgpu.ids ;;
+  trace) timeout 600 python scripts/estep_trace.py "${1-1}" "${2-}" 2>&1 | grep -v amdgpu.ids ;;
+  northstar) NS_SEPARATE="${NS_SEPARATE-1}" timeout 2400 python scripts/northstar.py gpurun_out/northstar.json > gpurun_out/ns.log 2> gpurun_out/ns.err; echo "northstar rc=$?"; tail -5 gpurun_out/ns.err | cut -c1-300; tail -40 gpurun_out/ns.log | cut -c1-300 ;;
   final) do_suite; do_bench; do_prof ;;
   *) echo "unknown task $task"; exit 2 ;;
 esac

@@ -3,7 +3,7 @@
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, bench
 from psmc_amd import hip, sim, hostlib

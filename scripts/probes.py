@@ -2,7 +2,7 @@
 """Round 3 probes: (1) what overlaps with another wave's v_mfma_f64 on the same SIMD (VERDICT r2 item 5);
 (2) where the waves of shard-sized launches land.  -> gpurun_out/r03_pipe_probe.json, r03_place_probe.json"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from psmc_amd import hip
 out_dir = os.path.join(ROOT, "gpurun_out")

@@ -2,7 +2,7 @@
 """One line per E-step of a rocprofv3 --kernel-trace run (rocpd database): when each kernel of the step started / ended, relative to
 the step's first kernel.  Complements scripts/prof_timeline.py (which lists the last step kernel by kernel): bimodal steps show here.
 
-    python scripts/r04/timeline_steps.py gpurun_out/prof/tl_results.db [k_reduce2|k_reduce_factored2] [first_step]
+    python scripts/timeline_steps.py gpurun_out/prof/tl_results.db [k_reduce2|k_reduce_factored2] [first_step]
 """
 import sqlite3, sys, re, glob
 db = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/prof/*.db"))[-1]

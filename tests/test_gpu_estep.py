@@ -463,7 +463,8 @@ def tri_sums(A):
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
                                   dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, **GENOME), dict(GENOME), dict(chunk=1001, warmup=100, merge1=0), dict(chunk=264, warmup=300, warm_shift=1),
                                   dict(chunk=256, warmup=512, coarse=2), dict(chunk=1001, warmup=100, coarse=3), dict(chunk=264, warmup=64, coarse=2, merge1=0), dict(chunk=256, warmup=512, coarse=2, ckpt=0, **GENOME),
-                                  dict(lanes8=1), dict(chunk=264, warmup=300, lanes8=1), dict(chunk=256, warmup=512, lanes8=1, coarse=2), dict(chunk=1001, warmup=100, lanes8=1, **GENOME)])
+                                  dict(lanes8=1), dict(chunk=264, warmup=300, lanes8=1), dict(chunk=256, warmup=512, lanes8=1, coarse=2), dict(chunk=1001, warmup=100, lanes8=1, **GENOME),
+                                  dict(ckpt=0, lanes8b=1), dict(chunk=264, warmup=300, ckpt=0, lanes8b=1), dict(chunk=1001, warmup=100, ckpt=0, lanes8b=1, lanes8=1, **GENOME), dict(chunk=256, warmup=64, ckpt=0, lanes8b=1, coarse=2)])
 def test_fast_factored_statistics(hip, golden, oracle, opts):
     """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
     (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset.
@@ -855,7 +856,7 @@ def test_fast_stress_tiny_tiles_recycled_memory(hip, golden, oracle):
     Every E-step (full counts and factored statistics) stays inside the tolerance.  This is the stress that found (1) exit
     vectors computed from a forward table under repair (about one E-step in 1 500 off by up to 3e-2 in that build) and
     (2) a symbol block read below the first segment's observations by an idle backward row (a page fault with the right
-    allocation history); scripts/dbg_flaky_tiling.py is the long version."""
+    allocation history); profiles/experiments/dbg_flaky_tiling.py is the long version."""
     import random
     p = golden.params("n64_curve")
     segs = golden.segs_small + golden.segs_mid[3:]

@@ -15,7 +15,7 @@ def test_lease_script_parses():
 
 
 def test_python_scripts_parse():
-    for d in ("scripts", os.path.join("scripts", "r03")):
+    for d in ("scripts", os.path.join("profiles", "experiments")):
         for f in sorted(os.listdir(os.path.join(ROOT, d))):
             if f.endswith(".py"):
                 ast.parse(open(os.path.join(ROOT, d, f)).read(), filename=f)

@@ -136,7 +136,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           entry; 0 = replicate-major order (every launch then lasts as long as the longest trunk).  Bit-identical.
  *  "batch_slots"   0        psmc_hip_estep_batch without the f table, several launches: entries per launch; 0 = four per compute unit of the
  *                           context's share of the device (the recompute pass holds that many at a time; one more waits for a whole round).
- *                           psmc_boot --main without compute-unit masks leaves the main run's sweeps some slots this way
+ *                           (psmc_boot --main with PSMC_BOOT_MAIN_CUS=0 uses it; measured slower than compute-unit masks)
  *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1, 2 = no f table -- the expect pass recomputes the forward sweep in its own
  *                           work-group (bit-identical), so a launch group holds twice the replicates; 2 = two entries per work-group
  *                           (two producer waves, two consumer waves: four entries per compute unit), 1 = one; 0 = f and b tables,

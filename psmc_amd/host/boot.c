@@ -27,13 +27,14 @@ typedef struct {
 } replicate;
 
 /* the main run's EM rounds (psmc_run_finish) on a thread of their own */
-typedef struct { psmc_run_state *st; int status; double ms; } main_job;
+typedef struct { psmc_run_state *st; int status; double ms; volatile int finished; } main_job;
 static void *main_thread(void *arg)
 {
 	main_job *j = (main_job *)arg;
 	const double t0 = now_ms();
 	j->status = psmc_run_finish(j->st);
 	j->ms = now_ms() - t0;
+	__atomic_store_n(&j->finished, 1, __ATOMIC_RELEASE);
 	return 0;
 }
 
@@ -120,7 +121,8 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 	int failed = 0;
 	/* The main run starts now: every draw from drand48 -- its own (psmc_run_begin) and the replicates' (above) -- is done, and from here
 	 * on the two only share the device: the main run's sweeps on the compute units its context was given, the batch on the others. */
-	main_job mj = {main_run, 0, 0.0};
+	main_job mj = {main_run, 0, 0.0, 0};
+	int main_released = 0;
 	pthread_t main_tid;
 	int main_started = 0;
 	if (main_run) {
@@ -173,6 +175,11 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		}
 		if (timing)
 			fprintf(stderr, "[psmc_boot] iteration %d: %d E-steps %.1f ms on %d device(s), M-steps %.1f ms\n", it + 1, n_rep, t1 - t0, bb->n_dev, now_ms() - t1);
+		if (main_started && !main_released && bb->main_done && __atomic_load_n(&mj.finished, __ATOMIC_ACQUIRE)) {
+			bb->main_done(bb->self); /* the main run is over: the batch gets its compute units back for the remaining iterations */
+			main_released = 1;
+			if (timing) fprintf(stderr, "[psmc_boot] main run finished during iteration %d: the batch has the whole device again\n", it + 1);
+		}
 	}
 	status = failed ? 1 : 0;
 	if (main_started) {

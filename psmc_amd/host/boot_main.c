@@ -12,15 +12,17 @@
  *
  * --main / --main-input: the whole workflow of the reference's README:49-62 as ONE job -- the un-resampled main run
  * (`psmc <psmc options> -o out.psmc in.psmcfa`, on the unsplit input) runs on a thread of its own BESIDE the replicates, on the
- * first device; its 3 s E-steps -- the critical path of one wave over the longest chromosome -- hide behind the batch's 7 s ones
- * instead of preceding them.  Exact mode, default (PSMC_BOOT_MAIN_CUS=0): no compute-unit masks; the batch keeps
- * PSMC_BOOT_MAIN_SLOTS (64) entry slots per launch free, because each of the main run's long sweeps keeps one recompute
- * work-group out of its compute unit (measured, 100 replicates of a 30 M-bin genome: batch 6.75 -> 7.17 s per iteration, main
- * run 3.1 -> 3.25 s per E-step).  PSMC_BOOT_MAIN_CUS=<multiple of 32>: the main run's context is masked to that many compute
- * units and the batch to the others (psmc_hip_set_cu_range; the mask's bits go round the XCDs, then round the four shader
- * engines of an XCD, so only multiples of 32 leave every engine the same number of units -- 24 left the engines 7 / 7 / 7 / 8
- * and the batch's launches took 1.6 x as long; with 32: 7.42 s).  The main output is byte-identical to `psmc`'s, the
- * replicates to a run without --main (tests/test_host_cli.py).
+ * first device; its 3.3 s E-steps -- the critical path of one wave over the longest chromosome -- hide behind the batch's 7 s ones
+ * instead of preceding them.  Exact mode: the main run's context is masked to PSMC_BOOT_MAIN_CUS compute units (default 32) and the
+ * batch to the others (psmc_hip_set_cu_range), so that the two never share a SIMD and the batch sizes its launches for its share.
+ * The mask's bits go round the XCDs, then round the four shader engines of an XCD, and the dispatcher deals a launch evenly over
+ * the ENGINES: only multiples of 32 leave every engine the same number of units.  Measured with the main run alive (100 replicates
+ * of a 30 M-bin genome, profiles/r05_boot_schedule.txt): batch alone 6.75 s per EM iteration; with the main run on 32 masked
+ * units 7.27 s, the main run 3.3 s per E-step (alone: 3.09); on 24 units (engines left 7 / 7 / 7 / 8 units) 9.4 s; without masks
+ * (PSMC_BOOT_MAIN_CUS=0: the batch keeps PSMC_BOOT_MAIN_SLOTS entry slots per launch free) 10 s -- the main run's resident waves
+ * keep the batch's work-groups, which need a whole SIMD's registers, out of their compute units, and a launch that has to place one
+ * work-group late lasts twice as long.  The main output is byte-identical to `psmc`'s, the replicates to a run without --main
+ * (tests/test_host_cli.py).
  * There is no CPU E-step in this binary. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,7 +32,7 @@
 #include "hipbe.h"
 
 #define MAX_DEV 64
-typedef struct { int n_dev, n_states, n_rep; psmc_hip_ctx *ctx[MAX_DEV]; } hip_bb;
+typedef struct { int n_dev, n_states, n_rep; psmc_hip_ctx *ctx[MAX_DEV]; int dev_id[MAX_DEV], main_dev; } hip_bb;
 
 static int bb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L)
 {
@@ -41,6 +43,13 @@ static int bb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, co
 static int bb_reserve(void *self, int dev, int64_t table_bins)
 {
 	return psmc_hip_reserve_batch_tables(((hip_bb *)self)->ctx[dev], table_bins);
+}
+/* the main run that shared device main_dev is over: its compute units (and the entry slots kept free) go back to the batch */
+static void bb_main_done(void *self)
+{
+	hip_bb *h = (hip_bb *)self;
+	for (int d = 0; d < h->n_dev; ++d)
+		if (h->dev_id[d] == h->main_dev) { (void)psmc_hip_set_cu_range(h->ctx[d], 0, 0); (void)psmc_hip_set_option(h->ctx[d], "batch_slots", 0); }
 }
 static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
                           const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
@@ -131,11 +140,13 @@ int main(int argc, char *argv[])
 			psmc_options_free(&o);
 			return 2;
 		}
+		h.dev_id[d] = list[d];
 		h.n_dev = d + 1;
 	}
+	h.main_dev = -1;
 	h.n_rep = n_rep;
 	const char *fs = getenv("PSMC_FACTORED");
-	psmc_batch_backend bb = {&h, h.n_dev, bb_load, bb_estep_batch, bb_error, bb_destroy, mode == PSMC_HIP_MODE_FAST && !(fs && atoi(fs) == 0), bb_reserve};
+	psmc_batch_backend bb = {&h, h.n_dev, bb_load, bb_estep_batch, bb_error, bb_destroy, mode == PSMC_HIP_MODE_FAST && !(fs && atoi(fs) == 0), bb_reserve, 0};
 	/* the main run: a context of its own on the first device, begun (header, input, RD 0, tables) before the batch sizes its tables */
 	psmc_estep_backend be_main;
 	psmc_run_state *main_run = 0;
@@ -144,14 +155,14 @@ int main(int argc, char *argv[])
 		const int use_factored = om.fast_mstep && mode == PSMC_HIP_MODE_FAST && n_states <= 128 && !(fs && atoi(fs) == 0);
 		int rc = psmc_hipbe_create(&be_main, n_states, mode, use_factored, 0, list[0]);
 		if (rc == 0 && mode == PSMC_HIP_MODE_EXACT) { /* split the first device: [0, m) main run, [m, all) the batch contexts on it */
+			h.main_dev = list[0]; bb.main_done = bb_main_done;
 			const char *ms = getenv("PSMC_BOOT_MAIN_CUS");
-			const int cus = psmc_hip_device_cus(list[0]), m = ms ? atoi(ms) : 0;
+			const int cus = psmc_hip_device_cus(list[0]), m = ms ? atoi(ms) : 32;
 			if (m > 0 && m < cus) {
 				rc = psmc_hip_set_cu_range(psmc_hipbe_ctx(&be_main), 0, m);
 				for (int d = 0; d < h.n_dev && rc == 0; ++d)
 					if (list[d] == list[0]) rc = psmc_hip_set_cu_range(h.ctx[d], m, cus - m);
-			} else if (m <= 0) { /* no masks: the main run's long sweeps (one per chromosome) each keep a recompute work-group out of its
-			                      * compute unit, so the batch leaves them PSMC_BOOT_MAIN_SLOTS entry slots per launch (default 64) */
+			} else if (m <= 0) { /* no masks (A/B; measured slower: see the top of the file): the batch leaves PSMC_BOOT_MAIN_SLOTS entry slots per launch free */
 				const char *ss = getenv("PSMC_BOOT_MAIN_SLOTS");
 				const int keep = ss ? atoi(ss) : 64;
 				for (int d = 0; d < h.n_dev && rc == 0; ++d)

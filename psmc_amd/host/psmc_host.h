@@ -168,6 +168,9 @@ typedef struct psmc_batch_backend {
 	 * bins the device's replicates need together (the padded lengths of every replicate's UNIQUE trunks): the backend can take
 	 * its table memory now, sized for exactly this job (psmc_hip_reserve_batch_tables) */
 	int  (*reserve)(void *self, int dev, int64_t table_bins);
+	/* optional (may be NULL): the main run that shared the first device (psmc_boot --main) has finished; called once, between two
+	 * EM iterations: the backend can give the batch the whole device back */
+	void (*main_done)(void *self);
 } psmc_batch_backend;
 /* main_run (may be NULL): a psmc_run_begin()'ed run -- the un-resampled main run of README:49-53 on its own input -- whose EM
  * rounds psmc_boot_run drives on a thread of its own beside the replicates (psmc_boot --main) */

@@ -78,7 +78,7 @@ int main(int argc, char **argv)
 	if (psmc_pattern_parse(o.pattern_text ? o.pattern_text : "4+5*3+4", &pat)) return 1;
 	orc_bb ob; memset(&ob, 0, sizeof ob);
 	ob.n = pat.n_states;
-	psmc_batch_backend bb = {&ob, 2, obb_load, obb_estep_batch, obb_error, obb_destroy, o.fast_mstep, 0};
+	psmc_batch_backend bb = {&ob, 2, obb_load, obb_estep_batch, obb_error, obb_destroy, o.fast_mstep, 0, 0};
 	/* --main: the un-resampled run on its own input beside the replicates (boot_main.c does the same with the HIP backend) */
 	orc_be om_be; memset(&om_be, 0, sizeof om_be);
 	psmc_estep_backend be_main = {&om_be, ob_load, ob_estep, ob_tables, 0, 0, ob_error, ob_destroy, 0, 0};

@@ -397,7 +397,7 @@ def test_psmc_boot_binary_equals_single_runs_on_gpu(tmp_path, pattern):
 def test_psmc_boot_main_run_on_gpu(tmp_path, main_cus):
     """psmc_boot --main: the README:49-62 workflow as one job.  The main run (`psmc <options> -o main.psmc
     whole.psmcfa`) runs beside the replicates on the same device -- its context masked to a range of compute units and the batch
-    to the others (PSMC_BOOT_MAIN_CUS=32), or unmasked with entry slots kept free (=0, the default) -- and writes the bytes `psmc` writes;
+    to the others (PSMC_BOOT_MAIN_CUS=32, the default), or unmasked with entry slots kept free (=0) -- and writes the bytes `psmc` writes;
     the replicates write the bytes they write without --main (entry schedule, launch count and compute-unit share do not
     reach the results)."""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "psmc_amd", "csrc")], check=True)

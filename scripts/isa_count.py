@@ -69,6 +69,10 @@ def main():
             # one wave-instruction serves four tiles: wave-instructions per bin = valu / (4 tiles x positions) ... valu_per_bin above is already per tile-position
             res["kernels"][name]["valu_per_launch"] = vpb * bins
             print(name, big[0], big[1], big[2], "-> %.1f wave-level vector instructions per bin" % vpb)
+    # the counts are valid for THESE kernel sources only: bench.py compares the hash and drops the issue roofline when they have changed
+    import hashlib
+    res["kernel_sources"] = ["psmc_amd/csrc/estep_factored.hip", "psmc_amd/csrc/struct_prims.h", "psmc_amd/csrc/estep_struct.hip", "psmc_amd/csrc/wave_prims.h"]
+    res["kernel_src_sha16"] = hashlib.sha256(b"".join(open(os.path.join(ROOT, s), "rb").read() for s in res["kernel_sources"])).hexdigest()[:16]
     json.dump(res, open(os.path.join(ROOT, "profiles", "sq_factored.json"), "w"), indent=1)
 
 if __name__ == "__main__":

@@ -123,7 +123,7 @@ static int plan_fast(psmc_hip_ctx *c)
 			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
 		c->chunk_cap = nc;
 	}
-	if ((rc = dev_alloc(c, &c->d_Cpart, (size_t)nc * c->n_sub_used * c->ns * c->ns))) return rc;
+	// (the partial counts, d_Cpart, are sized per E-step by what its back half writes: enqueue_fast)
 	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub_used * 3 * c->ns))) return rc;
 	if ((rc = ensure_fast_buffers(c))) return rc;
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
@@ -419,6 +419,15 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	// where the longer step of the 8 x 8 form costs more than its fewer instructions save (3.75 M bins: 3.23 vs 2.96 ms)
 	p.lanes8 = (c->lanes8 >= 0 ? c->lanes8 != 0 && p.fused != 0 : p.fused == 2 && p.n_chunks > 4096) && c->ns == 64 ? 1 : 0;
 	p.lanes8b = c->lanes8b && c->ns == 64 && p.fused == 2 && !p.ckpt ? 1 : 0;
+	{
+		// Partial counts.  Round 4 gave every plan n_tiles x ns^2 doubles (266 MB for a genome's 8127 tiles) whatever its back half: the unfused
+		// counts kernel writes that much, the fused one a partial per GROUP of four tiles (a quarter), the factored one seven vectors per
+		// tile (a ninth) -- and a fast bootstrap keeps a plan per replicate: 26 GB for 100 of them, cleared by the driver on allocation
+		// (profiles/r05_boot_first_iteration.txt).  Sized here, per E-step, for the back half that runs; grows, never shrinks.
+		const size_t nc_ = c->chunks.size(), S_ = (size_t)c->ns;
+		const size_t need = p.fused == 2 ? nc_ * 7 * S_ + 64 : (p.fused == 1 ? (nc_ / 4 + 8) * S_ * S_ : nc_ * (size_t)c->n_sub_used * S_ * S_);
+		if (c->cpart_cap < need) { if ((rc = dev_alloc(c, &c->d_Cpart, need))) return rc; c->cpart_cap = need; }
+	}
 	p.d_gate = (c->gate >= 0 ? c->gate != 0 : coarse > 1) ? c->d_gate : nullptr;
 	p.coarse = coarse; p.d_singles_b = c->d_items + 24 * (size_t)p.n_chunks; p.n_singles_b = c->n_singles_b;
 	p.n_B_b = c->n_B_b; p.runs_in_b = c->runs_in_b ? 1 : 0; p.n_list_a = c->n_list_a; p.n_list_b = c->n_list_b; p.d_ftiles = c->d_ftiles; p.count_group = c->count_group;

@@ -13,7 +13,9 @@
 // so nothing has to be broadcast back.  No FMA (the library is built with -ffp-contract=off; tests/test_abi.py audits
 // this file's assembly), true division, every sum in index order: bit-identical to khmm.c, checked against the oracle
 // and against goldens of the reference itself at 150 and 200 states (tests/test_gpu_wide.py).
-// This path is about ACCEPTING the input, not about speed: two chains of n dependent adds per position (~2 us at n = 200).
+// This path is about ACCEPTING the input, not about speed: a position costs 13 us at n = 200 (7.5 forward + 5.9 backward: the n matrix
+// elements of a lane come from the L2, eight per round trip; fetching 32 a block ahead by hand was SLOWER, 10.4 + 11.1 us -- round 5,
+// profiles/r05_wide_timing.json), i.e. 1.4e6 bins/s over 20 segments, 60 x one host core of the reference at that size.
 #include <hip/hip_runtime.h>
 #include "psmc_hip_internal.h"
 
@@ -34,65 +36,41 @@ __device__ __forceinline__ double ordered_sum_lds(const double *v, int n)
 	return s;
 }
 
-// acc = sum_{l<n} x[l] * m[l * S]   (x in LDS, m = this lane's column, row stride S), left to right from 0.0.
-// The matrix elements come from the L2 (0.3-0.6 us per trip): B of them are fetched a block ahead of the block that is being
-// added, so that a position waits for n / B round trips instead of n / 8 (first version: 7.5 us per position at n = 200).
-template <int B>
+// acc = sum_{l<n} x[l] * m[l * S]   (x in LDS, m = this lane's column, row stride S), left to right from 0.0
 __device__ __forceinline__ double ordered_dot_col(const double *x, const double *__restrict__ m, int n, int S)
 {
-	double acc = 0.0, mc[B], mn[B];
+	double acc = 0.0;
 	int l = 0;
-	if (n >= B) {
+	for (; l + 8 <= n; l += 8) {
+		double mv[8], xv[8];
 #pragma unroll
-		for (int j = 0; j < B; ++j) mc[j] = m[(int64_t)j * S];
-		for (; l + 2 * B <= n; l += B) {
+		for (int j = 0; j < 8; ++j) { mv[j] = m[(int64_t)(l + j) * S]; xv[j] = x[l + j]; }
 #pragma unroll
-			for (int j = 0; j < B; ++j) mn[j] = m[(int64_t)(l + B + j) * S]; // the next block's elements: in flight during this block's adds
-			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for (int j = 0; j < B; ++j) acc += x[l + j] * mc[j]; // tmp += fu1[l] * aa[l]
-#pragma unroll
-			for (int j = 0; j < B; ++j) mc[j] = mn[j];
-		}
-#pragma unroll
-		for (int j = 0; j < B; ++j) acc += x[l + j] * mc[j];
-		l += B;
+		for (int j = 0; j < 8; ++j) acc += xv[j] * mv[j]; // tmp += fu1[l] * aa[l]
 	}
 	for (; l < n; ++l) acc += x[l] * m[(int64_t)l * S];
 	return acc;
 }
 
 // the same with the emission factor: acc += (e[l] * m[l * S]) * x[l], the product e*a rounded first (hmm_pre_backward, khmm.c:203)
-template <int B>
 __device__ __forceinline__ double ordered_dot_col_e(const double *x, const double *ev, const double *__restrict__ m, int n, int S)
 {
-	double acc = 0.0, mc[B], mn[B];
+	double acc = 0.0;
 	int l = 0;
-	if (n >= B) {
+	for (; l + 8 <= n; l += 8) {
+		double mv[8], xv[8], ee[8];
 #pragma unroll
-		for (int j = 0; j < B; ++j) mc[j] = m[(int64_t)j * S];
-		for (; l + 2 * B <= n; l += B) {
+		for (int j = 0; j < 8; ++j) { mv[j] = m[(int64_t)(l + j) * S]; xv[j] = x[l + j]; ee[j] = ev[l + j]; }
 #pragma unroll
-			for (int j = 0; j < B; ++j) mn[j] = m[(int64_t)(l + B + j) * S];
-			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for (int j = 0; j < B; ++j) { const double q = ev[l + j] * mc[j]; acc += q * x[l + j]; } // tmp += q[l] * bu1[l]
-#pragma unroll
-			for (int j = 0; j < B; ++j) mc[j] = mn[j];
-		}
-#pragma unroll
-		for (int j = 0; j < B; ++j) { const double q = ev[l + j] * mc[j]; acc += q * x[l + j]; }
-		l += B;
+		for (int j = 0; j < 8; ++j) { const double q = ee[j] * mv[j]; acc += q * xv[j]; } // tmp += q[l] * bu1[l]
 	}
 	for (; l < n; ++l) { const double q = ev[l] * m[(int64_t)l * S]; acc += q * x[l]; }
 	return acc;
 }
 
 // ---------------------------------------------------------------- forward (khmm.c:145-190)
-// grid = entries, block = S threads.  LDS: xs[2][S] | gs[S] | es[3][S].  MAXT: the largest block this instantiation is launched with
-// (256: 129 .. 256 states, a register budget for 32 prefetched matrix elements; 1024: up to 1024 states, 8)
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void k_fwd_wide(const double *__restrict__ a, const double *__restrict__ e, const double *__restrict__ a0,
+// grid = entries, block = S threads.  LDS: xs[2][S] | gs[S] | es[3][S]
+__global__ __launch_bounds__(1024) void k_fwd_wide(const double *__restrict__ a, const double *__restrict__ e, const double *__restrict__ a0,
                                                    const uint8_t *__restrict__ obs, const int64_t *__restrict__ seg_off,
                                                    const int32_t *__restrict__ seg_len, const ExWork wl, int n, int S,
                                                    double *__restrict__ f, double *__restrict__ s)
@@ -115,7 +93,7 @@ __global__ __launch_bounds__(MAXT) void k_fwd_wide(const double *__restrict__ a,
 		const int sym = o[u];
 		double g;
 		if (u == 0) g = k < n ? a0[k] * es[sym * S + k] : 0.0;                         // khmm.c:171-172
-		else { const double tmp = ordered_dot_col<MAXT <= 256 ? 32 : 8>(xs + cur * S, col, n, S); g = es[sym * S + k] * tmp; } // khmm.c:179-180
+		else { const double tmp = ordered_dot_col(xs + cur * S, col, n, S); g = es[sym * S + k] * tmp; } // khmm.c:179-180
 		gs[k] = g;
 		__syncthreads();
 		const double sum = ordered_sum_lds(gs, n);
@@ -130,8 +108,7 @@ __global__ __launch_bounds__(MAXT) void k_fwd_wide(const double *__restrict__ a,
 
 // ---------------------------------------------------------------- backward (khmm.c:210-241) + the underflow check value
 // LDS: bs[2][S] | ts[S] | es[3][S]
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void k_bwd_wide(const double *__restrict__ aT, const double *__restrict__ e, const double *__restrict__ a0,
+__global__ __launch_bounds__(1024) void k_bwd_wide(const double *__restrict__ aT, const double *__restrict__ e, const double *__restrict__ a0,
                                                    const uint8_t *__restrict__ obs, const int64_t *__restrict__ seg_off,
                                                    const int32_t *__restrict__ seg_len, const ExWork wl, int n, int S,
                                                    const double *__restrict__ s, double *__restrict__ b, double *__restrict__ chk)
@@ -156,7 +133,7 @@ __global__ __launch_bounds__(MAXT) void k_bwd_wide(const double *__restrict__ aT
 	__syncthreads();
 	for (int u = L - 2; u >= 0; --u) { // index u = position u + 1; uses b[u+1], obs[u+1], s[u]
 		const int sym = o[u + 1];
-		const double tmp = ordered_dot_col_e<MAXT <= 256 ? 32 : 8>(bs + cur * S, es + sym * S, row, n, S); // khmm.c:231-232
+		const double tmp = ordered_dot_col_e(bs + cur * S, es + sym * S, row, n, S); // khmm.c:231-232
 		x = tmp / so[u];                                                              // khmm.c:233
 		bo[(int64_t)u * S + k] = x;
 		bs[(cur ^ 1) * S + k] = x;
@@ -260,11 +237,9 @@ int launch_exact_wide(const EstepLaunch &p)
 	const size_t lds = sizeof(double) * 6 * (size_t)S;
 	const int H = S / 64;
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
-	if (S <= 256) hipLaunchKernelGGL(k_fwd_wide<256>, dim3(p.n_work), dim3(S), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_f, p.d_s);
-	else hipLaunchKernelGGL(k_fwd_wide<1024>, dim3(p.n_work), dim3(S), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_f, p.d_s);
+	hipLaunchKernelGGL(k_fwd_wide, dim3(p.n_work), dim3(S), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_f, p.d_s);
 	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
-	if (S <= 256) hipLaunchKernelGGL(k_bwd_wide<256>, dim3(p.n_work), dim3(S), lds, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_s, p.d_b, p.d_chk);
-	else hipLaunchKernelGGL(k_bwd_wide<1024>, dim3(p.n_work), dim3(S), lds, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_s, p.d_b, p.d_chk);
+	hipLaunchKernelGGL(k_bwd_wide, dim3(p.n_work), dim3(S), lds, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_s, p.d_b, p.d_chk);
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
 	hipLaunchKernelGGL(k_expect_wide, dim3(p.n_work, (S / 4) * H + H), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, S,
 	                   p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);

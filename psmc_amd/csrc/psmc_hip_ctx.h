@@ -115,6 +115,7 @@ struct psmc_hip_ctx {
 	int chunk_cap = 0, chunk_used = 0;
 	double *d_entry = nullptr, *d_bentry = nullptr, *d_bexit = nullptr, *d_Cpart = nullptr, *d_Epart = nullptr,
 	       *d_LLpart = nullptr;
+	size_t cpart_cap = 0; // doubles in d_Cpart (api_fast.hip enqueue_fast)
 	int *d_dirty = nullptr, *d_cnt = nullptr, *h_cnt = nullptr, *d_touch = nullptr;
 	hipStream_t stream2 = nullptr, stream3 = nullptr, stream4 = nullptr;
 	hipEvent_t evx[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -88,6 +88,10 @@ def test_stress_fast_within_tolerance(hip, stress, plan):
             rd, pl["tiles"], pl["tile_len"], d["fwd_rounds"], d["bwd_rounds"], d["fwd_tiles"], d["bwd_tiles"], pl["glued_fwd"], pl["glued_bwd"],
             pl["warm_fwd_max"], pl["warm_bwd_max"]))
     print("\nstress, %s plan:\n  " % plan + "\n  ".join(log))
+    rec = os.path.join(ROOT, "gpurun_out")   # what the verify / repair net had to do, kept when the suite runs on the GPU box (-> profiles/r05_stress_fast.txt)
+    if os.path.isdir(rec):
+        with open(os.path.join(rec, "stress_fast_%s.txt" % plan), "w") as fh:
+            fh.write("stress fixture (tests/golden/stress), fast mode, %s plan, parameters of EM rounds 0, 1, 2, 0 on one context:\n  " % plan + "\n  ".join(log) + "\n")
     es.close()
 
 

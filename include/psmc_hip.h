@@ -74,7 +74,11 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           within the stated tolerance, two contexts with the same history agree bit for bit
  *  "warm_shift"    auto     such a tile first gets a warm-up of warmup << warm_shift bins of its own and is glued only
  *                           if that fails too; 0 = glue at once.  auto: 1 with the two-round plan, 0 with one round
- *  "group_cap"     131072   longest run of glued tiles, in bins
+ *  "group_cap"     131072   longest run of glued tiles, in bins (full tiles of missing data do not count: "gap_tiles")
+ *  "gap_tiles"     1        full tiles that consist of missing data only (runs of `N`: centromeres, assembly gaps) are glued to their neighbours
+ *                           when the plan is made -- inside such a run the chain forgets at the rate of the matrix's second eigenvalue alone,
+ *                           ~5e5 bins, so no warm-up works -- do not count against "group_cap" / "kc_div", and share ONE transfer matrix per
+ *                           direction (a^T to the tile length).  0: as rounds 1-4 (a 2e5-bin gap then costs ~50 repair rounds per E-step)
  *  "two_phase"     auto     2: the fused back half runs as two launches, odd tiles of the second list start from the exit
  *                           vector of the tile above instead of speculating backward; 0: every tile speculates, one
  *                           launch when the tiles fit one round.  auto: 2 with two rounds, 0 with one

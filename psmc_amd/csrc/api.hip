@@ -199,6 +199,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "runs_late") { c->runs_late = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
 	else if (k == "lanes8") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->lanes8 = (int)v; }
+	else if (k == "gap_tiles") { c->gap_tiles = v != 0 ? 1 : 0; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "lanes8b") { c->lanes8b = v != 0 ? 1 : 0; }
 	else if (k == "gate") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->gate = (int)v; }
 	else if (k == "coarse") { if (v < -1 || v > 16) return PSMC_HIP_EINVAL; c->coarse = (int)v; c->plan_dirty = true; c->items_dirty = true; }

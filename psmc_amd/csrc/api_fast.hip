@@ -107,6 +107,7 @@ static int plan_fast(psmc_hip_ctx *c)
 	}
 	c->items_dirty = true;
 	int rc;
+	c->gap.assign(nc, 0);
 	if (nc > c->chunk_cap) {
 		if ((rc = dev_alloc(c, &c->d_chunks, (size_t)nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_entry, (size_t)nc * c->ns))) return rc;
@@ -115,7 +116,7 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_items, (size_t)26 * nc + 64))) return rc;
+		if ((rc = dev_alloc(c, &c->d_items, (size_t)30 * nc + 64))) return rc; // (+ 4 nc: matrix slot of every KcTile | the KcTile that computes a slot)
 		if ((rc = dev_alloc(c, &c->d_ftiles, (size_t)2 * (nc + 16)))) return rc;
 		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
 		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
@@ -127,6 +128,26 @@ static int plan_fast(psmc_hip_ctx *c)
 	if ((rc = dev_alloc(c, &c->d_Epart, (size_t)nc * c->n_sub_used * 3 * c->ns))) return rc;
 	if ((rc = ensure_fast_buffers(c))) return rc;
 	HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * nc, hipMemcpyHostToDevice));
+	if (st && c->gap_tiles) {
+		// Tiles of missing data (round 5; estep_struct.hip k_tile_allmiss).  A FULL tile inside its segment (not the first, not the last: position 1
+		// and position L are special) that is all `N` is a "gap tile": glued to its neighbours now, in both directions, together with the first
+		// tile after the gap in either direction -- their start vectors hang on what entered the gap however long it is.
+		std::vector<int> fl(nc, 0);
+		if (launch_tile_allmiss(c->stream, c->d_obs, c->d_chunks, nc, c->d_dirty) != 0) return fail(c, PSMC_HIP_EDEVICE, "k_tile_allmiss", hipGetLastError());
+		HIPCHK(c, hipMemcpyAsync(fl.data(), c->d_dirty, sizeof(int) * nc, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, sizeof(int) * nc, c->stream)); // (borrowed as scratch: back to what an allocation holds)
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		for (int b = 0; b < nc; ++b) {
+			const Chunk &ch = c->chunks[b];
+			c->gap[b] = fl[b] && ch.lo > 1 && ch.hi < ch.L && ch.hi - ch.lo + 1 == T;
+		}
+		auto same = [&](int x, int y) { return x >= 0 && y < nc && c->chunks[x].off == c->chunks[y].off; };
+		for (int b = 0; b < nc; ++b) {
+			if (c->gap[b]) { if (same(b - 1, b)) c->glue_f[b] = 1; if (same(b, b + 1)) c->glue_b[b] = 1; }
+			if (b > 0 && c->gap[b - 1] && same(b - 1, b)) c->glue_f[b] = 1;      // the first tile after a gap, forward
+			if (b + 1 < nc && c->gap[b + 1] && same(b, b + 1)) c->glue_b[b] = 1;  // ... and backward
+		}
+	}
 	c->plan_dirty = false; c->chunks_dirty = false;
 	return 0;
 }
@@ -157,9 +178,14 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 	std::vector<char> from_above(nc, 0), in_run(nc, 0), in_run_f(nc, 0), in_run_b(nc, 0); // in_run: member of a glued run of either direction
 	std::vector<std::pair<int, int>> gf, gb; // forward / backward groups (first, count): learned runs and bulk items
 	auto same_seg = [&](int x, int y) { return c->chunks[x].off == c->chunks[y].off; };
+	// "group_cap" bounds the bins of a run that carry DATA: a run of missing data costs its tiles one shared transfer matrix, however long it is
+	const bool gaps = c->gap_tiles && (int)c->gap.size() == nc;
+	std::vector<int64_t> eff(nc + 1, 0);
+	for (int b = 0; b < nc; ++b) eff[b + 1] = eff[b] + ((gaps && c->gap[b]) ? 0 : c->chunks[b].hi - c->chunks[b].lo + 1);
+	auto span_ok = [&](int b, int e) { return eff[e + 1] - eff[b] <= (int64_t)c->group_cap; }; // tiles b .. e
 	for (int b = 0; b < nc;) { // forward: head b, members b+1.. while glued
 		int e = b + 1;
-		while (e < nc && c->glue_f[e] && same_seg(e, b) && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap) ++e;
+		while (e < nc && c->glue_f[e] && same_seg(e, b) && span_ok(b, e)) ++e;
 		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = in_run_f[t] = 1;
 		else // a bulk item: the unglued tiles that follow, up to the next coarse boundary or the head of a run
 			while (e < nc && e - b < cf && same_seg(e, b) && idx[e] % cf != 0 && !c->glue_f[e] && !(e + 1 < nc && c->glue_f[e + 1] && same_seg(e + 1, e))) ++e;
@@ -168,7 +194,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 	}
 	for (int b = 0; b < nc;) { // backward: tiles b..e-1, top tile e-1; glue_b[t] ties t to t+1
 		int e = b + 1;
-		while (e < nc && c->glue_b[e - 1] && same_seg(e, b) && c->chunks[e].hi - c->chunks[b].lo + 1 <= c->group_cap &&
+		while (e < nc && c->glue_b[e - 1] && same_seg(e, b) && span_ok(b, e) &&
 		       c->chunks[e].lo < c->chunks[e].L) // a last tile holding only position L owns no transition: never a group's top
 			++e;
 		if (e - b > 1) for (int t = b; t < e; ++t) in_run[t] = in_run_b[t] = 1;
@@ -270,7 +296,16 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 	// neutral all the same, 12.95 vs 13.07 ms: the longest walk is a head with a doubled warm-up, 6144 steps), and the
 	// boundary vectors of its other tiles come from the transfer matrices, the head's first.
 	//   d_items + 12nc: wl_f (2nc) | wl_b (2nc) | kc tiles (4nc: KcTile) | runs (4nc + : KcRun)
-	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b;
+	std::vector<int> wl((size_t)4 * nc, 0), kc, runs_f, runs_b, kslot, kuniq; // kslot[j]: matrix slot of KcTile j; kuniq[u]: the KcTile that computes slot u
+	int gap_slot[2] = {-1, -1}; // the slot every gap tile of a direction shares
+	auto push_kc = [&](int t, int dir) {
+		const int j = (int)kc.size() / 2;
+		kc.push_back(t); kc.push_back(dir);
+		if (gaps && c->gap[t]) {
+			if (gap_slot[dir] < 0) { gap_slot[dir] = (int)kuniq.size(); kuniq.push_back(j); }
+			kslot.push_back(gap_slot[dir]);
+		} else { kslot.push_back((int)kuniq.size()); kuniq.push_back(j); }
+	};
 	c->n_wl_f = c->n_wl_b = 0;
 	// auto: measured per model size and plan (profiles/r03_kc_min_sweep.txt): one more tile is walked where there are two rounds of tiles
 	const int kc_min = c->kc_min >= 0 ? c->kc_min : (c->ns == 128 ? (nc > 4096 ? 12 : 8) : (nc > 4096 ? 5 : 4));
@@ -285,8 +320,12 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 		int budget = std::max(64, nc / c->kc_div);
 		for (int i = 0; i < n_long; ++i) {
 			int first = k[i].second.first, count = k[i].second.second;
-			const bool chain = chains && count >= kc_min && count - 1 <= budget;
-			if (chain) budget -= count - 1;
+			// what a run's matrices cost: one column kernel per tile that carries data (gap tiles share a matrix computed once per direction)
+			int cost = 0;
+			for (int tt = first; tt < first + count; ++tt) cost += (gaps && c->gap[tt]) ? 0 : 1;
+			cost = std::max(cost - 1, 1);
+			const bool chain = chains && count >= kc_min && cost <= budget;
+			if (chain) budget -= cost;
 			if (chain && !bwd && c->chunks[first].lo == 1) {
 				// position 1 is an initial condition, not a step: there is no X_0 for a transfer matrix to start from.
 				// Walk through the first tile as well and chain from the second one.
@@ -294,27 +333,29 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 				first += 1; count -= 1;
 				if (count >= 2) {
 					rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
-					for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
+					for (int t = first; t < first + count - 1; ++t) push_kc(t, 0);
 				}
 			} else if (chain) {
 				w[2 * nw] = bwd ? first + count - 1 : first; w[2 * nw + 1] = head_count; ++nw; // the head tile's start vector
 				rv.push_back(first); rv.push_back(count); rv.push_back((int)(kc.size() / 2)); rv.push_back(0);
-				if (!bwd) for (int t = first; t < first + count - 1; ++t) { kc.push_back(t); kc.push_back(0); }
-				else for (int t = first + count - 1; t > first; --t) { kc.push_back(t); kc.push_back(1); }
+				if (!bwd) for (int t = first; t < first + count - 1; ++t) push_kc(t, 0);
+				else for (int t = first + count - 1; t > first; --t) push_kc(t, 1);
 			} else { w[2 * nw] = first; w[2 * nw + 1] = (head_count == 0 && !bwd) ? -(count - 1) : count; ++nw; } // k_walk1_struct forward: stop where the last tile starts
 		}
 	};
 	add_runs(kf, c->n_long_f, false);
 	add_runs(kb, c->n_long_b, true);
-	c->n_chain_f = (int)runs_f.size() / 4; c->n_chain_b = (int)runs_b.size() / 4; c->n_kc = (int)kc.size() / 2;
+	c->n_chain_f = (int)runs_f.size() / 4; c->n_chain_b = (int)runs_b.size() / 4; c->n_kc = (int)kc.size() / 2; c->n_kuniq = (int)kuniq.size();
 	if ((size_t)c->n_kc > (size_t)2 * nc || (size_t)(c->n_chain_f + c->n_chain_b) > (size_t)nc) return fail(c, PSMC_HIP_ESTATE, "build_items: list overflow");
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)12 * nc, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice));
 	if (c->n_kc > 0) {
 		std::vector<int> runs(runs_f); runs.insert(runs.end(), runs_b.begin(), runs_b.end());
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)16 * nc, kc.data(), sizeof(int) * kc.size(), hipMemcpyHostToDevice));
 		HIPCHK(c, hipMemcpy(c->d_items + (size_t)20 * nc, runs.data(), sizeof(int) * runs.size(), hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_items + (size_t)26 * nc, kslot.data(), sizeof(int) * kslot.size(), hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemcpy(c->d_items + (size_t)28 * nc, kuniq.data(), sizeof(int) * kuniq.size(), hipMemcpyHostToDevice));
 		const size_t nsub = kcol2_on(c) ? (size_t)c->kc_sub_used : 1; // k_kcol2_struct: kc_sub matrices per tile
-		const size_t need = (size_t)c->n_kc * nsub * ((size_t)c->ns * c->ns + c->ns); // the matrices, then one exponent per column
+		const size_t need = (size_t)c->n_kuniq * nsub * ((size_t)c->ns * c->ns + c->ns); // the matrices (one per slot), then one exponent per column
 		if (need > c->kcol_cap) { int rc; if ((rc = dev_alloc(c, &c->d_Kcol, need))) return rc; c->kcol_cap = need; }
 	}
 	c->items_dirty = false;
@@ -446,9 +487,10 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	p.d_wl_f = c->d_items + 12 * (size_t)p.n_chunks; p.d_wl_b = c->d_items + 14 * (size_t)p.n_chunks; p.n_wl_f = c->n_wl_f; p.n_wl_b = c->n_wl_b;
 	p.d_kc = c->d_items + 16 * (size_t)p.n_chunks; p.d_kruns = c->d_items + 20 * (size_t)p.n_chunks;
 	p.n_kc = c->n_kc; p.n_chain_f = c->n_chain_f; p.n_chain_b = c->n_chain_b;
+	p.d_kslot = c->d_items + 26 * (size_t)p.n_chunks; p.d_kuniq = c->d_items + 28 * (size_t)p.n_chunks; p.n_kuniq = c->n_kuniq;
 	p.kcol_prio = c->kcol_prio;
 	p.d_Kcol = c->d_Kcol; p.kc_sub = kcol2_on(c) ? c->kc_sub_used : 1;
-	p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kc * p.kc_sub * c->ns * c->ns : nullptr; p.stream5 = c->stream5;
+	p.d_Kexp = c->d_Kcol ? c->d_Kcol + (size_t)c->n_kuniq * p.kc_sub * c->ns * c->ns : nullptr; p.stream5 = c->stream5;
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
@@ -458,6 +500,19 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 		psmc_hip_ctx *R = dbg_root(c);
 		R->dbg_acc[4] += dbg_now() - t0;
 		R->dbg_acc[6] += c->report.fwd_rounds + c->report.bwd_rounds; R->dbg_acc[7] += c->report.fwd_tiles + c->report.bwd_tiles;
+	}
+	if (getenv("PSMC_HIP_DEBUG_FLAGGED")) { // which tiles the verify / repair net had to touch in this E-step, and what the plan knew about them
+		auto dump = [&](const char *dir, const std::vector<int> &fl, const std::vector<uint8_t> &glue, bool bwd) {
+			std::vector<int> u(fl); std::sort(u.begin(), u.end()); u.erase(std::unique(u.begin(), u.end()), u.end());
+			fprintf(stderr, "[psmc_hip] flagged %s: %zu tile repairs, %zu distinct tiles, rounds %d:", dir, fl.size(), u.size(), bwd ? c->report.bwd_rounds : c->report.fwd_rounds);
+			for (size_t i = 0; i < u.size() && i < 400; ++i) {
+				const int b = u[i]; const Chunk &ch = c->chunks[b];
+				int seg = 0; while (seg + 1 < c->n_seg && c->off[seg + 1] <= ch.off) ++seg;
+				fprintf(stderr, " [t%d seg%d %d..%d w%d g%d x%d]", b, seg, ch.lo, ch.hi, bwd ? ch.wb : ch.wf, (int)glue[b], (int)std::count(fl.begin(), fl.end(), b));
+			}
+			fprintf(stderr, "\n");
+		};
+		dump("fwd", c->flagged_f, c->glue_f, false); dump("bwd", c->flagged_b, c->glue_b, true);
 	}
 	if (!c->report.converged) return fail(c, PSMC_HIP_ECONVERGE, "fast mode: tile boundaries did not converge within max_rounds");
 	if (c->use_struct && c->learn) learn_groups(c);

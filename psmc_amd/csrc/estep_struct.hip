@@ -606,7 +606,7 @@ __host__ __device__ inline void kc_range(const Chunk &c, int dir, int &lo, int &
 template <int NPL>
 __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ sp, const double *__restrict__ e,
                                                       const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks,
-                                                      const KcTile *__restrict__ kc, double *__restrict__ Kcol,
+                                                      const KcTile *__restrict__ kc, const int *__restrict__ uniq, double *__restrict__ Kcol,
                                                       double *__restrict__ Kexp)
 {
 	constexpr int S = 16 * NPL, BPT = S / 4; // S unit vectors per tile, four per wave: BPT blocks per tile
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 	// the transfer matrices head the longest dependency chain of the first phase (columns -> chain -> run tiles ->
 	// the fused back half may start): ahead of the bulk sweeps, behind the walks
 	__builtin_amdgcn_s_setprio(2);
-	const KcTile kt = kc[j];
+	const KcTile kt = kc[uniq[j]]; // slot j's matrix is computed from this tile (tiles of missing data share one slot per direction)
 	const Chunk c = chunks[kt.tile];
 	const bool fwd = kt.dir == 0;
 	// backward: the map stops above the tile's lowest scaled position p* (the first p >= lo with p % 4 == 0); the
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(64) void k_kcol_struct(const double *__restrict__ s
 // above it, its prefix sums those of the quarters below it.
 template <int NQ>
 __global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restrict__ kcc, const uint8_t *__restrict__ obs,
-                                                            const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc,
+                                                            const Chunk *__restrict__ chunks, const KcTile *__restrict__ kc, const int *__restrict__ uniq,
                                                             double *__restrict__ Kcol, double *__restrict__ Kexp, int sub, int prio)
 {
 	constexpr int S = 32 * NQ, NCG = S / 64, KD = 11 * S; // KD: doubles per direction = mS | mP | 3 x (wS.e | wP.e | dd.e)
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(64 * NQ) void k_kcol2_struct(const double *__restri
 	const int j = (int)blockIdx.x / NCG, cg = (int)blockIdx.x % NCG, jt = j / sub, js = j % sub;
 	const int col = 64 * cg + lane;
 	if (prio >= 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1); // s_setprio takes an immediate
-	const KcTile kt = kc[jt];
+	const KcTile kt = kc[uniq[jt]]; // slot jt's matrices are computed from this tile
 	const Chunk c = chunks[kt.tile];
 	const bool fwd = kt.dir == 0;
 	for (int i = threadIdx.x; i < KD; i += 64 * NQ) tab[i] = kcc[(fwd ? 0 : KD) + i];
@@ -788,7 +788,8 @@ __device__ __forceinline__ void struct_step1n(const StructPar1 (&c)[PER], double
 // barrier per product, double-buffered), every wave adds them in wave order and carries the whole vector, so that the
 // normalisation, the backward sweep's last steps and the next product need no further exchange.  ~0.3 us per product.
 template <int PER>
-__global__ __launch_bounds__(64 * (PER == 1 ? 2 : 8)) void k_kchain_struct(const KcRun *__restrict__ runs, int n_f, const double *__restrict__ Kcol,
+__global__ __launch_bounds__(64 * (PER == 1 ? 2 : 8)) void k_kchain_struct(const KcRun *__restrict__ runs, int n_f, const int *__restrict__ kslot,
+                                                        const double *__restrict__ Kcol,
                                                         const double *__restrict__ Kexp, const double *__restrict__ sp,
                                                         const double *__restrict__ e, const uint8_t *__restrict__ obs,
                                                         const Chunk *__restrict__ chunks, double *__restrict__ entry,
@@ -814,12 +815,11 @@ __global__ __launch_bounds__(64 * (PER == 1 ? 2 : 8)) void k_kchain_struct(const
 		s1[q].mS = sp[3 * S + k]; s1[q].wS = sp[S + k]; s1[q].mP = sp[2 * S + k]; s1[q].wP = sp[k]; s1[q].dd = sp[4 * S + k];
 		e0[q] = e[k]; e1[q] = e[S + k];
 	}
-	const int n_mats = (r.count - 1) * sub; // matrix j = tile j / sub of the run, range j % sub: consecutive in Kcol
-	const int64_t kb0 = (int64_t)r.kc0 * sub * S;
+	const int n_mats = (r.count - 1) * sub; // matrix j = tile j / sub of the run, range j % sub; the tile's matrices sit in slot kslot[kc0 + j / sub]
 	const int row0 = RW * w, src_h = row0 >> 6, src_l = row0 & 63; // this wave's rows = source states row0 .. row0 + RW - 1: register src_h, lanes src_l ..
 	double ma[RW][PER], mb[RW][PER], ea[PER], eb[PER];
 	auto load = [&](int j, double (&m)[RW][PER], double (&ex)[PER]) {
-		const int64_t kb = kb0 + (int64_t)j * S;
+		const int64_t kb = ((int64_t)kslot[r.kc0 + j / sub] * sub + j % sub) * S;
 #pragma unroll
 		for (int i = 0; i < RW; ++i)
 #pragma unroll
@@ -1039,21 +1039,42 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 	PSMC_DBG("launch_sweeps", nf, nb, top_only);
 #undef PSMC_LS
 }
+// Plan time: which tiles consist of missing data only (symbol 2 at every position lo..hi)?  Real .psmcfa files carry runs of 1e4 .. 3e5 `N`
+// bins (centromeres, assembly gaps: utils/fq2psmcfa.c:114-127); inside such a run the chain forgets at the rate of the transition matrix's
+// second eigenvalue alone -- 0.99995 for a human-like model: 5e5 bins to 1e-12 -- so no speculative warm-up ever works there and every tile
+// of the run hangs on the vector at its start.  The planner glues them at once, and their transfer matrix (a^T to the tile length,
+// whatever the tile) is computed ONCE per direction (api_fast.hip build_items).
+__global__ __launch_bounds__(64) void k_tile_allmiss(const uint8_t *__restrict__ obs, const Chunk *__restrict__ chunks, int *__restrict__ flags)
+{
+	const Chunk c = chunks[blockIdx.x];
+	const uint8_t *o = obs + c.off;
+	int bad = 0;
+	for (int p = c.lo + (int)threadIdx.x; p <= c.hi; p += 64) bad |= ((int)o[p - 1] & 3) != 2;
+	const int any_bad = __any(bad);
+	if (threadIdx.x == 0) flags[blockIdx.x] = any_bad ? 0 : 1;
+}
+int launch_tile_allmiss(hipStream_t st, const uint8_t *d_obs, const Chunk *d_chunks, int n_chunks, int *d_flags)
+{
+	if (n_chunks <= 0) return 0;
+	hipLaunchKernelGGL(k_tile_allmiss, dim3(n_chunks), dim3(64), 0, st, d_obs, d_chunks, d_flags);
+	return (int)hipGetLastError();
+}
+
 void launch_kchain(const EstepLaunch &p, hipStream_t st_cols, hipStream_t st_chain, hipEvent_t ev_cols)
 {
 	if (p.n_kc <= 0) return;
 	if (p.ns == 128) // 65..128 states: unit vectors as sweep tiles (the column-per-lane kernel's chain path ends later there)
-		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kc * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
-		                   (const KcTile *)p.d_kc, p.d_Kcol, p.d_Kexp);
+		hipLaunchKernelGGL(k_kcol_struct<8>, dim3(p.n_kuniq * 32), dim3(64), 0, st_cols, p.d_sp, p.d_e, p.d_obs, p.d_chunks,
+		                   (const KcTile *)p.d_kc, p.d_kuniq, p.d_Kcol, p.d_Kexp);
 	else
-		hipLaunchKernelGGL(k_kcol2_struct<2>, dim3(p.n_kc * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc,
+		hipLaunchKernelGGL(k_kcol2_struct<2>, dim3(p.n_kuniq * p.kc_sub), dim3(128), 0, st_cols, p.d_kcc, p.d_obs, p.d_chunks, (const KcTile *)p.d_kc, p.d_kuniq,
 		                   p.d_Kcol, p.d_Kexp, p.kc_sub, p.kcol_prio);
 	if (st_cols != st_chain) { (void)hipEventRecord(ev_cols, st_cols); (void)hipStreamWaitEvent(st_chain, ev_cols, 0); }
 	if (p.ns == 128)
-		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(512), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
+		hipLaunchKernelGGL(k_kchain_struct<2>, dim3(p.n_chain_f + p.n_chain_b), dim3(512), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f, p.d_kslot,
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kc_sub);
 	else
-		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(128), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f,
+		hipLaunchKernelGGL(k_kchain_struct<1>, dim3(p.n_chain_f + p.n_chain_b), dim3(128), 0, st_chain, (const KcRun *)p.d_kruns, p.n_chain_f, p.d_kslot,
 		                   p.d_Kcol, p.d_Kexp, p.d_sp, p.d_e, p.d_obs, p.d_chunks, p.d_entry, p.d_bentry, p.kc_sub);
 	PSMC_DBG("launch_kchain", p.n_kc, p.n_chain_f, p.n_chain_b);
 }

@@ -75,6 +75,10 @@ struct psmc_hip_ctx {
 	int *h_ritems = nullptr;   // pinned + device-mapped, 2 * 2*n_chunks ints
 	int *m_ritems = nullptr, *m_cnt = nullptr; // device views of h_ritems / h_cnt
 	std::vector<uint8_t> glue_f, glue_b; // glue_f[b]: tile b continues the forward item of b-1; glue_b[b]: b continues b+1's backward item
+	std::vector<uint8_t> gap;            // gap[b]: tile b is a FULL tile of missing data inside its segment (plan_fast: k_tile_allmiss): glued at once,
+	                                     // free of "group_cap", one shared transfer matrix per direction (build_items)
+	int gap_tiles = 1;                   // "gap_tiles": 0 = treat tiles of missing data like any other (rounds 1-4)
+	int n_kuniq = 0;                     // transfer-matrix slots of the current item lists
 	std::vector<int> flagged_f, flagged_b;
 	bool items_dirty = true;
 	int n_items_f = 0, n_items_b = 0;

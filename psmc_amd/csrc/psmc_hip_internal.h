@@ -92,6 +92,8 @@ struct EstepLaunch {
 	// walks: heads of the chain runs (count 1) followed by the short runs; transfer-matrix chains of the long runs
 	const int *d_wl_f, *d_wl_b; int n_wl_f, n_wl_b;
 	const int *d_kc, *d_kruns; int n_kc, n_chain_f, n_chain_b; // KcTile[n_kc], KcRun[n_chain_f + n_chain_b]
+	const int *d_kslot, *d_kuniq; int n_kuniq;                 // matrix slot of every KcTile; the KcTile that computes slot u (round 5: the full tiles of a
+	                                                           // run of missing data all have the SAME transfer matrix -- one slot per direction for all of them)
 	double *d_Kcol, *d_Kexp;                                  // [n_kc][64][64], [n_kc][64]
 	int *d_ritems_f, *d_ritems_b;     // [n_chunks][2] flagged tiles of the current repair round as one-tile items
 	int *h_ritems;                    // host view of pinned, device-mapped [2][n_chunks][2]: the same lists, so that the host can learn the groups
@@ -147,6 +149,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep);
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
+int launch_tile_allmiss(hipStream_t st, const uint8_t *d_obs, const Chunk *d_chunks, int n_chunks, int *d_flags); // estep_struct.hip
 void launch_walks(const EstepLaunch &p, hipStream_t st);
 void launch_gate(hipStream_t st, const int *ctr, int want);
 int walk_blocks(const EstepLaunch &p);

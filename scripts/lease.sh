@@ -29,6 +29,7 @@ print("headline %.3f ms  %.3e bins/s  frac %.3f  steady %s" % (r["ms_per_step"],
 if "kernels_ms" in r["roofline"]: print("kernels", {k: round(v, 2) for k, v in r["roofline"]["kernels_ms"].items()})
 print("factored", r.get("factored_stats", {}).get("ms_per_step"))
 for w in r.get("shard_sweep", {}).get("workloads", []): print("shard", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in w.items() if k != "kernels_ms"})
+print("real_shape", {k: v for k, v in r.get("real_shape", {}).items() if k not in ("workload", "kernels_ms")})
 print("group", r.get("group_engine")); print("boot", json.dumps(r.get("boot"))[:1200])
 n = r.get("n128", {})
 print("n128", n.get("ms_per_step"), n.get("ms_min"), n.get("factored_stats", {}).get("ms_per_step") if isinstance(n.get("factored_stats"), dict) else n.get("factored_stats"), n.get("roofline", {}).get("frac"), n.get("error"))

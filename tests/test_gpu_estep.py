@@ -18,8 +18,8 @@ FAST_TOL_LL = 1e-12     # relative
 # that carries weight (>= 1e-6 of the largest), the relative L1 error, and the error of the two sums hmm_Q reads
 # (khmm.c:363-382).  Bounds = what the suite measures on the MI355X, rounded up (DESIGN.md section 3 has the observed values).
 FAST_TOL_CELL = 1e-9    # largest relative error of a cell >= 1e-6 x the largest cell (A and E); observed <= 5e-13 (fixtures), 5e-12 (30 M bins, bench.py)
-FAST_TOL_L1 = 1e-10     # sum |A - ref| / sum |ref|
-FAST_TOL_Q = 1e-11      # sum A log a and sum E log e, relative
+FAST_TOL_L1 = 1e-10     # sum |A - ref| / sum |ref|; observed <= 8.7e-12
+FAST_TOL_Q = 1e-10      # sum A log a and sum E log e, relative; observed <= 8.1e-12 over the suite, 3.7e-12 at 30 M bins
 FAST_SEEN = []          # every comparison of the session (conftest prints the worst of each at the end)
 
 

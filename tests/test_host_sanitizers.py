@@ -40,7 +40,8 @@ def asan_psmc():
 
 
 CASES = [os.path.basename(f)[:-5] for f in sorted(glob.glob(os.path.join(CLI, "*.args")))]
-SMALL = [c for c in CASES if "n128" not in c and "mid_n64" not in c] or CASES[:4]
+# (the wide-state goldens run minutes under ASan; their host path is the same code as the small ones)
+SMALL = [c for c in CASES if "n128" not in c and "mid_n64" not in c and "n200" not in c and "n149" not in c] or CASES[:4]
 
 
 @pytest.mark.parametrize("name", SMALL)

@@ -57,7 +57,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 /* Options.  None is needed: the defaults are what bench.py and the psmc binary run, and the plan adapts to the input
  * (see "auto").  PSMC_HIP_OPTIONS="key=value,key=value" in the environment sets them for every context of a process.
  * Unknown keys and out-of-range values return PSMC_HIP_EINVAL.  Setting any option drops the per-replicate plans a
- * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_slots" and "exact_refwd".
+ * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_slots" and "exact_refwd" ("batch_first" is accepted and has no effect).
  *
  *  key             default  meaning
  *  --- plan of the fast mode (tiles, speculation) ---------------------------------------------------------------
@@ -135,6 +135,10 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "rep_impl"      auto     row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical); -1 = auto:
  *                           0 when a launch has more than one wave per SIMD (bootstrap batch), else 1
  *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch; 0 = what fits the free device memory
+ *  "batch_first"   0        psmc_hip_estep_batch, fast mode: replicate 0 of the calls that follow is replicate <value> of the context's
+ *                           replicates -- a caller that sends its replicates in several groups (psmc_boot: the M-steps of one group run
+ *                           under the E-steps of the next) names each group's first position, so that every replicate meets the tile plan
+ *                           it had in the previous EM iteration.  Exact mode keeps nothing per replicate and ignores it.
  *  "batch_sort"    1        psmc_hip_estep_batch: the entries -- (replicate, segment) sweeps -- of ALL replicates are dealt to the launches
  *                           longest first, so that the long trunks share one launch and the others end with their own, shorter, longest
  *                           entry; 0 = replicate-major order (every launch then lasts as long as the longest trunk).  Bit-identical.

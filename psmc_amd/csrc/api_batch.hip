@@ -325,7 +325,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 // so nothing is re-planned or re-learned from one EM iteration to the next.  Children share the parent's tables.
 static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 {
-	while ((int)c->kids.size() <= r) {
+	while ((int)c->kids.size() <= r) { // (positions below r that no call has named yet get their context too: unselected, no tables of their own)
 		psmc_hip_ctx *k = new (std::nothrow) psmc_hip_ctx();
 		if (!k) return nullptr;
 		k->n = c->n; k->ns = c->ns; k->device = c->device; k->mode = c->mode; k->parent = c;
@@ -381,7 +381,7 @@ static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double 
 	double t_est = 0.0;
 	for (int r = 0; r < n_rep; ++r) {
 		const double t_k = dbg_now();
-		psmc_hip_ctx *k = batch_child(c, r);
+		psmc_hip_ctx *k = batch_child(c, c->batch_first + r);
 		c->dbg_acc[0] += dbg_now() - t_k;
 		if (!k) return fail(c, PSMC_HIP_ENOMEM, "estep_batch: cannot create the replicate context");
 		const int n_sel = sel_off[r + 1] - sel_off[r];

@@ -1,8 +1,9 @@
 /* boot.c -- config 4: the bootstrap farm of lh3/psmc (README:57-62 there: `seq 100 | xargs -i echo psmc -N25 ... -b
  * -o round-{}.psmc split.fa | sh`) as ONE process that keeps the trunks in HBM once and runs all replicates' EM
- * iterations in lock step: per iteration the E-steps of every replicate go to the device(s) as one batch each
- * (psmc_hip_estep_batch: exact mode packs hundreds of trunk sweeps into one grid; fast mode keeps a learned tile plan
- * per replicate), then the Hooke-Jeeves M-steps (host, em.c:56-68) run on host threads, one replicate each.
+ * iterations together: the E-steps of a group of replicates go to a device as one batch (psmc_hip_estep_batch: exact
+ * mode packs hundreds of trunk sweeps into one grid; fast mode keeps a learned tile plan per replicate), the
+ * Hooke-Jeeves M-steps (host, em.c:56-68) run on host threads, one replicate each -- and while they run, the device
+ * is already busy with the E-steps of the device's other group (two groups per device: PSMC_BOOT_GROUPS).
  *
  * Replicate r is `PSMC_SEED=<seed0+r> psmc -b <options>`: the same srand48 seed, hence the same psmc_resamp draw
  * (aux.c:8-47) and the same -I initial parameters, the same .psmc stream -- byte for byte in exact mode
@@ -35,6 +36,96 @@ static void *main_thread(void *arg)
 	j->status = psmc_run_finish(j->st);
 	j->ms = now_ms() - t0;
 	__atomic_store_n(&j->finished, 1, __ATOMIC_RELEASE);
+	return 0;
+}
+
+
+/* ---- the EM iterations of all replicates as a two-stage pipeline: E-steps on the devices, M-steps on host threads */
+#define MAX_GRP 8
+typedef struct {
+	psmc_options *o; psmc_batch_backend *bb; replicate *rep; int n_rep, N, factored, n_grp, timing;
+	main_job *mj;
+	pthread_mutex_t mu; pthread_cond_t cv; /* guard everything below */
+	int *e_done;        /* [device * n_grp + group]: EM iterations whose E-step results of that group are in rep[] */
+	int m_done[MAX_GRP]; /* EM iterations whose M-steps of the group (all devices) are done */
+	double *e_ms;       /* [device * n_iters + iteration]: time inside estep_batch */
+	int failed;
+} pipeline;
+typedef struct { pipeline *P; int dev; pthread_t tid; } dev_job;
+
+static void pipe_fail(pipeline *P) { pthread_mutex_lock(&P->mu); P->failed = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); }
+static int pipe_failed(pipeline *P) { pthread_mutex_lock(&P->mu); const int f = P->failed; pthread_mutex_unlock(&P->mu); return f; }
+/* device d drives replicates d, d + n_dev, ...: positions [lo, hi) of that list are its group g */
+static void group_range(const pipeline *P, int d, int g, int *lo, int *hi)
+{
+	const int cnt = P->n_rep > d ? (P->n_rep - d + P->bb->n_dev - 1) / P->bb->n_dev : 0;
+	*lo = (int)((int64_t)cnt * g / P->n_grp); *hi = (int)((int64_t)cnt * (g + 1) / P->n_grp);
+}
+
+/* one batch: the E-steps of positions [lo, hi) of device d's replicates, results into rep[] */
+static int estep_group(pipeline *P, int d, int lo, int hi)
+{
+	psmc_batch_backend *bb = P->bb;
+	replicate *rep = P->rep;
+	const int N = P->N, cnt = hi - lo, nd = bb->n_dev;
+	int tot = 0;
+	for (int j = lo; j < hi; ++j) tot += rep[d + j * nd].n_idx;
+	double *a = (double *)malloc(sizeof(double) * (size_t)cnt * N * N), *e = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N);
+	double *a0 = (double *)malloc(sizeof(double) * (size_t)cnt * N);
+	double *A = P->factored ? 0 : (double *)malloc(sizeof(double) * (size_t)cnt * N * N);
+	double *S5 = P->factored ? (double *)malloc(sizeof(double) * (size_t)cnt * 5 * N) : 0;
+	double *E = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N), *LL = (double *)malloc(sizeof(double) * (size_t)cnt);
+	int32_t *off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cnt + 1)), *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(tot > 0 ? tot : 1));
+	off[0] = 0;
+	for (int j = 0; j < cnt; ++j) {
+		const replicate *R = &rep[d + (lo + j) * nd];
+		memcpy(a + (size_t)j * N * N, R->m->a, sizeof(double) * (size_t)N * N);
+		memcpy(e + (size_t)j * 2 * N, R->m->e, sizeof(double) * (size_t)2 * N); /* rows hom, het; the missing row is implied */
+		memcpy(a0 + (size_t)j * N, R->m->a0, sizeof(double) * (size_t)N);
+		memcpy(idx + off[j], R->idx, sizeof(int32_t) * (size_t)R->n_idx);
+		off[j + 1] = off[j] + R->n_idx;
+	}
+	const int rc = bb->estep_batch(bb->self, d, lo, cnt, a, e, a0, off, idx, A, S5, E, LL);
+	if (rc) fprintf(stderr, "psmc_boot: E-step batch failed on device %d: %s\n", d, bb->error(bb->self, d));
+	for (int j = 0; j < cnt && !rc; ++j) {
+		replicate *R = &rep[d + (lo + j) * nd];
+		if (A) memcpy(R->A, A + (size_t)j * N * N, sizeof(double) * (size_t)N * N);
+		if (S5) memcpy(R->sums, S5 + (size_t)j * 5 * N, sizeof(double) * (size_t)5 * N);
+		memcpy(R->E, E + (size_t)j * 2 * N, sizeof(double) * (size_t)2 * N);
+		R->LL = LL[j];
+	}
+	free(a); free(e); free(a0); free(A); free(S5); free(E); free(LL); free(off); free(idx);
+	return rc;
+}
+
+static void *dev_thread(void *arg)
+{
+	dev_job *J = (dev_job *)arg;
+	pipeline *P = J->P;
+	const int d = J->dev;
+	int main_released = 0;
+	for (int it = 0; it != P->o->n_iters; ++it)
+		for (int g = 0; g < P->n_grp; ++g) {
+			int lo, hi, ok;
+			pthread_mutex_lock(&P->mu);
+			while (!P->failed && P->m_done[g] < it) pthread_cond_wait(&P->cv, &P->mu); /* the group's parameters of this iteration exist */
+			ok = !P->failed;
+			pthread_mutex_unlock(&P->mu);
+			if (!ok) return 0;
+			if (P->mj && !main_released && P->bb->main_done && __atomic_load_n(&P->mj->finished, __ATOMIC_ACQUIRE)) {
+				P->bb->main_done(P->bb->self, d); /* the main run is over: this device's batches get its compute units back */
+				main_released = 1;
+				if (P->timing) fprintf(stderr, "[psmc_boot] main run finished before iteration %d, group %d of device %d: its batches have the whole device again\n", it + 1, g, d);
+			}
+			group_range(P, d, g, &lo, &hi);
+			const double t0 = now_ms();
+			if (hi > lo && estep_group(P, d, lo, hi)) { pipe_fail(P); return 0; }
+			pthread_mutex_lock(&P->mu);
+			P->e_ms[(size_t)d * P->o->n_iters + it] += now_ms() - t0;
+			P->e_done[d * P->n_grp + g] = it + 1;
+			pthread_cond_broadcast(&P->cv);
+			pthread_mutex_unlock(&P->mu);
+		}
 	return 0;
 }
 
@@ -122,64 +213,79 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 	/* The main run starts now: every draw from drand48 -- its own (psmc_run_begin) and the replicates' (above) -- is done, and from here
 	 * on the two only share the device: the main run's sweeps on the compute units its context was given, the batch on the others. */
 	main_job mj = {main_run, 0, 0.0, 0};
-	int main_released = 0;
 	pthread_t main_tid;
 	int main_started = 0;
 	if (main_run) {
 		if (pthread_create(&main_tid, 0, main_thread, &mj) == 0) main_started = 1;
 		else { fprintf(stderr, "psmc_boot: cannot start the main run's thread\n"); failed = 1; }
 	}
-	for (int it = 0; it != o->n_iters && !failed; ++it) { /* main.c:16-20, all replicates in lock step */
-		const double t0 = now_ms();
-		/* E-steps: one batch per device */
-#pragma omp parallel for schedule(static, 1) num_threads(bb->n_dev) reduction(| : failed)
-		for (int d = 0; d < bb->n_dev; ++d) {
-			int cnt = 0, tot = 0;
-			for (int r = d; r < n_rep; r += bb->n_dev) { ++cnt; tot += rep[r].n_idx; }
-			if (cnt == 0) continue;
-			double *a = (double *)malloc(sizeof(double) * (size_t)cnt * N * N), *e = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N);
-			double *a0 = (double *)malloc(sizeof(double) * (size_t)cnt * N);
-			double *A = factored ? 0 : (double *)malloc(sizeof(double) * (size_t)cnt * N * N);
-			double *S5 = factored ? (double *)malloc(sizeof(double) * (size_t)cnt * 5 * N) : 0;
-			double *E = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N), *LL = (double *)malloc(sizeof(double) * (size_t)cnt);
-			int32_t *off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cnt + 1)), *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)tot);
-			int j = 0; off[0] = 0;
-			for (int r = d; r < n_rep; r += bb->n_dev, ++j) {
-				const psmc_model *m = rep[r].m;
-				memcpy(a + (size_t)j * N * N, m->a, sizeof(double) * (size_t)N * N);
-				memcpy(e + (size_t)j * 2 * N, m->e, sizeof(double) * (size_t)2 * N); /* rows hom, het; the missing row is implied */
-				memcpy(a0 + (size_t)j * N, m->a0, sizeof(double) * (size_t)N);
-				memcpy(idx + off[j], rep[r].idx, sizeof(int32_t) * (size_t)rep[r].n_idx);
-				off[j + 1] = off[j] + rep[r].n_idx;
-			}
-			const int rc = bb->estep_batch(bb->self, d, cnt, a, e, a0, off, idx, A, S5, E, LL);
-			if (rc) { fprintf(stderr, "psmc_boot: E-step batch failed on device %d: %s\n", d, bb->error(bb->self, d)); failed |= 1; }
-			j = 0;
-			for (int r = d; r < n_rep && !rc; r += bb->n_dev, ++j) {
-				if (A) memcpy(rep[r].A, A + (size_t)j * N * N, sizeof(double) * (size_t)N * N);
-				if (S5) memcpy(rep[r].sums, S5 + (size_t)j * 5 * N, sizeof(double) * (size_t)5 * N);
-				memcpy(rep[r].E, E + (size_t)j * 2 * N, sizeof(double) * (size_t)2 * N);
-				rep[r].LL = LL[j];
-			}
-			free(a); free(e); free(a0); free(A); free(S5); free(E); free(LL); free(off); free(idx);
+	{ /* main.c:16-20 for every replicate.  Each device's replicates form n_grp groups; a device thread sends group after group to
+	   * the device, and the M-steps of a group (host threads, here) run while the device is busy with the NEXT group's E-steps:
+	   * E(g0,1) | E(g1,1) + M(g0,1) | E(g0,2) + M(g1,1) | ...  A replicate still sees E, M, E, M, ... in order: same output. */
+		pipeline P;
+		const char *gs = getenv("PSMC_BOOT_GROUPS");
+		memset(&P, 0, sizeof P);
+		P.n_grp = gs ? atoi(gs) : 2;
+		if (P.n_grp < 1) P.n_grp = 1;
+		if (P.n_grp > MAX_GRP) P.n_grp = MAX_GRP;
+		if ((n_rep + bb->n_dev - 1) / bb->n_dev < P.n_grp) P.n_grp = 1; /* (no device with a replicate for every group: one batch per iteration) */
+		P.o = o; P.bb = bb; P.rep = rep; P.n_rep = n_rep; P.N = N; P.factored = factored; P.mj = main_started ? &mj : 0; P.timing = timing;
+		P.failed = failed;
+		pthread_mutex_init(&P.mu, 0); pthread_cond_init(&P.cv, 0);
+		P.e_done = (int *)calloc((size_t)bb->n_dev * P.n_grp, sizeof(int));
+		P.e_ms = (double *)calloc((size_t)bb->n_dev * (size_t)(o->n_iters > 0 ? o->n_iters : 1), sizeof(double));
+		dev_job *dj = (dev_job *)calloc((size_t)bb->n_dev, sizeof(dev_job));
+		int n_thr = 0;
+		for (int d = 0; d < bb->n_dev && !P.failed; ++d) {
+			dj[d].P = &P; dj[d].dev = d;
+			if (pthread_create(&dj[d].tid, 0, dev_thread, &dj[d]) == 0) ++n_thr;
+			else { fprintf(stderr, "psmc_boot: cannot start the thread of device %d\n", d); pipe_fail(&P); }
 		}
-		if (failed) break;
-		const double t1 = now_ms();
-		/* M-steps: independent models, one host thread each (em.c:56-74), then the round's output */
+		int *list = (int *)malloc(sizeof(int) * (size_t)n_rep);
+		double t_prev = now_ms();
+		for (int it = 0; it != o->n_iters && !pipe_failed(&P); ++it) {
+			double m_ms = 0.0;
+			for (int g = 0; g < P.n_grp; ++g) {
+				int n_list = 0, ok = 1;
+				pthread_mutex_lock(&P.mu);
+				for (int d = 0; d < bb->n_dev; ++d)
+					while (!P.failed && P.e_done[d * P.n_grp + g] < it + 1) pthread_cond_wait(&P.cv, &P.mu);
+				ok = !P.failed;
+				pthread_mutex_unlock(&P.mu);
+				if (!ok) break;
+				for (int d = 0; d < bb->n_dev; ++d) {
+					int lo, hi; group_range(&P, d, g, &lo, &hi);
+					for (int j = lo; j < hi; ++j) list[n_list++] = d + j * bb->n_dev;
+				}
+				const double t1 = now_ms();
+				/* M-steps: independent models, one host thread each (em.c:56-74), then the round's output */
 #pragma omp parallel for schedule(dynamic, 1)
-		for (int r = 0; r < n_rep; ++r) {
-			replicate *R = &rep[r];
-			psmc_em_mstep(R->m, R->A, R->E, R->sums, R->LL, R->out);
-			fprintf(R->out, "RD\t%d\n", it + 1);
-			psmc_print_round(R->m, R->sum_called, R->out);
+				for (int q = 0; q < n_list; ++q) {
+					replicate *R = &rep[list[q]];
+					psmc_em_mstep(R->m, R->A, R->E, R->sums, R->LL, R->out);
+					fprintf(R->out, "RD\t%d\n", it + 1);
+					psmc_print_round(R->m, R->sum_called, R->out);
+				}
+				m_ms += now_ms() - t1;
+				pthread_mutex_lock(&P.mu);
+				P.m_done[g] = it + 1;
+				pthread_cond_broadcast(&P.cv);
+				pthread_mutex_unlock(&P.mu);
+			}
+			if (timing && !pipe_failed(&P)) {
+				double e_ms = 0.0;
+				pthread_mutex_lock(&P.mu);
+				for (int d = 0; d < bb->n_dev; ++d) if (P.e_ms[(size_t)d * o->n_iters + it] > e_ms) e_ms = P.e_ms[(size_t)d * o->n_iters + it];
+				pthread_mutex_unlock(&P.mu);
+				const double t_now = now_ms();
+				fprintf(stderr, "[psmc_boot] iteration %d: %d E-steps %.1f ms on %d device(s), M-steps %.1f ms, %d group(s), wall %.1f ms\n", it + 1, n_rep, e_ms, bb->n_dev, m_ms, P.n_grp, t_now - t_prev);
+				t_prev = t_now;
+			}
 		}
-		if (timing)
-			fprintf(stderr, "[psmc_boot] iteration %d: %d E-steps %.1f ms on %d device(s), M-steps %.1f ms\n", it + 1, n_rep, t1 - t0, bb->n_dev, now_ms() - t1);
-		if (main_started && !main_released && bb->main_done && __atomic_load_n(&mj.finished, __ATOMIC_ACQUIRE)) {
-			bb->main_done(bb->self); /* the main run is over: the batch gets its compute units back for the remaining iterations */
-			main_released = 1;
-			if (timing) fprintf(stderr, "[psmc_boot] main run finished during iteration %d: the batch has the whole device again\n", it + 1);
-		}
+		for (int d = 0; d < n_thr; ++d) pthread_join(dj[d].tid, 0);
+		failed = P.failed;
+		free(list); free(dj); free(P.e_done); free(P.e_ms);
+		pthread_mutex_destroy(&P.mu); pthread_cond_destroy(&P.cv);
 	}
 	status = failed ? 1 : 0;
 	if (main_started) {

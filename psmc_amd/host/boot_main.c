@@ -45,16 +45,18 @@ static int bb_reserve(void *self, int dev, int64_t table_bins)
 	return psmc_hip_reserve_batch_tables(((hip_bb *)self)->ctx[dev], table_bins);
 }
 /* the main run that shared device main_dev is over: its compute units (and the entry slots kept free) go back to the batch */
-static void bb_main_done(void *self)
+static void bb_main_done(void *self, int d)
 {
 	hip_bb *h = (hip_bb *)self;
-	for (int d = 0; d < h->n_dev; ++d)
-		if (h->dev_id[d] == h->main_dev) { (void)psmc_hip_set_cu_range(h->ctx[d], 0, 0); (void)psmc_hip_set_option(h->ctx[d], "batch_slots", 0); }
+	if (h->dev_id[d] == h->main_dev) { (void)psmc_hip_set_cu_range(h->ctx[d], 0, 0); (void)psmc_hip_set_option(h->ctx[d], "batch_slots", 0); }
 }
-static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
+/* (fast mode keeps a tile plan per replicate: "batch_first" names the call's first replicate among the context's) */
+static int bb_estep_batch(void *self, int dev, int first, int n_rep, const double *a, const double *e, const double *a0,
                           const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
 {
-	return psmc_hip_estep_batch(((hip_bb *)self)->ctx[dev], n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
+	psmc_hip_ctx *c = ((hip_bb *)self)->ctx[dev];
+	const int rc = psmc_hip_set_option(c, "batch_first", first);
+	return rc ? rc : psmc_hip_estep_batch(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
 }
 static const char *bb_error(void *self, int dev) { return psmc_hip_last_error(((hip_bb *)self)->ctx[dev]); }
 static void bb_destroy(void *self) { hip_bb *h = (hip_bb *)self; for (int d = 0; d < h->n_dev; ++d) psmc_hip_destroy(h->ctx[d]); }

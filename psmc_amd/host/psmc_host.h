@@ -152,14 +152,17 @@ psmc_model *psmc_model_start(const psmc_options *o, const psmc_setup *su, int64_
 /* ---- bootstrap driver (config 4): n_rep replicates of `psmc -b` in one process.  Replicate r draws its trunks and
  * its initial parameters from srand48(seed0 + r) exactly as `PSMC_SEED=<seed0+r> psmc -b ...` does, and writes the
  * same .psmc stream to the file named by out_pattern (one %d = r).  Per EM iteration the E-steps of all replicates
- * go to the device(s) as batches, the M-steps run on host threads. */
+ * go to the device(s) as batches -- two groups per device, one after the other -- and the M-steps of a group run on host
+ * threads while the device works on the other group's E-steps. */
 typedef struct psmc_batch_backend {
 	void *self;
 	int  n_dev; /* replicates are dealt round robin over the devices; one host thread drives each device */
 	int  (*load)(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L);
 	/* n_rep E-steps over the loaded trunks: parameters a n_rep*n*n, e n_rep*2*n (rows hom, het), a0 n_rep*n;
-	 * multisets sel_idx[sel_off[r] .. sel_off[r+1]); outputs A n_rep*n*n or NULL, sums n_rep*5n or NULL, E n_rep*2n, LL */
-	int  (*estep_batch)(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
+	 * multisets sel_idx[sel_off[r] .. sel_off[r+1]); outputs A n_rep*n*n or NULL, sums n_rep*5n or NULL, E n_rep*2n, LL.
+	 * `first`: the call's replicates are positions first .. first + n_rep - 1 of the device's replicates -- the same position means
+	 * the same replicate (same multiset) in every EM iteration, so a backend may keep what it learned per position */
+	int  (*estep_batch)(void *self, int dev, int first, int n_rep, const double *a, const double *e, const double *a0,
 	                    const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL);
 	const char *(*error)(void *self, int dev);
 	void (*destroy)(void *self);
@@ -168,9 +171,9 @@ typedef struct psmc_batch_backend {
 	 * bins the device's replicates need together (the padded lengths of every replicate's UNIQUE trunks): the backend can take
 	 * its table memory now, sized for exactly this job (psmc_hip_reserve_batch_tables) */
 	int  (*reserve)(void *self, int dev, int64_t table_bins);
-	/* optional (may be NULL): the main run that shared the first device (psmc_boot --main) has finished; called once, between two
-	 * EM iterations: the backend can give the batch the whole device back */
-	void (*main_done)(void *self);
+	/* optional (may be NULL): the main run that shared the first device (psmc_boot --main) has finished; called once per device, by
+	 * the thread that drives it, between two of its batches: the backend can give the batch the whole device back */
+	void (*main_done)(void *self, int dev);
 } psmc_batch_backend;
 /* main_run (may be NULL): a psmc_run_begin()'ed run -- the un-resampled main run of README:49-53 on its own input -- whose EM
  * rounds psmc_boot_run drives on a thread of its own beside the replicates (psmc_boot --main) */

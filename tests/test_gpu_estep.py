@@ -833,9 +833,19 @@ def test_fast_batch_keeps_a_plan_per_replicate(hip, golden, oracle, share):
         f = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
         f.load_segments(segs); f.select(sel)
         fresh.append(f)
+    # the same replicates sent in two groups ("batch_first": psmc_boot's E / M pipeline): every replicate meets its own plan again
+    es_g = hip.HipEStep(64, mode=hip.MODE_FAST, share_learn=0, **opts)
+    es_g.load_segments(segs)
     for it in range(3):
         got = es.estep_batch(params, sels, want="both")
         assert es.batch_info()["replicate_contexts"] == 4
+        es_g.set_option("batch_first", 2)
+        g1 = es_g.estep_batch(params[2:], sels[2:], want="both")     # (the second group first: contexts 0, 1 exist, unplanned, until their call)
+        es_g.set_option("batch_first", 0)
+        g0 = es_g.estep_batch(params[:2], sels[:2], want="both")
+        assert es_g.batch_info()["replicate_contexts"] == 4
+        for key in ("A", "sums", "E", "LL"):
+            assert bits_equal(np.concatenate([g0[key], g1[key]]), got[key]), (it, key)
         for r, sel in enumerate(sels):
             a, e, a0 = params[r]
             o = oracle.estep(a, e, a0, [segs[i] for i in sel])
@@ -847,7 +857,7 @@ def test_fast_batch_keeps_a_plan_per_replicate(hip, golden, oracle, share):
             assert bits_equal(got["A"][r], w["A"]) and got["LL"][r] == wf["LL"] and bits_equal(got["sums"][r], wf["sums"])
     for f in fresh:
         f.close()
-    es.close()
+    es.close(); es_g.close()
 
 
 def test_fast_stress_tiny_tiles_recycled_memory(hip, golden, oracle):

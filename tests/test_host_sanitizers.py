@@ -73,10 +73,11 @@ def tsan_reports_between_our_threads(stderr):
 
 @pytest.mark.parametrize("fast_mstep", ["0", "1"])
 def test_boot_driver_asan_and_tsan_clean(tmp_path, fast_mstep):
-    """boot.c: replicates in lock step, M-steps on OpenMP threads, one driver thread per (pretend) device -- under
+    """boot.c: the E / M pipeline -- one driver thread per (pretend) device sending its two groups of replicates in turn (mutex +
+    condition variable), M-steps of a finished group on OpenMP threads -- under
     AddressSanitizer and under ThreadSanitizer.  gcc's libgomp is not TSan-instrumented: the barrier that ends a parallel
     region is invisible to TSan, so accesses on either side of it are reported as races.  Those are filtered; a report whose
-    both sides sit in the SAME parallel region (the E-step loop over devices, the M-step loop over replicates) is a real
+    both sides sit in the SAME parallel region (the M-step loop over a group's replicates) is a real
     race and fails the test."""
     args = ["-N2", "-I", "0.3", os.path.join(CLI, "mid.psmcfa.gz")]
     outs = {}

@@ -57,7 +57,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 /* Options.  None is needed: the defaults are what bench.py and the psmc binary run, and the plan adapts to the input
  * (see "auto").  PSMC_HIP_OPTIONS="key=value,key=value" in the environment sets them for every context of a process.
  * Unknown keys and out-of-range values return PSMC_HIP_EINVAL.  Setting any option drops the per-replicate plans a
- * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_slots" and "exact_refwd" ("batch_first" is accepted and has no effect).
+ * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_tailfill", "batch_slots" and "exact_refwd" ("batch_first" is accepted and has no effect).
  *
  *  key             default  meaning
  *  --- plan of the fast mode (tiles, speculation) ---------------------------------------------------------------
@@ -142,6 +142,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "batch_sort"    1        psmc_hip_estep_batch: the entries -- (replicate, segment) sweeps -- of ALL replicates are dealt to the launches
  *                           longest first, so that the long trunks share one launch and the others end with their own, shorter, longest
  *                           entry; 0 = replicate-major order (every launch then lasts as long as the longest trunk).  Bit-identical.
+ *  "batch_tailfill" 1       psmc_hip_estep_batch with "batch_sort": when memory and entry slots would allow one launch fewer than filling them
+ *                           longest first gives, the shortest entries go into the spare slots of the memory-bound launches (no last launch
+ *                           of a few dozen entries on an empty device); 0 = plain head fill.  Bit-identical.
  *  "batch_slots"   0        psmc_hip_estep_batch without the f table, several launches: entries per launch; 0 = four per compute unit of the
  *                           context's share of the device (the recompute pass holds that many at a time; one more waits for a whole round).
  *                           (psmc_boot --main with PSMC_BOOT_MAIN_CUS=0 uses it; measured slower than compute-unit masks)

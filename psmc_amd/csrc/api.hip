@@ -189,6 +189,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 {
 	if (!c || !key) return PSMC_HIP_EINVAL;
 	std::string k(key);
+	if (k == "batch_first") { if (v < 0 || v > 1e6) return PSMC_HIP_EINVAL; c->batch_first = (int)v; return PSMC_HIP_OK; } // (names a replicate context: they all stay)
 	destroy_kids(c); // replicate contexts of a batch copied the options when they were made: start them afresh
 	if (k == "chunk") { if (v < 0) return PSMC_HIP_EINVAL; c->chunk = (int)v; c->plan_dirty = true; }
 	else if (k == "warmup") { if (v < 0) return PSMC_HIP_EINVAL; c->warmup = (int)v; c->plan_dirty = true; }
@@ -218,7 +219,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; c->reserved_refwd = -1; c->reserved_cap = 0; }
 	else if (k == "batch_sort") { c->batch_sort = v != 0 ? 1 : 0; }
 	else if (k == "batch_slots") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_slots = (int)v; }
-	else if (k == "batch_first") { if (v < 0 || v > 1e6) return PSMC_HIP_EINVAL; c->batch_first = (int)v; }
+	else if (k == "batch_tailfill") c->batch_tailfill = v != 0;
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;

@@ -160,24 +160,66 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	std::vector<int32_t> wseg, wpar; std::vector<int64_t> wtab, wtab_s; std::vector<int> l_first; // l_first: first entry of every launch
 	std::vector<std::vector<int>> ent_of(n_rep); // [replicate][work index] -> entry
 	for (int r = 0; r < n_rep; ++r) ent_of[r].assign(reps[r].work.size(), -1);
+	// Blocks -> launches.  Greedy from the head of the list (longest first) until the table memory (cap) or the entry slots (ent_cap) are
+	// used up.  That leaves launches that are full of bins with entry slots to spare (the long trunks), launches that are out of slots
+	// with memory to spare (the short ones) -- and a last launch of a few dozen short entries that lasts as long as ITS longest sweep with
+	// the device empty (40 entries: 0.36 s of a 6.75 s iteration, profiles/r05_boot_schedule.txt).  When the totals fit one launch
+	// fewer, the head fill stops a little below cap and the shortest blocks of the list go into the spare slots instead.
+	std::vector<std::vector<int>> lblocks;
+	{
+		std::vector<int64_t> lbins;
+		size_t next = 0;
+		auto head_fill = [&](int64_t cap_head, size_t max_launches) {
+			lblocks.clear(); lbins.clear(); next = 0;
+			while (next < blocks.size() && lblocks.size() < max_launches) {
+				lblocks.emplace_back(); lbins.push_back(0);
+				while (next < blocks.size()) {
+					const Block &b = blocks[next];
+					if (!lblocks.back().empty() && (lbins.back() + b.bins > cap_head || (lblocks.back().size() + 1) * (size_t)align > ent_cap)) break;
+					lblocks.back().push_back((int)next); lbins.back() += b.bins; ++next;
+				}
+			}
+		};
+		head_fill(cap, SIZE_MAX);
+		int64_t tot_bins = 0;
+		for (const Block &b : blocks) tot_bins += b.bins;
+		const size_t by_bins = (size_t)((tot_bins + cap - 1) / cap), by_slots = ent_cap == SIZE_MAX ? 1 : (blocks.size() * (size_t)align + ent_cap - 1) / ent_cap;
+		const size_t fewest = std::max<size_t>(1, std::max(by_bins, by_slots));
+		if (c->batch_sort && c->batch_tailfill && lblocks.size() > fewest) {
+			const std::vector<std::vector<int>> greedy = lblocks;
+			bool done = false;
+			for (double keep : {0.0025, 0.005, 0.01, 0.02, 0.04, 0.08}) {
+				head_fill(cap - (int64_t)(keep * (double)cap), fewest);
+				bool ok = true;
+				for (size_t t = next; t < blocks.size() && ok; ++t) { // the rest, longest first, each into the LAST launch with room (its entries are the most like it)
+					ok = false;
+					for (size_t k = lblocks.size(); k-- > 0 && !ok;)
+						if ((lblocks[k].size() + 1) * (size_t)align <= ent_cap && lbins[k] + blocks[t].bins <= cap) { lblocks[k].push_back((int)t); lbins[k] += blocks[t].bins; ok = true; }
+				}
+				if (ok) { done = true; break; }
+			}
+			if (!done) lblocks = greedy;
+		}
+	}
 	int64_t worst = 0; size_t worst_entries = 0;
 	{
-		int64_t s_run = 0, run = 0; size_t e0 = 0;
-		l_first.push_back(0);
-		for (const Block &b : blocks) {
-			if (wseg.size() > e0 && (run + b.bins > cap || (wseg.size() - e0) + (size_t)align > ent_cap)) { // next launch
-				worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
-				s_run += run; run = 0; e0 = wseg.size(); l_first.push_back((int)e0);
+		int64_t s_run = 0;
+		for (const std::vector<int> &lb : lblocks) {
+			int64_t run = 0; const size_t e0 = wseg.size();
+			l_first.push_back((int)e0);
+			for (int bi : lb) {
+				const Block &b = blocks[bi];
+				for (int i = 0; i < align; ++i) {
+					if (i < b.n) {
+						const int32_t wi = ord[b.rep][b.first + i], sg = reps[b.rep].work[wi];
+						ent_of[b.rep][wi] = (int)wseg.size();
+						wseg.push_back(sg); wpar.push_back(b.rep); wtab.push_back(run); wtab_s.push_back(s_run + run); run += padded_len(sg);
+					} else { wseg.push_back(-1); wpar.push_back(b.rep); wtab.push_back(0); wtab_s.push_back(0); }
+				}
 			}
-			for (int i = 0; i < align; ++i) {
-				if (i < b.n) {
-					const int32_t wi = ord[b.rep][b.first + i], sg = reps[b.rep].work[wi];
-					ent_of[b.rep][wi] = (int)wseg.size();
-					wseg.push_back(sg); wpar.push_back(b.rep); wtab.push_back(run); wtab_s.push_back(s_run + run); run += padded_len(sg);
-				} else { wseg.push_back(-1); wpar.push_back(b.rep); wtab.push_back(0); wtab_s.push_back(0); }
-			}
+			worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
+			s_run += run;
 		}
-		worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
 		l_first.push_back((int)wseg.size());
 	}
 	const int n_launches = (int)l_first.size() - 1, n_all = (int)wseg.size();

@@ -8,7 +8,8 @@
  * writes what  for r in 0..99: PSMC_SEED=$((1+r)) psmc -N25 -t15 -r5 -b -p ... -o round-$r.psmc split.psmcfa  would
  * (-b is implied).  PSMC_HIP_MODE=exact|fast and PSMC_FAST_MSTEP as for psmc; PSMC_HIP_DEVICES=0,1,.. (a device may be
  * listed twice = two contexts on it; default: all visible devices, twice each in fast mode); OMP_NUM_THREADS bounds
- * the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr.
+ * the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr; PSMC_BOOT_GROUPS: groups of replicates per context whose
+ * M-steps run under the next group's E-steps (default 2 in fast mode, 1 in exact mode).
  *
  * --main / --main-input: the whole workflow of the reference's README:49-62 as ONE job -- the un-resampled main run
  * (`psmc <psmc options> -o out.psmc in.psmcfa`, on the unsplit input) runs on a thread of its own BESIDE the replicates, on the
@@ -115,6 +116,12 @@ int main(int argc, char *argv[])
 	const int mode = (mode_s && strcmp(mode_s, "fast") == 0) ? PSMC_HIP_MODE_FAST : PSMC_HIP_MODE_EXACT;
 	o.fast_mstep = fm ? atoi(fm) != 0 : (mode == PSMC_HIP_MODE_FAST);
 	om.fast_mstep = o.fast_mstep;
+	/* The E / M pipeline of boot.c (PSMC_BOOT_GROUPS groups of replicates per context, the M-steps of one under the E-steps of the next): two
+	 * groups in fast mode, where a batch runs its replicates one after the other anyway.  Exact mode keeps ONE batch per iteration: its launches
+	 * are sized by the device's memory and entry slots, and two half batches need one launch more than a whole one whenever the main run
+	 * holds part of the device -- more than the 0.6 s of M-steps they would hide (100 replicates, no main run: 6.61 s per iteration with two
+	 * groups against 6.81 with one; profiles/r05_groups_ab.json). */
+	if (!getenv("PSMC_BOOT_GROUPS")) setenv("PSMC_BOOT_GROUPS", mode == PSMC_HIP_MODE_FAST ? "2" : "1", 1);
 	hip_bb h;
 	memset(&h, 0, sizeof h);
 	h.n_states = n_states;

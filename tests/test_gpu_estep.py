@@ -720,6 +720,33 @@ def test_exact_batch_entry_schedule(hip, golden, sort):
         es.close()
 
 
+def test_exact_batch_tail_fill(hip, golden):
+    """"batch_tailfill": filling the launches longest first leaves the launches of long entries with entry slots to spare and a last
+    launch of a few short entries; when memory and slots allow fewer launches, the shortest entries go into the spare slots.  The
+    same twelve replicates, 100 k table bins and 32 entry slots per launch: 6 launches become 3, the statistics keep their bits."""
+    segs = golden.segs_small + golden.segs_mid[2:]
+    rng = np.random.default_rng(14)
+    params = _traj_params(6) * 2
+    sels = [rng.integers(0, len(segs), size=rng.integers(1, len(segs))).tolist() for _ in range(12)]
+    got = {}
+    for fill in (0, 1):
+        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=100000, batch_slots=32, exact_refwd=2, batch_tailfill=fill)
+        es.load_segments(segs)
+        got[fill] = es.estep_batch(params, sels)
+        got[fill]["groups"] = es.batch_info()["groups"]
+        es.close()
+    assert got[0]["groups"] == 6 and got[1]["groups"] == 3, (got[0]["groups"], got[1]["groups"])
+    for key in ("A", "E", "LL"):
+        assert bits_equal(got[0][key], got[1][key]), key
+    ref = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    ref.load_segments(segs)
+    for r in (0, 5, 11):
+        ref.select(sels[r])
+        w = ref.estep(*params[r])
+        assert bits_equal(got[1]["A"][r], w["A"]) and bits_equal(got[1]["E"][r], w["E"]) and got[1]["LL"][r] == w["LL"], r
+    ref.close()
+
+
 def test_exact_batch_reserve_then_smaller_batch_then_single_estep(hip, golden):
     """psmc_hip_reserve_batch_tables decides about the f table from the caller's upper bound, the batch that
     follows used to decide again from its own count of unique bins -- two answers, an f table allocated at the b-only capacity.

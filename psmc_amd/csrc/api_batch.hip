@@ -88,6 +88,8 @@ extern "C" int psmc_hip_reserve_batch_tables(psmc_hip_ctx *c, int64_t max_bins)
 	int rc = batch_refwd(c, max_bins, &refwd);
 	if (rc || (rc = batch_capacity(c, &cap, refwd, max_bins))) return rc;
 	rc = ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !refwd);
+	// (several launches without the f table: the call-wide scale factors -- 15 GB for 100 replicates of a genome -- now as well, not inside the first EM iteration)
+	if (rc == 0 && refwd && max_bins > cap && c->s_all_cap < (size_t)max_bins + 128 && (rc = dev_alloc(c, &c->d_s_all, (size_t)max_bins + 128)) == 0) c->s_all_cap = (size_t)max_bins + 128;
 	if (rc == 0) {
 		if (c->exact_refwd < 0) c->reserved_refwd = refwd ? 1 : 0; // (a fixed "exact_refwd" needs no memory)
 		c->reserved_cap = cap; // the batches that follow plan their launches for THIS capacity: a second estimate from a different bound

@@ -105,6 +105,13 @@ def cpu_baseline(a, e, a0, segs, sample_bins):
         pass
     out = {"value": tot / dt, "unit": "bins/s", "cores": 1, "kind": kind, "host_cpu": model, "host_cores": os.cpu_count(),
            "sample": "%d bins in %d trunks of <=500k, n=64, single thread, %.1f s" % (tot, len(sample), dt)}
+    if kind == "reference":   # which build of the reference this is: the GPU box cannot rebuild it
+        import hashlib
+        try:
+            out["artefact"] = {"file": "oracle/_ref/libpsmc_ref.so", "sha256_16": hashlib.sha256(open(orc.REF_SO, "rb").read()).hexdigest()[:16],
+                               "built_by": "`make -C oracle ref`: gcc -g -Wall -O2 (the reference's own flags) on its unmodified khmm.c kmin.c cli.c core.c em.c aux.c + oracle/ref_shim.c, in the build container; git-ignored, travels with the snapshot"}
+        except OSError:
+            pass
     try:
         out["multi"] = cpu_baseline_multi(a, e, a0, segs, kind, tot / dt)
     except Exception as ex_:

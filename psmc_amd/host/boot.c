@@ -55,10 +55,13 @@ typedef struct { pipeline *P; int dev; pthread_t tid; } dev_job;
 
 static void pipe_fail(pipeline *P) { pthread_mutex_lock(&P->mu); P->failed = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); }
 static int pipe_failed(pipeline *P) { pthread_mutex_lock(&P->mu); const int f = P->failed; pthread_mutex_unlock(&P->mu); return f; }
-/* device d drives replicates d, d + n_dev, ...: positions [lo, hi) of that list are its group g */
-static void group_range(const pipeline *P, int d, int g, int *lo, int *hi)
+/* device d drives replicates d, d + n_dev, ...: positions [lo, hi) of that list are its group g.  In the FIRST EM iteration group 0 is
+ * the whole list and the others are empty: the backend's first batch call sees every replicate of the device, so what it derives
+ * from that call (fast mode: ONE tile length for all replicates, from the largest) does not depend on the grouping */
+static void group_range(const pipeline *P, int d, int g, int it, int *lo, int *hi)
 {
 	const int cnt = P->n_rep > d ? (P->n_rep - d + P->bb->n_dev - 1) / P->bb->n_dev : 0;
+	if (it == 0) { *lo = 0; *hi = g == 0 ? cnt : 0; return; }
 	*lo = (int)((int64_t)cnt * g / P->n_grp); *hi = (int)((int64_t)cnt * (g + 1) / P->n_grp);
 }
 
@@ -117,7 +120,7 @@ static void *dev_thread(void *arg)
 				main_released = 1;
 				if (P->timing) fprintf(stderr, "[psmc_boot] main run finished before iteration %d, group %d of device %d: its batches have the whole device again\n", it + 1, g, d);
 			}
-			group_range(P, d, g, &lo, &hi);
+			group_range(P, d, g, it, &lo, &hi);
 			const double t0 = now_ms();
 			if (hi > lo && estep_group(P, d, lo, hi)) { pipe_fail(P); return 0; }
 			pthread_mutex_lock(&P->mu);
@@ -221,7 +224,7 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 	}
 	{ /* main.c:16-20 for every replicate.  Each device's replicates form n_grp groups; a device thread sends group after group to
 	   * the device, and the M-steps of a group (host threads, here) run while the device is busy with the NEXT group's E-steps:
-	   * E(g0,1) | E(g1,1) + M(g0,1) | E(g0,2) + M(g1,1) | ...  A replicate still sees E, M, E, M, ... in order: same output. */
+	   * E(all,1) | M(all,1) | E(g0,2) | E(g1,2) + M(g0,2) | E(g0,3) + M(g1,2) | ...  A replicate still sees E, M, E, M, ... in order: same output. */
 		pipeline P;
 		const char *gs = getenv("PSMC_BOOT_GROUPS");
 		memset(&P, 0, sizeof P);
@@ -254,7 +257,7 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 				pthread_mutex_unlock(&P.mu);
 				if (!ok) break;
 				for (int d = 0; d < bb->n_dev; ++d) {
-					int lo, hi; group_range(&P, d, g, &lo, &hi);
+					int lo, hi; group_range(&P, d, g, it, &lo, &hi);
 					for (int j = lo; j < hi; ++j) list[n_list++] = d + j * bb->n_dev;
 				}
 				const double t1 = now_ms();

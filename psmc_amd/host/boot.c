@@ -10,12 +10,45 @@
  * (tests/test_host_cli.py).  Replicates are independent whole EM runs: no collective; with several devices they are
  * dealt round robin, one host thread driving each device.
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include "psmc_host.h"
+
+/* The processors this process may really use: its affinity mask, capped by the CPU quota of its control group (v2 cpu.max, v1
+ * cpu.cfs_quota_us).  A container on a 256-thread host with a quota of 16 shows 256 processors to OpenMP: 256 M-step threads spend
+ * the quota of a 100 ms scheduler period in its first milliseconds, and the kernel then stops EVERY thread of the group -- the ones
+ * that feed the device included -- until the period ends (measured: iterations quantised to multiples of 100 ms). */
+int psmc_usable_cpus(void)
+{
+	int n = 0;
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+	if (n < 1) n = 1;
+	double quota = -1.0, period = 0.0;
+	FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (fp) {
+		char q[64];
+		if (fscanf(fp, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+		fclose(fp);
+	} else {
+		FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fr = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+		if (fq && fr && fscanf(fq, "%lf", &quota) == 1 && fscanf(fr, "%lf", &period) == 1) { /* (-1: no quota) */ }
+		else quota = -1.0;
+		if (fq) fclose(fq);
+		if (fr) fclose(fr);
+	}
+	if (quota > 0.0 && period > 0.0) {
+		const int c = (int)(quota / period + 0.5);
+		if (c >= 1 && c < n) n = c;
+	}
+	return n;
+}
 
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
@@ -245,6 +278,12 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 			else { fprintf(stderr, "psmc_boot: cannot start the thread of device %d\n", d); pipe_fail(&P); }
 		}
 		int *list = (int *)malloc(sizeof(int) * (size_t)n_rep);
+		/* M-step threads: what the process may use, less the threads that drive the devices (they spin inside the HIP runtime while a batch
+		 * runs) and the main run's; OMP_NUM_THREADS, when set, is taken as given */
+		int m_threads = psmc_usable_cpus() - bb->n_dev - (main_started ? 1 : 0);
+		if (m_threads < 1) m_threads = 1;
+		if (getenv("OMP_NUM_THREADS") && atoi(getenv("OMP_NUM_THREADS")) > 0) m_threads = atoi(getenv("OMP_NUM_THREADS"));
+		if (timing) fprintf(stderr, "[psmc_boot] %d usable processors, %d M-step threads, %d device thread(s)%s\n", psmc_usable_cpus(), m_threads, bb->n_dev, main_started ? ", 1 main-run thread" : "");
 		double t_prev = now_ms();
 		for (int it = 0; it != o->n_iters && !pipe_failed(&P); ++it) {
 			double m_ms = 0.0;
@@ -262,7 +301,7 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 				}
 				const double t1 = now_ms();
 				/* M-steps: independent models, one host thread each (em.c:56-74), then the round's output */
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(m_threads)
 				for (int q = 0; q < n_list; ++q) {
 					replicate *R = &rep[list[q]];
 					psmc_em_mstep(R->m, R->A, R->E, R->sums, R->LL, R->out);

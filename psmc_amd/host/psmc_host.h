@@ -179,6 +179,7 @@ typedef struct psmc_batch_backend {
  * rounds psmc_boot_run drives on a thread of its own beside the replicates (psmc_boot --main) */
 int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_pattern, psmc_batch_backend *bb, psmc_run_state *main_run);
 void psmc_print_round(const psmc_model *m, int64_t sum_called, FILE *out); /* psmc_print_data, aux.c:49-82 */
+int  psmc_usable_cpus(void); /* affinity mask capped by the control group's CPU quota (boot.c) */
 
 /* synthetic data for benchmarks: hmm_simulate-like draw (khmm.c:386-423) with our own RNG */
 void psmc_simulate_segment(int n, const double *a, const double *e, const double *a0, int32_t L, uint64_t seed,

@@ -7,7 +7,7 @@
  * e.g.  psmc_boot -R 100 -S 1 -O round-%d.psmc -- -N25 -t15 -r5 -p "4+25*2+4+6" split.psmcfa
  * writes what  for r in 0..99: PSMC_SEED=$((1+r)) psmc -N25 -t15 -r5 -b -p ... -o round-$r.psmc split.psmcfa  would
  * (-b is implied).  PSMC_HIP_MODE=exact|fast and PSMC_FAST_MSTEP as for psmc; PSMC_HIP_DEVICES=0,1,.. (a device may be
- * listed twice = two contexts on it; default: all visible devices, twice each in fast mode); OMP_NUM_THREADS bounds
+ * listed several times = as many contexts on it; default: all visible devices, three times each in fast mode); OMP_NUM_THREADS bounds
  * the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr; PSMC_BOOT_GROUPS: groups of replicates per context whose
  * M-steps run under the next group's E-steps (default 2 in fast mode, 1 in exact mode).
  *
@@ -131,11 +131,12 @@ int main(int argc, char *argv[])
 		for (char *t = strtok(dup, ","); t && n_list < MAX_DEV; t = strtok(0, ",")) list[n_list++] = atoi(t);
 		free(dup);
 	} else {
-		/* all visible devices.  Fast mode: TWO contexts per device, each with its own tables and driver thread -- a fast
-		 * E-step is a chain of short launches with host decisions in between, and the second thread's replicate fills the
-		 * gaps of the first (100 replicates of a 30 M-bin genome: 1.05 s per EM iteration instead of 1.3).  Exact mode
-		 * packs the device with one batch already, and wants all of the memory for its tables. */
-		const int nd = psmc_hip_device_count(), per = mode == PSMC_HIP_MODE_FAST ? 2 : 1;
+		/* all visible devices.  Fast mode: THREE contexts per device, each with its own tables and driver thread -- a fast
+		 * E-step is a chain of short launches with host decisions in between, and the other threads' replicates fill the
+		 * gaps of the first (100 replicates of a 30 M-bin genome, per EM iteration: one context 1.19 s, two 0.69, three 0.585,
+		 * four 0.72, six 0.66: profiles/r05_fast_contexts.txt).  Exact mode packs the device with one batch already, and
+		 * wants all of the memory for its tables. */
+		const int nd = psmc_hip_device_count(), per = mode == PSMC_HIP_MODE_FAST ? 3 : 1;
 		for (int d = 0; d < nd && n_list + per <= MAX_DEV; ++d)
 			for (int k = 0; k < per; ++k) list[n_list++] = d;
 	}

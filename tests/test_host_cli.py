@@ -175,6 +175,25 @@ class Pattern(C.Structure):
     _fields_ = [("n_states", C.c_int), ("n_free", C.c_int), ("group", C.POINTER(C.c_int))]
 
 
+def test_usable_cpus_follow_the_cgroup_quota(host):
+    """psmc_usable_cpus (boot.c): the affinity mask capped by the control group's CPU quota -- what sizes psmc_boot's M-step team
+    (256 OpenMP threads on a quota of 16 froze the whole process for the rest of every scheduler period).  Same rule as bench.py's
+    usable_cores(), which sizes the multi-process CPU baseline."""
+    host.psmc_usable_cpus.restype = C.c_int
+    n = host.psmc_usable_cpus()
+    want = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        if os.path.exists(path):
+            q, per = open(path).read().split()
+            if q != "max":
+                want = min(want, max(1, int(float(q) / float(per) + 0.5)))
+    if not os.path.exists("/sys/fs/cgroup/cpu.max") and os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        q, per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            want = min(want, max(1, int(q / per + 0.5)))
+    assert n == want and n >= 1
+
+
 def test_pattern_kats(host, golden):
     """psmc_parse_pattern KATs (cli.c:66-99): '4+5*3+4' -> n=22, 7 free; '4+25*2+4+6' -> 63, 28; '64*2' -> 127, 64."""
     for key, v in golden.kats.items():

@@ -57,7 +57,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 /* Options.  None is needed: the defaults are what bench.py and the psmc binary run, and the plan adapts to the input
  * (see "auto").  PSMC_HIP_OPTIONS="key=value,key=value" in the environment sets them for every context of a process.
  * Unknown keys and out-of-range values return PSMC_HIP_EINVAL.  Setting any option drops the per-replicate plans a
- * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_tailfill", "batch_slots" and "exact_refwd" ("batch_first" is accepted and has no effect).
+ * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_tailfill", "batch_major", "batch_slots" and "exact_refwd" ("batch_first" is accepted and has no effect).
  *
  *  key             default  meaning
  *  --- plan of the fast mode (tiles, speculation) ---------------------------------------------------------------
@@ -145,6 +145,10 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "batch_tailfill" 1       psmc_hip_estep_batch with "batch_sort": when memory and entry slots would allow one launch fewer than filling them
  *                           longest first gives, the shortest entries go into the spare slots of the memory-bound launches (no last launch
  *                           of a few dozen entries on an empty device); 0 = plain head fill.  Bit-identical.
+ *  "batch_major"   1        psmc_hip_estep_batch_cb with "batch_sort", several launches: when half of the entry blocks or more share their longest
+ *                           length (utils/splitfa.c cuts the trunks to one length), the blocks no longer than that keep the caller's replicate
+ *                           order -- longer ones still first, by length -- so that replicates complete launch by launch and `done` can hand
+ *                           them to the caller's M-steps while the later launches run.  Not when the tail fill saves a launch.  Bit-identical.
  *  "batch_slots"   0        psmc_hip_estep_batch without the f table, several launches: entries per launch; 0 = four per compute unit of the
  *                           context's share of the device (the recompute pass holds that many at a time; one more waits for a whole round).
  *                           (psmc_boot --main with PSMC_BOOT_MAIN_CUS=0 uses it; measured slower than compute-unit masks)
@@ -216,6 +220,15 @@ int psmc_hip_reserve_tables(psmc_hip_ctx *ctx);
 int psmc_hip_reserve_batch_tables(psmc_hip_ctx *ctx, int64_t max_bins);
 int psmc_hip_estep_batch(psmc_hip_ctx *ctx, int n_rep, const double *a, const double *e, const double *a0,
                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL);
+/* The same with a progress callback: `done(user, n, replicates)` is called on the calling thread, between two launches (exact mode)
+ * or after each replicate's E-step (fast mode), with the replicates -- positions in this call -- whose rows of A / sums / E / LL are
+ * final from now on; every replicate is named exactly once, the last ones before the call returns.  What em.c:56-68 does next, the
+ * M-step, needs nothing else: a caller can run the finished replicates' M-steps on its own threads while the device works on the
+ * rest of the batch (psmc_boot does).  The callback must not call into this context.  done = NULL: psmc_hip_estep_batch. */
+typedef void (*psmc_hip_batch_done_fn)(void *user, int n_done, const int32_t *replicates);
+int psmc_hip_estep_batch_cb(psmc_hip_ctx *ctx, int n_rep, const double *a, const double *e, const double *a0,
+                            const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL,
+                            psmc_hip_batch_done_fn done, void *user);
 /* Diagnostic: out = {launch groups of the last exact batch (fast: replicates run), replicate contexts alive}. */
 int psmc_hip_batch_info(psmc_hip_ctx *ctx, int out[2]);
 

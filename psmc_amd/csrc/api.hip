@@ -220,6 +220,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "batch_sort") { c->batch_sort = v != 0 ? 1 : 0; }
 	else if (k == "batch_slots") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_slots = (int)v; }
 	else if (k == "batch_tailfill") c->batch_tailfill = v != 0;
+	else if (k == "batch_major") c->batch_major = v != 0;
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;

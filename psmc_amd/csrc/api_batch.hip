@@ -112,7 +112,7 @@ namespace {
 struct Block { int rep; int first, n; int64_t bins; int32_t maxL; }; // entries ord[rep][first .. first + n) of a replicate
 }
 static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0, const int32_t *sel_off,
-                       const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+                       const int32_t *sel_idx, double *A, double *sums, double *E, double *LL, psmc_hip_batch_done_fn done, void *user)
 {
 	const int n = c->n;
 	const size_t S = (size_t)c->ns, PL = c->par_len;
@@ -156,6 +156,7 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 			blocks.push_back(b);
 		}
 	}
+	const std::vector<Block> blocks_made = blocks; // replicate-major, longest first inside a replicate
 	if (c->batch_sort) std::stable_sort(blocks.begin(), blocks.end(), [](const Block &x, const Block &y) { return x.maxL > y.maxL; });
 	// The work list of the whole call in launch order, every block padded to `align` entries: entry -> segment, replicate (= its
 	// parameter block), offset of its tables inside ITS launch, offset of its scale factors in the call-wide s table.
@@ -187,9 +188,9 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		for (const Block &b : blocks) tot_bins += b.bins;
 		const size_t by_bins = (size_t)((tot_bins + cap - 1) / cap), by_slots = ent_cap == SIZE_MAX ? 1 : (blocks.size() * (size_t)align + ent_cap - 1) / ent_cap;
 		const size_t fewest = std::max<size_t>(1, std::max(by_bins, by_slots));
+		bool tail_filled = false;
 		if (c->batch_sort && c->batch_tailfill && lblocks.size() > fewest) {
 			const std::vector<std::vector<int>> greedy = lblocks;
-			bool done = false;
 			for (double keep : {0.0025, 0.005, 0.01, 0.02, 0.04, 0.08}) {
 				head_fill(cap - (int64_t)(keep * (double)cap), fewest);
 				bool ok = true;
@@ -198,9 +199,29 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 					for (size_t k = lblocks.size(); k-- > 0 && !ok;)
 						if ((lblocks[k].size() + 1) * (size_t)align <= ent_cap && lbins[k] + blocks[t].bins <= cap) { lblocks[k].push_back((int)t); lbins[k] += blocks[t].bins; ok = true; }
 				}
-				if (ok) { done = true; break; }
+				if (ok) { tail_filled = true; break; }
 			}
-			if (!done) lblocks = greedy;
+			if (!tail_filled) lblocks = greedy;
+		}
+		// Replicates that complete launch by launch ("batch_major").  With every block in order of length, each replicate's short trunks sit in
+		// the last launch and no replicate is complete before it.  But utils/splitfa.c cuts the trunks to ONE length (500 k bins; only the
+		// chromosomes' tails differ): when half of the blocks or more share their longest length Lc, a launch of blocks <= Lc lasts as long as
+		// an Lc sweep whatever else is in it -- so those blocks keep the callers' replicate order (the longer ones still go first, by length),
+		// a replicate is complete a launch or two after its first block, and the caller's M-steps (`done`) run under the launches that follow.
+		// Not when the tail fill saved a launch (worth as much), nor when this order would need a launch more.
+		if (c->batch_sort && c->batch_major && done && !tail_filled && lblocks.size() > 1) {
+			std::vector<int32_t> ls;
+			for (const Block &b : blocks) ls.push_back(b.maxL);
+			std::sort(ls.begin(), ls.end());
+			int32_t Lc = 0; size_t best = 0;
+			for (size_t i = 0; i < ls.size();) { size_t j = i; while (j < ls.size() && ls[j] == ls[i]) ++j; if (j - i > best) { best = j - i; Lc = ls[i]; } i = j; }
+			if (best * 2 >= blocks.size()) {
+				const std::vector<Block> sorted = blocks; const std::vector<std::vector<int>> by_len = lblocks;
+				blocks = blocks_made;
+				std::stable_sort(blocks.begin(), blocks.end(), [Lc](const Block &x, const Block &y) { return std::max(x.maxL, Lc) > std::max(y.maxL, Lc); });
+				head_fill(cap, SIZE_MAX);
+				if (lblocks.size() > by_len.size()) { blocks = sorted; lblocks = by_len; }
+			}
 		}
 	}
 	int64_t worst = 0; size_t worst_entries = 0;
@@ -275,6 +296,43 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	// per-entry results of the whole call on the host (34 KB each): a replicate's entries may sit in different launches
 	c->h_segA.resize((size_t)n_all * S * S); c->h_segE.resize((size_t)n_all * 3 * S);
 	std::vector<double> lk_all((size_t)n_all, 0.0);
+	// the launch after which a replicate's statistics are complete
+	std::vector<int> last_launch(n_rep, 0);
+	{
+		std::vector<int> launch_of((size_t)n_all, 0);
+		for (int g = 0; g < n_launches; ++g) for (int i = l_first[g]; i < l_first[g + 1]; ++i) launch_of[i] = g;
+		for (int r = 0; r < n_rep; ++r) for (int w : ent_of[r]) if (w >= 0) last_launch[r] = std::max(last_launch[r], launch_of[w]);
+	}
+	// hmm_add_expect in selection order per replicate (khmm.c:346-359), he_sum starting from zeros; LL += hmm_lk (em.c:48)
+	std::vector<double> sA((size_t)n * n), sE((size_t)2 * n);
+	double t_sums = 0.0;
+	auto finalize = [&](int r) {
+		const RepSel &R = reps[r];
+		std::fill(sA.begin(), sA.end(), 0.0); std::fill(sE.begin(), sE.end(), 0.0);
+		double ll = 0.0;
+		for (size_t i = 0; i < R.sel2work.size(); ++i) {
+			const int w = ent_of[r][R.sel2work[i]];
+			const double *hA = &c->h_segA[(size_t)w * S * S], *hE = &c->h_segE[(size_t)w * 3 * S];
+			ll += lk_all[(size_t)w];
+			for (int k = 0; k < n; ++k)
+				for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * S + l];
+			for (int b = 0; b < 2; ++b)
+				for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * S + l];
+		}
+		if (A) memcpy(A + (size_t)r * n * n, sA.data(), sizeof(double) * n * n);
+		if (E) memcpy(E + (size_t)r * 2 * n, sE.data(), sizeof(double) * 2 * n);
+		if (LL) LL[r] = ll;
+		if (sums) { // SL | SU | DG | CL | CU of the summed matrix, for callers with the O(N) objective
+			double *q = sums + (size_t)r * 5 * n;
+			memset(q, 0, sizeof(double) * 5 * n);
+			for (int k = 0; k < n; ++k)
+				for (int l = 0; l < n; ++l) {
+					const double v = sA[(size_t)k * n + l];
+					if (l < k) { q[k] += v; q[3 * n + l] += v; } else if (l > k) { q[n + k] += v; q[4 * n + l] += v; } else q[2 * n + k] = v;
+				}
+		}
+	};
+	std::vector<int32_t> finished;
 	for (int g = 0; g < n_launches; ++g) {
 		const double t_a = now();
 		const int e0 = l_first[g], nw = l_first[g + 1] - e0;
@@ -330,37 +388,18 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		                   g, nw, (int)longest, run / 1e6, t_b - t_a, t_c - t_b, c->last_ms[1], c->last_ms[2], c->last_ms[3],
 		                   fwd_all ? (g == 0 ? (std::string("; forward pass of all entries ") + std::to_string(fwd_all_s) + " s").c_str() : "; fwd: see launch 0") : "", t_d - t_c, now() - t_d);
 		++c->last_batch_groups;
+		// the replicates this launch completed: their sums now, and the caller hears of them before the next launch starts
+		const double t_f = now();
+		finished.clear();
+		for (int r = 0; r < n_rep; ++r) if (last_launch[r] == g) { finalize(r); finished.push_back(r); }
+		t_sums += now() - t_f;
+		if (done && !finished.empty()) done(user, (int)finished.size(), finished.data());
 	}
-	// hmm_add_expect in selection order per replicate (khmm.c:346-359), he_sum starting from zeros; LL += hmm_lk (em.c:48)
-	const double t_s = now();
-	std::vector<double> sA((size_t)n * n), sE((size_t)2 * n);
-	for (int r = 0; r < n_rep; ++r) {
-		const RepSel &R = reps[r];
-		std::fill(sA.begin(), sA.end(), 0.0); std::fill(sE.begin(), sE.end(), 0.0);
-		double ll = 0.0;
-		for (size_t i = 0; i < R.sel2work.size(); ++i) {
-			const int w = ent_of[r][R.sel2work[i]];
-			const double *hA = &c->h_segA[(size_t)w * S * S], *hE = &c->h_segE[(size_t)w * 3 * S];
-			ll += lk_all[(size_t)w];
-			for (int k = 0; k < n; ++k)
-				for (int l = 0; l < n; ++l) sA[(size_t)k * n + l] += hA[k * S + l];
-			for (int b = 0; b < 2; ++b)
-				for (int l = 0; l < n; ++l) sE[(size_t)b * n + l] += hE[b * S + l];
-		}
-		if (A) memcpy(A + (size_t)r * n * n, sA.data(), sizeof(double) * n * n);
-		if (E) memcpy(E + (size_t)r * 2 * n, sE.data(), sizeof(double) * 2 * n);
-		if (LL) LL[r] = ll;
-		if (sums) { // SL | SU | DG | CL | CU of the summed matrix, for callers with the O(N) objective
-			double *q = sums + (size_t)r * 5 * n;
-			memset(q, 0, sizeof(double) * 5 * n);
-			for (int k = 0; k < n; ++k)
-				for (int l = 0; l < n; ++l) {
-					const double v = sA[(size_t)k * n + l];
-					if (l < k) { q[k] += v; q[3 * n + l] += v; } else if (l > k) { q[n + k] += v; q[4 * n + l] += v; } else q[2 * n + k] = v;
-				}
-		}
+	if (dbg_t) {
+		std::string per;
+		for (int g = 0; g < n_launches; ++g) per += (g ? " " : "") + std::to_string(std::count(last_launch.begin(), last_launch.end(), g));
+		fprintf(stderr, "[psmc_hip] batch: %d replicates, %d entries in %d launches (replicates complete after launch 0..: %s), host sums %.3f s\n", n_rep, n_all, n_launches, per.c_str(), t_sums);
 	}
-	if (dbg_t) fprintf(stderr, "[psmc_hip] batch: %d replicates, %d entries in %d launches, host sums %.3f s\n", n_rep, n_all, n_launches, now() - t_s);
 	return PSMC_HIP_OK;
 }
 
@@ -394,7 +433,7 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 }
 
 static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0, const int32_t *sel_off,
-                      const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+                      const int32_t *sel_idx, double *A, double *sums, double *E, double *LL, psmc_hip_batch_done_fn done, void *user)
 {
 	const int n = c->n;
 	if (c->share_T == 0 && c->share_learn) {
@@ -445,6 +484,7 @@ static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double 
 		}
 		t_est += dbg_now() - t_e;
 		if (rc) { c->err = "replicate " + std::to_string(r) + ": " + k->err; return rc; }
+		if (done) { const int32_t rr = r; done(user, 1, &rr); } // its statistics are final: the caller's M-step can run under the next replicate's E-step
 	}
 	if (dbg_t) {
 		const double *q = c->dbg_acc;
@@ -460,12 +500,19 @@ static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double 
 extern "C" int psmc_hip_estep_batch(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0,
                                     const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
 {
+	return psmc_hip_estep_batch_cb(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL, nullptr, nullptr);
+}
+
+extern "C" int psmc_hip_estep_batch_cb(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0,
+                                       const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL,
+                                       psmc_hip_batch_done_fn done, void *user)
+{
 	if (!c || n_rep < 1 || !a || !e || !a0 || !sel_off || !sel_idx || (!A && !sums)) return fail(c, PSMC_HIP_EINVAL, "estep_batch: bad argument");
 	if (c->parent) return fail(c, PSMC_HIP_EINVAL, "estep_batch: not on a replicate context");
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep_batch: no segments loaded");
 	HIPCHK(c, hipSetDevice(c->device));
-	if (c->mode == PSMC_HIP_MODE_EXACT || c->ns > 128) return batch_exact(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL); // (beyond 128 states: the wide exact kernels whatever the mode)
-	return batch_fast(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
+	if (c->mode == PSMC_HIP_MODE_EXACT || c->ns > 128) return batch_exact(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL, done, user); // (beyond 128 states: the wide exact kernels whatever the mode)
+	return batch_fast(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL, done, user);
 }
 
 extern "C" int psmc_hip_batch_info(psmc_hip_ctx *c, int out[2])

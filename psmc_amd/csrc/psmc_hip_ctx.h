@@ -153,6 +153,7 @@ struct psmc_hip_ctx {
 	int batch_sort = 1;                // "batch_sort": the exact batch deals ENTRIES to its launches longest first (api_batch.hip); 0 = replicate-major order
 	int batch_slots = 0;               // "batch_slots": entries per launch of an exact batch that needs several (0: four per compute unit of the context's share)
 	int batch_tailfill = 1;            // "batch_tailfill": the exact batch puts the shortest entries into the spare slots of the memory-bound launches when that saves a launch
+	int batch_major = 1;               // "batch_major": blocks no longer than the dominant trunk length keep replicate order (replicates complete launch by launch)
 	int batch_first = 0;               // "batch_first": the next batch calls' replicate 0 is replicate batch_first of the context (fast mode: which kept plan it uses)
 	int64_t reserved_cap = 0;          // ... and the per-launch capacity it sized the tables for
 	int reserved_refwd = -1;           // what psmc_hip_reserve_batch_tables decided about the f table (-1: nothing reserved): the batches that follow keep it

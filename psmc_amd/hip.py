@@ -27,7 +27,7 @@ EXPORTS = [
     "psmc_hip_device_count", "psmc_hip_device_cus", "psmc_hip_set_cu_range", "psmc_hip_reserve_tables", "psmc_hip_create", "psmc_hip_destroy", "psmc_hip_strerror",
     "psmc_hip_last_error", "psmc_hip_set_option", "psmc_hip_load_segments",
     "psmc_hip_load_segments_device", "psmc_hip_select", "psmc_hip_estep",
-    "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_reserve_batch_tables", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
+    "psmc_hip_estep_segments", "psmc_hip_estep_batch", "psmc_hip_estep_batch_cb", "psmc_hip_reserve_batch_tables", "psmc_hip_batch_info", "psmc_hip_estep_device", "psmc_hip_fast_diag", "psmc_hip_fast_repairs", "psmc_hip_fast_info", "psmc_hip_estep_factored",
     "psmc_hip_get_tables", "psmc_hip_decode", "psmc_hip_posterior", "psmc_hip_post_counts",
     "psmc_hip_group_selfcheck", "psmc_hip_fast_plan",
     "psmc_hip_group_create", "psmc_hip_group_destroy", "psmc_hip_group_last_error", "psmc_hip_group_set_option",
@@ -239,9 +239,10 @@ class HipEStep:
                                                    _p(chk)), "estep_segments")
         return dict(seg_A=sA, seg_E=sE, seg_A0=sA0, seg_LL=sLL, chk=chk)
 
-    def estep_batch(self, params, selections, want="A"):
+    def estep_batch(self, params, selections, want="A", on_done=None):
         """Config 4: one call for n_rep replicates.  params: list of (a, e, a0); selections: list of index lists
         (bootstrap multisets over the loaded segments).  want: "A" (full counts), "sums" (5 triangular sums) or "both".
+        on_done(replicates, out): psmc_hip_estep_batch_cb's progress callback -- the positions whose rows of `out` are final now.
         -> dict(A (R,n,n) | sums (R,5,n), E (R,2,n), LL (R,))."""
         R, n = len(params), self.n
         assert len(selections) == R
@@ -254,14 +255,21 @@ class HipEStep:
         A = np.zeros((R, n, n)) if want in ("A", "both") else None
         sums = np.zeros((R, 5, n)) if want in ("sums", "both") else None
         E = np.zeros((R, 2, n)); LL = np.zeros(R)
-        self.lib.psmc_hip_estep_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _i32p, _dp, _dp, _dp, _dp]
-        self._chk(self.lib.psmc_hip_estep_batch(self.h, R, _p(a), _p(e), _p(a0), off.ctypes.data_as(_i32p), idx.ctypes.data_as(_i32p),
-                                                _p(A), _p(sums), _p(E), _p(LL)), "estep_batch")
         out = dict(E=E, LL=LL)
         if A is not None:
             out["A"] = A
         if sums is not None:
             out["sums"] = sums
+        if on_done is None:
+            self.lib.psmc_hip_estep_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _i32p, _dp, _dp, _dp, _dp]
+            self._chk(self.lib.psmc_hip_estep_batch(self.h, R, _p(a), _p(e), _p(a0), off.ctypes.data_as(_i32p), idx.ctypes.data_as(_i32p),
+                                                    _p(A), _p(sums), _p(E), _p(LL)), "estep_batch")
+            return out
+        fn_t = C.CFUNCTYPE(None, C.c_void_p, C.c_int, _i32p)
+        cb = fn_t(lambda user, n_done, reps: on_done([int(reps[i]) for i in range(n_done)], out))
+        self.lib.psmc_hip_estep_batch_cb.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _i32p, _dp, _dp, _dp, _dp, fn_t, C.c_void_p]
+        self._chk(self.lib.psmc_hip_estep_batch_cb(self.h, R, _p(a), _p(e), _p(a0), off.ctypes.data_as(_i32p), idx.ctypes.data_as(_i32p),
+                                                   _p(A), _p(sums), _p(E), _p(LL), cb, None), "estep_batch_cb")
         return out
 
     def batch_info(self):

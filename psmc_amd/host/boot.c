@@ -1,9 +1,9 @@
 /* boot.c -- config 4: the bootstrap farm of lh3/psmc (README:57-62 there: `seq 100 | xargs -i echo psmc -N25 ... -b
  * -o round-{}.psmc split.fa | sh`) as ONE process that keeps the trunks in HBM once and runs all replicates' EM
- * iterations together: the E-steps of a group of replicates go to a device as one batch (psmc_hip_estep_batch: exact
+ * iterations together: the E-steps of a device's replicates go to it as one batch (psmc_hip_estep_batch_cb: exact
  * mode packs hundreds of trunk sweeps into one grid; fast mode keeps a learned tile plan per replicate), the
- * Hooke-Jeeves M-steps (host, em.c:56-68) run on host threads, one replicate each -- and while they run, the device
- * is already busy with the E-steps of the device's other group (two groups per device: PSMC_BOOT_GROUPS).
+ * Hooke-Jeeves M-steps (host, em.c:56-68) run on host threads, one replicate each -- starting as soon as the batch
+ * reports a replicate's statistics final, while the device is still busy with the rest of the batch.
  *
  * Replicate r is `PSMC_SEED=<seed0+r> psmc -b <options>`: the same srand48 seed, hence the same psmc_resamp draw
  * (aux.c:8-47) and the same -I initial parameters, the same .psmc stream -- byte for byte in exact mode
@@ -58,6 +58,7 @@ typedef struct {
 	int64_t sum_called, sum_het;
 	FILE *out;
 	double *A, *E, *sums, LL;
+	int it;                        /* the EM iteration A / E / sums / LL belong to */
 } replicate;
 
 /* the main run's EM rounds (psmc_run_finish) on a thread of their own */
@@ -73,39 +74,84 @@ static void *main_thread(void *arg)
 }
 
 
-/* ---- the EM iterations of all replicates as a two-stage pipeline: E-steps on the devices, M-steps on host threads */
-#define MAX_GRP 8
+/* ---- the EM iterations of all replicates as a two-stage pipeline: E-steps on the devices, M-steps on host threads.
+ * A device thread sends ALL replicates of its device as one batch per EM iteration; the backend reports replicates as their statistics
+ * become final (psmc_hip_estep_batch_cb: exact mode after each launch of the batch, fast mode after each replicate), and from that
+ * moment a replicate's M-step (em.c:56-68) runs on one of the M-step threads -- under the rest of the batch.  A device starts its next
+ * iteration when the M-steps of all ITS replicates are done; devices do not wait for each other. */
 typedef struct {
-	psmc_options *o; psmc_batch_backend *bb; replicate *rep; int n_rep, N, factored, n_grp, timing;
+	psmc_options *o; psmc_batch_backend *bb; replicate *rep; int n_rep, N, factored, timing;
 	main_job *mj;
 	pthread_mutex_t mu; pthread_cond_t cv; /* guard everything below */
-	int *e_done;        /* [device * n_grp + group]: EM iterations whose E-step results of that group are in rep[] */
-	int m_done[MAX_GRP]; /* EM iterations whose M-steps of the group (all devices) are done */
-	double *e_ms;       /* [device * n_iters + iteration]: time inside estep_batch */
-	int failed;
+	int *queue, q_head, q_tail;  /* ring of n_rep + 1 replicate numbers whose E-step results are in rep[] and whose M-step has not started */
+	int *m_left;                 /* [device]: M-steps of the device's current iteration not finished yet */
+	int stop, failed;
+	/* per EM iteration, for PSMC_TIMING */
+	int *it_done;                /* replicates through their M-step */
+	double *e_ms, *e_end, *it_end, *m_work; /* longest batch call; when the last one ended; when the last M-step ended; summed M-step time */
 } pipeline;
 typedef struct { pipeline *P; int dev; pthread_t tid; } dev_job;
+typedef struct { pipeline *P; int dev, it; const double *A, *S5, *E, *LL; } done_ctx;
 
 static void pipe_fail(pipeline *P) { pthread_mutex_lock(&P->mu); P->failed = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu); }
-static int pipe_failed(pipeline *P) { pthread_mutex_lock(&P->mu); const int f = P->failed; pthread_mutex_unlock(&P->mu); return f; }
-/* device d drives replicates d, d + n_dev, ...: positions [lo, hi) of that list are its group g.  In the FIRST EM iteration group 0 is
- * the whole list and the others are empty: the backend's first batch call sees every replicate of the device, so what it derives
- * from that call (fast mode: ONE tile length for all replicates, from the largest) does not depend on the grouping */
-static void group_range(const pipeline *P, int d, int g, int it, int *lo, int *hi)
+
+/* the backend's progress report: positions `pos` of the running batch are final -- copy them out, queue their M-steps */
+static void batch_done(void *user, int n_done, const int32_t *pos)
 {
-	const int cnt = P->n_rep > d ? (P->n_rep - d + P->bb->n_dev - 1) / P->bb->n_dev : 0;
-	if (it == 0) { *lo = 0; *hi = g == 0 ? cnt : 0; return; }
-	*lo = (int)((int64_t)cnt * g / P->n_grp); *hi = (int)((int64_t)cnt * (g + 1) / P->n_grp);
+	done_ctx *D = (done_ctx *)user;
+	pipeline *P = D->P;
+	const int N = P->N, nd = P->bb->n_dev;
+	for (int i = 0; i < n_done; ++i) {
+		const int j = pos[i];
+		replicate *R = &P->rep[D->dev + j * nd];
+		if (D->A) memcpy(R->A, D->A + (size_t)j * N * N, sizeof(double) * (size_t)N * N);
+		if (D->S5) memcpy(R->sums, D->S5 + (size_t)j * 5 * N, sizeof(double) * (size_t)5 * N);
+		memcpy(R->E, D->E + (size_t)j * 2 * N, sizeof(double) * (size_t)2 * N);
+		R->LL = D->LL[j];
+		R->it = D->it;
+	}
+	pthread_mutex_lock(&P->mu);
+	for (int i = 0; i < n_done; ++i) { P->queue[P->q_tail] = D->dev + pos[i] * nd; P->q_tail = (P->q_tail + 1) % (P->n_rep + 1); }
+	pthread_cond_broadcast(&P->cv);
+	pthread_mutex_unlock(&P->mu);
 }
 
-/* one batch: the E-steps of positions [lo, hi) of device d's replicates, results into rep[] */
-static int estep_group(pipeline *P, int d, int lo, int hi)
+static void *mstep_thread(void *arg)
+{
+	pipeline *P = (pipeline *)arg;
+	for (;;) {
+		pthread_mutex_lock(&P->mu);
+		while (P->q_head == P->q_tail && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
+		if (P->q_head == P->q_tail) { pthread_mutex_unlock(&P->mu); return 0; } /* stop, nothing queued */
+		const int r = P->queue[P->q_head];
+		P->q_head = (P->q_head + 1) % (P->n_rep + 1);
+		pthread_mutex_unlock(&P->mu);
+		replicate *R = &P->rep[r];
+		const double t0 = now_ms();
+		/* independent models (em.c:56-74), then the round's output */
+		psmc_em_mstep(R->m, R->A, R->E, R->sums, R->LL, R->out);
+		fprintf(R->out, "RD\t%d\n", R->it + 1);
+		psmc_print_round(R->m, R->sum_called, R->out);
+		const double t1 = now_ms();
+		pthread_mutex_lock(&P->mu);
+		--P->m_left[r % P->bb->n_dev];
+		++P->it_done[R->it];
+		P->m_work[R->it] += t1 - t0;
+		if (t1 > P->it_end[R->it]) P->it_end[R->it] = t1;
+		pthread_cond_broadcast(&P->cv);
+		pthread_mutex_unlock(&P->mu);
+	}
+}
+
+/* one EM iteration's batch of device d: the E-steps of all its replicates; the results leave through batch_done */
+static int estep_device(pipeline *P, int d, int it)
 {
 	psmc_batch_backend *bb = P->bb;
 	replicate *rep = P->rep;
-	const int N = P->N, cnt = hi - lo, nd = bb->n_dev;
+	const int N = P->N, nd = bb->n_dev;
+	const int cnt = P->n_rep > d ? (P->n_rep - d + nd - 1) / nd : 0;
 	int tot = 0;
-	for (int j = lo; j < hi; ++j) tot += rep[d + j * nd].n_idx;
+	for (int j = 0; j < cnt; ++j) tot += rep[d + j * nd].n_idx;
 	double *a = (double *)malloc(sizeof(double) * (size_t)cnt * N * N), *e = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N);
 	double *a0 = (double *)malloc(sizeof(double) * (size_t)cnt * N);
 	double *A = P->factored ? 0 : (double *)malloc(sizeof(double) * (size_t)cnt * N * N);
@@ -114,23 +160,20 @@ static int estep_group(pipeline *P, int d, int lo, int hi)
 	int32_t *off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cnt + 1)), *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(tot > 0 ? tot : 1));
 	off[0] = 0;
 	for (int j = 0; j < cnt; ++j) {
-		const replicate *R = &rep[d + (lo + j) * nd];
+		const replicate *R = &rep[d + j * nd];
 		memcpy(a + (size_t)j * N * N, R->m->a, sizeof(double) * (size_t)N * N);
 		memcpy(e + (size_t)j * 2 * N, R->m->e, sizeof(double) * (size_t)2 * N); /* rows hom, het; the missing row is implied */
 		memcpy(a0 + (size_t)j * N, R->m->a0, sizeof(double) * (size_t)N);
 		memcpy(idx + off[j], R->idx, sizeof(int32_t) * (size_t)R->n_idx);
 		off[j + 1] = off[j] + R->n_idx;
 	}
-	const int rc = bb->estep_batch(bb->self, d, lo, cnt, a, e, a0, off, idx, A, S5, E, LL);
+	done_ctx D = {P, d, it, A, S5, E, LL};
+	pthread_mutex_lock(&P->mu);
+	P->m_left[d] = cnt;
+	pthread_mutex_unlock(&P->mu);
+	const int rc = bb->estep_batch(bb->self, d, cnt, a, e, a0, off, idx, A, S5, E, LL, batch_done, &D);
 	if (rc) fprintf(stderr, "psmc_boot: E-step batch failed on device %d: %s\n", d, bb->error(bb->self, d));
-	for (int j = 0; j < cnt && !rc; ++j) {
-		replicate *R = &rep[d + (lo + j) * nd];
-		if (A) memcpy(R->A, A + (size_t)j * N * N, sizeof(double) * (size_t)N * N);
-		if (S5) memcpy(R->sums, S5 + (size_t)j * 5 * N, sizeof(double) * (size_t)5 * N);
-		memcpy(R->E, E + (size_t)j * 2 * N, sizeof(double) * (size_t)2 * N);
-		R->LL = LL[j];
-	}
-	free(a); free(e); free(a0); free(A); free(S5); free(E); free(LL); free(off); free(idx);
+	free(a); free(e); free(a0); free(A); free(S5); free(E); free(LL); free(off); free(idx); /* (batch_done copied every row out) */
 	return rc;
 }
 
@@ -140,28 +183,23 @@ static void *dev_thread(void *arg)
 	pipeline *P = J->P;
 	const int d = J->dev;
 	int main_released = 0;
-	for (int it = 0; it != P->o->n_iters; ++it)
-		for (int g = 0; g < P->n_grp; ++g) {
-			int lo, hi, ok;
-			pthread_mutex_lock(&P->mu);
-			while (!P->failed && P->m_done[g] < it) pthread_cond_wait(&P->cv, &P->mu); /* the group's parameters of this iteration exist */
-			ok = !P->failed;
-			pthread_mutex_unlock(&P->mu);
-			if (!ok) return 0;
-			if (P->mj && !main_released && P->bb->main_done && __atomic_load_n(&P->mj->finished, __ATOMIC_ACQUIRE)) {
-				P->bb->main_done(P->bb->self, d); /* the main run is over: this device's batches get its compute units back */
-				main_released = 1;
-				if (P->timing) fprintf(stderr, "[psmc_boot] main run finished before iteration %d, group %d of device %d: its batches have the whole device again\n", it + 1, g, d);
-			}
-			group_range(P, d, g, it, &lo, &hi);
-			const double t0 = now_ms();
-			if (hi > lo && estep_group(P, d, lo, hi)) { pipe_fail(P); return 0; }
-			pthread_mutex_lock(&P->mu);
-			P->e_ms[(size_t)d * P->o->n_iters + it] += now_ms() - t0;
-			P->e_done[d * P->n_grp + g] = it + 1;
-			pthread_cond_broadcast(&P->cv);
-			pthread_mutex_unlock(&P->mu);
+	for (int it = 0; it != P->o->n_iters; ++it) {
+		if (P->mj && !main_released && P->bb->main_done && __atomic_load_n(&P->mj->finished, __ATOMIC_ACQUIRE)) {
+			P->bb->main_done(P->bb->self, d); /* the main run is over: this device's batches get its compute units back */
+			main_released = 1;
+			if (P->timing) fprintf(stderr, "[psmc_boot] main run finished before iteration %d of device %d: its batches have the whole device again\n", it + 1, d);
 		}
+		const double t0 = now_ms();
+		if (estep_device(P, d, it)) { pipe_fail(P); return 0; }
+		const double t1 = now_ms();
+		pthread_mutex_lock(&P->mu);
+		if (t1 - t0 > P->e_ms[it]) P->e_ms[it] = t1 - t0;
+		if (t1 > P->e_end[it]) P->e_end[it] = t1;
+		while (!P->failed && P->m_left[d] > 0) pthread_cond_wait(&P->cv, &P->mu); /* the parameters of the next iteration exist when every M-step of this one is through */
+		const int ok = !P->failed;
+		pthread_mutex_unlock(&P->mu);
+		if (!ok) return 0;
+	}
 	return 0;
 }
 
@@ -255,78 +293,60 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		if (pthread_create(&main_tid, 0, main_thread, &mj) == 0) main_started = 1;
 		else { fprintf(stderr, "psmc_boot: cannot start the main run's thread\n"); failed = 1; }
 	}
-	{ /* main.c:16-20 for every replicate.  Each device's replicates form n_grp groups; a device thread sends group after group to
-	   * the device, and the M-steps of a group (host threads, here) run while the device is busy with the NEXT group's E-steps:
-	   * E(all,1) | M(all,1) | E(g0,2) | E(g1,2) + M(g0,2) | E(g0,3) + M(g1,2) | ...  A replicate still sees E, M, E, M, ... in order: same output. */
+	{ /* main.c:16-20 for every replicate */
 		pipeline P;
-		const char *gs = getenv("PSMC_BOOT_GROUPS");
 		memset(&P, 0, sizeof P);
-		P.n_grp = gs ? atoi(gs) : 2;
-		if (P.n_grp < 1) P.n_grp = 1;
-		if (P.n_grp > MAX_GRP) P.n_grp = MAX_GRP;
-		if ((n_rep + bb->n_dev - 1) / bb->n_dev < P.n_grp) P.n_grp = 1; /* (no device with a replicate for every group: one batch per iteration) */
 		P.o = o; P.bb = bb; P.rep = rep; P.n_rep = n_rep; P.N = N; P.factored = factored; P.mj = main_started ? &mj : 0; P.timing = timing;
 		P.failed = failed;
 		pthread_mutex_init(&P.mu, 0); pthread_cond_init(&P.cv, 0);
-		P.e_done = (int *)calloc((size_t)bb->n_dev * P.n_grp, sizeof(int));
-		P.e_ms = (double *)calloc((size_t)bb->n_dev * (size_t)(o->n_iters > 0 ? o->n_iters : 1), sizeof(double));
+		const size_t ni = (size_t)(o->n_iters > 0 ? o->n_iters : 1);
+		P.queue = (int *)calloc((size_t)n_rep + 1, sizeof(int));
+		P.m_left = (int *)calloc((size_t)bb->n_dev, sizeof(int));
+		P.it_done = (int *)calloc(ni, sizeof(int));
+		P.e_ms = (double *)calloc(ni, sizeof(double)); P.e_end = (double *)calloc(ni, sizeof(double));
+		P.it_end = (double *)calloc(ni, sizeof(double)); P.m_work = (double *)calloc(ni, sizeof(double));
+		/* M-step threads: what the process may use, less the threads that drive the devices (they spin inside the HIP runtime while a batch
+		 * runs) and the main run's; OMP_NUM_THREADS, when set, is taken as given (the M-steps were an OpenMP loop until round 5) */
+		int m_threads = psmc_usable_cpus() - bb->n_dev - (main_started ? 1 : 0);
+		if (m_threads < 1) m_threads = 1;
+		if (getenv("OMP_NUM_THREADS") && atoi(getenv("OMP_NUM_THREADS")) > 0) m_threads = atoi(getenv("OMP_NUM_THREADS"));
+		if (m_threads > n_rep) m_threads = n_rep;
+		if (timing) fprintf(stderr, "[psmc_boot] %d usable processors, %d M-step threads, %d device thread(s)%s\n", psmc_usable_cpus(), m_threads, bb->n_dev, main_started ? ", 1 main-run thread" : "");
+		pthread_t *mt = (pthread_t *)calloc((size_t)m_threads, sizeof(pthread_t));
 		dev_job *dj = (dev_job *)calloc((size_t)bb->n_dev, sizeof(dev_job));
-		int n_thr = 0;
+		int n_mt = 0, n_thr = 0;
+		for (int k = 0; k < m_threads && !P.failed; ++k) {
+			if (pthread_create(&mt[k], 0, mstep_thread, &P) == 0) ++n_mt;
+			else if (n_mt == 0) { fprintf(stderr, "psmc_boot: cannot start an M-step thread\n"); pipe_fail(&P); }
+			else break; /* fewer threads than asked for */
+		}
 		for (int d = 0; d < bb->n_dev && !P.failed; ++d) {
 			dj[d].P = &P; dj[d].dev = d;
 			if (pthread_create(&dj[d].tid, 0, dev_thread, &dj[d]) == 0) ++n_thr;
 			else { fprintf(stderr, "psmc_boot: cannot start the thread of device %d\n", d); pipe_fail(&P); }
 		}
-		int *list = (int *)malloc(sizeof(int) * (size_t)n_rep);
-		/* M-step threads: what the process may use, less the threads that drive the devices (they spin inside the HIP runtime while a batch
-		 * runs) and the main run's; OMP_NUM_THREADS, when set, is taken as given */
-		int m_threads = psmc_usable_cpus() - bb->n_dev - (main_started ? 1 : 0);
-		if (m_threads < 1) m_threads = 1;
-		if (getenv("OMP_NUM_THREADS") && atoi(getenv("OMP_NUM_THREADS")) > 0) m_threads = atoi(getenv("OMP_NUM_THREADS"));
-		if (timing) fprintf(stderr, "[psmc_boot] %d usable processors, %d M-step threads, %d device thread(s)%s\n", psmc_usable_cpus(), m_threads, bb->n_dev, main_started ? ", 1 main-run thread" : "");
-		double t_prev = now_ms();
-		for (int it = 0; it != o->n_iters && !pipe_failed(&P); ++it) {
-			double m_ms = 0.0;
-			for (int g = 0; g < P.n_grp; ++g) {
-				int n_list = 0, ok = 1;
+		if (timing) { /* one line per EM iteration, when its last M-step is through */
+			double t_prev = now_ms();
+			for (int it = 0; it != o->n_iters; ++it) {
 				pthread_mutex_lock(&P.mu);
-				for (int d = 0; d < bb->n_dev; ++d)
-					while (!P.failed && P.e_done[d * P.n_grp + g] < it + 1) pthread_cond_wait(&P.cv, &P.mu);
-				ok = !P.failed;
+				while (!P.failed && P.it_done[it] < n_rep) pthread_cond_wait(&P.cv, &P.mu);
+				const int ok = !P.failed;
+				const double e_ms = P.e_ms[it], tail = P.it_end[it] - P.e_end[it], work = P.m_work[it], t_end = P.it_end[it];
 				pthread_mutex_unlock(&P.mu);
 				if (!ok) break;
-				for (int d = 0; d < bb->n_dev; ++d) {
-					int lo, hi; group_range(&P, d, g, it, &lo, &hi);
-					for (int j = lo; j < hi; ++j) list[n_list++] = d + j * bb->n_dev;
-				}
-				const double t1 = now_ms();
-				/* M-steps: independent models, one host thread each (em.c:56-74), then the round's output */
-#pragma omp parallel for schedule(dynamic, 1) num_threads(m_threads)
-				for (int q = 0; q < n_list; ++q) {
-					replicate *R = &rep[list[q]];
-					psmc_em_mstep(R->m, R->A, R->E, R->sums, R->LL, R->out);
-					fprintf(R->out, "RD\t%d\n", it + 1);
-					psmc_print_round(R->m, R->sum_called, R->out);
-				}
-				m_ms += now_ms() - t1;
-				pthread_mutex_lock(&P.mu);
-				P.m_done[g] = it + 1;
-				pthread_cond_broadcast(&P.cv);
-				pthread_mutex_unlock(&P.mu);
-			}
-			if (timing && !pipe_failed(&P)) {
-				double e_ms = 0.0;
-				pthread_mutex_lock(&P.mu);
-				for (int d = 0; d < bb->n_dev; ++d) if (P.e_ms[(size_t)d * o->n_iters + it] > e_ms) e_ms = P.e_ms[(size_t)d * o->n_iters + it];
-				pthread_mutex_unlock(&P.mu);
-				const double t_now = now_ms();
-				fprintf(stderr, "[psmc_boot] iteration %d: %d E-steps %.1f ms on %d device(s), M-steps %.1f ms, %d group(s), wall %.1f ms\n", it + 1, n_rep, e_ms, bb->n_dev, m_ms, P.n_grp, t_now - t_prev);
-				t_prev = t_now;
+				fprintf(stderr, "[psmc_boot] iteration %d: %d E-steps %.1f ms on %d device(s), M-steps %.1f ms after the last batch (%.0f ms of work on %d threads, the rest under the batches), wall %.1f ms\n",
+				        it + 1, n_rep, e_ms, bb->n_dev, tail > 0.0 ? tail : 0.0, work, n_mt, t_end - t_prev);
+				t_prev = t_end;
 			}
 		}
 		for (int d = 0; d < n_thr; ++d) pthread_join(dj[d].tid, 0);
+		pthread_mutex_lock(&P.mu);
+		P.stop = 1;
+		pthread_cond_broadcast(&P.cv);
+		pthread_mutex_unlock(&P.mu);
+		for (int k = 0; k < n_mt; ++k) pthread_join(mt[k], 0);
 		failed = P.failed;
-		free(list); free(dj); free(P.e_done); free(P.e_ms);
+		free(mt); free(dj); free(P.queue); free(P.m_left); free(P.it_done); free(P.e_ms); free(P.e_end); free(P.it_end); free(P.m_work);
 		pthread_mutex_destroy(&P.mu); pthread_cond_destroy(&P.cv);
 	}
 	status = failed ? 1 : 0;

@@ -8,8 +8,9 @@
  * writes what  for r in 0..99: PSMC_SEED=$((1+r)) psmc -N25 -t15 -r5 -b -p ... -o round-$r.psmc split.psmcfa  would
  * (-b is implied).  PSMC_HIP_MODE=exact|fast and PSMC_FAST_MSTEP as for psmc; PSMC_HIP_DEVICES=0,1,.. (a device may be
  * listed several times = as many contexts on it; default: all visible devices, three times each in fast mode); OMP_NUM_THREADS bounds
- * the M-step threads; PSMC_TIMING=1 prints per-iteration times to stderr; PSMC_BOOT_GROUPS: groups of replicates per context whose
- * M-steps run under the next group's E-steps (default 2 in fast mode, 1 in exact mode).
+ * the M-step threads (default: the processors the control group's CPU quota allows, less the device threads); PSMC_TIMING=1 prints
+ * per-iteration times to stderr.  A replicate's M-step starts when the batch reports its statistics final (psmc_hip_estep_batch_cb)
+ * and runs under the rest of the batch.
  *
  * --main / --main-input: the whole workflow of the reference's README:49-62 as ONE job -- the un-resampled main run
  * (`psmc <psmc options> -o out.psmc in.psmcfa`, on the unsplit input) runs on a thread of its own BESIDE the replicates, on the
@@ -51,13 +52,11 @@ static void bb_main_done(void *self, int d)
 	hip_bb *h = (hip_bb *)self;
 	if (h->dev_id[d] == h->main_dev) { (void)psmc_hip_set_cu_range(h->ctx[d], 0, 0); (void)psmc_hip_set_option(h->ctx[d], "batch_slots", 0); }
 }
-/* (fast mode keeps a tile plan per replicate: "batch_first" names the call's first replicate among the context's) */
-static int bb_estep_batch(void *self, int dev, int first, int n_rep, const double *a, const double *e, const double *a0,
-                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
+                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL,
+                          void (*done)(void *user, int n_done, const int32_t *pos), void *user)
 {
-	psmc_hip_ctx *c = ((hip_bb *)self)->ctx[dev];
-	const int rc = psmc_hip_set_option(c, "batch_first", first);
-	return rc ? rc : psmc_hip_estep_batch(c, n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL);
+	return psmc_hip_estep_batch_cb(((hip_bb *)self)->ctx[dev], n_rep, a, e, a0, sel_off, sel_idx, A, sums, E, LL, done, user);
 }
 static const char *bb_error(void *self, int dev) { return psmc_hip_last_error(((hip_bb *)self)->ctx[dev]); }
 static void bb_destroy(void *self) { hip_bb *h = (hip_bb *)self; for (int d = 0; d < h->n_dev; ++d) psmc_hip_destroy(h->ctx[d]); }
@@ -116,12 +115,6 @@ int main(int argc, char *argv[])
 	const int mode = (mode_s && strcmp(mode_s, "fast") == 0) ? PSMC_HIP_MODE_FAST : PSMC_HIP_MODE_EXACT;
 	o.fast_mstep = fm ? atoi(fm) != 0 : (mode == PSMC_HIP_MODE_FAST);
 	om.fast_mstep = o.fast_mstep;
-	/* The E / M pipeline of boot.c (PSMC_BOOT_GROUPS groups of replicates per context, the M-steps of one under the E-steps of the next): two
-	 * groups in fast mode, where a batch runs its replicates one after the other anyway.  Exact mode keeps ONE batch per iteration: its launches
-	 * are sized by the device's memory and entry slots, and two half batches need one launch more than a whole one whenever the main run
-	 * holds part of the device -- more than the 0.6 s of M-steps they would hide (100 replicates, no main run: 6.61 s per iteration with two
-	 * groups against 6.81 with one; profiles/r05_groups_ab.json). */
-	if (!getenv("PSMC_BOOT_GROUPS")) setenv("PSMC_BOOT_GROUPS", mode == PSMC_HIP_MODE_FAST ? "2" : "1", 1);
 	hip_bb h;
 	memset(&h, 0, sizeof h);
 	h.n_states = n_states;

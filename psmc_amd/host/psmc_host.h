@@ -152,18 +152,19 @@ psmc_model *psmc_model_start(const psmc_options *o, const psmc_setup *su, int64_
 /* ---- bootstrap driver (config 4): n_rep replicates of `psmc -b` in one process.  Replicate r draws its trunks and
  * its initial parameters from srand48(seed0 + r) exactly as `PSMC_SEED=<seed0+r> psmc -b ...` does, and writes the
  * same .psmc stream to the file named by out_pattern (one %d = r).  Per EM iteration the E-steps of all replicates
- * go to the device(s) as batches -- two groups per device, one after the other -- and the M-steps of a group run on host
- * threads while the device works on the other group's E-steps. */
+ * go to the device(s) as one batch each, and a replicate's M-step runs on a host thread as soon as the batch reports its
+ * statistics final -- under the rest of the batch. */
 typedef struct psmc_batch_backend {
 	void *self;
 	int  n_dev; /* replicates are dealt round robin over the devices; one host thread drives each device */
 	int  (*load)(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L);
 	/* n_rep E-steps over the loaded trunks: parameters a n_rep*n*n, e n_rep*2*n (rows hom, het), a0 n_rep*n;
 	 * multisets sel_idx[sel_off[r] .. sel_off[r+1]); outputs A n_rep*n*n or NULL, sums n_rep*5n or NULL, E n_rep*2n, LL.
-	 * `first`: the call's replicates are positions first .. first + n_rep - 1 of the device's replicates -- the same position means
-	 * the same replicate (same multiset) in every EM iteration, so a backend may keep what it learned per position */
-	int  (*estep_batch)(void *self, int dev, int first, int n_rep, const double *a, const double *e, const double *a0,
-	                    const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL);
+	 * `done(user, n, pos)` must be called (on the calling thread) for every replicate exactly once, as soon as its rows of the
+	 * outputs are final -- at the latest before the call returns: the driver starts that replicate's M-step at once */
+	int  (*estep_batch)(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
+	                    const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL,
+	                    void (*done)(void *user, int n_done, const int32_t *pos), void *user);
 	const char *(*error)(void *self, int dev);
 	void (*destroy)(void *self);
 	int  can_factor; /* estep_batch can produce the triangular sums directly */

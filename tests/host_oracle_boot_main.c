@@ -24,12 +24,13 @@ static int obb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, c
 	for (int i = 0; i < n_seg; ++i) { o->sym[i] = sym[i]; o->L[i] = L[i]; }
 	return 0;
 }
-static int obb_estep_batch(void *self, int dev, int first, int n_rep, const double *a, const double *e, const double *a0,
-                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL)
+static int obb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
+                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL,
+                          void (*done)(void *user, int n_done, const int32_t *pos), void *user)
 {
 	orc_bb *o = (orc_bb *)self;
 	const int n = o->n;
-	(void)dev; (void)first;
+	(void)dev;
 	for (int r = 0; r < n_rep; ++r) {
 		const int ns = sel_off[r + 1] - sel_off[r];
 		const uint8_t **sq = (const uint8_t **)malloc(sizeof(void *) * ns);
@@ -50,6 +51,7 @@ static int obb_estep_batch(void *self, int dev, int first, int n_rep, const doub
 				}
 		}
 		free(sq); free(ln); free(e3); free(Ar);
+		{ const int32_t rr = r; done(user, 1, &rr); } /* final: its M-step may start */
 	}
 	return 0;
 }

@@ -747,6 +747,68 @@ def test_exact_batch_tail_fill(hip, golden):
     ref.close()
 
 
+def test_exact_batch_progress_callback(hip, golden):
+    """psmc_hip_estep_batch_cb: `done` names every replicate exactly once, when its rows are final -- a copy taken inside the callback
+    equals the row after the call.  Trunks cut to one length like utils/splitfa.c's (2000 bins + the segments' tails), ten replicates,
+    memory and slots for a third of the entries per launch: with "batch_major" the replicates complete launch by launch (the first
+    callback comes before the last launch and names only some of them), with batch_major=0 (everything by length) their short tails
+    all sit in the last launch.  Same bits either way, and the same as without a callback."""
+    trunks = []
+    for sgm in golden.segs_mid:
+        pos = 0
+        while len(sgm) - pos >= 3000:
+            trunks.append(sgm[pos:pos + 2000]); pos += 2000
+        trunks.append(sgm[pos:])
+    rng = np.random.default_rng(3)
+    params = _traj_params(5) * 2
+    sels = [rng.integers(0, len(trunks), size=len(trunks)).tolist() for _ in range(10)]
+    entries = sum(len(set(x)) for x in sels)
+    bins = sum(sum((len(trunks[i]) + 63) // 64 * 64 for i in set(x)) for x in sels)
+    plain = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    plain.load_segments(trunks)
+    want = plain.estep_batch(params, sels)
+    plain.close()
+    firsts = {}
+    for major in (1, 0):
+        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=bins // 3 + 4096, batch_slots=(entries // 3 + 8) // 4 * 4, exact_refwd=2, batch_tailfill=0, batch_major=major)
+        es.load_segments(trunks)
+        seen, calls = {}, []
+        def on_done(reps, out):
+            calls.append(list(reps))
+            for r in reps:
+                assert r not in seen
+                seen[r] = (out["A"][r].copy(), out["E"][r].copy(), float(out["LL"][r]))
+        got = es.estep_batch(params, sels, on_done=on_done)
+        launches = es.batch_info()["groups"]
+        es.close()
+        assert sorted(seen) == list(range(10)) and launches >= 3
+        for r in range(10):
+            assert bits_equal(seen[r][0], got["A"][r]) and bits_equal(seen[r][1], got["E"][r]) and seen[r][2] == got["LL"][r]
+            assert bits_equal(got["A"][r], want["A"][r]) and bits_equal(got["E"][r], want["E"][r]) and got["LL"][r] == want["LL"][r]
+        firsts[major] = (len(calls), len(calls[0]), len(calls[-1]))
+    assert firsts[1][0] >= 2 and firsts[1][1] < 10 and firsts[1][2] < 10, firsts     # launch by launch
+    assert firsts[0][2] >= firsts[1][2], firsts                                     # by length: the tails complete (nearly) everybody at the end
+
+
+def test_fast_batch_progress_callback(hip, golden):
+    """Fast mode runs its replicates one after the other: `done` after each, in order, with the rows final."""
+    segs = golden.segs_mid
+    params = _traj_params(4)
+    sels = [[5, 4, 5, 3, 5], [0, 1, 2], [2, 2, 1, 0, 4], list(range(6))]
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, chunk=768, warmup=256)
+    es.load_segments(segs)
+    calls, rows = [], {}
+    def on_done(reps, out):
+        calls.append(list(reps))
+        for r in reps:
+            rows[r] = (out["sums"][r].copy(), float(out["LL"][r]))
+    got = es.estep_batch(params, sels, want="sums", on_done=on_done)
+    es.close()
+    assert calls == [[0], [1], [2], [3]]
+    for r in range(4):
+        assert bits_equal(rows[r][0], got["sums"][r]) and rows[r][1] == got["LL"][r]
+
+
 def test_exact_batch_reserve_then_smaller_batch_then_single_estep(hip, golden):
     """psmc_hip_reserve_batch_tables decides about the f table from the caller's upper bound, the batch that
     follows used to decide again from its own count of unique bins -- two answers, an f table allocated at the b-only capacity.

@@ -132,13 +132,12 @@ def test_boot_driver_equals_single_bootstrap_runs(oracle_psmc, tmp_path, fast_ms
         assert got == one.stdout, k
         seen.add(got)
     assert len(seen) == 5   # the replicates really differ
-    # the E / M pipeline (two groups per device by default: device 0 has replicates {0} {2, 4}, device 1 {1} {3}): one group
-    # (lock step, as in round 4) and three groups (device 1 then has an empty one) write the same files
-    for groups in ("1", "3"):
-        r = subprocess.run([exe, "5", "17", str(tmp_path / ("g%s-%%d.psmc" % groups))] + args, capture_output=True, text=True, env=dict(env, PSMC_BOOT_GROUPS=groups, PSMC_TIMING="1"))
-        assert r.returncode == 0 and ("%s group(s)" % groups) in r.stderr, r.stderr
+    # the M-steps run on a pool of threads, each replicate's as soon as the batch reports it final: one thread and three write the same files
+    for threads in ("1", "3"):
+        r = subprocess.run([exe, "5", "17", str(tmp_path / ("t%s-%%d.psmc" % threads))] + args, capture_output=True, text=True, env=dict(env, OMP_NUM_THREADS=threads, PSMC_TIMING="1"))
+        assert r.returncode == 0 and ("%s M-step threads" % threads) in r.stderr and "iteration 2: 5 E-steps" in r.stderr, r.stderr
         for k in range(5):
-            assert open(tmp_path / ("g%s-%d.psmc" % (groups, k))).read() == open(tmp_path / ("boot-%d.psmc" % k)).read(), (groups, k)
+            assert open(tmp_path / ("t%s-%d.psmc" % (threads, k))).read() == open(tmp_path / ("boot-%d.psmc" % k)).read(), (threads, k)
 
 
 def test_boot_main_run_beside_replicates(oracle_psmc, tmp_path):
@@ -461,15 +460,14 @@ def test_psmc_boot_binary_fast_mode_close(tmp_path):
         for a, b in zip(ex[1:], fa[1:]):
             assert abs(a["LK"] - b["LK"]) <= 1e-6 * abs(a["LK"])
             assert max(abs(x - y) / y for x, y in zip(b["lam"], a["lam"])) < 1e-3
-    # the E / M pipeline in fast mode: with one group per context (lock step) every replicate meets the same plan history ("batch_first")
-    # and writes the same bytes as with the default two groups
+    # fast mode is reproducible for a given dealing of the replicates over contexts, whatever the M-step threads do
     args5 = ["-N3"] + args[1:]
-    for groups in ("1", "2"):
-        r = subprocess.run([os.path.join(HOST, "psmc_boot"), "-R", "5", "-S", "5", "-O", str(tmp_path / ("g" + groups + "-%d.psmc")), "--"] + args5,
-                           capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_MODE="fast", PSMC_BOOT_GROUPS=groups, PSMC_HIP_DEVICES="0", PSMC_TIMING="1"))
-        assert r.returncode == 0 and (groups + " group(s)") in r.stderr, r.stderr
+    for threads in ("1", "6"):
+        r = subprocess.run([os.path.join(HOST, "psmc_boot"), "-R", "5", "-S", "5", "-O", str(tmp_path / ("g" + threads + "-%d.psmc")), "--"] + args5,
+                           capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_MODE="fast", OMP_NUM_THREADS=threads, PSMC_HIP_DEVICES="0,0", PSMC_TIMING="1"))
+        assert r.returncode == 0 and (threads + " M-step threads") in r.stderr, r.stderr
     for k in range(5):
-        assert open(tmp_path / ("g1-%d.psmc" % k)).read() == open(tmp_path / ("g2-%d.psmc" % k)).read(), k
+        assert open(tmp_path / ("g1-%d.psmc" % k)).read() == open(tmp_path / ("g6-%d.psmc" % k)).read(), k
 
 
 @pytest.mark.gpu

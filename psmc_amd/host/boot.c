@@ -306,8 +306,10 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		P.e_ms = (double *)calloc(ni, sizeof(double)); P.e_end = (double *)calloc(ni, sizeof(double));
 		P.it_end = (double *)calloc(ni, sizeof(double)); P.m_work = (double *)calloc(ni, sizeof(double));
 		/* M-step threads: what the process may use, less the threads that drive the devices (they spin inside the HIP runtime while a batch
-		 * runs) and the main run's; OMP_NUM_THREADS, when set, is taken as given (the M-steps were an OpenMP loop until round 5) */
-		int m_threads = psmc_usable_cpus() - bb->n_dev - (main_started ? 1 : 0);
+		 * runs), the main run's, and two for the runtime's own helpers -- the M-steps now run WHILE the device threads feed the device, and a
+		 * process that overdraws its CPU quota is stopped whole; OMP_NUM_THREADS, when set, is taken as given (the M-steps were an OpenMP
+		 * loop until round 5) */
+		int m_threads = psmc_usable_cpus() - bb->n_dev - (main_started ? 1 : 0) - 2;
 		if (m_threads < 1) m_threads = 1;
 		if (getenv("OMP_NUM_THREADS") && atoi(getenv("OMP_NUM_THREADS")) > 0) m_threads = atoi(getenv("OMP_NUM_THREADS"));
 		if (m_threads > n_rep) m_threads = n_rep;

@@ -136,9 +136,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           0 when a launch has more than one wave per SIMD (bootstrap batch), else 1
  *  "batch_bins"    0        psmc_hip_estep_batch: table bins per launch; 0 = what fits the free device memory
  *  "batch_first"   0        psmc_hip_estep_batch, fast mode: replicate 0 of the calls that follow is replicate <value> of the context's
- *                           replicates -- a caller that sends its replicates in several groups (psmc_boot: the M-steps of one group run
- *                           under the E-steps of the next) names each group's first position, so that every replicate meets the tile plan
- *                           it had in the previous EM iteration.  Exact mode keeps nothing per replicate and ignores it.
+ *                           replicates -- a caller that sends its replicates in several calls names each call's first position, so that
+ *                           every replicate meets the tile plan it had in the previous EM iteration.  Exact mode keeps nothing per
+ *                           replicate and ignores it.
  *  "batch_sort"    1        psmc_hip_estep_batch: the entries -- (replicate, segment) sweeps -- of ALL replicates are dealt to the launches
  *                           longest first, so that the long trunks share one launch and the others end with their own, shorter, longest
  *                           entry; 0 = replicate-major order (every launch then lasts as long as the longest trunk).  Bit-identical.

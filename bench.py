@@ -406,7 +406,7 @@ def boot_extra(n_rep=16, iters=3):
     tmp = tempfile.mkdtemp(prefix="psmc_bench_")
     fd = nd.files(tmp)
     res = {"workload": "%d trunks, %d bins, longest %d; %d replicates, -N%d -t15 -r5 -p %s" % (fd["n_trunks"], fd["trunk_bins"], fd["longest_trunk"], n_rep, iters, PATTERN),
-           "note": "psmc_boot binary (psmc_hip_estep_batch under it): all replicates in lock step, E-steps batched on the device, M-steps on host threads; "
+           "note": "psmc_boot binary (psmc_hip_estep_batch_cb under it): the E-steps of a context's replicates as one batch on the device, each replicate's M-step on a host thread as soon as the batch reports it final; msteps = what is left of them after the last batch; "
                    "per_iteration_ms covers ALL replicates; exact_with_main: the same plus the main run of the 90-segment genome on a thread of its own (--main)"}
     try:
         for m in ("fast", "exact", "exact_with_main"):

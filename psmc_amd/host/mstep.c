@@ -56,63 +56,84 @@ double psmc_Q(int n, const double *a, const double *e, const double *A, const do
 	return sum - Q0;
 }
 
-/* ---- Hooke-Jeeves direct search: RESTATED from lh3/psmc kmin.c:48-107, statement order kept on purpose (the search
- * branches on `<` of nearly equal objective values, so a byte-identical .psmc needs the same evaluation order).
- * kmin.c is Copyright (c) 2008, by Heng Li <lh3@live.co.uk>, MIT License ("Based on the pseudocodes by Bell and Pike
- * (CACM 9(9):684-685), and the revision by Tomlin and Smith (CACM 12(11):637-638)"); the full notice is in /NOTICE. */
-/* one exploratory sweep around x1 along every axis (kmin.c:48-66) */
-static double explore(psmc_objective f, int n, double *x1, void *data, double fx1, double *dx, int *calls)
+/* ---- Hooke-Jeeves direct search (Hooke & Jeeves 1961; Bell & Pike, CACM 9(9):684-685; Tomlin & Smith, CACM 12(11):637-638).
+ *
+ * The search compares nearly equal objective values with `<`, so a byte-identical .psmc needs the reference's search to the
+ * last evaluation: the same trial points (each coordinate produced by the same additions, rounding included), in the same
+ * order, with the same acceptance tests -- kmin.c:48-107 of lh3/psmc, Copyright (c) 2008 Heng Li, MIT License (full notice
+ * in /NOTICE).  Own here: the decomposition into a search state with three moves (sweep, advance, shrink); the arithmetic
+ * of each move is the reference's and is marked. */
+typedef struct {
+	psmc_objective f; void *data;
+	int n, calls, max_calls;
+	double *step;  /* signed step per axis: the sign remembers which direction last helped */
+} hj_search;
+
+static double hj_eval(hj_search *S, double *pt) { ++S->calls; return S->f(S->n, pt, S->data); }
+
+/* Sweep: along every axis in turn move `pt` by the axis' step; if that is no better, turn the step round and try the other side;
+ * if neither helps, put the coordinate back.  The three updates of pt[k] are kmin.c:54-63's -- pt[k] + d, then + (-d + -d), then
+ * - (-d): not the same double as "the old value" in general, and the search's later points depend on it. */
+static double hj_sweep(hj_search *S, double *pt, double f_pt)
 {
-	for (int k = 0; k < n; ++k) {
-		x1[k] += dx[k];
-		double ft = f(n, x1, data); ++*calls;
-		if (ft < fx1) fx1 = ft;
-		else { /* try the opposite direction */
-			dx[k] = 0.0 - dx[k];
-			x1[k] += dx[k] + dx[k];
-			ft = f(n, x1, data); ++*calls;
-			if (ft < fx1) fx1 = ft;
-			else x1[k] -= dx[k];
-		}
+	for (int k = 0; k < S->n; ++k) {
+		pt[k] += S->step[k];
+		double f_try = hj_eval(S, pt);
+		if (f_try < f_pt) { f_pt = f_try; continue; }
+		S->step[k] = 0.0 - S->step[k];
+		pt[k] += S->step[k] + S->step[k];
+		f_try = hj_eval(S, pt);
+		if (f_try < f_pt) f_pt = f_try;
+		else pt[k] -= S->step[k];
 	}
-	return fx1;
+	return f_pt;
 }
 
+/* Advance: the sweep's result becomes the base, and the next trial point lies as far beyond it as it lies beyond the old base
+ * (kmin.c:78-83); every step now points the way its axis moved. */
+static void hj_advance(hj_search *S, double *base, double *trial)
+{
+	for (int k = 0; k < S->n; ++k) {
+		const double old = base[k];
+		S->step[k] = trial[k] > base[k] ? fabs(S->step[k]) : 0.0 - fabs(S->step[k]);
+		base[k] = trial[k];
+		trial[k] = trial[k] + trial[k] - old;
+	}
+}
+
+/* did the last sweep leave the pattern point on any axis by more than half a step?  (kmin.c:90-93) */
+static int hj_left_pattern(const hj_search *S, const double *base, const double *trial)
+{
+	for (int k = 0; k < S->n; ++k)
+		if (fabs(trial[k] - base[k]) > .5 * fabs(S->step[k])) return 1;
+	return 0;
+}
+
+/* Minimises f from x (updated in place to the last accepted base point).  Returns the value of the last SWEEP, which is what
+ * kmin_hj returns -- not necessarily f(x) (the caller, like em.c:67, only prints it). */
 double psmc_hooke_jeeves(psmc_objective f, int n, double *x, void *data, double r, double eps, int max_calls)
 {
-	double *x1 = (double *)calloc((size_t)n, sizeof(double)), *dx = (double *)calloc((size_t)n, sizeof(double));
-	int calls = 0;
-	for (int k = 0; k < n; ++k) { dx[k] = fabs(x[k]) * r; if (dx[k] == 0) dx[k] = r; }
-	double radius = r, fx, fx1;
-	fx1 = fx = f(n, x, data); ++calls;
+	hj_search S = {f, data, n, 0, max_calls, (double *)calloc((size_t)n, sizeof(double))};
+	double *trial = (double *)calloc((size_t)n, sizeof(double));
+	for (int k = 0; k < n; ++k) { S.step[k] = fabs(x[k]) * r; if (S.step[k] == 0) S.step[k] = r; }
+	double radius = r, f_base = hj_eval(&S, x), f_trial = f_base;
 	for (;;) {
-		memcpy(x1, x, sizeof(double) * (size_t)n);
-		fx1 = explore(f, n, x1, data, fx, dx, &calls);
-		while (fx1 < fx) { /* pattern moves */
-			for (int k = 0; k < n; ++k) {
-				const double t = x[k];
-				dx[k] = x1[k] > x[k] ? fabs(dx[k]) : 0.0 - fabs(dx[k]);
-				x[k] = x1[k];
-				x1[k] = x1[k] + x1[k] - t;
-			}
-			fx = fx1;
-			if (calls >= max_calls) break;
-			fx1 = f(n, x1, data); ++calls;
-			fx1 = explore(f, n, x1, data, fx1, dx, &calls);
-			if (fx1 >= fx) break;
-			int k;
-			for (k = 0; k < n; ++k)
-				if (fabs(x1[k] - x[k]) > .5 * fabs(dx[k])) break;
-			if (k == n) break;
+		memcpy(trial, x, sizeof(double) * (size_t)n);
+		f_trial = hj_sweep(&S, trial, f_base);
+		while (f_trial < f_base) { /* pattern moves for as long as they pay */
+			hj_advance(&S, x, trial);
+			f_base = f_trial;
+			if (S.calls >= S.max_calls) break;
+			f_trial = hj_eval(&S, trial);
+			f_trial = hj_sweep(&S, trial, f_trial);
+			if (f_trial >= f_base || !hj_left_pattern(&S, x, trial)) break;
 		}
-		if (radius >= eps) {
-			if (calls >= max_calls) break;
-			radius *= r;
-			for (int k = 0; k < n; ++k) dx[k] *= r;
-		} else break;
+		if (radius < eps || S.calls >= S.max_calls) break;
+		radius *= r; /* shrink: the same search, half the steps */
+		for (int k = 0; k < n; ++k) S.step[k] *= r;
 	}
-	free(x1); free(dx);
-	return fx1;
+	free(trial); free(S.step);
+	return f_trial;
 }
 
 typedef struct {

@@ -74,6 +74,22 @@ def test_host_logic_byte_identical(oracle_psmc, name):
         assert len(a) == len(b)
 
 
+@pytest.mark.parametrize("args", [["-N25", "-t15", "-r5", "-p", "4+25*2+4+6", "small.psmcfa"], ["-N30", "-t15", "-r5", "-p", "4+5*3+4", "t10k.psmcfa"],
+                                  ["-N8", "-t15", "-r5", "-T", "0.1", "-p", "4+5*3+4", "small.psmcfa"]])
+def test_long_em_runs_equal_the_reference_binary(oracle_psmc, args):
+    """The host driver (model.c's interval factors expanded to the matrix, mstep.c's Hooke-Jeeves search, run.c's output) over 25-30
+    EM rounds -- tens of thousands of objective calls, each deciding the next trial point with `<` -- against the reference's own
+    binary built from its sources (oracle/_ref/psmc_ref): the same bytes.  Skipped where that binary did not travel."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "psmc_ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/psmc_ref not built (make -C oracle ref needs /root/reference)")
+    a = args[:-1] + [os.path.join(CLI, args[-1])]
+    want = subprocess.run([ref] + a, capture_output=True, text=True)
+    got = subprocess.run([oracle_psmc] + a, capture_output=True, text=True)
+    assert want.returncode == 0 and got.returncode == 0, (want.stderr[-500:], got.stderr[-500:])
+    assert got.stdout == want.stdout and want.stdout.count("\nRD\t") >= 9
+
+
 @pytest.mark.parametrize("factored", ["0", "1"])
 def test_fast_mstep_objective_close(oracle_psmc, factored):
     """PSMC_FAST_MSTEP=1 (the O(N) objective PSMC_HIP_MODE=fast uses: 5N logarithms and the triangular

@@ -151,6 +151,7 @@ static int estep_device(pipeline *P, int d, int it)
 	const int N = P->N, nd = bb->n_dev;
 	const int cnt = P->n_rep > d ? (P->n_rep - d + nd - 1) / nd : 0;
 	int tot = 0;
+	if (cnt == 0) return 0; /* more devices than replicates: nothing for this one */
 	for (int j = 0; j < cnt; ++j) tot += rep[d + j * nd].n_idx;
 	double *a = (double *)malloc(sizeof(double) * (size_t)cnt * N * N), *e = (double *)malloc(sizeof(double) * (size_t)cnt * 2 * N);
 	double *a0 = (double *)malloc(sizeof(double) * (size_t)cnt * N);

@@ -209,6 +209,23 @@ def test_usable_cpus_follow_the_cgroup_quota(host):
     assert n == want and n >= 1
 
 
+def test_model_update_equals_reference_on_random_parameters(reference):
+    """model.c (the interval factors and their expansion to a / e / a0) against the reference's psmc_update_hmm (core.c:61-133, through
+    oracle/_ref) on random parameter vectors -- orders of magnitude apart in theta, rho, max_t and the lambdas, so that the closed form
+    of the mean coalescence time also leaves its interval and takes the fallback (core.c:113-114): every double the same."""
+    from psmc_amd import hostlib
+    rng = np.random.default_rng(20260927)
+    for pattern in ("4+5*3+4", "4+25*2+4+6", "64*2", "1*10", "3+2*17+15*1+1*12"):
+        n_free = reference.parse_pattern(pattern)[1]
+        for trial in range(40):
+            theta = 10.0 ** rng.uniform(-4, -0.5); rho = 10.0 ** rng.uniform(-5, -0.5); max_t = 10.0 ** rng.uniform(-0.3, 1.7)
+            lam = 10.0 ** rng.uniform(-2.5, 2.5, size=n_free) if trial % 3 else 10.0 ** rng.uniform(-0.3, 0.3, size=n_free)
+            params = np.concatenate([[theta, rho, max_t], lam])
+            want = reference.hmm_params(pattern, params)
+            a, e, a0 = hostlib.hmm_params(pattern, params)
+            assert a.tobytes() == want["a"].tobytes() and e[:2].tobytes() == want["e"][:2].tobytes() and a0.tobytes() == want["a0"].tobytes(), (pattern, trial)
+
+
 def test_pattern_kats(host, golden):
     """psmc_parse_pattern KATs (cli.c:66-99): '4+5*3+4' -> n=22, 7 free; '4+25*2+4+6' -> 63, 28; '64*2' -> 127, 64."""
     for key, v in golden.kats.items():

@@ -300,6 +300,29 @@ def test_hooke_jeeves_kat(host, golden):
     assert np.allclose(x0, x, atol=1e-6) and abs(fx - float(golden.kats["kmin.fx"])) < 1e-9
 
 
+def test_hooke_jeeves_equals_reference_search_bit_for_bit(host, reference):
+    """mstep.c's search (sweep / advance / shrink) against the reference's kmin_hj (kmin.c:48-107, through oracle/_ref) on the SAME
+    compiled objective (tests/host_hj_check.c = the quadratic of oracle/ref_shim.c), random centres and starts incl. zeros (a zero
+    coordinate gets the absolute step r): every coordinate of the end point and the returned value, bit for bit."""
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libhjcheck.so")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "host_hj_check.c"), "-I" + HOST, "-L" + HOST,
+                    "-lpsmc_host", "-Wl,-rpath," + HOST, "-lm"], check=True)
+    lib = C.CDLL(so)
+    lib.mine_kmin_quad.restype = C.c_double
+    lib.mine_kmin_quad.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        n = int(rng.integers(1, 30))
+        centre = rng.normal(size=n) * 10.0 ** rng.uniform(-2, 2)
+        x0 = rng.normal(size=n) * 10.0 ** rng.uniform(-2, 2)
+        x0[rng.random(n) < 0.15] = 0.0
+        xr, fr = reference.kmin_quad(x0.copy(), centre.copy())
+        xm = x0.copy()
+        fm = lib.mine_kmin_quad(n, xm.ctypes.data_as(C.POINTER(C.c_double)), centre.ctypes.data_as(C.POINTER(C.c_double)), 50000)
+        assert xm.tobytes() == np.asarray(xr).tobytes() and np.float64(fm).tobytes() == np.float64(fr).tobytes(), trial
+
+
 def test_resample_kat(host, golden):
     """psmc_resamp (aux.c:8-47) with a fixed srand48 seed picks the same multiset in the same order."""
     lens = golden.kats["resample.lens"]

@@ -205,10 +205,11 @@ int psmc_hip_reserve_tables(psmc_hip_ctx *ctx);
  * segments (psmc_resamp, aux.c:8-47: repeats allowed, order matters for the exact sum).  Replaces n_rep runs of
  * em.c:33-55, i.e. what README:57-62 of the reference farms out with xargs.  Outputs, any may be NULL but one of
  * A / sums is needed: A n_rep*n*n, sums n_rep*5n (SL|SU|DG|CL|CU as psmc_hip_estep_factored), E n_rep*2n, LL n_rep.
- *   exact mode: the sweeps of all replicates that fit the table memory run in ONE grid per kernel (replicate-major;
- *     one wave per (replicate, unique segment)), so the device holds hundreds of sweeps instead of one replicate's
- *     dozens; results are bit-identical to n_rep separate psmc_hip_select + psmc_hip_estep calls.  "batch_bins"
- *     (psmc_hip_set_option) caps the table bins per group; default: what fits the free memory.
+ *   exact mode: an ENTRY is one (replicate, unique segment) sweep, one wave; the entries of all replicates are dealt to launches
+ *     by length (options "batch_sort", "batch_tailfill", "batch_major"), as many per launch as table memory and wave slots hold,
+ *     so the device holds hundreds of sweeps instead of one replicate's dozens; results are bit-identical to n_rep separate
+ *     psmc_hip_select + psmc_hip_estep calls whatever the dealing.  "batch_bins" caps the table bins per launch; default: what
+ *     fits the free memory.
  *   fast mode: one replicate fills the device, so they run back to back, each on its own learned tile plan (kept in
  *     a per-replicate child context that shares this context's observations and tables); sums = factored statistics.
  * Segment tables are in batch layout afterwards: decode / get_tables need a single E-step first. */

@@ -252,8 +252,10 @@ int psmc_hip_estep_device(psmc_hip_ctx *ctx, const double *a, const double *e, c
 int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err_bwd, int *n_chunks,
                        int *warmup_used);
 /* How much repair the speculation needed: verify/repair rounds and the total
- * number of tile re-runs, forward and backward; out[0..3]. */
-int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[4]);
+ * number of tile re-runs, forward and backward, out[0..3]; out[4] = forward
+ * repairs that stopped where they met the stored trajectory ("merge_cap"),
+ * out[5] = 1 when a second pass of the counts had to run. */
+int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[6]);
 /* Diagnostic: the plan the NEXT fast E-step of this context will run with: out = {tiles, tile length in bins, mean forward
  * warm-up of the speculating tiles in bins, mean backward warm-up, longest forward, longest backward, tiles glued to their
  * predecessor (forward), tiles glued to their successor (backward)}. */

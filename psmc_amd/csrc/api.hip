@@ -158,6 +158,11 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 		for (void *p : mine) if (p) (void)hipFree(p);
 		if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 		if (c->h_ritems) (void)hipHostFree(c->h_ritems);
+		if (c->h_mlen) (void)hipHostFree(c->h_mlen);
+		if (c->h_chunks) (void)hipHostFree(c->h_chunks);
+		if (c->h_mis) (void)hipHostFree(c->h_mis);
+		if (c->d_prevx) (void)hipFree(c->d_prevx);
+		if (c->d_finv) (void)hipFree(c->d_finv);
 		delete c;
 		return;
 	}
@@ -175,6 +180,11 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
 	if (c->h_ritems) (void)hipHostFree(c->h_ritems);
+	if (c->h_mlen) (void)hipHostFree(c->h_mlen);
+	if (c->h_chunks) (void)hipHostFree(c->h_chunks);
+	if (c->h_mis) (void)hipHostFree(c->h_mis);
+	if (c->d_prevx) (void)hipFree(c->d_prevx);
+	if (c->d_finv) (void)hipFree(c->d_finv);
 	for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 14; ++i) if (c->evx[i]) (void)hipEventDestroy(c->evx[i]);
 	if (c->stream4) (void)hipStreamDestroy(c->stream4);
@@ -196,6 +206,10 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "max_rounds") c->max_rounds = (int)v;
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
+	else if (k == "merge") { c->merge = v != 0 ? 1 : 0; }
+	else if (k == "adapt_margin") { if (v < 0 || v > 6) return PSMC_HIP_EINVAL; c->adapt_margin = v; }
+	else if (k == "adapt") { c->adapt = v != 0 ? 1 : 0; c->plan_dirty = true; }
+	else if (k == "prev_start") { c->prev_start = v != 0 ? 1 : 0; c->prev_ok = false; }
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
 	else if (k == "runs_late") { c->runs_late = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
@@ -448,6 +462,7 @@ int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins, bool need_f)
 		c->tab_bins = c->parent->tab_bins; c->have_b = c->parent->have_b;
 		return rc;
 	}
+	++c->tab_serial; // whoever asks for the tables is about to write them (api_fast.hip: is the X of the last fast E-step still there?)
 	const int64_t bins = std::max(c->total, want_bins) + 128;
 	int rc = ensure_tables_once(c, need_b, bins, need_f);
 	if (rc == PSMC_HIP_ENOMEM && c->tab_bins > bins) {

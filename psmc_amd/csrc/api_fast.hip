@@ -114,9 +114,18 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_bexit, (size_t)(nc + 1) * c->ns))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bentry, (size_t)nc * c->ns))) return rc;
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_touch, (size_t)2 * nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_touch, (size_t)3 * nc))) return rc; // touch_f | touch_b | fmerge
+		if ((rc = dev_alloc(c, &c->d_finv, (size_t)nc))) return rc;
+		if ((rc = dev_alloc(c, &c->d_prevx, (size_t)nc * c->ns))) return rc;
+		if (c->h_mlen) { (void)hipHostFree(c->h_mlen); c->h_mlen = nullptr; }
+		if (c->h_mis) { (void)hipHostFree(c->h_mis); c->h_mis = nullptr; }
+		if (hipHostMalloc((void **)&c->h_mlen, (size_t)nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+		    hipHostGetDevicePointer((void **)&c->m_mlen, c->h_mlen, 0) != hipSuccess ||
+		    hipHostMalloc((void **)&c->h_mis, (size_t)2 * nc * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+		    hipHostGetDevicePointer((void **)&c->m_mis, c->h_mis, 0) != hipSuccess)
+			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_items, (size_t)30 * nc + 64))) return rc; // (+ 4 nc: matrix slot of every KcTile | the KcTile that computes a slot)
+		if ((rc = dev_alloc(c, &c->d_items, (size_t)32 * nc + 64))) return rc; // (+ 4 nc: matrix slot of every KcTile | the KcTile that computes a slot; + 2 nc: the fix pass's tiles)
 		if ((rc = dev_alloc(c, &c->d_ftiles, (size_t)2 * (nc + 16)))) return rc;
 		if (c->h_ritems) { (void)hipHostFree(c->h_ritems); c->h_ritems = nullptr; }
 		if (hipHostMalloc((void **)&c->h_ritems, (size_t)4 * nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
@@ -148,7 +157,7 @@ static int plan_fast(psmc_hip_ctx *c)
 			if (b + 1 < nc && c->gap[b + 1] && same(b, b + 1)) c->glue_b[b] = 1;  // ... and backward
 		}
 	}
-	c->plan_dirty = false; c->chunks_dirty = false;
+	c->plan_dirty = false; c->chunks_dirty = false; c->prev_ok = false;
 	return 0;
 }
 
@@ -266,6 +275,8 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 			}
 	}
 	c->n_items_f = (int)kf.size(); c->n_items_b = (int)kb.size();
+	c->order_f.clear();
+	for (const auto &it : kf) if (!in_run_f[it.second.first]) c->order_f.push_back(it.second.first);
 	c->n_long_f = c->n_long_b = 0; // glued runs sort first (more steps than any single tile)
 	while (c->n_long_f < c->n_items_f && in_run_f[kf[c->n_long_f].second.first]) ++c->n_long_f;
 	while (c->n_long_b < c->n_items_b && in_run_b[kb[c->n_long_b].second.first]) ++c->n_long_b;
@@ -290,6 +301,14 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 		if (!sg.empty()) HIPCHK(c, hipMemcpy(c->d_items + (size_t)24 * nc, sg.data(), sizeof(int) * sg.size(), hipMemcpyHostToDevice));
 	}
 	HIPCHK(c, hipMemcpy(c->d_items + (size_t)8 * nc, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
+	{ // the forward fix pass (estep_struct.hip FwdCtl) right after the bulk sweep: every tile outside the forward runs whose predecessor is outside
+	  // them too (a bulk tile above a run is checked against a row the runs' path writes later: left to the verify that follows the back half)
+		std::vector<int> fx;
+		for (int b = 0; b < nc; ++b)
+			if (!in_run_f[b] && !(b > 0 && in_run_f[b - 1] && same_seg(b - 1, b))) { fx.push_back(b); fx.push_back(1); }
+		c->n_fix_f = (int)fx.size() / 2;
+		if (!fx.empty()) HIPCHK(c, hipMemcpy(c->d_items + (size_t)30 * nc, fx.data(), sizeof(int) * fx.size(), hipMemcpyHostToDevice));
+	}
 	// Walk lists and transfer-matrix chains.  A run of >= kc_min tiles is a "chain run": a walk delivers the start vector
 	// of its head tile (the usual speculative warm-up, nothing more: walk item with count <= 0, see k_walk1_struct; round 1
 	// and most of round 2 also walked THROUGH the head tile, 3712 dependent steps whose result nobody read -- measured
@@ -416,12 +435,59 @@ static void learn_groups(psmc_hip_ctx *c)
 	}
 }
 
+// Per-tile forward warm-ups (round 6).  Round 3 built this once and took it out again: a tile whose shrunken warm-up overshot cost a repair
+// round of 8 ms (the whole tile again, then its group of the counts again), so the plan had to be sized by its slowest tiles.  With the fix
+// pass (estep_struct.hip FwdCtl) a tile that falls short is rewritten for the blocks it was short by, before the back half starts, and
+// nothing is counted twice -- so every speculating tile can follow what ITS stretch of the sequence needs: the pass leaves the mismatch of
+// every speculation and the blocks every repair took (host-mapped memory); a tile that failed gets the bins its repair needed, plus a margin; a
+// tile more than a decade inside the tolerance gives up part of the surplus, an eighth of its warm-up at most per E-step (at 1e-16 the
+// measurement is at its floor: all it says is "at least four decades").  Tiles anchored at their segment's start, members and heads of glued
+// runs keep what they have.  What this buys is bounded by profiles/r06_warmup_sensitivity.txt: half the warm-up at no cost at all is 0.35 ms
+// of 12.25 (the forward sweep ends earlier, the runs' path then overlaps the counts instead).
+static void adapt_warmups(psmc_hip_ctx *c)
+{
+	const int nc = (int)c->chunks.size();
+	const int cap = c->warmup << c->warm_shift_used, floor_w = std::min(c->warmup, 256);
+	const double tol = c->warm_tol;
+	bool changed = false;
+	for (int b = 0; b < nc; ++b) {
+		const double m = c->h_mis[b];
+		if (!(m > 0.0)) continue; // not checked (anchored, first tile), or not a speculation (inside a bulk item: bitwise its neighbour's vector)
+		if (c->glue_f[b] || (b + 1 < nc && c->glue_f[b + 1] && c->chunks[b + 1].off == c->chunks[b].off)) continue;
+		Chunk &ch = c->chunks[b];
+		if (ch.lo - ch.wf <= 1) continue; // the warm-up reaches the start of the segment: exact
+		int w = ch.wf;
+		if (m > tol) {
+			const int ml = c->h_mlen[b]; // blocks the fix pass rewrote; -1: the whole tile
+			w = std::min(std::max(cap, w), w + (ml > 0 ? 16 * ml + 64 : w));
+		} else {
+			const double slack = log10(tol / std::max(m, 1e-17)), keep = c->adapt_margin; // decades inside the tolerance; the parameters of the next E-step are other parameters
+			if (slack > keep) w = std::max(floor_w, w - (((int)std::min((slack - keep) * 160.0, w / 8.0) + 15) & ~15));
+		}
+		if (w != ch.wf) { ch.wf = w; changed = true; }
+	}
+	if (changed) {
+		c->chunks_dirty = true;
+		// The four rows of a wave should end together: the items were sorted by step count when the lists were built, and the warm-ups have
+		// moved since.  Issue slots the bulk forward sweep now wastes on rows that are done while another row of their wave is not: when
+		// they pass 3 % of its work, sort again (build_items: a few hundred microseconds of host time).
+		int64_t total = 0, waste = 0;
+		for (size_t i = 0; i + 3 < c->order_f.size(); i += 4) {
+			int64_t s4 = 0, mx = 0;
+			for (int r = 0; r < 4; ++r) { const Chunk &ch = c->chunks[c->order_f[i + r]]; const int64_t st = (int64_t)ch.hi - std::max(1, ch.lo - ch.wf) + 1; s4 += st; mx = std::max(mx, st); }
+			total += 4 * mx; waste += 4 * mx - s4;
+		}
+		if (total > 0 && waste * 100 > total * 3) c->items_dirty = true;
+	}
+}
+
 int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double *a0, double *d_out,
                         hipStream_t st)
 {
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "estep: no segments loaded");
 	int rc;
+	const unsigned long long serial0 = dbg_root(c)->tab_serial; // has anybody used the tables since this context's last fast E-step?
 	if ((rc = ensure_tables(c, false))) return rc;
 	c->tables_batch = false;
 	if ((rc = stage_params(c, a, e, a0, st))) return rc; // also decides whether the structured sweeps apply
@@ -444,9 +510,17 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	// from the exit vectors of the first at no cost in scheduling, and half of the backward warm-up pass disappears)
 	const bool two_phase_bwd = c->two_phase_used >= 1 && p.fused == 1; // the fused back half only: the factored one is a single pass over item lists
 	p.merge1 = c->merge1_used; p.merge_order = c->merge_order >= 0 ? c->merge_order : (c->chunk_used < c->warmup ? 1 : 0);
-	if (c->chunks_dirty) { // learned warm-ups (learn_groups) reach the device before the next launch reads them
-		HIPCHK(c, hipStreamSynchronize(st));
-		HIPCHK(c, hipMemcpy(c->d_chunks, c->chunks.data(), sizeof(Chunk) * c->chunks.size(), hipMemcpyHostToDevice));
+	if (c->chunks_dirty) { // learned / adapted warm-ups (learn_groups, adapt_warmups) reach the device before the next launch reads them
+		// (from a pinned copy, on the E-step's stream: a blocking copy of pageable memory waits for every kernel on the device, and with
+		// per-tile warm-ups this happens before every E-step)
+		if (c->h_chunks_cap < c->chunks.size()) {
+			if (c->h_chunks) { (void)hipHostFree(c->h_chunks); c->h_chunks = nullptr; }
+			if (hipHostMalloc((void **)&c->h_chunks, sizeof(Chunk) * c->chunks.size(), hipHostMallocDefault) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
+			c->h_chunks_cap = c->chunks.size();
+		}
+		HIPCHK(c, hipStreamSynchronize(st)); // (the previous copy out of the same buffer is done)
+		memcpy(c->h_chunks, c->chunks.data(), sizeof(Chunk) * c->chunks.size());
+		HIPCHK(c, hipMemcpyAsync(c->d_chunks, c->h_chunks, sizeof(Chunk) * c->chunks.size(), hipMemcpyHostToDevice, st));
 		c->chunks_dirty = false;
 	}
 	// coarse bulk items: the fused and the factored back half only (their backward pass of phase 1 leaves start vectors, no table)
@@ -468,6 +542,19 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 		const size_t nc_ = c->chunks.size(), S_ = (size_t)c->ns;
 		const size_t need = p.fused == 2 ? nc_ * 7 * S_ + 64 : (p.fused == 1 ? (nc_ / 4 + 8) * S_ * S_ : nc_ * (size_t)c->n_sub_used * S_ * S_);
 		if (c->cpart_cap < need) { if ((rc = dev_alloc(c, &c->d_Cpart, need))) return rc; c->cpart_cap = need; }
+	}
+	{
+		// the forward fix pass: where the back half knows about its merge records (the fused one of a 64-state model), tiles of whole 16-bin blocks
+		c->merge_used = c->merge != 0 && c->use_struct && p.fused == 1 && c->ns == 64 && c->chunk_used % 16 == 0;
+		p.merge = c->merge_used ? 1 : 0;
+		p.d_fmerge = c->d_touch + 2 * (size_t)p.n_chunks; p.d_finv = c->d_finv; p.m_mlen = c->m_mlen; p.h_mlen = c->h_mlen; p.m_mis = c->m_mis;
+		p.d_fix_f = c->d_items + 30 * (size_t)p.n_chunks; p.n_fix_f = c->n_fix_f;
+		if (c->h_mlen) memset(c->h_mlen, 0, sizeof(int) * p.n_chunks); // (the E-step that wrote it is over: launch_fast reads the verify counts before it returns)
+		if (c->h_mis) for (int b = 0; b < p.n_chunks; ++b) c->h_mis[b] = -1.0; // "not measured": the tiles neither fix launch looks at keep their warm-ups
+		// forward warm-ups from the previous E-step's X: same plan, same kind of table, and nobody else has used the tables in between
+		const bool prev = c->prev_start && c->prev_ok && c->use_struct && c->prev_serial == serial0 && c->prev_f == c->d_f && c->prev_ckpt == p.ckpt;
+		p.d_prevx = prev ? c->d_prevx : nullptr;
+		c->prev_ok = false;
 	}
 	p.d_gate = (c->gate >= 0 ? c->gate != 0 : coarse > 1) ? c->d_gate : nullptr;
 	p.coarse = coarse; p.d_singles_b = c->d_items + 24 * (size_t)p.n_chunks; p.n_singles_b = c->n_singles_b;
@@ -494,6 +581,7 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	for (int i = 0; i < 14; ++i) p.evx[i] = c->evx[i];
 	p.d_LLpart = c->d_LLpart; p.d_stage = c->d_stage; p.d_stats = d_out; p.d_warm = c->d_warm;
 	p.tiny_total = (double)c->sel.size() * HMM_TINY_H;
+	if (p.d_prevx) launch_gather_prev(p, st, c->n_long_f, c->n_items_f - c->n_long_f, c->d_prevx); // before the sweep overwrites those rows
 	{
 		const double t0 = dbg_now();
 		if (launch_fast(p, &c->report) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_fast", hipGetLastError());
@@ -508,14 +596,24 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 			for (size_t i = 0; i < u.size() && i < 400; ++i) {
 				const int b = u[i]; const Chunk &ch = c->chunks[b];
 				int seg = 0; while (seg + 1 < c->n_seg && c->off[seg + 1] <= ch.off) ++seg;
-				fprintf(stderr, " [t%d seg%d %d..%d w%d g%d x%d]", b, seg, ch.lo, ch.hi, bwd ? ch.wb : ch.wf, (int)glue[b], (int)std::count(fl.begin(), fl.end(), b));
+				fprintf(stderr, " [t%d seg%d %d..%d w%d g%d x%d m%.1e ml%d]", b, seg, ch.lo, ch.hi, bwd ? ch.wb : ch.wf, (int)glue[b], (int)std::count(fl.begin(), fl.end(), b),
+				        c->h_mis ? c->h_mis[(bwd ? c->chunks.size() : 0) + b] : 0.0, (!bwd && c->h_mlen) ? c->h_mlen[b] : 0);
 			}
 			fprintf(stderr, "\n");
 		};
 		dump("fwd", c->flagged_f, c->glue_f, false); dump("bwd", c->flagged_b, c->glue_b, true);
 	}
 	if (!c->report.converged) return fail(c, PSMC_HIP_ECONVERGE, "fast mode: tile boundaries did not converge within max_rounds");
+	if (c->merge_used && c->h_mlen)
+		for (size_t b = 0; b < c->chunks.size(); ++b) {
+			c->report.merged += c->h_mlen[b] > 0;
+			// what the fix pass had to rewrite to its end -- or, without per-tile warm-ups, at all -- is what the plan learns from, like a
+			// tile the verify rounds flag: a longer warm-up of its own first, then glued to its neighbour (learn_groups)
+			if (c->h_mlen[b] < 0 || (c->h_mlen[b] > 0 && !c->adapt)) c->flagged_f.push_back((int)b);
+		}
+	if (c->use_struct && c->adapt && c->merge_used && c->h_mis) adapt_warmups(c); // (only where falling short is cheap)
 	if (c->use_struct && c->learn) learn_groups(c);
+	if (c->use_struct) { c->prev_ok = true; c->prev_serial = dbg_root(c)->tab_serial; c->prev_f = c->d_f; c->prev_ckpt = p.ckpt; }
 	return 0;
 }
 
@@ -552,11 +650,12 @@ extern "C" int psmc_hip_fast_diag(psmc_hip_ctx *c, double *wf, double *wb, int *
 	return PSMC_HIP_OK;
 }
 
-extern "C" int psmc_hip_fast_repairs(psmc_hip_ctx *c, int out[4])
+extern "C" int psmc_hip_fast_repairs(psmc_hip_ctx *c, int out[6])
 {
 	if (!c || !out) return PSMC_HIP_EINVAL;
 	out[0] = c->report.fwd_rounds; out[1] = c->report.bwd_rounds;
 	out[2] = c->report.fwd_tiles; out[3] = c->report.bwd_tiles;
+	out[4] = c->report.merged; out[5] = c->report.recounted;
 	return PSMC_HIP_OK;
 }
 

@@ -238,8 +238,10 @@ template <bool BWD, int S>
 __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks, int n_chunks, double tol,
                                                  const double *__restrict__ f, const double *__restrict__ mine,
                                                  const double *__restrict__ bexit, int *__restrict__ dirty,
-                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm, int with_scale)
+                                                 int *__restrict__ cnt, unsigned long long *__restrict__ warm, int with_scale,
+                                                 double *__restrict__ mis)
 {
+	// mis (first verify of an E-step; host-mapped memory): the mismatch itself, for the per-tile warm-ups
 	// with_scale (backward, bt table in use): row lo-1 of the table is written by the tile below as ITS start vector
 	// and read by this tile's counts next to its own bt[lo+1], so the two tiles must agree on the scale as well.  A
 	// warm-up of at least one normalising position leaves the natural scale; without one (warmup < 4) a start vector
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(64) void k_verify(const Chunk *__restrict__ chunks,
 		const int bad = check && !(m <= tol);
 		dirty[b] = bad;
 		if (bad) atomicAdd(cnt, 1);
+		if (mis) mis[b] = check ? m : -1.0;
 		if (check) atomicMax(&warm[BWD ? 1 : 0], (unsigned long long)__double_as_longlong(m));
 	}
 }
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ ch
 template <int S>
 __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, const double *__restrict__ f,
                                              const double *__restrict__ invd, const double *__restrict__ entry,
-                                             double *__restrict__ LLpart)
+                                             double *__restrict__ LLpart, const int *__restrict__ fmerge, const double *__restrict__ finv)
 {
 	const int lane = threadIdx.x;
 	const Chunk c = chunks[blockIdx.x];
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(64) void k_ll(const Chunk *__restrict__ chunks, con
 		if (S == 128) v += f[(c.off + c.L - 1) * S + 64 + lane];
 		ll += log(wave_add(v));
 	}
+	if (fmerge && fmerge[blockIdx.x] > 0) ll -= log(finv[blockIdx.x]); // a merging repair: the rows above its merge point are 1/finv times what the rows below continue to (estep_struct.hip FwdCtl)
 	if (lane == 0) LLpart[blockIdx.x] = ll * (double)c.mult;
 }
 
@@ -592,10 +596,10 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	const dim3 g(p.n_chunks), b(64);
 	const bool ov = p.overlap != 0;
 	hipStream_t sm = p.stream, sa = ov ? p.stream2 : p.stream, sx = ov ? p.stream3 : p.stream;
-	rep->fwd_rounds = rep->bwd_rounds = rep->fwd_tiles = rep->bwd_tiles = 0;
+	rep->fwd_rounds = rep->bwd_rounds = rep->fwd_tiles = rep->bwd_tiles = rep->merged = rep->recounted = 0;
 	rep->converged = 1;
 	(void)hipMemsetAsync(p.d_warm, 0, 2 * sizeof(unsigned long long), sm);
-	(void)hipMemsetAsync(p.d_touch_f, 0, 2 * sizeof(int) * (size_t)p.n_chunks, sm); // touch_f | touch_b
+	(void)hipMemsetAsync(p.d_touch_f, 0, 3 * sizeof(int) * (size_t)p.n_chunks, sm); // touch_f | touch_b | fmerge
 	if (p.d_gate) (void)hipMemsetAsync(p.d_gate, 0, 2 * sizeof(int), sm); // started-counters of the walks and of the bulk grid
 	if (p.ev[0]) (void)hipEventRecord(p.ev[0], sm);
 	(void)hipEventRecord(p.evx[0], sm);
@@ -625,6 +629,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	if (gated) launch_gate(sm, p.d_gate, walk_blocks(p));
 	if (mg) {
 		launch_sweeps(p, sm, ff0, p.n_items_f - ff0, fb0, p.n_items_b - fb0 - p.n_B_b, true);
+		if (p.merge) launch_fwd_struct(p, sm, 6, 0, p.n_fix_f); // the fix pass: the back half finds every bulk tile's forward table final
 		(void)hipEventRecord(p.evx[1], sm);
 	}
 	if (lw) {
@@ -655,7 +660,13 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (p.ev[6]) (void)hipEventRecord(p.ev[6], sm);
 	} else if (p.structured) launch_fwd_struct(p, sm, 0, ff0, p.n_items_f - ff0);
 	else launch_fwd<false>(p, sm);
+	if (!mg && p.merge) launch_fwd_struct(p, sm, 6, 0, p.n_fix_f); // the fix pass over the bulk tiles (estep_struct.hip FwdCtl)
 	if (!mg) (void)hipEventRecord(p.evx[1], sm);
+	if (p.merge && lf) { // ... and over the run tiles: the head of a run is checked against the last row of a bulk tile
+		if (ov && sw != sm) (void)hipStreamWaitEvent(sw, p.evx[1], 0);
+		launch_fwd_struct(p, sw, 7, 0, p.n_mem_f);
+		(void)hipEventRecord(p.evx[7], sw); // (what waits for the run tiles from here on waits for their check as well)
+	}
 	if (p.ev[5]) (void)hipEventRecord(p.ev[5], sm);
 	if (one && ov) (void)hipStreamWaitEvent(sa, p.evx[1], 0); // the backward chain follows the same launch
 	if (!one && p.ev[7]) (void)hipEventRecord(p.ev[7], sa);
@@ -720,7 +731,8 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		(void)hipMemsetAsync(p.d_cnt + c.slot, 0, sizeof(int), c.st);
 		(void)hipMemsetAsync(p.d_warm + c.slot, 0, sizeof(unsigned long long), c.st);
 #define PSMC_LV(BW, S, MINE, DIRTY, CNT) hipLaunchKernelGGL((k_verify<BW, S>), g, b, 0, c.st, p.d_chunks, p.n_chunks, p.tol, p.d_f, \
-			MINE, p.d_bexit, DIRTY, CNT, p.d_warm, (BW && !p.fused) ? 1 : 0)
+			MINE, p.d_bexit, DIRTY, CNT, p.d_warm, (BW && !p.fused) ? 1 : 0, \
+			(p.m_mis && c.round == 0 && (BW || !p.merge)) ? p.m_mis + (BW ? p.n_chunks : 0) : nullptr) /* (forward, with the fix pass: it has recorded them) */
 		if (!c.bwd) { if (p.ns == 128) PSMC_LV(false, 128, p.d_entry, p.d_dirty, p.d_cnt); else PSMC_LV(false, 64, p.d_entry, p.d_dirty, p.d_cnt); }
 		else { if (p.ns == 128) PSMC_LV(true, 128, p.d_bentry, p.d_dirty_b, p.d_cnt + 1); else PSMC_LV(true, 64, p.d_bentry, p.d_dirty_b, p.d_cnt + 1); }
 #undef PSMC_LV
@@ -731,8 +743,9 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 	};
 	if (lw && ov) { if (sw != sm) (void)hipStreamWaitEvent(sm, p.evx[7], 0); (void)hipStreamWaitEvent(sa, p.evx[9], 0); } // run tiles done
 	auto launch_ll = [&](hipStream_t st) { // the log-likelihood needs the forward tables only
-		if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, st, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
-		else hipLaunchKernelGGL(k_ll<64>, g, b, 0, st, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart);
+		const int *fm = p.merge ? p.d_fmerge : nullptr;
+		if (p.ns == 128) hipLaunchKernelGGL(k_ll<128>, g, b, 0, st, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart, fm, p.d_finv);
+		else hipLaunchKernelGGL(k_ll<64>, g, b, 0, st, p.d_chunks, p.d_f, p.d_s, p.d_entry, p.d_LLpart, fm, p.d_finv);
 		PSMC_DBG("k_ll", p.n_chunks, 0, 0);
 	};
 	auto launch_reduce = [&](hipStream_t sm) { // (the parameter shadows the main stream on purpose: the optimistic tail reduces on another one)
@@ -816,7 +829,9 @@ int launch_fast(const EstepLaunch &p, FastReport *rep)
 		if (ov) { (void)hipEventRecord(p.evx[2], sa); (void)hipStreamWaitEvent(sm, p.evx[2], 0); } // backward chain done
 		if (p.ev[2]) (void)hipEventRecord(p.ev[2], sm);
 		// tiles whose X a forward repair rewrote after their counts were taken (only repairs set the touch flags)
-		if (repaired) {
+		const bool recount = repaired;
+		rep->recounted = recount ? 1 : 0;
+		if (recount) {
 			if (p.fused == 2) launch_bwd_acc(p, sm, 2, 0, p.n_chunks); else { launch_bwd_count(p, sm, 0, true); launch_bwd_count(p, sm, 1, true); }
 		}
 	} else if (ov) {

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
                                                                 double *__restrict__ bentry, double *__restrict__ bexit,
                                                                 double *__restrict__ Cpart,
                                                                 double *__restrict__ Epart, const int *__restrict__ touch_f,
-                                                                const int *__restrict__ touch_b)
+                                                                const int *__restrict__ touch_b, const int *__restrict__ fmerge, const double *__restrict__ finv)
 {
 	__shared__ double lds_e[4 * SF], lds_m[8]; // e rows: hom, het, 1, 1;  count masks per symbol
 	const int lane = threadIdx.x, row = lane >> 4, m = lane & 15, k0 = NPLF * m;
@@ -143,6 +143,20 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 	loadN<NPLF>((from_above ? bexit + (int64_t)(tile + 1) * SF : bentry + (int64_t)tile * SF) + k0, x);
 	if (from_above) storeN<NPLF>(bentry + (int64_t)tile * SF + k0, x); // what verify compares and a redo starts from
 	const int p_min = lo, p_max = max(top, lo);
+	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
+	const int ng = g_hi - g_lo + 1;
+	const int64_t off0 = readlane_i64f(c.off, 0), off1 = readlane_i64f(c.off, 16), off2 = readlane_i64f(c.off, 32), off3 = readlane_i64f(c.off, 48);
+	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
+	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
+	const int ng_max = max(max(n0, n1), max(n2, n3));
+	// Where the forward fix pass stopped rewriting a tile (estep_struct.hip FwdCtl), the rows above and below differ by a recorded factor: the
+	// weight takes it when the sweep steps from group g_merge + 1 into group g_merge
+	int g_merge = -1;
+	double rho_fix = 1.0;
+	if (fmerge != nullptr && work) {
+		const int bm = fmerge[tile];
+		if (bm > 0 && lo + 16 * bm - 1 < p_max) { g_merge = (lo + 16 * bm - 2) >> 2; rho_fix = finv[tile]; }
+	}
 	double rho; // mult / I of this row's tile
 	{ // the pre-step: I = sum_k X_top[k] (a bt_{top+1})[k]
 		double y[NPLF], Xt[NPLF];
@@ -161,12 +175,6 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 		for (int j2 = 0; j2 < 4; ++j2) acc[j][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0};
 		S[0][j] = S[1][j] = 0.0;
 	}
-	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
-	const int ng = g_hi - g_lo + 1;
-	const int64_t off0 = readlane_i64f(c.off, 0), off1 = readlane_i64f(c.off, 16), off2 = readlane_i64f(c.off, 32), off3 = readlane_i64f(c.off, 48);
-	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
-	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
-	const int ng_max = max(max(n0, n1), max(n2, n3));
 	auto load_row = [&](int g, int j, double (&Xq)[NPLF]) { // X of position 4g + j + 1, clamped into the tile
 		const int p = min(max(4 * g + j + 1, p_min), p_max);
 		loadN<NPLF>(fo + (int64_t)(p - 1) * SF, Xq);
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 		const int s3 = (int)((w >> 24) & 3u), s2 = (int)((w >> 16) & 3u), s1 = (int)((w >> 8) & 3u), s0 = (int)(w & 3u);
 		const int pb = 4 * g + 1;
 		const double inv = inv_cur;
+		rho = (in_tile && g == g_merge) ? rho * rho_fix : rho;
 		double FAn[NPLF], FBn[NPLF];
 #define PSMC_C4F(NORM, J, SYM)                                                                                                   \
 		count4f_step<NORM, MASKED>(sc, lds_e, lds_m, k0, SYM, Xg[J], x, in_tile && pb + J <= top && pb + J >= lo, inv, rho, FAn, FBn, S); \
@@ -678,7 +687,7 @@ void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo,
 		return;
 	}
 	hipLaunchKernelGGL(k_bwd_count4f_struct, dim3(n_groups), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
-	                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+	                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, p.merge ? p.d_fmerge : nullptr, p.d_finv);
 	PSMC_DBG("launch_bwd_count", list, redo, n_groups);
 }
 

@@ -147,6 +147,24 @@ constexpr int SWEEP_ALTERNATE = 32; // k_sweep_struct: even blocks forward, odd 
 constexpr int SWEEP_COARSE = 128;   // bulk items may span several tiles (api_fast.hip build_items, "coarse"): they are not the few latency-critical runs
 constexpr int SWEEP_CKPT = 16;     // forward: store X only at the positions p % 8 == 0 (and the item's last one): the
                                    // factored counts recompute the rest from these checkpoints (estep_factored.hip)
+constexpr int SWEEP_MERGE = 256;    // forward REPAIR over a list of ALL tiles: verify each, rewrite the flagged ones until they meet their stored trajectory (FwdCtl)
+// What the forward sweeps need beyond the tables.
+// prevx (speculative sweeps, round 6): the start vector of every item's warm-up, taken from the PREVIOUS E-step's X at the position the warm-up
+// starts (api_fast.hip), instead of the stationary vector: the parameters of consecutive EM rounds are close, so the error the warm-up has to
+// forget starts decades lower.
+// The rest: the FIX pass (REPAIR with SWEEP_MERGE; launch_fwd_fix), which runs between the forward sweep and the back half.  Every row takes a
+// tile, compares the vector the tile was built on with what its neighbour computed (k_verify's test), and where they disagree rewrites the
+// tile from the true vector -- but only until the new trajectory has the DIRECTION of the stored one again (checked at the end of every full
+// 16-bin block): a speculation that fell short by a decade or two is wrong for a few hundred bins, not for a tile.  Two forward vectors over
+// the same observations never meet in VALUE (A x' -> c A x, c the ratio of the likelihoods of what follows given the two starts, 1 + O(mismatch),
+// for ever), so the pass records the factor between the stored rows above the merge point and its own rows below it (finv = 1/c, fmerge = the
+// block) and the two consumers of both halves put it in: the back half scales its posterior weight by finv when it steps from the stored part
+// into the rewritten part (estep_fused.hip), k_ll adds log c.  Everything else that reads X is scale-free.  Because the pass is over before the
+// back half starts, nothing is counted twice (rounds 1-5: the whole tile again, then its group of the counts again, 8 ms per round at genome
+// size), and nothing waits for anything: a first version let the repairs run UNDER the counts, behind a per-tile flag the counts waited on --
+// a vector wave beside a wave that streams f64 matrix instructions crawls (ten times slower: HISTORY.md), and the waits timed out.
+// mis / mlen (host-mapped): each tile's mismatch and the blocks its repair took -- what the per-tile warm-ups follow (api_fast.hip adapt_warmups).
+struct FwdCtl { const double *prevx; double tol; double *mis; int *mlen; int *fmerge; double *finv; };
 
 // ------------------------------------------------------------------ forward
 // per-row bookkeeping of the tile boundary the sweep crosses next
@@ -214,7 +232,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
                                                 const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
                                                 int n_items, int W, int T, int flags, double *__restrict__ f,
                                                 double *__restrict__ invd, double *__restrict__ entry,
-                                                int *__restrict__ touch_f)
+                                                int *__restrict__ touch_f, const FwdCtl ctl = FwdCtl{nullptr, 0.0, nullptr, nullptr, nullptr, nullptr})
 {
 	const bool walk = (flags & SWEEP_WALK) != 0, from_entry = (flags & SWEEP_FROM_ENTRY) != 0; // SWEEP_CKPT: the CK instantiation
 	constexpr int S = LPT * NPL, R = 64 / LPT; // R tiles per wave
@@ -244,14 +262,48 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	load_struct_par<NPL, LPT>(sp, k0, true, sc);
 	double x[NPL];
 	int p_first;
-	if (REPAIR && valid && m == 0 && !(flags & SWEEP_NO_TOUCH)) touch_f[it.first] = 1; // X / inv_d of this tile change
-	if (REPAIR && c.lo > 1) { // from the neighbour's stored X_{lo-1}, or from the boundary vector a walk left
+	// the fix pass (per row): is this tile's start vector what its neighbour computed?
+	bool merging = false;
+	if constexpr (REPAIR && !CK) {
+		if (flags & SWEEP_MERGE) {
+			const bool check = valid && c.lo > 1 && !(c.flags & CHUNK_ANCHOR_F);
+			double mm = 0.0, scl = 1.0;
+			if (check) { // max_k |u/|u| - v/|v|| / max_k v/|v|, u = the vector the tile was built on, v = the neighbour's X_{lo-1}
+				double u[NPL];
+				loadN<NPL>(entry + (int64_t)it.first * S + k0, u);
+				loadN<NPL>(fo + (int64_t)(c.lo - 2) * S, x);
+				const double su = tile_sum<NPL, LPT>(u), sv = tile_sum<NPL, LPT>(x);
+				const double iu = 1.0 / su, iv = 1.0 / sv;
+				double num = 0.0, den = 0.0;
+#pragma unroll
+				for (int i = 0; i < NPL; ++i) { num = fmax(num, fabs(u[i] * iu - x[i] * iv)); den = fmax(den, fabs(x[i] * iv)); }
+				num = row_max16(num); den = row_max16(den);
+				mm = num / den;
+				scl = su * iv; // the true vector at the length of the one the tile used: the factor between the two trajectories stays near 1
+			}
+			if (valid && m == 0 && ctl.mis) ctl.mis[it.first] = check ? mm : -1.0;
+			merging = check && !(mm <= ctl.tol) && scl > 0.0 && scl < 1e300; // (a NaN anywhere: left to the verify / repair rounds that follow)
+			if (merging) {
+#pragma unroll
+				for (int i = 0; i < NPL; ++i) x[i] *= scl;
+			}
+		}
+	}
+	const bool fix = REPAIR && (flags & SWEEP_MERGE) != 0;
+	if (REPAIR && valid && m == 0 && !fix) {
+		if (!(flags & SWEEP_NO_TOUCH)) touch_f[it.first] = 1; // X / inv_d of this tile change
+		if (ctl.fmerge) ctl.fmerge[it.first] = 0;               // ... all of it: what the fix pass recorded about it no longer applies
+	}
+	if (fix) { // x holds the start vector of a row that has work
+		p_first = c.lo;
+	} else if (REPAIR && c.lo > 1) { // from the neighbour's stored X_{lo-1}, or from the boundary vector a walk left
 		if (from_entry) loadN<NPL>(entry + (int64_t)it.first * S + k0, x);
 		else loadN<NPL>(fo + (int64_t)(c.lo - 2) * S, x);
 		p_first = c.lo;
 	} else {
 		const int ws = max(1, c.lo - chunk_warm_f(c, W));
-		loadN<NPL>(a0 + k0, x);
+		if (!REPAIR && ctl.prevx && ws > 1) loadN<NPL>(ctl.prevx + (int64_t)it.first * S + k0, x); // the previous E-step's X at position ws - 1
+		else loadN<NPL>(a0 + k0, x);
 		if (ws == 1) { // true start: X_1 = a0*e[o_1], d_1 = 1 (khmm.c:171-174 without the division)
 			double ev[NPL];
 			ev_load<NPL, LPT>(lds_e + ((int)o[0] & 3) * S, k0, ev);
@@ -269,7 +321,7 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 	cur.tile = c.lo >= p_first ? it.first : it.first + 1;
 	cur.next_lo = c.lo >= p_first ? c.lo : c.lo + T;
 	const int b_first = (p_first - 1) >> 4;
-	const int nblk = (valid && p_last >= p_first) ? ((p_last - 1) >> 4) - b_first + 1 : 0;
+	int nblk = (valid && p_last >= p_first && !(fix && !merging)) ? ((p_last - 1) >> 4) - b_first + 1 : 0;
 	// row-uniform scalars (lane 16r speaks for row r)
 	int64_t roff[R]; int rbf[R], rnb[R];
 	int nb_max = 0;
@@ -299,10 +351,41 @@ __device__ __forceinline__ void fwd_struct_body(int block, const double *__restr
 #ifdef PSMC_TRACE_SWEEP
 			if (tr && tr_first && __all(mode == 1)) { tr_first = false; PSMC_TRACE(g_trace_f, block, 1, wall_clock64()); }
 #endif
+			double old[NPL];
+			bool chk = false;
+			if constexpr (REPAIR && !CK) { // what the table holds at the block's last position, before this block overwrites it
+				chk = merging && mode == 1;
+				if (chk) loadN<NPL>(fo + (int64_t)(base + 15) * S, old);
+			}
 			if (__all(mode == 1)) fwd_block<1, NPL, CK, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 			else if (__all(mode == 2)) fwd_block<2, NPL, CK, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
 			else fwd_block<0, NPL, CK, LPT>(sc, hm, lds_e, k0, m, sv, base, p_first, p_last, lo_store, T, cur, x, fo, io, entry);
+			if constexpr (REPAIR && !CK) {
+				if (__any(chk)) {
+					double num = 0.0, den = 0.0, ratio = 1.0;
+					if (chk) { // the two vectors as directions (both divided by their sum), like k_verify
+						const double sn = tile_sum<NPL, LPT>(x), so = tile_sum<NPL, LPT>(old);
+						const double in = 1.0 / sn, io_ = 1.0 / so;
+						ratio = so * in; // stored / rewritten
+#pragma unroll
+						for (int i = 0; i < NPL; ++i) { num = fmax(num, fabs(x[i] * in - old[i] * io_)); den = fmax(den, fabs(old[i] * io_)); }
+					}
+					num = row_max16(num); den = row_max16(den);
+					const bool hit = chk && num <= ctl.tol * den && ratio > 0.0 && ratio < 1e300; // (false when anything is NaN)
+					if (hit) { // the rest of the tile stands as it is; the factor between the two parts goes on record
+						nblk = bi + 1; merging = false;
+						if (m == 0) {
+							if (base + 16 < p_last) { ctl.finv[it.first] = ratio; ctl.fmerge[it.first] = bi + 1; } // (met in the tile's last block: a whole new tile, nothing to stitch)
+							if (ctl.mlen) ctl.mlen[it.first] = bi + 1;
+						}
+					}
+				}
+			}
 		}
+		if constexpr (REPAIR) { if (!__any(bi + 1 < nblk)) break; } // every row has met its stored trajectory (or its end)
+	}
+	if constexpr (REPAIR && !CK) { // a row that ran to the end of its tile: a whole new tile, nothing to stitch
+		if (fix && valid && merging && m == 0 && ctl.mlen) ctl.mlen[it.first] = -1;
 	}
 #ifdef PSMC_TRACE_SWEEP
 	if (tr) PSMC_TRACE(g_trace_f, block, 2, wall_clock64());
@@ -315,10 +398,10 @@ __global__ __launch_bounds__(64) void k_fwd_struct(const double *__restrict__ sp
                                                      const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items,
                                                      int n_items, int W, int T, int flags, double *__restrict__ f,
                                                      double *__restrict__ invd, double *__restrict__ entry,
-                                                     int *__restrict__ touch_f, int *__restrict__ started)
+                                                     int *__restrict__ touch_f, int *__restrict__ started, const FwdCtl ctl)
 {
 	announce_start(started);
-	fwd_struct_body<REPAIR, NPL, CK, LPT>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f);
+	fwd_struct_body<REPAIR, NPL, CK, LPT>(blockIdx.x, sp, e, a0, obs, chunks, items, n_items, W, T, flags, f, invd, entry, touch_f, ctl);
 }
 
 // ------------------------------------------------------------------ backward
@@ -916,7 +999,7 @@ __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ 
                                                        int flags_f, int flags_b, double *__restrict__ f, double *__restrict__ invd,
                                                        double *__restrict__ entry, double *__restrict__ bt,
                                                        double *__restrict__ sb, double *__restrict__ bentry,
-                                                       double *__restrict__ bexit, int *__restrict__ started)
+                                                       double *__restrict__ bexit, int *__restrict__ started, const double *__restrict__ prevx)
 {
 	announce_start(started);
 	// Block order.  The dispatcher deals the work-groups of a grid out breadth first -- XCD = index % 8, then shader engine,
@@ -931,7 +1014,7 @@ __global__ __launch_bounds__(64) void k_sweep_struct(const double *__restrict__ 
 	if (!(flags_b & SWEEP_ALTERNATE)) { fwd = b < nbf; blk = fwd ? b : b - nbf; }
 	else if (b < both) { fwd = (b & 1) == 0; blk = b >> 1; }
 	else { fwd = nbf > nbb; blk = b - both + min(nbf, nbb); }
-	if (fwd) fwd_struct_body<false, NPL, CK, LPT>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, flags_f, f, invd, entry, nullptr);
+	if (fwd) fwd_struct_body<false, NPL, CK, LPT>(blk, sp, e, a0, obs, chunks, items_f, n_f, W, T, flags_f, f, invd, entry, nullptr, FwdCtl{prevx, 0.0, nullptr, nullptr, nullptr, nullptr});
 	else bwd_struct_body<false, NPL, LPT>(blk, sp, e, obs, chunks, items_b, n_b, W, T, flags_b, bt, sb, bentry, bexit, nullptr);
 }
 
@@ -974,15 +1057,18 @@ void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int firs
 	// instructions per tile-step; the latency-bound launches -- repairs, run tiles -- keep four, whose step is a third shorter)
 	const bool l8 = p.lanes8 && p.ns == 64 && which == 0;
 	const dim3 g(l8 ? (n_items + 7) / 8 : (n_items + 3) / 4), b(64);
-	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 ? p.d_members_f : p.d_items_f)) + first;
+	const SweepItem *items = (const SweepItem *)(which == 1 ? p.d_ritems_f : (which == 3 || which == 7 ? p.d_members_f : (which == 6 ? p.d_fix_f : p.d_items_f))) + first;
+	// which 6 / 7: the fix pass over the tiles outside the glued runs / over the run tiles (one-tile items; launch_fast)
+	const bool fixp = which == 6 || which == 7;
 	const int flags = (which == 3 ? (SWEEP_FROM_ENTRY | SWEEP_NO_TOUCH) : 0) // run tiles are done before the counts start
-	                  | (p.ckpt ? SWEEP_CKPT : 0) | (which == 0 && p.coarse > 1 ? SWEEP_COARSE : 0);
+	                  | (p.ckpt ? SWEEP_CKPT : 0) | (which == 0 && p.coarse > 1 ? SWEEP_COARSE : 0) | (fixp ? SWEEP_MERGE : 0);
+	const FwdCtl ctl = {which == 0 ? p.d_prevx : nullptr, p.tol, fixp ? p.m_mis : nullptr, fixp ? p.m_mlen : nullptr, p.d_fmerge, p.d_finv};
 #define PSMC_LF(REP, NPL, CK) hipLaunchKernelGGL((k_fwd_struct<REP, NPL, CK>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
-		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f, which == 0 && p.d_gate ? p.d_gate + 1 : nullptr)
+		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f, which == 0 && p.d_gate ? p.d_gate + 1 : nullptr, ctl)
 	const bool rep = which != 0;
 	if (l8) {
 #define PSMC_LF8(CK) hipLaunchKernelGGL((k_fwd_struct<false, 8, CK, 8>), g, b, 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
-		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f, p.d_gate ? p.d_gate + 1 : nullptr)
+		items, n_items, p.warmup, p.tile_len, flags, p.d_f, p.d_s, p.d_entry, p.d_touch_f, p.d_gate ? p.d_gate + 1 : nullptr, ctl)
 		if (p.ckpt) PSMC_LF8(true); else PSMC_LF8(false);
 #undef PSMC_LF8
 	} else if (p.ns == 128) { if (rep) PSMC_LF(true, 8, false); else PSMC_LF(false, 8, false); }
@@ -1029,16 +1115,38 @@ void launch_sweeps(const EstepLaunch &p, hipStream_t st, int ff, int nf, int fb,
 	          flags_b = (top_only ? (co ? SWEEP_WALK | co : SWEEP_TOP_ONLY) : 0) | (top_only && p.merge_order ? SWEEP_MERGED : SWEEP_ALTERNATE);
 #define PSMC_LS(NPL, CK) hipLaunchKernelGGL((k_sweep_struct<NPL, CK>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
-		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_gate ? p.d_gate + 1 : nullptr)
+		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_gate ? p.d_gate + 1 : nullptr, p.d_prevx)
 #define PSMC_LS8(CK) hipLaunchKernelGGL((k_sweep_struct<8, CK, 8>), dim3(nblk), dim3(64), 0, st, p.d_sp, p.d_e, p.d_a0, p.d_obs, p.d_chunks, \
 		(const SweepItem *)p.d_items_f + ff, nf, (const SweepItem *)p.d_items_b + fb, nb, p.warmup, p.tile_len, flags_f, flags_b, \
-		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_gate ? p.d_gate + 1 : nullptr)
+		p.d_f, p.d_s, p.d_entry, p.d_b, p.d_sb, p.d_bentry, p.d_bexit, p.d_gate ? p.d_gate + 1 : nullptr, p.d_prevx)
 	if (l8) { if (p.ckpt) PSMC_LS8(true); else PSMC_LS8(false); }
 	else if (p.ns == 128) PSMC_LS(8, false); else if (p.ckpt) PSMC_LS(4, true); else PSMC_LS(4, false);
 #undef PSMC_LS8
 	PSMC_DBG("launch_sweeps", nf, nb, top_only);
 #undef PSMC_LS
 }
+// Start vectors of the forward speculation from the previous E-step's table (FwdCtl::prevx): row lo - wf - 1 of the head tile of every bulk
+// item, copied out BEFORE the sweep starts to overwrite the table (a wave reading the row inside the sweep could see it half rewritten by the
+// wave of the tile below: a good vector either way, but a result that depends on timing).  ck: the table holds every 8th row only.
+__global__ __launch_bounds__(64) void k_gather_prev(const Chunk *__restrict__ chunks, const SweepItem *__restrict__ items, int S, const double *__restrict__ f,
+                                                      const double *__restrict__ a0, double *__restrict__ prevx, int ck)
+{
+	const SweepItem it = items[blockIdx.x];
+	const Chunk c = chunks[it.first];
+	const int ws = max(1, c.lo - c.wf);
+	const bool have = ws > 1 && !(ck && ((ws - 1) & 7)); // (a checkpoint table holds the rows p % 8 == 0)
+	for (int k = threadIdx.x; k < S; k += 64) {
+		double v = a0[k];
+		if (have) { const double t = f[(c.off + ws - 2) * S + k]; v = (t > 0.0 && t < 1e300) ? t : v; } // (a row nobody wrote, a NaN: the stationary value)
+		prevx[(int64_t)it.first * S + k] = v;
+	}
+}
+void launch_gather_prev(const EstepLaunch &p, hipStream_t st, int first, int n_items, double *prevx)
+{
+	if (n_items <= 0) return;
+	hipLaunchKernelGGL(k_gather_prev, dim3(n_items), dim3(64), 0, st, p.d_chunks, (const SweepItem *)p.d_items_f + first, p.ns, p.d_f, p.d_a0, prevx, p.ckpt);
+}
+
 // Plan time: which tiles consist of missing data only (symbol 2 at every position lo..hi)?  Real .psmcfa files carry runs of 1e4 .. 3e5 `N`
 // bins (centromeres, assembly gaps: utils/fq2psmcfa.c:114-127); inside such a run the chain forgets at the rate of the transition matrix's
 // second eigenvalue alone -- 0.99995 for a human-like model: 5e5 bins to 1e-12 -- so no speculative warm-up ever works there and every tile

@@ -67,6 +67,23 @@ struct psmc_hip_ctx {
 	int fuse128 = 2;           // "fuse128": the same with 65..128 states: 2 = k_bwd_count8x_struct (sixteen tiles per work-group, one sweep per tile, operands
 	                           // exchanged through LDS), 1 = k_bwd_count8_struct (four waves redo the sweep of four tiles), 0 = unfused
 	int count_group = 4;       // tiles per work-group of the fused back half, what the tile lists are padded to (build_items)
+	// Round 6: mis-speculation made cheap, then warm-ups sized per tile -- built, measured, and OFF: halving every warm-up at no
+	// cost at all is worth 0.35 ms of 12.25 (profiles/r06_warmup_sensitivity.txt), and the three together cost more than that (profiles/r06_fix_pass_ab.txt).
+	int merge = 0;             // "merge": the forward fix pass between the forward sweep and the back half (estep_struct.hip FwdCtl): a mis-speculated tile is rewritten
+	                           // until it meets its stored trajectory, nothing is counted twice (0: verify afterwards, whole tiles and their groups of the counts again)
+	int adapt = 0;             // "adapt": with "merge", every speculating tile's forward warm-up follows the mismatch its speculation left at the last E-step (0: "warmup" for all)
+	double adapt_margin = 2.0; // "adapt_margin": decades inside "warm_tol" a speculation is allowed to keep before its warm-up shrinks
+	int prev_start = 0;        // "prev_start": forward warm-ups start from the previous E-step's X at that position instead of the stationary vector
+	int *h_mlen = nullptr, *m_mlen = nullptr;        // pinned + device-mapped [n_chunks]: blocks each merging repair rewrote / -1
+	double *h_mis = nullptr, *m_mis = nullptr;       // pinned + device-mapped [2][n_chunks]: first-verify mismatch of every tile, forward | backward
+	double *d_prevx = nullptr, *d_finv = nullptr;    // [n_chunks][ns] gathered start vectors; [n_chunks] scale factors of the merging repairs
+	std::vector<int> order_f;                        // head tiles of the bulk forward items in launch order (build_items): adapt_warmups looks at how well the rows of a wave still match
+	int n_fix_f = 0;
+	bool merge_used = false;                         // what the last E-step decided about "merge"; n_fix_f: tiles of its first fix launch
+	Chunk *h_chunks = nullptr; size_t h_chunks_cap = 0; // pinned staging copy of the tiles (their warm-ups change between E-steps)
+	bool prev_ok = false;                            // the X table holds a complete forward sweep of THIS plan ...
+	unsigned long long prev_serial = 0, tab_serial = 0; // ... and nobody has used the tables since (tab_serial: on the root context, ensure_tables)
+	const double *prev_f = nullptr; int prev_ckpt = 0;
 	int learn = 1;             // "learn": glue tiles that needed a repair to their neighbour for the following E-steps
 	int warm_shift = 1;        // "warm_shift": before that, once, give such a tile a warm-up of warmup << warm_shift bins (0: glue at once)
 	bool chunks_dirty = false; // a tile's warm-up changed: d_chunks is stale
@@ -130,7 +147,7 @@ struct psmc_hip_ctx {
 	int runs_late = 1;         // "runs_late": two-phase plan, 1 = run tiles go to the second launch of the fused back half
 	bool runs_in_b = false;    // two-phase plan: every tile of a glued run is in the second list of the fused back half (build_items)
 	int *d_ftiles = nullptr;   // [2 * (n_tiles + 4)] tile lists A | B of the fused back half (bit 30: start from the tile above)
-	FastReport report = {0, 0, 0, 0, 1};
+	FastReport report = {0, 0, 0, 0, 1, 0, 0};
 	double *d_stage = nullptr, *d_stats = nullptr;
 	unsigned long long *d_warm = nullptr;
 	double warm_err[2] = {0, 0};

@@ -42,7 +42,7 @@ struct ExWork {
 	int64_t par_stride;  // doubles between consecutive parameter sets
 };
 
-struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged; };
+struct FastReport { int fwd_rounds, bwd_rounds, fwd_tiles, bwd_tiles, converged, merged, recounted; }; // merged: tiles the forward fix pass rewrote in part (until they met their stored trajectory); recounted: 1 = a second pass of the counts ran
 
 // Everything a launch needs (device pointers unless noted).
 struct EstepLaunch {
@@ -115,6 +115,17 @@ struct EstepLaunch {
 	double *d_entry, *d_bentry, *d_bexit; // [n_chunks][64] boundary vectors used / produced by each tile
 	int *d_dirty, *d_dirty_b, *d_cnt, *h_cnt; // per-tile repair flags (fwd, bwd), flagged counts [2] (device, pinned host)
 	int *d_touch_f, *d_touch_b;           // [n_chunks] each, contiguous: repaired-this-E-step flags
+	// The forward fix pass (round 6; estep_struct.hip FwdCtl, launch_fast): between the forward sweep and the back half every tile's start vector is
+	// checked and a tile that fails is rewritten until it meets its stored trajectory.  merge == 0: rounds 1-5 (verify afterwards, whole tiles again,
+	// their groups of the counts again).
+	int merge;
+	const int *d_fix_f; int n_fix_f;      // one-tile items: every tile outside the forward runs whose predecessor is outside them too (checked right after the bulk sweep)
+	int *d_fmerge;                        // [n_chunks] (follows d_touch_b) the 16-bin block (1-based, from the tile's first) at whose end a fix stopped, 0 = none
+	double *d_finv;                       // [n_chunks] ... and the factor stored rows / rewritten rows at that point
+	int *m_mlen, *h_mlen;                 // [n_chunks] mapped host memory (device / host view): 16-bin blocks a fix rewrote (> 0), -1 = the whole tile
+	double *m_mis;                        // [2][n_chunks] mapped host memory: each tile's mismatch when first checked in this E-step (forward | backward):
+	                                      // what the per-tile warm-ups follow (api_fast.hip adapt_warmups)
+	const double *d_prevx;                // [n_chunks][ns] start vectors of the forward speculation taken from the previous E-step's X, or null (stationary vector)
 	double *d_sb;                         // backward scale factors (fast mode), like d_s
 	double tol; int max_rounds;
 	double *d_Cpart;            // [n_chunks*n_sub][4096]
@@ -149,6 +160,7 @@ int launch_fast(const EstepLaunch &p, FastReport *rep);
 void launch_fwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_bwd_struct(const EstepLaunch &p, hipStream_t st, int which, int first, int n_items);
 void launch_compact(const EstepLaunch &p, hipStream_t st, bool bwd);
+void launch_gather_prev(const EstepLaunch &p, hipStream_t st, int first, int n_items, double *prevx); // estep_struct.hip
 int launch_tile_allmiss(hipStream_t st, const uint8_t *d_obs, const Chunk *d_chunks, int n_chunks, int *d_flags); // estep_struct.hip
 void launch_walks(const EstepLaunch &p, hipStream_t st);
 void launch_gate(hipStream_t st, const int *ctr, int want);

@@ -297,12 +297,12 @@ class HipEStep:
     def fast_diag(self):
         wf = C.c_double(0); wb = C.c_double(0); nc = C.c_int(0); wu = C.c_int(0)
         self._chk(self.lib.psmc_hip_fast_diag(self.h, C.byref(wf), C.byref(wb), C.byref(nc), C.byref(wu)), "fast_diag")
-        rp = (C.c_int * 4)()
+        rp = (C.c_int * 6)()
         self._chk(self.lib.psmc_hip_fast_repairs(self.h, rp), "fast_repairs")
         fi = (C.c_int * 8)()
         self._chk(self.lib.psmc_hip_fast_info(self.h, fi), "fast_info")
         return dict(warm_err_fwd=wf.value, warm_err_bwd=wb.value, n_chunks=nc.value, warmup=wu.value,
-                    fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3],
+                    fwd_rounds=rp[0], bwd_rounds=rp[1], fwd_tiles=rp[2], bwd_tiles=rp[3], merged=rp[4], recounted=rp[5],
                     structured=bool(fi[0]), tile_len=fi[1], items_fwd=fi[2], items_bwd=fi[3], back_half=fi[4], ckpt=bool(fi[5]),
                     fused_launches=fi[6], merged_phase1=fi[7])
 

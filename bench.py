@@ -167,6 +167,33 @@ def cpu_baseline_multi(a, e, a0, segs, kind, one_core_rate):
                                       "only parallelism the reference's algorithm has (em.c:36-55)"}}
 
 
+# the kernel sources a replayed counter record (profiles/pmc_traffic*.json, sq_factored.json) must have been taken from to be quoted
+TRAFFIC_SOURCES = ["psmc_amd/csrc/estep_fused.hip", "psmc_amd/csrc/estep_struct.hip", "psmc_amd/csrc/estep_fast.hip", "psmc_amd/csrc/struct_prims.h", "psmc_amd/csrc/wave_prims.h"]
+
+
+def kernel_src_sha16(sources, root=ROOT):
+    import hashlib
+    return hashlib.sha256(b"".join(open(os.path.join(root, s), "rb").read() for s in sources)).hexdigest()[:16]
+
+
+def replayed_traffic(path, bins, kernel):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc record -- only when the record was taken from the kernel sources
+    of THIS build (after a kernel change the line must not quote the old kernel's traffic).  -> (bytes or None, note)."""
+    try:
+        pj = json.load(open(path))
+    except Exception:
+        return None, "no PMC record (%s)" % os.path.basename(path)
+    want = pj.get("kernel_src_sha16")
+    if not want:
+        return None, "%s carries no kernel_src_sha16: taken before round 6, cannot be matched to this build (scripts/lease.sh prof re-takes it)" % os.path.basename(path)
+    have = kernel_src_sha16(pj.get("kernel_sources", TRAFFIC_SOURCES))
+    if have != want:
+        return None, "%s was taken from other kernel sources (sha %s, now %s): no traffic figure until it is re-taken (scripts/lease.sh prof)" % (os.path.basename(path), want, have)
+    if abs(pj.get("bins", -1) - bins) > 64 or kernel not in pj.get("kernels", {}):
+        return None, "%s has no entry for %s at %d bins" % (os.path.basename(path), kernel, bins)
+    return pj["kernels"][kernel]["hbm_bytes_per_launch"], "replayed from %s (a separate rocprofv3 --pmc pass of this command, same kernel sources: sha %s)" % (os.path.basename(path), want)
+
+
 def factored_roofline(bins, kern, dt_step):
     """the path `psmc` runs in fast mode has no matrix instruction and little memory traffic (130 B per bin with
     checkpoints); its kernels are bound by vector-instruction ISSUE.  One SIMD issues at most one f64 vector instruction per 4
@@ -230,13 +257,8 @@ def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, dia
     flop_b = 2 * N_STATES * N_STATES + 24 * N_STATES
     fused_ms = kern.get("expect", 0.0)
     tfl = bins * flop_b / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0
-    traffic = None
-    try:  # HBM bytes per launch from the rocprofv3 PMC pass of this same command (profiles/, scripts/gpu_pmc.sh)
-        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if abs(pj["bins"] - bins) <= 64 and dom in pj["kernels"]:
-            traffic = pj["kernels"][dom]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    # HBM bytes per launch from the rocprofv3 PMC pass of this same command (profiles/, scripts/lease.sh prof), guarded by the sources' hash
+    traffic, traffic_note = replayed_traffic(os.path.join(ROOT, "profiles", "pmc_traffic.json"), bins, dom)
     out = {
         "metric": "genome bins/sec through forward-backward (n=64)",
         "value": value, "unit": "bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -279,7 +301,7 @@ def make_line(args, fast, world, bins, total_bins, lens, n_local_segs, kern, dia
                         ({"also": {"bound": "hbm", "kernel": "k_fwd_struct<speculate>", "kernel_ms": kern["fwd_sweep"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                    "achieved": bins * (8 * N_STATES + 9) / (kern["fwd_sweep"] * 1e-3) / 1e9,
                                    "frac": bins * (8 * N_STATES + 9) / (kern["fwd_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS}} if fused and kern.get("fwd_sweep", 0) > 0 else {})),
-                     "traffic": traffic, "kernel_ms": dom_ms,
+                     "traffic": traffic, "traffic_note": traffic_note, "kernel_ms": dom_ms,
                      "pipeline": {"alg_bytes_per_bin": bytes_per_bin, "ms": kern["total"], "achieved": pipe,
                                   "frac": pipe / HBM_PEAK_GBS},
                      "kernels_ms": kern,
@@ -494,6 +516,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
+    comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -501,6 +524,19 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # First contact: does the exchange the timed steps will use see every rank, and which devices are they on?  (VERDICT r5 item 3c:
+        # a SCALE record must answer "did RCCL see N ranks" by itself.)  One all-reduce of ones, one gather of the ranks' devices.
+        ones = torch.ones(1, dtype=torch.float64, device="cpu" if single_gpu_test else "cuda")
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(local)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "device": local, "name": props.name, "pci_bus": getattr(props, "pci_bus_id", None)})
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_in_allreduce": int(round(float(ones.item()))),
+                "rank_devices": seen, "distinct_devices": len({(d["device"], d["pci_bus"]) for d in seen})}
+        try:
+            comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if comm["backend"] == "nccl" else None
+        except Exception:
+            comm["rccl_version"] = None
 
     a, e, a0 = load_params()
     traj, traj_src = load_trajectory(args.traj)
@@ -626,6 +662,8 @@ def main():
     if rank == 0:
         out = make_line(args, mode == hip.MODE_FAST, world, bins, total_bins, lens, len(segs), kern, diag, value, ms_per_step, traj_src,
                         len(moving), sh.stats.numel())
+        if comm is not None:
+            out["config"]["comm"] = comm   # the exchange behind "sharding": backend, the ranks one all-reduce of ones counted, every rank's device
         if steady is not None:
             out["steady_state"] = steady
         if first_ms is not None:
@@ -773,17 +811,11 @@ def main():
                 fac8 = {"error": str(ex_)}
             # roofline of the back half on the ALGORITHMIC flops: 2 n^2 (counts, v_mfma_f64_16x16x4) + 24 n (one O(n) backward sweep) per bin.
             # k_bwd_count8x_struct (round 4: sixteen tiles per work-group, one sweep per tile, operands exchanged through LDS) executes
-            # exactly that; round 3's k_bwd_count8_struct ("fuse128=1") redoes the sweep in each of its four waves: executed_flop_per_bin
+            # exactly that
             flop8 = 2 * 128 * 128 + 24 * 128
-            kname8 = "k_bwd_count8x_struct" if "fuse128=1" not in args.opt else "k_bwd_count8_struct"
+            kname8 = "k_bwd_count8x_struct"
             tf8 = bins * flop8 / (kern8["expect"] * 1e-3) / 1e12 if kern8.get("expect", 0) > 0 else 0.0
-            traffic8 = None
-            try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_n128.json")))
-                if abs(pj["bins"] - bins) <= 64 and kname8 in pj["kernels"]:
-                    traffic8 = pj["kernels"][kname8]["hbm_bytes_per_launch"]
-            except Exception:
-                pass
+            traffic8, traffic8_note = replayed_traffic(os.path.join(ROOT, "profiles", "pmc_traffic_n128.json"), bins, kname8)
             out["n128"] = {"value": bins / (d8 * 1e-3), "unit": "bins/s", "ms_per_step": d8, "ms_min": d8min, "first_call_ms": f8, "kernels_ms": kern8, "factored_stats": fac8,
                            "config": "configs[4]: -p 64*2 (128 states), %d bins in %d segments, fast mode; parameters: %s; median of %d steps after %d warm-up steps"
                                      % (bins, len(segs), par8, NT8, NW8),
@@ -793,8 +825,8 @@ def main():
                                         "achieved": tf8, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf8 / F64_PEAK_TFLOPS, "alg_flop_per_bin": flop8,
                                         "mfma_only_frac": bins * 2 * 128 * 128 / (kern8["expect"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS if kern8.get("expect", 0) > 0 else None,
                                         "hbm": {"alg_bytes_per_bin": 8 * 128 + 9, "achieved_GBs": bins * (8 * 128 + 9) / (kern8["expect"] * 1e-3) / 1e9 if kern8.get("expect", 0) > 0 else None},
-                                        "traffic": traffic8,
-                                        "executed_flop_per_bin": flop8 if kname8 == "k_bwd_count8x_struct" else 2 * 128 * 128 + 4 * 24 * 128,
+                                        "traffic": traffic8, "traffic_note": traffic8_note,
+                                        "executed_flop_per_bin": flop8,
                                         "note": "frac is on the algorithmic flops 2 n^2 + 24 n (VERDICT r3 item 2); mfma_only_frac counts the 2 n^2 alone; "
                                                 "traffic = PMC bytes per launch from profiles/pmc_traffic_n128.json (a separate rocprofv3 --pmc pass of this command), null if absent"}}
             s8.close()

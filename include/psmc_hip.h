@@ -57,7 +57,7 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
 /* Options.  None is needed: the defaults are what bench.py and the psmc binary run, and the plan adapts to the input
  * (see "auto").  PSMC_HIP_OPTIONS="key=value,key=value" in the environment sets them for every context of a process.
  * Unknown keys and out-of-range values return PSMC_HIP_EINVAL.  Setting any option drops the per-replicate plans a
- * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_tailfill", "batch_major", "batch_slots" and "exact_refwd" ("batch_first" is accepted and has no effect).
+ * fast-mode batch has learned.  Exact mode reads only "rep_impl", "batch_bins", "batch_sort", "batch_tailfill", "batch_major" and "exact_refwd" ("batch_first" is accepted and has no effect).
  *
  *  key             default  meaning
  *  --- plan of the fast mode (tiles, speculation) ---------------------------------------------------------------
@@ -65,10 +65,17 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           SIMD and four tiles per wave in each of two launches) for genome-sized inputs, ONE round
  *                           (4096 tiles, every tile speculating in both directions, one launch) below 8192 x warmup
  *                           bins (25 M) -- a single chromosome, one rank's share of a genome at 2/4/8 GPUs
- *  "struct_tiles"  8192     tiles aimed at when chunk = 0 (fixes the plan: no adaptation to the input size)
  *  "warmup"        3072     bins a tile starts outside itself (from the stationary vector) in each direction
  *  "warm_tol"      1e-12    agreement demanded between the vector a tile built on and what its neighbour computed
  *  "max_rounds"    4096     verify / repair rounds before PSMC_HIP_ECONVERGE
+ *  "merge"         0        1: a forward FIX pass between the forward sweep and the back half (64 states, fused back half): every tile's start
+ *                           vector is checked there, and a tile that fails is rewritten from the true vector until its trajectory has the
+ *                           direction of the stored one again (the factor between the two parts is kept for the counts and the likelihood) --
+ *                           nothing is counted twice.  0: verify after the back half, whole tiles and their groups of the counts again.
+ *                           Built in round 6 with "adapt" and "prev_start" (VERDICT r5 item 1), measured, off: DESIGN.md section 8
+ *  "adapt"         0        1, with "merge": every speculating tile's forward warm-up follows the mismatch its speculation left (shrinks while it
+ *                           is more than two decades inside "warm_tol", grows by what a repair needed)
+ *  "prev_start"    0        1: forward warm-ups start from the previous E-step's X at that position instead of the stationary vector
  *  "learn"         1        tiles that needed a repair are treated differently in the following E-steps of the context
  *                           (longer warm-up, then glued to their neighbour); results then depend on the call history
  *                           within the stated tolerance, two contexts with the same history agree bit for bit
@@ -82,15 +89,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "two_phase"     auto     2: the fused back half runs as two launches, odd tiles of the second list start from the exit
  *                           vector of the tile above instead of speculating backward; 0: every tile speculates, one
  *                           launch when the tiles fit one round.  auto: 2 with two rounds, 0 with one
- *  "runs_late"     1        two launches of the fused back half: every tile of a glued run is in the second list, so that the
- *                           first launch waits for the bulk sweeps only and the runs' path (walk -> chain -> run tiles)
- *                           has until the end of that launch; 0: both launches after the runs' path
  *  "merge1"        auto     1: bulk forward sweep and backward warm-up pass in ONE grid, so that the dispatcher puts
  *                           their waves on distinct SIMDs, and the dependent chain walks -> chains -> run tiles -> back
  *                           half on one stream; 0: side by side on streams of their own.  auto: 1 with one round
- *  "merge_order"   auto     block order of that grid: 1 = the forward blocks, then the backward blocks (the dispatcher deals blocks out
- *                           XCD first, so alternating directions put each direction on four of the eight XCDs); 0 = alternating.
- *                           auto: 1 while a tile is shorter than its warm-up
  *  "coarse"        auto     a bulk sweep item spans up to this many consecutive tiles of a segment: ONE speculative warm-up per item
  *                           and direction (the forward sweep runs through its tiles, the backward pass of phase 1 walks the item and
  *                           leaves every tile's start vector), so the back half keeps its ~4096 tiles while phase 1 pays half the
@@ -101,11 +102,6 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           auto: with the factored statistics of a genome-sized input (their forward sweep stores checkpoints only, three
  *                           waves per SIMD: issue-bound); slower for the full-count E-step (forward sweep paced by its table stores) and for
  *                           shard-sized inputs (one wave per SIMD: the 8 x 8 step is a third longer)
- *  "lanes8b"       0        1: the factored back half without checkpoints ("ckpt" = 0) runs eight tiles per wave too (8 lanes x 8 states,
- *                           one wave per SIMD).  A measured experiment of round 5, kept for A/B: slower than four tiles
- *  "gate"          auto     1: one-wave gate kernels order the DISPATCH of phase 1's grids across streams -- walks, then the bulk
- *                           grid, then the transfer matrices -- so that every walk gets a SIMD slot of its own (they give up after
- *                           ~200 us); 0: whatever order the queues come up in.  auto: with coarse items
  *  "share_learn"   1        psmc_hip_estep_batch, fast mode: the replicates tile every segment with ONE tile length (the largest
  *                           replicate's) and a replicate that plans starts from the glue flags and warm-ups its predecessors learned
  *                           at the same (segment, tile) -- the slow regions belong to the data, so replicate 2..R skip most of the repair
@@ -115,22 +111,17 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "kc_min"        auto     runs of at least this many tiles get their boundary vectors from a chain of tile transfer
  *                           matrices instead of a walk; 0 = never.  auto (-1): 4 with 64 states (5 in the two-round plan), 8 with
  *                           65..128 (12)
- *  "kc_div"        16       at most n_tiles / kc_div tiles per direction get a transfer matrix
  *  "kc_sub"        auto     64 states: a tile's steps are cut into this many ranges with a matrix (and a pair of
  *                           waves) each; auto: ranges of about (tile + warmup) / 8 steps, at most 4
- *  "kcol_prio"     2        wave priority of the transfer-matrix kernel (0..2; the bulk forward sweep runs at 1)
  *  --- back half ----------------------------------------------------------------------------------------------------
  *  "fuse"          1        structured sweeps, up to 64 states: the backward sweep feeds the counts' matrix
  *                           instructions directly, bt never stored; 0: bt table + separate counts kernel
  *  "fuse128"       2        the same with 65..128 states: 2 = sixteen tiles per work-group, one sweep per tile, operands of the matrix
- *                           instructions exchanged through LDS; 1 = round 3's kernel (four waves redo the sweep of four tiles); 0 = unfused
+ *                           instructions exchanged through LDS; 0 = unfused
  *  "ckpt"          1        psmc_hip_estep_factored keeps X only every 8th position and recomputes the rest
  *  "structured"    1        1 = O(N) sweeps when a[][] has the PSMC form (checked per call), 0 = always the dense sweeps
  *  "overlap"       1        forward chain, backward chain, counts and walks on streams of their own; 0: one stream
  *  --- dense sweeps / unfused counts (any matrix up to 64 states) ----------------------------------------------------
- *  "target_waves"  1536     tiles aimed at by the dense sweeps (one per wave)
- *  "n_sub"         6        waves per tile in the separate counts kernel
- *  "expect_impl"   1        separate counts kernel: 1 v_mfma_f64_16x16x4, 0 vector instructions (cross-check)
  *  --- exact mode ---------------------------------------------------------------------------------------------------
  *  "rep_impl"      auto     row replication of the ordered sums: 1 v_permlane16/32_swap, 0 ds_bpermute (bit-identical); -1 = auto:
  *                           0 when a launch has more than one wave per SIMD (bootstrap batch), else 1
@@ -149,19 +140,17 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *                           length (utils/splitfa.c cuts the trunks to one length), the blocks no longer than that keep the caller's replicate
  *                           order -- longer ones still first, by length -- so that replicates complete launch by launch and `done` can hand
  *                           them to the caller's M-steps while the later launches run.  Not when the tail fill saves a launch.  Bit-identical.
- *  "batch_slots"   0        psmc_hip_estep_batch without the f table, several launches: entries per launch; 0 = four per compute unit of the
- *                           context's share of the device (the recompute pass holds that many at a time; one more waits for a whole round).
- *                           (psmc_boot --main with PSMC_BOOT_MAIN_CUS=0 uses it; measured slower than compute-unit masks)
  *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1, 2 = no f table -- the expect pass recomputes the forward sweep in its own
  *                           work-group (bit-identical), so a launch group holds twice the replicates; 2 = two entries per work-group
  *                           (two producer waves, two consumer waves: four entries per compute unit), 1 = one; 0 = f and b tables,
  *                           three kernels.  auto: 2, and only when the tables of all replicates would not fit one launch group
  *
- * With 65..128 states "lanes8", "gate", "kc_sub", "kcol_prio" and "ckpt" are accepted and ignored (their kernels are 64-state ones);
+ * With 65..128 states "lanes8", "kc_sub", "ckpt", "merge" and "adapt" are accepted and ignored (their kernels are 64-state ones);
  * beyond 128 states only "batch_bins" and "batch_sort" are read.
- * Removed in round 3 after losing their A/B (HISTORY.md keeps the measurements): "count_impl", "kc_warm",
- * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "exact_lds", and the value 1 of "two_phase" ("lanes8" came back in
- * round 4 with new semantics, see above). */
+ * Removed after losing their A/B or settling on one value (HISTORY.md keeps the measurements) -- round 3: "count_impl", "kc_warm",
+ * "walk_heads", "walk_impl", "kcol_impl", "fuse_order", "exact_lds", the value 1 of "two_phase"; round 6: "lanes8b" (with its kernel),
+ * "batch_slots", "expect_impl" (with the vector-instruction counts kernel), the value 1 of "fuse128" (with round 3's 128-state kernel),
+ * "struct_tiles", "target_waves", "n_sub", "runs_late", "merge_order", "gate", "kc_div", "kcol_prio" (what they chose is now what the plan does). */
 int psmc_hip_set_option(psmc_hip_ctx *ctx, const char *key, double value);
 
 /* Restrict the kernels of this context to `count` compute units starting at `first` in the bit order of HIP's compute-unit
@@ -252,8 +241,8 @@ int psmc_hip_estep_device(psmc_hip_ctx *ctx, const double *a, const double *e, c
 int psmc_hip_fast_diag(psmc_hip_ctx *ctx, double *warm_err_fwd, double *warm_err_bwd, int *n_chunks,
                        int *warmup_used);
 /* How much repair the speculation needed: verify/repair rounds and the total
- * number of tile re-runs, forward and backward, out[0..3]; out[4] = forward
- * repairs that stopped where they met the stored trajectory ("merge_cap"),
+ * number of tile re-runs, forward and backward, out[0..3]; out[4] = tiles
+ * the forward fix pass rewrote in part ("merge"),
  * out[5] = 1 when a second pass of the counts had to run. */
 int psmc_hip_fast_repairs(psmc_hip_ctx *ctx, int out[6]);
 /* Diagnostic: the plan the NEXT fast E-step of this context will run with: out = {tiles, tile length in bins, mean forward

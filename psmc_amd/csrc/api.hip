@@ -140,6 +140,7 @@ extern "C" int psmc_hip_create(psmc_hip_ctx **out, int n_states, int device, int
 
 static void destroy_kids(psmc_hip_ctx *c)
 {
+	if (c->x_twin) { psmc_hip_destroy(c->x_twin); c->x_twin = nullptr; } // (it borrows this context's observations and copied its segment list)
 	for (psmc_hip_ctx *k : c->kids) psmc_hip_destroy(k);
 	c->kids.clear();
 	c->share_T = 0; // the shared learning goes with the plans it was made for
@@ -207,41 +208,29 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
 	else if (k == "merge") { c->merge = v != 0 ? 1 : 0; }
-	else if (k == "adapt_margin") { if (v < 0 || v > 6) return PSMC_HIP_EINVAL; c->adapt_margin = v; }
 	else if (k == "adapt") { c->adapt = v != 0 ? 1 : 0; c->plan_dirty = true; }
 	else if (k == "prev_start") { c->prev_start = v != 0 ? 1 : 0; c->prev_ok = false; }
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
-	else if (k == "runs_late") { c->runs_late = v != 0 ? 1 : 0; c->items_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
 	else if (k == "lanes8") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->lanes8 = (int)v; }
 	else if (k == "gap_tiles") { c->gap_tiles = v != 0 ? 1 : 0; c->plan_dirty = true; c->items_dirty = true; }
-	else if (k == "lanes8b") { c->lanes8b = v != 0 ? 1 : 0; }
-	else if (k == "gate") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->gate = (int)v; }
 	else if (k == "coarse") { if (v < -1 || v > 16) return PSMC_HIP_EINVAL; c->coarse = (int)v; c->plan_dirty = true; c->items_dirty = true; }
-	else if (k == "merge_order") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge_order = (int)v; }
-	else if (k == "kcol_prio") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->kcol_prio = (int)v; }
 	else if (k == "kc_sub") { if (v < 1 || v > 16) return PSMC_HIP_EINVAL; c->kc_sub = (int)v; c->kc_sub_set = true; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "two_phase") { if (v != -1 && v != 0 && v != 2) return PSMC_HIP_EINVAL; c->two_phase = (int)v; c->plan_dirty = true; c->items_dirty = true; }
-	else if (k == "kc_div") { if (v < 1) return PSMC_HIP_EINVAL; c->kc_div = (int)v; c->items_dirty = true; }
 	else if (k == "kc_min") { if (v < -1) return PSMC_HIP_EINVAL; c->kc_min = (int)v; c->items_dirty = true; }
 	else if (k == "ckpt") { c->ckpt = v != 0 ? 1 : 0; }
 	else if (k == "fuse") { c->fuse = v != 0 ? 1 : 0; c->plan_dirty = true; }
-	else if (k == "fuse128") { if (v < 0 || v > 2) return PSMC_HIP_EINVAL; c->fuse128 = (int)v; c->plan_dirty = true; c->items_dirty = true; }
+	else if (k == "fuse128") { if (v != 0 && v != 2) return PSMC_HIP_EINVAL; c->fuse128 = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
-	else if (k == "struct_tiles") { if (v < 1) return PSMC_HIP_EINVAL; c->struct_tiles = (int)v; c->struct_tiles_set = true; c->plan_dirty = true; }
 	else if (k == "share_learn") { c->share_learn = v != 0 ? 1 : 0; }
 	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; c->reserved_refwd = -1; c->reserved_cap = 0; }
 	else if (k == "batch_sort") { c->batch_sort = v != 0 ? 1 : 0; }
-	else if (k == "batch_slots") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_slots = (int)v; }
 	else if (k == "batch_tailfill") c->batch_tailfill = v != 0;
 	else if (k == "batch_major") c->batch_major = v != 0;
 	else if (k == "batch_bins") { if (v < 0) return PSMC_HIP_EINVAL; c->batch_bins = (int64_t)v; }
 	else if (k == "overlap") c->overlap = v != 0 ? 1 : 0;
 	else if (k == "warm_tol") c->warm_tol = v;
 	else if (k == "rep_impl") c->rep_impl = v < 0 ? -1 : (v != 0 ? 1 : 0);
-	else if (k == "expect_impl") c->expect_impl = v != 0 ? 1 : 0;
-	else if (k == "n_sub") { if (v < 1 || v > 64) return PSMC_HIP_EINVAL; c->n_sub = (int)v; c->plan_dirty = true; }
-	else if (k == "target_waves") { if (v < 1) return PSMC_HIP_EINVAL; c->target_waves = (int)v; c->plan_dirty = true; }
 	else return PSMC_HIP_EINVAL;
 	return PSMC_HIP_OK;
 }
@@ -481,7 +470,7 @@ int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins, bool need_f)
 }
 
 // fused backward sweep + counts: structured matrices; 64 states, or 128 with "fuse128"
-bool fused_counts(const psmc_hip_ctx *c) { return c->fuse && c->expect_impl == 1 && (c->ns == 64 || (c->ns == 128 && c->fuse128)); }
+bool fused_counts(const psmc_hip_ctx *c) { return c->fuse && (c->ns == 64 || (c->ns == 128 && c->fuse128)); }
 
 // the column-per-lane transfer-matrix kernel (k_kcol2_struct): 64 states.  With 65..128 states it takes 2.3x fewer vector
 // instructions too, but its chain path ends later and the E-step is slower -- round 2: 30.6 vs 28.3 ms factored; round 3, with
@@ -493,7 +482,7 @@ void fill_common(psmc_hip_ctx *c, EstepLaunch &p, hipStream_t st, const double *
 {
 	memset(&p, 0, sizeof(p));
 	p.stream = st;
-	p.rep_impl = c->rep_impl; p.expect_impl = c->expect_impl; p.n_states = c->n;
+	p.rep_impl = c->rep_impl; p.n_states = c->n;
 	const double *pb = par_base ? par_base : c->d_par; // parameter block (batch: the first of the group's blocks)
 	p.d_a = pb; p.d_aeT = pb + 4096; p.d_e = pb + 4 * 4096; p.d_a0 = pb + 4 * 4096 + 192;
 	p.d_re = pb + 4 * 4096 + 192 + 64;

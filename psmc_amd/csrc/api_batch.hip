@@ -139,7 +139,6 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		int cus = c->cu_count;
 		if (cus <= 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0)) { (void)hipGetLastError(); cus = 256; }
 		ent_cap = (size_t)cus * (c->exact_refwd == 1 ? 2 : 4);
-		if (c->batch_slots > 0) ent_cap = (size_t)std::max(c->batch_slots, 4) / 4 * 4;
 	}
 	// blocks of every replicate
 	std::vector<std::vector<int32_t>> ord(n_rep); // work indices of a replicate, longest first ("batch_sort") or as selected
@@ -413,13 +412,13 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		if (!k) return nullptr;
 		k->n = c->n; k->ns = c->ns; k->device = c->device; k->mode = c->mode; k->parent = c;
 		k->chunk = c->chunk > 0 ? c->chunk : c->share_T; // (share_T = 0 without "share_learn": its own tiling)
-		k->warmup = c->warmup; k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl; k->expect_impl = c->expect_impl;
+		k->warmup = c->warmup; k->max_rounds = c->max_rounds; k->rep_impl = c->rep_impl;
 		k->n_sub = c->n_sub; k->target_waves = c->target_waves; k->overlap = c->overlap; k->warm_tol = c->warm_tol; k->struct_opt = c->struct_opt;
 		k->struct_tiles_set = c->struct_tiles_set; k->struct_tiles = c->struct_tiles;
 		k->two_phase = c->two_phase; k->kc_div = c->kc_div; k->kc_min = c->kc_min; k->ckpt = c->ckpt; k->fuse = c->fuse;
 		k->learn = c->learn; k->group_cap = c->group_cap; k->warm_shift = c->warm_shift; k->kc_sub = c->kc_sub; k->kcol_prio = c->kcol_prio;
-		k->fuse128 = c->fuse128; k->coarse = c->coarse; k->gate = c->gate; k->lanes8 = c->lanes8; k->lanes8b = c->lanes8b; k->gap_tiles = c->gap_tiles; k->exact_refwd = c->exact_refwd;
-		k->merge = c->merge; k->adapt_margin = c->adapt_margin; k->adapt = c->adapt; k->prev_start = c->prev_start;
+		k->fuse128 = c->fuse128; k->coarse = c->coarse; k->gate = c->gate; k->lanes8 = c->lanes8; k->gap_tiles = c->gap_tiles; k->exact_refwd = c->exact_refwd;
+		k->merge = c->merge; k->adapt = c->adapt; k->prev_start = c->prev_start;
 		k->merge1 = c->merge1; k->merge_order = c->merge_order; k->runs_late = c->runs_late; k->warm_shift_set = c->warm_shift_set; k->kc_sub_set = c->kc_sub_set;
 		k->stream = c->stream; k->stream2 = c->stream2; k->stream3 = c->stream3; k->stream4 = c->stream4; k->stream5 = c->stream5;
 		for (int i = 0; i < 14; ++i) k->evx[i] = c->evx[i];
@@ -431,6 +430,38 @@ static psmc_hip_ctx *batch_child(psmc_hip_ctx *c, int r)
 		c->kids.push_back(k);
 	}
 	return c->kids[r];
+}
+
+// A replicate whose fast E-step ends with PSMC_HIP_ECONVERGE (the verify / repair rounds of its tiles ran out) used to end the whole batch --
+// a hundred-replicate job of psmc_boot -- where `psmc` repeats that one E-step with the exact kernels (host/hipbe.c; khmm.c:145-324 has no
+// such failure mode).  The batch does the same: an exact twin of the context over the same observations (borrowed, already in HBM), made on
+// first need, runs THAT replicate's selection; a line on stderr says so; the batch goes on in fast mode.  
+static int batch_exact_once(psmc_hip_ctx *c, int r, const int32_t *idx, int n_sel, const double *a, const double *e, const double *a0,
+                            double *A, double *sums, double *E, double *LL, const char *why)
+{
+	const int n = c->n;
+	fprintf(stderr, "[psmc_hip] replicate %d: fast E-step did not converge (%s); repeating this E-step with the exact kernels\n", c->batch_first + r, why);
+	int rc = 0;
+	if (!c->x_twin) {
+		if ((rc = psmc_hip_create(&c->x_twin, n, c->device, PSMC_HIP_MODE_EXACT))) return fail(c, rc, "estep_batch: cannot create the exact twin context");
+		if ((rc = psmc_hip_load_segments_device(c->x_twin, c->n_seg, c->d_obs, c->off.data(), c->L.data()))) {
+			c->err = "exact twin: " + c->x_twin->err; psmc_hip_destroy(c->x_twin); c->x_twin = nullptr; return rc;
+		}
+	}
+	std::vector<double> Af;
+	double *Ao = A;
+	if (!Ao) { Af.resize((size_t)n * n); Ao = Af.data(); }
+	if ((rc = psmc_hip_select(c->x_twin, n_sel, idx)) || (rc = psmc_hip_estep(c->x_twin, a, e, a0, Ao, E, nullptr, LL, nullptr))) { c->err = "exact twin: " + c->x_twin->err; return rc; }
+	if (sums) { // SL | SU | DG | CL | CU of the exact counts (what psmc_hip_estep_factored returns)
+		memset(sums, 0, sizeof(double) * 5 * (size_t)n);
+		for (int k = 0; k < n; ++k)
+			for (int l = 0; l < n; ++l) {
+				const double v = Ao[(size_t)k * n + l];
+				if (l < k) { sums[k] += v; sums[3 * n + l] += v; } else if (l > k) { sums[n + k] += v; sums[4 * n + l] += v; } else sums[2 * n + k] = v;
+			}
+	}
+	++c->n_exact_fallbacks;
+	return PSMC_HIP_OK;
 }
 
 static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double *e, const double *a0, const int32_t *sel_off,
@@ -480,8 +511,10 @@ static int batch_fast(psmc_hip_ctx *c, int n_rep, const double *a, const double 
 		const double t_e = dbg_now();
 		const double *ar = a + (size_t)r * n * n, *er = e + (size_t)r * 2 * n, *a0r = a0 + (size_t)r * n;
 		if (rc == 0) {
-			if (A) rc = psmc_hip_estep(k, ar, er, a0r, A + (size_t)r * n * n, E ? E + (size_t)r * 2 * n : nullptr, nullptr, LL ? LL + r : nullptr, nullptr);
-			if (rc == 0 && sums) rc = psmc_hip_estep_factored(k, ar, er, a0r, sums + (size_t)r * 5 * n, E ? E + (size_t)r * 2 * n : nullptr, LL ? LL + r : nullptr);
+			double *Ar = A ? A + (size_t)r * n * n : nullptr, *Sr = sums ? sums + (size_t)r * 5 * n : nullptr, *Er = E ? E + (size_t)r * 2 * n : nullptr, *Lr = LL ? LL + r : nullptr;
+			if (A) rc = psmc_hip_estep(k, ar, er, a0r, Ar, Er, nullptr, Lr, nullptr);
+			if (rc == 0 && sums) rc = psmc_hip_estep_factored(k, ar, er, a0r, Sr, Er, Lr);
+			if (rc == PSMC_HIP_ECONVERGE) rc = batch_exact_once(c, r, idx, n_sel, ar, er, a0r, Ar, Sr, Er, Lr, k->err.c_str());
 		}
 		t_est += dbg_now() - t_e;
 		if (rc) { c->err = "replicate " + std::to_string(r) + ": " + k->err; return rc; }

@@ -320,7 +320,10 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 	auto push_kc = [&](int t, int dir) {
 		const int j = (int)kc.size() / 2;
 		kc.push_back(t); kc.push_back(dir);
-		if (gaps && c->gap[t]) {
+		// (one shared matrix only when every gap tile covers the same steps: the backward matrix starts at ((lo + 3) & ~3) + 1 and the chain kernel
+		// adds the tile's own last steps, T in all only if every gap tile has the same lo mod 4, i.e. T % 4 == 0 -- ADVICE r5; a tile length the
+		// caller chose otherwise gets a matrix per tile)
+		if (gaps && c->gap[t] && c->chunk_used % 4 == 0) {
 			if (gap_slot[dir] < 0) { gap_slot[dir] = (int)kuniq.size(); kuniq.push_back(j); }
 			kslot.push_back(gap_slot[dir]);
 		} else { kslot.push_back((int)kuniq.size()); kuniq.push_back(j); }
@@ -341,7 +344,7 @@ static int build_items(psmc_hip_ctx *c, bool two_phase_bwd, int coarse)
 			int first = k[i].second.first, count = k[i].second.second;
 			// what a run's matrices cost: one column kernel per tile that carries data (gap tiles share a matrix computed once per direction)
 			int cost = 0;
-			for (int tt = first; tt < first + count; ++tt) cost += (gaps && c->gap[tt]) ? 0 : 1;
+			for (int tt = first; tt < first + count; ++tt) cost += (gaps && c->gap[tt] && c->chunk_used % 4 == 0) ? 0 : 1;
 			cost = std::max(cost - 1, 1);
 			const bool chain = chains && count >= kc_min && cost <= budget;
 			if (chain) budget -= cost;
@@ -461,7 +464,7 @@ static void adapt_warmups(psmc_hip_ctx *c)
 			const int ml = c->h_mlen[b]; // blocks the fix pass rewrote; -1: the whole tile
 			w = std::min(std::max(cap, w), w + (ml > 0 ? 16 * ml + 64 : w));
 		} else {
-			const double slack = log10(tol / std::max(m, 1e-17)), keep = c->adapt_margin; // decades inside the tolerance; the parameters of the next E-step are other parameters
+			const double slack = log10(tol / std::max(m, 1e-17)), keep = 2.0; // decades inside the tolerance a speculation may keep; the parameters of the next E-step are other parameters
 			if (slack > keep) w = std::max(floor_w, w - (((int)std::min((slack - keep) * 160.0, w / 8.0) + 15) & ~15));
 		}
 		if (w != ch.wf) { ch.wf = w; changed = true; }
@@ -533,7 +536,6 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	// auto: the factored statistics of a genome-sized input (issue-bound at three waves per SIMD); a shard-sized one runs one wave per SIMD,
 	// where the longer step of the 8 x 8 form costs more than its fewer instructions save (3.75 M bins: 3.23 vs 2.96 ms)
 	p.lanes8 = (c->lanes8 >= 0 ? c->lanes8 != 0 && p.fused != 0 : p.fused == 2 && p.n_chunks > 4096) && c->ns == 64 ? 1 : 0;
-	p.lanes8b = c->lanes8b && c->ns == 64 && p.fused == 2 && !p.ckpt ? 1 : 0;
 	{
 		// Partial counts.  Round 4 gave every plan n_tiles x ns^2 doubles (266 MB for a genome's 8127 tiles) whatever its back half: the unfused
 		// counts kernel writes that much, the fused one a partial per GROUP of four tiles (a quarter), the factored one seven vectors per

@@ -49,7 +49,7 @@ template <int NPL> __device__ __forceinline__ double lane_sum_a(const double (&x
 
 // One position p of one row: x = bt_{p+1} on entry, bt_p on exit; X = X_p.  NORM: p % NORM_EVERY == 0.
 // NPLA_ states per lane: 4 (up to 64 states) or 8 (up to 128, `-p "64*2"`); 16 lanes = one tile either way.
-// LPT lanes per tile: 16 (a DPP row), or 8 with 8 states per lane -- 64 states as eight tiles per wave ("lanes8b", round 5 experiment)
+// LPT lanes per tile: 16 (a DPP row), or 8 with 8 states per lane -- 64 states as eight tiles per wave (round 5 experiment, removed)
 template <bool NORM, int NPLA = 4, int LPT = 16>
 __device__ __forceinline__ void acc_step(const StructParN<NPLA> &sc, const double *lds_e, const double *lds_m, int k0, int sym,
                                          const double (&X)[NPLA], double (&x)[NPLA], double inv, double (&acc)[NACC][NPLA],
@@ -254,91 +254,8 @@ __global__ __launch_bounds__(64, NPLA == 4 ? 2 : 1) void k_bwd_acc_struct(const 
 	if (valid) acc_store<NPLA>(sc, (double)c.mult * iI, acc, part + (int64_t)tile * (NACC * SA) + k0);
 }
 
-// ROUND 5 EXPERIMENT ("lanes8b"): the same back half with EIGHT tiles per wave -- 8 lanes x 8 states per tile, the
-// scans one level shorter (struct_prims.h half8_*) -- for 64 states, X read from the full table (no checkpoints).  One wave per SIMD
-// (7 x 8 accumulators + 5 x 8 constants per lane: the 128-state kernel's register budget).  mode as k_bwd_acc_struct.
-__global__ __launch_bounds__(64, 1) void k_bwd_acc_struct_h8(const double *__restrict__ sp, const double *__restrict__ e,
-                                                             const double *__restrict__ invd, const uint8_t *__restrict__ obs,
-                                                             const Chunk *__restrict__ chunks, const SweepItemA *__restrict__ items,
-                                                             int n, int mode, const double *__restrict__ f,
-                                                             double *__restrict__ bentry, double *__restrict__ bexit,
-                                                             double *__restrict__ part, const int *__restrict__ touch_f,
-                                                             int *__restrict__ touch_b)
-{
-	constexpr int NP = 8, LPT = 8, SA = 64, R = 8;
-	__shared__ double lds_e[4 * SA], lds_m[8];
-	const int lane = threadIdx.x, row = lane >> 3, m = lane & 7, k0 = NP * m;
-	const Half8Masks hm = half8_masks(lane);
-	{ const int q = ev_slot<NP, LPT>(lane); lds_e[q] = e[lane]; lds_e[SA + q] = e[SA + lane]; lds_e[2 * SA + q] = 1.0; lds_e[3 * SA + q] = 1.0; }
-	if (lane < 8) lds_m[lane] = (lane == 0 || lane == 3) ? 1.0 : 0.0;
-	__syncthreads();
-	const int slot = blockIdx.x * R + row;
-	int tile; bool valid = slot < n;
-	if (mode == 2) { tile = valid ? slot : 0; valid = valid && touch_f[tile] != 0; }
-	else tile = items[valid ? slot : 0].first;
-	if (!__any(valid)) return;
-	if (mode == 1) __builtin_amdgcn_s_setprio(3);
-	const Chunk c = chunks[tile];
-	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
-	const bool work = valid && top >= lo;
-	const double *fo = f + c.off * SA + k0;
-	const double *io = invd + c.off;
-	StructParN<NP> sc; // backward: mS = c, wS = R, mP = qa, wP = P
-	loadN<NP>(sp + 3 * SA + k0, sc.mS); loadN<NP>(sp + SA + k0, sc.wS);
-	loadN<NP>(sp + 2 * SA + k0, sc.mP); loadN<NP>(sp + k0, sc.wP); loadN<NP>(sp + 4 * SA + k0, sc.dd);
-	double x[NP];
-	if (mode == 1) {
-		loadN<NP>(bexit + (int64_t)(tile + 1) * SA + k0, x);
-		if (work) { storeN<NP>(bentry + (int64_t)tile * SA + k0, x); if (m == 0) touch_b[tile] = 1; }
-	} else loadN<NP>(bentry + (int64_t)tile * SA + k0, x);
-	double acc[NACC][NP], accI = 1.0;
-#pragma unroll
-	for (int q = 0; q < NACC; ++q)
-#pragma unroll
-		for (int i = 0; i < NP; ++i) acc[q][i] = 0.0;
-	const int n_pos = work ? top - lo + 1 : 0;
-	auto load_inv = [&](int g) { return io[min(max(4 * g + 4, lo), max(top, lo)) - 1]; };
-	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
-	const int ng = g_hi - g_lo + 1;
-	int64_t roff[R]; int rgh[R], rn[R]; int ng_max = 0;
-#pragma unroll
-	for (int r = 0; r < R; ++r) {
-		roff[r] = readlane_i64a(c.off, LPT * r); rgh[r] = __builtin_amdgcn_readlane(g_hi, LPT * r); rn[r] = __builtin_amdgcn_readlane(ng, LPT * r);
-		ng_max = max(ng_max, rn[r]);
-	}
-	double Xg[4][NP];
-	auto load_row = [&](int g, int j, double (&X)[NP]) { const int p = min(max(4 * g + j + 1, lo), max(top, lo)); loadN<NP>(fo + (int64_t)(p - 1) * SA, X); };
-#pragma unroll
-	for (int j = 0; j < 4; ++j) load_row(max(g_hi, 0), j, Xg[j]);
-	double inv_cur = load_inv(max(g_hi, 0));
-	for (int gi = 0; gi < ng_max; ++gi) {
-		unsigned w = 0;
-#pragma unroll
-		for (int r = 0; r < R; ++r) { // the group's four symbols of every row: scalar loads
-			const unsigned wr = *reinterpret_cast<const unsigned *>(obs + roff[r] + 4 * (int64_t)max(rgh[r] - min(gi, max(rn[r] - 1, 0)), 0));
-			w = row == r ? wr : w;
-		}
-		if (gi < ng) {
-			const int g = g_hi - gi;
-			const double inv = inv_cur;
-			if (gi + 1 < ng) inv_cur = load_inv(g - 1);
-#pragma unroll
-			for (int j = 3; j >= 0; --j) { // every row is reloaded for the next group as soon as its step has used it (as with 128 states)
-				const int p = 4 * g + j + 1;
-				if (p <= top && p >= lo) {
-					const int sym = (int)((w >> (8 * j)) & 3u);
-					if (j == 3) acc_step<true, NP, LPT>(sc, lds_e, lds_m, k0, sym, Xg[j], x, inv, acc, accI, hm);
-					else acc_step<false, NP, LPT>(sc, lds_e, lds_m, k0, sym, Xg[j], x, inv, acc, accI, hm);
-					if (p == lo) storeN<NP>(bexit + (int64_t)tile * SA + k0, x);
-				}
-				if (gi + 1 < ng) load_row(g - 1, j, Xg[j]);
-			}
-		}
-	}
-	const double iI = tile_inv_I<LPT>(accI, n_pos);
-	if (valid) acc_store<NP, LPT>(sc, (double)c.mult * iI, acc, part + (int64_t)tile * (NACC * SA) + k0);
-}
-
+// (Round 5 measured this back half with EIGHT tiles per wave, 8 lanes x 8 states, k_bwd_acc_struct_h8 / option "lanes8b": 5.17 against 4.51 ms --
+// 7 x 8 accumulators + 5 x 8 constants per lane spill; removed in round 6, profiles/r05_lanes8b_ab.txt keeps the record.)
 constexpr int NPLA = 4, SA = 64; // the checkpointed variant below is the 64-state one
 
 // The same without the X table: the forward sweep left only the checkpoints X_p, p % 8 == 0 (SWEEP_CKPT in
@@ -535,9 +452,6 @@ void launch_bwd_acc(const EstepLaunch &p, hipStream_t st, int which, int first, 
 	if (p.ckpt)
 		hipLaunchKernelGGL(k_bwd_acc_ckpt, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_entry, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
-	else if (p.ns == 64 && p.lanes8b)
-		hipLaunchKernelGGL(k_bwd_acc_struct_h8, dim3((n + 7) / 8), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,
-		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);
 	else if (p.ns == 128)
 		hipLaunchKernelGGL(k_bwd_acc_struct<8>, dim3((n + 3) / 4), dim3(64), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, items, n,
 		                   mode, p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_touch_f, p.d_touch_b);

@@ -401,53 +401,6 @@ __global__ __launch_bounds__(64, 2) void k_expect_mfma(const Chunk *__restrict__
 	}
 }
 
-// VALU cross-check of the above: lane = k, 64 accumulators C[k][0..63] per lane.
-#define PSMC_OUTER4(N)                                                    \
-	fmac_bcast<N>(C[N], r[0], X);      fmac_bcast<N>(C[16 + N], r[1], X);    \
-	fmac_bcast<N>(C[32 + N], r[2], X); fmac_bcast<N>(C[48 + N], r[3], X);
-__global__ __launch_bounds__(64) void k_expect_valu(const Chunk *__restrict__ chunks, int n_sub,
-                                                      const uint8_t *__restrict__ obs, const double *__restrict__ f,
-                                                      const double *__restrict__ bt, const double *__restrict__ sb,
-                                                      const double *__restrict__ re, double *__restrict__ Cpart,
-                                                      double *__restrict__ Spart, const int *__restrict__ touch_f,
-                                                      const int *__restrict__ touch_b, int redo)
-{
-	const int lane = threadIdx.x;
-	const Chunk c = chunks[blockIdx.x / n_sub];
-	if (redo && !tile_touched(chunks, blockIdx.x / n_sub, touch_f, touch_b)) return;
-	const int sub = blockIdx.x % n_sub;
-	const int top = min(c.hi, c.L - 1), n = top - c.lo + 1;
-	const int per = n > 0 ? ((((n + n_sub - 1) / n_sub) + 3) & ~3) : 0;
-	const int p0 = c.lo + sub * per, p1 = min(top, p0 + per - 1);
-	const double *fo = f + c.off * 64, *bo = bt + c.off * 64, *sbo = sb + c.off;
-	const uint8_t *o = obs + c.off;
-	const double re0 = re[lane], re1 = re[64 + lane];
-	double C[64], S0 = 0.0, S1 = 0.0, S2 = 0.0;
-#pragma unroll
-	for (int l = 0; l < 64; ++l) C[l] = 0.0;
-	for (int p = p0; p <= p1; ++p) {
-		const int sym = o[p - 1];
-		const double sc = (p & (NORM_EVERY - 1)) == 0 ? sbo[p - 1] : 1.0;
-		const double g = fo[(int64_t)(p - 1) * 64 + lane] * bo[(int64_t)(p - 1) * 64 + lane] * (sym == 0 ? re0 : (sym == 1 ? re1 : 1.0));
-		const double iG = 1.0 / first_lane_f64(wave_sum_nat(g));
-		if (sym == 0) S0 += g * iG; else if (sym == 1) S1 += g * iG; else S2 += g * iG;
-		double X = fo[(int64_t)(p - 1) * 64 + lane] * (sc * iG);
-		double r[4];
-#pragma unroll
-		for (int j = 0; j < 4; ++j) r[j] = bo[(int64_t)p * 64 + 16 * j + (lane & 15)]; // replicated load of bt[p+1]
-		dpp_guard(r);
-		PSMC_OUTER4(0) PSMC_OUTER4(1) PSMC_OUTER4(2) PSMC_OUTER4(3) PSMC_OUTER4(4) PSMC_OUTER4(5)
-		PSMC_OUTER4(6) PSMC_OUTER4(7) PSMC_OUTER4(8) PSMC_OUTER4(9) PSMC_OUTER4(10) PSMC_OUTER4(11)
-		PSMC_OUTER4(12) PSMC_OUTER4(13) PSMC_OUTER4(14) PSMC_OUTER4(15)
-	}
-	const double mult = (double)c.mult;
-	double *out = Cpart + (int64_t)blockIdx.x * 4096 + lane * 64;
-#pragma unroll
-	for (int l = 0; l < 64; ++l) out[l] = C[l] * mult;
-	double *os = Spart + (int64_t)blockIdx.x * 192;
-	os[lane] = S0 * mult; os[64 + lane] = S1 * mult; os[128 + lane] = S2 * mult;
-}
-
 // ------------------------------------------------------------------ log-likelihood
 // LL of a tile = sum over its normalising positions of log d_p = -log inv_d  (+ log sum(X_L)
 // for the last tile): running products flushed through log() like hmm_lk (khmm.c:245-260).
@@ -558,10 +511,6 @@ static void launch_bwd(const EstepLaunch &p, hipStream_t st)
 static void launch_expect(const EstepLaunch &p, hipStream_t st, int redo)
 {
 	const int nC = p.n_chunks * p.n_sub;
-	if (p.expect_impl == 0)
-		hipLaunchKernelGGL(k_expect_valu, dim3(nC), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,
-		                   p.d_re, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b, redo);
-	else
 	{
 		if (p.ns == 128)
 			hipLaunchKernelGGL(k_expect_mfma<128>, dim3(nC * 4), dim3(64), 0, st, p.d_chunks, p.n_sub, p.d_obs, p.d_f, p.d_b, p.d_sb,

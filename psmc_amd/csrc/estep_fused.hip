@@ -253,184 +253,9 @@ __global__ __launch_bounds__(64, 1) void k_bwd_count4f_struct(const double *__re
 	}
 }
 
-// ---- 128 states (`-p "64*2"`): the same fusion with four waves per group of four tiles.
-// A lane holds eight adjacent states of its row's tile (k = 8 i + j), so the 128 x 128 partial is 64 blocks
-// C[8 M + j][8 N + j'] -- 512 accumulation registers, four times what a wave can spare next to the sweep.  The group's
-// four waves each run the whole backward sweep and own a quarter of the blocks: wave q the rows j = 2 q, 2 q + 1, all
-// eight j' -> 16 matrix instructions per step into 128 accumulation registers, like the 64-state kernel.  (Two waves
-// with 32 matrix instructions each would halve the redundant sweeps, but 256 accumulation registers leave the
-// sweep less than it needs: that version spilled accumulators to scratch inside the loop and ran at 35 ms against
-// the 27 ms of this one.)  Of X a wave reads only the two values per lane that are its operand A (a 16-byte load offset
-// by the wave number: an address, not a register index), and it takes the emission counts of the same two states -- whole
-// X rows are never in registers.  A barrier per group of four positions keeps the waves on the same cache lines.
 constexpr int NPL8 = 8, S8 = 128;
-template <bool NORM, bool MASKED>
-__device__ __forceinline__ void count8_step(const StructParN<NPL8> &sc, const double *lds_e, const double *lds_m, int k0, int sym, int q,
-                                            const double (&Xq)[2], double (&x)[NPL8], bool active, double inv, double &rho,
-                                            d4f_t (&acc)[2][NPL8], double (&S)[2][2])
-{
-	double ev[NPL8], y[NPL8], FA[2], FB[NPL8];
-	ev_load<NPL8>(lds_e + sym * S8, k0, ev);
-	const d2v_t mk = *reinterpret_cast<const d2v_t *>(lds_m + 2 * sym); // (1,0) hom, (0,1) het, (0,0) missing
-	double rho_next = rho;
-	if (NORM) { // bt keeps its own scaling, the weight follows both scale factors (see count4f_step)
-		double t = 0.0;
-#pragma unroll
-		for (int i = 0; i < NPL8; ++i) t += x[i];
-		const double tot = row_sum16(t);
-		const double sb = rcp_newton(tot);
-#pragma unroll
-		for (int i = 0; i < NPL8; ++i) ev[i] *= sb;
-		rho_next = rho * (inv * tot);
-		if (MASKED) rho_next = active ? rho_next : rho;
-	}
-#pragma unroll
-	for (int i = 0; i < NPL8; ++i) y[i] = x[i];
-	struct_step<NPL8>(sc, y);
-#pragma unroll
-	for (int j = 0; j < 2; ++j) { // operand A and the emission counts of the wave's two states: E[o_p][k] += rho X_p[k] y_p[k]
-		FA[j] = rho * Xq[j];
-		if (MASKED) FA[j] = active ? FA[j] : 0.0;
-		const double yq = q == 0 ? y[j] : (q == 1 ? y[2 + j] : (q == 2 ? y[4 + j] : y[6 + j])); // wave-uniform select
-		const double gk = MASKED ? (active ? FA[j] * yq : 0.0) : FA[j] * yq; // selected, not multiplied away (count4f_step)
-		S[0][j] = __builtin_fma(gk, mk.x, S[0][j]);
-		S[1][j] = __builtin_fma(gk, mk.y, S[1][j]);
-	}
-#pragma unroll
-	for (int i = 0; i < NPL8; ++i) {
-		FB[i] = MASKED ? (active ? x[i] : 0.0) : x[i];
-		const double nb = y[i] * ev[i];
-		x[i] = MASKED ? (active ? nb : x[i]) : nb;
-	}
-#pragma unroll
-	for (int j = 0; j < 2; ++j)
-#pragma unroll
-		for (int j2 = 0; j2 < NPL8; ++j2) acc[j][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[j], FB[j2], acc[j][j2], 0, 0, 0);
-	rho = rho_next;
-}
-
-__global__ __launch_bounds__(256, 1) void k_bwd_count8_struct(const double *__restrict__ sp, const double *__restrict__ e,
-                                                                const double *__restrict__ invd, const uint8_t *__restrict__ obs,
-                                                                const Chunk *__restrict__ chunks, const int *__restrict__ tiles,
-                                                                int group0, int mode, const double *__restrict__ f,
-                                                                double *__restrict__ bentry, double *__restrict__ bexit,
-                                                                double *__restrict__ Cpart,
-                                                                double *__restrict__ Epart, const int *__restrict__ touch_f,
-                                                                const int *__restrict__ touch_b)
-{
-	__shared__ double lds_e[4 * S8], lds_m[8];
-	const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, row = lane >> 4, m = lane & 15, k0 = NPL8 * m;
-	const bool wave0 = q == 0;
-	if (tid < S8) { const int q8 = ev_slot<NPL8>(tid); lds_e[q8] = e[tid]; lds_e[S8 + q8] = e[S8 + tid]; lds_e[2 * S8 + q8] = 1.0; lds_e[3 * S8 + q8] = 1.0; } // ev_load layout
-	if (tid < 8) lds_m[tid] = (tid == 0 || tid == 3) ? 1.0 : 0.0;
-	__syncthreads();
-	const int group = group0 + blockIdx.x;
-	const int entry = tiles[4 * blockIdx.x + row];
-	const bool valid = entry >= 0, from_above = valid && mode == 0 && (entry & (1 << 30)) != 0;
-	const int tile = valid ? (entry & ~(1 << 30)) : 0;
-	// (block-uniform: every wave sees the same four tiles)
-	if (mode == 2 && !__any(valid && (touch_f[tile] | touch_b[tile]) != 0)) return;
-	const Chunk c = chunks[tile];
-	const int L = c.L, lo = c.lo, top = min(c.hi, L - 1);
-	const bool work = valid && top >= lo;
-	const double *fo = f + c.off * S8 + k0;
-	const double *fq = fo + 2 * q; // the wave's two rows j = 2 q, 2 q + 1 of C
-	const double *io = invd + c.off;
-	StructParN<NPL8> sc; // backward: mS = c, wS = R, mP = qa, wP = P
-	loadN<NPL8>(sp + 3 * S8 + k0, sc.mS); loadN<NPL8>(sp + S8 + k0, sc.wS);
-	loadN<NPL8>(sp + 2 * S8 + k0, sc.mP); loadN<NPL8>(sp + k0, sc.wP); loadN<NPL8>(sp + 4 * S8 + k0, sc.dd);
-	double x[NPL8];
-	loadN<NPL8>((from_above ? bexit + (int64_t)(tile + 1) * S8 : bentry + (int64_t)tile * S8) + k0, x);
-	__syncthreads(); // every wave has read the vector before wave 0 overwrites bentry
-	if (from_above && wave0) storeN<NPL8>(bentry + (int64_t)tile * S8 + k0, x);
-	const int p_min = lo, p_max = max(top, lo);
-	double rho;
-	{
-		double y[NPL8], Xt[NPL8];
-		loadN<NPL8>(fo + (int64_t)(p_max - 1) * S8, Xt);
-#pragma unroll
-		for (int i = 0; i < NPL8; ++i) y[i] = x[i];
-		struct_step<NPL8>(sc, y);
-		double t = 0.0;
-#pragma unroll
-		for (int i = 0; i < NPL8; ++i) t = __builtin_fma(Xt[i], y[i], t);
-		rho = work ? (double)c.mult * rcp_newton(row_sum16(t)) : 0.0;
-	}
-	d4f_t acc[2][NPL8];
-	double S[2][2];
-#pragma unroll
-	for (int j = 0; j < 2; ++j) {
-#pragma unroll
-		for (int j2 = 0; j2 < NPL8; ++j2) acc[j][j2] = (d4f_t){0.0, 0.0, 0.0, 0.0};
-		S[0][j] = S[1][j] = 0.0;
-	}
-	const int g_hi = work ? (top - 1) >> 2 : -1, g_lo = work ? (lo - 1) >> 2 : 0;
-	const int ng = g_hi - g_lo + 1;
-	const int64_t off0 = readlane_i64f(c.off, 0), off1 = readlane_i64f(c.off, 16), off2 = readlane_i64f(c.off, 32), off3 = readlane_i64f(c.off, 48);
-	const int gh0 = __builtin_amdgcn_readlane(g_hi, 0), gh1 = __builtin_amdgcn_readlane(g_hi, 16), gh2 = __builtin_amdgcn_readlane(g_hi, 32), gh3 = __builtin_amdgcn_readlane(g_hi, 48);
-	const int n0 = __builtin_amdgcn_readlane(ng, 0), n1 = __builtin_amdgcn_readlane(ng, 16), n2 = __builtin_amdgcn_readlane(ng, 32), n3 = __builtin_amdgcn_readlane(ng, 48);
-	const int ng_max = max(max(n0, n1), max(n2, n3));
-	auto row_pos = [&](int g, int j) { return min(max(4 * g + j + 1, p_min), p_max); };
-	auto load_inv = [&](int g) { return io[min(max(4 * g + 4, p_min), p_max) - 1]; };
-	double Xq[4][2];
-#pragma unroll
-	for (int j = 0; j < 4; ++j) loadN<2>(fq + (int64_t)(row_pos(max(g_hi, 0), j) - 1) * S8, Xq[j]);
-	double inv_cur = load_inv(max(g_hi, 0));
-	auto all_full = [&](int gi_) {
-		const int g = max(g_hi - gi_, g_lo);
-		return __all(gi_ < ng && 4 * g + 1 >= lo && 4 * g + 4 <= top) != 0;
-	};
-	int gi = 0;
-	auto do_group = [&](auto masked_tag) {
-		constexpr bool MASKED = decltype(masked_tag)::value;
-		const unsigned w0 = *reinterpret_cast<const unsigned *>(obs + off0 + 4 * (int64_t)max(gh0 - min(gi, max(n0 - 1, 0)), 0));
-		const unsigned w1 = *reinterpret_cast<const unsigned *>(obs + off1 + 4 * (int64_t)max(gh1 - min(gi, max(n1 - 1, 0)), 0));
-		const unsigned w2 = *reinterpret_cast<const unsigned *>(obs + off2 + 4 * (int64_t)max(gh2 - min(gi, max(n2 - 1, 0)), 0));
-		const unsigned w3 = *reinterpret_cast<const unsigned *>(obs + off3 + 4 * (int64_t)max(gh3 - min(gi, max(n3 - 1, 0)), 0));
-		const unsigned w = row == 0 ? w0 : (row == 1 ? w1 : (row == 2 ? w2 : w3));
-		const int g = max(g_hi - gi, g_lo);
-		const bool in_tile = gi < ng;
-		const int s3 = (int)((w >> 24) & 3u), s2 = (int)((w >> 16) & 3u), s1 = (int)((w >> 8) & 3u), s0 = (int)(w & 3u);
-		const int pb = 4 * g + 1;
-		const double inv = inv_cur;
-#define PSMC_C8(NORM, J, SYM)                                                                                                            \
-		count8_step<NORM, MASKED>(sc, lds_e, lds_m, k0, SYM, q, Xq[J], x, in_tile && pb + J <= top && pb + J >= lo, inv, rho, acc, S); \
-		loadN<2>(fq + (int64_t)(row_pos(g - 1, J) - 1) * S8, Xq[J]);                                                                 \
-		if (J == 3) inv_cur = load_inv(g - 1);                                                                                       \
-		__builtin_amdgcn_sched_barrier(0);
-		PSMC_C8(true, 3, s3) PSMC_C8(false, 2, s2) PSMC_C8(false, 1, s1) PSMC_C8(false, 0, s0)
-#undef PSMC_C8
-		if (wave0 && in_tile && g == g_lo) storeN<NPL8>(bexit + (int64_t)tile * S8 + k0, x);
-		__syncthreads(); // the four waves walk the same cache lines
-	};
-	for (; gi < ng_max && !all_full(gi); ++gi) do_group(std::true_type{});
-	for (; gi < ng_max && all_full(gi); ++gi) do_group(std::false_type{});
-	for (; gi < ng_max; ++gi) do_group(std::true_type{});
-	// the matrix-core results are not interlocked against plain reads: let the last instructions drain
-	asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
-	             : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]),
-	               "+a"(acc[0][7]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[1][4]), "+a"(acc[1][5]),
-	               "+a"(acc[1][6]), "+a"(acc[1][7]));
-	// C[8 M + j][8 N + j2], j = 2 q + jj, M = row + 4 r, N = m: eight adjacent columns per lane
-	double *out = Cpart + (int64_t)group * (S8 * S8);
-#pragma unroll
-	for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			double v[NPL8];
-#pragma unroll
-			for (int j2 = 0; j2 < NPL8; ++j2) v[j2] = acc[jj][j2][r];
-			storeN<NPL8>(out + (int64_t)(8 * (row + 4 * r) + 2 * q + jj) * S8 + k0, v);
-		}
-	if (valid) {
-		double *os = Epart + (int64_t)tile * (3 * S8) + k0 + 2 * q;
-		const double zero[2] = {0.0, 0.0};
-		storeN<2>(os, S[0]); storeN<2>(os + S8, S[1]); storeN<2>(os + 2 * S8, zero);
-	}
-}
-
-// ---- 128 states, ONE sweep per tile (round 4): k_bwd_count8x_struct, "fuse128" = 2.
-// k_bwd_count8_struct above lets each of a group's four waves redo the whole eight-states-per-lane sweep of the SAME four tiles to
+// ---- 128 states (`-p "64*2"`), ONE sweep per tile (round 4): k_bwd_count8x_struct, "fuse128" = 2.
+// Round 3's kernel (k_bwd_count8_struct, "fuse128" = 1; removed in round 6) let each of a group's four waves redo the whole eight-states-per-lane sweep of the SAME four tiles to
 // own a quarter of C: three of the four sweeps are redundant (9.4 vector instructions per matrix instruction, 0.45 of the FP64 peak
 // on the algorithmic flops).  Here a work-group holds SIXTEEN tiles, four per wave.  Every wave sweeps only its own four tiles and
 // publishes, per position, both operands of the matrix instructions -- rho.X (8 per lane) and bt (8 per lane) -- to LDS; after one
@@ -677,12 +502,8 @@ void launch_bwd_count(const EstepLaunch &p, hipStream_t st, int list, bool redo,
 	const int *tl = p.d_ftiles + (list == 0 ? 0 : G * ga);
 	const int g0 = list == 0 ? 0 : ga, md = all_from_bentry ? 3 : (redo ? 2 : 0); // 3 (diagnostic): every group, every tile from its bentry
 	if (p.ns == 128) {
-		if (G == G8X)
-			hipLaunchKernelGGL(k_bwd_count8x_struct, dim3(n_groups), dim3(256), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
-			                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
-		else
-			hipLaunchKernelGGL(k_bwd_count8_struct, dim3(n_groups), dim3(256), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
-			                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
+		hipLaunchKernelGGL(k_bwd_count8x_struct, dim3(n_groups), dim3(256), 0, st, p.d_sp, p.d_e, p.d_s, p.d_obs, p.d_chunks, tl, g0, md,
+		                   p.d_f, p.d_bentry, p.d_bexit, p.d_Cpart, p.d_Epart, p.d_touch_f, p.d_touch_b);
 		PSMC_DBG("launch_bwd_count (128 states)", list, redo, n_groups);
 		return;
 	}

@@ -27,7 +27,7 @@ struct psmc_hip_ctx {
 	int n = 0, ns = 64, device = 0, mode = PSMC_HIP_MODE_EXACT; // ns: states padded to 64 or 128
 	std::string err;
 	// options
-	int chunk = 0, warmup = 3072, max_rounds = 4096, rep_impl = -1, expect_impl = 1, n_sub = 6, target_waves = 1536, overlap = 1;
+	int chunk = 0, warmup = 3072, max_rounds = 4096, rep_impl = -1, n_sub = 6, target_waves = 1536, overlap = 1;
 	double warm_tol = 1e-12;
 	int struct_opt = 1;        // "structured": 1 = use the O(N) sweeps when a[][] factors (auto), 0 = always dense
 	bool struct_tiles_set = false; // the caller chose struct_tiles: no adaptation to small inputs
@@ -47,7 +47,6 @@ struct psmc_hip_ctx {
 	int lanes8 = -1;           // "lanes8": 64 states, fused / factored plans: the bulk sweeps of phase 1 run eight tiles per wave (8 lanes x 8 states: a quarter
 	                           // fewer vector instructions per tile-step, half the waves).  -1 = with the factored statistics of a genome-sized input only (more than one round of tiles) -- measured (round 4, genome):
 	                           // factored 10.26 -> 9.91 ms; full counts 12.09 -> 12.73 (its forward sweep is paced by 15.6 GB of stores and half as many waves hide less)
-	int lanes8b = 0;           // "lanes8b": the factored back half WITHOUT checkpoints ("ckpt" = 0) runs eight tiles per wave (round 5 experiment: slower, off)
 	int gate = -1;             // "gate": order the dispatch of phase 1's grids walks -> bulk -> transfer matrices (estep_struct.hip k_gate); -1 = with coarse
 	                           // items (measured: without them the bulk grid is the critical path and walks that land late, stacked on few SIMDs, slow fewer of its waves)
 	int *d_gate = nullptr;
@@ -65,14 +64,13 @@ struct psmc_hip_ctx {
 	int ckpt = 1;              // "ckpt": factored statistics recompute X from checkpoints every 8 positions instead of reading the table
 	int fuse = 1;              // "fuse": backward sweep and counts in one kernel (estep_fused.hip): structured matrices, up to 64 states
 	int fuse128 = 2;           // "fuse128": the same with 65..128 states: 2 = k_bwd_count8x_struct (sixteen tiles per work-group, one sweep per tile, operands
-	                           // exchanged through LDS), 1 = k_bwd_count8_struct (four waves redo the sweep of four tiles), 0 = unfused
+	                           // exchanged through LDS), 0 = unfused (1, round 3's kernel -- four waves redo the sweep of four tiles -- was removed in round 6)
 	int count_group = 4;       // tiles per work-group of the fused back half, what the tile lists are padded to (build_items)
 	// Round 6: mis-speculation made cheap, then warm-ups sized per tile -- built, measured, and OFF: halving every warm-up at no
 	// cost at all is worth 0.35 ms of 12.25 (profiles/r06_warmup_sensitivity.txt), and the three together cost more than that (profiles/r06_fix_pass_ab.txt).
 	int merge = 0;             // "merge": the forward fix pass between the forward sweep and the back half (estep_struct.hip FwdCtl): a mis-speculated tile is rewritten
 	                           // until it meets its stored trajectory, nothing is counted twice (0: verify afterwards, whole tiles and their groups of the counts again)
 	int adapt = 0;             // "adapt": with "merge", every speculating tile's forward warm-up follows the mismatch its speculation left at the last E-step (0: "warmup" for all)
-	double adapt_margin = 2.0; // "adapt_margin": decades inside "warm_tol" a speculation is allowed to keep before its warm-up shrinks
 	int prev_start = 0;        // "prev_start": forward warm-ups start from the previous E-step's X at that position instead of the stationary vector
 	int *h_mlen = nullptr, *m_mlen = nullptr;        // pinned + device-mapped [n_chunks]: blocks each merging repair rewrote / -1
 	double *h_mis = nullptr, *m_mis = nullptr;       // pinned + device-mapped [2][n_chunks]: first-verify mismatch of every tile, forward | backward
@@ -168,7 +166,6 @@ struct psmc_hip_ctx {
 	int64_t *d_lkoff = nullptr; size_t lkoff_cap = 0;                     // ... and where each entry's begin
 	double *d_s_all = nullptr; size_t s_all_cap = 0; // exact batch without the f table, several groups: the scale factors of ALL replicates (one forward pass)
 	int batch_sort = 1;                // "batch_sort": the exact batch deals ENTRIES to its launches longest first (api_batch.hip); 0 = replicate-major order
-	int batch_slots = 0;               // "batch_slots": entries per launch of an exact batch that needs several (0: four per compute unit of the context's share)
 	int batch_tailfill = 1;            // "batch_tailfill": the exact batch puts the shortest entries into the spare slots of the memory-bound launches when that saves a launch
 	int batch_major = 1;               // "batch_major": blocks no longer than the dominant trunk length keep replicate order (replicates complete launch by launch)
 	int batch_first = 0;               // "batch_first": the next batch calls' replicate 0 is replicate batch_first of the context (fast mode: which kept plan it uses)
@@ -179,6 +176,8 @@ struct psmc_hip_ctx {
 	bool tables_batch = false;         // the tables hold the slots of a batch group, not the segments at their own offsets
 	// fast batch: one plan-holding child per replicate; children share the parent's streams, events, parameter
 	// staging, observations and TABLES (they run one after the other)
+	psmc_hip_ctx *x_twin = nullptr;    // fast batch: an exact-mode context over the same observations, made when a replicate's fast E-step does not converge (api_batch.hip batch_exact_once)
+	int n_exact_fallbacks = 0;
 	psmc_hip_ctx *parent = nullptr;
 	std::vector<psmc_hip_ctx *> kids;
 	// ... and what the replicates of one parent have LEARNED is shared through the parent (round 4): they tile every segment with the

@@ -49,7 +49,7 @@ struct EstepLaunch {
 	hipStream_t stream, stream2, stream3; // forward chain (main), backward chain, early expect
 	hipEvent_t evx[14];          // cross-stream dependencies; 4/5: count read-backs of the two chains; 6/7: glued runs done
 	int overlap;
-	int rep_impl, expect_impl, n_states;
+	int rep_impl, n_states;
 	const int64_t *d_work_tab_s; // ExWork::tab_s
 	int *d_cu_mask = nullptr;    // k_expect_exact_rf2: 4096 zeroed words, or null (static wave roles)
 	int exact_only;              // exact batch: 1 = only the forward pass (scale factors), 2 = everything but the forward pass, 0 = all three
@@ -78,7 +78,6 @@ struct EstepLaunch {
 	const int *d_members_f, *d_members_b; // every tile of the glued runs as a one-tile item
 	int n_mem_f, n_mem_b;
 	int lanes8;                       // 64 states: the bulk sweeps of phase 1 run eight tiles per wave (estep_struct.hip launch_fwd_struct)
-	int lanes8b;                      // 64 states, factored back half without checkpoints: eight tiles per wave as well (estep_factored.hip k_bwd_acc_struct_h8; experiment)
 	int *d_gate;                      // [0] walk blocks started, [1] bulk blocks started: the gates that order the DISPATCH of phase 1's grids (estep_struct.hip
 	                                  // k_gate); null: no gates
 	int coarse;                       // > 1: a bulk item spans up to this many tiles (one speculation per item; the backward pass of the fused /

@@ -21,7 +21,7 @@
  * the ENGINES: only multiples of 32 leave every engine the same number of units.  Measured with the main run alive (100 replicates
  * of a 30 M-bin genome, profiles/r05_boot_schedule.txt): batch alone 6.75 s per EM iteration; with the main run on 32 masked
  * units 7.27 s, the main run 3.3 s per E-step (alone: 3.09); on 24 units (engines left 7 / 7 / 7 / 8 units) 9.4 s; without masks
- * (PSMC_BOOT_MAIN_CUS=0: the batch keeps PSMC_BOOT_MAIN_SLOTS entry slots per launch free) 10 s -- the main run's resident waves
+ * (round 5's A/B: the batch kept entry slots free instead; removed in round 6) 10 s -- the main run's resident waves
  * keep the batch's work-groups, which need a whole SIMD's registers, out of their compute units, and a launch that has to place one
  * work-group late lasts twice as long.  The main output is byte-identical to `psmc`'s, the replicates to a run without --main
  * (tests/test_host_cli.py).
@@ -46,11 +46,11 @@ static int bb_reserve(void *self, int dev, int64_t table_bins)
 {
 	return psmc_hip_reserve_batch_tables(((hip_bb *)self)->ctx[dev], table_bins);
 }
-/* the main run that shared device main_dev is over: its compute units (and the entry slots kept free) go back to the batch */
+/* the main run that shared device main_dev is over: its compute units go back to the batch */
 static void bb_main_done(void *self, int d)
 {
 	hip_bb *h = (hip_bb *)self;
-	if (h->dev_id[d] == h->main_dev) { (void)psmc_hip_set_cu_range(h->ctx[d], 0, 0); (void)psmc_hip_set_option(h->ctx[d], "batch_slots", 0); }
+	if (h->dev_id[d] == h->main_dev) (void)psmc_hip_set_cu_range(h->ctx[d], 0, 0);
 }
 static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
                           const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL,
@@ -165,11 +165,6 @@ int main(int argc, char *argv[])
 				rc = psmc_hip_set_cu_range(psmc_hipbe_ctx(&be_main), 0, m);
 				for (int d = 0; d < h.n_dev && rc == 0; ++d)
 					if (list[d] == list[0]) rc = psmc_hip_set_cu_range(h.ctx[d], m, cus - m);
-			} else if (m <= 0) { /* no masks (A/B; measured slower: see the top of the file): the batch leaves PSMC_BOOT_MAIN_SLOTS entry slots per launch free */
-				const char *ss = getenv("PSMC_BOOT_MAIN_SLOTS");
-				const int keep = ss ? atoi(ss) : 64;
-				for (int d = 0; d < h.n_dev && rc == 0; ++d)
-					if (list[d] == list[0] && 4 * cus - keep >= 4) rc = psmc_hip_set_option(h.ctx[d], "batch_slots", 4 * cus - keep);
 			}
 		}
 		if (rc) {

@@ -146,6 +146,18 @@ int psmc_hipbe_create(psmc_estep_backend *be, int n_states, int mode, int use_fa
 		rc = psmc_hip_group_create(&h->grp, n_states, n_list, list, mode);
 		const char *rc_s = getenv("PSMC_HIP_RCCL");
 		if (rc == 0 && rc_s) rc = psmc_hip_group_set_option(h->grp, "rccl", atof(rc_s));
+		if (rc == 0) {
+			/* first contact with the devices, before a segment is loaded: every listed device answers, the exchange the
+			 * E-steps will use comes up and adds correctly in stream order -- a failure names its step here, not in the first E-step */
+			int sc[4] = {0, 0, 0, 0};
+			static const char *path[] = {"single shard", "RCCL all-reduce", "host sum of the shards' vectors", "exact mode: ordered per-segment sum, nothing to exchange"};
+			rc = psmc_hip_group_selfcheck(h->grp, sc);
+			if (rc) fprintf(stderr, "psmc: devices %s: self-check failed: %s\n", devs, psmc_hip_group_last_error(h->grp));
+			else {
+				if (sc[3]) fprintf(stderr, "psmc: devices %s: RCCL wanted but not usable (%s); the host adds the shards' vectors\n", devs, psmc_hip_group_last_error(h->grp));
+				if (getenv("PSMC_TIMING")) fprintf(stderr, "[timing] devices %s: self-check ok, %d shards, exchange: %s%s\n", devs, sc[0], path[sc[1] >= 0 && sc[1] <= 3 ? sc[1] : 0], sc[2] ? " (communicator up)" : "");
+			}
+		}
 	} else rc = psmc_hip_create(&h->ctx, n_states, devs && *devs ? atoi(devs) : device, mode);
 	if (rc) { if (h->grp) psmc_hip_group_destroy(h->grp); free(h->devs); free(h); return rc; }
 	be->self = h; be->load = hb_load; be->estep = hb_estep; be->tables = hb_tables; be->decode = hb_decode;

@@ -63,6 +63,11 @@ if os.path.exists(os.path.join(pm, NAME + "_FETCH_SIZE_counter_collection.csv"))
                                 correction="bytes_read = 2 * FETCH_SIZE * 1024 (gfx950 tallies 128-B requests at 64 B: 524296 KB raw for 2^30 B); bytes_written = WRITE_SIZE * 1024 (exact)"),
                note="the back-half kernels are launched several times per E-step (two lists, side passes over run tiles, redo of repaired tiles) and k_fwd_struct<speculate> also runs checkpoint-only for the factored statistics: the LARGEST launch is reported for them",
                kernels={})
+    # the record is only as good as the kernels it was taken from: bench.py quotes it for a build with the same sources only
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    out["kernel_sources"] = list(_bench.TRAFFIC_SOURCES)
+    out["kernel_src_sha16"] = _bench.kernel_src_sha16(out["kernel_sources"])
     for k, d in sorted(res.items()):
         if not k.startswith('k_'): continue
         rd = d.get('FETCH_SIZE', {}); wr = d.get('WRITE_SIZE', {})

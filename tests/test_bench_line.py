@@ -47,3 +47,25 @@ def test_bench_line_contract(case):
     if case == "fused_counts_longest":
         assert r["kernel"] == "k_bwd_count4f_struct" and r["bound"] == "mfma" and r["also"]["kernel"].startswith("k_fwd_struct")
         assert abs(r["achieved"] - bins * (2 * 64 * 64 + 24 * 64) / 6.8e-3 / 1e12) < 1e-9
+
+
+def test_replayed_traffic_is_guarded_by_the_kernel_sources(tmp_path):
+    """roofline.traffic is replayed from a committed rocprofv3 --pmc record: only a record taken from the kernel sources of
+    this build may be quoted -- a record without a hash, or with another one, gives null and says why."""
+    import bench
+    rec = {"bins": 30000001, "kernels": {"k_bwd_count4f_struct": {"hbm_bytes_per_launch": 7.9e9}}, "kernel_sources": list(bench.TRAFFIC_SOURCES)}
+    p = tmp_path / "pmc.json"
+    p.write_text(json.dumps(rec))
+    t, note = bench.replayed_traffic(str(p), 30000001, "k_bwd_count4f_struct")
+    assert t is None and "no kernel_src_sha16" in note
+    rec["kernel_src_sha16"] = "0123456789abcdef"
+    p.write_text(json.dumps(rec))
+    t, note = bench.replayed_traffic(str(p), 30000001, "k_bwd_count4f_struct")
+    assert t is None and "other kernel sources" in note
+    rec["kernel_src_sha16"] = bench.kernel_src_sha16(rec["kernel_sources"])
+    p.write_text(json.dumps(rec))
+    t, note = bench.replayed_traffic(str(p), 30000001, "k_bwd_count4f_struct")
+    assert t == 7.9e9 and "same kernel sources" in note
+    assert bench.replayed_traffic(str(p), 123, "k_bwd_count4f_struct")[0] is None          # another workload
+    assert bench.replayed_traffic(str(p), 30000001, "k_nothing")[0] is None                 # another kernel
+    assert bench.replayed_traffic(str(tmp_path / "absent.json"), 30000001, "k")[0] is None

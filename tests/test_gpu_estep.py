@@ -282,11 +282,10 @@ def check_fast(r, o, p=None):
         assert m["QA"] <= FAST_TOL_Q and m["QE"] <= FAST_TOL_Q, m
 
 
-@pytest.mark.parametrize("expect_impl", [1, 0])
 @pytest.mark.parametrize("key", ["n64_curve", "n64_flat", "n23_curve"])
-def test_fast_small_golden(hip, golden, key, expect_impl):
+def test_fast_small_golden(hip, golden, key):
     p = golden.params(key)
-    es = hip.HipEStep(p["a"].shape[0], mode=hip.MODE_FAST, expect_impl=expect_impl)
+    es = hip.HipEStep(p["a"].shape[0], mode=hip.MODE_FAST)
     es.load_segments(golden.segs_small)
     r = es.estep(p["a"], p["e"], p["a0"])
     g = golden.small
@@ -294,8 +293,8 @@ def test_fast_small_golden(hip, golden, key, expect_impl):
     es.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(chunk=1024), dict(chunk=256, n_sub=1), dict(chunk=4096, rep_impl=0),
-                                  dict(chunk=2048, expect_impl=0), dict(chunk=1024, overlap=0), dict(chunk=512, warmup=128, overlap=3), dict(chunk=512, warmup=128, overlap=1),
+@pytest.mark.parametrize("opts", [dict(), dict(chunk=1024), dict(chunk=256), dict(chunk=4096, rep_impl=0),
+                                  dict(chunk=2048, fuse=0), dict(chunk=1024, overlap=0), dict(chunk=512, warmup=128, overlap=3), dict(chunk=512, warmup=128, overlap=1),
                                   dict(chunk=512, warmup=128, overlap=0), dict(chunk=1024, fuse=0), dict(chunk=512, warmup=128, overlap=0, fuse=0)])
 def test_fast_mid_golden(hip, golden, opts):
     key = "n64_curve"
@@ -325,6 +324,43 @@ def test_fast_speculation_is_repaired(hip, golden, opts):
     g = golden.mid
     check_fast(r, dict(A=g[key + ".A"], E=g[key + ".E"], LL=float(g[key + ".LL"])))
     es.close()
+
+
+@pytest.mark.parametrize("opts", [dict(chunk=2048, warmup=1024), dict(chunk=512, warmup=128, **GENOME), dict(chunk=2048, warmup=512, overlap=0)])
+def test_fast_fix_pass(hip, golden, oracle, opts):
+    """"merge" (round 6): between the forward sweep and the back half every tile's start vector is checked, and a tile whose
+    speculation fell short is rewritten from the true vector only until its trajectory has the direction of the stored one
+    again; the factor between the two parts goes into the counts and the likelihood.  The forward failures then cost no
+    verify / repair round and no second pass of the counts; with "adapt" + "prev_start" the warm-ups follow the measured
+    mismatch and start from the previous E-step's X.  Results inside the fast tolerance for moving parameters, and two
+    contexts with the same call history agree bit for bit."""
+    pa, pb = golden.params("n64_curve"), golden.params("n64_flat")
+    oa, ob = (oracle.estep(p["a"], p["e"], p["a0"], golden.segs_mid) for p in (pa, pb))
+    tiles = {}
+    for merge in (0, 1):
+        es = hip.HipEStep(64, mode=hip.MODE_FAST, merge=merge, learn=0, **opts)
+        es.load_segments(golden.segs_mid)
+        check_fast(es.estep(pa["a"], pa["e"], pa["a0"]), oa, pa)
+        d = es.fast_diag()
+        tiles[merge] = (d["merged"], d["fwd_tiles"])
+        es.close()
+    # the pass rewrote tiles in part, and the verify / repair rounds after the back half had fewer whole tiles left to redo (a tile the pass
+    # had to rewrite to its end changes its last row: its neighbour above may still fail afterwards)
+    assert tiles[0][0] == 0 and tiles[1][0] > 0 and tiles[1][1] < tiles[0][1], tiles
+    runs = []
+    for rep in range(2):
+        es = hip.HipEStep(64, mode=hip.MODE_FAST, merge=1, adapt=1, prev_start=1, **opts)
+        es.load_segments(golden.segs_mid)
+        out = []
+        for it in range(6):
+            p, o = (pa, oa) if it % 2 == 0 else (pb, ob)
+            r = es.estep(p["a"], p["e"], p["a0"])
+            check_fast(r, o, p)
+            out.append(r)
+        es.close()
+        runs.append(out)
+    for r1, r2 in zip(*runs):
+        assert bits_equal(r1["A"], r2["A"]) and bits_equal(r1["E"], r2["E"]) and r1["LL"] == r2["LL"]
 
 
 def test_fast_overlap_equals_sequential(hip, golden):
@@ -374,8 +410,9 @@ def test_fast_structured_and_dense_sweeps(hip, golden, oracle):
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
                                   dict(two_phase=2), dict(chunk=256, warmup=512, two_phase=2), dict(GENOME), dict(chunk=256, warmup=512, **GENOME), dict(chunk=768, warmup=256, overlap=0, **GENOME), dict(chunk=768, warmup=64, merge1=0),
                                   dict(merge1=1, two_phase=2), dict(chunk=256, warmup=512, merge1=1, warm_shift=1), dict(chunk=1000, warmup=100, kc_sub=2),
-                                  dict(chunk=1000, warmup=100, **GENOME), dict(chunk=256, warmup=512, runs_late=0, **GENOME),
-                                  dict(chunk=768, warmup=64, runs_late=0, **GENOME),
+                                  dict(chunk=1000, warmup=100, **GENOME),
+                                  dict(merge=1), dict(chunk=256, warmup=64, merge=1), dict(chunk=1024, warmup=128, merge=1, adapt=1, prev_start=1), dict(chunk=768, warmup=64, merge=1, adapt=1, prev_start=1, **GENOME),
+                                  dict(chunk=1024, warmup=128, merge=1, learn=0), dict(chunk=256, warmup=512, prev_start=1), dict(chunk=1024, warmup=256, merge=1, coarse=2),
                                   dict(chunk=256, warmup=512, coarse=2), dict(chunk=256, warmup=64, coarse=3), dict(chunk=1000, warmup=100, coarse=2, merge1=0), dict(chunk=768, warmup=64, coarse=4, learn=0),
                                   dict(chunk=256, warmup=512, coarse=2, **GENOME), dict(chunk=1000, warmup=100, coarse=2, overlap=0),
                                   dict(lanes8=1), dict(chunk=256, warmup=512, lanes8=1), dict(chunk=1000, warmup=100, lanes8=1, **GENOME), dict(chunk=256, warmup=64, lanes8=1, coarse=2),
@@ -463,8 +500,7 @@ def tri_sums(A):
 @pytest.mark.parametrize("opts", [dict(), dict(chunk=256, warmup=512), dict(chunk=1000, warmup=100, overlap=0), dict(chunk=768, warmup=256, learn=0),
                                   dict(ckpt=0), dict(chunk=1001, warmup=100), dict(chunk=8, warmup=64), dict(chunk=264, warmup=300, kc_min=0), dict(chunk=256, warmup=512, **GENOME), dict(GENOME), dict(chunk=1001, warmup=100, merge1=0), dict(chunk=264, warmup=300, warm_shift=1),
                                   dict(chunk=256, warmup=512, coarse=2), dict(chunk=1001, warmup=100, coarse=3), dict(chunk=264, warmup=64, coarse=2, merge1=0), dict(chunk=256, warmup=512, coarse=2, ckpt=0, **GENOME),
-                                  dict(lanes8=1), dict(chunk=264, warmup=300, lanes8=1), dict(chunk=256, warmup=512, lanes8=1, coarse=2), dict(chunk=1001, warmup=100, lanes8=1, **GENOME),
-                                  dict(ckpt=0, lanes8b=1), dict(chunk=264, warmup=300, ckpt=0, lanes8b=1), dict(chunk=1001, warmup=100, ckpt=0, lanes8b=1, lanes8=1, **GENOME), dict(chunk=256, warmup=64, ckpt=0, lanes8b=1, coarse=2)])
+                                  dict(lanes8=1), dict(chunk=264, warmup=300, lanes8=1), dict(chunk=256, warmup=512, lanes8=1, coarse=2), dict(chunk=1001, warmup=100, lanes8=1, **GENOME)])
 def test_fast_factored_statistics(hip, golden, oracle, opts):
     """psmc_hip_estep_factored: the five triangular sums of A, E and LL straight from the backward sweep
     (no N x N counts), against the same sums of the oracle's A; repairs, learned runs, bootstrap multiset.
@@ -723,14 +759,15 @@ def test_exact_batch_entry_schedule(hip, golden, sort):
 def test_exact_batch_tail_fill(hip, golden):
     """"batch_tailfill": filling the launches longest first leaves the launches of long entries with entry slots to spare and a last
     launch of a few short entries; when memory and slots allow fewer launches, the shortest entries go into the spare slots.  The
-    same twelve replicates, 100 k table bins and 32 entry slots per launch: 6 launches become 3, the statistics keep their bits."""
+    same twelve replicates, 100 k table bins and 32 entry slots per launch (a context on eight compute units): 6 launches become 3, the statistics keep their bits."""
     segs = golden.segs_small + golden.segs_mid[2:]
     rng = np.random.default_rng(14)
     params = _traj_params(6) * 2
     sels = [rng.integers(0, len(segs), size=rng.integers(1, len(segs))).tolist() for _ in range(12)]
     got = {}
     for fill in (0, 1):
-        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=100000, batch_slots=32, exact_refwd=2, batch_tailfill=fill)
+        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=100000, exact_refwd=2, batch_tailfill=fill)
+        es.set_cu_range(0, 8)   # eight compute units: 32 entry slots per launch
         es.load_segments(segs)
         got[fill] = es.estep_batch(params, sels)
         got[fill]["groups"] = es.batch_info()["groups"]
@@ -770,7 +807,8 @@ def test_exact_batch_progress_callback(hip, golden):
     plain.close()
     firsts = {}
     for major in (1, 0):
-        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=bins // 3 + 4096, batch_slots=(entries // 3 + 8) // 4 * 4, exact_refwd=2, batch_tailfill=0, batch_major=major)
+        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=bins // 3 + 4096, exact_refwd=2, batch_tailfill=0, batch_major=major)
+        es.set_cu_range(0, (entries // 3 + 8) // 4)   # four entry slots per compute unit of the context's share
         es.load_segments(trunks)
         seen, calls = {}, []
         def on_done(reps, out):
@@ -1143,7 +1181,7 @@ for opts in (dict(chunk=100, warmup=30), dict(chunk=37, warmup=5, group_cap=3000
 g8 = np.load(os.path.join(%r, "tests", "golden", "estep_n128.npz"))
 a, e, a0 = g8["n128_curve.a"], g8["n128_curve.e"], g8["n128_curve.a0"]
 o = orc.Oracle().estep(a, e, a0, segs)
-for opts in (dict(), dict(fuse128=1), dict(chunk=400, warmup=64)):
+for opts in (dict(), dict(fuse128=0), dict(chunk=400, warmup=64)):
     es = hip.HipEStep(128, mode=hip.MODE_FAST, **opts); es.load_segments(segs)
     for it in range(2):
         r = es.estep(a, e, a0)

@@ -194,6 +194,9 @@ def test_bench_two_ranks_on_one_device():
     assert len(lines) == 1, r.stdout[-2000:]   # rank 0 prints ONE line
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3 and j["warmup"] == 2 and j["unit"] == "bins/s"
+    cm = j["config"]["comm"]   # what a SCALE record needs to say by itself: the backend, how many ranks one all-reduce counted, where they sat
+    assert cm["backend"] == "gloo" and cm["world_size"] == 2 and cm["ranks_in_allreduce"] == 2, cm
+    assert [d["rank"] for d in cm["rank_devices"]] == [0, 1] and cm["distinct_devices"] == 1, cm   # (BENCH_SINGLE_GPU_TEST: both on device 0)
     from psmc_amd import sim
     genome_bins = int(sim.human_like_lengths(3_000_000, n_seg=9).sum())
     assert abs(j["value"] - 2 * genome_bins / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]   # whole-job aggregate: both ranks' genomes

@@ -65,7 +65,7 @@ def test_stress_psmc_binary_byte_identical(hip):
     assert r.stdout == gzip.open(os.path.join(STRESS, "stress_N3.psmc.gz"), "rt").read()
 
 
-@pytest.mark.parametrize("plan", ["genome", "default", "genome_factored", "genome_gap_tiles_off"])
+@pytest.mark.parametrize("plan", ["genome", "default", "genome_factored", "genome_gap_tiles_off", "chunk1001", "chunk1001_factored"])
 def test_stress_fast_within_tolerance(hip, stress, plan):
     """... and the repairs STOP (round 5, "gap_tiles"): inside a run of missing data the chain forgets at the rate of the matrix's second
     eigenvalue alone (~5e5 bins), so every tile of a gap hangs on the vector that entered it; until round 4 "group_cap" cut the 2e5-bin gaps
@@ -76,6 +76,9 @@ def test_stress_fast_within_tolerance(hip, stress, plan):
     segs, g = stress
     opts = dict(GENOME) if plan.startswith("genome") else {}
     if plan.endswith("gap_tiles_off"): opts["gap_tiles"] = 0
+    # a tile length that is not a multiple of four: the gap tiles of a direction then do NOT cover the same steps (the backward
+    # matrix of a tile starts at its first normalising position), so they cannot share one transfer matrix
+    if plan.startswith("chunk1001"): opts = dict(chunk=1001, two_phase=2, merge1=0, warm_shift=1)
     es = hip.HipEStep(64, mode=hip.MODE_FAST, **opts)
     es.load_segments(segs)
     log = []
@@ -83,7 +86,7 @@ def test_stress_fast_within_tolerance(hip, stress, plan):
         k = "rd%d" % rd
         p = dict(a=g[k + ".a"], e=g[k + ".e"], a0=g[k + ".a0"])
         o = dict(A=g[k + ".A"], E=g[k + ".E"], LL=float(g[k + ".LL"]))
-        if plan == "genome_factored":
+        if plan.endswith("factored"):
             f = es.estep_factored(p["a"], p["e"], p["a0"])
             assert relmax(f["sums"], tri_sums(o["A"])) < FAST_TOL_STATS and relmax(f["E"], o["E"]) < FAST_TOL_STATS
             assert abs(f["LL"] - o["LL"]) <= FAST_TOL_LL * abs(o["LL"])
@@ -95,6 +98,7 @@ def test_stress_fast_within_tolerance(hip, stress, plan):
             rd, pl["tiles"], pl["tile_len"], d["fwd_rounds"], d["bwd_rounds"], d["fwd_tiles"], d["bwd_tiles"], pl["glued_fwd"], pl["glued_bwd"],
             pl["warm_fwd_max"], pl["warm_bwd_max"]))
     if plan.endswith("gap_tiles_off"): assert d["fwd_rounds"] + d["bwd_rounds"] >= 10, d    # what rounds 1-4 did on every E-step
+    elif plan.startswith("chunk1001"): assert d["fwd_rounds"] + d["bwd_rounds"] <= 4, d       # (2200 tiles of 1001 bins under 3072-bin warm-ups: still learning)
     else: assert d["fwd_rounds"] + d["bwd_rounds"] <= 1, d                                   # the plan has learned the input
     print("\nstress, %s plan:\n  " % plan + "\n  ".join(log))
     rec = os.path.join(ROOT, "gpurun_out")   # what the verify / repair net had to do, kept when the suite runs on the GPU box (-> profiles/r05_stress_fast.txt)
@@ -128,3 +132,42 @@ def test_fast_run_that_cannot_converge_falls_back_to_exact(hip):
     with pytest.raises(hip.HipError, match="converge"):
         es.estep(p["a"], p["e"], p["a0"])
     es.close()
+
+
+def test_fast_bootstrap_that_cannot_converge_falls_back_per_replicate(hip, tmp_path):
+    """The same through psmc_boot: a replicate whose fast E-step returns PSMC_HIP_ECONVERGE no longer ends the batch --
+    psmc_hip_estep_batch repeats THAT replicate's E-step on an exact twin context over the same observations, says so once per replicate
+    and EM iteration, and the job finishes; LK of every round as close to the exact-mode replicates as any fast run's."""
+    def rounds(txt):
+        return [float(l.split()[1]) for l in txt.splitlines() if l.startswith("LK")]
+    args = ["-N2", "-t15", "-r5", "-p", "4+25*2+4+6", os.path.join(GOLD, "cli", "mid.psmcfa.gz")]
+    boot = os.path.join(HOST, "psmc_boot")
+    lk = {}
+    for mode, opt in (("exact", ""), ("fast", "warmup=64,chunk=512,max_rounds=0,learn=0")):
+        r = subprocess.run([boot, "-R", "3", "-S", "5", "-O", str(tmp_path / (mode + "-%d.psmc")), "--"] + args, capture_output=True, text=True,
+                           env=dict(os.environ, PSMC_HIP_MODE=mode, PSMC_HIP_OPTIONS=opt))
+        assert r.returncode == 0, r.stderr[-800:]
+        if mode == "fast":
+            assert r.stderr.count("repeating this E-step with the exact kernels") == 3 * 2, r.stderr[-800:]   # three replicates x two EM iterations
+        lk[mode] = [rounds(open(tmp_path / ("%s-%d.psmc" % (mode, k))).read()) for k in range(3)]
+    for ex, fa in zip(lk["exact"], lk["fast"]):
+        assert len(ex) == len(fa) == 3
+        for x, y in zip(ex[1:], fa[1:]):
+            assert abs(x - y) <= 1e-6 * abs(x)
+    # the library entry point itself: the replicate's statistics are the exact ones, the others stay fast
+    from conftest import Golden
+    from test_gpu_estep import check_fast
+    import orc
+    gd = Golden(); p = gd.params("n64_curve")
+    es = hip.HipEStep(64, mode=hip.MODE_FAST, warmup=64, chunk=512, max_rounds=0, learn=0)
+    es.load_segments(gd.segs_mid)
+    sels = [[5, 4, 5, 3, 5], [0, 1, 2]]
+    got = es.estep_batch([(p["a"], p["e"], p["a0"])] * 2, sels)
+    es.close()
+    ex = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    ex.load_segments(gd.segs_mid)
+    for r_, sel in enumerate(sels):
+        ex.select(sel)
+        w = ex.estep(p["a"], p["e"], p["a0"])
+        assert bits_equal(got["A"][r_], w["A"]) and bits_equal(got["E"][r_], w["E"]) and got["LL"][r_] == w["LL"], r_
+    ex.close()

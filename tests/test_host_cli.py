@@ -478,7 +478,7 @@ def test_psmc_boot_binary_equals_single_runs_on_gpu(tmp_path, pattern):
 def test_psmc_boot_main_run_on_gpu(tmp_path, main_cus):
     """psmc_boot --main: the README:49-62 workflow as one job.  The main run (`psmc <options> -o main.psmc
     whole.psmcfa`) runs beside the replicates on the same device -- its context masked to a range of compute units and the batch
-    to the others (PSMC_BOOT_MAIN_CUS=32, the default), or unmasked with entry slots kept free (=0) -- and writes the bytes `psmc` writes;
+    to the others (PSMC_BOOT_MAIN_CUS=32, the default), or unmasked (=0) -- and writes the bytes `psmc` writes;
     the replicates write the bytes they write without --main (entry schedule, launch count and compute-unit share do not
     reach the results)."""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "psmc_amd", "csrc")], check=True)
@@ -498,6 +498,60 @@ def test_psmc_boot_main_run_on_gpu(tmp_path, main_cus):
         assert open(tmp_path / ("m-%d.psmc" % k)).read() == open(tmp_path / ("p-%d.psmc" % k)).read(), k
     single = subprocess.run([os.path.join(HOST, "psmc"), "-b"] + opts + [split], capture_output=True, text=True, env=dict(env, PSMC_SEED="44", PSMC_HIP_OPTIONS=""))
     assert single.returncode == 0 and open(tmp_path / "m-4.psmc").read() == single.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devs", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_psmc_boot_main_run_over_a_device_list(tmp_path, devs, mode):
+    """psmc_boot --main with a device LIST (boot_main.c splits the FIRST device between the main run and the batch
+    contexts that sit on it, `list[d] == list[0]`): two and three batch contexts on device 0.  Exact mode: every replicate writes the
+    bytes the one-context job writes, the main run the bytes `psmc` writes.  Fast mode: same layout, LK of every round within the fast
+    tolerance of the exact replicates and of `psmc`'s own fast run."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "psmc_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", HOST], check=True)
+    opts = ["-N3", "-t15", "-r5", "-I", "0.2", "-p", "4+25*2+4+6"]
+    split, whole = os.path.join(CLI, "mid.psmcfa.gz"), os.path.join(CLI, "small.psmcfa")
+    boot = os.path.join(HOST, "psmc_boot")
+    env1 = dict(os.environ, PSMC_SEED="7", PSMC_HIP_MODE="exact")
+    ref = subprocess.run([boot, "-R", "7", "-S", "40", "-O", str(tmp_path / "one-%d.psmc"), "--"] + opts + [split], capture_output=True, text=True, env=env1)
+    assert ref.returncode == 0, ref.stderr[-600:]
+    env = dict(os.environ, PSMC_SEED="7", PSMC_HIP_MODE=mode, PSMC_HIP_DEVICES=devs, PSMC_TIMING="1")
+    r = subprocess.run([boot, "-R", "7", "-S", "40", "-O", str(tmp_path / "l-%d.psmc"), "--main", str(tmp_path / "main.psmc"), "--main-input", whole, "--"] + opts + [split],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    one = subprocess.run([os.path.join(HOST, "psmc")] + opts + [whole], capture_output=True, text=True, env=dict(os.environ, PSMC_SEED="7", PSMC_HIP_MODE=mode))
+    assert one.returncode == 0 and "RD\t3" in one.stdout
+    if mode == "exact":
+        assert open(tmp_path / "main.psmc").read() == one.stdout
+    else:
+        for x, y in zip(_rounds(open(tmp_path / "main.psmc").read())[1:], _rounds(one.stdout)[1:]):
+            assert abs(x["LK"] - y["LK"]) <= 1e-6 * abs(y["LK"])
+    for k in range(7):
+        got, want = open(tmp_path / ("l-%d.psmc" % k)).read(), open(tmp_path / ("one-%d.psmc" % k)).read()
+        if mode == "exact":
+            assert got == want, k
+        else:
+            a, b = _rounds(got), _rounds(want)
+            assert len(a) == len(b) == 4
+            for x, y in zip(a[1:], b[1:]):
+                assert abs(x["LK"] - y["LK"]) <= 1e-6 * abs(y["LK"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,path", [("exact", "exact mode: ordered per-segment sum"), ("fast", "host sum of the shards' vectors")])
+def test_psmc_sharded_run_starts_with_the_group_selfcheck(mode, path):
+    """PSMC_HIP_DEVICES with more than one entry: the backend calls psmc_hip_group_selfcheck before a segment is
+    loaded -- every listed device answers, the exchange comes up and adds correctly -- and PSMC_TIMING=1 prints what it found."""
+    args = open(os.path.join(CLI, "mid_n64_N4.args")).read().split()
+    r = subprocess.run([os.path.join(HOST, "psmc")] + args, cwd=CLI, capture_output=True, text=True,
+                       env=dict(os.environ, PSMC_HIP_MODE=mode, PSMC_HIP_DEVICES="0,0", PSMC_TIMING="1"))
+    assert r.returncode == 0, r.stderr[-600:]
+    assert "devices 0,0: self-check ok, 2 shards, exchange: " + path in r.stderr, r.stderr[-800:]
+    if mode == "exact":
+        assert r.stdout == golden_text("mid_n64_N4")
+    bad = subprocess.run([os.path.join(HOST, "psmc")] + args, cwd=CLI, capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_DEVICES="0,99"))
+    assert bad.returncode != 0 and bad.stdout.count("RD") == 0   # a device that is not there: named before anything is computed
 
 
 @pytest.mark.gpu

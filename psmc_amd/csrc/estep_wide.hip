@@ -13,9 +13,10 @@
 // so nothing has to be broadcast back.  No FMA (the library is built with -ffp-contract=off; tests/test_abi.py audits
 // this file's assembly), true division, every sum in index order: bit-identical to khmm.c, checked against the oracle
 // and against goldens of the reference itself at 150 and 200 states (tests/test_gpu_wide.py).
-// This path is about ACCEPTING the input, not about speed: a position costs 13 us at n = 200 (7.5 forward + 5.9 backward: the n matrix
+// These general kernels are about ACCEPTING the input, not about speed: a position costs 13 us at n = 200 (7.5 forward + 5.9 backward: the n matrix
 // elements of a lane come from the L2, eight per round trip; fetching 32 a block ahead by hand was SLOWER, 10.4 + 11.1 us -- round 5,
-// profiles/r05_wide_timing.json), i.e. 1.4e6 bins/s over 20 segments, 60 x one host core of the reference at that size.
+// profiles/r05_wide_timing.json).  Round 6: 129 .. 224 states keep the matrix in REGISTERS instead (k_fwd_wide2 / k_bwd_wide2 below): 5.9 us per
+// position at n = 200, 4.9 at 149 (profiles/r06_wide_timing.json) -- 3.1e6 bins/s over 20 segments, 130 x one host core of the reference.
 #include <hip/hip_runtime.h>
 #include "psmc_hip_internal.h"
 
@@ -146,6 +147,169 @@ __global__ __launch_bounds__(1024) void k_bwd_wide(const double *__restrict__ aT
 	if (k == 0) chk[blockIdx.x] = ordered_sum_lds(ts, n);
 }
 
+// ---------------------------------------------------------------- 129 .. 224 states: the matrix in REGISTERS (round 6)
+// k_fwd_wide / k_bwd_wide fetch every lane's n matrix elements from the L2 at every position: 7.5 + 5.9 us per position at n = 200, nearly
+// all of it round trips (profiles/r05_wide_timing.json).  A compute unit's register file holds 64 K doubles -- an n x n matrix up to n = 224
+// with room to work in -- so here a work-group of 2 S threads (two waves per SIMD, 256 registers each) keeps it there: thread (q, k) owns
+// state k's column (forward; row, backward) for l in [q C, q C + C), C = 96 / 104 / 112: C matrix elements in registers for the whole
+// sweep, zero beyond n.  The reference's left-to-right sum over l (khmm.c:180, 232) is walked in two STAGES: the threads of stage 0 add their
+// C products onto 0.0 in order and hand the partial sum to stage 1 through LDS, which ends with the full sum -- the same additions in the
+// same order as one thread doing all n (a zero product appended to a part leaves its sum as it is), hence the same bits.  One barrier per
+// stage.  The operands that are the same for every state (the previous row, the emission factors) come out of LDS as broadcast reads, several
+// in flight in a ring of registers: left to itself the compiler keeps ONE read in flight and waits for it before every pair of additions.
+// The normaliser of the forward sweep is the reference's sum in state order, added by every wave of the last stage for itself out of LDS.
+typedef double d2w_t __attribute__((ext_vector_type(2)));
+constexpr int WRING = 6; // 16-byte LDS reads in flight
+template <int C>
+__device__ __forceinline__ double stage_dot(double acc, const double *xv, const double (&m)[C])
+{
+	static_assert(C % 2 == 0 && C / 2 > WRING, "pairs");
+	const d2w_t *x2 = reinterpret_cast<const d2w_t *>(xv);
+	d2w_t ring[WRING];
+#pragma unroll
+	for (int i = 0; i < WRING; ++i) ring[i] = x2[i];
+#pragma unroll
+	for (int i = 0; i < C / 2; ++i) {
+		const d2w_t v = ring[i % WRING];
+		if (i + WRING < C / 2) ring[i % WRING] = x2[i + WRING];
+		acc += v.x * m[2 * i];                                      // tmp += fu1[l] * aa[l], l in order (khmm.c:180)
+		acc += v.y * m[2 * i + 1];
+	}
+	return acc;
+}
+template <int C>
+__device__ __forceinline__ double stage_dot_e(double acc, const double *bv, const double *ev, const double (&m)[C])
+{
+	constexpr int R = WRING / 2;
+	const d2w_t *b2 = reinterpret_cast<const d2w_t *>(bv), *e2 = reinterpret_cast<const d2w_t *>(ev);
+	d2w_t rb[R], re[R];
+#pragma unroll
+	for (int i = 0; i < R; ++i) { rb[i] = b2[i]; re[i] = e2[i]; }
+#pragma unroll
+	for (int i = 0; i < C / 2; ++i) {
+		const d2w_t vb = rb[i % R], ve = re[i % R];
+		if (i + R < C / 2) { rb[i % R] = b2[i + R]; re[i % R] = e2[i + R]; }
+		const double q0 = ve.x * m[2 * i]; acc += q0 * vb.x;      // tmp += q[l] * bu1[l], q = e * a rounded first (khmm.c:203, 231-232)
+		const double q1 = ve.y * m[2 * i + 1]; acc += q1 * vb.y;
+	}
+	return acc;
+}
+// strict left-to-right sum of v[0..n) out of LDS, WRING reads in flight.  v[n ..] must be +0.0 up to the next multiple of 2 WRING and readable one
+// ring turn beyond that: the sum runs over whole turns of the ring (adding +0.0 to a non-negative sum leaves its bits as they are), so that no
+// read needs a bound
+__device__ __forceinline__ double ordered_sum_ring(const double *v, int n)
+{
+	const d2w_t *v2 = reinterpret_cast<const d2w_t *>(v);
+	const int turns = (n + 2 * WRING - 1) / (2 * WRING);
+	double s = 0.0;
+	d2w_t ring[WRING];
+#pragma unroll
+	for (int i = 0; i < WRING; ++i) ring[i] = v2[i];
+	for (int tr = 0; tr < turns; ++tr) { // (a whole turn of the ring per trip: the registers keep their places)
+		v2 += WRING;
+#pragma unroll
+		for (int r = 0; r < WRING; ++r) {
+			const d2w_t t = ring[r];
+			ring[r] = v2[r];
+			s += t.x; s += t.y;
+		}
+	}
+	return s;
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void k_fwd_wide2(const double *__restrict__ a, const double *__restrict__ e, const double *__restrict__ a0,
+                                                   const uint8_t *__restrict__ obs, const int64_t *__restrict__ seg_off,
+                                                   const int32_t *__restrict__ seg_len, const ExWork wl, int n, int S,
+                                                   double *__restrict__ f, double *__restrict__ s)
+{
+	extern __shared__ double lds_w[];
+	double *xs = lds_w, *gs = lds_w + 2 * S, *es = lds_w + 3 * S, *hand = lds_w + 6 * S; // xs[2][S] | gs[S] | es[3][S] | hand[S]
+	const int t = threadIdx.x, q = t / S, k = t - q * S;
+	const int seg = wl.seg[blockIdx.x];
+	if (seg < 0) return; // padding entry of a batch (block-uniform)
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[blockIdx.x] : off;
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x] * wl.par_stride : 0; a += po; e += po; a0 += po; }
+	const int L = seg_len[seg];
+	const uint8_t *o = obs + off;
+	double *fo = f + toff * S, *so = s + toff;
+	for (int i = t; i < 3 * S; i += 2 * S) es[i] = e[i];
+	for (int i = t; i < 3 * S; i += 2 * S) xs[i] = 0.0; // (a part may reach past n: those products are 0 * 0; gs beyond n: +0.0 for ordered_sum_ring)
+	double m[C]; // at[k][l] = a[l][k] (khmm.c:162-166), l = q C + j
+#pragma unroll
+	for (int j = 0; j < C; ++j) { const int l = q * C + j; m[j] = (l < n && l < S) ? a[(int64_t)l * S + k] : 0.0; }
+	__syncthreads();
+	int cur = 0;
+	double g = 0.0;
+	int sym = o[0];
+	for (int u = 0; u < L; ++u) { // index u = position u + 1
+		const int sym_next = o[min(u + 1, L - 1)];
+		if (u == 0) {
+			if (q == 1) { g = k < n ? a0[k] * es[sym * S + k] : 0.0; gs[k] = g; }                    // khmm.c:171-172
+			__syncthreads();
+		} else {
+			const double *xv = xs + cur * S + q * C;
+			if (q == 0) hand[k] = stage_dot<C>(0.0, xv, m);
+			__syncthreads();
+			if (q == 1) { g = es[sym * S + k] * stage_dot<C>(hand[k], xv, m); gs[k] = g; }            // khmm.c:179-180
+			__syncthreads();
+		}
+		if (q == 1) { // every wave of the last stage: the same n additions in the same order, the same bits
+			const double sum = ordered_sum_ring(gs, n);                                                 // khmm.c:181 (sum in state order)
+			const double x = g / sum;                                                                   // khmm.c:173, 182
+			fo[(int64_t)u * S + k] = x; xs[(cur ^ 1) * S + k] = x;
+			if (k == 0) so[u] = sum;
+		}
+		cur ^= 1; sym = sym_next;
+		__syncthreads();
+	}
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void k_bwd_wide2(const double *__restrict__ aT, const double *__restrict__ e, const double *__restrict__ a0,
+                                                   const uint8_t *__restrict__ obs, const int64_t *__restrict__ seg_off,
+                                                   const int32_t *__restrict__ seg_len, const ExWork wl, int n, int S,
+                                                   const double *__restrict__ s, double *__restrict__ b, double *__restrict__ chk)
+{
+	extern __shared__ double lds_w[];
+	double *bs = lds_w, *es = lds_w + 3 * S, *hand = lds_w + 6 * S; // bs[2][S] | (unused [S]) | es[3][S] | hand[S]
+	const int t = threadIdx.x, q = t / S, k = t - q * S;
+	const int seg = wl.seg[blockIdx.x];
+	if (seg < 0) return;
+	const int64_t off = seg_off[seg], toff = wl.tab ? wl.tab[blockIdx.x] : off;
+	{ const int64_t po = wl.par ? wl.par[blockIdx.x] * wl.par_stride : 0; aT += po; e += po; a0 += po; }
+	const int L = seg_len[seg];
+	const uint8_t *o = obs + off;
+	const double *so = s + toff;
+	double *bo = b + toff * S;
+	for (int i = t; i < 3 * S; i += 2 * S) es[i] = e[i];
+	for (int i = t; i < 2 * S; i += 2 * S) bs[i] = 0.0;
+	double m[C]; // aT[l * S + k] = a[k][l], l = q C + j
+#pragma unroll
+	for (int j = 0; j < C; ++j) { const int l = q * C + j; m[j] = (l < n && l < S) ? aT[(int64_t)l * S + k] : 0.0; }
+	__syncthreads();
+	double x = 1.0 / so[L - 1];  // b[L][k] = 1/s[L] (khmm.c:226)
+	if (q == 1) { bo[(int64_t)(L - 1) * S + k] = x; bs[k] = x; }
+	int cur = 0;
+	double s_u = L >= 2 ? so[L - 2] : 1.0;
+	int sym = L >= 2 ? o[L - 1] : 0;
+	__syncthreads();
+	for (int u = L - 2; u >= 0; --u) { // index u = position u + 1; uses b[u+1], obs[u+1], s[u]
+		const double s_next = so[max(u - 1, 0)]; // (a round trip to memory: asked for a position ahead)
+		const int sym_next = o[max(u, 1)];
+		const double *bv = bs + cur * S + q * C, *ev = es + sym * S + q * C;
+		if (q == 0) hand[k] = stage_dot_e<C>(0.0, bv, ev, m);
+		__syncthreads();
+		if (q == 1) { x = stage_dot_e<C>(hand[k], bv, ev, m) / s_u; bo[(int64_t)u * S + k] = x; bs[(cur ^ 1) * S + k] = x; } // khmm.c:233
+		__syncthreads();
+		cur ^= 1; s_u = s_next; sym = sym_next;
+	}
+	// khmm.c:237-238: sum_l a0[l] * b[1][l] * e[o_1][l], products left to right, the sum in state order
+	if (q == 1) hand[k] = k < n ? a0[k] * x * es[o[0] * S + k] : 0.0;
+	__syncthreads();
+	if (t == 0) chk[blockIdx.x] = ordered_sum_lds(hand, n);
+}
+
 // ---------------------------------------------------------------- expect (khmm.c:297-324)
 // grid = (entries, (S/4) * H + H), H = S / 64, one wave each: the first (S/4) * H blocks accumulate rows 4g .. 4g+3 of A for
 // the 64 columns of one column block (lane = column) in position order; the last H accumulate E and A0 of 64 states.
@@ -237,9 +401,20 @@ int launch_exact_wide(const EstepLaunch &p)
 	const size_t lds = sizeof(double) * 6 * (size_t)S;
 	const int H = S / 64;
 	if (p.ev[0]) hipEventRecord(p.ev[0], p.stream);
-	hipLaunchKernelGGL(k_fwd_wide, dim3(p.n_work), dim3(S), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_f, p.d_s);
-	if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
-	hipLaunchKernelGGL(k_bwd_wide, dim3(p.n_work), dim3(S), lds, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_s, p.d_b, p.d_chk);
+	const size_t lds2 = sizeof(double) * 7 * (size_t)S;
+	static const bool no2 = getenv("PSMC_HIP_WIDE_L2") != nullptr; // (A/B, and the tests of the general kernels at sizes the register kernels take)
+	const int reg2 = no2 ? 0 : (S == 192 ? 96 : (S == 256 && n <= 208 ? 104 : (S == 256 && n <= 224 ? 112 : 0))); // matrix in registers: 129 .. 224 states
+#define PSMC_W2(C) do { \
+		hipLaunchKernelGGL(k_fwd_wide2<C>, dim3(p.n_work), dim3(2 * S), lds2, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_f, p.d_s); \
+		if (p.ev[1]) hipEventRecord(p.ev[1], p.stream); \
+		hipLaunchKernelGGL(k_bwd_wide2<C>, dim3(p.n_work), dim3(2 * S), lds2, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_s, p.d_b, p.d_chk); } while (0)
+	if (reg2 == 96) PSMC_W2(96); else if (reg2 == 104) PSMC_W2(104); else if (reg2 == 112) PSMC_W2(112);
+	else {
+		hipLaunchKernelGGL(k_fwd_wide, dim3(p.n_work), dim3(S), lds, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_f, p.d_s);
+		if (p.ev[1]) hipEventRecord(p.ev[1], p.stream);
+		hipLaunchKernelGGL(k_bwd_wide, dim3(p.n_work), dim3(S), lds, p.stream, p.d_aeT, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, n, S, p.d_s, p.d_b, p.d_chk);
+	}
+#undef PSMC_W2
 	if (p.ev[2]) hipEventRecord(p.ev[2], p.stream);
 	hipLaunchKernelGGL(k_expect_wide, dim3(p.n_work, (S / 4) * H + H), dim3(64), 0, p.stream, p.d_a, p.d_e, p.d_a0, p.d_obs, p.d_seg_off, p.d_seg_len, wl, S,
 	                   p.d_f, p.d_b, p.d_s, p.d_segA, p.d_segE, p.d_segA0);

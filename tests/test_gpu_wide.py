@@ -54,7 +54,7 @@ def test_wide_golden(hip, golden, key):
         es.close()
 
 
-@pytest.mark.parametrize("n", [129, 150, 192, 256, 300, 513, 1024])
+@pytest.mark.parametrize("n", [129, 150, 192, 193, 200, 208, 209, 224, 225, 256, 300, 513, 1024])   # register kernels: C = 96 (.. 192), 104 (.. 208), 112 (.. 224); beyond: the matrix from the L2
 def test_wide_vs_oracle_random(hip, oracle, n):
     """Random dense HMMs, a bootstrap multiset with repeats, edge lengths; decoding (-d, -D, -c branches) on the resident tables."""
     rng = np.random.default_rng(500 + n)
@@ -102,3 +102,30 @@ def test_wide_batch_equals_separate_calls(hip, oracle, sort):
         o = oracle.estep(pars[r][0], pars[r][1], pars[r][2], [segs[i] for i in sel])
         assert bits_equal(got["A"][r], o["A"]) and bits_equal(got["E"][r], o["E"]) and got["LL"][r] == o["LL"], r
     es.close()
+
+
+def test_wide_general_kernels_at_register_kernel_sizes():
+    """129 .. 224 states run the register-resident kernels (k_fwd_wide2 / k_bwd_wide2) by default; PSMC_HIP_WIDE_L2=1 sends the same sizes
+    through the general kernels (matrix from the L2, what 225 .. 1024 states use): both give the reference's bits on the 200- and
+    149-state goldens."""
+    import subprocess, sys
+    code = """
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from psmc_amd import hip
+from conftest import bits_equal, Golden
+g = dict(np.load(os.path.join(%r, "tests", "golden", "estep_wide.npz")))
+segs = Golden().segs_small[:8]
+for key in ("n200", "n149"):
+    a, e, a0 = g[key + ".a"], g[key + ".e"], g[key + ".a0"]
+    es = hip.HipEStep(a.shape[0], mode=hip.MODE_EXACT); es.load_segments(segs)
+    r = es.estep(a, e, a0)
+    assert bits_equal(r["A"], g[key + ".A"]) and bits_equal(r["E"], g[key + ".E"]) and r["LL"] == float(g[key + ".LL"]) and bits_equal(r["chk"], g[key + ".seg_chk"]), key
+    f, b, sc = es.tables(5)
+    assert bits_equal(f[::7], g[key + ".f65"]) and bits_equal(b[::7], g[key + ".b65"]) and bits_equal(sc, g[key + ".s65"]), key
+    es.close()
+print("wide l2 ok")
+""" % (ROOT, ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PSMC_HIP_WIDE_L2="1"), timeout=600)
+    assert r.returncode == 0 and "wide l2 ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -206,7 +206,11 @@ int psmc_hip_reserve_tables(psmc_hip_ctx *ctx);
  * max_bins <= 0: no upper bound), max_bins = the table bins all replicates together can need, e.g. n_rep x the padded
  * length of the loaded segments -- instead of inside the first psmc_hip_estep_batch.  The driver clears what it hands out:
  * ~250 GB take 4-6 s, which a caller can spend while it is still loading (psmc_boot does; the first EM iteration then costs
- * what the others do).  Fast mode: no-op. */
+ * what the others do).  Fast mode: no-op.
+ * A SECOND call while that reservation stands (64 states, batch without the f table) adds what has become free since -- psmc_boot
+ * --main: the main run that shared the device is over -- as a second chunk of table beside the first, up to max_bins in all: the batches
+ * that follow plan their launches for both (an entry's table is an offset from the first chunk either way).  Growing the first chunk
+ * instead would free and allocate it again: 8 s for 260 GB on this driver against 0.5 s for 31 GB more. */
 int psmc_hip_reserve_batch_tables(psmc_hip_ctx *ctx, int64_t max_bins);
 int psmc_hip_estep_batch(psmc_hip_ctx *ctx, int n_rep, const double *a, const double *e, const double *a0,
                          const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL);

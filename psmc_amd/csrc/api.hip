@@ -176,7 +176,7 @@ extern "C" void psmc_hip_destroy(psmc_hip_ctx *c)
 	void *ptrs[] = {c->d_seg_off, c->d_seg_len, c->d_work, c->d_par, c->d_f, c->d_b, c->d_s, c->d_segA, c->d_segE,
 	                c->d_segA0, c->d_chk, c->d_chunks, c->d_entry, c->d_bexit, c->d_Cpart, c->d_Epart, c->d_LLpart,
 	                c->d_stage, c->d_stats, c->d_warm, c->d_bentry, c->d_dirty, c->d_cnt, c->d_gate, c->d_touch, c->d_sb, c->d_items, c->d_ftiles, c->d_Kcol,
-	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar, c->d_s_all, c->d_cu_mask, c->d_lkp, c->d_lkoff};
+	                c->d_bw_seg, c->d_bw_par, c->d_bw_tab, c->d_bpar, c->d_s_all, c->d_cu_mask, c->d_lkp, c->d_lkoff, c->d_b2};
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	if (c->h_par) (void)hipHostFree(c->h_par);
 	if (c->h_cnt) (void)hipHostFree(c->h_cnt);
@@ -223,7 +223,7 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "fuse128") { if (v != 0 && v != 2) return PSMC_HIP_EINVAL; c->fuse128 = (int)v; c->plan_dirty = true; c->items_dirty = true; }
 	else if (k == "group_cap") { if (v < 0) return PSMC_HIP_EINVAL; c->group_cap = (int)v; c->items_dirty = true; }
 	else if (k == "share_learn") { c->share_learn = v != 0 ? 1 : 0; }
-	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; c->reserved_refwd = -1; c->reserved_cap = 0; }
+	else if (k == "exact_refwd") { if (v < -1 || v > 2) return PSMC_HIP_EINVAL; c->exact_refwd = (int)v; c->reserved_refwd = -1; c->reserved_cap = 0; if (c->d_b2) { (void)hipFree(c->d_b2); c->d_b2 = nullptr; c->b2_bins = c->b2_alloc = 0; } }
 	else if (k == "batch_sort") { c->batch_sort = v != 0 ? 1 : 0; }
 	else if (k == "batch_tailfill") c->batch_tailfill = v != 0;
 	else if (k == "batch_major") c->batch_major = v != 0;
@@ -239,6 +239,7 @@ int set_segments_common(psmc_hip_ctx *c, int n_seg, const int32_t *L)
 {
 	destroy_kids(c); // batch children hold plans over the previous segments
 	c->reserved_refwd = -1; c->reserved_cap = 0;
+	if (c->d_b2) { (void)hipFree(c->d_b2); c->d_b2 = nullptr; c->b2_bins = c->b2_alloc = 0; }
 	c->n_seg = n_seg;
 	c->L.assign(L, L + n_seg);
 	int rc;
@@ -428,6 +429,7 @@ static int ensure_tables_once(psmc_hip_ctx *c, bool need_b, int64_t bins, bool n
 	if (c->tab_bins < bins) { // grow: everything goes, and comes back as needed
 		if (c->d_f) { (void)hipFree(c->d_f); c->d_f = nullptr; }
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
+		if (c->d_b2) { (void)hipFree(c->d_b2); c->d_b2 = nullptr; c->b2_bins = c->b2_alloc = 0; c->reserved_cap = 0; }
 		c->have_b = false;
 		if ((rc = dev_alloc(c, &c->d_s, (size_t)bins))) { c->tab_bins = 0; return rc; }
 		if (c->mode == PSMC_HIP_MODE_FAST && (rc = dev_alloc(c, &c->d_sb, (size_t)bins))) { c->tab_bins = 0; return rc; }
@@ -460,6 +462,7 @@ int ensure_tables(psmc_hip_ctx *c, bool need_b, int64_t want_bins, bool need_f)
 		// batch).  Start over at what THIS call needs.
 		if (c->d_f) { (void)hipFree(c->d_f); c->d_f = nullptr; }
 		if (c->d_b) { (void)hipFree(c->d_b); c->d_b = nullptr; }
+		if (c->d_b2) { (void)hipFree(c->d_b2); c->d_b2 = nullptr; c->b2_bins = c->b2_alloc = 0; }
 		if (c->d_s) { (void)hipFree(c->d_s); c->d_s = nullptr; }
 		if (c->d_sb) { (void)hipFree(c->d_sb); c->d_sb = nullptr; }
 		c->have_b = false; c->tab_bins = 0; c->reserved_refwd = -1; c->reserved_cap = 0;

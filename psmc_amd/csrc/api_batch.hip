@@ -42,7 +42,7 @@ static int batch_capacity(psmc_hip_ctx *c, int64_t *cap, bool refwd, int64_t all
 	size_t fr = 0, tot = 0;
 	HIPCHK(c, hipMemGetInfo(&fr, &tot));
 	const double S = (double)c->ns, per_bin = S * 8.0 * (refwd ? 1.0 : 2.0) + 8.0;
-	const double held = (double)c->tab_bins * (S * 8.0 * ((c->have_b ? 1.0 : 0.0) + (c->d_f ? 1.0 : 0.0)) + 8.0 + (c->d_sb ? 8.0 : 0.0));
+	const double held = (double)c->tab_bins * (S * 8.0 * ((c->have_b ? 1.0 : 0.0) + (c->d_f ? 1.0 : 0.0)) + 8.0 + (c->d_sb ? 8.0 : 0.0)) + (double)c->b2_alloc * S * 8.0;
 	// (the call-wide scale-factor table stays allocated between calls: count it as free, or the second call would see a smaller
 	// capacity than the first and cut other launches)
 	double budget = ((double)fr + held + (double)c->s_all_cap * 8.0) * 0.9;
@@ -82,9 +82,30 @@ extern "C" int psmc_hip_reserve_batch_tables(psmc_hip_ctx *c, int64_t max_bins)
 	if (c->mode != PSMC_HIP_MODE_EXACT && c->ns <= 128) return PSMC_HIP_OK; // fast mode keeps one replicate's tables: nothing to reserve
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->n_seg < 1) return fail(c, PSMC_HIP_ESTATE, "reserve_batch_tables: no segments loaded");
+	// A SECOND call while the reservation stands and more memory has become free (psmc_boot --main: the main run that shared the device is over
+	// and its 31 GB of tables are gone): a second chunk of b table beside the first.  Growing the first would mean freeing and allocating 250+ GB
+	// again -- this driver clears what it hands out, 24 ms per GB: 6.2 s + 1.7 s for the free (profiles/experiments/r06_realloc_probe.cpp) --
+	// while 31 GB more cost half a second; an entry's table is a 64-bit offset from d_b, so a slot in the second chunk is just another offset
+	// (batch_exact).  Only without the f table (the scale factors of such a batch live in a call-wide table of their own), once.
+	if (c->reserved_cap > 0 && c->have_b && !c->d_f && c->tab_bins > 128 && c->batch_bins <= 0 && c->ns == 64 && (c->reserved_refwd == 1 || c->exact_refwd >= 1)) {
+		const int64_t cap1 = c->tab_bins - 128;
+		if (c->d_b2 || (max_bins > 0 && cap1 >= max_bins)) return PSMC_HIP_OK;
+		size_t fr = 0, tot = 0;
+		HIPCHK(c, hipMemGetInfo(&fr, &tot));
+		const int64_t slack = 1 << 20; // (an entry that does not fit the rest of the first chunk starts the second: at most one entry's bins are left unused)
+		int64_t extra = (int64_t)((double)fr * 0.9 / ((double)c->ns * 8.0)) - slack - 256;
+		if (max_bins > 0) extra = std::min(extra, max_bins - cap1);
+		if (extra < std::max<int64_t>(4096, cap1 / 64)) return PSMC_HIP_OK; // (not worth a launch)
+		double *p2 = nullptr;
+		if (hipMalloc((void **)&p2, (size_t)(extra + slack + 8) * c->ns * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return PSMC_HIP_OK; } // (as before, then)
+		c->d_b2 = p2; c->b2_alloc = extra + slack + 8; c->b2_bins = extra + slack;
+		c->reserved_cap = cap1 + extra;
+		return PSMC_HIP_OK;
+	}
 	int64_t cap = 0;
 	bool refwd = false;
 	c->reserved_refwd = -1; c->reserved_cap = 0;
+	if (c->d_b2) { (void)hipFree(c->d_b2); c->d_b2 = nullptr; c->b2_bins = c->b2_alloc = 0; } // a new reservation starts from one chunk
 	int rc = batch_refwd(c, max_bins, &refwd);
 	if (rc || (rc = batch_capacity(c, &cap, refwd, max_bins))) return rc;
 	rc = ensure_tables(c, true, max_bins > 0 ? std::min(cap, max_bins) : cap, !refwd);
@@ -224,23 +245,36 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		}
 	}
 	int64_t worst = 0; size_t worst_entries = 0;
+	bool uses2 = false; // an entry's b table sits in the second chunk (psmc_hip_reserve_batch_tables, second call)
 	{
+		// the second chunk as an offset from d_b, in bins (rows of S doubles): its first row at a whole number of rows from d_b
+		const bool two = refwd && c->d_b2 != nullptr && c->d_b != nullptr && c->tab_bins > 128;
+		const int64_t row = (int64_t)S * 8, cap1 = two ? c->tab_bins - 128 : INT64_MAX;
+		int64_t delta2 = 0, cap2 = 0;
+		if (two) {
+			const int64_t diff = (int64_t)((intptr_t)c->d_b2 - (intptr_t)c->d_b), skew = ((diff % row) + row) % row, shift = (row - skew) % row;
+			delta2 = (diff + shift) / row; cap2 = c->b2_bins - (shift ? 1 : 0);
+		}
 		int64_t s_run = 0;
 		for (const std::vector<int> &lb : lblocks) {
-			int64_t run = 0; const size_t e0 = wseg.size();
+			int64_t run = 0, run2 = 0; const size_t e0 = wseg.size();
 			l_first.push_back((int)e0);
 			for (int bi : lb) {
 				const Block &b = blocks[bi];
 				for (int i = 0; i < align; ++i) {
 					if (i < b.n) {
 						const int32_t wi = ord[b.rep][b.first + i], sg = reps[b.rep].work[wi];
+						const int64_t len = padded_len(sg);
 						ent_of[b.rep][wi] = (int)wseg.size();
-						wseg.push_back(sg); wpar.push_back(b.rep); wtab.push_back(run); wtab_s.push_back(s_run + run); run += padded_len(sg);
+						const bool in2 = two && (run2 > 0 || run + len > cap1);
+						if (in2 && run2 + len > cap2) return fail(c, PSMC_HIP_ESTATE, "estep_batch: launch does not fit the two table chunks");
+						wseg.push_back(sg); wpar.push_back(b.rep); wtab.push_back(in2 ? delta2 + run2 : run); wtab_s.push_back(s_run + run + run2);
+						if (in2) { run2 += len; uses2 = true; } else run += len;
 					} else { wseg.push_back(-1); wpar.push_back(b.rep); wtab.push_back(0); wtab_s.push_back(0); }
 				}
 			}
 			worst = std::max(worst, run); worst_entries = std::max(worst_entries, wseg.size() - e0);
-			s_run += run;
+			s_run += run + run2;
 		}
 		l_first.push_back((int)wseg.size());
 	}
@@ -249,12 +283,12 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 	// entries of ALL of them -- thousands of waves, issue-bound, instead of one latency-bound launch of ~1000 waves each (100
 	// replicates of a genome: 1.25 s against 4 x 0.9 s per EM iteration) -- into a call-wide s table (15 GB for 1.9 G bins).  Its
 	// waves start in list order: longest first.
-	const bool fwd_all = refwd && n_launches > 1;
+	const bool fwd_all = refwd && (n_launches > 1 || uses2); // (the second chunk holds b rows only: the scale factors of its entries need the call-wide table)
 	{
 		// tables: for the largest launch when the caller fixed "batch_bins"; else for everything that fits (or all entries at once), ONCE -- a
 		// hipMalloc of 250 GB takes 4-6 s on this driver (it clears the memory: profiles/r04_boot_breakdown.txt), so the size must not depend
 		// on this call's launches, and psmc_hip_reserve_batch_tables lets a caller pay for it while it loads
-		if ((rc = ensure_tables(c, true, c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins)), !refwd))) return rc;
+		if ((rc = ensure_tables(c, true, c->d_b2 ? std::min<int64_t>(worst, c->tab_bins - 128) : (c->batch_bins > 0 ? worst : std::max(worst, std::min(cap, all_bins))), !refwd))) return rc;
 		if ((rc = ensure_seg_outputs(c, (int)worst_entries))) return rc;
 		if (c->bw_cap < (size_t)n_all) {
 			if ((rc = dev_alloc(c, &c->d_bw_seg, (size_t)n_all))) return rc;

@@ -169,6 +169,7 @@ struct psmc_hip_ctx {
 	int batch_tailfill = 1;            // "batch_tailfill": the exact batch puts the shortest entries into the spare slots of the memory-bound launches when that saves a launch
 	int batch_major = 1;               // "batch_major": blocks no longer than the dominant trunk length keep replicate order (replicates complete launch by launch)
 	int batch_first = 0;               // "batch_first": the next batch calls' replicate 0 is replicate batch_first of the context (fast mode: which kept plan it uses)
+	double *d_b2 = nullptr; int64_t b2_bins = 0, b2_alloc = 0; // exact batch without the f table: a second chunk of b table, allocated when memory became free later (api_batch.hip)
 	int64_t reserved_cap = 0;          // ... and the per-launch capacity it sized the tables for
 	int reserved_refwd = -1;           // what psmc_hip_reserve_batch_tables decided about the f table (-1: nothing reserved): the batches that follow keep it
 	int cu_first = 0, cu_count = 0;    // psmc_hip_set_cu_range: the streams of this context are masked to these compute units (0: the whole device)

@@ -34,7 +34,12 @@
 #include "hipbe.h"
 
 #define MAX_DEV 64
-typedef struct { int n_dev, n_states, n_rep; psmc_hip_ctx *ctx[MAX_DEV]; int dev_id[MAX_DEV], main_dev; } hip_bb;
+typedef struct {
+	int n_dev, n_states, n_rep; psmc_hip_ctx *ctx[MAX_DEV]; int dev_id[MAX_DEV], main_dev;
+	int64_t want_bins[MAX_DEV];      /* what bb_reserve was asked for: the second call, when the main run is over, asks again */
+	psmc_estep_backend *be_main;     /* the main run's backend, so that its context (and its 31 GB of tables) can go the moment the run is over */
+	int main_gone;
+} hip_bb;
 
 static int bb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, const int32_t *L)
 {
@@ -44,13 +49,20 @@ static int bb_load(void *self, int dev, int n_seg, const uint8_t *const *sym, co
  * it hands out: seconds for 250 GB) -- part of the set-up, not of an iteration */
 static int bb_reserve(void *self, int dev, int64_t table_bins)
 {
+	((hip_bb *)self)->want_bins[dev] = table_bins;
 	return psmc_hip_reserve_batch_tables(((hip_bb *)self)->ctx[dev], table_bins);
 }
 /* the main run that shared device main_dev is over: its compute units go back to the batch */
 static void bb_main_done(void *self, int d)
 {
 	hip_bb *h = (hip_bb *)self;
-	if (h->dev_id[d] == h->main_dev) (void)psmc_hip_set_cu_range(h->ctx[d], 0, 0);
+	if (h->dev_id[d] != h->main_dev) return;
+	(void)psmc_hip_set_cu_range(h->ctx[d], 0, 0);
+	/* ... and its memory: the main run's context goes now (the first device thread to get here does it), and this batch context asks for its
+	 * tables again -- the library adds what has become free as a second chunk (psmc_hip_reserve_batch_tables), so that the iterations still to
+	 * come need a launch fewer (round 5 kept five launches to the end: 12 s of 197) */
+	if (h->be_main && !__atomic_exchange_n(&h->main_gone, 1, __ATOMIC_ACQ_REL) && h->be_main->destroy) { h->be_main->destroy(h->be_main->self); h->be_main->destroy = 0; }
+	if (h->want_bins[d] > 0) (void)psmc_hip_reserve_batch_tables(h->ctx[d], h->want_bins[d]);
 }
 static int bb_estep_batch(void *self, int dev, int n_rep, const double *a, const double *e, const double *a0,
                           const int32_t *sel_off, const int32_t *sel_idx, double *A, double *sums, double *E, double *LL,
@@ -173,6 +185,7 @@ int main(int argc, char *argv[])
 			bb.destroy(bb.self); psmc_options_free(&o); psmc_options_free(&om);
 			return 2;
 		}
+		h.be_main = &be_main;
 		main_run = psmc_run_begin(&om, &be_main);
 		if (main_run && (rc = psmc_hip_reserve_tables(psmc_hipbe_ctx(&be_main)))) {
 			fprintf(stderr, "psmc_boot: no device memory for the main run's tables (%s)\n", psmc_hip_strerror(rc));

@@ -784,6 +784,42 @@ def test_exact_batch_tail_fill(hip, golden):
     ref.close()
 
 
+def test_exact_batch_second_table_chunk(hip, golden):
+    """psmc_hip_reserve_batch_tables called a second time (psmc_boot --main does when the main run that shared the
+    device is over): what has become free is added as a SECOND chunk of b table beside the first, and the launches that follow place
+    entries in both -- an entry's table is a 64-bit offset from the first chunk either way.  A third of the needed bins first, all of
+    them at the second call: one launch instead of three, the same bits as separate calls."""
+    segs = golden.segs_small + golden.segs_mid[2:]
+    rng = np.random.default_rng(21)
+    params = _traj_params(5) * 2
+    sels = [rng.integers(0, len(segs), size=rng.integers(2, len(segs))).tolist() for _ in range(10)]
+    need = sum(sum((len(segs[i]) + 63) // 64 * 64 for i in set(x)) for x in sels)
+    es = hip.HipEStep(64, mode=hip.MODE_EXACT, exact_refwd=2)
+    es.load_segments(segs)
+    es.reserve_batch_tables(need // 3)
+    first = es.estep_batch(params, sels)          # (the tables grow to what the call needs: one chunk, as always)
+    es.close()
+    es = hip.HipEStep(64, mode=hip.MODE_EXACT, exact_refwd=2)
+    es.load_segments(segs)
+    es.reserve_batch_tables(need // 3)
+    es.reserve_batch_tables(need)                  # the second chunk
+    got = es.estep_batch(params, sels)
+    assert es.batch_info()["groups"] == 1
+    got2 = es.estep_batch(params[::-1], sels)      # and again, other parameters: the reservation stands
+    es.close()
+    for key in ("A", "E", "LL"):
+        assert bits_equal(got[key], first[key]), key
+    ref = hip.HipEStep(64, mode=hip.MODE_EXACT)
+    ref.load_segments(segs)
+    for r in (0, 4, 9):
+        ref.select(sels[r])
+        w = ref.estep(*params[r])
+        assert bits_equal(got["A"][r], w["A"]) and bits_equal(got["E"][r], w["E"]) and got["LL"][r] == w["LL"], r
+        w2 = ref.estep(*params[::-1][r])
+        assert bits_equal(got2["A"][r], w2["A"]) and got2["LL"][r] == w2["LL"], r
+    ref.close()
+
+
 def test_exact_batch_progress_callback(hip, golden):
     """psmc_hip_estep_batch_cb: `done` names every replicate exactly once, when its rows are final -- a copy taken inside the callback
     equals the row after the call.  Trunks cut to one length like utils/splitfa.c's (2000 bins + the segments' tails), ten replicates,

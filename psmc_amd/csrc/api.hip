@@ -207,9 +207,9 @@ extern "C" int psmc_hip_set_option(psmc_hip_ctx *c, const char *key, double v)
 	else if (k == "max_rounds") c->max_rounds = (int)v;
 	else if (k == "structured") { c->struct_opt = v != 0 ? 1 : 0; }
 	else if (k == "learn") { c->learn = v != 0 ? 1 : 0; }
-	else if (k == "merge") { c->merge = v != 0 ? 1 : 0; }
-	else if (k == "adapt") { c->adapt = v != 0 ? 1 : 0; c->plan_dirty = true; }
-	else if (k == "prev_start") { c->prev_start = v != 0 ? 1 : 0; c->prev_ok = false; }
+	else if (k == "merge") { c->merge = v != 0 ? 1 : 0; c->plan_dirty = true; c->chunk_cap = 0; }
+	else if (k == "adapt") { c->adapt = v != 0 ? 1 : 0; c->plan_dirty = true; c->chunk_cap = 0; }
+	else if (k == "prev_start") { c->prev_start = v != 0 ? 1 : 0; c->prev_ok = false; c->plan_dirty = true; c->chunk_cap = 0; }
 	else if (k == "warm_shift") { if (v < 0 || v > 4) return PSMC_HIP_EINVAL; c->warm_shift = (int)v; c->warm_shift_set = true; c->plan_dirty = true; }
 	else if (k == "merge1") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->merge1 = (int)v; c->plan_dirty = true; }
 	else if (k == "lanes8") { if (v < -1 || v > 1) return PSMC_HIP_EINVAL; c->lanes8 = (int)v; }

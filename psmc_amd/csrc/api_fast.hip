@@ -116,13 +116,16 @@ static int plan_fast(psmc_hip_ctx *c)
 		if ((rc = dev_alloc(c, &c->d_dirty, (size_t)2 * nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_touch, (size_t)3 * nc))) return rc; // touch_f | touch_b | fmerge
 		if ((rc = dev_alloc(c, &c->d_finv, (size_t)nc))) return rc;
-		if ((rc = dev_alloc(c, &c->d_prevx, (size_t)nc * c->ns))) return rc;
-		if (c->h_mlen) { (void)hipHostFree(c->h_mlen); c->h_mlen = nullptr; }
-		if (c->h_mis) { (void)hipHostFree(c->h_mis); c->h_mis = nullptr; }
-		if (hipHostMalloc((void **)&c->h_mlen, (size_t)nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
-		    hipHostGetDevicePointer((void **)&c->m_mlen, c->h_mlen, 0) != hipSuccess ||
-		    hipHostMalloc((void **)&c->h_mis, (size_t)2 * nc * sizeof(double), hipHostMallocMapped) != hipSuccess ||
-		    hipHostGetDevicePointer((void **)&c->m_mis, c->h_mis, 0) != hipSuccess)
+		// (what only the round-6 options use is allocated only with them: a fast bootstrap keeps a plan per replicate, and a hundred pairs of
+		// pinned buffers cost seconds to make and to free)
+		if (c->h_mlen) { (void)hipHostFree(c->h_mlen); c->h_mlen = nullptr; c->m_mlen = nullptr; }
+		if (c->h_mis) { (void)hipHostFree(c->h_mis); c->h_mis = nullptr; c->m_mis = nullptr; }
+		if (c->prev_start && (rc = dev_alloc(c, &c->d_prevx, (size_t)nc * c->ns))) return rc;
+		if ((c->merge || c->adapt) &&
+		    (hipHostMalloc((void **)&c->h_mlen, (size_t)nc * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+		     hipHostGetDevicePointer((void **)&c->m_mlen, c->h_mlen, 0) != hipSuccess ||
+		     hipHostMalloc((void **)&c->h_mis, (size_t)2 * nc * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+		     hipHostGetDevicePointer((void **)&c->m_mis, c->h_mis, 0) != hipSuccess))
 			return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc (mapped)");
 		if ((rc = dev_alloc(c, &c->d_LLpart, (size_t)nc))) return rc;
 		if ((rc = dev_alloc(c, &c->d_items, (size_t)32 * nc + 64))) return rc; // (+ 4 nc: matrix slot of every KcTile | the KcTile that computes a slot; + 2 nc: the fix pass's tiles)
@@ -516,14 +519,15 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	if (c->chunks_dirty) { // learned / adapted warm-ups (learn_groups, adapt_warmups) reach the device before the next launch reads them
 		// (from a pinned copy, on the E-step's stream: a blocking copy of pageable memory waits for every kernel on the device, and with
 		// per-tile warm-ups this happens before every E-step)
-		if (c->h_chunks_cap < c->chunks.size()) {
-			if (c->h_chunks) { (void)hipHostFree(c->h_chunks); c->h_chunks = nullptr; }
-			if (hipHostMalloc((void **)&c->h_chunks, sizeof(Chunk) * c->chunks.size(), hipHostMallocDefault) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
-			c->h_chunks_cap = c->chunks.size();
+		psmc_hip_ctx *R = dbg_root(c); // (one staging buffer per root context: its replicates run one after the other)
+		if (R->h_chunks_cap < c->chunks.size()) {
+			if (R->h_chunks) { (void)hipHostFree(R->h_chunks); R->h_chunks = nullptr; }
+			if (hipHostMalloc((void **)&R->h_chunks, sizeof(Chunk) * c->chunks.size(), hipHostMallocDefault) != hipSuccess) return fail(c, PSMC_HIP_ENOMEM, "hipHostMalloc");
+			R->h_chunks_cap = c->chunks.size();
 		}
 		HIPCHK(c, hipStreamSynchronize(st)); // (the previous copy out of the same buffer is done)
-		memcpy(c->h_chunks, c->chunks.data(), sizeof(Chunk) * c->chunks.size());
-		HIPCHK(c, hipMemcpyAsync(c->d_chunks, c->h_chunks, sizeof(Chunk) * c->chunks.size(), hipMemcpyHostToDevice, st));
+		memcpy(R->h_chunks, c->chunks.data(), sizeof(Chunk) * c->chunks.size());
+		HIPCHK(c, hipMemcpyAsync(c->d_chunks, R->h_chunks, sizeof(Chunk) * c->chunks.size(), hipMemcpyHostToDevice, st));
 		c->chunks_dirty = false;
 	}
 	// coarse bulk items: the fused and the factored back half only (their backward pass of phase 1 leaves start vectors, no table)
@@ -547,14 +551,14 @@ int enqueue_fast(psmc_hip_ctx *c, const double *a, const double *e, const double
 	}
 	{
 		// the forward fix pass: where the back half knows about its merge records (the fused one of a 64-state model), tiles of whole 16-bin blocks
-		c->merge_used = c->merge != 0 && c->use_struct && p.fused == 1 && c->ns == 64 && c->chunk_used % 16 == 0;
+		c->merge_used = c->merge != 0 && c->h_mlen && c->use_struct && p.fused == 1 && c->ns == 64 && c->chunk_used % 16 == 0;
 		p.merge = c->merge_used ? 1 : 0;
 		p.d_fmerge = c->d_touch + 2 * (size_t)p.n_chunks; p.d_finv = c->d_finv; p.m_mlen = c->m_mlen; p.h_mlen = c->h_mlen; p.m_mis = c->m_mis;
 		p.d_fix_f = c->d_items + 30 * (size_t)p.n_chunks; p.n_fix_f = c->n_fix_f;
 		if (c->h_mlen) memset(c->h_mlen, 0, sizeof(int) * p.n_chunks); // (the E-step that wrote it is over: launch_fast reads the verify counts before it returns)
 		if (c->h_mis) for (int b = 0; b < p.n_chunks; ++b) c->h_mis[b] = -1.0; // "not measured": the tiles neither fix launch looks at keep their warm-ups
 		// forward warm-ups from the previous E-step's X: same plan, same kind of table, and nobody else has used the tables in between
-		const bool prev = c->prev_start && c->prev_ok && c->use_struct && c->prev_serial == serial0 && c->prev_f == c->d_f && c->prev_ckpt == p.ckpt;
+		const bool prev = c->prev_start && c->d_prevx && c->prev_ok && c->use_struct && c->prev_serial == serial0 && c->prev_f == c->d_f && c->prev_ckpt == p.ckpt;
 		p.d_prevx = prev ? c->d_prevx : nullptr;
 		c->prev_ok = false;
 	}

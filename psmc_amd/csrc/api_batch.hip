@@ -327,6 +327,11 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		if (dbg_t) { (void)hipStreamSynchronize(c->stream); fwd_all_s = now() - t0; }
 	}
 	// per-entry results of the whole call on the host (34 KB each): a replicate's entries may sit in different launches
+	// (34 KB per entry at 64 states, 8 MB at 1024: a hundred replicates of sixty trunks would be 48 GB of pageable memory there -- ADVICE r5)
+	if ((double)n_all * (double)(S * S) * 8.0 > 16e9) {
+		c->err = "estep_batch: the per-entry statistics of this call (" + std::to_string(n_all) + " entries x " + std::to_string(S) + "^2 doubles) need more than 16 GB of host memory: send fewer replicates per call at this many states";
+		return PSMC_HIP_ENOMEM;
+	}
 	c->h_segA.resize((size_t)n_all * S * S); c->h_segE.resize((size_t)n_all * 3 * S);
 	std::vector<double> lk_all((size_t)n_all, 0.0);
 	// the launch after which a replicate's statistics are complete

@@ -219,11 +219,12 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		pat_ok = 0; /* a second %d, or any other conversion */
 	}
 	if (pat_ok && strlen(out_pattern) + 16 >= 4096) pat_ok = 0; /* the expansion below writes into char fn[4096]: a longer pattern would be cut, and every replicate would open the same file */
-	if (n_rep < 1 || !pat_ok || !pat_d) { fprintf(stderr, "psmc_boot: need a replicate count and an output pattern with exactly one %%d (and no other conversion)\n"); return 1; }
-	if (o->decode || o->cnt_file || o->print_prob || o->simulate) { fprintf(stderr, "psmc_boot: decoding / simulation options make no sense on bootstrap replicates\n"); return 1; }
-	if (psmc_setup_begin(o, &su)) return 1;
+	/* (every way out before the main run's thread exists takes the begun main run with it: psmc_run_abort -- ADVICE r5) */
+	if (n_rep < 1 || !pat_ok || !pat_d) { fprintf(stderr, "psmc_boot: need a replicate count and an output pattern with exactly one %%d (and no other conversion)\n"); psmc_run_abort(main_run); return 1; }
+	if (o->decode || o->cnt_file || o->print_prob || o->simulate) { fprintf(stderr, "psmc_boot: decoding / simulation options make no sense on bootstrap replicates\n"); psmc_run_abort(main_run); return 1; }
+	if (psmc_setup_begin(o, &su)) { psmc_run_abort(main_run); return 1; }
 	const int N = su.pat.n_states;
-	if (psmc_input_read(o->in_file, &in) || in.n_seg == 0) { fprintf(stderr, "psmc_boot: no sequence in %s\n", o->in_file); psmc_setup_end(&su); return 1; }
+	if (psmc_input_read(o->in_file, &in) || in.n_seg == 0) { fprintf(stderr, "psmc_boot: no sequence in %s\n", o->in_file); psmc_setup_end(&su); psmc_run_abort(main_run); return 1; }
 	for (int i = 0; i < in.n_seg; ++i)
 		if (in.seg[i].L < 1) { fprintf(stderr, "psmc_boot: empty sequence '%s'\n", in.seg[i].name); goto done_input; }
 	{ /* the trunks go to every device once */
@@ -367,6 +368,7 @@ done_rep:
 	}
 	free(rep);
 done_input:
+	if (main_run) { psmc_run_abort(main_run); main_run = 0; } /* begun, its thread never started */
 	psmc_input_free(&in);
 	psmc_setup_end(&su);
 	return status;

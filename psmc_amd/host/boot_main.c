@@ -86,7 +86,10 @@ int main(int argc, char *argv[])
 	int n_rep = 0, i = 1;
 	long seed0 = 1;
 	const char *pattern = 0, *main_out = 0, *main_in = 0;
-	setenv("GPU_MAX_HW_QUEUES", "16", 1); /* before the first HIP call: the main run's stream and the batch's must not share a hardware queue */
+	{ /* before the first HIP call: the main run's stream and the batch's must not share a hardware queue (a larger value the user exported stands) */
+		const char *q = getenv("GPU_MAX_HW_QUEUES");
+		if (!q || atoi(q) < 16) setenv("GPU_MAX_HW_QUEUES", "16", 1);
+	}
 	for (; i < argc; ++i) {
 		if (!strcmp(argv[i], "--")) { ++i; break; }
 		if (!strcmp(argv[i], "-R") && i + 1 < argc) n_rep = atoi(argv[++i]);
@@ -113,7 +116,11 @@ int main(int argc, char *argv[])
 		om.bootstrap = 0;
 		free(om.in_file); om.in_file = strdup(main_in);
 		free(om.out_file); om.out_file = strdup(main_out);
-		if (om.decode || om.cnt_file || om.print_prob || om.simulate) { fprintf(stderr, "psmc_boot: decoding / simulation options make no sense on bootstrap replicates\n"); return 1; }
+		if (om.decode || om.cnt_file || om.print_prob || om.simulate) {
+			fprintf(stderr, "psmc_boot: --main shares its psmc options with the replicates: decoding / simulation options (-d -D -s -c -S) cannot be given here\n");
+			psmc_options_free(&o); psmc_options_free(&om);
+			return 1;
+		}
 	}
 	psmc_pattern pat;
 	int n_states = 0;
@@ -189,7 +196,7 @@ int main(int argc, char *argv[])
 		main_run = psmc_run_begin(&om, &be_main);
 		if (main_run && (rc = psmc_hip_reserve_tables(psmc_hipbe_ctx(&be_main)))) {
 			fprintf(stderr, "psmc_boot: no device memory for the main run's tables (%s)\n", psmc_hip_strerror(rc));
-			main_run = 0;
+			psmc_run_abort(main_run); main_run = 0;
 		}
 		if (!main_run) { be_main.destroy(be_main.self); bb.destroy(bb.self); psmc_options_free(&o); psmc_options_free(&om); return 1; }
 	}

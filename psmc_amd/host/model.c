@@ -7,6 +7,7 @@
  * params = [theta0, rho0, max_t, lambda_0..lambda_{n_free-1}, (dt)].
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "psmc_host.h"
@@ -87,7 +88,10 @@ static int intervals_alloc(intervals *v, int N)
 {
 	v->N = N;
 	v->buf = (double *)calloc((size_t)IV_ARRAYS * (size_t)(N + 1), sizeof(double));
-	if (!v->buf) return -1;
+	if (!v->buf) { /* 15 short arrays: out of memory here is out of memory for the run, and going on with the previous parameters in place would be silent garbage */
+		fprintf(stderr, "psmc: out of memory (model intervals, %d states)\n", N);
+		abort();
+	}
 	double **slot[IV_ARRAYS] = {&v->lam, &v->width, &v->surv, &v->drop, &v->cum, &v->g, &v->start, &v->mass, &v->pi, &v->sigma, &v->stay,
 	                            &v->below, &v->above, &v->diag, &v->mean_t};
 	for (int i = 0; i < IV_ARRAYS; ++i) *slot[i] = v->buf + (size_t)i * (size_t)(N + 1);

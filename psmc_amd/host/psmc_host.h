@@ -135,6 +135,7 @@ int psmc_run(psmc_options *o, psmc_estep_backend *be);
 typedef struct psmc_run_state psmc_run_state;
 psmc_run_state *psmc_run_begin(psmc_options *o, psmc_estep_backend *be);
 int psmc_run_finish(psmc_run_state *st);
+void psmc_run_abort(psmc_run_state *st); /* begun, never to be finished: removes the output it opened, frees the state */
 
 /* one EM round (psmc_em, em.c:27-78); prints the IT line to out */
 int psmc_em_round(psmc_model *m, const psmc_input *in, psmc_estep_backend *be, FILE *out);

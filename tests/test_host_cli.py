@@ -178,6 +178,11 @@ def test_boot_main_run_beside_replicates(oracle_psmc, tmp_path):
     assert "RD\t2" in one.stdout
     for k in range(3):
         assert open(tmp_path / ("with-%d.psmc" % k)).read() == open(tmp_path / ("plain-%d.psmc" % k)).read(), k
+    # a job that fails before the main run's thread exists (here: a replicate's output cannot be opened) takes the begun main run with it:
+    # psmc_run_abort removes the header + RD 0 it had written -- no truncated main.psmc stays behind
+    r2 = subprocess.run([exe, "3", "17", str(tmp_path / "no_such_dir" / "x-%d.psmc"), "--main", str(tmp_path / "main2.psmc"), whole] + opts + [split],
+                        capture_output=True, text=True, env=env)
+    assert r2.returncode != 0 and "cannot write" in r2.stderr and not os.path.exists(tmp_path / "main2.psmc"), r2.stderr
 
 
 @pytest.fixture(scope="module")

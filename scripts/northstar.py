@@ -8,7 +8,7 @@ whether the main output of the joint job equals `psmc`'s own byte for byte, the 
 mode from the exact run, and what that extrapolates to on 8 GPUs -- stated as an extrapolation.
 
     python scripts/northstar.py gpurun_out/r05_northstar.json
-Environment: NS_REPLICATES (100), NS_ITERS (25), NS_MODES ("exact,fast"), NS_SEPARATE=1 (also time `psmc` alone, exact and
+Environment: NS_REPLICATES (100), NS_ITERS (25), NS_MODES ("fast,exact": the fast job first -- a job started right after the exact one waits ~3.5 s in its first device allocations while the driver wipes the 250 GB that job released, profiles/r06_fast_after_exact.txt), NS_SEPARATE=1 (also time `psmc` alone, exact and
 fast, and check the joint job's main output against it), NS_MAIN_CUS (PSMC_BOOT_MAIN_CUS of the exact job; default: unset),
 NS_TRAJ128=<path> (dump the parameter trajectory of `psmc -p 64*2` for bench.py's n128 extra).
 """
@@ -37,7 +37,7 @@ def final_round(text):
 def main():
     out_json = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_northstar.json")
     n_rep = int(os.environ.get("NS_REPLICATES", "100")); iters = int(os.environ.get("NS_ITERS", "25"))
-    modes = os.environ.get("NS_MODES", "exact,fast").split(",")
+    modes = os.environ.get("NS_MODES", "fast,exact").split(",")
     tmp = os.environ.get("TMPDIR", "/tmp")
     f = nd.files(tmp)
     res = {"target": "BASELINE.json north_star: one -N25 whole-genome run (n = 64, ~30 M bins) plus 100 bootstraps", "device": "1 x MI355X",
@@ -64,7 +64,7 @@ def main():
         res["one_schedule"][mode] = dict(
             rc=r.returncode, wall_s=round(wall, 2), iterations=len(its), esteps_ms_first=float(es[0]) if len(es) else None,
             esteps_ms_median_later=float(np.median(es[2:])) if len(es) > 2 else None, msteps_ms_median=float(np.median(ms)) if len(ms) else None,
-            main_run=dict(total_s=float(mm.group(1)) / 1e3 if mm else None, estep_ms_median=float(np.median([x for x, _ in mes[1:]])) if len(mes) > 1 else None,
+            main_run=dict(total_s=float(mm.group(1)) / 1e3 if mm else None, estep_ms_first=mes[0][0] if mes else None, estep_ms_median=float(np.median([x for x, _ in mes[1:]])) if len(mes) > 1 else None,
                           mstep_ms_median=float(np.median([y for _, y in mes])) if mes else None),
             per_iteration_ms=[dict(esteps=x, msteps=y) for x, y in its], stderr_tail=r.stderr[-500:] if r.returncode else "")
         sys.stderr.write("[northstar] one schedule, %s: %.1f s\n" % (mode, wall))

@@ -208,28 +208,33 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		for (const Block &b : blocks) tot_bins += b.bins;
 		const size_t by_bins = (size_t)((tot_bins + cap - 1) / cap), by_slots = ent_cap == SIZE_MAX ? 1 : (blocks.size() * (size_t)align + ent_cap - 1) / ent_cap;
 		const size_t fewest = std::max<size_t>(1, std::max(by_bins, by_slots));
-		bool tail_filled = false;
-		if (c->batch_sort && c->batch_tailfill && lblocks.size() > fewest) {
-			const std::vector<std::vector<int>> greedy = lblocks;
+		// head fill a little below cap into `max_launches` launches, then the rest of the list -- its shortest blocks -- each into the LAST launch with room
+		auto tail_fill = [&](size_t max_launches) {
 			for (double keep : {0.0025, 0.005, 0.01, 0.02, 0.04, 0.08}) {
-				head_fill(cap - (int64_t)(keep * (double)cap), fewest);
+				head_fill(cap - (int64_t)(keep * (double)cap), max_launches);
 				bool ok = true;
-				for (size_t t = next; t < blocks.size() && ok; ++t) { // the rest, longest first, each into the LAST launch with room (its entries are the most like it)
+				for (size_t t = next; t < blocks.size() && ok; ++t) {
 					ok = false;
 					for (size_t k = lblocks.size(); k-- > 0 && !ok;)
 						if ((lblocks[k].size() + 1) * (size_t)align <= ent_cap && lbins[k] + blocks[t].bins <= cap) { lblocks[k].push_back((int)t); lbins[k] += blocks[t].bins; ok = true; }
 				}
-				if (ok) { tail_filled = true; break; }
+				if (ok) return true;
 			}
-			if (!tail_filled) lblocks = greedy;
+			return false;
+		};
+		if (c->batch_sort && c->batch_tailfill && lblocks.size() > fewest) {
+			const std::vector<std::vector<int>> greedy = lblocks;
+			if (!tail_fill(fewest)) lblocks = greedy;
 		}
 		// Replicates that complete launch by launch ("batch_major").  With every block in order of length, each replicate's short trunks sit in
 		// the last launch and no replicate is complete before it.  But utils/splitfa.c cuts the trunks to ONE length (500 k bins; only the
 		// chromosomes' tails differ): when half of the blocks or more share their longest length Lc, a launch of blocks <= Lc lasts as long as
 		// an Lc sweep whatever else is in it -- so those blocks keep the callers' replicate order (the longer ones still go first, by length),
 		// a replicate is complete a launch or two after its first block, and the caller's M-steps (`done`) run under the launches that follow.
-		// Not when the tail fill saved a launch (worth as much), nor when this order would need a launch more.
-		if (c->batch_sort && c->batch_major && done && !tail_filled && lblocks.size() > 1) {
+		// Not when this order would need a launch more than the order by length does -- with or without its tail fill (round 6: it used to
+		// be skipped whenever the tail fill had saved a launch; with the second table chunk the 100-replicate job fits four launches
+		// EITHER way, and by length all hundred M-steps -- 0.4-0.55 s on 12 threads -- waited for the last one).
+		if (c->batch_sort && c->batch_major && done && lblocks.size() > 1) {
 			std::vector<int32_t> ls;
 			for (const Block &b : blocks) ls.push_back(b.maxL);
 			std::sort(ls.begin(), ls.end());
@@ -239,7 +244,24 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 				const std::vector<Block> sorted = blocks; const std::vector<std::vector<int>> by_len = lblocks;
 				blocks = blocks_made;
 				std::stable_sort(blocks.begin(), blocks.end(), [Lc](const Block &x, const Block &y) { return std::max(x.maxL, Lc) > std::max(y.maxL, Lc); });
+				const std::vector<Block> major = blocks;
 				head_fill(cap, SIZE_MAX);
+				// a launch too many: the same with the few shortest blocks of the call taken out of the replicates' order and put where there is
+				// room (the tail fill above; the launch of the long trunks is out of memory with slots to spare, the others out of slots)
+				size_t n_over = 0;
+				for (size_t k = by_len.size(); k < lblocks.size(); ++k) n_over += lblocks[k].size();
+				for (size_t mult = 1; lblocks.size() > by_len.size() && c->batch_tailfill && mult <= 8; mult *= 2) {
+					const size_t K = std::min(major.size(), n_over * mult);
+					std::vector<int> idx(major.size());
+					for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+					std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return major[x].bins < major[y].bins; });
+					std::vector<char> out(major.size(), 0);
+					for (size_t i = 0; i < K; ++i) out[idx[i]] = 1;
+					blocks.clear();
+					for (size_t i = 0; i < major.size(); ++i) if (!out[i]) blocks.push_back(major[i]);
+					for (size_t i = K; i-- > 0;) blocks.push_back(major[idx[i]]); // (the longest of the short ones first)
+					if (!tail_fill(by_len.size())) { blocks = major; head_fill(cap, SIZE_MAX); }
+				}
 				if (lblocks.size() > by_len.size()) { blocks = sorted; lblocks = by_len; }
 			}
 		}
@@ -298,6 +320,16 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		}
 		if (c->bpar_cap < (size_t)n_rep) { if ((rc = dev_alloc(c, &c->d_bpar, (size_t)n_rep * PL))) return rc; c->bpar_cap = (size_t)n_rep; }
 		if (refwd && !c->d_cu_mask && (rc = dev_alloc(c, &c->d_cu_mask, (size_t)4096))) return rc;
+		// (hmm_lk's products and their offsets for the LARGEST launch, here: growing them between two launches frees the old buffer, and hipFree
+		// waits for every kernel on the device -- beside psmc_boot's main run that was its 3.3 s E-step: 2.66 s of "read-back" in launch 1)
+		size_t lk_worst = 0;
+		for (int g = 0; g < n_launches; ++g) {
+			size_t t = 0;
+			for (int i = l_first[g]; i < l_first[g + 1]; ++i) t += wseg[i] >= 0 ? (size_t)(c->L[wseg[i]] / LKP_DIV + LKP_MIN) : 1;
+			lk_worst = std::max(lk_worst, t);
+		}
+		if (c->lkp_cap < lk_worst) { if ((rc = dev_alloc(c, &c->d_lkp, lk_worst))) return rc; c->lkp_cap = lk_worst; }
+		if (c->lkoff_cap < worst_entries) { if ((rc = dev_alloc(c, &c->d_lkoff, worst_entries))) return rc; c->lkoff_cap = worst_entries; }
 		if (fwd_all && c->s_all_cap < (size_t)all_bins + 128) { if ((rc = dev_alloc(c, &c->d_s_all, (size_t)all_bins + 128))) return rc; c->s_all_cap = (size_t)all_bins + 128; }
 	}
 	static const bool dbg_t = getenv("PSMC_HIP_DEBUG_TIMES") != nullptr;
@@ -392,8 +424,6 @@ static int batch_exact(psmc_hip_ctx *c, int n_rep, const double *a, const double
 		std::vector<int64_t> lkoff((size_t)nw);
 		int64_t lk_tot = 0;
 		for (int i = 0; i < nw; ++i) { lkoff[i] = lk_tot; lk_tot += wseg[e0 + i] >= 0 ? c->L[wseg[e0 + i]] / LKP_DIV + LKP_MIN : 1; }
-		if (c->lkp_cap < (size_t)lk_tot) { if ((rc = dev_alloc(c, &c->d_lkp, (size_t)lk_tot))) return rc; c->lkp_cap = (size_t)lk_tot; }
-		if (c->lkoff_cap < (size_t)nw) { if ((rc = dev_alloc(c, &c->d_lkoff, (size_t)nw))) return rc; c->lkoff_cap = (size_t)nw; }
 		HIPCHK(c, hipMemcpyAsync(c->d_lkoff, lkoff.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, c->stream));
 		if (launch_lk_products(c->stream, p, fwd_all ? c->d_s_all : c->d_s, c->d_lkoff, c->d_lkp) != 0) return fail(c, PSMC_HIP_EDEVICE, "launch_lk_products", hipGetLastError());
 		c->h_lkp.resize((size_t)lk_tot);

@@ -864,6 +864,44 @@ def test_exact_batch_progress_callback(hip, golden):
     assert firsts[0][2] >= firsts[1][2], firsts                                     # by length: the tails complete (nearly) everybody at the end
 
 
+def test_exact_batch_major_with_tail_fill(hip, golden):
+    """The north-star job's schedule at 1/250 of its lengths (round 6): sixty trunks cut like utils/splitfa.c's, a hundred resampled
+    replicates, 1024 entry slots and table memory for a little more than a quarter of the bins per launch.  By length the entries need
+    five launches, four with the tail fill -- and then every replicate's short tail sits in the last one (a single callback names
+    nearly all of them).  "batch_major" with the tail fill keeps the four launches AND the replicates' order: three callbacks of about
+    a third each, so the caller's M-steps run under the launches that follow.  The statistics keep their bits."""
+    from psmc_amd import sim
+    Ls = []
+    for L in sim.human_like_lengths(30_000_000, n_seg=22):
+        pos = 0
+        while L - pos >= 750_000:
+            Ls.append(2000); pos += 500_000
+        Ls.append((L - pos) // 250)
+    rng = np.random.default_rng(5)
+    trunks = [rng.integers(0, 2, size=l).astype(np.uint8) for l in Ls]
+    sels = []
+    for _ in range(100):
+        s, sel = 0, []
+        while s < sum(Ls):
+            k = int(rng.integers(len(Ls))); sel.append(k); s += Ls[k]
+        sels.append(sel)
+    params = _traj_params(4) * 25
+    bins = sum(sum((Ls[i] + 63) // 64 * 64 for i in set(x)) for x in sels)
+    res = {}
+    for major, fill in ((1, 1), (0, 1), (1, 0)):
+        es = hip.HipEStep(64, mode=hip.MODE_EXACT, batch_bins=int(bins / 3.78), exact_refwd=2, batch_tailfill=fill, batch_major=major)
+        es.load_segments(trunks)
+        calls = []
+        got = es.estep_batch(params, sels, on_done=lambda reps, out: calls.append(len(reps)))
+        res[major, fill] = (es.batch_info()["groups"], calls, got)
+        es.close()
+    assert res[0, 1][0] == res[1, 1][0] < res[1, 0][0], [v[0] for v in res.values()]       # the tail fill saves a launch, with either order
+    assert max(res[0, 1][1]) >= 90, res[0, 1][1]                                            # by length: (nearly) everybody at the end
+    assert len(res[1, 1][1]) >= 3 and max(res[1, 1][1]) <= 45, res[1, 1][1]                # replicate order: launch by launch
+    for key in ("A", "E", "LL"):
+        assert bits_equal(res[1, 1][2][key], res[0, 1][2][key]) and bits_equal(res[1, 1][2][key], res[1, 0][2][key]), key
+
+
 def test_fast_batch_progress_callback(hip, golden):
     """Fast mode runs its replicates one after the other: `done` after each, in order, with the rows final."""
     segs = golden.segs_mid

@@ -139,7 +139,9 @@ const char *psmc_hip_last_error(const psmc_hip_ctx *ctx);
  *  "batch_major"   1        psmc_hip_estep_batch_cb with "batch_sort", several launches: when half of the entry blocks or more share their longest
  *                           length (utils/splitfa.c cuts the trunks to one length), the blocks no longer than that keep the caller's replicate
  *                           order -- longer ones still first, by length -- so that replicates complete launch by launch and `done` can hand
- *                           them to the caller's M-steps while the later launches run.  Not when the tail fill saves a launch.  Bit-identical.
+ *                           them to the caller's M-steps while the later launches run.  Where that order alone needs a launch more than the tail
+ *                           fill, the few shortest blocks of the call leave the replicates' order and go where there is room (round 6); not
+ *                           when it still needs a launch more.  Bit-identical.
  *  "exact_refwd"   auto     psmc_hip_estep_batch, 64 states: 1, 2 = no f table -- the expect pass recomputes the forward sweep in its own
  *                           work-group (bit-identical), so a launch group holds twice the replicates; 2 = two entries per work-group
  *                           (two producer waves, two consumer waves: four entries per compute unit), 1 = one; 0 = f and b tables,

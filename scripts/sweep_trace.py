@@ -38,7 +38,7 @@ def main():
     es = sh.es
     stream = torch.cuda.current_stream()
     es.estep(*traj[0])
-    for i in range(10):
+    for i in range(int(os.environ.get("TRACE_WARM", "10"))):   # (adaptive warm-ups, "adapt=1", settle over ~30 steps)
         es.estep_device(*traj[i % len(traj)], sh.stats.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     d = es.fast_diag()

@@ -6,7 +6,8 @@ Every case: 1-12 segments with lengths log-uniform in [1, 300 k], simulated unde
 (64 or 128 states), with planted runs of missing data (up to 60 k bins) and of homozygous bins; a random plan (chunk, warmup,
 fused or not, gap tiles, the round-6 options merge / adapt / prev_start); four E-steps with DIFFERENT parameter sets on the same
 context (the plan learns across them), full counts and factored sums, each compared with exact mode at the bounds the suite uses
-(tests/test_gpu_estep.py check_fast).  PSMC_HIP_ECONVERGE is an allowed answer for plans that cannot converge (it is counted)."""
+(tests/test_gpu_estep.py check_fast).  PSMC_HIP_ECONVERGE is an allowed answer for plans that cannot converge (it is counted).
+FUZZ_DEFAULT=1: every case with the default plan (what a caller without options gets)."""
 import json
 import os
 import sys
@@ -59,6 +60,7 @@ def main():
         P = T[n]
         segs = make_segments(rng, P[int(rng.integers(len(P)))])
         opts = {}
+        if os.environ.get("FUZZ_DEFAULT"): rng = np.random.default_rng(seed + 10**6)   # the default plan only (the options' draws go to a stream nobody reads)
         if rng.random() < 0.7: opts["chunk"] = int(rng.choice([37, 256, 512, 768, 1001, 1024, 2048, 3712]))
         if rng.random() < 0.5: opts["warmup"] = int(rng.choice([128, 512, 1024, 3072]))
         if rng.random() < 0.2: opts["fuse"] = 0
@@ -67,6 +69,7 @@ def main():
             opts["merge"] = 1
             if rng.random() < 0.5: opts["adapt"] = 1
             if rng.random() < 0.5: opts["prev_start"] = 1
+        if os.environ.get("FUZZ_DEFAULT"): opts = {}; rng = np.random.default_rng(seed + 2 * 10**6)
         case = dict(seed=seed, n=n, segs=[len(s) for s in segs], opts=opts)
         try:
             ex = hip.HipEStep(n, mode=hip.MODE_EXACT); ex.load_segments(segs)
@@ -85,7 +88,9 @@ def main():
                     if kind == "counts":
                         m = fast_error_metrics(r, o, p[0], p[1])
                         for k, v in m.items():
-                            stats["worst"][k] = max(stats["worst"][k], v)
+                            if v > stats["worst"][k]:
+                                stats["worst"][k] = v
+                                if k == "A_cell": stats["worst_A_cell_case"] = dict(case, step=step)
                         bad = {k: v for k, v in m.items() if not v <= TOL[k]}
                     else:
                         so = sums_of(np.asarray(o["A"])[:n, :n])

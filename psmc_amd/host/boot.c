@@ -268,21 +268,9 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 		R->sums = factored ? (double *)calloc((size_t)5 * N, sizeof(double)) : 0;
 		R->E = (double *)calloc((size_t)2 * N, sizeof(double));
 	}
-	const int timing = getenv("PSMC_TIMING") != 0;
-	int failed = 0;
-	/* The main run starts now: every draw from drand48 -- its own (psmc_run_begin) and the replicates' (above) -- is done, and from here
-	 * on the two only share the device: the main run's sweeps on the compute units its context was given, the batch on the others.
-	 * (Round 6: BEFORE the devices reserve the replicates' tables -- its own are reserved already, boot_main.c -- see below.) */
-	main_job mj = {main_run, 0, 0.0, 0};
-	pthread_t main_tid;
-	int main_started = 0;
-	if (main_run) {
-		if (pthread_create(&main_tid, 0, main_thread, &mj) == 0) main_started = 1;
-		else { fprintf(stderr, "psmc_boot: cannot start the main run's thread\n"); failed = 1; }
-	}
-	if (bb->reserve) { /* the replicates are drawn: every device learns what its batch will need, and takes it before the first E-step -- 250 GB of an
-	                     * exact job's tables are 6 s on a device whose memory was in use before (the driver clears what it hands out): the main run's
-	                     * first sweeps run under them */
+	if (bb->reserve) { /* the replicates are drawn: every device learns what its batch will need, and takes it before the first E-step (250 GB of an exact job's tables
+	                     * are 6 s on a device whose memory was in use before -- the driver clears what it hands out; starting the main run's thread
+	                     * first does not hide them: the runtime serialises its calls behind the allocation, profiles/r06_boot_exit.txt) */
 		for (int d = 0; d < bb->n_dev; ++d) {
 			int64_t bins = 0;
 			unsigned char *seen = (unsigned char *)malloc((size_t)(in.n_seg > 0 ? in.n_seg : 1));
@@ -295,8 +283,19 @@ int psmc_boot_run(psmc_options *o, int n_rep, long seed0, const char *out_patter
 			}
 			free(seen);
 			const int rc = bb->reserve(bb->self, d, bins);
-			if (rc) { fprintf(stderr, "psmc_boot: cannot reserve the tables on device %d: %s\n", d, bb->error(bb->self, d)); failed = 1; break; }
+			if (rc) { fprintf(stderr, "psmc_boot: cannot reserve the tables on device %d: %s\n", d, bb->error(bb->self, d)); goto done_rep; }
 		}
+	}
+	const int timing = getenv("PSMC_TIMING") != 0;
+	int failed = 0;
+	/* The main run starts now: every draw from drand48 -- its own (psmc_run_begin) and the replicates' (above) -- is done, and from here
+	 * on the two only share the device: the main run's sweeps on the compute units its context was given, the batch on the others. */
+	main_job mj = {main_run, 0, 0.0, 0};
+	pthread_t main_tid;
+	int main_started = 0;
+	if (main_run) {
+		if (pthread_create(&main_tid, 0, main_thread, &mj) == 0) main_started = 1;
+		else { fprintf(stderr, "psmc_boot: cannot start the main run's thread\n"); failed = 1; }
 	}
 	{ /* main.c:16-20 for every replicate */
 		pipeline P;

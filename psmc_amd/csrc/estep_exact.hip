@@ -860,7 +860,8 @@ __global__ __launch_bounds__(64) void k_post_full(const double *__restrict__ a, 
 				const int k = PER * lane + j;
 				t[j] = fu[j] * dg[j] * b[(g + 1) * S + k] * e[sym * S + k]; // fu[l] * a[l][l] * bu1[l] * eu1[l]
 			}
-			pr = 1.0 - ordered_sum_states<S>(t[0], PER > 1 ? t[PER - 1] : 0.0);
+			const double sm = ordered_sum_states<S>(t[0], PER > 1 ? t[PER - 1] : 0.0);
+			pr = sm != sm ? sm : 1.0 - sm; // (a NaN keeps its sign through x86's subsd; the source modifier of v_add_f64 would flip it: "nan" for the reference's "-nan" in a run whose parameters have already diverged)
 		}
 		if (lane == 0) recomb[u] = pr;
 	}

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void k_post_full_wide(const double *__restric
 		if (u < L - 1 && k < n) t = fu * dg * b[(g + 1) * S + k] * e[obs[g + 1] * S + k]; // fu[l] * a[l][l] * bu1[l] * eu1[l]
 		lds_w[k] = t;
 		__syncthreads();
-		if (k == 0) recomb[u] = u < L - 1 ? 1.0 - ordered_sum_lds(lds_w, n) : 0.0;
+		if (k == 0) { const double sm = u < L - 1 ? ordered_sum_lds(lds_w, n) : 1.0; recomb[u] = sm != sm ? sm : 1.0 - sm; } // (NaN: sign kept, as estep_exact.hip k_post_full)
 		__syncthreads();
 	}
 }

@@ -242,6 +242,29 @@ def test_exact_device_posterior_and_counts(hip, golden, oracle, key):
     es.close()
 
 
+@pytest.mark.parametrize("n", [6, 100, 150])
+def test_exact_posterior_of_a_diverged_model_keeps_the_nan_sign(hip, oracle, n):
+    """A run whose parameters have diverged prints "-nan" from the reference: x86 makes a NEGATIVE quiet NaN of an invalid operation and
+    carries an operand's NaN, sign included, through every later instruction -- also through the subtraction 1.0 - p of aux.c:192.  A
+    v_add_f64 with a source negation modifier flips that sign ("nan" in the first DF column where the reference writes "-nan":
+    scripts/fuzz_cli.py, seed 178, round 6).  Parameters that are all such NaNs: posteriors and recombination probabilities bit for bit."""
+    rng = np.random.default_rng(n)
+    a, e, a0 = random_hmm(rng, n)
+    neg_nan = np.copysign(np.nan, -1.0)
+    a = np.full_like(a, neg_nan); e = np.array(e); e[:2] = neg_nan
+    segs = [rng.choice(3, size=L, p=[0.86, 0.1, 0.04]).astype(np.uint8) for L in (70, 5)]
+    es = hip.HipEStep(n, mode=hip.MODE_EXACT)
+    es.load_segments(segs)
+    es.estep(a, e, a0)
+    for k in (0, 1):
+        f, b, s, lk, chk = oracle.fwd_bwd(a, e, a0, segs[k])
+        post, rec = oracle.post_full(a, e, segs[k], f, b, s)
+        pp, rr = es.posterior(k)
+        assert np.isnan(rec[1:-1]).all() and np.signbit(rec[1:-1]).all()
+        assert bits_equal(pp, post[1:]) and bits_equal(rr, rec[1:]), k
+    es.close()
+
+
 def test_errors(hip):
     es = hip.HipEStep(8, mode=hip.MODE_EXACT)
     a, e, a0 = random_hmm(np.random.default_rng(0), 8)

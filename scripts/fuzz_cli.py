@@ -2,7 +2,7 @@
 """Randomised end-to-end run of the `psmc` binary (exact mode on the GPU) against the reference's own binary built from its sources
 (oracle/_ref/psmc_ref; test infrastructure), byte for byte (round 6; `python scripts/fuzz_cli.py SECONDS [SEED0]`).
 Every case: a random .psmcfa (1-6 sequences of 60..40 k bins, heterozygosity drifting along the sequence, runs of N), a random pattern
-(3..150 hidden states: the 64-state, 128-state and wide kernels all come up), -N1..4, random -t / -r, sometimes -d or -d -D."""
+(3..150 hidden states: the 64-state, 128-state and wide kernels all come up), -N1..4, random -t / -r, sometimes -d or -d -D; FUZZ_MORE=1 adds -s, -C, -T and -l."""
 import json
 import os
 import subprocess
@@ -51,6 +51,12 @@ def main():
         u = rng.random()
         if u < 0.25: args.append("-d")
         elif u < 0.4: args += ["-d", "-D"]
+        if os.environ.get("FUZZ_MORE"):   # (second generation of cases: the draws above stay what they were for a given seed)
+            v = rng.random()
+            if v < 0.12: args += ["-d", "-s"] if "-d" not in args else ["-s"]
+            elif v < 0.24: args += (["-d"] if "-d" not in args else []) + ["-C", str(int(rng.integers(1, 12)))]
+            if rng.random() < 0.15: args += ["-T", "%g" % round(rng.uniform(0.05, 2.0), 2)]
+            if rng.random() < 0.1: args += ["-l", "%g" % round(rng.uniform(0.05, 0.3), 2)]
         case = dict(seed=seed, lens=lens, args=args)
         outs = []
         for exe, env in ((REF, os.environ), (OURS, dict(os.environ, PSMC_HIP_MODE="exact"))):

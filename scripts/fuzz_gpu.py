@@ -7,7 +7,8 @@ Every case: 1-12 segments with lengths log-uniform in [1, 300 k], simulated unde
 fused or not, gap tiles, the round-6 options merge / adapt / prev_start); four E-steps with DIFFERENT parameter sets on the same
 context (the plan learns across them), full counts and factored sums, each compared with exact mode at the bounds the suite uses
 (tests/test_gpu_estep.py check_fast).  PSMC_HIP_ECONVERGE is an allowed answer for plans that cannot converge (it is counted).
-FUZZ_DEFAULT=1: every case with the default plan (what a caller without options gets)."""
+FUZZ_DEFAULT=1: every case with the default plan (what a caller without options gets).  FUZZ_BIG=1: segments of 20 k..1 M bins and
+small tiles, so that the plans have more than 4096 tiles (two rounds of the fused back half)."""
 import json
 import os
 import sys
@@ -30,7 +31,7 @@ def traj(n):
 def make_segments(rng, p):
     segs = []
     for _ in range(int(rng.integers(1, 13))):
-        L = int(np.exp(rng.uniform(0, np.log(300_000))))
+        L = int(np.exp(rng.uniform(np.log(20_000), np.log(1_000_000)))) if os.environ.get("FUZZ_BIG") else int(np.exp(rng.uniform(0, np.log(300_000))))
         s = sim.simulate_segment(p[0], p[1], p[2], L, rng)
         for _ in range(int(rng.integers(0, 4))):           # planted runs: missing data or homozygous
             if L < 8: break
@@ -61,7 +62,8 @@ def main():
         segs = make_segments(rng, P[int(rng.integers(len(P)))])
         opts = {}
         if os.environ.get("FUZZ_DEFAULT"): rng = np.random.default_rng(seed + 10**6)   # the default plan only (the options' draws go to a stream nobody reads)
-        if rng.random() < 0.7: opts["chunk"] = int(rng.choice([37, 256, 512, 768, 1001, 1024, 2048, 3712]))
+        if os.environ.get("FUZZ_BIG"): opts["chunk"] = int(rng.choice([256, 256, 512, 1024]))   # more than 4096 tiles: the two-round plan (lists A and B)
+        elif rng.random() < 0.7: opts["chunk"] = int(rng.choice([37, 256, 512, 768, 1001, 1024, 2048, 3712]))
         if rng.random() < 0.5: opts["warmup"] = int(rng.choice([128, 512, 1024, 3072]))
         if rng.random() < 0.2: opts["fuse"] = 0
         if rng.random() < 0.2: opts["gap_tiles"] = 0

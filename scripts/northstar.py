@@ -101,8 +101,10 @@ def main():
             except Exception:
                 pass
             sep[mode] = dict(rc=r.returncode, psmc_wall_s=round(w, 2), estep_ms_median=float(np.median([x for x, _ in tim[1:]])) if len(tim) > 1 else None,
-                             main_output_of_the_joint_job_is_byte_identical=same)
+                             main_output_of_the_joint_job_is_byte_identical=same, estep_ms_first=tim[0][0] if tim else None)
             save()
+        sep["note"] = ("psmc_wall_s of the FIRST program run here follows the exact joint job: its first allocations wait for the driver to clear the 250 GB that "
+                       "job released (estep_ms_first holds the wait); on a quiet device the fast run takes 1.0 s in all (profiles/r06_fast_after_exact.txt)")
         res["separate_main_run"] = sep
     # ---- totals and the 8-GPU extrapolation (NOT measured: no 8-GPU node from a build session)
     try:

@@ -122,6 +122,9 @@ typedef struct {
 	char *out_file;   /* -o */
 	char *in_file;
 	FILE *out;
+	/* not a reference option: an input the caller has read already (psmc's main() reads it on a thread while the device comes up);
+	 * psmc_run_begin takes it over -- ownership included -- instead of reading in_file.  prefetch_rc: what psmc_input_read returned. */
+	psmc_input *prefetched; int prefetch_rc;
 } psmc_options;
 void psmc_options_default(psmc_options *o);
 int  psmc_options_parse(psmc_options *o, int argc, char **argv); /* 0 ok, 1 usage printed */

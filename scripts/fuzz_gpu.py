@@ -55,6 +55,8 @@ def main():
     t_end = time.time() + budget
     stats = dict(cases=0, esteps=0, econverge=0, failures=[], worst={k: 0.0 for k in TOL}, worst_factored=0.0, bins=0)
     seed = seed0
+    one = os.environ.get("FUZZ_ONE")   # replay one seed, every metric of every E-step printed
+    if one: seed = int(one); t_end = time.time() + 1e9
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
         n = 64 if rng.random() < 0.8 else 128
@@ -89,6 +91,10 @@ def main():
                     stats["esteps"] += 1
                     if kind == "counts":
                         m = fast_error_metrics(r, o, p[0], p[1])
+                        if one:
+                            Ao = np.asarray(o["A"]); Eo = np.asarray(o["E"])[:2]; Er = np.asarray(r["E"])[:2]
+                            big = Eo >= 1e-6 * Eo.max(); rel = np.where(big, np.abs(Er - Eo) / np.where(big, Eo, 1.0), 0.0); w = np.unravel_index(rel.argmax(), rel.shape)
+                            print("step", step, {k: float("%.3g" % v) for k, v in m.items()}, "worst E cell", w, "value %.3g of max %.3g, abs err %.3g" % (Eo[w], Eo.max(), abs(Er[w] - Eo[w])), "repairs", fa.fast_diag() if hasattr(fa, "fast_diag") else None, flush=True)
                         for k, v in m.items():
                             if v > stats["worst"][k]:
                                 stats["worst"][k] = v
@@ -109,6 +115,7 @@ def main():
             print("FAIL", json.dumps(stats["failures"][-1]), flush=True)
         stats["cases"] += 1; stats["bins"] += sum(len(s) for s in segs)
         seed += 1
+        if one: break
     stats["seeds"] = [seed0, seed - 1]
     print(json.dumps(stats, indent=1))
 

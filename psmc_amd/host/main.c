@@ -59,7 +59,8 @@ int main(int argc, char *argv[])
 	 * program that takes 1.0 s in all in fast mode (profiles/r06_fast_after_exact.txt).  psmc_run_begin takes the result over. */
 	pthread_t rd_tid;
 	prefetch_job pj = {o.in_file, (psmc_input *)calloc(1, sizeof(psmc_input)), 0};
-	const int rd_started = pj.in && pthread_create(&rd_tid, 0, prefetch_input, &pj) == 0;
+	/* (not from stdin: a device that does not come up must say so at once, not after the pipe has closed) */
+	const int rd_started = pj.in && o.in_file && strcmp(o.in_file, "-") != 0 && pthread_create(&rd_tid, 0, prefetch_input, &pj) == 0;
 	psmc_estep_backend be;
 	const int rc = psmc_hipbe_create(&be, n_states, mode, use_factored, devs, dev_s ? atoi(dev_s) : 0);
 	if (rd_started) { pthread_join(rd_tid, 0); o.prefetched = pj.in; o.prefetch_rc = pj.rc; }

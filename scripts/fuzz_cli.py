@@ -2,7 +2,8 @@
 """Randomised end-to-end run of the `psmc` binary (exact mode on the GPU) against the reference's own binary built from its sources
 (oracle/_ref/psmc_ref; test infrastructure), byte for byte (round 6; `python scripts/fuzz_cli.py SECONDS [SEED0]`).
 Every case: a random .psmcfa (1-6 sequences of 60..40 k bins, heterozygosity drifting along the sequence, runs of N), a random pattern
-(3..150 hidden states: the 64-state, 128-state and wide kernels all come up), -N1..4, random -t / -r, sometimes -d or -d -D; FUZZ_MORE=1 adds -s, -C, -T and -l."""
+(3..150 hidden states: the 64-state, 128-state and wide kernels all come up), -N1..4, random -t / -r, sometimes -d or -d -D; FUZZ_MORE=1 adds -s, -C, -T and -l;
+FUZZ_ONE=<seed> replays one case and keeps both outputs."""
 import json
 import os
 import subprocess
@@ -42,6 +43,8 @@ def main():
     t_end = time.time() + budget
     stats = dict(cases=0, failures=[], by_pattern={})
     seed = seed0
+    one = os.environ.get("FUZZ_ONE")   # replay one seed; both outputs stay in $TMPDIR as fuzz_cli_ref.psmc / fuzz_cli_ours.psmc
+    if one: seed = int(one); t_end = time.time() + 1e9
     while time.time() < t_end:
         rng = np.random.default_rng(seed)
         fa = os.path.join(tmp, "fuzz_cli.psmcfa")
@@ -63,7 +66,7 @@ def main():
             o = os.path.join(tmp, "fuzz_cli_%s.psmc" % ("ref" if exe == REF else "ours"))
             r = subprocess.run([exe] + args + ["-o", o, fa], capture_output=True, text=True, env=env, timeout=600)
             outs.append((r.returncode, open(o, "rb").read() if os.path.exists(o) else b"", r.stderr[-300:]))
-            if os.path.exists(o): os.remove(o)
+            if os.path.exists(o) and not one: os.remove(o)
         if outs[0][0] < 0 and outs[1][0] == 0 and outs[1][1].startswith(outs[0][1][:outs[0][1].rfind(b"\n") + 1]):
             stats["reference_aborted"] = stats.get("reference_aborted", 0) + 1   # (the reference's own crash, e.g. -d with three states: what it wrote before is a prefix of ours)
         elif outs[0][0] != outs[1][0] or outs[0][1] != outs[1][1]:
@@ -72,6 +75,7 @@ def main():
             print("FAIL", json.dumps(stats["failures"][-1]), flush=True)
         stats["cases"] += 1; stats["by_pattern"][pat] = stats["by_pattern"].get(pat, 0) + 1
         seed += 1
+        if one: print("args", args, "lens", lens); break
     stats["seeds"] = [seed0, seed - 1]
     print(json.dumps(stats, indent=1))
     return 1 if stats["failures"] else 0
